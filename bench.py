@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- capacity-plan scenarios/sec on the BASELINE.json workload.
+
+A "step" = one pass of the hot path over ONE scenario batch already resident in HBM:
+config 3 of BASELINE.json (10k pods x 488..1511 nodes, 1024 node counts x 4 pod orders = 4096
+scenarios) per GPU.  With N ranks (one process per GPU, launched by torch.distributed.run) every
+rank owns 4096 scenarios of the 1024 x (4N) grid, interleaved so that each rank sees every node
+count (N = 8 is config 4: 32k scenarios); scenarios are independent, so there is no data-path
+collective -- only the per-rank best plan (48 B) is all-gathered over RCCL each step to pick the
+global minimum-node plan.  value = scenarios all ranks completed / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only for the cpu_baseline leg.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+
+
+def algorithmic_bytes(scen, n_pods):
+    """per pod-placement step on an n-node scenario 56*n + 108 bytes."""
+    n = scen[:, 0].astype(np.int64)
+    return int((n_pods * (56 * n + 108)).sum())
+
+
+def cpu_baseline(prob, scen, orders, budget_s=12.0):
+    """Time the single-threaded C oracle on a bounded sample of the same scenarios (rank 0 only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.load()
+    S = len(scen)
+    pick = np.linspace(0, S - 1, 8).astype(int)            # spread over node counts and orders
+    t0 = time.perf_counter()
+    oracle_lib.run(prob, scen[pick[:1]], orders, want_placement=False)
+    per = max(time.perf_counter() - t0, 1e-6)
+    k = int(max(2, min(len(pick), budget_s / per)))
+    sample = scen[pick[:k]]
+    t0 = time.perf_counter()
+    oracle_lib.run(prob, sample, orders, want_placement=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(k / dt, 4), "unit": "scenarios/s", "cores": 1, "kind": "port",
+            "sample": f"{k} of the {S} scenarios of this rank's batch (evenly spaced over node counts/orders), "
+                      f"{dt:.1f} s, single-threaded C oracle (restated CPU baseline, not the Go reference binary)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--counts", type=int, default=1024, help="node counts in the sweep (1024 = BASELINE config 3/4)")
+    ap.add_argument("--pods", type=int, default=10000)
+    ap.add_argument("--orders-per-gpu", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from open_simulator_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n_orders = args.orders_per_gpu * world
+    seed = synth.SEED + (3 if world == 1 else 4)
+    prob, scen_all, orders = synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=seed)
+    scen = np.ascontiguousarray(scen_all[rank::world])       # every rank gets every node count
+    S_local, S_total = len(scen), len(scen_all)
+
+    ctx = capi.Context(local_rank)
+    ctx.load_problem(prob)
+    ctx.load_scenarios(scen, orders)                          # inputs resident in HBM before timing
+    plan_dev = torch.zeros(4, dtype=torch.int64, device="cuda")
+    gathered = [torch.zeros_like(plan_dev) for _ in range(world)]
+
+    def step():
+        ctx.run_loaded(want_placement=bool(args.placement))
+        plan = ctx.min_plan()                                 # device-side reduction of this rank's batch
+        if world > 1:
+            key = plan.n_nodes if plan.found else (1 << 40)
+            plan_dev.copy_(torch.tensor([key, rank, plan.scenario, plan.order_id], dtype=torch.int64))
+            dist.all_gather(gathered, plan_dev)               # RCCL: 32 B per rank
+            best = min((g.tolist() for g in gathered), key=lambda r: (r[0], r[1]))
+            return best
+        return [plan.n_nodes if plan.found else -1, rank, plan.scenario, plan.order_id]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = step()
+        kernel_ms.append(ctx.stats().kernel_ms)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        st = ctx.stats()
+        k_ms = float(np.mean(kernel_ms))
+        alg = algorithmic_bytes(scen, prob.n_pods)
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        value = S_total * args.steps / dt
+        out = {
+            "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),
+            "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 (gcd-normalised int64) + f64 (BalancedAllocation)", "data": "synthetic",
+            "pods_placed_per_sec": round(value * prob.n_pods, 1),
+            "config": {"workload": f"BASELINE config {'3' if world == 1 else '4-style'}: {prob.n_pods} pods x "
+                                   f"{int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, {args.counts} node counts x "
+                                   f"{n_orders} pod orders = {S_total} scenarios ({S_local} per GPU)",
+                       "scenarios_per_gpu": S_local, "pods": prob.n_pods, "node_pool": prob.n_nodes,
+                       "placement_matrix": bool(args.placement),
+                       "kernel": {1: "narrow", 2: "wide"}.get(st.kernel_variant, "?"), "workgroup": st.workgroup_size,
+                       "slots_per_lane": st.slots_per_lane, "plan": best},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "simon::narrow_kernel", "kernel_ms": round(k_ms, 3),
+                         "algorithmic_bytes_per_launch": alg,
+                         "note": "algorithmic bytes = sum_s P*(56*n_s+108) (SURVEY 8d); node state is register-"
+                                 "resident, so this ratio is not bounded by 1 -- see DESIGN.md section 6 for the "
+                                 "VALU-issue roofline that actually binds"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, scen, orders)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

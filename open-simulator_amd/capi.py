@@ -1,0 +1,466 @@
+"""ctypes binding of include/simon_hip.h (the C-ABI of libsimon_hip.so).
+
+This is the Python twin of the cgo stub shown in INTEGRATION.md: plain pointers and sizes, no torch
+types.  The struct layouts below mirror include/simon_hip.h field for field; `Problem` is a
+numpy-side container that keeps the arrays alive while the C structs point into them.
+
+The product path fails loudly when the HIP library is missing: `load_library()` raises, there is no
+CPU fallback (the oracle under oracle/ is test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_GPU_DEV = 8
+MAX_SCALAR = 4
+
+UNSCHEDULED = -1
+GATED = -2
+
+FAIL_STATIC = 0x8000
+FAIL_FIT = 0x4000
+FIT_PODS, FIT_CPU, FIT_MEM, FIT_EPH, FIT_SCALAR0 = 0x1, 0x2, 0x4, 0x8, 0x10
+FAIL_ANTI_INCOMING = 0x2001
+FAIL_ANTI_EXISTING = 0x2002
+FAIL_GPUSHARE = 0x1000
+
+KERNEL_NARROW = 1
+KERNEL_WIDE = 2
+
+_p64 = C.POINTER(C.c_int64)
+_p32 = C.POINTER(C.c_int32)
+_pu64 = C.POINTER(C.c_uint64)
+_pu8 = C.POINTER(C.c_uint8)
+_pu16 = C.POINTER(C.c_uint16)
+
+
+class NodesSoA(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_nodes", C.c_int32),
+        ("alloc_cpu", _p64), ("alloc_mem", _p64), ("alloc_eph", _p64), ("alloc_pods", _p32),
+        ("init_req_cpu", _p64), ("init_req_mem", _p64), ("init_req_eph", _p64),
+        ("init_nz_cpu", _p64), ("init_nz_mem", _p64), ("init_npods", _p32),
+        ("node_class", _p32),
+        ("n_scalar", C.c_int32), ("scalar_alloc", _p64), ("init_scalar_req", _p64),
+        ("gpu_cnt", _p32), ("gpu_mem_total", _p64), ("init_gpu_used", _p64),
+        ("n_topo_keys", C.c_int32), ("topo_dom", _p32), ("topo_n_dom", _p32),
+    ]
+
+
+class PodsSoA(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_pods", C.c_int32),
+        ("req_cpu", _p64), ("req_mem", _p64), ("req_eph", _p64), ("nz_cpu", _p64), ("nz_mem", _p64),
+        ("scalar_req", _p64), ("pod_class", _p32), ("preset_node", _p32), ("gate_node", _p32),
+        ("gpu_mem", _p64), ("gpu_cnt", _p32),
+    ]
+
+
+class ClassTables(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_pod_classes", C.c_int32), ("n_node_classes", C.c_int32),
+        ("static_mask", _pu64), ("static_reason", _pu8), ("simon_raw", _p64), ("const_score", _p64),
+        ("n_terms", C.c_int32), ("term_topo_key", _p32),
+        ("anti_off", _p32), ("anti_idx", _p32), ("match_off", _p32), ("match_idx", _p32),
+    ]
+
+
+class Scenario(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("order_id", C.c_int32)]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("flags", C.c_uint32),
+        ("unscheduled", _p32), ("used_cpu", _p64), ("used_mem", _p64), ("placement", _p32),
+    ]
+
+
+class Plan(C.Structure):
+    _fields_ = [
+        ("found", C.c_int32), ("scenario", C.c_int32), ("n_nodes", C.c_int32), ("order_id", C.c_int32),
+        ("cpu_pct", C.c_int32), ("mem_pct", C.c_int32), ("used_cpu", C.c_int64), ("used_mem", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+        ("n_launches", C.c_int32), ("kernel_variant", C.c_int32), ("workgroup_size", C.c_int32),
+        ("slots_per_lane", C.c_int32), ("lds_bytes", C.c_int64),
+    ]
+
+
+def _arr(a, dtype, shape=None) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _ptr(a: Optional[np.ndarray], ctype):
+    if a is None:
+        return C.cast(None, C.POINTER(ctype))
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+@dataclass
+class Problem:
+    """Numpy-side mirror of (simon_nodes_soa, simon_pods_soa, simon_class_tables).
+
+    Field meaning is documented in include/simon_hip.h; None = optional array omitted.
+    """
+    # nodes
+    alloc_cpu: np.ndarray = None
+    alloc_mem: np.ndarray = None
+    alloc_pods: np.ndarray = None
+    alloc_eph: Optional[np.ndarray] = None
+    init_req_cpu: Optional[np.ndarray] = None
+    init_req_mem: Optional[np.ndarray] = None
+    init_req_eph: Optional[np.ndarray] = None
+    init_nz_cpu: Optional[np.ndarray] = None
+    init_nz_mem: Optional[np.ndarray] = None
+    init_npods: Optional[np.ndarray] = None
+    node_class: Optional[np.ndarray] = None
+    scalar_alloc: Optional[np.ndarray] = None      # [K][N]
+    init_scalar_req: Optional[np.ndarray] = None   # [K][N]
+    gpu_cnt: Optional[np.ndarray] = None
+    gpu_mem_total: Optional[np.ndarray] = None
+    init_gpu_used: Optional[np.ndarray] = None     # [N][8]
+    topo_dom: Optional[np.ndarray] = None          # [Kt][N]
+    topo_n_dom: Optional[np.ndarray] = None        # [Kt]
+    # pods
+    req_cpu: np.ndarray = None
+    req_mem: np.ndarray = None
+    req_eph: Optional[np.ndarray] = None
+    nz_cpu: Optional[np.ndarray] = None
+    nz_mem: Optional[np.ndarray] = None
+    scalar_req: Optional[np.ndarray] = None        # [K][P]
+    pod_class: Optional[np.ndarray] = None
+    preset_node: Optional[np.ndarray] = None
+    gate_node: Optional[np.ndarray] = None
+    gpu_mem: Optional[np.ndarray] = None
+    pod_gpu_cnt: Optional[np.ndarray] = None
+    # class tables
+    n_pod_classes: int = 1
+    n_node_classes: int = 1
+    static_mask: Optional[np.ndarray] = None       # [Cp][ceil(N/64)] uint64
+    static_reason: Optional[np.ndarray] = None     # [Cp][N] uint8
+    simon_raw: Optional[np.ndarray] = None         # [Cp][Cn]
+    const_score: Optional[np.ndarray] = None       # [Cp]
+    term_topo_key: Optional[np.ndarray] = None     # [T]
+    anti_off: Optional[np.ndarray] = None
+    anti_idx: Optional[np.ndarray] = None
+    match_off: Optional[np.ndarray] = None
+    match_idx: Optional[np.ndarray] = None
+    _keep: list = field(default_factory=list, repr=False)
+
+    @property
+    def n_nodes(self) -> int:
+        return int(len(self.alloc_cpu))
+
+    @property
+    def n_pods(self) -> int:
+        return int(len(self.req_cpu))
+
+    def normalise(self) -> "Problem":
+        N, P = self.n_nodes, self.n_pods
+        i64, i32 = np.int64, np.int32
+        self.alloc_cpu = _arr(self.alloc_cpu, i64, (N,))
+        self.alloc_mem = _arr(self.alloc_mem, i64, (N,))
+        self.alloc_pods = _arr(self.alloc_pods, i32, (N,))
+        for name in ("alloc_eph", "init_req_cpu", "init_req_mem", "init_req_eph", "init_nz_cpu", "init_nz_mem",
+                     "gpu_mem_total"):
+            setattr(self, name, _arr(getattr(self, name), i64, (N,)))
+        for name in ("init_npods", "node_class", "gpu_cnt"):
+            setattr(self, name, _arr(getattr(self, name), i32, (N,)))
+        K = 0
+        if self.scalar_alloc is not None:
+            self.scalar_alloc = _arr(self.scalar_alloc, i64)
+            K = self.scalar_alloc.shape[0]
+            assert self.scalar_alloc.shape == (K, N) and K <= MAX_SCALAR
+        self.init_scalar_req = _arr(self.init_scalar_req, i64, (K, N)) if self.init_scalar_req is not None else None
+        self.init_gpu_used = _arr(self.init_gpu_used, i64, (N, MAX_GPU_DEV)) if self.init_gpu_used is not None else None
+        Kt = 0
+        if self.topo_dom is not None:
+            self.topo_dom = _arr(self.topo_dom, i32)
+            Kt = self.topo_dom.shape[0]
+            assert self.topo_dom.shape == (Kt, N)
+            self.topo_n_dom = _arr(self.topo_n_dom, i32, (Kt,))
+        self.req_cpu = _arr(self.req_cpu, i64, (P,))
+        self.req_mem = _arr(self.req_mem, i64, (P,))
+        for name in ("req_eph", "nz_cpu", "nz_mem", "gpu_mem"):
+            setattr(self, name, _arr(getattr(self, name), i64, (P,)))
+        for name in ("pod_class", "preset_node", "gate_node", "pod_gpu_cnt"):
+            setattr(self, name, _arr(getattr(self, name), i32, (P,)))
+        self.scalar_req = _arr(self.scalar_req, i64, (K, P)) if self.scalar_req is not None else None
+        Cp, Cn = self.n_pod_classes, self.n_node_classes
+        words = (N + 63) // 64
+        self.static_mask = _arr(self.static_mask, np.uint64, (Cp, words)) if self.static_mask is not None else None
+        self.static_reason = _arr(self.static_reason, np.uint8, (Cp, N)) if self.static_reason is not None else None
+        if self.simon_raw is None:
+            self.simon_raw = np.zeros((Cp, Cn), dtype=i64)
+        self.simon_raw = _arr(self.simon_raw, i64, (Cp, Cn))
+        self.const_score = _arr(self.const_score, i64, (Cp,)) if self.const_score is not None else None
+        if self.term_topo_key is not None:
+            self.term_topo_key = _arr(self.term_topo_key, i32)
+            for name in ("anti_off", "match_off"):
+                setattr(self, name, _arr(getattr(self, name), i32, (Cp + 1,)))
+            for name in ("anti_idx", "match_idx"):
+                v = getattr(self, name)
+                setattr(self, name, _arr(v if v is not None and len(v) else np.zeros(1, i32), i32))
+        return self
+
+    # --- C views ---------------------------------------------------------------------------
+    def c_nodes(self) -> NodesSoA:
+        self.normalise()
+        s = NodesSoA()
+        s.struct_size = C.sizeof(NodesSoA)
+        s.n_nodes = self.n_nodes
+        for name in ("alloc_cpu", "alloc_mem", "alloc_eph", "init_req_cpu", "init_req_mem", "init_req_eph",
+                     "init_nz_cpu", "init_nz_mem", "scalar_alloc", "init_scalar_req", "gpu_mem_total",
+                     "init_gpu_used"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int64))
+        for name in ("alloc_pods", "init_npods", "node_class", "gpu_cnt", "topo_dom", "topo_n_dom"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int32))
+        s.n_scalar = 0 if self.scalar_alloc is None else self.scalar_alloc.shape[0]
+        s.n_topo_keys = 0 if self.topo_dom is None else self.topo_dom.shape[0]
+        return s
+
+    def c_pods(self) -> PodsSoA:
+        self.normalise()
+        s = PodsSoA()
+        s.struct_size = C.sizeof(PodsSoA)
+        s.n_pods = self.n_pods
+        for name in ("req_cpu", "req_mem", "req_eph", "nz_cpu", "nz_mem", "scalar_req", "gpu_mem"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int64))
+        for name in ("pod_class", "preset_node", "gate_node"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int32))
+        s.gpu_cnt = _ptr(self.pod_gpu_cnt, C.c_int32)
+        return s
+
+    def c_tables(self) -> ClassTables:
+        self.normalise()
+        s = ClassTables()
+        s.struct_size = C.sizeof(ClassTables)
+        s.n_pod_classes = self.n_pod_classes
+        s.n_node_classes = self.n_node_classes
+        s.static_mask = _ptr(self.static_mask, C.c_uint64)
+        s.static_reason = _ptr(self.static_reason, C.c_uint8)
+        s.simon_raw = _ptr(self.simon_raw, C.c_int64)
+        s.const_score = _ptr(self.const_score, C.c_int64)
+        s.n_terms = 0 if self.term_topo_key is None else len(self.term_topo_key)
+        for name in ("term_topo_key", "anti_off", "anti_idx", "match_off", "match_idx"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int32))
+        return s
+
+
+@dataclass
+class BatchResult:
+    unscheduled: np.ndarray
+    used_cpu: np.ndarray
+    used_mem: np.ndarray
+    placement: Optional[np.ndarray]
+
+    def c_out(self) -> BatchOut:
+        o = BatchOut()
+        o.struct_size = C.sizeof(BatchOut)
+        o.flags = 0
+        o.unscheduled = _ptr(self.unscheduled, C.c_int32)
+        o.used_cpu = _ptr(self.used_cpu, C.c_int64)
+        o.used_mem = _ptr(self.used_mem, C.c_int64)
+        o.placement = _ptr(self.placement, C.c_int32)
+        return o
+
+    @staticmethod
+    def alloc(S: int, P: int, want_placement: bool = True) -> "BatchResult":
+        return BatchResult(np.zeros(S, np.int32), np.zeros(S, np.int64), np.zeros(S, np.int64),
+                           np.full((S, P), -9, np.int32) if want_placement else None)
+
+
+def scenarios_array(scen: Sequence) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(scen, dtype=np.int32).reshape(-1, 2))
+    return a
+
+
+def _pkg_dir() -> str:
+    return os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path() -> str:
+    return os.path.join(_pkg_dir(), "csrc", "libsimon_hip.so")
+
+
+_LIB = None
+
+EXPORTS = [
+    "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
+    "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
+    "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_explain",
+    "simon_get_stats", "simon_device_results",
+]
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libsimon_hip.so and declare prototypes.  Raises if the library is missing."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    path = path or library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.simon_hip_version.restype = C.c_int
+    lib.simon_hip_device_count.restype = C.c_int
+    lib.simon_ctx_create.restype = vp
+    lib.simon_ctx_create.argtypes = [C.c_int]
+    lib.simon_ctx_destroy.argtypes = [vp]
+    lib.simon_ctx_destroy.restype = None
+    lib.simon_last_error.restype = C.c_char_p
+    lib.simon_last_error.argtypes = [vp]
+    lib.simon_load_nodes.argtypes = [vp, C.POINTER(NodesSoA)]
+    lib.simon_load_pods.argtypes = [vp, C.POINTER(PodsSoA)]
+    lib.simon_load_class_tables.argtypes = [vp, C.POINTER(ClassTables)]
+    lib.simon_load_scenarios.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32]
+    lib.simon_run_loaded.argtypes = [vp, C.c_int32]
+    lib.simon_fetch_results.argtypes = [vp, C.POINTER(BatchOut)]
+    lib.simon_fetch_placement.argtypes = [vp, C.c_int32, _p32]
+    lib.simon_run_batch.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32, C.POINTER(BatchOut)]
+    lib.simon_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(Plan)]
+    lib.simon_explain.argtypes = [vp, Scenario, _p32, _p32, _pu16, C.c_int32]
+    lib.simon_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.simon_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int or name.startswith(("simon_load", "simon_run", "simon_fetch", "simon_min",
+                                                        "simon_explain", "simon_get", "simon_device")):
+            fn.restype = C.c_int
+    if lib.simon_hip_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: library {lib.simon_hip_version()} != binding {ABI_VERSION}")
+    if path == library_path():
+        _LIB = lib
+    return lib
+
+
+class SimonError(RuntimeError):
+    pass
+
+
+class Context:
+    """RAII wrapper over simon_ctx (one HIP device, one stream)."""
+
+    def __init__(self, device_id: int = 0, lib=None):
+        self.lib = lib or load_library()
+        self.h = self.lib.simon_ctx_create(int(device_id))
+        if not self.h:
+            raise SimonError("simon_ctx_create failed (no gfx950 device visible?)")
+        self.problem: Optional[Problem] = None
+        self.S = 0
+        self.scen: Optional[np.ndarray] = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.simon_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            msg = self.lib.simon_last_error(self.h)
+            raise SimonError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        return rc
+
+    def load_problem(self, prob: Problem):
+        prob.normalise()
+        n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
+        self._check(self.lib.simon_load_nodes(self.h, C.byref(n)), "simon_load_nodes")
+        self._check(self.lib.simon_load_pods(self.h, C.byref(p)), "simon_load_pods")
+        self._check(self.lib.simon_load_class_tables(self.h, C.byref(t)), "simon_load_class_tables")
+        self.problem = prob
+
+    def load_scenarios(self, scen, orders: np.ndarray):
+        scen = scenarios_array(scen)
+        orders = np.ascontiguousarray(orders, dtype=np.int32).reshape(-1, self.problem.n_pods)
+        self._check(self.lib.simon_load_scenarios(self.h, scen.ctypes.data_as(C.POINTER(Scenario)), len(scen),
+                                                  _ptr(orders, C.c_int32), orders.shape[0]), "simon_load_scenarios")
+        self.S = len(scen)
+        self.scen = scen
+
+    def run_loaded(self, want_placement: bool = True):
+        self._check(self.lib.simon_run_loaded(self.h, 1 if want_placement else 0), "simon_run_loaded")
+
+    def fetch(self, want_placement: bool = True) -> BatchResult:
+        res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement)
+        out = res.c_out()
+        self._check(self.lib.simon_fetch_results(self.h, C.byref(out)), "simon_fetch_results")
+        return res
+
+    def fetch_placement(self, scenario: int) -> np.ndarray:
+        row = np.zeros(self.problem.n_pods, np.int32)
+        self._check(self.lib.simon_fetch_placement(self.h, int(scenario), _ptr(row, C.c_int32)),
+                    "simon_fetch_placement")
+        return row
+
+    def run_batch(self, scen, orders: np.ndarray, want_placement: bool = True) -> BatchResult:
+        scen = scenarios_array(scen)
+        orders = np.ascontiguousarray(orders, dtype=np.int32).reshape(-1, self.problem.n_pods)
+        res = BatchResult.alloc(len(scen), self.problem.n_pods, want_placement)
+        out = res.c_out()
+        self._check(self.lib.simon_run_batch(self.h, scen.ctypes.data_as(C.POINTER(Scenario)), len(scen),
+                                             _ptr(orders, C.c_int32), orders.shape[0], C.byref(out)),
+                    "simon_run_batch")
+        self.S = len(scen)
+        self.scen = scen
+        return res
+
+    def min_plan(self, max_cpu_pct: int = 100, max_mem_pct: int = 100) -> Plan:
+        plan = Plan()
+        self._check(self.lib.simon_min_plan(self.h, int(max_cpu_pct), int(max_mem_pct), C.byref(plan)),
+                    "simon_min_plan")
+        return plan
+
+    def explain(self, n_nodes: int, order: np.ndarray, max_failed: int = 64):
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        failed = np.full(max_failed, -1, np.int32)
+        codes = np.zeros((max_failed, n_nodes), np.uint16)
+        sc = Scenario(int(n_nodes), 0)
+        n = self._check(self.lib.simon_explain(self.h, sc, _ptr(order, C.c_int32), _ptr(failed, C.c_int32),
+                                               _ptr(codes, C.c_uint16), int(max_failed)), "simon_explain")
+        k = min(n, max_failed)
+        return n, failed[:k], codes[:k]
+
+    def stats(self) -> Stats:
+        st = Stats()
+        self._check(self.lib.simon_get_stats(self.h, C.byref(st)), "simon_get_stats")
+        return st
+
+    def device_results(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self.lib.simon_device_results(self.h, C.byref(a), C.byref(b), C.byref(c)),
+                    "simon_device_results")
+        return a.value, b.value, c.value

@@ -1,0 +1,590 @@
+// simon_hip.hip -- C-ABI of libsimon_hip.so (include/simon_hip.h): context, input staging into
+// HBM (SoA), kernel-variant selection, launches, result fetch, min-plan reduction.
+//
+// Data layout in HBM (one copy per context, shared by every scenario of a batch):
+//   nodes   NARROW: a_cpu/a_mem u32 (gcd-normalised), a_pods/ncls i32, initial state u32/i32
+//           WIDE:   the int64 arrays of simon_nodes_soa as they come
+//   pods    PodRowN[P] (32 B rows, read through scalar loads) / WidePod[P]
+//   orders  int32 [n_orders][P];  scenarios {n_nodes, order_id}[S];  perm[S] (LPT launch order)
+//   tables  simon_raw as i32/i64 [Cp][Cn]; static_mask u64 [Cp][ceil(N/64)]
+//   out     unscheduled i32[S], used_cpu/used_mem i64[S], placement i32[S][P] (optional)
+#include "../../include/simon_hip.h"
+#include "simon_device.h"
+#include "simon_wide.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace simon {
+hipError_t launch_narrow(const NarrowArgs& a, int T, int slots, bool has_mask, bool rcp_div, size_t lds_bytes,
+                         hipStream_t st);
+}  // namespace simon
+
+using namespace simon;
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = std::max<size_t>(count, 1);
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& h, hipStream_t st) {
+        hipError_t e = ensure(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    }
+};
+
+struct PlanKernelOut {
+    unsigned long long key;  // (n_nodes << 32) | scenario, min-reduced; ~0 = none
+};
+
+}  // namespace
+
+struct simon_ctx : simon::HostInputs {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // host copies of the inputs live in the HostInputs base (caller buffers are never retained)
+    bool have_nodes = false, have_pods = false, have_tables = false, staged = false;
+    // ---- variant decision ----
+    int variant = 0;
+    uint64_t g_cpu = 1, g_mem = 1;
+    bool rcp_div = true;
+    int force_T = 0;  // env SIMON_WG
+    // ---- device buffers ----
+    DevBuf<uint32_t> d_a_cpu, d_a_mem, d_i_rq_cpu, d_i_rq_mem, d_i_nz_cpu, d_i_nz_mem;
+    DevBuf<int32_t> d_a_pods, d_ncls, d_i_npods, d_raw32;
+    DevBuf<PodRowN> d_podsN;
+    DevBuf<uint64_t> d_mask;
+    DevBuf<int64_t> d_prefix_cpu, d_prefix_mem;
+    WideDevice wide;
+    // scenarios
+    int S = 0, n_orders = 0, max_n = 0;
+    std::vector<ScenarioDesc> scen;
+    DevBuf<ScenarioDesc> d_scen;
+    DevBuf<int32_t> d_orders, d_perm;
+    // outputs
+    DevBuf<int32_t> d_unsched, d_place;
+    DevBuf<int64_t> d_used_cpu, d_used_mem;
+    DevBuf<unsigned long long> d_plan;
+    bool have_results = false, have_placement = false;
+    simon_stats stats{};
+};
+
+namespace {
+
+int fail(simon_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), e_ == hipErrorOutOfMemory ? SIMON_ENOMEM : SIMON_ENODEV, "%s: %s", \
+                        #call, hipGetErrorString(e_));                                           \
+    } while (0)
+
+template <class T>
+void copy_opt(std::vector<T>& dst, const T* src, size_t n, T fill = T()) {
+    if (src) dst.assign(src, src + n);
+    else dst.assign(n, fill);
+}
+
+uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
+
+uint64_t gcd_of(std::initializer_list<const std::vector<int64_t>*> vs) {
+    uint64_t g = 0;
+    for (auto* v : vs) for (int64_t x : *v) { if (x < 0) return 0; g = gcd_u64(g, (uint64_t)x); if (g == 1) return 1; }
+    return g ? g : 1;
+}
+
+// Decide NARROW vs WIDE and compute the gcd normalisation.
+// NARROW needs: cpu+mem+pods only; every quantity non-negative; after dividing by the gcd all
+// node totals and the worst-case accumulated NonZeroRequested stay < 2^31; simon raw scores fit
+// 30 bits; original quantities < 2^53 (exact in fp64, so BalancedAllocation is scale-invariant).
+void choose_variant(simon_ctx* c) {
+    c->variant = SIMON_KERNEL_WIDE;
+    c->g_cpu = c->g_mem = 1;
+    if (const char* f = getenv("SIMON_FORCE_WIDE")) if (f[0] == '1') return;
+    if (c->K > 0 || c->has_gpu || c->Tm > 0) return;
+    for (int64_t x : c->alloc_eph) if (x) return;
+    for (int64_t x : c->i_req_eph) if (x) return;
+    for (int64_t x : c->p_req_eph) if (x) return;
+    if (c->N >= (1 << 20) - 1) return;
+    const uint64_t gc = gcd_of({&c->alloc_cpu, &c->i_req_cpu, &c->i_nz_cpu, &c->p_req_cpu, &c->p_nz_cpu});
+    const uint64_t gm = gcd_of({&c->alloc_mem, &c->i_req_mem, &c->i_nz_mem, &c->p_req_mem, &c->p_nz_mem});
+    if (!gc || !gm) return;  // negative quantity somewhere
+    const uint64_t lim53 = 1ull << 53, lim31 = 1ull << 31;
+    auto bounded = [&](const std::vector<int64_t>& alloc, const std::vector<int64_t>& irq, const std::vector<int64_t>& inz,
+                       const std::vector<int64_t>& prq, const std::vector<int64_t>& pnz, uint64_t g) {
+        uint64_t max_node = 0, sum_p = 0;
+        for (size_t j = 0; j < alloc.size(); ++j)
+            max_node = std::max({max_node, (uint64_t)alloc[j], (uint64_t)irq[j], (uint64_t)inz[j]});
+        for (size_t p = 0; p < prq.size(); ++p) {
+            sum_p += std::max((uint64_t)prq[p], (uint64_t)pnz[p]);
+            if (sum_p >= lim53) return false;
+        }
+        if (max_node + sum_p >= lim53) return false;
+        return (max_node + sum_p) / g < lim31;
+    };
+    if (!bounded(c->alloc_cpu, c->i_req_cpu, c->i_nz_cpu, c->p_req_cpu, c->p_nz_cpu, gc)) return;
+    if (!bounded(c->alloc_mem, c->i_req_mem, c->i_nz_mem, c->p_req_mem, c->p_nz_mem, gm)) return;
+    for (int64_t r : c->simon_raw) if (r < 0 || r >= (1ll << 30)) return;
+    if ((size_t)c->Cp * c->Cn * sizeof(int32_t) > 60 * 1024) return;  // simon_raw must fit LDS
+    c->variant = SIMON_KERNEL_NARROW;
+    c->g_cpu = gc;
+    c->g_mem = gm;
+}
+
+int stage_narrow(simon_ctx* c) {
+    const int N = c->N, P = c->P;
+    std::vector<uint32_t> a_cpu(N), a_mem(N), rqc(N), rqm(N), nzc(N), nzm(N);
+    for (int j = 0; j < N; ++j) {
+        a_cpu[j] = (uint32_t)(c->alloc_cpu[j] / c->g_cpu);
+        a_mem[j] = (uint32_t)(c->alloc_mem[j] / c->g_mem);
+        rqc[j] = (uint32_t)(c->i_req_cpu[j] / c->g_cpu);
+        rqm[j] = (uint32_t)(c->i_req_mem[j] / c->g_mem);
+        nzc[j] = (uint32_t)(c->i_nz_cpu[j] / c->g_cpu);
+        nzm[j] = (uint32_t)(c->i_nz_mem[j] / c->g_mem);
+    }
+    std::vector<PodRowN> rows(P);
+    for (int p = 0; p < P; ++p) {
+        PodRowN& r = rows[p];
+        r.req_cpu = (uint32_t)(c->p_req_cpu[p] / c->g_cpu);
+        r.req_mem = (uint32_t)(c->p_req_mem[p] / c->g_mem);
+        r.nz_cpu = (uint32_t)(c->p_nz_cpu[p] / c->g_cpu);
+        r.nz_mem = (uint32_t)(c->p_nz_mem[p] / c->g_mem);
+        r.cls = c->p_cls[p];
+        r.preset = c->p_preset[p];
+        r.gate = c->p_gate[p];
+        r.flags = (c->p_req_cpu[p] == 0 && c->p_req_mem[p] == 0) ? 1u : 0u;
+    }
+    std::vector<int32_t> raw32(c->simon_raw.begin(), c->simon_raw.end());
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->d_a_cpu.upload(a_cpu, st));
+    HIP_TRY(c, c->d_a_mem.upload(a_mem, st));
+    HIP_TRY(c, c->d_i_rq_cpu.upload(rqc, st));
+    HIP_TRY(c, c->d_i_rq_mem.upload(rqm, st));
+    HIP_TRY(c, c->d_i_nz_cpu.upload(nzc, st));
+    HIP_TRY(c, c->d_i_nz_mem.upload(nzm, st));
+    HIP_TRY(c, c->d_a_pods.upload(c->alloc_pods, st));
+    HIP_TRY(c, c->d_ncls.upload(c->node_class, st));
+    HIP_TRY(c, c->d_i_npods.upload(c->i_npods, st));
+    HIP_TRY(c, c->d_podsN.upload(rows, st));
+    HIP_TRY(c, c->d_raw32.upload(raw32, st));
+    if (c->has_mask) HIP_TRY(c, c->d_mask.upload(c->static_mask, st));
+    HIP_TRY(c, hipStreamSynchronize(st));  // staging vectors die at scope exit
+    return SIMON_OK;
+}
+
+int stage(simon_ctx* c) {
+    if (!(c->have_nodes && c->have_pods && c->have_tables))
+        return fail(c, SIMON_ESTATE, "load nodes, pods and class tables before scenarios");
+    if (c->staged) return SIMON_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // cross-validation of the three inputs
+    for (int p = 0; p < c->P; ++p) {
+        if (c->p_cls[p] < 0 || c->p_cls[p] >= c->Cp) return fail(c, SIMON_EINVAL, "pod %d: class %d out of range", p, c->p_cls[p]);
+        if (c->p_preset[p] >= c->N) return fail(c, SIMON_EINVAL, "pod %d: preset node %d out of range", p, c->p_preset[p]);
+    }
+    for (int j = 0; j < c->N; ++j)
+        if (c->node_class[j] < 0 || c->node_class[j] >= c->Cn) return fail(c, SIMON_EINVAL, "node %d: class out of range", j);
+    if (c->has_mask && c->static_mask.size() != (size_t)c->Cp * ((c->N + 63) / 64))
+        return fail(c, SIMON_EINVAL, "static_mask size mismatch");
+    choose_variant(c);
+    // prefix sums of allocatable for the occupancy caps (satisfyResourceSetting, apply.go:737-760)
+    std::vector<int64_t> pc(c->N + 1, 0), pm(c->N + 1, 0);
+    for (int j = 0; j < c->N; ++j) { pc[j + 1] = pc[j] + c->alloc_cpu[j]; pm[j + 1] = pm[j] + c->alloc_mem[j]; }
+    HIP_TRY(c, c->d_prefix_cpu.upload(pc, c->stream));
+    HIP_TRY(c, c->d_prefix_mem.upload(pm, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = c->variant == SIMON_KERNEL_NARROW ? stage_narrow(c) : wide_stage(c->wide, *c, c->stream, c->err);
+    if (rc) return rc;
+    c->staged = true;
+    return SIMON_OK;
+}
+
+// ---- min-plan reduction (pkg/apply/apply.go:203-259 + satisfyResourceSetting :689-775) --------
+__global__ void plan_kernel(const ScenarioDesc* __restrict__ scen, int S, const int32_t* __restrict__ unsched,
+                            const int64_t* __restrict__ used_cpu, const int64_t* __restrict__ used_mem,
+                            const int64_t* __restrict__ prefix_cpu, const int64_t* __restrict__ prefix_mem, int max_cpu,
+                            int max_mem, unsigned long long* __restrict__ out) {
+    unsigned long long best = ~0ull;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += gridDim.x * blockDim.x) {
+        if (unsched[s] != 0) continue;
+        const int n = scen[s].n_nodes;
+        // int(float64(used.MilliValue()) / float64(alloc.MilliValue()) * 100), apply.go:759-760
+        const int cpu = (int)((double)used_cpu[s] / (double)prefix_cpu[n] * 100.0);
+        const int mem = (int)((double)(used_mem[s] * 1000) / (double)(prefix_mem[n] * 1000) * 100.0);
+        if (cpu > max_cpu || mem > max_mem) continue;
+        const unsigned long long key = ((unsigned long long)(unsigned)n << 32) | (unsigned)s;
+        best = key < best ? key : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(out, best);
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int simon_hip_version(void) { return SIMON_HIP_ABI_VERSION; }
+
+int simon_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+simon_ctx* simon_ctx_create(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    simon_ctx* c = new (std::nothrow) simon_ctx();
+    if (!c) return nullptr;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
+    if (const char* e = getenv("SIMON_WG")) c->force_T = atoi(e);
+    if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
+    return c;
+}
+
+void simon_ctx_destroy(simon_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    c->wide.release();
+    // DevBuf destructors free device memory
+    hipStream_t st = c->stream;
+    delete c;
+    if (st) (void)hipStreamDestroy(st);
+}
+
+const char* simon_last_error(simon_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int simon_load_nodes(simon_ctx* c, const simon_nodes_soa* nd) {
+    if (!c || !nd) return SIMON_EINVAL;
+    if (nd->struct_size != sizeof(simon_nodes_soa)) return fail(c, SIMON_EINVAL, "simon_nodes_soa size mismatch");
+    const int N = nd->n_nodes;
+    if (N <= 0 || !nd->alloc_cpu || !nd->alloc_mem || !nd->alloc_pods) return fail(c, SIMON_EINVAL, "nodes: missing required arrays");
+    if (nd->n_scalar < 0 || nd->n_scalar > SIMON_MAX_SCALAR) return fail(c, SIMON_EINVAL, "n_scalar out of range");
+    if (nd->n_scalar > 0 && !nd->scalar_alloc) return fail(c, SIMON_EINVAL, "scalar_alloc missing");
+    if (nd->n_topo_keys < 0 || (nd->n_topo_keys > 0 && (!nd->topo_dom || !nd->topo_n_dom))) return fail(c, SIMON_EINVAL, "topology arrays missing");
+    c->N = N; c->K = nd->n_scalar; c->Kt = nd->n_topo_keys;
+    copy_opt(c->alloc_cpu, nd->alloc_cpu, N); copy_opt(c->alloc_mem, nd->alloc_mem, N);
+    copy_opt(c->alloc_eph, nd->alloc_eph, N); copy_opt(c->alloc_pods, nd->alloc_pods, N);
+    copy_opt(c->i_req_cpu, nd->init_req_cpu, N); copy_opt(c->i_req_mem, nd->init_req_mem, N);
+    copy_opt(c->i_req_eph, nd->init_req_eph, N); copy_opt(c->i_nz_cpu, nd->init_nz_cpu, N);
+    copy_opt(c->i_nz_mem, nd->init_nz_mem, N); copy_opt(c->i_npods, nd->init_npods, N);
+    copy_opt(c->node_class, nd->node_class, N);
+    copy_opt(c->scalar_alloc, nd->scalar_alloc, (size_t)c->K * N);
+    copy_opt(c->i_scalar_req, nd->init_scalar_req, (size_t)c->K * N);
+    c->has_gpu = nd->gpu_cnt != nullptr;
+    if (c->has_gpu && !nd->gpu_mem_total) return fail(c, SIMON_EINVAL, "gpu_mem_total missing");
+    copy_opt(c->gpu_cnt, nd->gpu_cnt, N); copy_opt(c->gpu_mem_total, nd->gpu_mem_total, N);
+    copy_opt(c->i_gpu_used, nd->init_gpu_used, (size_t)N * SIMON_MAX_GPU_DEV);
+    for (int j = 0; j < N; ++j)
+        if (c->gpu_cnt[j] < 0 || c->gpu_cnt[j] > SIMON_MAX_GPU_DEV) return fail(c, SIMON_ERANGE, "node %d: gpu_cnt %d > %d", j, c->gpu_cnt[j], SIMON_MAX_GPU_DEV);
+    copy_opt(c->topo_dom, nd->topo_dom, (size_t)c->Kt * N); copy_opt(c->topo_n_dom, nd->topo_n_dom, (size_t)c->Kt);
+    for (int k = 0; k < c->Kt; ++k)
+        for (int j = 0; j < N; ++j) {
+            const int d = c->topo_dom[(size_t)k * N + j];
+            if (d < -1 || d >= c->topo_n_dom[k]) return fail(c, SIMON_EINVAL, "topo_dom[%d][%d] out of range", k, j);
+        }
+    c->have_nodes = true; c->staged = false; c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_load_pods(simon_ctx* c, const simon_pods_soa* pd) {
+    if (!c || !pd) return SIMON_EINVAL;
+    if (pd->struct_size != sizeof(simon_pods_soa)) return fail(c, SIMON_EINVAL, "simon_pods_soa size mismatch");
+    if (!c->have_nodes) return fail(c, SIMON_ESTATE, "load nodes before pods");
+    const int P = pd->n_pods;
+    if (P < 0 || (P > 0 && (!pd->req_cpu || !pd->req_mem))) return fail(c, SIMON_EINVAL, "pods: missing required arrays");
+    c->P = P;
+    copy_opt(c->p_req_cpu, pd->req_cpu, P); copy_opt(c->p_req_mem, pd->req_mem, P); copy_opt(c->p_req_eph, pd->req_eph, P);
+    if (pd->nz_cpu) copy_opt(c->p_nz_cpu, pd->nz_cpu, P); else c->p_nz_cpu = c->p_req_cpu;
+    if (pd->nz_mem) copy_opt(c->p_nz_mem, pd->nz_mem, P); else c->p_nz_mem = c->p_req_mem;
+    copy_opt(c->p_scalar, pd->scalar_req, (size_t)c->K * P);
+    copy_opt(c->p_cls, pd->pod_class, P);
+    copy_opt(c->p_preset, pd->preset_node, P, (int32_t)-1);
+    copy_opt(c->p_gate, pd->gate_node, P, (int32_t)-1);
+    copy_opt(c->p_gpu_mem, pd->gpu_mem, P); copy_opt(c->p_gpu_cnt, pd->gpu_cnt, P);
+    c->have_pods = true; c->staged = false; c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_load_class_tables(simon_ctx* c, const simon_class_tables* tb) {
+    if (!c || !tb) return SIMON_EINVAL;
+    if (tb->struct_size != sizeof(simon_class_tables)) return fail(c, SIMON_EINVAL, "simon_class_tables size mismatch");
+    if (!c->have_nodes) return fail(c, SIMON_ESTATE, "load nodes before class tables");
+    if (tb->n_pod_classes <= 0 || tb->n_node_classes <= 0 || !tb->simon_raw) return fail(c, SIMON_EINVAL, "class tables: bad sizes");
+    c->Cp = tb->n_pod_classes; c->Cn = tb->n_node_classes;
+    const size_t words = (size_t)(c->N + 63) / 64;
+    c->has_mask = tb->static_mask != nullptr;
+    copy_opt(c->static_mask, tb->static_mask, c->has_mask ? (size_t)c->Cp * words : 0);
+    copy_opt(c->static_reason, tb->static_reason, tb->static_reason ? (size_t)c->Cp * c->N : 0);
+    copy_opt(c->simon_raw, tb->simon_raw, (size_t)c->Cp * c->Cn);
+    copy_opt(c->const_score, tb->const_score, (size_t)c->Cp);
+    c->Tm = tb->n_terms;
+    if (c->Tm < 0) return fail(c, SIMON_EINVAL, "n_terms < 0");
+    if (c->Tm > 0) {
+        if (!tb->term_topo_key || !tb->anti_off || !tb->match_off) return fail(c, SIMON_EINVAL, "anti-affinity CSR missing");
+        copy_opt(c->term_key, tb->term_topo_key, (size_t)c->Tm);
+        copy_opt(c->anti_off, tb->anti_off, (size_t)c->Cp + 1);
+        copy_opt(c->match_off, tb->match_off, (size_t)c->Cp + 1);
+        copy_opt(c->anti_idx, tb->anti_idx, (size_t)c->anti_off[c->Cp]);
+        copy_opt(c->match_idx, tb->match_idx, (size_t)c->match_off[c->Cp]);
+        for (int t = 0; t < c->Tm; ++t)
+            if (c->term_key[t] < 0 || c->term_key[t] >= c->Kt) return fail(c, SIMON_EINVAL, "term %d: topology key out of range", t);
+        for (int k = 0; k < c->Cp; ++k) {
+            if (c->anti_off[k + 1] - c->anti_off[k] > SIMON_MAX_TERMS_PER_CLASS * 4 || c->anti_off[k + 1] < c->anti_off[k] ||
+                c->match_off[k + 1] < c->match_off[k])
+                return fail(c, SIMON_EINVAL, "class %d: bad CSR", k);
+        }
+        for (int32_t t : c->anti_idx) if (t < 0 || t >= c->Tm) return fail(c, SIMON_EINVAL, "anti_idx out of range");
+        for (int32_t t : c->match_idx) if (t < 0 || t >= c->Tm) return fail(c, SIMON_EINVAL, "match_idx out of range");
+    } else {
+        c->term_key.clear(); c->anti_off.assign(c->Cp + 1, 0); c->match_off.assign(c->Cp + 1, 0);
+        c->anti_idx.clear(); c->match_idx.clear();
+    }
+    c->have_tables = true; c->staged = false; c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders) {
+    if (!c || !scen || S <= 0 || !orders || n_orders <= 0) return c ? fail(c, SIMON_EINVAL, "load_scenarios: bad arguments") : SIMON_EINVAL;
+    int rc = stage(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int P = c->P;
+    c->scen.resize(S);
+    int max_n = 0;
+    for (int s = 0; s < S; ++s) {
+        if (scen[s].n_nodes < 0 || scen[s].n_nodes > c->N) return fail(c, SIMON_EINVAL, "scenario %d: n_nodes %d outside [0,%d]", s, scen[s].n_nodes, c->N);
+        if (scen[s].order_id < 0 || scen[s].order_id >= n_orders) return fail(c, SIMON_EINVAL, "scenario %d: order_id out of range", s);
+        c->scen[s] = ScenarioDesc{scen[s].n_nodes, scen[s].order_id};
+        max_n = std::max(max_n, scen[s].n_nodes);
+    }
+    // every order must be a sequence of valid pod ids; preset targets must exist in each scenario
+    for (size_t i = 0; i < (size_t)n_orders * P; ++i)
+        if (orders[i] < 0 || orders[i] >= P) return fail(c, SIMON_EINVAL, "orders[%zu] = %d is not a pod id", i, orders[i]);
+    int min_n = c->N;
+    for (int s = 0; s < S; ++s) min_n = std::min(min_n, scen[s].n_nodes);
+    for (int p = 0; p < P; ++p)
+        if (c->p_preset[p] >= 0 && c->p_preset[p] >= min_n && c->p_gate[p] < c->p_preset[p])
+            return fail(c, SIMON_EINVAL, "pod %d is preset to node %d which a %d-node scenario lacks (gate it)", p, c->p_preset[p], min_n);
+    // LPT launch order: biggest scenarios first (cost ~ ceil(n / T) per pod)
+    std::vector<int32_t> perm(S);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return scen[a].n_nodes > scen[b].n_nodes; });
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, c->d_scen.upload(c->scen, c->stream));
+    HIP_TRY(c, c->d_perm.upload(perm, c->stream));
+    HIP_TRY(c, c->d_orders.ensure((size_t)n_orders * P));
+    HIP_TRY(c, hipMemcpyAsync(c->d_orders.p, orders, (size_t)n_orders * P * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, c->d_unsched.ensure(S));
+    HIP_TRY(c, c->d_used_cpu.ensure(S));
+    HIP_TRY(c, c->d_used_mem.ensure(S));
+    HIP_TRY(c, c->d_plan.ensure(1));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller buffers may die after return
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.h2d_ms = ms;
+    c->S = S; c->n_orders = n_orders; c->max_n = max_n;
+    c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
+    if (!c) return SIMON_EINVAL;
+    if (!c->staged || c->S <= 0) return fail(c, SIMON_ESTATE, "run_loaded: no scenarios loaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int S = c->S, P = c->P;
+    if (want_placement) HIP_TRY(c, c->d_place.ensure((size_t)S * P));
+    int T = 0, slots = 0;
+    size_t lds = 0;
+    if (c->variant == SIMON_KERNEL_NARROW) {
+        // workgroup shape: T = 256 (4 waves) with up to 8 node slots per lane covers 2048 nodes;
+        // larger pools widen the workgroup.  SIMON_WG overrides (tuning knob).
+        T = c->force_T ? c->force_T : (c->max_n <= 2048 ? 256 : c->max_n <= 4096 ? 512 : 1024);
+        slots = (std::max(c->max_n, 1) + T - 1) / T;
+        if (slots > 8) {  // pool too large for register residency even at T=1024 -> WIDE
+            return fail(c, SIMON_ERANGE, "narrow kernel: %d nodes exceed 8 slots x %d lanes; set SIMON_FORCE_WIDE=1", c->max_n, T);
+        }
+        if (slots == 5) slots = 6;
+        if (slots == 7) slots = 8;
+        lds = ((size_t)c->Cp * c->Cn * sizeof(int32_t) + 15) & ~(size_t)15;
+        NarrowArgs a{};
+        a.a_cpu = c->d_a_cpu.p; a.a_mem = c->d_a_mem.p; a.a_pods = c->d_a_pods.p; a.ncls = c->d_ncls.p;
+        a.i_rq_cpu = c->d_i_rq_cpu.p; a.i_rq_mem = c->d_i_rq_mem.p; a.i_nz_cpu = c->d_i_nz_cpu.p; a.i_nz_mem = c->d_i_nz_mem.p;
+        a.i_npods = c->d_i_npods.p;
+        a.pods = c->d_podsN.p; a.orders = c->d_orders.p; a.scen = c->d_scen.p; a.perm = c->d_perm.p;
+        a.static_mask = c->has_mask ? c->d_mask.p : nullptr;
+        a.simon_raw = c->d_raw32.p;
+        a.mask_words = (c->N + 63) / 64; a.Cn = c->Cn; a.Cp = c->Cp; a.P = P; a.S = S;
+        a.g_cpu = c->g_cpu; a.g_mem = c->g_mem;
+        a.unscheduled = c->d_unsched.p; a.used_cpu = c->d_used_cpu.p; a.used_mem = c->d_used_mem.p;
+        a.placement = want_placement ? c->d_place.p : nullptr;
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(c, launch_narrow(a, T, slots, c->has_mask, c->rcp_div, lds, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    } else {
+        T = c->force_T ? c->force_T : (c->max_n <= 512 ? 256 : c->max_n <= 4096 ? 512 : 1024);
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
+                          c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p,
+                          want_placement ? c->d_place.p : nullptr, c->stream, c->err);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.kernel_ms = ms;
+    c->stats.n_launches = 1;
+    c->stats.kernel_variant = c->variant;
+    c->stats.workgroup_size = T;
+    c->stats.slots_per_lane = slots;
+    c->stats.lds_bytes = (int64_t)lds;
+    c->have_results = true;
+    c->have_placement = want_placement != 0;
+    return SIMON_OK;
+}
+
+int simon_fetch_results(simon_ctx* c, simon_batch_out* out) {
+    if (!c || !out) return SIMON_EINVAL;
+    if (out->struct_size != sizeof(simon_batch_out)) return fail(c, SIMON_EINVAL, "simon_batch_out size mismatch");
+    if (!c->have_results) return fail(c, SIMON_ESTATE, "fetch_results: nothing has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t S = c->S, P = c->P;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (out->unscheduled) HIP_TRY(c, hipMemcpyAsync(out->unscheduled, c->d_unsched.p, S * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out->used_cpu) HIP_TRY(c, hipMemcpyAsync(out->used_cpu, c->d_used_cpu.p, S * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out->used_mem) HIP_TRY(c, hipMemcpyAsync(out->used_mem, c->d_used_mem.p, S * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out->placement) {
+        if (!c->have_placement) return fail(c, SIMON_ESTATE, "fetch_results: the last run skipped placements");
+        HIP_TRY(c, hipMemcpyAsync(out->placement, c->d_place.p, S * P * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.d2h_ms = ms;
+    return SIMON_OK;
+}
+
+int simon_fetch_placement(simon_ctx* c, int32_t scenario, int32_t* placement) {
+    if (!c || !placement) return SIMON_EINVAL;
+    if (!c->have_results || !c->have_placement) return fail(c, SIMON_ESTATE, "fetch_placement: no placements on device");
+    if (scenario < 0 || scenario >= c->S) return fail(c, SIMON_EINVAL, "fetch_placement: scenario out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(placement, c->d_place.p + (size_t)scenario * c->P, (size_t)c->P * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIMON_OK;
+}
+
+int simon_run_batch(simon_ctx* c, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
+                    simon_batch_out* out) {
+    if (!c || !out) return SIMON_EINVAL;
+    int rc = simon_load_scenarios(c, scen, S, orders, n_orders);
+    if (rc) return rc;
+    rc = simon_run_loaded(c, out->placement != nullptr);
+    if (rc) return rc;
+    return simon_fetch_results(c, out);
+}
+
+int simon_min_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, simon_plan* best) {
+    if (!c || !best) return SIMON_EINVAL;
+    if (!c->have_results) return fail(c, SIMON_ESTATE, "min_plan: nothing has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (max_cpu_pct > 100 || max_cpu_pct < 0) max_cpu_pct = 100;  // apply.go:698-700
+    if (max_mem_pct > 100 || max_mem_pct < 0) max_mem_pct = 100;
+    HIP_TRY(c, hipMemsetAsync(c->d_plan.p, 0xFF, sizeof(unsigned long long), c->stream));
+    const int blocks = std::min(64, (c->S + 255) / 256);
+    hipLaunchKernelGGL(plan_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scen.p, c->S, c->d_unsched.p,
+                       c->d_used_cpu.p, c->d_used_mem.p, c->d_prefix_cpu.p, c->d_prefix_mem.p, max_cpu_pct, max_mem_pct,
+                       c->d_plan.p);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long key = 0;
+    HIP_TRY(c, hipMemcpyAsync(&key, c->d_plan.p, sizeof key, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memset(best, 0, sizeof *best);
+    best->scenario = -1;
+    if (key == ~0ull) return SIMON_OK;
+    const int s = (int)(key & 0xFFFFFFFFu);
+    int64_t uc = 0, um = 0;
+    HIP_TRY(c, hipMemcpy(&uc, c->d_used_cpu.p + s, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&um, c->d_used_mem.p + s, 8, hipMemcpyDeviceToHost));
+    const int n = c->scen[s].n_nodes;
+    int64_t ac = 0, am = 0;
+    for (int j = 0; j < n; ++j) { ac += c->alloc_cpu[j]; am += c->alloc_mem[j]; }
+    best->found = 1; best->scenario = s; best->n_nodes = n; best->order_id = c->scen[s].order_id;
+    best->cpu_pct = (int)((double)uc / (double)ac * 100.0);
+    best->mem_pct = (int)((double)(um * 1000) / (double)(am * 1000) * 100.0);
+    best->used_cpu = uc; best->used_mem = um;
+    return SIMON_OK;
+}
+
+int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32_t* failed_pods, uint16_t* fail_codes,
+                  int32_t max_failed) {
+    if (!c || !order || !failed_pods || !fail_codes || max_failed <= 0) return c ? fail(c, SIMON_EINVAL, "explain: bad arguments") : SIMON_EINVAL;
+    int rc = stage(c);
+    if (rc) return rc;
+    if (scen.n_nodes < 0 || scen.n_nodes > c->N) return fail(c, SIMON_EINVAL, "explain: n_nodes out of range");
+    for (int i = 0; i < c->P; ++i) if (order[i] < 0 || order[i] >= c->P) return fail(c, SIMON_EINVAL, "explain: bad order");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int T = c->force_T ? c->force_T : (scen.n_nodes <= 512 ? 256 : scen.n_nodes <= 4096 ? 512 : 1024);
+    return wide_explain(c->wide, *c, scen.n_nodes, order, failed_pods, fail_codes, max_failed, T, c->stream, c->err);
+}
+
+int simon_get_stats(simon_ctx* c, simon_stats* st) {
+    if (!c || !st) return SIMON_EINVAL;
+    *st = c->stats;
+    return SIMON_OK;
+}
+
+int simon_device_results(simon_ctx* c, void** d_unscheduled, void** d_used_cpu, void** d_used_mem) {
+    if (!c) return SIMON_EINVAL;
+    if (!c->have_results) return fail(c, SIMON_ESTATE, "device_results: nothing has run");
+    if (d_unscheduled) *d_unscheduled = c->d_unsched.p;
+    if (d_used_cpu) *d_used_cpu = c->d_used_cpu.p;
+    if (d_used_mem) *d_used_mem = c->d_used_mem.p;
+    return SIMON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// simon_wide.h -- host inputs shared by the staging code, and the WIDE (all-feature, int64,
+// HBM/L2-streamed state) kernel interface.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/simon_hip.h"
+
+namespace simon {
+
+// Host-side copies of everything simon_load_* received (the caller's buffers are not retained).
+struct HostInputs {
+    int N = 0, P = 0, K = 0, Kt = 0, Cp = 1, Cn = 1, Tm = 0;
+    std::vector<int64_t> alloc_cpu, alloc_mem, alloc_eph, i_req_cpu, i_req_mem, i_req_eph, i_nz_cpu, i_nz_mem;
+    std::vector<int32_t> alloc_pods, i_npods, node_class;
+    std::vector<int64_t> scalar_alloc, i_scalar_req, gpu_mem_total, i_gpu_used;
+    std::vector<int32_t> gpu_cnt, topo_dom, topo_n_dom;
+    bool has_gpu = false;
+    std::vector<int64_t> p_req_cpu, p_req_mem, p_req_eph, p_nz_cpu, p_nz_mem, p_scalar, p_gpu_mem;
+    std::vector<int32_t> p_cls, p_preset, p_gate, p_gpu_cnt;
+    std::vector<uint64_t> static_mask;
+    std::vector<uint8_t> static_reason;
+    std::vector<int64_t> simon_raw, const_score;
+    std::vector<int32_t> term_key, anti_off, anti_idx, match_off, match_idx;
+    bool has_mask = false;
+};
+
+// One pod of the stream, WIDE layout (128 B).
+struct WidePod {
+    int64_t req_cpu, req_mem, req_eph, nz_cpu, nz_mem, gpu_mem;
+    int64_t scalar[SIMON_MAX_SCALAR];
+    int32_t cls, preset, gate, gpu_cnt;
+    uint32_t flags;  // bit0: all-zero request incl. scalars (fit.go:244-249)
+    uint32_t pad[7];
+};
+static_assert(sizeof(WidePod) == 128, "WidePod must be 128 bytes");
+
+struct WideScenario {
+    int32_t n_nodes, order_id;
+};
+
+struct WideArgs {
+    int32_t N, P, K, Kt, Cp, Cn, Tm, S;     // S = scenarios in THIS launch (chunk)
+    int32_t mask_words, total_dom, has_gpu, has_mask;
+    // static node arrays [N] (shared)
+    const int64_t* alloc_cpu; const int64_t* alloc_mem; const int64_t* alloc_eph; const int32_t* alloc_pods;
+    const int32_t* node_class; const int64_t* scalar_alloc /*[K][N]*/;
+    const int32_t* gpu_cnt; const int64_t* gpu_mem_total;
+    const int32_t* topo_dom /*[Kt][N]*/;
+    // initial state [N]
+    const int64_t* i_req_cpu; const int64_t* i_req_mem; const int64_t* i_req_eph; const int64_t* i_nz_cpu;
+    const int64_t* i_nz_mem; const int32_t* i_npods; const int64_t* i_scalar_req; const int64_t* i_gpu_used;
+    // tables
+    const uint64_t* static_mask; const uint8_t* static_reason; const int64_t* simon_raw;
+    const int32_t* term_key; const int32_t* term_dom_off /*[Tm] offset of term t's counters*/;
+    const int32_t* anti_off; const int32_t* anti_idx; const int32_t* match_off; const int32_t* match_idx;
+    // stream
+    const WidePod* pods; const int32_t* orders; const WideScenario* scen /*[S] of this chunk*/;
+    // per-scenario mutable state, [S_chunk][...]
+    int64_t* st_req_cpu; int64_t* st_req_mem; int64_t* st_req_eph; int64_t* st_nz_cpu; int64_t* st_nz_mem;
+    int32_t* st_npods; int64_t* st_scalar /*[S][K][N]*/; int64_t* st_gpu /*[S][N][8]*/;
+    int32_t* st_cnt /*[S][2][total_dom]*/;
+    // outputs of this chunk
+    int32_t* unscheduled; int64_t* used_cpu; int64_t* used_mem; int32_t* placement /*[S][P] or null*/;
+    // explain outputs (single scenario)
+    int32_t* failed_pods; uint16_t* fail_codes; int32_t max_failed; int32_t* n_failed;
+};
+
+struct WideDevice {
+    void* blobs[40] = {};
+    int n_blobs = 0;
+    int state_chunk = 0;   // scenarios whose state is allocated
+    int total_dom = 0;
+    // typed views
+    int64_t *alloc_cpu = nullptr, *alloc_mem = nullptr, *alloc_eph = nullptr, *scalar_alloc = nullptr, *gpu_mem_total = nullptr;
+    int32_t *alloc_pods = nullptr, *node_class = nullptr, *gpu_cnt = nullptr, *topo_dom = nullptr;
+    int64_t *i_req_cpu = nullptr, *i_req_mem = nullptr, *i_req_eph = nullptr, *i_nz_cpu = nullptr, *i_nz_mem = nullptr,
+            *i_scalar_req = nullptr, *i_gpu_used = nullptr;
+    int32_t* i_npods = nullptr;
+    uint64_t* static_mask = nullptr; uint8_t* static_reason = nullptr; int64_t* simon_raw = nullptr;
+    int32_t *term_key = nullptr, *term_dom_off = nullptr, *anti_off = nullptr, *anti_idx = nullptr, *match_off = nullptr,
+            *match_idx = nullptr;
+    WidePod* pods = nullptr;
+    // state
+    int64_t *st_req_cpu = nullptr, *st_req_mem = nullptr, *st_req_eph = nullptr, *st_nz_cpu = nullptr, *st_nz_mem = nullptr,
+            *st_scalar = nullptr, *st_gpu = nullptr;
+    int32_t *st_npods = nullptr, *st_cnt = nullptr;
+    void release();
+};
+
+// staging / launching (simon_wide.hip)
+int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string& err);
+int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t* h_perm_unused, int S,
+             const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
+             int32_t* d_place, hipStream_t st, std::string& err);
+int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
+                 uint16_t* fail_codes, int32_t max_failed, int T, hipStream_t st, std::string& err);
+
+}  // namespace simon

@@ -1,0 +1,96 @@
+"""Test-side loader of the CPU oracle (oracle/libsimon_oracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from open_simulator_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+class OQuantity(C.Structure):
+    _fields_ = [("value", C.c_int64), ("scale", C.c_int32)]
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(ORACLE_DIR, "libsimon_oracle.so")
+    src = os.path.join(ORACLE_DIR, "simon_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    lib = C.CDLL(so)
+    p32, p64, pu16 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint16)
+    lib.simon_oracle_run.restype = C.c_int
+    lib.simon_oracle_run.argtypes = [C.POINTER(capi.NodesSoA), C.POINTER(capi.PodsSoA), C.POINTER(capi.ClassTables),
+                                     C.POINTER(capi.Scenario), C.c_int32, p32, C.c_int32, C.POINTER(capi.BatchOut),
+                                     C.c_int32, p32, pu16, C.c_int32, p32]
+    lib.simon_oracle_score_pod.restype = C.c_int
+    lib.simon_oracle_score_pod.argtypes = [C.POINTER(capi.NodesSoA), C.POINTER(capi.PodsSoA),
+                                           C.POINTER(capi.ClassTables), C.c_int32, C.c_int32, p64, p64, p64, p64, p64]
+    lib.simon_oracle_min_plan.restype = C.c_int
+    lib.simon_oracle_min_plan.argtypes = [C.POINTER(capi.NodesSoA), C.POINTER(capi.Scenario), C.c_int32,
+                                          C.POINTER(capi.BatchOut), C.c_int32, C.c_int32, C.POINTER(capi.Plan)]
+    lib.simon_oracle_simon_raw.restype = C.c_int64
+    lib.simon_oracle_simon_raw.argtypes = [C.POINTER(OQuantity), C.POINTER(OQuantity), C.c_int32, C.c_int32]
+    lib.simon_oracle_splitmix64.restype = C.c_uint64
+    lib.simon_oracle_splitmix64.argtypes = [C.POINTER(C.c_uint64)]
+    lib.simon_oracle_gen_nodes.argtypes = [C.c_uint64, C.c_int32, C.c_int32, p64, p64, p32, p32]
+    lib.simon_oracle_gen_pods.argtypes = [C.c_uint64, C.c_int32, p64, p64]
+    _LIB = lib
+    return lib
+
+
+def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0):
+    """Run scenarios on the oracle; returns BatchResult (+ (n_failed, failed_pods, codes) when explaining)."""
+    lib = load()
+    prob.normalise()
+    scen = capi.scenarios_array(scen)
+    orders = np.ascontiguousarray(orders, np.int32).reshape(-1, prob.n_pods)
+    res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement)
+    out = res.c_out()
+    n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
+    if explain_scenario >= 0:
+        nmax = int(scen[explain_scenario, 0])
+        failed = np.full(max_failed, -1, np.int32)
+        codes = np.zeros((max_failed, nmax), np.uint16)
+        nf = C.c_int32(0)
+        rc = lib.simon_oracle_run(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
+                                  len(scen), capi._ptr(orders, C.c_int32), orders.shape[0], C.byref(out),
+                                  explain_scenario, capi._ptr(failed, C.c_int32), capi._ptr(codes, C.c_uint16),
+                                  max_failed, C.byref(nf))
+        assert rc == 0, rc
+        k = min(nf.value, max_failed)
+        return res, (nf.value, failed[:k], codes[:k])
+    rc = lib.simon_oracle_run(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
+                              len(scen), capi._ptr(orders, C.c_int32), orders.shape[0], C.byref(out), -1, None, None,
+                              0, None)
+    assert rc == 0, rc
+    return res
+
+
+def score_pod(prob: capi.Problem, n_nodes: int, pod: int):
+    lib = load()
+    prob.normalise()
+    n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
+    arrs = [np.zeros(n_nodes, np.int64) for _ in range(5)]
+    best = lib.simon_oracle_score_pod(C.byref(n), C.byref(p), C.byref(t), n_nodes, pod,
+                                      *[capi._ptr(a, C.c_int64) for a in arrs])
+    return best, dict(zip(["feasible", "la", "ba", "sn", "total"], arrs))
+
+
+def min_plan(prob: capi.Problem, scen, res: capi.BatchResult, max_cpu=100, max_mem=100) -> capi.Plan:
+    lib = load()
+    scen = capi.scenarios_array(scen)
+    n = prob.c_nodes()
+    out = res.c_out()
+    plan = capi.Plan()
+    rc = lib.simon_oracle_min_plan(C.byref(n), scen.ctypes.data_as(C.POINTER(capi.Scenario)), len(scen),
+                                   C.byref(out), max_cpu, max_mem, C.byref(plan))
+    assert rc == 0
+    return plan

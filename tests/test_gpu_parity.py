@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import randprob
+from open_simulator_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(prob, scen, orders, env=None, want_placement=True):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders, want_placement)
+            st = ctx.stats()
+            return res, st.kernel_variant
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def assert_same(a: capi.BatchResult, b: capi.BatchResult):
+    assert a.unscheduled.tolist() == b.unscheduled.tolist()
+    assert a.used_cpu.tolist() == b.used_cpu.tolist()
+    assert a.used_mem.tolist() == b.used_mem.tolist()
+    if a.placement is not None and b.placement is not None:
+        bad = np.argwhere(a.placement != b.placement)
+        assert len(bad) == 0, f"{len(bad)} placements differ, first (scenario,pod)={bad[0].tolist()}: " \
+                              f"{a.placement[tuple(bad[0])]} vs {b.placement[tuple(bad[0])]}"
+
+
+def test_library_loads_and_sees_device():
+    lib = capi.load_library()
+    assert lib.simon_hip_version() == capi.ABI_VERSION
+    assert lib.simon_hip_device_count() >= 1
+
+
+def test_known_answer_vector_on_gpu():
+    from test_oracle import kav_problem
+    prob, _ = kav_problem()
+    res, variant = run_gpu(prob, [[2, 0]], np.arange(2)[None])
+    assert variant == capi.KERNEL_NARROW
+    assert res.placement.tolist() == [[0, 0]] and res.unscheduled.tolist() == [0]
+
+
+@pytest.mark.parametrize("homogeneous", [False, True])
+def test_config2_single_scenario(homogeneous):
+    prob, scen, orders = synth.config2(homogeneous)
+    ref = O.run(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_NARROW
+    assert_same(res, ref)
+
+
+@pytest.mark.parametrize("rcp", ["0", "1"])
+def test_config3_full_size_subset(rcp):
+    """10k pods x 488..1511 nodes: 4 orders x 6 node counts at full size, every placement compared."""
+    prob, scen, orders = synth.config3()
+    pick = [0, 1, 2, 3, 4 * 7 + 1, 4 * 100, 4 * 300 + 2, 4 * 511 + 3, 4 * 512, 4 * 800 + 1, 4 * 1023 + 2, 4 * 1023 + 3]
+    sub = scen[pick]
+    ref = O.run(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders, env={"SIMON_RCP_DIV": rcp})
+    assert variant == capi.KERNEL_NARROW
+    assert_same(res, ref)
+
+
+def test_config3_homogeneous_ties():
+    """All nodes identical: almost every pod ties on score, the first-max rule decides everything."""
+    prob, scen, orders = synth.config3(n_counts=64, n_orders=4, n_pods=4000, n_het=100, homogeneous=True)
+    sub = scen[::9]
+    assert_same(run_gpu(prob, sub, orders)[0], O.run(prob, sub, orders))
+
+
+@pytest.mark.parametrize("wg", ["64", "128", "256", "512"])
+def test_workgroup_shapes(wg):
+    prob, scen, orders = synth.config3(n_counts=40, n_orders=3, n_pods=1500, n_het=90)
+    sub = scen[::5]
+    assert_same(run_gpu(prob, sub, orders, env={"SIMON_WG": wg})[0], O.run(prob, sub, orders))
+
+
+NARROW_FEATURES = [
+    dict(), dict(nz_differs=True), dict(init_state=True, nz_differs=True), dict(static_mask=True),
+    dict(presets=True), dict(gates=True, presets=True), dict(zero_pods=True, nz_differs=True), dict(tight_pods=True),
+    dict(odd_units=True), dict(static_mask=True, init_state=True, presets=True, gates=True, tight_pods=True, zero_pods=True,
+                               nz_differs=True),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(NARROW_FEATURES)))
+@pytest.mark.parametrize("force_wide", ["0", "1"])
+def test_random_cpu_mem_features(idx, force_wide):
+    feat = NARROW_FEATURES[idx]
+    for seed in range(3):
+        prob = randprob.rand_problem(100 * idx + seed, N=70 + 37 * seed, P=400, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=8)
+        ref = O.run(prob, scen, orders)
+        res, variant = run_gpu(prob, scen, orders, env={"SIMON_FORCE_WIDE": force_wide})
+        if force_wide == "1":
+            assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+
+
+WIDE_FEATURES = [
+    dict(eph=True), dict(scalars=2), dict(gpu=True), dict(anti=True), dict(gpu=True, init_state=True),
+    dict(eph=True, scalars=3, gpu=True, anti=True, static_mask=True, init_state=True, presets=True, gates=True,
+         nz_differs=True, zero_pods=True, tight_pods=True),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(WIDE_FEATURES)))
+def test_random_wide_features(idx):
+    feat = WIDE_FEATURES[idx]
+    for seed in range(3):
+        prob = randprob.rand_problem(1000 + 100 * idx + seed, N=50 + 41 * seed, P=350, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=6)
+        ref = O.run(prob, scen, orders)
+        res, variant = run_gpu(prob, scen, orders)
+        assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+
+
+def test_gpushare_example_and_hand_cases_on_gpu():
+    from test_oracle import gpushare_problem
+    prob = gpushare_problem()
+    assert_same(run_gpu(prob, [[2, 0]], np.arange(9)[None])[0], O.run(prob, [[2, 0]], np.arange(9)[None]))
+
+
+def test_explain_codes_match_oracle():
+    prob = randprob.rand_problem(7, N=24, P=300, eph=True, scalars=2, gpu=True, anti=True, static_mask=True,
+                                 tight_pods=True)
+    scen, orders = randprob.rand_scenarios(7, prob, S=2)
+    ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=16)
+    assert nf > 0
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        n, f2, c2 = ctx.explain(int(scen[0, 0]), orders[scen[0, 1]], max_failed=16)
+    assert n == nf and f2.tolist() == failed.tolist()
+    assert (c2 == codes).all()
+
+
+def test_min_plan_matches_oracle():
+    prob, scen, orders = synth.config3(n_counts=24, n_orders=2, n_pods=2500, n_het=110)
+    ref = O.run(prob, scen, orders, want_placement=False)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders, want_placement=False)
+        assert_same(res, ref)
+        for caps in ((100, 100), (60, 100), (100, 50), (1, 1)):
+            a, b = ctx.min_plan(*caps), O.min_plan(prob, scen, ref, *caps)
+            assert a.as_dict() == b.as_dict(), caps
+
+
+def test_size_independent_properties_full_batch():
+    """Whole config-3 batch (4096 scenarios): properties that hold without the oracle."""
+    prob, scen, orders = synth.config3()
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(want_placement=True)
+        res = ctx.fetch(want_placement=False)
+        total_cpu, total_mem = int(prob.req_cpu.sum()), int(prob.req_mem.sum())
+        full = res.unscheduled == 0
+        assert full.any()
+        assert (res.used_cpu[full] == total_cpu).all() and (res.used_mem[full] == total_mem).all()
+        assert (res.used_cpu <= total_cpu).all()
+        for s in (0, 1, 2047, 4095):
+            pl = ctx.fetch_placement(s)
+            n = scen[s, 0]
+            placed = pl >= 0
+            assert (pl[placed] < n).all() and int((pl == capi.UNSCHEDULED).sum()) == res.unscheduled[s]
+            assert (np.bincount(pl[placed], weights=prob.req_cpu[placed], minlength=n) <= prob.alloc_cpu[:n]).all()
+            assert (np.bincount(pl[placed], weights=prob.req_mem[placed], minlength=n) <= prob.alloc_mem[:n]).all()
+            assert res.used_cpu[s] == int(prob.req_cpu[placed].sum())
+        # idempotence: a second run of the loaded batch gives identical results
+        ctx.run_loaded(want_placement=False)
+        again = ctx.fetch(want_placement=False)
+        assert_same(again, res)
+
+
+def test_errors_are_reported_not_thrown():
+    prob, scen, orders = synth.config2()
+    with capi.Context(0) as ctx:
+        with pytest.raises(capi.SimonError):
+            ctx.problem = prob
+            ctx.load_scenarios(scen, orders)        # nothing loaded yet
+        ctx.load_problem(prob)
+        with pytest.raises(capi.SimonError):
+            ctx.run_batch([[prob.n_nodes + 1, 0]], orders)
+        with pytest.raises(capi.SimonError):
+            ctx.run_batch([[5, 3]], orders)
