@@ -21,6 +21,15 @@
 #include <vector>
 
 namespace simon {
+struct PodRowF { double req_c, req_m, nz_c, nz_m; int32_t cls, preset, gate; uint32_t flags; };
+struct FastScalars { int32_t mask_words, Cn, Cp, P, S; uint64_t g_cpu, g_mem; };
+struct FastLaunch {
+    const uint32_t *a_cpu, *a_mem; const int32_t *a_pods, *ncls; const uint32_t *i_rq_cpu, *i_rq_mem, *i_nz_cpu, *i_nz_mem;
+    const int32_t* i_npods; const PodRowF* pods; const int32_t* orders; const ScenarioDesc* scen; const int32_t* perm;
+    const uint64_t* static_mask; const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
+    int32_t* placement; FastScalars sc;
+};
+hipError_t launch_fast(const FastLaunch& a, int T, int slots, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
 hipError_t launch_narrow(const NarrowArgs& a, int T, int slots, bool has_mask, bool rcp_div, size_t lds_bytes,
                          hipStream_t st);
 }  // namespace simon
@@ -67,10 +76,13 @@ struct simon_ctx : simon::HostInputs {
     uint64_t g_cpu = 1, g_mem = 1;
     bool rcp_div = true;
     int force_T = 0;  // env SIMON_WG
+    bool force_v1 = false;  // env SIMON_NARROW_V1: use simon_narrow.hip even when simon_fast.hip applies
     // ---- device buffers ----
     DevBuf<uint32_t> d_a_cpu, d_a_mem, d_i_rq_cpu, d_i_rq_mem, d_i_nz_cpu, d_i_nz_mem;
     DevBuf<int32_t> d_a_pods, d_ncls, d_i_npods, d_raw32;
     DevBuf<PodRowN> d_podsN;
+    DevBuf<PodRowF> d_podsF;
+    bool fast_ok = false, nzeq = false;  // simon_fast.hip eligibility
     DevBuf<uint64_t> d_mask;
     DevBuf<int64_t> d_prefix_cpu, d_prefix_mem;
     WideDevice wide;
@@ -184,6 +196,20 @@ int stage_narrow(simon_ctx* c) {
     }
     std::vector<int32_t> raw32(c->simon_raw.begin(), c->simon_raw.end());
     hipStream_t st = c->stream;
+    // simon_fast.hip: <= 32 node classes, no zero-capacity node; NZEQ when NonZeroRequested == Requested everywhere
+    c->fast_ok = c->Cn <= 32 && (size_t)c->Cp * c->Cn * 8 <= 48 * 1024;
+    c->nzeq = true;
+    for (int j = 0; j < N; ++j) {
+        if (a_cpu[j] == 0 || a_mem[j] == 0) c->fast_ok = false;
+        if (rqc[j] != nzc[j] || rqm[j] != nzm[j]) c->nzeq = false;
+    }
+    std::vector<PodRowF> rowsF(P);
+    for (int p = 0; p < P; ++p) {
+        const PodRowN& r = rows[p];
+        rowsF[p] = PodRowF{(double)r.req_cpu, (double)r.req_mem, (double)r.nz_cpu, (double)r.nz_mem, r.cls, r.preset, r.gate, r.flags};
+        if (r.req_cpu != r.nz_cpu || r.req_mem != r.nz_mem) c->nzeq = false;
+    }
+    HIP_TRY(c, c->d_podsF.upload(rowsF, st));
     HIP_TRY(c, c->d_a_cpu.upload(a_cpu, st));
     HIP_TRY(c, c->d_a_mem.upload(a_mem, st));
     HIP_TRY(c, c->d_i_rq_cpu.upload(rqc, st));
@@ -277,6 +303,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     }
     if (const char* e = getenv("SIMON_WG")) c->force_T = atoi(e);
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     return c;
 }
 
@@ -436,7 +463,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     HIP_TRY(c, hipSetDevice(c->device));
     const int S = c->S, P = c->P;
     if (want_placement) HIP_TRY(c, c->d_place.ensure((size_t)S * P));
-    int T = 0, slots = 0;
+    int T = 0, slots = 0, variant_used = c->variant;
     size_t lds = 0;
     if (c->variant == SIMON_KERNEL_NARROW) {
         // workgroup shape: T = 256 (4 waves) with up to 8 node slots per lane covers 2048 nodes;
@@ -448,21 +475,37 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         }
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
-        lds = ((size_t)c->Cp * c->Cn * sizeof(int32_t) + 15) & ~(size_t)15;
-        NarrowArgs a{};
-        a.a_cpu = c->d_a_cpu.p; a.a_mem = c->d_a_mem.p; a.a_pods = c->d_a_pods.p; a.ncls = c->d_ncls.p;
-        a.i_rq_cpu = c->d_i_rq_cpu.p; a.i_rq_mem = c->d_i_rq_mem.p; a.i_nz_cpu = c->d_i_nz_cpu.p; a.i_nz_mem = c->d_i_nz_mem.p;
-        a.i_npods = c->d_i_npods.p;
-        a.pods = c->d_podsN.p; a.orders = c->d_orders.p; a.scen = c->d_scen.p; a.perm = c->d_perm.p;
-        a.static_mask = c->has_mask ? c->d_mask.p : nullptr;
-        a.simon_raw = c->d_raw32.p;
-        a.mask_words = (c->N + 63) / 64; a.Cn = c->Cn; a.Cp = c->Cp; a.P = P; a.S = S;
-        a.g_cpu = c->g_cpu; a.g_mem = c->g_mem;
-        a.unscheduled = c->d_unsched.p; a.used_cpu = c->d_used_cpu.p; a.used_mem = c->d_used_mem.p;
-        a.placement = want_placement ? c->d_place.p : nullptr;
-        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        HIP_TRY(c, launch_narrow(a, T, slots, c->has_mask, c->rcp_div, lds, c->stream));
-        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        if (c->fast_ok && !c->force_v1 && T >= 128) {
+            lds = ((size_t)c->Cp * c->Cn * 2 * sizeof(int32_t) + 15) & ~(size_t)15;
+            FastLaunch f{};
+            f.a_cpu = c->d_a_cpu.p; f.a_mem = c->d_a_mem.p; f.a_pods = c->d_a_pods.p; f.ncls = c->d_ncls.p;
+            f.i_rq_cpu = c->d_i_rq_cpu.p; f.i_rq_mem = c->d_i_rq_mem.p; f.i_nz_cpu = c->d_i_nz_cpu.p; f.i_nz_mem = c->d_i_nz_mem.p;
+            f.i_npods = c->d_i_npods.p; f.pods = c->d_podsF.p; f.orders = c->d_orders.p; f.scen = c->d_scen.p; f.perm = c->d_perm.p;
+            f.static_mask = c->has_mask ? c->d_mask.p : nullptr; f.simon_raw = c->d_raw32.p;
+            f.unscheduled = c->d_unsched.p; f.used_cpu = c->d_used_cpu.p; f.used_mem = c->d_used_mem.p;
+            f.placement = want_placement ? c->d_place.p : nullptr;
+            f.sc = FastScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, S, c->g_cpu, c->g_mem};
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_fast(f, T, slots, c->has_mask, c->nzeq, lds, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            variant_used = SIMON_KERNEL_NARROW_FAST;
+        } else {
+            lds = ((size_t)c->Cp * c->Cn * sizeof(int32_t) + 15) & ~(size_t)15;
+            NarrowArgs a{};
+            a.a_cpu = c->d_a_cpu.p; a.a_mem = c->d_a_mem.p; a.a_pods = c->d_a_pods.p; a.ncls = c->d_ncls.p;
+            a.i_rq_cpu = c->d_i_rq_cpu.p; a.i_rq_mem = c->d_i_rq_mem.p; a.i_nz_cpu = c->d_i_nz_cpu.p; a.i_nz_mem = c->d_i_nz_mem.p;
+            a.i_npods = c->d_i_npods.p;
+            a.pods = c->d_podsN.p; a.orders = c->d_orders.p; a.scen = c->d_scen.p; a.perm = c->d_perm.p;
+            a.static_mask = c->has_mask ? c->d_mask.p : nullptr;
+            a.simon_raw = c->d_raw32.p;
+            a.mask_words = (c->N + 63) / 64; a.Cn = c->Cn; a.Cp = c->Cp; a.P = P; a.S = S;
+            a.g_cpu = c->g_cpu; a.g_mem = c->g_mem;
+            a.unscheduled = c->d_unsched.p; a.used_cpu = c->d_used_cpu.p; a.used_mem = c->d_used_mem.p;
+            a.placement = want_placement ? c->d_place.p : nullptr;
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_narrow(a, T, slots, c->has_mask, c->rcp_div, lds, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        }
     } else {
         T = c->force_T ? c->force_T : (c->max_n <= 512 ? 256 : c->max_n <= 4096 ? 512 : 1024);
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -477,7 +520,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.kernel_ms = ms;
     c->stats.n_launches = 1;
-    c->stats.kernel_variant = c->variant;
+    c->stats.kernel_variant = variant_used;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;
     c->stats.lds_bytes = (int64_t)lds;

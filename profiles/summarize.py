@@ -13,7 +13,7 @@ def main(root):
         print("== kernel trace (rocprofv3 --kernel-trace --stats):", os.path.relpath(db, root))
         print(f"{'kernel':90s} {'calls':>6s} {'total_us':>14s} {'avg_us':>12s} {'pct':>7s}")
         for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-            print(f"{name[:90]:90s} {calls:6d} {total / 1e3:14.1f} {avg / 1e3:12.2f} {pct:7.2f}")
+            print(f"{name[:90]:90s} {calls:6d} {total:14.1f} {avg:12.2f} {pct:7.2f}")
         for r in con.execute("select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size "
                              "from kernels group by name"):
             print("   dispatch:", r[0][:70], dict(zip(["grid", "wg", "lds", "vgpr", "agpr", "sgpr", "scratch"], r[1:])))

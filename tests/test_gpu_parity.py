@@ -50,7 +50,7 @@ def test_known_answer_vector_on_gpu():
     from test_oracle import kav_problem
     prob, _ = kav_problem()
     res, variant = run_gpu(prob, [[2, 0]], np.arange(2)[None])
-    assert variant == capi.KERNEL_NARROW
+    assert variant in (capi.KERNEL_NARROW, capi.KERNEL_NARROW_FAST)
     assert res.placement.tolist() == [[0, 0]] and res.unscheduled.tolist() == [0]
 
 
@@ -59,19 +59,22 @@ def test_config2_single_scenario(homogeneous):
     prob, scen, orders = synth.config2(homogeneous)
     ref = O.run(prob, scen, orders)
     res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_NARROW_FAST
+    assert_same(res, ref)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NARROW_V1": "1"})
     assert variant == capi.KERNEL_NARROW
     assert_same(res, ref)
 
 
-@pytest.mark.parametrize("rcp", ["0", "1"])
-def test_config3_full_size_subset(rcp):
+@pytest.mark.parametrize("env", [{}, {"SIMON_NARROW_V1": "1", "SIMON_RCP_DIV": "0"}, {"SIMON_NARROW_V1": "1", "SIMON_RCP_DIV": "1"}])
+def test_config3_full_size_subset(env):
     """10k pods x 488..1511 nodes: 4 orders x 6 node counts at full size, every placement compared."""
     prob, scen, orders = synth.config3()
     pick = [0, 1, 2, 3, 4 * 7 + 1, 4 * 100, 4 * 300 + 2, 4 * 511 + 3, 4 * 512, 4 * 800 + 1, 4 * 1023 + 2, 4 * 1023 + 3]
     sub = scen[pick]
     ref = O.run(prob, sub, orders)
-    res, variant = run_gpu(prob, sub, orders, env={"SIMON_RCP_DIV": rcp})
-    assert variant == capi.KERNEL_NARROW
+    res, variant = run_gpu(prob, sub, orders, env=env)
+    assert variant == (capi.KERNEL_NARROW if env else capi.KERNEL_NARROW_FAST)
     assert_same(res, ref)
 
 
@@ -83,10 +86,23 @@ def test_config3_homogeneous_ties():
 
 
 @pytest.mark.parametrize("wg", ["64", "128", "256", "512"])
-def test_workgroup_shapes(wg):
+@pytest.mark.parametrize("v1", ["0", "1"])
+def test_workgroup_shapes(wg, v1):
     prob, scen, orders = synth.config3(n_counts=40, n_orders=3, n_pods=1500, n_het=90)
     sub = scen[::5]
-    assert_same(run_gpu(prob, sub, orders, env={"SIMON_WG": wg})[0], O.run(prob, sub, orders))
+    assert_same(run_gpu(prob, sub, orders, env={"SIMON_WG": wg, "SIMON_NARROW_V1": v1})[0], O.run(prob, sub, orders))
+
+
+def test_replica_runs_hit_the_score_cache():
+    """Pods grouped by request signature (what a Deployment's replicas look like): the fast kernel re-evaluates
+    only the node touched by the previous assume; results must still equal the oracle's."""
+    prob, scen, orders = synth.config3(n_counts=16, n_orders=4, n_pods=3000, n_het=60)
+    grouped = np.argsort(prob.pod_class, kind="stable").astype(np.int32)
+    orders = np.stack([grouped, grouped[::-1].copy(), orders[1], orders[2]])
+    ref = O.run(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_NARROW_FAST
+    assert_same(res, ref)
 
 
 NARROW_FEATURES = [
@@ -109,6 +125,10 @@ def test_random_cpu_mem_features(idx, force_wide):
         if force_wide == "1":
             assert variant == capi.KERNEL_WIDE
         assert_same(res, ref)
+        if force_wide == "0":
+            res, variant = run_gpu(prob, scen, orders, env={"SIMON_NARROW_V1": "1"})
+            assert variant in (capi.KERNEL_NARROW, capi.KERNEL_WIDE)   # odd_units (gcd 1) exceeds 31 bits -> WIDE
+            assert_same(res, ref)
 
 
 WIDE_FEATURES = [
