@@ -138,11 +138,11 @@ def main():
                                    f"{n_orders} pod orders = {S_total} scenarios ({S_local} per GPU)",
                        "scenarios_per_gpu": S_local, "pods": prob.n_pods, "node_pool": prob.n_nodes,
                        "placement_matrix": bool(args.placement),
-                       "kernel": {1: "narrow_v1", 2: "wide", 3: "narrow_fast"}.get(st.kernel_variant, "?"), "workgroup": st.workgroup_size,
+                       "kernel": {1: "narrow_v1", 2: "wide", 3: "narrow_fast", 4: "narrow_cache"}.get(st.kernel_variant, "?"), "workgroup": st.workgroup_size,
                        "slots_per_lane": st.slots_per_lane, "plan": best},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel"}.get(st.kernel_variant), "kernel_ms": round(k_ms, 3),
+                         "kernel": {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::cache_kernel"}.get(st.kernel_variant), "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg,
                          "note": "algorithmic bytes = sum_s P*(56*n_s+108) (SURVEY 8d); node state is register-"
                                  "resident, so this ratio is not bounded by 1 -- see DESIGN.md section 6 for the "

@@ -193,6 +193,7 @@ typedef struct simon_stats {
 #define SIMON_KERNEL_NARROW 1  /* cpu+mem+pods only, gcd-normalised 32-bit quantities, register-resident state */
 #define SIMON_KERNEL_WIDE 2    /* every feature, int64 quantities, state streamed from HBM/L2 */
 #define SIMON_KERNEL_NARROW_FAST 3 /* NARROW, second generation: scalarised control flow, fp64-resident state, score cache */
+#define SIMON_KERNEL_NARROW_CACHE 4 /* NARROW, third generation: one wave per scenario, (signature, node) score table in LDS */
 
 typedef struct simon_ctx simon_ctx;
 

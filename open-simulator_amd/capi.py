@@ -33,6 +33,7 @@ FAIL_GPUSHARE = 0x1000
 KERNEL_NARROW = 1
 KERNEL_WIDE = 2
 KERNEL_NARROW_FAST = 3
+KERNEL_NARROW_CACHE = 4
 
 _p64 = C.POINTER(C.c_int64)
 _p32 = C.POINTER(C.c_int32)

@@ -1,0 +1,380 @@
+// simon_cache.hip -- NARROW kernel, third generation: one WAVE = one capacity-planning scenario,
+// per-(pod signature, node) score table resident in LDS.
+//
+// Observation ("further lever"): a scheduling cycle changes ONE node.  For a pod
+// stream drawn from K <= 64 distinct request signatures (replicas of workloads), the pair
+// (feasible?, LeastAllocated + BalancedAllocation) of every (signature, node) is therefore a
+// table with K x n one-byte entries of which only one COLUMN (K bytes) changes per cycle:
+//   * filter + score of a pod  = read ONE ROW of the table (n bytes, ds_read_b128: 16 nodes per
+//     lane), packed 16-bit max tree, one DPP wave reduction            -> findNodesThatFitPod +
+//     prioritizeNodes + selectHost (V/core/generic_scheduler.go:131-209);
+//   * assume (V/scheduler.go:371 -> NodeInfo.AddPod, V/framework/types.go:482-508) = lane k
+//     re-evaluates signature k on the touched node with EXACTLY the arithmetic of
+//     simon_fast.hip (same fp64 sequences => same bits) and stores one byte.
+// Nodes are laid out class-major inside a scenario (stable in canonical order, every class
+// segment padded to 16) so that the 16 nodes of a lane share their Simon node class: the
+// normalised Simon/Open-Gpu-Share term (pkg/simulator/plugin/simon.go:76-101) is then one add per
+// lane AFTER the in-lane max.  Ties are broken on the canonical node index carried in the key,
+// i.e. determinised selectHost = first maximum in nodeTree.list() order.
+// The per-signature count of feasible nodes per node class is maintained incrementally
+// (feasibility only ever decreases: Requested grows, free pod slots shrink), which replaces the
+// phase-A reduction of the earlier generations by one LDS read + ballot.
+//
+// No barriers (one wave), no global traffic in the loop except the scalar pod-row stream and one
+// coalesced 256-byte placement store per 64 cycles.
+//
+// Eligibility (host, simon_hip.hip): NARROW preconditions + K <= 64 signatures, <= 64 node
+// shapes, Cn <= 32, no zero-capacity node, padded scenario size <= 2047, LDS <= 160 KiB.
+#include "simon_cache.h"
+
+#include <algorithm>
+
+namespace simon {
+
+__device__ __forceinline__ int la_term_c(double r, double rc100) {   // == la_term_f of simon_fast.hip
+    const double C = 100.0 + 0x1.0p-33;
+    return (int)__builtin_fma(-r, rc100, C);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
+}
+
+// LDS carve (all offsets multiples of 16)
+struct Carve {
+    int tab, state, nz, canon, cnt, raw, sn2, sig, shape, seg, tmp, total;
+};
+__host__ __device__ inline Carve carve(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+    auto al = [](int x) { return (x + 15) & ~15; };
+    Carve c;
+    int o = 0;
+    c.tab = o; o += al(K * stride);
+    c.state = o; o += ni_max * 16;
+    c.nz = o; o += nzeq ? 0 : al(ni_max * 8);
+    c.canon = o; o += al(ni_max * 2);
+    c.cnt = o; o += Cn * 64 * 4;
+    c.raw = o; o += al(Cp * Cn * 4);
+    c.sn2 = o; o += al(Cp * Cn * 4);
+    c.sig = o; o += K * 48;
+    c.shape = o; o += n_shapes * 48;
+    c.seg = o; o += 32 * 4;
+    c.tmp = o; o += 32 * 4;
+    c.total = o;
+    return c;
+}
+
+template <int SLOTS, bool HAS_MASK, bool NZEQ>
+__global__ __launch_bounds__(64) void cache_kernel(
+    const int32_t* __restrict__ ncls, const int32_t* __restrict__ rank, const int32_t* __restrict__ shape_of,
+    const int32_t* __restrict__ a_pods, const uint32_t* __restrict__ i_rq_cpu, const uint32_t* __restrict__ i_rq_mem,
+    const uint32_t* __restrict__ i_nz_cpu, const uint32_t* __restrict__ i_nz_mem, const int32_t* __restrict__ i_npods,
+    const int32_t* __restrict__ clsprefix, const SigRow* __restrict__ sigs, const ShapeRow* __restrict__ shapes,
+    const PodRowC* __restrict__ pods, const int32_t* __restrict__ orders, const ScenarioDesc* __restrict__ scen,
+    const int32_t* __restrict__ perm, const uint64_t* __restrict__ static_mask, const int32_t* __restrict__ simon_raw,
+    int32_t* __restrict__ unscheduled, int64_t* __restrict__ used_cpu, int64_t* __restrict__ used_mem,
+    int32_t* __restrict__ place_step, const CacheScalars sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K, stride = sc.stride;
+    const Carve cv = carve(K, stride, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ);
+    unsigned char* s_tab = smem + cv.tab;
+    uint4* s_state = (uint4*)(smem + cv.state);      // {Requested cpu, Requested mem, free pod slots, shape | class<<16}
+    uint2* s_nz = (uint2*)(smem + cv.nz);            // NonZeroRequested {cpu, mem} (only when !NZEQ)
+    unsigned short* s_canon = (unsigned short*)(smem + cv.canon);
+    int* s_cnt = (int*)(smem + cv.cnt);              // [Cn][64]: feasible nodes of class d for signature k
+    int* s_raw = (int*)(smem + cv.raw);
+    int* s_sn2 = (int*)(smem + cv.sn2);
+    const SigRow* s_sig = (const SigRow*)(smem + cv.sig);
+    const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);
+    int* s_seg = (int*)(smem + cv.seg);
+    int* s_tmp = (int*)(smem + cv.tmp);
+
+    const int lane = threadIdx.x;
+    const int s = perm[blockIdx.x];
+    const int n = scen[s].n_nodes;
+    const int32_t* __restrict__ order = orders + (size_t)scen[s].order_id * P;
+
+    // ---- prologue 1: clear, tables -> LDS ----------------------------------------------------
+    for (int i = lane; i < cv.cnt / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);   // tab, state, nz, canon
+    for (int i = lane; i < Cn * 64; i += 64) s_cnt[i] = 0;
+    for (int i = lane; i < Cp * Cn; i += 64) s_raw[i] = simon_raw[i];
+    for (int i = lane; i < K * 12; i += 64) ((int*)(smem + cv.sig))[i] = ((const int*)sigs)[i];
+    for (int i = lane; i < sc.n_shapes * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
+    __syncthreads();
+    for (int i = lane; i < sc.ni_max; i += 64) s_canon[i] = 0xFFFFu;
+    // class segments: count of class-d nodes among the first n canonical nodes, padded to 16
+    int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
+    int pad_d = (cnt_d + 15) & ~15;
+    int incl = pad_d;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane < 32) s_seg[lane] = incl - pad_d;
+    const int ni = __builtin_amdgcn_readlane(incl, 31);               // padded scenario size (lanes >= Cn add 0)
+    const unsigned bits_all = (unsigned)__ballot(cnt_d > 0);
+    __syncthreads();
+    // ---- prologue 2: scatter node rows into the class-major layout --------------------------
+    for (int j = lane; j < n; j += 64) {
+        const int d = ncls[j];
+        const int pos = s_seg[d] + rank[j];
+        s_state[pos] = make_uint4(i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j]),
+                                  (unsigned)shape_of[j] | ((unsigned)d << 16));
+        if (!NZEQ) s_nz[pos] = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
+        s_canon[pos] = (unsigned short)j;
+    }
+    // sn2_full[c][d] = 2 * NormalizeScore(raw[c][d]) over the node classes present (simon.go:76-101)
+    for (int i = lane; i < Cp * Cn; i += 64) {
+        const int c = i / Cn;
+        long long lo = 0x7fffffffll, hi = -0x7fffffffll;
+        for (int d = 0; d < Cn; ++d)
+            if ((bits_all >> d) & 1u) {
+                const long long r = s_raw[c * Cn + d];
+                lo = r < lo ? r : lo;
+                hi = r > hi ? r : hi;
+            }
+        const long long range = hi - lo;
+        s_sn2[i] = (range > 0) ? (int)(2 * ((((long long)s_raw[i] - lo) * 100) / range)) : 0;
+    }
+    __syncthreads();
+
+    // this lane's signature (lane k evaluates signature k on a touched node)
+    const int kk = lane < K ? lane : 0;
+    const double my_req_c = s_sig[kk].req_c, my_req_m = s_sig[kk].req_m;
+    const double my_nz_c = s_sig[kk].nz_c, my_nz_m = s_sig[kk].nz_m;
+    const bool my_zero = s_sig[kk].flags & 1u;
+    const int my_cls = s_sig[kk].cls;
+    unsigned char* my_col = s_tab + (size_t)kk * stride;
+
+    // (feasible, LeastAllocated + BalancedAllocation) of signature `lane` on a node: byte = 0 when
+    // NodeResourcesFit fails (fit.go:230-302), else 1 + score.  Same fp64 sequences as
+    // simon_fast.hip::eval_slot.
+    auto eval_node = [&](double rq_c, double rq_m, double nzs_c, double nzs_m, int freep, const ShapeRow& sh) -> unsigned {
+        const double t_c = rq_c + my_req_c, t_m = rq_m + my_req_m;
+        const bool res_ok = (sh.cap_c >= t_c) && (sh.cap_m >= t_m);
+        const bool ok = (freep >= 1) && (my_zero || res_ok);
+        // resource_allocation.go:91-98: requested = NonZeroRequested + pod non-zero request
+        const double r_c = NZEQ ? t_c : nzs_c + my_nz_c;
+        const double r_m = NZEQ ? t_m : nzs_m + my_nz_m;
+        const bool ge_c = r_c >= sh.cap_c, ge_m = r_m >= sh.cap_m;
+        const int la_c = ge_c ? 0 : la_term_c(r_c, sh.rc100_c);           // least_allocated.go:108-117
+        const int la_m = ge_m ? 0 : la_term_c(r_m, sh.rc100_m);
+        const double cf = div_by_rcp(r_c, sh.cap_c, sh.rc_c);             // balanced_allocation.go:82-119
+        const double mf = div_by_rcp(r_m, sh.cap_m, sh.rc_m);
+        const int bs = (int)((1.0 - __builtin_fabs(cf - mf)) * 100.0);
+        const int base = ((la_c + la_m) >> 1) + ((ge_c || ge_m) ? 0 : bs);
+        return ok ? (unsigned)(base + 1) : 0u;
+    };
+
+    // ---- prologue 3: fill the table (every real node, every signature) ----------------------
+    for (int p = 0; p < ni; ++p) {
+        const unsigned cj = s_canon[p];
+        if (cj == 0xFFFFu) continue;                                   // padding: stays infeasible
+        const uint4 st = s_state[p];
+        const ShapeRow sh = s_shape[st.w & 0xFFFFu];
+        double nzc = 0.0, nzm = 0.0;
+        if (!NZEQ) { const uint2 z = s_nz[p]; nzc = (double)z.x; nzm = (double)z.y; }
+        unsigned b = eval_node((double)st.x, (double)st.y, nzc, nzm, (int)st.z, sh);
+        if (HAS_MASK) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node)
+            const uint64_t w = static_mask[(size_t)my_cls * sc.mask_words + (cj >> 6)];
+            b = ((w >> (cj & 63)) & 1ull) ? b : 0u;
+        }
+        if (lane < K) {
+            my_col[p] = (unsigned char)b;
+            if (b) s_cnt[(st.w >> 16) * 64 + lane] += 1;
+        }
+    }
+    __syncthreads();
+
+    // node class of this lane's 16-node blocks (class segments are multiples of 16)
+    const int nblk = ni >> 4;
+    int ncl4[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int b = q * 64 + lane;
+        ncl4[q] = (b < nblk) ? (int)(s_state[b * 16].w >> 16) * 4 : 0;
+    }
+
+    int unsched = 0, plreg = 0;
+    int32_t* __restrict__ place = place_step ? place_step + (size_t)s * P : nullptr;
+
+    int pid_next = P > 0 ? order[0] : 0;
+    PodRowC row_next = pods[pid_next];
+    int pid_next2 = P > 1 ? order[1] : 0;
+
+    for (int i = 0; i < P; ++i) {
+        const PodRowC row = row_next;
+        pid_next = pid_next2;
+        row_next = pods[pid_next];
+        pid_next2 = (i + 2 < P) ? order[i + 2] : 0;
+
+        int res, pstar = -1;
+        if (row.gate >= n) {
+            res = -2;                                                  // pod not part of this scenario
+        } else if (row.preset >= 0) {                                  // addPodToCache path (V/eventhandlers.go:223-236)
+            res = row.preset;
+            pstar = s_seg[ncls[row.preset]] + rank[row.preset];
+        } else {
+            const int k = row.sig;
+            // -------- which node classes still have a feasible node for this signature --------
+            const int cvv = (lane < Cn) ? s_cnt[lane * 64 + k] : 0;
+            const unsigned bits = (unsigned)__ballot(cvv > 0);
+            if (bits == 0u) {                                          // FitError: pod deleted, state unchanged
+                ++unsched;
+                res = -1;
+            } else {
+                // -------- SimonPlugin/GpuSharePlugin NormalizeScore row (x2: both plugins) ----
+                const int* snrow;
+                if (bits == bits_all) {
+                    snrow = s_sn2 + row.cls * Cn;
+                } else {
+                    const int c = lane < Cn ? lane : 0;
+                    const int rawc = s_raw[row.cls * Cn + c];
+                    const bool inb = (lane < Cn) && ((bits >> c) & 1u);
+                    const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
+                    const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
+                    const int range = hi - lo;
+                    const double rr = range ? 1.0 / (double)range : 0.0;
+                    const int sn = range ? (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
+                    if (lane < 32) s_tmp[lane] = inb ? 2 * sn : 0;
+                    __builtin_amdgcn_wave_barrier();
+                    snrow = s_tmp;
+                }
+                // -------- row scan: 16 nodes per lane and slot ---------------------------------
+                const uint4* rowp = (const uint4*)(s_tab + (size_t)k * stride);
+                unsigned key = 0;
+#pragma unroll
+                for (int q = 0; q < SLOTS; ++q) {
+                    const int b = q * 64 + lane;
+                    if (SLOTS == 1 || q * 64 < nblk) {
+                        const uint4 R = rowp[b < nblk ? b : 0];
+                        // key16 = byte << 4 | (15 - position): max = best base score, first position on ties
+                        const unsigned M8 = 0x00FF00FFu;
+#define SIMON_LO(w, q4) ((((w) & M8) << 4) | (unsigned)((15 - (q4)) | ((15 - ((q4) + 2)) << 16)))
+#define SIMON_HI(w, q4) (((((w) >> 8) & M8) << 4) | (unsigned)((15 - ((q4) + 1)) | ((15 - ((q4) + 3)) << 16)))
+                        unsigned m0 = pkmax(SIMON_LO(R.x, 0), SIMON_HI(R.x, 0));
+                        unsigned m1 = pkmax(SIMON_LO(R.y, 4), SIMON_HI(R.y, 4));
+                        unsigned m2 = pkmax(SIMON_LO(R.z, 8), SIMON_HI(R.z, 8));
+                        unsigned m3 = pkmax(SIMON_LO(R.w, 12), SIMON_HI(R.w, 12));
+#undef SIMON_LO
+#undef SIMON_HI
+                        m0 = pkmax(pkmax(m0, m1), pkmax(m2, m3));
+                        const unsigned m16 = max(m0 & 0xFFFFu, m0 >> 16);
+                        const unsigned M = m16 >> 4;                   // 0: no feasible node here; else 1 + LA + BA
+                        const int p = b * 16 + 15 - (int)(m16 & 15u);
+                        const unsigned canon = s_canon[b < nblk ? p : 0];
+                        const int sn2 = *(const int*)((const char*)snrow + ncl4[q]);
+                        // total = BA + LA + Simon + GpuShare (weights: registry.go:118-131, utils.go:321-333)
+                        const unsigned kq = ((M - 1u + (unsigned)sn2) << 22) | ((2047u - canon) << 11) | (unsigned)p;
+                        key = max(key, (M != 0u && b < nblk) ? kq : 0u);
+                    }
+                }
+                key = wave_max_u32(key);
+                pstar = (int)(key & 2047u);
+                res = (int)(2047u - ((key >> 11) & 2047u));           // first maximum in canonical order
+            }
+        }
+        // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column ---------
+        if (pstar >= 0) {
+            const SigRow& cur = s_sig[row.sig];
+            uint4 st = s_state[pstar];
+            st.x += (unsigned)cur.req_c;
+            st.y += (unsigned)cur.req_m;
+            st.z -= 1u;
+            double nzc = 0.0, nzm = 0.0;
+            if (!NZEQ) {
+                uint2 z = s_nz[pstar];
+                z.x += (unsigned)cur.nz_c;
+                z.y += (unsigned)cur.nz_m;
+                if (lane == 0) s_nz[pstar] = z;
+                nzc = (double)z.x; nzm = (double)z.y;
+            }
+            const unsigned old = my_col[pstar];
+            if (lane == 0) s_state[pstar] = st;
+            const ShapeRow sh = s_shape[st.w & 0xFFFFu];
+            unsigned nb = eval_node((double)st.x, (double)st.y, nzc, nzm, (int)st.z, sh);
+            nb = old ? nb : 0u;                                        // static mask / monotone infeasibility
+            if (lane < K && nb != old) {
+                my_col[pstar] = (unsigned char)nb;
+                if (!nb) s_cnt[(st.w >> 16) * 64 + lane] -= 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
+        plreg = ((i & 63) == lane) ? res : plreg;
+        if (place && (i & 63) == 63) place[(i & ~63) + lane] = plreg;
+    }
+    if (place && (P & 63) && lane < (P & 63)) place[(P & ~63) + lane] = plreg;
+
+    // ---- epilogue: sum of Requested over the scenario's nodes -------------------------------
+    long long uc = 0, um = 0;
+    for (int p = lane; p < ni; p += 64) { const uint4 st = s_state[p]; uc += st.x; um += st.y; }
+    uc = wave_sum_i64(uc);
+    um = wave_sum_i64(um);
+    if (lane == 0) {
+        unscheduled[s] = unsched;
+        used_cpu[s] = uc * (long long)sc.g_cpu;
+        used_mem[s] = um * (long long)sc.g_mem;
+    }
+}
+
+// placement[s][pod] = place_step[s][inv_order[order_id(s)][pod]]: gather (scattered reads hit L2,
+// stores coalesced)
+__global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restrict__ place_step,
+                                                        const int32_t* __restrict__ inv_orders,
+                                                        const ScenarioDesc* __restrict__ scen, int P,
+                                                        int32_t* __restrict__ placement) {
+    const int s = blockIdx.y;
+    const int32_t* __restrict__ inv = inv_orders + (size_t)scen[s].order_id * P;
+    const int32_t* __restrict__ src = place_step + (size_t)s * P;
+    int32_t* __restrict__ dst = placement + (size_t)s * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
+}
+
+template <int SLOTS, bool M, bool Z>
+static hipError_t launch_smz(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    auto kern = cache_kernel<SLOTS, M, Z>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.ncls, a.rank, a.shape_of, a.a_pods, a.i_rq_cpu,
+                       a.i_rq_mem, a.i_nz_cpu, a.i_nz_mem, a.i_npods, a.clsprefix, a.sigs, a.shapes, a.pods, a.orders,
+                       a.scen, a.perm, a.static_mask, a.simon_raw, a.unscheduled, a.used_cpu, a.used_mem, a.place_step,
+                       a.sc);
+    return hipGetLastError();
+}
+
+template <int SLOTS>
+static hipError_t launch_s(const CacheLaunch& a, int n_blocks, bool m, bool z, size_t lds, hipStream_t st) {
+    if (m) return z ? launch_smz<SLOTS, true, true>(a, n_blocks, lds, st) : launch_smz<SLOTS, true, false>(a, n_blocks, lds, st);
+    return z ? launch_smz<SLOTS, false, true>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, false>(a, n_blocks, lds, st);
+}
+
+size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+    return (size_t)carve(K, stride, ni_max, Cn, Cp, n_shapes, nzeq).total;
+}
+
+// n_blocks scenarios starting at perm offset `a.perm`
+hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    const int slots = (a.sc.ni_max / 16 + 63) / 64;
+    switch (slots) {
+        case 1: return launch_s<1>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
+        case 2: return launch_s<2>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
+                            int32_t* placement, hipStream_t st) {
+    if (S <= 0 || P <= 0) return hipSuccess;
+    const int bx = std::min(64, (P + 255) / 256);
+    for (int s0 = 0; s0 < S; s0 += 65535) {   // gridDim.y limit
+        const int ns = std::min(65535, S - s0);
+        hipLaunchKernelGGL(unpermute_kernel, dim3(bx, ns), dim3(256), 0, st, place_step + (size_t)s0 * P, inv_orders,
+                           scen + s0, P, placement + (size_t)s0 * P);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace simon

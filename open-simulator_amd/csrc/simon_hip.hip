@@ -11,12 +11,15 @@
 #include "../../include/simon_hip.h"
 #include "simon_device.h"
 #include "simon_wide.h"
+#include "simon_cache.h"
 
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <numeric>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -83,6 +86,17 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<PodRowN> d_podsN;
     DevBuf<PodRowF> d_podsF;
     bool fast_ok = false, nzeq = false;  // simon_fast.hip eligibility
+    // ---- simon_cache.hip (LDS score table, one wave per scenario) ----
+    bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
+    int n_sigs = 0, n_shapes = 0, max_bands = 6;
+    DevBuf<SigRow> d_sigs;
+    DevBuf<ShapeRow> d_shapes;
+    DevBuf<PodRowC> d_podsC;
+    DevBuf<int32_t> d_rank, d_shape_of, d_clsprefix, d_inv_orders, d_place_step;
+    std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn]; padded size of every loaded scenario
+    std::vector<int32_t> h_perm;
+    hipStream_t band_stream[8] = {};
+    hipEvent_t band_ev[8] = {}, fork_ev = nullptr;
     DevBuf<uint64_t> d_mask;
     DevBuf<int64_t> d_prefix_cpu, d_prefix_mem;
     WideDevice wide;
@@ -209,6 +223,58 @@ int stage_narrow(simon_ctx* c) {
         rowsF[p] = PodRowF{(double)r.req_cpu, (double)r.req_mem, (double)r.nz_cpu, (double)r.nz_mem, r.cls, r.preset, r.gate, r.flags};
         if (r.req_cpu != r.nz_cpu || r.req_mem != r.nz_mem) c->nzeq = false;
     }
+    // simon_cache.hip: intern pod request signatures and node shapes
+    c->cache_ok = c->fast_ok && N <= kCacheMaxNodes;
+    if (c->cache_ok) {
+        std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t>, int> sig_id;
+        std::vector<SigRow> sigs;
+        std::vector<PodRowC> rowsC(P);
+        for (int p = 0; p < P && c->cache_ok; ++p) {
+            const PodRowN& r = rows[p];
+            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, r.cls, r.flags);
+            auto it = sig_id.find(key);
+            if (it == sig_id.end()) {
+                if ((int)sigs.size() == kCacheMaxSigs) { c->cache_ok = false; break; }
+                it = sig_id.emplace(key, (int)sigs.size()).first;
+                SigRow sr{};
+                sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = r.cls; sr.flags = r.flags;
+                sigs.push_back(sr);
+            }
+            rowsC[p] = PodRowC{it->second, r.preset, r.gate, r.cls};
+        }
+        std::map<std::pair<uint32_t, uint32_t>, int> shape_id;
+        std::vector<ShapeRow> shapes;
+        std::vector<int32_t> shape_of(N), rank(N), prefix((size_t)(N + 1) * c->Cn, 0);
+        for (int j = 0; j < N && c->cache_ok; ++j) {
+            auto key = std::make_pair(a_cpu[j], a_mem[j]);
+            auto it = shape_id.find(key);
+            if (it == shape_id.end()) {
+                if ((int)shapes.size() == kCacheMaxShapes) { c->cache_ok = false; break; }
+                it = shape_id.emplace(key, (int)shapes.size()).first;
+                ShapeRow sh{};
+                sh.cap_c = (double)a_cpu[j]; sh.cap_m = (double)a_mem[j];
+                sh.rc_c = 1.0 / sh.cap_c; sh.rc_m = 1.0 / sh.cap_m;           // IEEE, as the device's correctly rounded '/'
+                sh.rc100_c = 100.0 * sh.rc_c; sh.rc100_m = 100.0 * sh.rc_m;
+                shapes.push_back(sh);
+            }
+            shape_of[j] = it->second;
+            const int d = c->node_class[j];
+            rank[j] = prefix[(size_t)j * c->Cn + d];
+            for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
+        }
+        if (c->cache_ok) {
+            c->n_sigs = (int)sigs.size(); c->n_shapes = (int)shapes.size();
+            if (sigs.empty()) sigs.push_back(SigRow{});
+            c->h_clsprefix = prefix;
+            HIP_TRY(c, c->d_sigs.upload(sigs, st));
+            HIP_TRY(c, c->d_shapes.upload(shapes, st));
+            HIP_TRY(c, c->d_podsC.upload(rowsC, st));
+            HIP_TRY(c, c->d_rank.upload(rank, st));
+            HIP_TRY(c, c->d_shape_of.upload(shape_of, st));
+            HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+    }
     HIP_TRY(c, c->d_podsF.upload(rowsF, st));
     HIP_TRY(c, c->d_a_cpu.upload(a_cpu, st));
     HIP_TRY(c, c->d_a_mem.upload(a_mem, st));
@@ -304,6 +370,13 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_WG")) c->force_T = atoi(e);
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
+    bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 8 && ok; ++i)
+        ok = hipStreamCreateWithFlags(&c->band_stream[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->band_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { simon_ctx_destroy(c); return nullptr; }
     return c;
 }
 
@@ -313,6 +386,11 @@ void simon_ctx_destroy(simon_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    for (int i = 0; i < 8; ++i) {
+        if (c->band_stream[i]) { (void)hipStreamSynchronize(c->band_stream[i]); (void)hipStreamDestroy(c->band_stream[i]); }
+        if (c->band_ev[i]) (void)hipEventDestroy(c->band_ev[i]);
+    }
     c->wide.release();
     // DevBuf destructors free device memory
     hipStream_t st = c->stream;
@@ -447,6 +525,31 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     HIP_TRY(c, c->d_used_cpu.ensure(S));
     HIP_TRY(c, c->d_used_mem.ensure(S));
     HIP_TRY(c, c->d_plan.ensure(1));
+    c->h_perm = perm;
+    c->cache_perm_ok = false;
+    if (c->variant == SIMON_KERNEL_NARROW && c->cache_ok) {
+        // placements are recorded by scheduling step and gathered back to pod ids through the inverse orders,
+        // which exist only when every order is a permutation of [0, P)
+        std::vector<int32_t> inv((size_t)n_orders * P, -1);
+        bool is_perm = true;
+        for (int o = 0; o < n_orders && is_perm; ++o)
+            for (int i = 0; i < P; ++i) {
+                int32_t& slot = inv[(size_t)o * P + orders[(size_t)o * P + i]];
+                if (slot >= 0) { is_perm = false; break; }
+                slot = i;
+            }
+        if (is_perm) {
+            HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->cache_perm_ok = true;
+        }
+        c->scen_ni.resize(S);
+        for (int s = 0; s < S; ++s) {
+            int ni = 0;
+            for (int d = 0; d < c->Cn; ++d) ni += (c->h_clsprefix[(size_t)scen[s].n_nodes * c->Cn + d] + 15) & ~15;
+            c->scen_ni[s] = ni;
+        }
+    }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller buffers may die after return
     float ms = 0;
@@ -475,7 +578,61 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         }
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
-        if (c->fast_ok && !c->force_v1 && T >= 128) {
+        bool use_cache = c->cache_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kCacheMaxNodes;
+        if (use_cache) {
+            int ni_top = 0;
+            for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
+            use_cache = ni_top <= kCacheMaxPadded &&
+                        cache_lds_bytes(c->n_sigs, cache_stride(std::max(ni_top, 16)), std::max(ni_top, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) <= kLdsPerCU;
+        }
+        if (use_cache) {
+            // Bands: scenarios in LPT order (largest first) are cut where the number of workgroups that fit
+            // one CU's 160 KiB of LDS changes; every band is its own launch (own LDS size) on its own
+            // stream, so small scenarios run at higher residency while the big ones are still going.
+            struct Band { int start, count, ni_max; size_t lds; };
+            std::vector<Band> bands;
+            auto lds_of = [&](int ni) { ni = std::max(ni, 16); return cache_lds_bytes(c->n_sigs, cache_stride(ni), ni, c->Cn, c->Cp, c->n_shapes, c->nzeq); };
+            for (int b = 0; b < S;) {
+                const int ni0 = c->scen_ni[c->h_perm[b]];
+                const int occ0 = (int)(kLdsPerCU / lds_of(ni0));
+                int e = b + 1;
+                if ((int)bands.size() + 1 < c->max_bands)
+                    while (e < S && (int)(kLdsPerCU / lds_of(c->scen_ni[c->h_perm[e]])) == occ0) ++e;
+                else e = S;
+                bands.push_back(Band{b, e - b, std::max(ni0, 16), lds_of(ni0)});
+                b = e;
+            }
+            if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
+            CacheLaunch f{};
+            f.ncls = c->d_ncls.p; f.rank = c->d_rank.p; f.shape_of = c->d_shape_of.p; f.a_pods = c->d_a_pods.p;
+            f.i_rq_cpu = c->d_i_rq_cpu.p; f.i_rq_mem = c->d_i_rq_mem.p; f.i_nz_cpu = c->d_i_nz_cpu.p; f.i_nz_mem = c->d_i_nz_mem.p;
+            f.i_npods = c->d_i_npods.p; f.clsprefix = c->d_clsprefix.p; f.sigs = c->d_sigs.p; f.shapes = c->d_shapes.p;
+            f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.scen = c->d_scen.p;
+            f.static_mask = c->has_mask ? c->d_mask.p : nullptr; f.simon_raw = c->d_raw32.p;
+            f.unscheduled = c->d_unsched.p; f.used_cpu = c->d_used_cpu.p; f.used_mem = c->d_used_mem.p;
+            f.place_step = want_placement ? c->d_place_step.p : nullptr;
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
+            for (size_t bi = 0; bi < bands.size(); ++bi) {
+                const Band& bd = bands[bi];
+                hipStream_t bs = bands.size() == 1 ? c->stream : c->band_stream[bi];
+                if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
+                f.perm = c->d_perm.p + bd.start;
+                f.sc = CacheScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max,
+                                    cache_stride(bd.ni_max), c->g_cpu, c->g_mem};
+                HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, bd.lds, bs));
+                if (bs != c->stream) {
+                    HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
+                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev[bi], 0));
+                }
+            }
+            if (want_placement)
+                HIP_TRY(c, launch_unpermute(c->d_place_step.p, c->d_inv_orders.p, c->d_scen.p, S, P, c->d_place.p, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            variant_used = SIMON_KERNEL_NARROW_CACHE;
+            T = 64; slots = (bands[0].ni_max / 16 + 63) / 64; lds = bands[0].lds;
+            c->stats.n_launches = (int)bands.size();
+        } else if (c->fast_ok && !c->force_v1 && T >= 128) {
             lds = ((size_t)c->Cp * c->Cn * 2 * sizeof(int32_t) + 15) & ~(size_t)15;
             FastLaunch f{};
             f.a_cpu = c->d_a_cpu.p; f.a_mem = c->d_a_mem.p; f.a_pods = c->d_a_pods.p; f.ncls = c->d_ncls.p;
@@ -519,7 +676,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.kernel_ms = ms;
-    c->stats.n_launches = 1;
+    if (variant_used != SIMON_KERNEL_NARROW_CACHE) c->stats.n_launches = 1;
     c->stats.kernel_variant = variant_used;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;

@@ -50,8 +50,11 @@ def test_known_answer_vector_on_gpu():
     from test_oracle import kav_problem
     prob, _ = kav_problem()
     res, variant = run_gpu(prob, [[2, 0]], np.arange(2)[None])
-    assert variant in (capi.KERNEL_NARROW, capi.KERNEL_NARROW_FAST)
+    assert variant == capi.KERNEL_NARROW_CACHE
     assert res.placement.tolist() == [[0, 0]] and res.unscheduled.tolist() == [0]
+    for env in ({"SIMON_NO_CACHE": "1"}, {"SIMON_NARROW_V1": "1"}, {"SIMON_FORCE_WIDE": "1"}):
+        res, _ = run_gpu(prob, [[2, 0]], np.arange(2)[None], env=env)
+        assert res.placement.tolist() == [[0, 0]] and res.unscheduled.tolist() == [0]
 
 
 @pytest.mark.parametrize("homogeneous", [False, True])
@@ -59,6 +62,9 @@ def test_config2_single_scenario(homogeneous):
     prob, scen, orders = synth.config2(homogeneous)
     ref = O.run(prob, scen, orders)
     res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_NARROW_CACHE
+    assert_same(res, ref)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_CACHE": "1"})
     assert variant == capi.KERNEL_NARROW_FAST
     assert_same(res, ref)
     res, variant = run_gpu(prob, scen, orders, env={"SIMON_NARROW_V1": "1"})
@@ -66,7 +72,11 @@ def test_config2_single_scenario(homogeneous):
     assert_same(res, ref)
 
 
-@pytest.mark.parametrize("env", [{}, {"SIMON_NARROW_V1": "1", "SIMON_RCP_DIV": "0"}, {"SIMON_NARROW_V1": "1", "SIMON_RCP_DIV": "1"}])
+VARIANT_OF_ENV = {"": capi.KERNEL_NARROW_CACHE, "SIMON_NO_CACHE": capi.KERNEL_NARROW_FAST, "SIMON_NARROW_V1": capi.KERNEL_NARROW}
+
+
+@pytest.mark.parametrize("env", [{}, {"SIMON_CACHE_BANDS": "1"}, {"SIMON_NO_CACHE": "1"}, {"SIMON_NARROW_V1": "1", "SIMON_RCP_DIV": "0"},
+                                 {"SIMON_NARROW_V1": "1", "SIMON_RCP_DIV": "1"}])
 def test_config3_full_size_subset(env):
     """10k pods x 488..1511 nodes: 4 orders x 6 node counts at full size, every placement compared."""
     prob, scen, orders = synth.config3()
@@ -74,7 +84,9 @@ def test_config3_full_size_subset(env):
     sub = scen[pick]
     ref = O.run(prob, sub, orders)
     res, variant = run_gpu(prob, sub, orders, env=env)
-    assert variant == (capi.KERNEL_NARROW if env else capi.KERNEL_NARROW_FAST)
+    want = capi.KERNEL_NARROW if "SIMON_NARROW_V1" in env else capi.KERNEL_NARROW_FAST if "SIMON_NO_CACHE" in env \
+        else capi.KERNEL_NARROW_CACHE
+    assert variant == want
     assert_same(res, ref)
 
 
@@ -82,7 +94,9 @@ def test_config3_homogeneous_ties():
     """All nodes identical: almost every pod ties on score, the first-max rule decides everything."""
     prob, scen, orders = synth.config3(n_counts=64, n_orders=4, n_pods=4000, n_het=100, homogeneous=True)
     sub = scen[::9]
-    assert_same(run_gpu(prob, sub, orders)[0], O.run(prob, sub, orders))
+    ref = O.run(prob, sub, orders)
+    assert_same(run_gpu(prob, sub, orders)[0], ref)
+    assert_same(run_gpu(prob, sub, orders, env={"SIMON_NO_CACHE": "1"})[0], ref)
 
 
 @pytest.mark.parametrize("wg", ["64", "128", "256", "512"])
@@ -90,7 +104,8 @@ def test_config3_homogeneous_ties():
 def test_workgroup_shapes(wg, v1):
     prob, scen, orders = synth.config3(n_counts=40, n_orders=3, n_pods=1500, n_het=90)
     sub = scen[::5]
-    assert_same(run_gpu(prob, sub, orders, env={"SIMON_WG": wg, "SIMON_NARROW_V1": v1})[0], O.run(prob, sub, orders))
+    assert_same(run_gpu(prob, sub, orders, env={"SIMON_WG": wg, "SIMON_NARROW_V1": v1, "SIMON_NO_CACHE": "1"})[0],
+                O.run(prob, sub, orders))
 
 
 def test_replica_runs_hit_the_score_cache():
@@ -100,8 +115,11 @@ def test_replica_runs_hit_the_score_cache():
     grouped = np.argsort(prob.pod_class, kind="stable").astype(np.int32)
     orders = np.stack([grouped, grouped[::-1].copy(), orders[1], orders[2]])
     ref = O.run(prob, scen, orders)
-    res, variant = run_gpu(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_CACHE": "1"})
     assert variant == capi.KERNEL_NARROW_FAST
+    assert_same(res, ref)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_NARROW_CACHE
     assert_same(res, ref)
 
 
@@ -126,8 +144,13 @@ def test_random_cpu_mem_features(idx, force_wide):
             assert variant == capi.KERNEL_WIDE
         assert_same(res, ref)
         if force_wide == "0":
+            if "odd_units" not in feat:                                 # odd_units (gcd 1) exceeds 31 bits -> WIDE
+                assert variant == capi.KERNEL_NARROW_CACHE
             res, variant = run_gpu(prob, scen, orders, env={"SIMON_NARROW_V1": "1"})
-            assert variant in (capi.KERNEL_NARROW, capi.KERNEL_WIDE)   # odd_units (gcd 1) exceeds 31 bits -> WIDE
+            assert variant in (capi.KERNEL_NARROW, capi.KERNEL_WIDE)
+            assert_same(res, ref)
+            res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_CACHE": "1"})
+            assert variant in (capi.KERNEL_NARROW_FAST, capi.KERNEL_NARROW, capi.KERNEL_WIDE)
             assert_same(res, ref)
 
 
