@@ -38,6 +38,7 @@ struct CacheLaunch {
     const int32_t *i_npods, *clsprefix; const SigRow* sigs; const ShapeRow* shapes; const PodRowC* pods;
     const int32_t* orders; const ScenarioDesc* scen; const int32_t* perm; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem; int32_t* place_step;
+    unsigned char* ws;   // HBM workspace [n_blocks][cache_ws_bytes] (table + node state) or nullptr = LDS-resident
     CacheScalars sc;
 };
 
@@ -47,10 +48,11 @@ constexpr int kCacheMaxSigs = 64;       // one lane per signature
 constexpr int kCacheMaxShapes = 256;
 constexpr size_t kLdsPerCU = 160 * 1024;
 
-inline int cache_stride(int ni) {       // >= ni, multiple of 16, == 16 (mod 128): column stores hit distinct banks
-    return ni + ((16 + 128 - (ni % 128)) % 128);
+inline int cache_stride(int ni) {       // >= ni (a multiple of 16), odd multiple of 16: the K column bytes spread over 8 bank groups
+    return (ni / 16) % 2 ? ni : ni + 16;
 }
-size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
+size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global);
+size_t cache_ws_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
 // launches a.sc.S scenarios (blocks), scenario of block b = a.perm[b]
 hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,

@@ -42,17 +42,19 @@ __device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
 }
 
-// LDS carve (all offsets multiples of 16)
+// LDS carve (all offsets multiples of 16).  GLOBAL: the score table and the node state live in a
+// per-workgroup HBM workspace (L2 / Infinity-Cache resident) instead of LDS.
 struct Carve {
     int tab, state, nz, canon, cnt, raw, sn2, sig, shape, seg, tmp, total;
+    int ws_tab, ws_state, ws_nz, ws_total;   // workspace offsets (GLOBAL only)
 };
-__host__ __device__ inline Carve carve(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+__host__ __device__ inline Carve carve(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global) {
     auto al = [](int x) { return (x + 15) & ~15; };
     Carve c;
     int o = 0;
-    c.tab = o; o += al(K * stride);
-    c.state = o; o += ni_max * 16;
-    c.nz = o; o += nzeq ? 0 : al(ni_max * 8);
+    c.tab = o; o += global ? 0 : al(K * stride);
+    c.state = o; o += global ? 0 : ni_max * 16;
+    c.nz = o; o += (global || nzeq) ? 0 : al(ni_max * 8);
     c.canon = o; o += al(ni_max * 2);
     c.cnt = o; o += Cn * 64 * 4;
     c.raw = o; o += al(Cp * Cn * 4);
@@ -62,10 +64,15 @@ __host__ __device__ inline Carve carve(int K, int stride, int ni_max, int Cn, in
     c.seg = o; o += 32 * 4;
     c.tmp = o; o += 32 * 4;
     c.total = o;
+    int w = 0;
+    c.ws_tab = w; w += (al(K * stride) + 127) & ~127;
+    c.ws_state = w; w += (ni_max * 16 + 127) & ~127;
+    c.ws_nz = w; w += nzeq ? 0 : ((ni_max * 8 + 127) & ~127);
+    c.ws_total = w;
     return c;
 }
 
-template <int SLOTS, bool HAS_MASK, bool NZEQ>
+template <int SLOTS, bool HAS_MASK, bool NZEQ, bool GLOBAL>
 __global__ __launch_bounds__(64) void cache_kernel(
     const int32_t* __restrict__ ncls, const int32_t* __restrict__ rank, const int32_t* __restrict__ shape_of,
     const int32_t* __restrict__ a_pods, const uint32_t* __restrict__ i_rq_cpu, const uint32_t* __restrict__ i_rq_mem,
@@ -74,13 +81,14 @@ __global__ __launch_bounds__(64) void cache_kernel(
     const PodRowC* __restrict__ pods, const int32_t* __restrict__ orders, const ScenarioDesc* __restrict__ scen,
     const int32_t* __restrict__ perm, const uint64_t* __restrict__ static_mask, const int32_t* __restrict__ simon_raw,
     int32_t* __restrict__ unscheduled, int64_t* __restrict__ used_cpu, int64_t* __restrict__ used_mem,
-    int32_t* __restrict__ place_step, const CacheScalars sc) {
+    int32_t* __restrict__ place_step, unsigned char* ws, const CacheScalars sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K, stride = sc.stride;
-    const Carve cv = carve(K, stride, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ);
-    unsigned char* s_tab = smem + cv.tab;
-    uint4* s_state = (uint4*)(smem + cv.state);      // {Requested cpu, Requested mem, free pod slots, shape | class<<16}
-    uint2* s_nz = (uint2*)(smem + cv.nz);            // NonZeroRequested {cpu, mem} (only when !NZEQ)
+    const Carve cv = carve(K, stride, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ, GLOBAL);
+    unsigned char* const wsb = GLOBAL ? ws + (size_t)blockIdx.x * (size_t)cv.ws_total : nullptr;
+    unsigned char* s_tab = GLOBAL ? wsb + cv.ws_tab : smem + cv.tab;
+    uint4* s_state = (uint4*)(GLOBAL ? wsb + cv.ws_state : smem + cv.state);   // {Requested cpu, mem, free pod slots, shape | class<<16}
+    uint2* s_nz = (uint2*)(GLOBAL ? wsb + cv.ws_nz : smem + cv.nz);            // NonZeroRequested {cpu, mem} (only when !NZEQ)
     unsigned short* s_canon = (unsigned short*)(smem + cv.canon);
     int* s_cnt = (int*)(smem + cv.cnt);              // [Cn][64]: feasible nodes of class d for signature k
     int* s_raw = (int*)(smem + cv.raw);
@@ -96,12 +104,11 @@ __global__ __launch_bounds__(64) void cache_kernel(
     const int32_t* __restrict__ order = orders + (size_t)scen[s].order_id * P;
 
     // ---- prologue 1: clear, tables -> LDS ----------------------------------------------------
-    for (int i = lane; i < cv.cnt / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);   // tab, state, nz, canon
+    if (!GLOBAL) for (int i = lane; i < cv.canon / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);   // tab, state, nz
     for (int i = lane; i < Cn * 64; i += 64) s_cnt[i] = 0;
     for (int i = lane; i < Cp * Cn; i += 64) s_raw[i] = simon_raw[i];
     for (int i = lane; i < K * 12; i += 64) ((int*)(smem + cv.sig))[i] = ((const int*)sigs)[i];
     for (int i = lane; i < sc.n_shapes * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
-    __syncthreads();
     for (int i = lane; i < sc.ni_max; i += 64) s_canon[i] = 0xFFFFu;
     // class segments: count of class-d nodes among the first n canonical nodes, padded to 16
     int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
@@ -116,15 +123,8 @@ __global__ __launch_bounds__(64) void cache_kernel(
     const int ni = __builtin_amdgcn_readlane(incl, 31);               // padded scenario size (lanes >= Cn add 0)
     const unsigned bits_all = (unsigned)__ballot(cnt_d > 0);
     __syncthreads();
-    // ---- prologue 2: scatter node rows into the class-major layout --------------------------
-    for (int j = lane; j < n; j += 64) {
-        const int d = ncls[j];
-        const int pos = s_seg[d] + rank[j];
-        s_state[pos] = make_uint4(i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j]),
-                                  (unsigned)shape_of[j] | ((unsigned)d << 16));
-        if (!NZEQ) s_nz[pos] = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
-        s_canon[pos] = (unsigned short)j;
-    }
+    // ---- prologue 2: scatter canonical indices into the class-major layout ------------------
+    for (int j = lane; j < n; j += 64) s_canon[s_seg[ncls[j]] + rank[j]] = (unsigned short)j;
     // sn2_full[c][d] = 2 * NormalizeScore(raw[c][d]) over the node classes present (simon.go:76-101)
     for (int i = lane; i < Cp * Cn; i += 64) {
         const int c = i / Cn;
@@ -140,24 +140,17 @@ __global__ __launch_bounds__(64) void cache_kernel(
     }
     __syncthreads();
 
-    // this lane's signature (lane k evaluates signature k on a touched node)
-    const int kk = lane < K ? lane : 0;
-    const double my_req_c = s_sig[kk].req_c, my_req_m = s_sig[kk].req_m;
-    const double my_nz_c = s_sig[kk].nz_c, my_nz_m = s_sig[kk].nz_m;
-    const bool my_zero = s_sig[kk].flags & 1u;
-    const int my_cls = s_sig[kk].cls;
-    unsigned char* my_col = s_tab + (size_t)kk * stride;
-
-    // (feasible, LeastAllocated + BalancedAllocation) of signature `lane` on a node: byte = 0 when
+    // (feasible, LeastAllocated + BalancedAllocation) of one signature on one node: byte = 0 when
     // NodeResourcesFit fails (fit.go:230-302), else 1 + score.  Same fp64 sequences as
     // simon_fast.hip::eval_slot.
-    auto eval_node = [&](double rq_c, double rq_m, double nzs_c, double nzs_m, int freep, const ShapeRow& sh) -> unsigned {
-        const double t_c = rq_c + my_req_c, t_m = rq_m + my_req_m;
+    auto eval_node = [&](double q_req_c, double q_req_m, double q_nz_c, double q_nz_m, bool q_zero, double rq_c, double rq_m,
+                         double nzs_c, double nzs_m, int freep, const ShapeRow& sh) -> unsigned {
+        const double t_c = rq_c + q_req_c, t_m = rq_m + q_req_m;
         const bool res_ok = (sh.cap_c >= t_c) && (sh.cap_m >= t_m);
-        const bool ok = (freep >= 1) && (my_zero || res_ok);
+        const bool ok = (freep >= 1) && (q_zero || res_ok);
         // resource_allocation.go:91-98: requested = NonZeroRequested + pod non-zero request
-        const double r_c = NZEQ ? t_c : nzs_c + my_nz_c;
-        const double r_m = NZEQ ? t_m : nzs_m + my_nz_m;
+        const double r_c = NZEQ ? t_c : nzs_c + q_nz_c;
+        const double r_m = NZEQ ? t_m : nzs_m + q_nz_m;
         const bool ge_c = r_c >= sh.cap_c, ge_m = r_m >= sh.cap_m;
         const int la_c = ge_c ? 0 : la_term_c(r_c, sh.rc100_c);           // least_allocated.go:108-117
         const int la_m = ge_m ? 0 : la_term_c(r_m, sh.rc100_m);
@@ -168,25 +161,50 @@ __global__ __launch_bounds__(64) void cache_kernel(
         return ok ? (unsigned)(base + 1) : 0u;
     };
 
-    // ---- prologue 3: fill the table (every real node, every signature) ----------------------
-    for (int p = 0; p < ni; ++p) {
-        const unsigned cj = s_canon[p];
-        if (cj == 0xFFFFu) continue;                                   // padding: stays infeasible
-        const uint4 st = s_state[p];
-        const ShapeRow sh = s_shape[st.w & 0xFFFFu];
-        double nzc = 0.0, nzm = 0.0;
-        if (!NZEQ) { const uint2 z = s_nz[p]; nzc = (double)z.x; nzm = (double)z.y; }
-        unsigned b = eval_node((double)st.x, (double)st.y, nzc, nzm, (int)st.z, sh);
-        if (HAS_MASK) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node)
-            const uint64_t w = static_mask[(size_t)my_cls * sc.mask_words + (cj >> 6)];
-            b = ((w >> (cj & 63)) & 1ull) ? b : 0u;
+    // ---- prologue 3: node rows + the whole table; lanes = 64 consecutive positions, loop over signatures
+    for (int p0 = 0; p0 < ni; p0 += 64) {
+        const int p = p0 + lane;
+        const unsigned cj = p < ni ? s_canon[p] : 0xFFFFu;
+        const bool real = cj != 0xFFFFu;
+        const int j = real ? (int)cj : 0;
+        const int d = real ? ncls[j] : 0;
+        const uint4 st = real ? make_uint4(i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j]),
+                                           (unsigned)shape_of[j] | ((unsigned)d << 16))
+                              : make_uint4(0, 0, 0, 0);
+        uint2 z = make_uint2(0, 0);
+        if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
+        if (p < sc.ni_max) {
+            s_state[p] = st;
+            if (!NZEQ) s_nz[p] = z;
         }
-        if (lane < K) {
-            my_col[p] = (unsigned char)b;
-            if (b) s_cnt[(st.w >> 16) * 64 + lane] += 1;
+        const ShapeRow sh = s_shape[st.w & 0xFFFFu];
+        // classes present in this chunk form a contiguous range (class-major layout)
+        const int dlo = wave_min_i32(real ? d : 0x7fffffff), dhi = wave_max_i32(real ? d : (int)0x80000000);
+        for (int k = 0; k < K; ++k) {
+            const SigRow q = s_sig[k];
+            unsigned b = eval_node(q.req_c, q.req_m, q.nz_c, q.nz_m, q.flags & 1u, (double)st.x, (double)st.y, (double)z.x,
+                                   (double)z.y, (int)st.z, sh);
+            b = real ? b : 0u;
+            if (HAS_MASK) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node)
+                const uint64_t w = static_mask[(size_t)q.cls * sc.mask_words + (j >> 6)];
+                b = ((w >> (j & 63)) & 1ull) ? b : 0u;
+            }
+            if (p < stride) s_tab[(size_t)k * stride + p] = (unsigned char)b;
+            for (int dd = dlo; dd <= dhi; ++dd) {
+                const int c = __popcll(__ballot(b != 0u && d == dd));
+                if (lane == 0 && c) s_cnt[dd * 64 + k] += c;
+            }
         }
     }
+    if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    // this lane's signature (lane k re-evaluates signature k on a touched node)
+    const int kk = lane < K ? lane : 0;
+    const double my_req_c = s_sig[kk].req_c, my_req_m = s_sig[kk].req_m;
+    const double my_nz_c = s_sig[kk].nz_c, my_nz_m = s_sig[kk].nz_m;
+    const bool my_zero = s_sig[kk].flags & 1u;
+    unsigned char* my_col = s_tab + (size_t)kk * stride;
 
     // node class of this lane's 16-node blocks (class segments are multiples of 16)
     const int nblk = ni >> 4;
@@ -200,24 +218,30 @@ __global__ __launch_bounds__(64) void cache_kernel(
     int unsched = 0, plreg = 0;
     int32_t* __restrict__ place = place_step ? place_step + (size_t)s * P : nullptr;
 
-    int pid_next = P > 0 ? order[0] : 0;
-    PodRowC row_next = pods[pid_next];
-    int pid_next2 = P > 1 ? order[1] : 0;
+    // pod stream: 64 rows per vector load (lane l holds step i0 + l), one chunk ahead
+    int4 cur = make_int4(0, -1, 0x7fffffff, 0), nxt = cur;
+    auto load_chunk = [&](int i0) -> int4 {
+        const int idx = i0 + lane;
+        if (idx >= P) return make_int4(0, -1, 0x7fffffff, 0);
+        const PodRowC r = pods[order[idx]];
+        return make_int4(r.sig, r.preset, r.gate, r.cls);
+    };
+    if (P > 0) nxt = load_chunk(0);
 
     for (int i = 0; i < P; ++i) {
-        const PodRowC row = row_next;
-        pid_next = pid_next2;
-        row_next = pods[pid_next];
-        pid_next2 = (i + 2 < P) ? order[i + 2] : 0;
+        const int il = i & 63;
+        if (il == 0) { cur = nxt; nxt = load_chunk(i + 64); }
+        const int r_sig = __builtin_amdgcn_readlane(cur.x, il), r_preset = __builtin_amdgcn_readlane(cur.y, il);
+        const int r_gate = __builtin_amdgcn_readlane(cur.z, il), r_cls = __builtin_amdgcn_readlane(cur.w, il);
 
         int res, pstar = -1;
-        if (row.gate >= n) {
+        if (r_gate >= n) {
             res = -2;                                                  // pod not part of this scenario
-        } else if (row.preset >= 0) {                                  // addPodToCache path (V/eventhandlers.go:223-236)
-            res = row.preset;
-            pstar = s_seg[ncls[row.preset]] + rank[row.preset];
+        } else if (r_preset >= 0) {                                    // addPodToCache path (V/eventhandlers.go:223-236)
+            res = r_preset;
+            pstar = __builtin_amdgcn_readfirstlane(s_seg[ncls[r_preset]] + rank[r_preset]);
         } else {
-            const int k = row.sig;
+            const int k = r_sig;
             // -------- which node classes still have a feasible node for this signature --------
             const int cvv = (lane < Cn) ? s_cnt[lane * 64 + k] : 0;
             const unsigned bits = (unsigned)__ballot(cvv > 0);
@@ -228,10 +252,10 @@ __global__ __launch_bounds__(64) void cache_kernel(
                 // -------- SimonPlugin/GpuSharePlugin NormalizeScore row (x2: both plugins) ----
                 const int* snrow;
                 if (bits == bits_all) {
-                    snrow = s_sn2 + row.cls * Cn;
+                    snrow = s_sn2 + r_cls * Cn;
                 } else {
                     const int c = lane < Cn ? lane : 0;
-                    const int rawc = s_raw[row.cls * Cn + c];
+                    const int rawc = s_raw[r_cls * Cn + c];
                     const bool inb = (lane < Cn) && ((bits >> c) & 1u);
                     const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
                     const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
@@ -278,33 +302,39 @@ __global__ __launch_bounds__(64) void cache_kernel(
         }
         // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column ---------
         if (pstar >= 0) {
-            const SigRow& cur = s_sig[row.sig];
+            const SigRow& cur_sig = s_sig[r_sig];
             uint4 st = s_state[pstar];
-            st.x += (unsigned)cur.req_c;
-            st.y += (unsigned)cur.req_m;
+            st.x += (unsigned)cur_sig.req_c;
+            st.y += (unsigned)cur_sig.req_m;
             st.z -= 1u;
             double nzc = 0.0, nzm = 0.0;
             if (!NZEQ) {
                 uint2 z = s_nz[pstar];
-                z.x += (unsigned)cur.nz_c;
-                z.y += (unsigned)cur.nz_m;
+                z.x += (unsigned)cur_sig.nz_c;
+                z.y += (unsigned)cur_sig.nz_m;
                 if (lane == 0) s_nz[pstar] = z;
                 nzc = (double)z.x; nzm = (double)z.y;
             }
             const unsigned old = my_col[pstar];
             if (lane == 0) s_state[pstar] = st;
             const ShapeRow sh = s_shape[st.w & 0xFFFFu];
-            unsigned nb = eval_node((double)st.x, (double)st.y, nzc, nzm, (int)st.z, sh);
+            unsigned nb = eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st.x, (double)st.y, nzc, nzm,
+                                    (int)st.z, sh);
             nb = old ? nb : 0u;                                        // static mask / monotone infeasibility
             if (lane < K && nb != old) {
                 my_col[pstar] = (unsigned char)nb;
                 if (!nb) s_cnt[(st.w >> 16) * 64 + lane] -= 1;
             }
+            // HBM workspace: the column bytes and the state row must have left this wave's store queue before
+            // other lanes load them (one wave: the TCP serves its accesses in order; the wait makes it explicit)
+#ifdef SIMON_CACHE_DRAIN_STORES
+            if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_wave_barrier();
         }
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
-        plreg = ((i & 63) == lane) ? res : plreg;
-        if (place && (i & 63) == 63) place[(i & ~63) + lane] = plreg;
+        plreg = (il == lane) ? res : plreg;
+        if (place && il == 63) place[(i & ~63) + lane] = plreg;
     }
     if (place && (P & 63) && lane < (P & 63)) place[(P & ~63) + lane] = plreg;
 
@@ -333,34 +363,38 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restric
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
 }
 
-template <int SLOTS, bool M, bool Z>
+template <int SLOTS, bool M, bool Z, bool G>
 static hipError_t launch_smz(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = cache_kernel<SLOTS, M, Z>;
+    auto kern = cache_kernel<SLOTS, M, Z, G>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.ncls, a.rank, a.shape_of, a.a_pods, a.i_rq_cpu,
                        a.i_rq_mem, a.i_nz_cpu, a.i_nz_mem, a.i_npods, a.clsprefix, a.sigs, a.shapes, a.pods, a.orders,
                        a.scen, a.perm, a.static_mask, a.simon_raw, a.unscheduled, a.used_cpu, a.used_mem, a.place_step,
-                       a.sc);
+                       a.ws, a.sc);
     return hipGetLastError();
 }
 
-template <int SLOTS>
+template <int SLOTS, bool G>
 static hipError_t launch_s(const CacheLaunch& a, int n_blocks, bool m, bool z, size_t lds, hipStream_t st) {
-    if (m) return z ? launch_smz<SLOTS, true, true>(a, n_blocks, lds, st) : launch_smz<SLOTS, true, false>(a, n_blocks, lds, st);
-    return z ? launch_smz<SLOTS, false, true>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, false>(a, n_blocks, lds, st);
+    if (m) return z ? launch_smz<SLOTS, true, true, G>(a, n_blocks, lds, st) : launch_smz<SLOTS, true, false, G>(a, n_blocks, lds, st);
+    return z ? launch_smz<SLOTS, false, true, G>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, false, G>(a, n_blocks, lds, st);
 }
 
-size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
-    return (size_t)carve(K, stride, ni_max, Cn, Cp, n_shapes, nzeq).total;
+size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global) {
+    return (size_t)carve(K, stride, ni_max, Cn, Cp, n_shapes, nzeq, global).total;
+}
+size_t cache_ws_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+    return (size_t)carve(K, stride, ni_max, Cn, Cp, n_shapes, nzeq, true).ws_total;
 }
 
-// n_blocks scenarios starting at perm offset `a.perm`
+// n_blocks scenarios; scenario of block b = a.perm[b]; a.ws != nullptr selects the HBM-workspace variant
 hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
     const int slots = (a.sc.ni_max / 16 + 63) / 64;
+    const bool g = a.ws != nullptr;
     switch (slots) {
-        case 1: return launch_s<1>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
-        case 2: return launch_s<2>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
+        case 1: return g ? launch_s<1, true>(a, n_blocks, has_mask, nzeq, lds_bytes, st) : launch_s<1, false>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
+        case 2: return g ? launch_s<2, true>(a, n_blocks, has_mask, nzeq, lds_bytes, st) : launch_s<2, false>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -88,7 +88,9 @@ struct simon_ctx : simon::HostInputs {
     bool fast_ok = false, nzeq = false;  // simon_fast.hip eligibility
     // ---- simon_cache.hip (LDS score table, one wave per scenario) ----
     bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
-    int n_sigs = 0, n_shapes = 0, max_bands = 6;
+    bool cache_global = true;   // env SIMON_CACHE_GLOBAL=0: keep the score table + node state in LDS instead of the HBM workspace
+    DevBuf<unsigned char> d_ws;
+    int n_sigs = 0, n_shapes = 0, max_bands = 8;
     DevBuf<SigRow> d_sigs;
     DevBuf<ShapeRow> d_shapes;
     DevBuf<PodRowC> d_podsC;
@@ -371,6 +373,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_CACHE_GLOBAL")) c->cache_global = atoi(e) != 0;
     if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
     bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 8 && ok; ++i)
@@ -579,29 +582,35 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
         bool use_cache = c->cache_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kCacheMaxNodes;
+        const bool glob = c->cache_global;
+        auto lds_of = [&](int ni) { ni = std::max(ni, 16); return cache_lds_bytes(c->n_sigs, cache_stride(ni), ni, c->Cn, c->Cp, c->n_shapes, c->nzeq, glob); };
+        auto ws_of = [&](int ni) { ni = std::max(ni, 16); return cache_ws_bytes(c->n_sigs, cache_stride(ni), ni, c->Cn, c->Cp, c->n_shapes, c->nzeq); };
         if (use_cache) {
             int ni_top = 0;
             for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
-            use_cache = ni_top <= kCacheMaxPadded &&
-                        cache_lds_bytes(c->n_sigs, cache_stride(std::max(ni_top, 16)), std::max(ni_top, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) <= kLdsPerCU;
+            use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
         }
         if (use_cache) {
-            // Bands: scenarios in LPT order (largest first) are cut where the number of workgroups that fit
-            // one CU's 160 KiB of LDS changes; every band is its own launch (own LDS size) on its own
-            // stream, so small scenarios run at higher residency while the big ones are still going.
-            struct Band { int start, count, ni_max; size_t lds; };
+            // Bands: scenarios in LPT order (largest first) are cut where the launch shape changes -- LDS variant:
+            // the number of workgroups that fit one CU's 160 KiB of LDS; HBM-workspace variant: every 256 padded
+            // nodes (row stride, slots per lane).  Every band is its own launch on its own stream, so small
+            // scenarios run at higher residency while the big ones are still going.
+            struct Band { int start, count, ni_max; size_t lds, ws_off; };
             std::vector<Band> bands;
-            auto lds_of = [&](int ni) { ni = std::max(ni, 16); return cache_lds_bytes(c->n_sigs, cache_stride(ni), ni, c->Cn, c->Cp, c->n_shapes, c->nzeq); };
+            auto band_key = [&](int ni) { return glob ? (std::max(ni, 16) + 255) / 256 : (int)(kLdsPerCU / lds_of(ni)); };
+            size_t ws_total = 0;
             for (int b = 0; b < S;) {
                 const int ni0 = c->scen_ni[c->h_perm[b]];
-                const int occ0 = (int)(kLdsPerCU / lds_of(ni0));
+                const int key0 = band_key(ni0);
                 int e = b + 1;
                 if ((int)bands.size() + 1 < c->max_bands)
-                    while (e < S && (int)(kLdsPerCU / lds_of(c->scen_ni[c->h_perm[e]])) == occ0) ++e;
+                    while (e < S && band_key(c->scen_ni[c->h_perm[e]]) == key0) ++e;
                 else e = S;
-                bands.push_back(Band{b, e - b, std::max(ni0, 16), lds_of(ni0)});
+                bands.push_back(Band{b, e - b, std::max(ni0, 16), lds_of(ni0), ws_total});
+                ws_total += glob ? ws_of(ni0) * (size_t)(e - b) : 0;
                 b = e;
             }
+            if (glob) HIP_TRY(c, c->d_ws.ensure(ws_total));
             if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
             CacheLaunch f{};
             f.ncls = c->d_ncls.p; f.rank = c->d_rank.p; f.shape_of = c->d_shape_of.p; f.a_pods = c->d_a_pods.p;
@@ -618,6 +627,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 hipStream_t bs = bands.size() == 1 ? c->stream : c->band_stream[bi];
                 if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
                 f.perm = c->d_perm.p + bd.start;
+                f.ws = glob ? c->d_ws.p + bd.ws_off : nullptr;
                 f.sc = CacheScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max,
                                     cache_stride(bd.ni_max), c->g_cpu, c->g_mem};
                 HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, bd.lds, bs));
