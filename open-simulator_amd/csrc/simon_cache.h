@@ -29,7 +29,8 @@ struct PodRowC { int32_t sig, preset, gate, cls; };   // 16 B, one s_load_dwordx
 struct CacheScalars {
     int32_t mask_words, Cn, Cp, P, S, K, n_shapes;
     int32_t ni_max;      // padded scenario size bound of this launch (multiple of 16, <= 2032)
-    int32_t stride;      // table row stride in bytes: >= ni_max, multiple of 16, == 16 (mod 128)
+    int32_t stride;      // table row stride in bytes: >= ni_max, odd multiple of 16
+    int32_t ablate;      // timing experiments only (env SIMON_CACHE_ABLATE): results are wrong when non-zero
     uint64_t g_cpu, g_mem;
 };
 
@@ -38,6 +39,7 @@ struct CacheLaunch {
     const int32_t *i_npods, *clsprefix; const SigRow* sigs; const ShapeRow* shapes; const PodRowC* pods;
     const int32_t* orders; const ScenarioDesc* scen; const int32_t* perm; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem; int32_t* place_step;
+    bool reg_state;      // keep Requested / free pod slots of every node in VGPRs (needs ws, nzeq, |free pod slots| and P < 2^22, <= 256 shapes)
     unsigned char* ws;   // HBM workspace [n_blocks][cache_ws_bytes] (table + node state) or nullptr = LDS-resident
     CacheScalars sc;
 };

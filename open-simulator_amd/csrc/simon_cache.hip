@@ -72,7 +72,11 @@ __host__ __device__ inline Carve carve(int K, int stride, int ni_max, int Cn, in
     return c;
 }
 
-template <int SLOTS, bool HAS_MASK, bool NZEQ, bool GLOBAL>
+// 32-way uniform switch over the register-resident node state (REGSTATE)
+#define SIMON_ST16(X, o) X(o + 0) X(o + 1) X(o + 2) X(o + 3) X(o + 4) X(o + 5) X(o + 6) X(o + 7) X(o + 8) X(o + 9) X(o + 10) \
+    X(o + 11) X(o + 12) X(o + 13) X(o + 14) X(o + 15)
+
+template <int SLOTS, bool HAS_MASK, bool NZEQ, bool GLOBAL, bool REGSTATE>
 __global__ __launch_bounds__(64) void cache_kernel(
     const int32_t* __restrict__ ncls, const int32_t* __restrict__ rank, const int32_t* __restrict__ shape_of,
     const int32_t* __restrict__ a_pods, const uint32_t* __restrict__ i_rq_cpu, const uint32_t* __restrict__ i_rq_mem,
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(64) void cache_kernel(
                               : make_uint4(0, 0, 0, 0);
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
-        if (p < sc.ni_max) {
+        if (!REGSTATE && p < sc.ni_max) {
             s_state[p] = st;
             if (!NZEQ) s_nz[p] = z;
         }
@@ -206,13 +210,28 @@ __global__ __launch_bounds__(64) void cache_kernel(
     const bool my_zero = s_sig[kk].flags & 1u;
     unsigned char* my_col = s_tab + (size_t)kk * stride;
 
-    // node class of this lane's 16-node blocks (class segments are multiples of 16)
+    // node class of this lane's 16-node blocks (class segments are multiples of 16); REGSTATE: the
+    // dynamic state of those 16 x SLOTS nodes lives in this lane's registers
     const int nblk = ni >> 4;
     int ncl4[SLOTS];
+    unsigned rqc[REGSTATE ? SLOTS * 16 : 1], rqm[REGSTATE ? SLOTS * 16 : 1], fps[REGSTATE ? SLOTS * 16 : 1];
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q) {
         const int b = q * 64 + lane;
-        ncl4[q] = (b < nblk) ? (int)(s_state[b * 16].w >> 16) * 4 : 0;
+        const unsigned cj0 = (b < nblk) ? s_canon[b * 16] : 0xFFFFu;
+        ncl4[q] = (cj0 != 0xFFFFu) ? ncls[cj0] * 4 : 0;
+        if (REGSTATE) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const unsigned cj = (b < nblk) ? s_canon[b * 16 + t] : 0xFFFFu;
+                const bool real = cj != 0xFFFFu;
+                const int j = real ? (int)cj : 0;
+                rqc[q * 16 + t] = real ? i_rq_cpu[j] : 0u;
+                rqm[q * 16 + t] = real ? i_rq_mem[j] : 0u;
+                // free pod slots << 8 (signed, upper 24 bits: decrements never borrow from the shape id) | shape
+                fps[q * 16 + t] = real ? (((unsigned)(a_pods[j] - i_npods[j]) << 8) | (unsigned)shape_of[j]) : 0u;
+            }
+        }
     }
 
     int unsched = 0, plreg = 0;
@@ -228,11 +247,30 @@ __global__ __launch_bounds__(64) void cache_kernel(
     };
     if (P > 0) nxt = load_chunk(0);
 
+    // table row of the NEXT pod's signature, loaded one cycle ahead; the one byte the current
+    // cycle changes in it is patched in registers
+    uint4 Rn[SLOTS];
+    auto load_row = [&](int k) {
+        const uint4* rowp = (const uint4*)(s_tab + (size_t)k * stride);
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int b = q * 64 + lane;
+            if (SLOTS == 1 || q * 64 < nblk) Rn[q] = rowp[b < nblk ? b : 0];
+            else Rn[q] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (P > 0) load_row(__builtin_amdgcn_readlane(nxt.x, 0));
+
     for (int i = 0; i < P; ++i) {
         const int il = i & 63;
         if (il == 0) { cur = nxt; nxt = load_chunk(i + 64); }
         const int r_sig = __builtin_amdgcn_readlane(cur.x, il), r_preset = __builtin_amdgcn_readlane(cur.y, il);
         const int r_gate = __builtin_amdgcn_readlane(cur.z, il), r_cls = __builtin_amdgcn_readlane(cur.w, il);
+        const int k_next = il < 63 ? __builtin_amdgcn_readlane(cur.x, (il + 1) & 63) : __builtin_amdgcn_readlane(nxt.x, 0);
+        uint4 R[SLOTS];
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) R[q] = Rn[q];
+        if (i + 1 < P && !(sc.ablate & 8)) load_row(k_next);
 
         int res, pstar = -1;
         if (r_gate >= n) {
@@ -267,21 +305,20 @@ __global__ __launch_bounds__(64) void cache_kernel(
                     snrow = s_tmp;
                 }
                 // -------- row scan: 16 nodes per lane and slot ---------------------------------
-                const uint4* rowp = (const uint4*)(s_tab + (size_t)k * stride);
                 unsigned key = 0;
 #pragma unroll
                 for (int q = 0; q < SLOTS; ++q) {
                     const int b = q * 64 + lane;
                     if (SLOTS == 1 || q * 64 < nblk) {
-                        const uint4 R = rowp[b < nblk ? b : 0];
+                        const uint4 Rq = R[q];
                         // key16 = byte << 4 | (15 - position): max = best base score, first position on ties
                         const unsigned M8 = 0x00FF00FFu;
 #define SIMON_LO(w, q4) ((((w) & M8) << 4) | (unsigned)((15 - (q4)) | ((15 - ((q4) + 2)) << 16)))
 #define SIMON_HI(w, q4) (((((w) >> 8) & M8) << 4) | (unsigned)((15 - ((q4) + 1)) | ((15 - ((q4) + 3)) << 16)))
-                        unsigned m0 = pkmax(SIMON_LO(R.x, 0), SIMON_HI(R.x, 0));
-                        unsigned m1 = pkmax(SIMON_LO(R.y, 4), SIMON_HI(R.y, 4));
-                        unsigned m2 = pkmax(SIMON_LO(R.z, 8), SIMON_HI(R.z, 8));
-                        unsigned m3 = pkmax(SIMON_LO(R.w, 12), SIMON_HI(R.w, 12));
+                        unsigned m0 = pkmax(SIMON_LO(Rq.x, 0), SIMON_HI(Rq.x, 0));
+                        unsigned m1 = pkmax(SIMON_LO(Rq.y, 4), SIMON_HI(Rq.y, 4));
+                        unsigned m2 = pkmax(SIMON_LO(Rq.z, 8), SIMON_HI(Rq.z, 8));
+                        unsigned m3 = pkmax(SIMON_LO(Rq.w, 12), SIMON_HI(Rq.w, 12));
 #undef SIMON_LO
 #undef SIMON_HI
                         m0 = pkmax(pkmax(m0, m1), pkmax(m2, m3));
@@ -303,30 +340,81 @@ __global__ __launch_bounds__(64) void cache_kernel(
         // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column ---------
         if (pstar >= 0) {
             const SigRow& cur_sig = s_sig[r_sig];
-            uint4 st = s_state[pstar];
-            st.x += (unsigned)cur_sig.req_c;
-            st.y += (unsigned)cur_sig.req_m;
-            st.z -= 1u;
+            const unsigned add_c = (unsigned)cur_sig.req_c, add_m = (unsigned)cur_sig.req_m;
+            const int blk = pstar >> 4, owner = blk & 63, pos = pstar & 15;
+            const unsigned old = (sc.ablate & 1) ? 1u : my_col[pstar]; // this signature's byte before the cycle
+            unsigned st_c, st_m, shape_id, dcls;
+            int st_f;
             double nzc = 0.0, nzm = 0.0;
-            if (!NZEQ) {
-                uint2 z = s_nz[pstar];
-                z.x += (unsigned)cur_sig.nz_c;
-                z.y += (unsigned)cur_sig.nz_m;
-                if (lane == 0) s_nz[pstar] = z;
-                nzc = (double)z.x; nzm = (double)z.y;
+            if (REGSTATE) {
+                unsigned v_c = 0, v_m = 0, v_f = 0;
+                const int t_idx = (blk >> 6) * 16 + pos;
+#define SIMON_CASE(t)                                                                                       \
+    case (t):                                                                                               \
+        v_c = (unsigned)__builtin_amdgcn_readlane((int)rqc[(t) < SLOTS * 16 ? (t) : 0], owner) + add_c;     \
+        v_m = (unsigned)__builtin_amdgcn_readlane((int)rqm[(t) < SLOTS * 16 ? (t) : 0], owner) + add_m;     \
+        v_f = (unsigned)__builtin_amdgcn_readlane((int)fps[(t) < SLOTS * 16 ? (t) : 0], owner) - 256u;      \
+        if (lane == owner) { rqc[(t) < SLOTS * 16 ? (t) : 0] = v_c; rqm[(t) < SLOTS * 16 ? (t) : 0] = v_m; fps[(t) < SLOTS * 16 ? (t) : 0] = v_f; } \
+        break;
+                switch (t_idx) {
+                    SIMON_ST16(SIMON_CASE, 0)
+                    SIMON_ST16(SIMON_CASE, 16)
+                    default: break;
+                }
+#undef SIMON_CASE
+                st_c = v_c; st_m = v_m;
+                st_f = (int)v_f >> 8;                                  // |free pod slots| + P < 2^22 checked on the host
+                shape_id = v_f & 0xFFu;
+                dcls = (unsigned)__builtin_amdgcn_readlane(ncl4[0], owner) >> 2;
+                if (SLOTS > 1 && (blk >> 6)) dcls = (unsigned)__builtin_amdgcn_readlane(ncl4[SLOTS - 1], owner) >> 2;
+            } else {
+                uint4 st = (sc.ablate & 4) ? make_uint4(1, 1, 50, 0) : s_state[pstar];
+                st.x += add_c;
+                st.y += add_m;
+                st.z -= 1u;
+                if (!NZEQ) {
+                    uint2 z = s_nz[pstar];
+                    z.x += (unsigned)cur_sig.nz_c;
+                    z.y += (unsigned)cur_sig.nz_m;
+                    if (lane == 0) s_nz[pstar] = z;
+                    nzc = (double)z.x; nzm = (double)z.y;
+                }
+                if (lane == 0 && !(sc.ablate & 4)) s_state[pstar] = st;
+                st_c = st.x; st_m = st.y; st_f = (int)st.z; shape_id = st.w & 0xFFFFu; dcls = st.w >> 16;
             }
-            const unsigned old = my_col[pstar];
-            if (lane == 0) s_state[pstar] = st;
-            const ShapeRow sh = s_shape[st.w & 0xFFFFu];
-            unsigned nb = eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st.x, (double)st.y, nzc, nzm,
-                                    (int)st.z, sh);
-            nb = old ? nb : 0u;                                        // static mask / monotone infeasibility
-            if (lane < K && nb != old) {
+            const ShapeRow sh = s_shape[shape_id];
+            const unsigned nb_raw = (sc.ablate & 16) ? 100u : eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st_c,
+                                                                        (double)st_m, nzc, nzm, st_f, sh);
+            // -------- patch the prefetched row of the next pod (its load preceded this cycle's stores) ----
+            if (i + 1 < P) {
+                const int dwi = pos >> 2, sh8 = (pos & 3) * 8, qq = SLOTS > 1 ? (blk >> 6) : 0;
+                unsigned w = dwi == 0 ? Rn[0].x : dwi == 1 ? Rn[0].y : dwi == 2 ? Rn[0].z : Rn[0].w;
+                if (SLOTS > 1) {
+                    const unsigned w1 = dwi == 0 ? Rn[SLOTS - 1].x : dwi == 1 ? Rn[SLOTS - 1].y : dwi == 2 ? Rn[SLOTS - 1].z : Rn[SLOTS - 1].w;
+                    w = qq ? w1 : w;
+                }
+                const unsigned wo = (unsigned)__builtin_amdgcn_readlane((int)w, owner);
+                const unsigned old_n = (wo >> sh8) & 0xFFu;
+                const unsigned new_n = old_n ? (unsigned)__builtin_amdgcn_readlane((int)nb_raw, k_next) : 0u;
+                const unsigned wn = (wo & ~(0xFFu << sh8)) | (new_n << sh8);
+                const bool mine = lane == owner;
+                switch (qq * 4 + dwi) {
+                    case 0: Rn[0].x = mine ? wn : Rn[0].x; break;
+                    case 1: Rn[0].y = mine ? wn : Rn[0].y; break;
+                    case 2: Rn[0].z = mine ? wn : Rn[0].z; break;
+                    case 3: Rn[0].w = mine ? wn : Rn[0].w; break;
+                    case 4: Rn[SLOTS - 1].x = mine ? wn : Rn[SLOTS - 1].x; break;
+                    case 5: Rn[SLOTS - 1].y = mine ? wn : Rn[SLOTS - 1].y; break;
+                    case 6: Rn[SLOTS - 1].z = mine ? wn : Rn[SLOTS - 1].z; break;
+                    default: Rn[SLOTS - 1].w = mine ? wn : Rn[SLOTS - 1].w; break;
+                }
+            }
+            // -------- table column + feasible-node counters (off the critical path) -------------------
+            const unsigned nb = old ? nb_raw : 0u;                     // static mask / monotone infeasibility
+            if (lane < K && nb != old && !(sc.ablate & 2)) {
                 my_col[pstar] = (unsigned char)nb;
-                if (!nb) s_cnt[(st.w >> 16) * 64 + lane] -= 1;
+                if (!nb) s_cnt[dcls * 64 + lane] -= 1;
             }
-            // HBM workspace: the column bytes and the state row must have left this wave's store queue before
-            // other lanes load them (one wave: the TCP serves its accesses in order; the wait makes it explicit)
 #ifdef SIMON_CACHE_DRAIN_STORES
             if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -340,7 +428,12 @@ __global__ __launch_bounds__(64) void cache_kernel(
 
     // ---- epilogue: sum of Requested over the scenario's nodes -------------------------------
     long long uc = 0, um = 0;
-    for (int p = lane; p < ni; p += 64) { const uint4 st = s_state[p]; uc += st.x; um += st.y; }
+    if (REGSTATE) {
+#pragma unroll
+        for (int t = 0; t < SLOTS * 16; ++t) { uc += rqc[t]; um += rqm[t]; }
+    } else {
+        for (int p = lane; p < ni; p += 64) { const uint4 st = s_state[p]; uc += st.x; um += st.y; }
+    }
     uc = wave_sum_i64(uc);
     um = wave_sum_i64(um);
     if (lane == 0) {
@@ -363,9 +456,9 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restric
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
 }
 
-template <int SLOTS, bool M, bool Z, bool G>
+template <int SLOTS, bool M, bool Z, bool G, bool R>
 static hipError_t launch_smz(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = cache_kernel<SLOTS, M, Z, G>;
+    auto kern = cache_kernel<SLOTS, M, Z, G, R>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.ncls, a.rank, a.shape_of, a.a_pods, a.i_rq_cpu,
@@ -377,8 +470,11 @@ static hipError_t launch_smz(const CacheLaunch& a, int n_blocks, size_t lds, hip
 
 template <int SLOTS, bool G>
 static hipError_t launch_s(const CacheLaunch& a, int n_blocks, bool m, bool z, size_t lds, hipStream_t st) {
-    if (m) return z ? launch_smz<SLOTS, true, true, G>(a, n_blocks, lds, st) : launch_smz<SLOTS, true, false, G>(a, n_blocks, lds, st);
-    return z ? launch_smz<SLOTS, false, true, G>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, false, G>(a, n_blocks, lds, st);
+    if (G && z && a.reg_state) {   // node state in registers: NonZeroRequested == Requested, HBM workspace for the table
+        return m ? launch_smz<SLOTS, true, true, G, G>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, true, G, G>(a, n_blocks, lds, st);
+    }
+    if (m) return z ? launch_smz<SLOTS, true, true, G, false>(a, n_blocks, lds, st) : launch_smz<SLOTS, true, false, G, false>(a, n_blocks, lds, st);
+    return z ? launch_smz<SLOTS, false, true, G, false>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, false, G, false>(a, n_blocks, lds, st);
 }
 
 size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global) {

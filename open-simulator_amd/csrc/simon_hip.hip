@@ -88,6 +88,8 @@ struct simon_ctx : simon::HostInputs {
     bool fast_ok = false, nzeq = false;  // simon_fast.hip eligibility
     // ---- simon_cache.hip (LDS score table, one wave per scenario) ----
     bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
+    int ablate = 0;
+    bool cache_reg_ok = false, no_reg_state = false;  // |alloc_pods - init_npods|, P < 2^22; env SIMON_CACHE_NO_REGSTATE
     bool cache_global = true;   // env SIMON_CACHE_GLOBAL=0: keep the score table + node state in LDS instead of the HBM workspace
     DevBuf<unsigned char> d_ws;
     int n_sigs = 0, n_shapes = 0, max_bands = 8;
@@ -264,6 +266,12 @@ int stage_narrow(simon_ctx* c) {
             rank[j] = prefix[(size_t)j * c->Cn + d];
             for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
         }
+        c->cache_reg_ok = true;
+        for (int j = 0; j < N; ++j) {
+            const long long fr = (long long)c->alloc_pods[j] - c->i_npods[j];
+            if (fr < -(1 << 22) || fr > (1 << 22)) c->cache_reg_ok = false;
+        }
+        if (P >= (1 << 22)) c->cache_reg_ok = false;
         if (c->cache_ok) {
             c->n_sigs = (int)sigs.size(); c->n_shapes = (int)shapes.size();
             if (sigs.empty()) sigs.push_back(SigRow{});
@@ -374,6 +382,8 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
     if (const char* e = getenv("SIMON_CACHE_GLOBAL")) c->cache_global = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_CACHE_NO_REGSTATE")) c->no_reg_state = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_CACHE_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
     bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 8 && ok; ++i)
@@ -628,8 +638,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
                 f.perm = c->d_perm.p + bd.start;
                 f.ws = glob ? c->d_ws.p + bd.ws_off : nullptr;
+                f.reg_state = glob && c->nzeq && c->cache_reg_ok && !c->no_reg_state;
                 f.sc = CacheScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max,
-                                    cache_stride(bd.ni_max), c->g_cpu, c->g_mem};
+                                    cache_stride(bd.ni_max), c->ablate, c->g_cpu, c->g_mem};
                 HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, bd.lds, bs));
                 if (bs != c->stream) {
                     HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
