@@ -29,7 +29,6 @@ struct PodRowC { int32_t sig, preset, gate, cls; };   // 16 B, one s_load_dwordx
 struct CacheScalars {
     int32_t mask_words, Cn, Cp, P, S, K, n_shapes;
     int32_t ni_max;      // padded scenario size bound of this launch (multiple of 16, <= 2032)
-    int32_t stride;      // table row stride in bytes: >= ni_max, odd multiple of 16
     int32_t ablate;      // timing experiments only (env SIMON_CACHE_ABLATE): results are wrong when non-zero
     uint64_t g_cpu, g_mem;
 };
@@ -39,8 +38,7 @@ struct CacheLaunch {
     const int32_t *i_npods, *clsprefix; const SigRow* sigs; const ShapeRow* shapes; const PodRowC* pods;
     const int32_t* orders; const ScenarioDesc* scen; const int32_t* perm; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem; int32_t* place_step;
-    bool reg_state;      // keep Requested / free pod slots of every node in VGPRs (needs ws, nzeq, |free pod slots| and P < 2^22, <= 256 shapes)
-    unsigned char* ws;   // HBM workspace [n_blocks][cache_ws_bytes] (table + node state) or nullptr = LDS-resident
+    unsigned char* ws;   // HBM workspace [n_blocks][cache_ws_bytes]: tiles + node state
     CacheScalars sc;
 };
 
@@ -50,12 +48,12 @@ constexpr int kCacheMaxSigs = 64;       // one lane per signature
 constexpr int kCacheMaxShapes = 256;
 constexpr size_t kLdsPerCU = 160 * 1024;
 
-inline int cache_stride(int ni) {       // >= ni (a multiple of 16), odd multiple of 16: the K column bytes spread over 8 bank groups
-    return (ni / 16) % 2 ? ni : ni + 16;
-}
-size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global);
-size_t cache_ws_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
-// launches a.sc.S scenarios (blocks), scenario of block b = a.perm[b]
+// summary row pitch in u16 entries: >= nblk and == 2 (mod 4), so the K column entries of one block
+// (pitch * 2 bytes apart) fall into distinct LDS banks
+__host__ __device__ inline int cache_nbp(int nblk) { return nblk + ((2 - (nblk & 3)) & 3); }
+size_t cache_lds_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
+size_t cache_ws_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
+// launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
                             int32_t* placement, hipStream_t st);

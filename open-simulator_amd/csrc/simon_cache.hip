@@ -1,30 +1,35 @@
 // simon_cache.hip -- NARROW kernel, third generation: one WAVE = one capacity-planning scenario,
-// per-(pod signature, node) score table resident in LDS.
+// a two-level (signature, node) score table instead of re-evaluating every node for every pod.
 //
 // Observation ("further lever"): a scheduling cycle changes ONE node.  For a pod
 // stream drawn from K <= 64 distinct request signatures (replicas of workloads), the pair
-// (feasible?, LeastAllocated + BalancedAllocation) of every (signature, node) is therefore a
-// table with K x n one-byte entries of which only one COLUMN (K bytes) changes per cycle:
-//   * filter + score of a pod  = read ONE ROW of the table (n bytes, ds_read_b128: 16 nodes per
-//     lane), packed 16-bit max tree, one DPP wave reduction            -> findNodesThatFitPod +
-//     prioritizeNodes + selectHost (V/core/generic_scheduler.go:131-209);
-//   * assume (V/scheduler.go:371 -> NodeInfo.AddPod, V/framework/types.go:482-508) = lane k
-//     re-evaluates signature k on the touched node with EXACTLY the arithmetic of
-//     simon_fast.hip (same fp64 sequences => same bits) and stores one byte.
-// Nodes are laid out class-major inside a scenario (stable in canonical order, every class
-// segment padded to 16) so that the 16 nodes of a lane share their Simon node class: the
-// normalised Simon/Open-Gpu-Share term (pkg/simulator/plugin/simon.go:76-101) is then one add per
-// lane AFTER the in-lane max.  Ties are broken on the canonical node index carried in the key,
-// i.e. determinised selectHost = first maximum in nodeTree.list() order.
+// (feasible?, LeastAllocated + BalancedAllocation) of every (signature, node) is a table of
+// one-byte entries (0 = NodeResourcesFit fails, else 1 + score <= 201) of which only the K bytes
+// of the touched node change per cycle.  Two levels:
+//   * TILES in an HBM workspace (L2-resident): tile[block of 16 nodes][signature][16 bytes].  The
+//     K bytes of one node are 16 bytes apart inside one <= 1 KiB tile, so the update of a cycle is
+//     ONE coalesced 16-byte-per-lane load (lane k: signature k's 16 nodes of the touched block)
+//     and one byte store per lane into the same few cache lines -- no scattered accesses;
+//   * SUMMARY in LDS: sum[signature][block] = max over the block of (byte << 4 | 15 - position)
+//     as u16, i.e. the best base score of the block and the FIRST node that reaches it.
+// Per pod (findNodesThatFitPod + prioritizeNodes + selectHost, V/core/generic_scheduler.go:131-209):
+// read one summary row (2 bytes per 16 nodes), add the normalised Simon/Open-Gpu-Share term of
+// the block's node class (pkg/simulator/plugin/simon.go:76-101; nodes are laid out class-major,
+// stable in canonical order, every class padded to 16, so a block has ONE class), build
+// key = total << 22 | (2047 - canonical index) << 11 | position, one DPP wave max = first maximum
+// in nodeTree.list() order (determinised selectHost).  assume (V/scheduler.go:371 ->
+// NodeInfo.AddPod, V/framework/types.go:482-508): lane k re-evaluates signature k on the touched
+// node with EXACTLY the fp64 sequences of simon_fast.hip, patches its 16-byte tile row, stores
+// the byte, re-reduces the 16 bytes and stores the new summary entry.
 // The per-signature count of feasible nodes per node class is maintained incrementally
 // (feasibility only ever decreases: Requested grows, free pod slots shrink), which replaces the
 // phase-A reduction of the earlier generations by one LDS read + ballot.
 //
-// No barriers (one wave), no global traffic in the loop except the scalar pod-row stream and one
-// coalesced 256-byte placement store per 64 cycles.
+// No barriers (one wave).  Global traffic per cycle: one 16 B state row, <= 1 KiB of tile, K byte
+// stores into that tile; placements leave as one coalesced 256 B store per 64 cycles.
 //
-// Eligibility (host, simon_hip.hip): NARROW preconditions + K <= 64 signatures, <= 64 node
-// shapes, Cn <= 32, no zero-capacity node, padded scenario size <= 2047, LDS <= 160 KiB.
+// Eligibility (host, simon_hip.hip): NARROW preconditions + K <= 64 signatures, <= 256 node
+// shapes, Cn <= 32, no zero-capacity node, padded scenario size <= 2032, orders are permutations.
 #include "simon_cache.h"
 
 #include <algorithm>
@@ -42,41 +47,61 @@ __device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
 }
 
-// LDS carve (all offsets multiples of 16).  GLOBAL: the score table and the node state live in a
-// per-workgroup HBM workspace (L2 / Infinity-Cache resident) instead of LDS.
+// max over the 16 bytes of one tile row of (byte << 4 | 15 - position)
+__device__ __forceinline__ unsigned block_key16(const uint4 R) {
+    const unsigned M8 = 0x00FF00FFu;
+#define SIMON_LO(w, q4) ((((w) & M8) << 4) | (unsigned)((15 - (q4)) | ((15 - ((q4) + 2)) << 16)))
+#define SIMON_HI(w, q4) (((((w) >> 8) & M8) << 4) | (unsigned)((15 - ((q4) + 1)) | ((15 - ((q4) + 3)) << 16)))
+    unsigned m0 = pkmax(SIMON_LO(R.x, 0), SIMON_HI(R.x, 0));
+    unsigned m1 = pkmax(SIMON_LO(R.y, 4), SIMON_HI(R.y, 4));
+    unsigned m2 = pkmax(SIMON_LO(R.z, 8), SIMON_HI(R.z, 8));
+    unsigned m3 = pkmax(SIMON_LO(R.w, 12), SIMON_HI(R.w, 12));
+#undef SIMON_LO
+#undef SIMON_HI
+    m0 = pkmax(pkmax(m0, m1), pkmax(m2, m3));
+    return max(m0 & 0xFFFFu, m0 >> 16);
+}
+
+// max over each 16-lane row (result in every lane of the row)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+    v = max(v, (unsigned)SIMON_DPP(0, (int)v, 0xB1, 0xF));
+    v = max(v, (unsigned)SIMON_DPP(0, (int)v, 0x4E, 0xF));
+    v = max(v, (unsigned)SIMON_DPP(0, (int)v, 0x141, 0xF));
+    v = max(v, (unsigned)SIMON_DPP(0, (int)v, 0x140, 0xF));
+    return v;
+}
+
 struct Carve {
-    int tab, state, nz, canon, cnt, raw, sn2, sig, shape, seg, tmp, total;
-    int ws_tab, ws_state, ws_nz, ws_total;   // workspace offsets (GLOBAL only)
+    int sum, canon, cnt, raw, sn2, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
+    int ws_tile, ws_state, ws_nz, ws_total;                  // HBM workspace offsets per scenario
+    int nbp, Kp;
 };
-__host__ __device__ inline Carve carve(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global) {
+__host__ __device__ inline Carve carve(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
     auto al = [](int x) { return (x + 15) & ~15; };
     Carve c;
+    const int nblk = ni_max / 16;
+    c.nbp = cache_nbp(nblk);
+    c.Kp = (K + 3) & ~3;
+    if (c.Kp < 4) c.Kp = 4;
     int o = 0;
-    c.tab = o; o += global ? 0 : al(K * stride);
-    c.state = o; o += global ? 0 : ni_max * 16;
-    c.nz = o; o += (global || nzeq) ? 0 : al(ni_max * 8);
+    c.sum = o; o += al(K * c.nbp * 2);
     c.canon = o; o += al(ni_max * 2);
     c.cnt = o; o += Cn * 64 * 4;
     c.raw = o; o += al(Cp * Cn * 4);
     c.sn2 = o; o += al(Cp * Cn * 4);
-    c.sig = o; o += K * 48;
     c.shape = o; o += n_shapes * 48;
     c.seg = o; o += 32 * 4;
     c.tmp = o; o += 32 * 4;
     c.total = o;
     int w = 0;
-    c.ws_tab = w; w += (al(K * stride) + 127) & ~127;
+    c.ws_tile = w; w += (nblk * c.Kp * 16 + 127) & ~127;
     c.ws_state = w; w += (ni_max * 16 + 127) & ~127;
     c.ws_nz = w; w += nzeq ? 0 : ((ni_max * 8 + 127) & ~127);
     c.ws_total = w;
     return c;
 }
 
-// 32-way uniform switch over the register-resident node state (REGSTATE)
-#define SIMON_ST16(X, o) X(o + 0) X(o + 1) X(o + 2) X(o + 3) X(o + 4) X(o + 5) X(o + 6) X(o + 7) X(o + 8) X(o + 9) X(o + 10) \
-    X(o + 11) X(o + 12) X(o + 13) X(o + 14) X(o + 15)
-
-template <int SLOTS, bool HAS_MASK, bool NZEQ, bool GLOBAL, bool REGSTATE>
+template <bool HAS_MASK, bool NZEQ>
 __global__ __launch_bounds__(64) void cache_kernel(
     const int32_t* __restrict__ ncls, const int32_t* __restrict__ rank, const int32_t* __restrict__ shape_of,
     const int32_t* __restrict__ a_pods, const uint32_t* __restrict__ i_rq_cpu, const uint32_t* __restrict__ i_rq_mem,
@@ -87,17 +112,18 @@ __global__ __launch_bounds__(64) void cache_kernel(
     int32_t* __restrict__ unscheduled, int64_t* __restrict__ used_cpu, int64_t* __restrict__ used_mem,
     int32_t* __restrict__ place_step, unsigned char* ws, const CacheScalars sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K, stride = sc.stride;
-    const Carve cv = carve(K, stride, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ, GLOBAL);
-    unsigned char* const wsb = GLOBAL ? ws + (size_t)blockIdx.x * (size_t)cv.ws_total : nullptr;
-    unsigned char* s_tab = GLOBAL ? wsb + cv.ws_tab : smem + cv.tab;
-    uint4* s_state = (uint4*)(GLOBAL ? wsb + cv.ws_state : smem + cv.state);   // {Requested cpu, mem, free pod slots, shape | class<<16}
-    uint2* s_nz = (uint2*)(GLOBAL ? wsb + cv.ws_nz : smem + cv.nz);            // NonZeroRequested {cpu, mem} (only when !NZEQ)
+    const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
+    const Carve cv = carve(K, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ);
+    const int nbp = cv.nbp, Kp = cv.Kp;
+    unsigned char* const wsb = ws + (size_t)blockIdx.x * (size_t)cv.ws_total;
+    unsigned char* g_tile = wsb + cv.ws_tile;                 // [block][Kp][16] bytes
+    uint4* g_state = (uint4*)(wsb + cv.ws_state);             // {Requested cpu, mem, free pod slots, shape | class<<16}
+    uint2* g_nz = (uint2*)(wsb + cv.ws_nz);                   // NonZeroRequested {cpu, mem} (only when !NZEQ)
+    unsigned short* s_sum = (unsigned short*)(smem + cv.sum); // [K][nbp]
     unsigned short* s_canon = (unsigned short*)(smem + cv.canon);
-    int* s_cnt = (int*)(smem + cv.cnt);              // [Cn][64]: feasible nodes of class d for signature k
+    int* s_cnt = (int*)(smem + cv.cnt);                       // [Cn][64]: feasible nodes of class d for signature k
     int* s_raw = (int*)(smem + cv.raw);
     int* s_sn2 = (int*)(smem + cv.sn2);
-    const SigRow* s_sig = (const SigRow*)(smem + cv.sig);
     const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);
     int* s_seg = (int*)(smem + cv.seg);
     int* s_tmp = (int*)(smem + cv.tmp);
@@ -108,10 +134,9 @@ __global__ __launch_bounds__(64) void cache_kernel(
     const int32_t* __restrict__ order = orders + (size_t)scen[s].order_id * P;
 
     // ---- prologue 1: clear, tables -> LDS ----------------------------------------------------
-    if (!GLOBAL) for (int i = lane; i < cv.canon / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);   // tab, state, nz
+    for (int i = lane; i < cv.canon / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);   // summary
     for (int i = lane; i < Cn * 64; i += 64) s_cnt[i] = 0;
     for (int i = lane; i < Cp * Cn; i += 64) s_raw[i] = simon_raw[i];
-    for (int i = lane; i < K * 12; i += 64) ((int*)(smem + cv.sig))[i] = ((const int*)sigs)[i];
     for (int i = lane; i < sc.n_shapes * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
     for (int i = lane; i < sc.ni_max; i += 64) s_canon[i] = 0xFFFFu;
     // class segments: count of class-d nodes among the first n canonical nodes, padded to 16
@@ -125,6 +150,7 @@ __global__ __launch_bounds__(64) void cache_kernel(
     }
     if (lane < 32) s_seg[lane] = incl - pad_d;
     const int ni = __builtin_amdgcn_readlane(incl, 31);               // padded scenario size (lanes >= Cn add 0)
+    const int nblk = ni >> 4;
     const unsigned bits_all = (unsigned)__ballot(cnt_d > 0);
     __syncthreads();
     // ---- prologue 2: scatter canonical indices into the class-major layout ------------------
@@ -165,7 +191,7 @@ __global__ __launch_bounds__(64) void cache_kernel(
         return ok ? (unsigned)(base + 1) : 0u;
     };
 
-    // ---- prologue 3: node rows + the whole table; lanes = 64 consecutive positions, loop over signatures
+    // ---- prologue 3: node rows, tiles and summary; lanes = 64 consecutive positions (4 blocks) ----
     for (int p0 = 0; p0 < ni; p0 += 64) {
         const int p = p0 + lane;
         const unsigned cj = p < ni ? s_canon[p] : 0xFFFFu;
@@ -177,15 +203,16 @@ __global__ __launch_bounds__(64) void cache_kernel(
                               : make_uint4(0, 0, 0, 0);
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
-        if (!REGSTATE && p < sc.ni_max) {
-            s_state[p] = st;
-            if (!NZEQ) s_nz[p] = z;
+        if (p < ni) {
+            g_state[p] = st;
+            if (!NZEQ) g_nz[p] = z;
         }
         const ShapeRow sh = s_shape[st.w & 0xFFFFu];
         // classes present in this chunk form a contiguous range (class-major layout)
         const int dlo = wave_min_i32(real ? d : 0x7fffffff), dhi = wave_max_i32(real ? d : (int)0x80000000);
+        unsigned char* tp = g_tile + ((size_t)(p >> 4) * Kp) * 16 + (p & 15);
         for (int k = 0; k < K; ++k) {
-            const SigRow q = s_sig[k];
+            const SigRow q = sigs[k];
             unsigned b = eval_node(q.req_c, q.req_m, q.nz_c, q.nz_m, q.flags & 1u, (double)st.x, (double)st.y, (double)z.x,
                                    (double)z.y, (int)st.z, sh);
             b = real ? b : 0u;
@@ -193,45 +220,34 @@ __global__ __launch_bounds__(64) void cache_kernel(
                 const uint64_t w = static_mask[(size_t)q.cls * sc.mask_words + (j >> 6)];
                 b = ((w >> (j & 63)) & 1ull) ? b : 0u;
             }
-            if (p < stride) s_tab[(size_t)k * stride + p] = (unsigned char)b;
+            if (p < ni) tp[k * 16] = (unsigned char)b;
+            const unsigned m16 = row16_max_u32((b << 4) | (unsigned)(15 - (p & 15)));
+            if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
             for (int dd = dlo; dd <= dhi; ++dd) {
                 const int c = __popcll(__ballot(b != 0u && d == dd));
                 if (lane == 0 && c) s_cnt[dd * 64 + k] += c;
             }
         }
     }
-    if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // this lane's signature (lane k re-evaluates signature k on a touched node)
     const int kk = lane < K ? lane : 0;
-    const double my_req_c = s_sig[kk].req_c, my_req_m = s_sig[kk].req_m;
-    const double my_nz_c = s_sig[kk].nz_c, my_nz_m = s_sig[kk].nz_m;
-    const bool my_zero = s_sig[kk].flags & 1u;
-    unsigned char* my_col = s_tab + (size_t)kk * stride;
+    const SigRow mysig = sigs[kk];
+    const double my_req_c = mysig.req_c, my_req_m = mysig.req_m, my_nz_c = mysig.nz_c, my_nz_m = mysig.nz_m;
+    const bool my_zero = mysig.flags & 1u;
+    const unsigned my_add_c = (unsigned)mysig.req_c, my_add_m = (unsigned)mysig.req_m;
+    const unsigned my_addz_c = (unsigned)mysig.nz_c, my_addz_m = (unsigned)mysig.nz_m;
+    unsigned short* my_sum = s_sum + kk * nbp;
 
-    // node class of this lane's 16-node blocks (class segments are multiples of 16); REGSTATE: the
-    // dynamic state of those 16 x SLOTS nodes lives in this lane's registers
-    const int nblk = ni >> 4;
-    int ncl4[SLOTS];
-    unsigned rqc[REGSTATE ? SLOTS * 16 : 1], rqm[REGSTATE ? SLOTS * 16 : 1], fps[REGSTATE ? SLOTS * 16 : 1];
+    // node class of this lane's two blocks (class segments are multiples of 16)
+    int ncl4[2];
 #pragma unroll
-    for (int q = 0; q < SLOTS; ++q) {
+    for (int q = 0; q < 2; ++q) {
         const int b = q * 64 + lane;
         const unsigned cj0 = (b < nblk) ? s_canon[b * 16] : 0xFFFFu;
         ncl4[q] = (cj0 != 0xFFFFu) ? ncls[cj0] * 4 : 0;
-        if (REGSTATE) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const unsigned cj = (b < nblk) ? s_canon[b * 16 + t] : 0xFFFFu;
-                const bool real = cj != 0xFFFFu;
-                const int j = real ? (int)cj : 0;
-                rqc[q * 16 + t] = real ? i_rq_cpu[j] : 0u;
-                rqm[q * 16 + t] = real ? i_rq_mem[j] : 0u;
-                // free pod slots << 8 (signed, upper 24 bits: decrements never borrow from the shape id) | shape
-                fps[q * 16 + t] = real ? (((unsigned)(a_pods[j] - i_npods[j]) << 8) | (unsigned)shape_of[j]) : 0u;
-            }
-        }
     }
 
     int unsched = 0, plreg = 0;
@@ -247,30 +263,11 @@ __global__ __launch_bounds__(64) void cache_kernel(
     };
     if (P > 0) nxt = load_chunk(0);
 
-    // table row of the NEXT pod's signature, loaded one cycle ahead; the one byte the current
-    // cycle changes in it is patched in registers
-    uint4 Rn[SLOTS];
-    auto load_row = [&](int k) {
-        const uint4* rowp = (const uint4*)(s_tab + (size_t)k * stride);
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) {
-            const int b = q * 64 + lane;
-            if (SLOTS == 1 || q * 64 < nblk) Rn[q] = rowp[b < nblk ? b : 0];
-            else Rn[q] = make_uint4(0, 0, 0, 0);
-        }
-    };
-    if (P > 0) load_row(__builtin_amdgcn_readlane(nxt.x, 0));
-
     for (int i = 0; i < P; ++i) {
         const int il = i & 63;
         if (il == 0) { cur = nxt; nxt = load_chunk(i + 64); }
         const int r_sig = __builtin_amdgcn_readlane(cur.x, il), r_preset = __builtin_amdgcn_readlane(cur.y, il);
         const int r_gate = __builtin_amdgcn_readlane(cur.z, il), r_cls = __builtin_amdgcn_readlane(cur.w, il);
-        const int k_next = il < 63 ? __builtin_amdgcn_readlane(cur.x, (il + 1) & 63) : __builtin_amdgcn_readlane(nxt.x, 0);
-        uint4 R[SLOTS];
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) R[q] = Rn[q];
-        if (i + 1 < P && !(sc.ablate & 8)) load_row(k_next);
 
         int res, pstar = -1;
         if (r_gate >= n) {
@@ -304,32 +301,22 @@ __global__ __launch_bounds__(64) void cache_kernel(
                     __builtin_amdgcn_wave_barrier();
                     snrow = s_tmp;
                 }
-                // -------- row scan: 16 nodes per lane and slot ---------------------------------
+                // -------- summary scan: one u16 per block of 16 nodes, two blocks per lane ---------
+                const unsigned short* srow = s_sum + k * nbp;
                 unsigned key = 0;
 #pragma unroll
-                for (int q = 0; q < SLOTS; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     const int b = q * 64 + lane;
-                    if (SLOTS == 1 || q * 64 < nblk) {
-                        const uint4 Rq = R[q];
-                        // key16 = byte << 4 | (15 - position): max = best base score, first position on ties
-                        const unsigned M8 = 0x00FF00FFu;
-#define SIMON_LO(w, q4) ((((w) & M8) << 4) | (unsigned)((15 - (q4)) | ((15 - ((q4) + 2)) << 16)))
-#define SIMON_HI(w, q4) (((((w) >> 8) & M8) << 4) | (unsigned)((15 - ((q4) + 1)) | ((15 - ((q4) + 3)) << 16)))
-                        unsigned m0 = pkmax(SIMON_LO(Rq.x, 0), SIMON_HI(Rq.x, 0));
-                        unsigned m1 = pkmax(SIMON_LO(Rq.y, 4), SIMON_HI(Rq.y, 4));
-                        unsigned m2 = pkmax(SIMON_LO(Rq.z, 8), SIMON_HI(Rq.z, 8));
-                        unsigned m3 = pkmax(SIMON_LO(Rq.w, 12), SIMON_HI(Rq.w, 12));
-#undef SIMON_LO
-#undef SIMON_HI
-                        m0 = pkmax(pkmax(m0, m1), pkmax(m2, m3));
-                        const unsigned m16 = max(m0 & 0xFFFFu, m0 >> 16);
-                        const unsigned M = m16 >> 4;                   // 0: no feasible node here; else 1 + LA + BA
+                    if (q == 0 || nblk > 64) {
+                        const bool in = b < nblk;
+                        const unsigned m16 = srow[in ? b : 0];
+                        const unsigned M = m16 >> 4;                   // 0: no feasible node in the block; else 1 + LA + BA
                         const int p = b * 16 + 15 - (int)(m16 & 15u);
-                        const unsigned canon = s_canon[b < nblk ? p : 0];
+                        const unsigned canon = s_canon[in ? p : 0];
                         const int sn2 = *(const int*)((const char*)snrow + ncl4[q]);
                         // total = BA + LA + Simon + GpuShare (weights: registry.go:118-131, utils.go:321-333)
                         const unsigned kq = ((M - 1u + (unsigned)sn2) << 22) | ((2047u - canon) << 11) | (unsigned)p;
-                        key = max(key, (M != 0u && b < nblk) ? kq : 0u);
+                        key = max(key, (M != 0u && in) ? kq : 0u);
                     }
                 }
                 key = wave_max_u32(key);
@@ -337,87 +324,44 @@ __global__ __launch_bounds__(64) void cache_kernel(
                 res = (int)(2047u - ((key >> 11) & 2047u));           // first maximum in canonical order
             }
         }
-        // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column ---------
+        // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + tile row + summary ----
         if (pstar >= 0) {
-            const SigRow& cur_sig = s_sig[r_sig];
-            const unsigned add_c = (unsigned)cur_sig.req_c, add_m = (unsigned)cur_sig.req_m;
-            const int blk = pstar >> 4, owner = blk & 63, pos = pstar & 15;
-            const unsigned old = (sc.ablate & 1) ? 1u : my_col[pstar]; // this signature's byte before the cycle
-            unsigned st_c, st_m, shape_id, dcls;
-            int st_f;
+            const int blk = pstar >> 4, pos = pstar & 15;
+            const int dwi = pos >> 2, sh8 = (pos & 3) * 8;
+            uint4* my_row = (uint4*)(g_tile + ((size_t)blk * Kp + kk) * 16);
+            uint4 T = (sc.ablate & 1) ? make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u) : *my_row;
+            uint4 st = (sc.ablate & 4) ? make_uint4(1, 1, 50, 0) : g_state[pstar];
+            st.x += (unsigned)__builtin_amdgcn_readlane((int)my_add_c, r_sig);
+            st.y += (unsigned)__builtin_amdgcn_readlane((int)my_add_m, r_sig);
+            st.z -= 1u;
             double nzc = 0.0, nzm = 0.0;
-            if (REGSTATE) {
-                unsigned v_c = 0, v_m = 0, v_f = 0;
-                const int t_idx = (blk >> 6) * 16 + pos;
-#define SIMON_CASE(t)                                                                                       \
-    case (t):                                                                                               \
-        v_c = (unsigned)__builtin_amdgcn_readlane((int)rqc[(t) < SLOTS * 16 ? (t) : 0], owner) + add_c;     \
-        v_m = (unsigned)__builtin_amdgcn_readlane((int)rqm[(t) < SLOTS * 16 ? (t) : 0], owner) + add_m;     \
-        v_f = (unsigned)__builtin_amdgcn_readlane((int)fps[(t) < SLOTS * 16 ? (t) : 0], owner) - 256u;      \
-        if (lane == owner) { rqc[(t) < SLOTS * 16 ? (t) : 0] = v_c; rqm[(t) < SLOTS * 16 ? (t) : 0] = v_m; fps[(t) < SLOTS * 16 ? (t) : 0] = v_f; } \
-        break;
-                switch (t_idx) {
-                    SIMON_ST16(SIMON_CASE, 0)
-                    SIMON_ST16(SIMON_CASE, 16)
-                    default: break;
-                }
-#undef SIMON_CASE
-                st_c = v_c; st_m = v_m;
-                st_f = (int)v_f >> 8;                                  // |free pod slots| + P < 2^22 checked on the host
-                shape_id = v_f & 0xFFu;
-                dcls = (unsigned)__builtin_amdgcn_readlane(ncl4[0], owner) >> 2;
-                if (SLOTS > 1 && (blk >> 6)) dcls = (unsigned)__builtin_amdgcn_readlane(ncl4[SLOTS - 1], owner) >> 2;
-            } else {
-                uint4 st = (sc.ablate & 4) ? make_uint4(1, 1, 50, 0) : s_state[pstar];
-                st.x += add_c;
-                st.y += add_m;
-                st.z -= 1u;
-                if (!NZEQ) {
-                    uint2 z = s_nz[pstar];
-                    z.x += (unsigned)cur_sig.nz_c;
-                    z.y += (unsigned)cur_sig.nz_m;
-                    if (lane == 0) s_nz[pstar] = z;
-                    nzc = (double)z.x; nzm = (double)z.y;
-                }
-                if (lane == 0 && !(sc.ablate & 4)) s_state[pstar] = st;
-                st_c = st.x; st_m = st.y; st_f = (int)st.z; shape_id = st.w & 0xFFFFu; dcls = st.w >> 16;
+            if (!NZEQ) {
+                uint2 z = g_nz[pstar];
+                z.x += (unsigned)__builtin_amdgcn_readlane((int)my_addz_c, r_sig);
+                z.y += (unsigned)__builtin_amdgcn_readlane((int)my_addz_m, r_sig);
+                if (lane == 0) g_nz[pstar] = z;
+                nzc = (double)z.x; nzm = (double)z.y;
             }
-            const ShapeRow sh = s_shape[shape_id];
-            const unsigned nb_raw = (sc.ablate & 16) ? 100u : eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st_c,
-                                                                        (double)st_m, nzc, nzm, st_f, sh);
-            // -------- patch the prefetched row of the next pod (its load preceded this cycle's stores) ----
-            if (i + 1 < P) {
-                const int dwi = pos >> 2, sh8 = (pos & 3) * 8, qq = SLOTS > 1 ? (blk >> 6) : 0;
-                unsigned w = dwi == 0 ? Rn[0].x : dwi == 1 ? Rn[0].y : dwi == 2 ? Rn[0].z : Rn[0].w;
-                if (SLOTS > 1) {
-                    const unsigned w1 = dwi == 0 ? Rn[SLOTS - 1].x : dwi == 1 ? Rn[SLOTS - 1].y : dwi == 2 ? Rn[SLOTS - 1].z : Rn[SLOTS - 1].w;
-                    w = qq ? w1 : w;
-                }
-                const unsigned wo = (unsigned)__builtin_amdgcn_readlane((int)w, owner);
-                const unsigned old_n = (wo >> sh8) & 0xFFu;
-                const unsigned new_n = old_n ? (unsigned)__builtin_amdgcn_readlane((int)nb_raw, k_next) : 0u;
-                const unsigned wn = (wo & ~(0xFFu << sh8)) | (new_n << sh8);
-                const bool mine = lane == owner;
-                switch (qq * 4 + dwi) {
-                    case 0: Rn[0].x = mine ? wn : Rn[0].x; break;
-                    case 1: Rn[0].y = mine ? wn : Rn[0].y; break;
-                    case 2: Rn[0].z = mine ? wn : Rn[0].z; break;
-                    case 3: Rn[0].w = mine ? wn : Rn[0].w; break;
-                    case 4: Rn[SLOTS - 1].x = mine ? wn : Rn[SLOTS - 1].x; break;
-                    case 5: Rn[SLOTS - 1].y = mine ? wn : Rn[SLOTS - 1].y; break;
-                    case 6: Rn[SLOTS - 1].z = mine ? wn : Rn[SLOTS - 1].z; break;
-                    default: Rn[SLOTS - 1].w = mine ? wn : Rn[SLOTS - 1].w; break;
-                }
-            }
-            // -------- table column + feasible-node counters (off the critical path) -------------------
+            if (lane == 0 && !(sc.ablate & 4)) g_state[pstar] = st;
+            const ShapeRow sh = s_shape[st.w & 0xFFFFu];
+            const unsigned nb_raw = (sc.ablate & 16) ? 100u : eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st.x,
+                                                                        (double)st.y, nzc, nzm, (int)st.z, sh);
+            const unsigned wsel = dwi == 0 ? T.x : dwi == 1 ? T.y : dwi == 2 ? T.z : T.w;
+            const unsigned old = (wsel >> sh8) & 0xFFu;                // this signature's byte before the cycle
             const unsigned nb = old ? nb_raw : 0u;                     // static mask / monotone infeasibility
-            if (lane < K && nb != old && !(sc.ablate & 2)) {
-                my_col[pstar] = (unsigned char)nb;
-                if (!nb) s_cnt[dcls * 64 + lane] -= 1;
+            const unsigned wnew = (wsel & ~(0xFFu << sh8)) | (nb << sh8);
+            T.x = dwi == 0 ? wnew : T.x;
+            T.y = dwi == 1 ? wnew : T.y;
+            T.z = dwi == 2 ? wnew : T.z;
+            T.w = dwi == 3 ? wnew : T.w;
+            // One wave: its vector memory accesses are served in order, so the next cycle's loads of this
+            // tile row / state row observe these stores (same guarantee the LLVM memory model gives
+            // wavefront-scope ordering); no cache maintenance, no wait.
+            if (lane < K && nb != old) {
+                if (!(sc.ablate & 2)) ((unsigned char*)my_row)[pos] = (unsigned char)nb;
+                my_sum[blk] = (unsigned short)block_key16(T);
+                if (!nb) s_cnt[(st.w >> 16) * 64 + lane] -= 1;
             }
-#ifdef SIMON_CACHE_DRAIN_STORES
-            if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             __builtin_amdgcn_wave_barrier();
         }
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
@@ -428,12 +372,7 @@ __global__ __launch_bounds__(64) void cache_kernel(
 
     // ---- epilogue: sum of Requested over the scenario's nodes -------------------------------
     long long uc = 0, um = 0;
-    if (REGSTATE) {
-#pragma unroll
-        for (int t = 0; t < SLOTS * 16; ++t) { uc += rqc[t]; um += rqm[t]; }
-    } else {
-        for (int p = lane; p < ni; p += 64) { const uint4 st = s_state[p]; uc += st.x; um += st.y; }
-    }
+    for (int p = lane; p < ni; p += 64) { const uint4 st = g_state[p]; uc += st.x; um += st.y; }
     uc = wave_sum_i64(uc);
     um = wave_sum_i64(um);
     if (lane == 0) {
@@ -456,9 +395,9 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restric
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
 }
 
-template <int SLOTS, bool M, bool Z, bool G, bool R>
-static hipError_t launch_smz(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = cache_kernel<SLOTS, M, Z, G, R>;
+template <bool M, bool Z>
+static hipError_t launch_mz(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    auto kern = cache_kernel<M, Z>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.ncls, a.rank, a.shape_of, a.a_pods, a.i_rq_cpu,
@@ -468,31 +407,17 @@ static hipError_t launch_smz(const CacheLaunch& a, int n_blocks, size_t lds, hip
     return hipGetLastError();
 }
 
-template <int SLOTS, bool G>
-static hipError_t launch_s(const CacheLaunch& a, int n_blocks, bool m, bool z, size_t lds, hipStream_t st) {
-    if (G && z && a.reg_state) {   // node state in registers: NonZeroRequested == Requested, HBM workspace for the table
-        return m ? launch_smz<SLOTS, true, true, G, G>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, true, G, G>(a, n_blocks, lds, st);
-    }
-    if (m) return z ? launch_smz<SLOTS, true, true, G, false>(a, n_blocks, lds, st) : launch_smz<SLOTS, true, false, G, false>(a, n_blocks, lds, st);
-    return z ? launch_smz<SLOTS, false, true, G, false>(a, n_blocks, lds, st) : launch_smz<SLOTS, false, false, G, false>(a, n_blocks, lds, st);
+size_t cache_lds_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+    return (size_t)carve(K, ni_max, Cn, Cp, n_shapes, nzeq).total;
+}
+size_t cache_ws_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+    return (size_t)carve(K, ni_max, Cn, Cp, n_shapes, nzeq).ws_total;
 }
 
-size_t cache_lds_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq, bool global) {
-    return (size_t)carve(K, stride, ni_max, Cn, Cp, n_shapes, nzeq, global).total;
-}
-size_t cache_ws_bytes(int K, int stride, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
-    return (size_t)carve(K, stride, ni_max, Cn, Cp, n_shapes, nzeq, true).ws_total;
-}
-
-// n_blocks scenarios; scenario of block b = a.perm[b]; a.ws != nullptr selects the HBM-workspace variant
+// n_blocks scenarios; scenario of block b = a.perm[b]; a.ws = [n_blocks][cache_ws_bytes]
 hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    const int slots = (a.sc.ni_max / 16 + 63) / 64;
-    const bool g = a.ws != nullptr;
-    switch (slots) {
-        case 1: return g ? launch_s<1, true>(a, n_blocks, has_mask, nzeq, lds_bytes, st) : launch_s<1, false>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
-        case 2: return g ? launch_s<2, true>(a, n_blocks, has_mask, nzeq, lds_bytes, st) : launch_s<2, false>(a, n_blocks, has_mask, nzeq, lds_bytes, st);
-        default: return hipErrorInvalidValue;
-    }
+    if (has_mask) return nzeq ? launch_mz<true, true>(a, n_blocks, lds_bytes, st) : launch_mz<true, false>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_mz<false, true>(a, n_blocks, lds_bytes, st) : launch_mz<false, false>(a, n_blocks, lds_bytes, st);
 }
 
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,

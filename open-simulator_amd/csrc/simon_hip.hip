@@ -89,10 +89,8 @@ struct simon_ctx : simon::HostInputs {
     // ---- simon_cache.hip (LDS score table, one wave per scenario) ----
     bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
     int ablate = 0;
-    bool cache_reg_ok = false, no_reg_state = false;  // |alloc_pods - init_npods|, P < 2^22; env SIMON_CACHE_NO_REGSTATE
-    bool cache_global = true;   // env SIMON_CACHE_GLOBAL=0: keep the score table + node state in LDS instead of the HBM workspace
     DevBuf<unsigned char> d_ws;
-    int n_sigs = 0, n_shapes = 0, max_bands = 8;
+    int n_sigs = 0, n_shapes = 0, max_bands = 4;
     DevBuf<SigRow> d_sigs;
     DevBuf<ShapeRow> d_shapes;
     DevBuf<PodRowC> d_podsC;
@@ -266,12 +264,6 @@ int stage_narrow(simon_ctx* c) {
             rank[j] = prefix[(size_t)j * c->Cn + d];
             for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
         }
-        c->cache_reg_ok = true;
-        for (int j = 0; j < N; ++j) {
-            const long long fr = (long long)c->alloc_pods[j] - c->i_npods[j];
-            if (fr < -(1 << 22) || fr > (1 << 22)) c->cache_reg_ok = false;
-        }
-        if (P >= (1 << 22)) c->cache_reg_ok = false;
         if (c->cache_ok) {
             c->n_sigs = (int)sigs.size(); c->n_shapes = (int)shapes.size();
             if (sigs.empty()) sigs.push_back(SigRow{});
@@ -381,8 +373,6 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
-    if (const char* e = getenv("SIMON_CACHE_GLOBAL")) c->cache_global = atoi(e) != 0;
-    if (const char* e = getenv("SIMON_CACHE_NO_REGSTATE")) c->no_reg_state = atoi(e) != 0;
     if (const char* e = getenv("SIMON_CACHE_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
     bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
@@ -592,35 +582,29 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
         bool use_cache = c->cache_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kCacheMaxNodes;
-        const bool glob = c->cache_global;
-        auto lds_of = [&](int ni) { ni = std::max(ni, 16); return cache_lds_bytes(c->n_sigs, cache_stride(ni), ni, c->Cn, c->Cp, c->n_shapes, c->nzeq, glob); };
-        auto ws_of = [&](int ni) { ni = std::max(ni, 16); return cache_ws_bytes(c->n_sigs, cache_stride(ni), ni, c->Cn, c->Cp, c->n_shapes, c->nzeq); };
+        auto lds_of = [&](int ni) { return cache_lds_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq); };
+        auto ws_of = [&](int ni) { return cache_ws_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq); };
         if (use_cache) {
             int ni_top = 0;
             for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
             use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
         }
         if (use_cache) {
-            // Bands: scenarios in LPT order (largest first) are cut where the launch shape changes -- LDS variant:
-            // the number of workgroups that fit one CU's 160 KiB of LDS; HBM-workspace variant: every 256 padded
-            // nodes (row stride, slots per lane).  Every band is its own launch on its own stream, so small
-            // scenarios run at higher residency while the big ones are still going.
+            // Bands: scenarios in LPT order (largest first) are cut into at most max_bands launches of equal
+            // scenario count; each band sizes its LDS summary and HBM workspace for its own largest scenario and
+            // runs on its own stream (the hardware exposes 4 compute queues; more bands would serialise).
             struct Band { int start, count, ni_max; size_t lds, ws_off; };
             std::vector<Band> bands;
-            auto band_key = [&](int ni) { return glob ? (std::max(ni, 16) + 255) / 256 : (int)(kLdsPerCU / lds_of(ni)); };
+            const int nb = std::max(1, std::min(c->max_bands, S));
             size_t ws_total = 0;
-            for (int b = 0; b < S;) {
-                const int ni0 = c->scen_ni[c->h_perm[b]];
-                const int key0 = band_key(ni0);
-                int e = b + 1;
-                if ((int)bands.size() + 1 < c->max_bands)
-                    while (e < S && band_key(c->scen_ni[c->h_perm[e]]) == key0) ++e;
-                else e = S;
-                bands.push_back(Band{b, e - b, std::max(ni0, 16), lds_of(ni0), ws_total});
-                ws_total += glob ? ws_of(ni0) * (size_t)(e - b) : 0;
-                b = e;
+            for (int bi = 0; bi < nb; ++bi) {
+                const int b = (int)((long long)S * bi / nb), e = (int)((long long)S * (bi + 1) / nb);
+                if (e <= b) continue;
+                const int ni0 = std::max(c->scen_ni[c->h_perm[b]], 16);
+                bands.push_back(Band{b, e - b, ni0, lds_of(ni0), ws_total});
+                ws_total += ws_of(ni0) * (size_t)(e - b);
             }
-            if (glob) HIP_TRY(c, c->d_ws.ensure(ws_total));
+            HIP_TRY(c, c->d_ws.ensure(ws_total));
             if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
             CacheLaunch f{};
             f.ncls = c->d_ncls.p; f.rank = c->d_rank.p; f.shape_of = c->d_shape_of.p; f.a_pods = c->d_a_pods.p;
@@ -637,10 +621,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 hipStream_t bs = bands.size() == 1 ? c->stream : c->band_stream[bi];
                 if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
                 f.perm = c->d_perm.p + bd.start;
-                f.ws = glob ? c->d_ws.p + bd.ws_off : nullptr;
-                f.reg_state = glob && c->nzeq && c->cache_reg_ok && !c->no_reg_state;
+                f.ws = c->d_ws.p + bd.ws_off;
                 f.sc = CacheScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max,
-                                    cache_stride(bd.ni_max), c->ablate, c->g_cpu, c->g_mem};
+                                    c->ablate, c->g_cpu, c->g_mem};
                 HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, bd.lds, bs));
                 if (bs != c->stream) {
                     HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
@@ -651,7 +634,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 HIP_TRY(c, launch_unpermute(c->d_place_step.p, c->d_inv_orders.p, c->d_scen.p, S, P, c->d_place.p, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
             variant_used = SIMON_KERNEL_NARROW_CACHE;
-            T = 64; slots = (bands[0].ni_max / 16 + 63) / 64; lds = bands[0].lds;
+            T = 64; slots = 2; lds = bands[0].lds;
             c->stats.n_launches = (int)bands.size();
         } else if (c->fast_ok && !c->force_v1 && T >= 128) {
             lds = ((size_t)c->Cp * c->Cn * 2 * sizeof(int32_t) + 15) & ~(size_t)15;
