@@ -165,3 +165,80 @@ def config4(rank: int = 0, world: int = 1, n_counts: int = 1024, n_orders: int =
     # interleave over node counts so that every rank gets every size (cost ~ n): order scenarios by
     # (count index, order) and deal them round-robin
     return prob, np.ascontiguousarray(scen[rank::world]), orders
+
+
+def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_orders: int = 4, n_groups: int = 50,
+            group_size: int = 100, seed: int = SEED + 5):
+    """gpushare-style workload (BASELINE config 5 / SURVEY 8d): 30 % GPU nodes (4 or 8 devices x 16 GiB), 20 % GPU
+    pods (gpu-mem 2/4/8/16 GiB, count 1/1/1/2), `n_groups` groups of `group_size` pods with required self
+    anti-affinity on kubernetes.io/hostname, 10 % of the nodes tainted NoSchedule with 20 % of the pods tolerating.
+    Scenarios: node counts spread over the upper half of the pool x `n_orders` pod orders."""
+    GiB = 1 << 30
+    rng = SplitMix64(seed)
+    cpu, mem, pods, ncls = gen_nodes(seed, n_nodes, n_nodes)
+    gpu_cnt = np.zeros(n_nodes, np.int32)
+    tainted = np.zeros(n_nodes, bool)
+    for j in range(n_nodes):
+        r = rng.next() % 100
+        if r < 30:
+            gpu_cnt[j] = 4 if (rng.next() & 1) else 8
+        tainted[j] = (rng.next() % 100) < 10
+    gpu_total = gpu_cnt.astype(np.int64) * 16 * GiB
+    pcpu, pmem = gen_pods(seed, n_pods)
+    gmem = np.zeros(n_pods, np.int64)
+    gcnt = np.zeros(n_pods, np.int32)
+    tol = np.zeros(n_pods, bool)
+    group = np.full(n_pods, -1, np.int32)
+    for p in range(n_pods):
+        if rng.next() % 100 < 20:
+            k = rng.next() % 4
+            gmem[p] = (2, 4, 8, 16)[k] * GiB
+            gcnt[p] = (1, 1, 1, 2)[k]
+        tol[p] = (rng.next() % 100) < 20
+    for g in range(n_groups):                                   # group g = pods g*group_size .. (members interleaved below)
+        group[g * group_size:(g + 1) * group_size] = g
+    perm = np.arange(n_pods)
+    r2 = SplitMix64(seed + 99)
+    for i in range(n_pods - 1, 0, -1):
+        j = r2.next() % (i + 1)
+        perm[i], perm[j] = perm[j], perm[i]
+    group = group[perm]                                         # scatter the group members over the stream
+    # pod classes: (cpu, mem) shape x tolerates x anti-affinity group (-1 = none); GPU demand is per pod, not per class
+    ids, table, pcls = {}, [], np.empty(n_pods, np.int32)
+    for p, key in enumerate(zip(pcpu.tolist(), pmem.tolist(), tol.tolist(), group.tolist())):
+        if key not in ids:
+            ids[key] = len(table)
+            table.append(key)
+        pcls[p] = ids[key]
+    Cp = len(table)
+    words = (n_nodes + 63) // 64
+    all_mask = np.zeros(words, np.uint64)
+    untainted = np.zeros(words, np.uint64)
+    for j in range(n_nodes):
+        all_mask[j // 64] |= np.uint64(1) << np.uint64(j % 64)
+        if not tainted[j]:
+            untainted[j // 64] |= np.uint64(1) << np.uint64(j % 64)
+    mask = np.stack([all_mask if t[2] else untainted for t in table])
+    reason = np.zeros((Cp, n_nodes), np.uint8)
+    for c, t in enumerate(table):
+        if not t[2]:
+            reason[c, tainted] = 7                              # host id of "node(s) had taint {dedicated: }, ..."
+    raw_shapes = simon_raw_table([(t[0], t[1]) for t in table])
+    # term g = (namespace, selector of group g, topologyKey hostname); class with group g both requires and matches it
+    anti_off, anti_idx, match_off, match_idx = [0], [], [0], []
+    for t in table:
+        if t[3] >= 0:
+            anti_idx.append(t[3]); match_idx.append(t[3])
+        anti_off.append(len(anti_idx)); match_off.append(len(match_idx))
+    prob = Problem(alloc_cpu=cpu, alloc_mem=mem, alloc_pods=pods, node_class=ncls, gpu_cnt=gpu_cnt, gpu_mem_total=gpu_total,
+                   topo_dom=np.arange(n_nodes, dtype=np.int32)[None], topo_n_dom=np.array([n_nodes], np.int32),
+                   req_cpu=pcpu, req_mem=pmem, pod_class=pcls, gpu_mem=gmem, pod_gpu_cnt=gcnt,
+                   n_pod_classes=Cp, n_node_classes=4, static_mask=mask, static_reason=reason, simon_raw=raw_shapes,
+                   const_score=np.full(Cp, CONST_SCORE, np.int64), term_topo_key=np.zeros(n_groups, np.int32),
+                   anti_off=np.array(anti_off, np.int32), anti_idx=np.array(anti_idx or [0], np.int32),
+                   match_off=np.array(match_off, np.int32), match_idx=np.array(match_idx or [0], np.int32)).normalise()
+    orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
+    n_counts = max(1, n_scen // n_orders)
+    counts = np.linspace(n_nodes // 2, n_nodes, n_counts).astype(np.int32)
+    scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)
+    return prob, np.ascontiguousarray(scen, np.int32), orders

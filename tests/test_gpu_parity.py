@@ -173,6 +173,20 @@ def test_random_wide_features(idx):
         assert_same(res, ref)
 
 
+def test_config5_gpushare_style():
+    """BASELINE config 5 shape (GPU share + required anti-affinity + taints): small pool, every placement compared;
+    then ONE scenario at full size (50k pods x 5k nodes)."""
+    prob, scen, orders = synth.config5(n_pods=5000, n_nodes=500, n_scen=16, n_orders=2, n_groups=10, group_size=50)
+    ref = O.run(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_WIDE
+    assert_same(res, ref)
+    assert ref.unscheduled.max() > 0 and ref.unscheduled.min() == 0        # the sweep crosses the feasibility boundary
+    prob, scen, orders = synth.config5()
+    sub = scen[[len(scen) // 2 + 1]]
+    assert_same(run_gpu(prob, sub, orders)[0], O.run(prob, sub, orders))
+
+
 def test_gpushare_example_and_hand_cases_on_gpu():
     from test_oracle import gpushare_problem
     prob = gpushare_problem()
@@ -229,6 +243,27 @@ def test_size_independent_properties_full_batch():
         ctx.run_loaded(want_placement=False)
         again = ctx.fetch(want_placement=False)
         assert_same(again, res)
+
+
+def test_golden_fixtures_on_gpu():
+    """HIP path against the committed fixtures (tests/golden/), no oracle in the loop."""
+    import golden_util as G
+    for name in G.SMALL:
+        d, prob, scen, orders = G.load(name)
+        for env in ({}, {"SIMON_NO_CACHE": "1"}, {"SIMON_FORCE_WIDE": "1"}):
+            G.check_against(d, run_gpu(prob, scen, orders, env=env)[0])
+    dg = G.digests()
+    for hom in (False, True):
+        prob, scen, orders = synth.config2(hom)
+        r, _ = run_gpu(prob, scen, orders)
+        want = dg[f"config2_{'homogeneous' if hom else 'heterogeneous'}"]
+        assert r.unscheduled.tolist() == want["unscheduled"] and G.sha(r.placement) == want["placement_sha256"]
+    prob, scen, orders = synth.config3()
+    want = dg["config3_subset"]
+    r, variant = run_gpu(prob, scen[want["pick"]], orders)
+    assert variant == capi.KERNEL_NARROW_CACHE
+    assert r.unscheduled.tolist() == want["unscheduled"] and r.used_cpu.tolist() == want["used_cpu"]
+    assert [G.sha(row) for row in r.placement] == want["placement_sha256"]
 
 
 def test_errors_are_reported_not_thrown():

@@ -1,0 +1,84 @@
+"""CPU tests of the host-side mirror: FitError strings, the C-ABI surface, Quantity conversions."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+import oracle_lib as O
+from open_simulator_amd import capi, fiterror
+from open_simulator_amd.quantity import parse_quantity as pq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GiB = 1 << 30
+
+
+def test_fit_error_string_matches_reference_format():
+    # 3 nodes: cpu+mem short, cpu short, too many pods + mem short (same case as test_oracle.test_fit_reasons...)
+    prob = capi.Problem(alloc_cpu=[1000, 1000, 4000], alloc_mem=[GiB, 4 * GiB, GiB], alloc_pods=[110, 110, 0],
+                        req_cpu=[2000], req_mem=[2 * GiB], n_pod_classes=1, n_node_classes=1)
+    _, (nf, failed, codes) = O.run(prob, [[3, 0]], np.arange(1)[None], explain_scenario=0, max_failed=2)
+    assert nf == 1
+    msg = fiterror.fit_error(codes[0])
+    # V/core/generic_scheduler.go:72-90: "<count> <reason>" sorted as strings
+    assert msg == "0/3 nodes are available: 1 Too many pods, 2 Insufficient cpu, 2 Insufficient memory."
+    full = fiterror.unscheduled_reason("simple", "big-pod", codes[0])
+    assert full.startswith("failed to schedule pod (simple/big-pod): Unschedulable: 0/3 nodes are available: ")
+
+
+def test_fit_error_mixed_plugins():
+    F = capi
+    codes = [F.FAIL_STATIC | 7, F.FAIL_STATIC | 3, F.FAIL_ANTI_INCOMING, F.FAIL_ANTI_EXISTING, F.FAIL_GPUSHARE,
+             F.FAIL_FIT | F.FIT_CPU | (F.FIT_SCALAR0 << 1)]
+    msg = fiterror.fit_error(codes, node_names=[f"n{j}" for j in range(6)],
+                             static_reasons={7: fiterror.taint_reason("node-role.kubernetes.io/master", "")},
+                             scalar_names=["example.com/foo", "alibabacloud.com/gpu-count"])
+    assert msg == ("0/6 nodes are available: 1 Insufficient alibabacloud.com/gpu-count, 1 Insufficient cpu, 1 Node:n4, "
+                   "1 node(s) didn't match Pod's node affinity, 1 node(s) didn't match pod anti-affinity rules, "
+                   "1 node(s) didn't satisfy existing pods anti-affinity rules, "
+                   "1 node(s) had taint {node-role.kubernetes.io/master: }, that the pod didn't tolerate, "
+                   "2 node(s) didn't match pod affinity/anti-affinity.")
+
+
+def test_library_exports_every_declared_symbol():
+    """include/simon_hip.h is the contract: every function it declares must be exported (no compute calls here)."""
+    hdr = open(os.path.join(ROOT, "include", "simon_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(simon_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(capi.EXPORTS)
+    lib = ctypes.CDLL(capi.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.simon_hip_version() == capi.ABI_VERSION
+    # without a device the context constructor fails cleanly instead of crashing or falling back
+    lib.simon_ctx_create.restype = ctypes.c_void_p
+    if lib.simon_hip_device_count() == 0:
+        assert lib.simon_ctx_create(0) is None
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors must have the sizes the C compiler gives the header structs."""
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent("""
+        #include <stdio.h>
+        #include "simon_hip.h"
+        int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(simon_nodes_soa), sizeof(simon_pods_soa),
+            sizeof(simon_class_tables), sizeof(simon_scenario), sizeof(simon_batch_out), sizeof(simon_plan), sizeof(simon_stats)); return 0; }
+    """)
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, c])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    mine = [ctypes.sizeof(t) for t in (capi.NodesSoA, capi.PodsSoA, capi.ClassTables, capi.Scenario, capi.BatchOut, capi.Plan,
+                                       capi.Stats)]
+    assert sizes == mine
+
+
+def test_quantity_value_is_ceil():
+    # quantity.go:729-750: Value()/MilliValue() round up
+    assert pq("100m").milli_value() == 100 and pq("1").milli_value() == 1000
+    assert pq("1500m").int_value() == 2 and pq("0.5").milli_value() == 500
+    assert pq("16Gi").int_value() == 16 * GiB and pq("256000Mi").int_value() == 256000 << 20
+    assert pq("1n").milli_value() == 1
