@@ -33,11 +33,13 @@
 extern "C" {
 #endif
 
-#define SIMON_HIP_ABI_VERSION 1
+#define SIMON_HIP_ABI_VERSION 2
 
 #define SIMON_MAX_GPU_DEV 8 /* devices per GPU-share node (pkg/type/open-gpu-share/cache/gpunodeinfo.go:34-56) */
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
 #define SIMON_MAX_TERMS_PER_CLASS 8
+#define SIMON_MAX_SPREAD 4  /* PodTopologySpread constraints per pod class and kind */
+#define SIMON_CLASS_AFF_SELF 0x1u /* pods of the class match all of their own required affinity terms (filtering.go:361-371) */
 
 /* error codes */
 #define SIMON_OK 0
@@ -64,6 +66,9 @@ extern "C" {
 #define SIMON_FIT_SCALAR0 0x0010u          /* << k : "Insufficient <scalar k>" */
 #define SIMON_FAIL_ANTI_INCOMING 0x2001u   /* "node(s) didn't match pod affinity/anti-affinity" + "...anti-affinity rules" (interpodaffinity/filtering.go:392) */
 #define SIMON_FAIL_ANTI_EXISTING 0x2002u   /* "...didn't satisfy existing pods anti-affinity rules" (:396) */
+#define SIMON_FAIL_AFFINITY 0x2003u        /* "...affinity/anti-affinity" + "node(s) didn't match pod affinity rules" (:388; UnschedulableAndUnresolvable) */
+#define SIMON_FAIL_SPREAD 0x2010u          /* "node(s) didn't match pod topology spread constraints" (podtopologyspread/filtering.go:326) */
+#define SIMON_FAIL_SPREAD_LABEL 0x2011u    /* "... (missing required label)" (:303; UnschedulableAndUnresolvable) */
 #define SIMON_FAIL_GPUSHARE 0x1000u        /* reason "Node:<name>" (pkg/simulator/plugin/open-gpu-share.go:64-78) */
 
 /* ---------------------------------------------------------------------------------------------
@@ -141,14 +146,67 @@ typedef struct simon_class_tables {
      * (pod class, node allocatable) only */
     const int64_t* simon_raw;      /* [Cp][Cn] */
     const int64_t* const_score;    /* [Cp] sum of the constant-score plugins x weight; optional, reporting only */
-    /* required pod anti-affinity, both directions (V/framework/plugins/interpodaffinity/filtering.go:133-148,317-401).
-     * A "term" = one interned (namespace set, label selector, topology key) triple. */
+    /* ---- ABI v2: static score inputs per (pod class, node class); NULL = the plugin scores every node alike and the
+     * host folds its constant into const_score.  The host interns node classes so that nodes of one class share
+     * allocatable AND every label/taint/annotation these tables depend on. ---- */
+    const int64_t* node_affinity_raw; /* [Cp][Cn] NodeAffinity.Score: sum of the weights of the matching preferred terms
+                                         (V/framework/plugins/nodeaffinity/node_affinity.go:77-103); DefaultNormalizeScore(100, false) */
+    const int64_t* taint_prefer_raw;  /* [Cp][Cn] TaintToleration.Score: intolerable PreferNoSchedule taints
+                                         (tainttoleration/taint_toleration.go:123-151); DefaultNormalizeScore(100, true) */
+    const int64_t* static_add;        /* [Cp][Cn] already weighted, never normalised: NodePreferAvoidPods x 10000
+                                         (nodepreferavoidpods/node_prefer_avoid_pods.go:58-82) */
+    /* ---- topology terms.  A "term" = one interned (namespace set, label selector, topology key) triple; the engine
+     * keeps, per scenario and per term, cnt_match[t][domain] = placed pods the term's selector MATCHES in that
+     * topology domain.  InterPodAffinity (V/framework/plugins/interpodaffinity/{filtering,scoring}.go) and
+     * PodTopologySpread (podtopologyspread/{filtering,scoring}.go) are all expressed over these counters. ---- */
     int32_t n_terms;               /* T */
     const int32_t* term_topo_key;  /* [T] index into topo_dom rows */
-    const int32_t* anti_off;       /* [Cp+1] CSR: terms class c itself REQUIRES (its RequiredAntiAffinityTerms) */
-    const int32_t* anti_idx;
+    const int32_t* term_node_set;  /* [T] row of node_sets: placed pods are counted only on nodes of that set (PodTopologySpread
+                                      counts pods on nodes that pass the incoming pod's nodeSelector/affinity and carry all
+                                      constraint keys, filtering.go:236-247, scoring.go:137-141); -1 = every node; optional */
+    int32_t n_node_sets;           /* R */
+    const uint64_t* node_sets;     /* [R][ceil(N/64)] */
     const int32_t* match_off;      /* [Cp+1] CSR: terms whose (namespaces, selector) MATCH pods of class c */
     const int32_t* match_idx;
+    /* required anti-affinity, both directions (filtering.go:133-148,317-346): terms class c itself REQUIRES */
+    const int32_t* anti_off;       /* [Cp+1] */
+    const int32_t* anti_idx;
+    /* required affinity (filtering.go:116-131,348-377).  For a RequiredAffinityTerms list L the host interns, per term i,
+     * a DERIVED term (pods matching ALL selectors of L, key_i): "existing pod matches all terms" is then one counter.
+     * Node passes iff every key exists and every derived counter is > 0; else the first-pod escape: no pod anywhere
+     * matches (all derived totals 0) and the class matches its own terms (SIMON_CLASS_AFF_SELF). */
+    const int32_t* aff_off;        /* [Cp+1]; optional (no required affinity) */
+    const int32_t* aff_idx;
+    const uint8_t* class_flags;    /* [Cp] SIMON_CLASS_*; optional */
+    /* InterPodAffinity.Score (scoring.go:87-236), raw(c, node) =
+     *   sum_{(t,w) in pref(c)} w * cnt_match[t][dom_t(node)]      incoming pod's preferred (anti: w < 0) terms
+     * + sum_{t in match(c)}   w_owner[t][dom_t(node)]             existing pods' terms that match the incoming pod, where
+     *   AddPod of class e adds w to w_owner[t][dom] for every (t,w) in own(e): required affinity terms with
+     *   HardPodAffinityWeight (= 1, V/apis/config/v1beta1/defaults.go:179), preferred affinity +w, preferred anti -w.
+     * NormalizeScore (:239-277): min/max start at 0, int64(100 * (float64(raw-min)/float64(max-min))). */
+    const int32_t* pref_off;       /* [Cp+1]; optional */
+    const int32_t* pref_idx;
+    const int32_t* pref_w;
+    const int32_t* own_off;        /* [Cp+1]; optional */
+    const int32_t* own_idx;
+    const int32_t* own_w;
+    /* PodTopologySpread.  hard = DoNotSchedule constraints (filtering.go:283-333): node fails when a key is missing or
+     * cnt_match[t][dom] + self - min over the term's domains > maxSkew.  soft = ScheduleAnyway constraints incl. the
+     * system defaults maxSkew 3 on hostname / 5 on zone for pods selected by a Service/RC/RS/STS (plugin.go:39-50,
+     * common.go:45-60): Score/NormalizeScore of scoring.go:174-256. */
+    const int32_t* spread_hard_off;  /* [Cp+1]; optional */
+    const int32_t* spread_hard_idx;  /* term */
+    const int32_t* spread_hard_skew; /* maxSkew */
+    const int32_t* spread_hard_self; /* 1 when the pod matches its own constraint selector */
+    const int32_t* spread_hard_set;  /* row of node_sets: the nodes that register a domain and feed the global minimum
+                                        (pass the pod's nodeSelector/affinity and carry every hard key, filtering.go:236-251);
+                                        -1 = every node carrying this key; NULL = all -1 */
+    const int32_t* spread_soft_off;  /* [Cp+1]; optional */
+    const int32_t* spread_soft_idx;
+    const int32_t* spread_soft_skew;
+    const uint8_t* topo_is_hostname; /* [Kt] 1 for kubernetes.io/hostname (scoring.go:100-104: size = scored nodes); optional */
+    const double* spread_log;        /* [N+1] spread_log[i] = Go math.Log(float64(i+2)) (scoring.go:279-281); the Go host fills
+                                        it with its own math.Log so the engine never approximates it; required with soft */
 } simon_class_tables;
 
 /* One capacity-planning scenario = one simulator.Simulate() call of the apply loop

@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_GPU_DEV = 8
 MAX_SCALAR = 4
 
@@ -28,7 +28,12 @@ FAIL_FIT = 0x4000
 FIT_PODS, FIT_CPU, FIT_MEM, FIT_EPH, FIT_SCALAR0 = 0x1, 0x2, 0x4, 0x8, 0x10
 FAIL_ANTI_INCOMING = 0x2001
 FAIL_ANTI_EXISTING = 0x2002
+FAIL_AFFINITY = 0x2003
+FAIL_SPREAD = 0x2010
+FAIL_SPREAD_LABEL = 0x2011
 FAIL_GPUSHARE = 0x1000
+CLASS_AFF_SELF = 0x1
+MAX_SPREAD = 4
 
 KERNEL_NARROW = 1
 KERNEL_WIDE = 2
@@ -40,6 +45,7 @@ _p32 = C.POINTER(C.c_int32)
 _pu64 = C.POINTER(C.c_uint64)
 _pu8 = C.POINTER(C.c_uint8)
 _pu16 = C.POINTER(C.c_uint16)
+_pf64 = C.POINTER(C.c_double)
 
 
 class NodesSoA(C.Structure):
@@ -68,8 +74,17 @@ class ClassTables(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("n_pod_classes", C.c_int32), ("n_node_classes", C.c_int32),
         ("static_mask", _pu64), ("static_reason", _pu8), ("simon_raw", _p64), ("const_score", _p64),
-        ("n_terms", C.c_int32), ("term_topo_key", _p32),
-        ("anti_off", _p32), ("anti_idx", _p32), ("match_off", _p32), ("match_idx", _p32),
+        ("node_affinity_raw", _p64), ("taint_prefer_raw", _p64), ("static_add", _p64),
+        ("n_terms", C.c_int32), ("term_topo_key", _p32), ("term_node_set", _p32),
+        ("n_node_sets", C.c_int32), ("node_sets", _pu64),
+        ("match_off", _p32), ("match_idx", _p32), ("anti_off", _p32), ("anti_idx", _p32),
+        ("aff_off", _p32), ("aff_idx", _p32), ("class_flags", _pu8),
+        ("pref_off", _p32), ("pref_idx", _p32), ("pref_w", _p32),
+        ("own_off", _p32), ("own_idx", _p32), ("own_w", _p32),
+        ("spread_hard_off", _p32), ("spread_hard_idx", _p32), ("spread_hard_skew", _p32),
+        ("spread_hard_self", _p32), ("spread_hard_set", _p32),
+        ("spread_soft_off", _p32), ("spread_soft_idx", _p32), ("spread_soft_skew", _p32),
+        ("topo_is_hostname", _pu8), ("spread_log", _pf64),
     ]
 
 
@@ -161,11 +176,35 @@ class Problem:
     static_reason: Optional[np.ndarray] = None     # [Cp][N] uint8
     simon_raw: Optional[np.ndarray] = None         # [Cp][Cn]
     const_score: Optional[np.ndarray] = None       # [Cp]
+    node_affinity_raw: Optional[np.ndarray] = None  # [Cp][Cn]
+    taint_prefer_raw: Optional[np.ndarray] = None   # [Cp][Cn]
+    static_add: Optional[np.ndarray] = None         # [Cp][Cn]
     term_topo_key: Optional[np.ndarray] = None     # [T]
+    term_node_set: Optional[np.ndarray] = None     # [T]
+    node_sets: Optional[np.ndarray] = None         # [R][ceil(N/64)] uint64
     anti_off: Optional[np.ndarray] = None
     anti_idx: Optional[np.ndarray] = None
     match_off: Optional[np.ndarray] = None
     match_idx: Optional[np.ndarray] = None
+    aff_off: Optional[np.ndarray] = None
+    aff_idx: Optional[np.ndarray] = None
+    class_flags: Optional[np.ndarray] = None       # [Cp] uint8
+    pref_off: Optional[np.ndarray] = None
+    pref_idx: Optional[np.ndarray] = None
+    pref_w: Optional[np.ndarray] = None
+    own_off: Optional[np.ndarray] = None
+    own_idx: Optional[np.ndarray] = None
+    own_w: Optional[np.ndarray] = None
+    spread_hard_off: Optional[np.ndarray] = None
+    spread_hard_idx: Optional[np.ndarray] = None
+    spread_hard_skew: Optional[np.ndarray] = None
+    spread_hard_self: Optional[np.ndarray] = None
+    spread_hard_set: Optional[np.ndarray] = None
+    spread_soft_off: Optional[np.ndarray] = None
+    spread_soft_idx: Optional[np.ndarray] = None
+    spread_soft_skew: Optional[np.ndarray] = None
+    topo_is_hostname: Optional[np.ndarray] = None  # [Kt] uint8
+    spread_log: Optional[np.ndarray] = None        # [N+1] float64
     _keep: list = field(default_factory=list, repr=False)
 
     @property
@@ -215,13 +254,45 @@ class Problem:
             self.simon_raw = np.zeros((Cp, Cn), dtype=i64)
         self.simon_raw = _arr(self.simon_raw, i64, (Cp, Cn))
         self.const_score = _arr(self.const_score, i64, (Cp,)) if self.const_score is not None else None
+        for name in ("node_affinity_raw", "taint_prefer_raw", "static_add"):
+            v = getattr(self, name)
+            setattr(self, name, _arr(v, i64, (Cp, Cn)) if v is not None else None)
         if self.term_topo_key is not None:
             self.term_topo_key = _arr(self.term_topo_key, i32)
-            for name in ("anti_off", "match_off"):
-                setattr(self, name, _arr(getattr(self, name), i32, (Cp + 1,)))
-            for name in ("anti_idx", "match_idx"):
-                v = getattr(self, name)
-                setattr(self, name, _arr(v if v is not None and len(v) else np.zeros(1, i32), i32))
+            T = len(self.term_topo_key)
+            if self.term_node_set is not None:
+                self.term_node_set = _arr(self.term_node_set, i32, (T,))
+            if self.node_sets is not None:
+                self.node_sets = _arr(self.node_sets, np.uint64)
+                assert self.node_sets.ndim == 2 and self.node_sets.shape[1] == words
+            zero_off = np.zeros(Cp + 1, i32)
+            for off, cols in (("match_off", ("match_idx",)), ("anti_off", ("anti_idx",)), ("aff_off", ("aff_idx",)),
+                              ("pref_off", ("pref_idx", "pref_w")), ("own_off", ("own_idx", "own_w")),
+                              ("spread_hard_off", ("spread_hard_idx", "spread_hard_skew", "spread_hard_self",
+                                                   "spread_hard_set")),
+                              ("spread_soft_off", ("spread_soft_idx", "spread_soft_skew"))):
+                o = getattr(self, off)
+                if o is None:
+                    if off in ("match_off", "anti_off"):       # always materialised (ABI v1 compatibility of callers)
+                        setattr(self, off, zero_off.copy())
+                        for cname in cols:
+                            setattr(self, cname, np.zeros(1, i32))
+                    continue
+                o = _arr(o, i32, (Cp + 1,))
+                setattr(self, off, o)
+                for cname in cols:
+                    v = getattr(self, cname)
+                    if v is None and cname == "spread_hard_set":
+                        continue
+                    v = _arr(v if v is not None and len(v) else np.zeros(1, i32), i32)
+                    assert len(v) >= max(1, int(o[-1])), (cname, len(v), int(o[-1]))
+                    setattr(self, cname, v)
+            if self.class_flags is not None:
+                self.class_flags = _arr(self.class_flags, np.uint8, (Cp,))
+            if self.topo_is_hostname is not None:
+                self.topo_is_hostname = _arr(self.topo_is_hostname, np.uint8, (Kt,))
+            if self.spread_log is not None:
+                self.spread_log = _arr(self.spread_log, np.float64, (N + 1,))
         return self
 
     # --- C views ---------------------------------------------------------------------------
@@ -262,9 +333,19 @@ class Problem:
         s.static_reason = _ptr(self.static_reason, C.c_uint8)
         s.simon_raw = _ptr(self.simon_raw, C.c_int64)
         s.const_score = _ptr(self.const_score, C.c_int64)
+        for name in ("node_affinity_raw", "taint_prefer_raw", "static_add"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int64))
         s.n_terms = 0 if self.term_topo_key is None else len(self.term_topo_key)
-        for name in ("term_topo_key", "anti_off", "anti_idx", "match_off", "match_idx"):
-            setattr(s, name, _ptr(getattr(self, name), C.c_int32))
+        s.n_node_sets = 0 if self.node_sets is None else int(self.node_sets.shape[0])
+        s.node_sets = _ptr(self.node_sets, C.c_uint64)
+        for name in ("term_topo_key", "term_node_set", "match_off", "match_idx", "anti_off", "anti_idx", "aff_off",
+                     "aff_idx", "pref_off", "pref_idx", "pref_w", "own_off", "own_idx", "own_w", "spread_hard_off",
+                     "spread_hard_idx", "spread_hard_skew", "spread_hard_self", "spread_hard_set", "spread_soft_off",
+                     "spread_soft_idx", "spread_soft_skew"):
+            setattr(s, name, _ptr(getattr(self, name) if s.n_terms else None, C.c_int32))
+        s.class_flags = _ptr(self.class_flags, C.c_uint8)
+        s.topo_is_hostname = _ptr(self.topo_is_hostname, C.c_uint8)
+        s.spread_log = _ptr(self.spread_log, C.c_double)
         return s
 
 

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -73,7 +74,7 @@ struct simon_ctx : simon::HostInputs {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     // host copies of the inputs live in the HostInputs base (caller buffers are never retained)
-    bool have_nodes = false, have_pods = false, have_tables = false, staged = false;
+    bool have_nodes = false, have_pods = false, have_tables = false, staged = false, wide_staged = false;
     // ---- variant decision ----
     int variant = 0;
     uint64_t g_cpu = 1, g_mem = 1;
@@ -157,7 +158,7 @@ void choose_variant(simon_ctx* c) {
     c->variant = SIMON_KERNEL_WIDE;
     c->g_cpu = c->g_mem = 1;
     if (const char* f = getenv("SIMON_FORCE_WIDE")) if (f[0] == '1') return;
-    if (c->K > 0 || c->has_gpu || c->Tm > 0) return;
+    if (c->K > 0 || c->has_gpu || c->Tm > 0 || c->v2_features()) return;
     for (int64_t x : c->alloc_eph) if (x) return;
     for (int64_t x : c->i_req_eph) if (x) return;
     for (int64_t x : c->p_req_eph) if (x) return;
@@ -315,8 +316,10 @@ int stage(simon_ctx* c) {
     HIP_TRY(c, c->d_prefix_cpu.upload(pc, c->stream));
     HIP_TRY(c, c->d_prefix_mem.upload(pm, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->wide_staged = false;
     int rc = c->variant == SIMON_KERNEL_NARROW ? stage_narrow(c) : wide_stage(c->wide, *c, c->stream, c->err);
     if (rc) return rc;
+    c->wide_staged = c->variant != SIMON_KERNEL_NARROW;
     c->staged = true;
     return SIMON_OK;
 }
@@ -467,27 +470,89 @@ int simon_load_class_tables(simon_ctx* c, const simon_class_tables* tb) {
     copy_opt(c->static_reason, tb->static_reason, tb->static_reason ? (size_t)c->Cp * c->N : 0);
     copy_opt(c->simon_raw, tb->simon_raw, (size_t)c->Cp * c->Cn);
     copy_opt(c->const_score, tb->const_score, (size_t)c->Cp);
+    const size_t cells = (size_t)c->Cp * c->Cn;
+    c->has_na = tb->node_affinity_raw != nullptr; c->has_tt = tb->taint_prefer_raw != nullptr; c->has_add = tb->static_add != nullptr;
+    copy_opt(c->na_raw, tb->node_affinity_raw, c->has_na ? cells : 0);
+    copy_opt(c->tt_raw, tb->taint_prefer_raw, c->has_tt ? cells : 0);
+    copy_opt(c->static_add, tb->static_add, c->has_add ? cells : 0);
+    for (int64_t x : c->na_raw) if (x < 0 || x >= (1ll << 40)) return fail(c, SIMON_ERANGE, "node_affinity_raw outside [0, 2^40)");
+    for (int64_t x : c->tt_raw) if (x < 0 || x >= (1ll << 40)) return fail(c, SIMON_ERANGE, "taint_prefer_raw outside [0, 2^40)");
+    for (int64_t x : c->static_add) if (x < 0 || x >= (1ll << 30)) return fail(c, SIMON_ERANGE, "static_add outside [0, 2^30)");
     c->Tm = tb->n_terms;
     if (c->Tm < 0) return fail(c, SIMON_EINVAL, "n_terms < 0");
+    c->term_key.clear(); c->term_set.clear(); c->node_sets.clear(); c->R = 0;
+    c->match_off.clear(); c->match_idx.clear(); c->anti_off.clear(); c->anti_idx.clear(); c->aff_off.clear(); c->aff_idx.clear();
+    c->class_flags.clear(); c->pref_off.clear(); c->pref_idx.clear(); c->pref_w.clear(); c->own_off.clear(); c->own_idx.clear();
+    c->own_w.clear(); c->sh_off.clear(); c->sh_idx.clear(); c->sh_skew.clear(); c->sh_self.clear(); c->sh_set.clear();
+    c->ss_off.clear(); c->ss_idx.clear(); c->ss_skew.clear(); c->topo_is_hostname.clear(); c->spread_log.clear();
+    c->has_ipa_score = false;
     if (c->Tm > 0) {
-        if (!tb->term_topo_key || !tb->anti_off || !tb->match_off) return fail(c, SIMON_EINVAL, "anti-affinity CSR missing");
+        if (!tb->term_topo_key) return fail(c, SIMON_EINVAL, "term_topo_key missing");
         copy_opt(c->term_key, tb->term_topo_key, (size_t)c->Tm);
-        copy_opt(c->anti_off, tb->anti_off, (size_t)c->Cp + 1);
-        copy_opt(c->match_off, tb->match_off, (size_t)c->Cp + 1);
-        copy_opt(c->anti_idx, tb->anti_idx, (size_t)c->anti_off[c->Cp]);
-        copy_opt(c->match_idx, tb->match_idx, (size_t)c->match_off[c->Cp]);
         for (int t = 0; t < c->Tm; ++t)
             if (c->term_key[t] < 0 || c->term_key[t] >= c->Kt) return fail(c, SIMON_EINVAL, "term %d: topology key out of range", t);
-        for (int k = 0; k < c->Cp; ++k) {
-            if (c->anti_off[k + 1] - c->anti_off[k] > SIMON_MAX_TERMS_PER_CLASS * 4 || c->anti_off[k + 1] < c->anti_off[k] ||
-                c->match_off[k + 1] < c->match_off[k])
-                return fail(c, SIMON_EINVAL, "class %d: bad CSR", k);
+        c->R = tb->n_node_sets;
+        if (c->R < 0 || (c->R > 0 && !tb->node_sets)) return fail(c, SIMON_EINVAL, "node_sets missing");
+        copy_opt(c->node_sets, tb->node_sets, (size_t)c->R * words);
+        copy_opt(c->term_set, tb->term_node_set, (size_t)c->Tm, (int32_t)-1);
+        for (int32_t r : c->term_set) if (r < -1 || r >= c->R) return fail(c, SIMON_EINVAL, "term_node_set out of range");
+        // one CSR list per role; idx entries are term ids
+        struct Csr { const char* name; const int32_t* off; const int32_t* idx; std::vector<int32_t>* h_off; std::vector<int32_t>* h_idx; int cap; };
+        Csr lists[] = {
+            {"match", tb->match_off, tb->match_idx, &c->match_off, &c->match_idx, 1 << 20},
+            {"anti", tb->anti_off, tb->anti_idx, &c->anti_off, &c->anti_idx, SIMON_MAX_TERMS_PER_CLASS * 4},
+            {"aff", tb->aff_off, tb->aff_idx, &c->aff_off, &c->aff_idx, SIMON_MAX_TERMS_PER_CLASS * 4},
+            {"pref", tb->pref_off, tb->pref_idx, &c->pref_off, &c->pref_idx, SIMON_MAX_TERMS_PER_CLASS * 4},
+            {"own", tb->own_off, tb->own_idx, &c->own_off, &c->own_idx, SIMON_MAX_TERMS_PER_CLASS * 8},
+            {"spread_hard", tb->spread_hard_off, tb->spread_hard_idx, &c->sh_off, &c->sh_idx, SIMON_MAX_SPREAD},
+            {"spread_soft", tb->spread_soft_off, tb->spread_soft_idx, &c->ss_off, &c->ss_idx, SIMON_MAX_SPREAD},
+        };
+        for (Csr& l : lists) {
+            if (!l.off) continue;
+            copy_opt(*l.h_off, l.off, (size_t)c->Cp + 1);
+            if ((*l.h_off)[0] != 0) return fail(c, SIMON_EINVAL, "%s_off[0] != 0", l.name);
+            for (int k = 0; k < c->Cp; ++k) {
+                const int len = (*l.h_off)[k + 1] - (*l.h_off)[k];
+                if (len < 0 || len > l.cap) return fail(c, SIMON_EINVAL, "class %d: %s list has %d entries (limit %d)", k, l.name, len, l.cap);
+            }
+            const size_t cnt = (size_t)(*l.h_off)[c->Cp];
+            if (cnt > 0 && !l.idx) return fail(c, SIMON_EINVAL, "%s_idx missing", l.name);
+            copy_opt(*l.h_idx, l.idx, cnt);
+            for (int32_t t : *l.h_idx) if (t < 0 || t >= c->Tm) return fail(c, SIMON_EINVAL, "%s_idx out of range", l.name);
         }
-        for (int32_t t : c->anti_idx) if (t < 0 || t >= c->Tm) return fail(c, SIMON_EINVAL, "anti_idx out of range");
-        for (int32_t t : c->match_idx) if (t < 0 || t >= c->Tm) return fail(c, SIMON_EINVAL, "match_idx out of range");
+        if (c->match_off.empty()) c->match_off.assign(c->Cp + 1, 0);
+        if (c->anti_off.empty()) c->anti_off.assign(c->Cp + 1, 0);
+        copy_opt(c->class_flags, tb->class_flags, tb->class_flags ? (size_t)c->Cp : 0);
+        if (!c->pref_idx.empty()) { if (!tb->pref_w) return fail(c, SIMON_EINVAL, "pref_w missing"); copy_opt(c->pref_w, tb->pref_w, c->pref_idx.size()); }
+        if (!c->own_idx.empty()) { if (!tb->own_w) return fail(c, SIMON_EINVAL, "own_w missing"); copy_opt(c->own_w, tb->own_w, c->own_idx.size()); }
+        c->has_ipa_score = !c->pref_idx.empty() || !c->own_idx.empty();
+        // counters are int32 on the device: bound the weighted sums by P * sum |w|
+        long long wsum = 0;
+        for (int32_t x : c->pref_w) wsum = std::max<long long>(wsum, std::llabs((long long)x));
+        long long osum = 0;
+        for (int k = 0; k < c->Cp && !c->own_off.empty(); ++k) {
+            long long sk = 0;
+            for (int e = c->own_off[k]; e < c->own_off[k + 1]; ++e) sk += std::llabs((long long)c->own_w[e]);
+            osum = std::max(osum, sk);
+        }
+        if (osum * std::max(c->P, 1) >= (1ll << 31)) return fail(c, SIMON_ERANGE, "own_w x pods overflows the int32 weight counters");
+        (void)wsum;
+        if (!c->sh_idx.empty()) {
+            if (!tb->spread_hard_skew || !tb->spread_hard_self) return fail(c, SIMON_EINVAL, "spread_hard_skew/self missing");
+            copy_opt(c->sh_skew, tb->spread_hard_skew, c->sh_idx.size());
+            copy_opt(c->sh_self, tb->spread_hard_self, c->sh_idx.size());
+            copy_opt(c->sh_set, tb->spread_hard_set, c->sh_idx.size(), (int32_t)-1);
+            for (int32_t r : c->sh_set) if (r < -1 || r >= c->R) return fail(c, SIMON_EINVAL, "spread_hard_set out of range");
+        }
+        if (!c->ss_idx.empty()) {
+            if (!tb->spread_soft_skew || !tb->spread_log) return fail(c, SIMON_EINVAL, "spread_soft_skew / spread_log missing");
+            copy_opt(c->ss_skew, tb->spread_soft_skew, c->ss_idx.size());
+            copy_opt(c->spread_log, tb->spread_log, (size_t)c->N + 1);
+            if ((long long)c->P * SIMON_MAX_SPREAD >= (1ll << 31) - 2) return fail(c, SIMON_ERANGE, "too many pods for the spread stamps");
+        }
+        copy_opt(c->topo_is_hostname, tb->topo_is_hostname, tb->topo_is_hostname ? (size_t)c->Kt : 0);
     } else {
-        c->term_key.clear(); c->anti_off.assign(c->Cp + 1, 0); c->match_off.assign(c->Cp + 1, 0);
-        c->anti_idx.clear(); c->match_idx.clear();
+        c->anti_off.assign(c->Cp + 1, 0); c->match_off.assign(c->Cp + 1, 0);
     }
     c->have_tables = true; c->staged = false; c->have_results = false;
     return SIMON_OK;
@@ -772,6 +837,11 @@ int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32
     if (scen.n_nodes < 0 || scen.n_nodes > c->N) return fail(c, SIMON_EINVAL, "explain: n_nodes out of range");
     for (int i = 0; i < c->P; ++i) if (order[i] < 0 || order[i] >= c->P) return fail(c, SIMON_EINVAL, "explain: bad order");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->wide_staged) {   // NARROW problem: the failure codes still come from the all-feature kernel
+        rc = wide_stage(c->wide, *c, c->stream, c->err);
+        if (rc) return rc;
+        c->wide_staged = true;
+    }
     const int T = c->force_T ? c->force_T : (scen.n_nodes <= 512 ? 256 : scen.n_nodes <= 4096 ? 512 : 1024);
     return wide_explain(c->wide, *c, scen.n_nodes, order, failed_pods, fail_codes, max_failed, T, c->stream, c->err);
 }

@@ -14,7 +14,7 @@ namespace simon {
 
 // Host-side copies of everything simon_load_* received (the caller's buffers are not retained).
 struct HostInputs {
-    int N = 0, P = 0, K = 0, Kt = 0, Cp = 1, Cn = 1, Tm = 0;
+    int N = 0, P = 0, K = 0, Kt = 0, Cp = 1, Cn = 1, Tm = 0, R = 0;
     std::vector<int64_t> alloc_cpu, alloc_mem, alloc_eph, i_req_cpu, i_req_mem, i_req_eph, i_nz_cpu, i_nz_mem;
     std::vector<int32_t> alloc_pods, i_npods, node_class;
     std::vector<int64_t> scalar_alloc, i_scalar_req, gpu_mem_total, i_gpu_used;
@@ -25,8 +25,23 @@ struct HostInputs {
     std::vector<uint64_t> static_mask;
     std::vector<uint8_t> static_reason;
     std::vector<int64_t> simon_raw, const_score;
-    std::vector<int32_t> term_key, anti_off, anti_idx, match_off, match_idx;
     bool has_mask = false;
+    // ABI v2: static (pod class, node class) score inputs
+    std::vector<int64_t> na_raw, tt_raw, static_add;
+    bool has_na = false, has_tt = false, has_add = false;
+    // topology terms (InterPodAffinity + PodTopologySpread)
+    std::vector<int32_t> term_key, term_set;
+    std::vector<uint64_t> node_sets;
+    std::vector<int32_t> match_off, match_idx, anti_off, anti_idx, aff_off, aff_idx;
+    std::vector<uint8_t> class_flags;
+    std::vector<int32_t> pref_off, pref_idx, pref_w, own_off, own_idx, own_w;
+    std::vector<int32_t> sh_off, sh_idx, sh_skew, sh_self, sh_set, ss_off, ss_idx, ss_skew;
+    std::vector<uint8_t> topo_is_hostname;
+    std::vector<double> spread_log;
+    bool has_ipa_score = false;   // any pref_* or own_* entry exists
+    bool v2_features() const {
+        return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty();
+    }
 };
 
 // One pod of the stream, WIDE layout (128 B).
@@ -34,10 +49,15 @@ struct WidePod {
     int64_t req_cpu, req_mem, req_eph, nz_cpu, nz_mem, gpu_mem;
     int64_t scalar[SIMON_MAX_SCALAR];
     int32_t cls, preset, gate, gpu_cnt;
-    uint32_t flags;  // bit0: all-zero request incl. scalars (fit.go:244-249)
+    uint32_t flags;  // kPod* bits
     uint32_t pad[7];
 };
 static_assert(sizeof(WidePod) == 128, "WidePod must be 128 bytes");
+constexpr uint32_t kPodZero = 1u;      // all-zero request incl. scalars (fit.go:244-249)
+constexpr uint32_t kPodTerms = 2u;     // class touches topology counters (match / anti / aff / own lists non-empty)
+constexpr uint32_t kPodHard = 4u;      // class has DoNotSchedule spread constraints
+constexpr uint32_t kPodSoft = 8u;      // class has ScheduleAnyway spread constraints
+constexpr uint32_t kPodIpa = 16u;      // InterPodAffinity.Score can be non-zero for this class
 
 struct WideScenario {
     int32_t n_nodes, order_id;
@@ -45,7 +65,7 @@ struct WideScenario {
 
 struct WideArgs {
     int32_t N, P, K, Kt, Cp, Cn, Tm, S;     // S = scenarios in THIS launch (chunk)
-    int32_t mask_words, total_dom, has_gpu, has_mask;
+    int32_t mask_words, total_dom, has_gpu, has_mask, has_eph, nzeq, seen_stride;
     // static node arrays [N] (shared)
     const int64_t* alloc_cpu; const int64_t* alloc_mem; const int64_t* alloc_eph; const int32_t* alloc_pods;
     const int32_t* node_class; const int64_t* scalar_alloc /*[K][N]*/;
@@ -56,14 +76,24 @@ struct WideArgs {
     const int64_t* i_nz_mem; const int32_t* i_npods; const int64_t* i_scalar_req; const int64_t* i_gpu_used;
     // tables
     const uint64_t* static_mask; const uint8_t* static_reason; const int64_t* simon_raw;
+    const int64_t* na_raw; const int64_t* tt_raw; const int64_t* static_add;   // [Cp][Cn] or null
     const int32_t* term_key; const int32_t* term_dom_off /*[Tm] offset of term t's counters*/;
+    const int32_t* term_set /*[Tm] row of node_sets or -1*/; const uint64_t* node_sets;
     const int32_t* anti_off; const int32_t* anti_idx; const int32_t* match_off; const int32_t* match_idx;
+    const int32_t* aff_off; const int32_t* aff_idx; const uint8_t* class_flags;
+    const int32_t* pref_off; const int32_t* pref_idx; const int32_t* pref_w;
+    const int32_t* own_off; const int32_t* own_idx; const int32_t* own_w;
+    const int32_t* sh_off; const int32_t* sh_idx; const int32_t* sh_skew; const int32_t* sh_self; const int32_t* sh_set;
+    const int32_t* sh_first_reg /*[E][N]: lowest eligible node index sharing node j's domain, INT_MAX if none*/;
+    const int32_t* ss_off; const int32_t* ss_idx; const int32_t* ss_skew;
+    const uint8_t* topo_is_hostname; const double* spread_log; const int32_t* key_seen_off /*[Kt]*/;
     // stream
     const WidePod* pods; const int32_t* orders; const WideScenario* scen /*[S] of this chunk*/;
     // per-scenario mutable state, [S_chunk][...]
     int64_t* st_req_cpu; int64_t* st_req_mem; int64_t* st_req_eph; int64_t* st_nz_cpu; int64_t* st_nz_mem;
     int32_t* st_npods; int64_t* st_scalar /*[S][K][N]*/; int64_t* st_gpu /*[S][N][8]*/;
-    int32_t* st_cnt /*[S][2][total_dom]*/;
+    int32_t* st_cnt /*[S][3*total_dom + Tm]: cnt_match, cnt_owner, w_owner, term_total*/;
+    int32_t* st_seen /*[S][seen_stride]: distinct-domain stamps of the soft spread constraints*/;
     // outputs of this chunk
     int32_t* unscheduled; int64_t* used_cpu; int64_t* used_mem; int32_t* placement /*[S][P] or null*/;
     // explain outputs (single scenario)
@@ -71,10 +101,11 @@ struct WideArgs {
 };
 
 struct WideDevice {
-    void* blobs[40] = {};
+    void* blobs[80] = {};
     int n_blobs = 0;
     int state_chunk = 0;   // scenarios whose state is allocated
-    int total_dom = 0;
+    int total_dom = 0, seen_stride = 0;
+    bool has_eph = false, nzeq = false;
     // typed views
     int64_t *alloc_cpu = nullptr, *alloc_mem = nullptr, *alloc_eph = nullptr, *scalar_alloc = nullptr, *gpu_mem_total = nullptr;
     int32_t *alloc_pods = nullptr, *node_class = nullptr, *gpu_cnt = nullptr, *topo_dom = nullptr;
@@ -82,13 +113,20 @@ struct WideDevice {
             *i_scalar_req = nullptr, *i_gpu_used = nullptr;
     int32_t* i_npods = nullptr;
     uint64_t* static_mask = nullptr; uint8_t* static_reason = nullptr; int64_t* simon_raw = nullptr;
-    int32_t *term_key = nullptr, *term_dom_off = nullptr, *anti_off = nullptr, *anti_idx = nullptr, *match_off = nullptr,
-            *match_idx = nullptr;
+    int64_t *na_raw = nullptr, *tt_raw = nullptr, *static_add = nullptr;
+    int32_t *term_key = nullptr, *term_dom_off = nullptr, *term_set = nullptr, *anti_off = nullptr, *anti_idx = nullptr,
+            *match_off = nullptr, *match_idx = nullptr, *aff_off = nullptr, *aff_idx = nullptr, *pref_off = nullptr,
+            *pref_idx = nullptr, *pref_w = nullptr, *own_off = nullptr, *own_idx = nullptr, *own_w = nullptr,
+            *sh_off = nullptr, *sh_idx = nullptr, *sh_skew = nullptr, *sh_self = nullptr, *sh_set = nullptr,
+            *sh_first_reg = nullptr, *ss_off = nullptr, *ss_idx = nullptr, *ss_skew = nullptr, *key_seen_off = nullptr;
+    uint64_t* node_sets = nullptr;
+    uint8_t *class_flags = nullptr, *topo_is_hostname = nullptr;
+    double* spread_log = nullptr;
     WidePod* pods = nullptr;
     // state
     int64_t *st_req_cpu = nullptr, *st_req_mem = nullptr, *st_req_eph = nullptr, *st_nz_cpu = nullptr, *st_nz_mem = nullptr,
             *st_scalar = nullptr, *st_gpu = nullptr;
-    int32_t *st_npods = nullptr, *st_cnt = nullptr;
+    int32_t *st_npods = nullptr, *st_cnt = nullptr, *st_seen = nullptr;
     void release();
 };
 

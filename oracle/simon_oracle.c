@@ -24,6 +24,8 @@ typedef struct {
     int64_t* gpu_used;   /* [N][SIMON_MAX_GPU_DEV] */
     int32_t** cnt_match; /* [T] -> [n_dom(key(t))]: placed pods matching term t per topology domain */
     int32_t** cnt_owner; /* [T] -> [...]: placed pods that REQUIRE anti-affinity term t per domain */
+    int64_t** w_owner;   /* [T] -> [...]: summed signed weights of placed pods' scoring terms (own_*) per domain */
+    int64_t* term_total; /* [T] sum over domains of cnt_match[t] */
 } state_t;
 
 static void* xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
@@ -33,7 +35,8 @@ static void state_free(state_t* s, int T) {
     free(s->npods); free(s->scalar_req); free(s->gpu_used);
     if (s->cnt_match) for (int t = 0; t < T; t++) free(s->cnt_match[t]);
     if (s->cnt_owner) for (int t = 0; t < T; t++) free(s->cnt_owner[t]);
-    free(s->cnt_match); free(s->cnt_owner);
+    if (s->w_owner) for (int t = 0; t < T; t++) free(s->w_owner[t]);
+    free(s->cnt_match); free(s->cnt_owner); free(s->w_owner); free(s->term_total);
 }
 
 static int state_init(state_t* s, const simon_nodes_soa* nd, const simon_class_tables* tb) {
@@ -45,9 +48,10 @@ static int state_init(state_t* s, const simon_nodes_soa* nd, const simon_class_t
     s->scalar_req = xcalloc((size_t)K * N, 8);
     s->gpu_used = xcalloc((size_t)N * SIMON_MAX_GPU_DEV, 8);
     s->cnt_match = xcalloc(T, sizeof(int32_t*)); s->cnt_owner = xcalloc(T, sizeof(int32_t*));
+    s->w_owner = xcalloc(T, sizeof(int64_t*)); s->term_total = xcalloc(T, 8);
     for (int t = 0; t < T; t++) {
         int nd_ = nd->topo_n_dom[tb->term_topo_key[t]];
-        s->cnt_match[t] = xcalloc(nd_, 4); s->cnt_owner[t] = xcalloc(nd_, 4);
+        s->cnt_match[t] = xcalloc(nd_, 4); s->cnt_owner[t] = xcalloc(nd_, 4); s->w_owner[t] = xcalloc(nd_, 8);
     }
     if (nd->init_req_cpu) memcpy(s->req_cpu, nd->init_req_cpu, (size_t)N * 8);
     if (nd->init_req_mem) memcpy(s->req_mem, nd->init_req_mem, (size_t)N * 8);
@@ -115,12 +119,59 @@ static int gpu_allocate(const simon_nodes_soa* nd, const int64_t* used /*[8]*/, 
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* topology helpers                                                                              */
+/* ------------------------------------------------------------------------------------------- */
+static int in_node_set(const simon_class_tables* tb, int N, int set, int j) {
+    if (set < 0 || !tb->node_sets) return 1;
+    size_t words = ((size_t)N + 63) / 64;
+    return (int)((tb->node_sets[(size_t)set * words + (size_t)j / 64] >> (j % 64)) & 1);
+}
+static int term_dom(const simon_nodes_soa* nd, const simon_class_tables* tb, int t, int j) {
+    return nd->topo_dom[(size_t)tb->term_topo_key[t] * nd->n_nodes + j];
+}
+static int csr_lo(const int32_t* off, int c) { return off ? off[c] : 0; }
+static int csr_hi(const int32_t* off, int c) { return off ? off[c + 1] : 0; }
+
+/* PodTopologySpread.PreFilter state (podtopologyspread/filtering.go:198-281) for the hard
+ * (DoNotSchedule) constraints of one pod: TpPairToMatchNum holds only pairs REGISTERED by an
+ * eligible node (:236-251) and criticalPaths[0].MatchNum is the minimum over them (:272-278). */
+typedef struct {
+    int n_hard;
+    int64_t min_match[SIMON_MAX_SPREAD];
+    uint8_t* reg[SIMON_MAX_SPREAD];
+} prefilter_t;
+
+static void prefilter_free(prefilter_t* pf) { for (int i = 0; i < pf->n_hard; i++) free(pf->reg[i]); }
+
+static void spread_prefilter(const simon_nodes_soa* nd, const simon_class_tables* tb, const state_t* s,
+                             const pod_t* p, int n, prefilter_t* pf) {
+    pf->n_hard = 0;
+    if (!tb || !tb->spread_hard_off) return;
+    int lo = tb->spread_hard_off[p->cls], hi = tb->spread_hard_off[p->cls + 1];
+    for (int e = lo; e < hi && pf->n_hard < SIMON_MAX_SPREAD; e++) {
+        int t = tb->spread_hard_idx[e], i = pf->n_hard++;
+        int set = tb->spread_hard_set ? tb->spread_hard_set[e] : -1;
+        int ndom = nd->topo_n_dom[tb->term_topo_key[t]];
+        pf->reg[i] = xcalloc(ndom, 1);
+        for (int j = 0; j < n; j++) {
+            if (!in_node_set(tb, nd->n_nodes, set, j)) continue;
+            int d = term_dom(nd, tb, t, j);
+            if (d >= 0) pf->reg[i][d] = 1;
+        }
+        int64_t mn = INT32_MAX;                                   /* newCriticalPaths: math.MaxInt32 (:91-93) */
+        for (int d = 0; d < ndom; d++)
+            if (pf->reg[i][d] && s->cnt_match[t][d] < mn) mn = s->cnt_match[t][d];
+        pf->min_match[i] = mn;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* One (pod, node) filter evaluation.  Order and early exit: RunFilterPlugins                    */
 /* V/framework/runtime/framework.go:527-552; plugin order V/algorithmprovider/registry.go:87-104 */
 /* + pkg/simulator/utils.go:321-333.  Returns a SIMON_FAIL_* code (0 = feasible).                */
 /* ------------------------------------------------------------------------------------------- */
 static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables* tb, const state_t* s,
-                            const pod_t* p, int j) {
+                            const pod_t* p, const prefilter_t* pf, int j) {
     int N = nd->n_nodes, K = nd->n_scalar;
     /* NodeUnschedulable, NodeName, TaintToleration, NodeAffinity: static per (class, node) */
     if (tb && tb->static_mask) {
@@ -148,17 +199,46 @@ static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables*
         }
     }
     if (fit) return (uint16_t)(SIMON_FAIL_FIT | fit);
-    /* InterPodAffinity, required anti-affinity (filtering.go:317-401).  satisfyPodAntiAffinity
-     * (:334-346) is checked before satisfyExistingPodsAntiAffinity (:319-332). */
+    /* PodTopologySpread.Filter, podtopologyspread/filtering.go:283-333 (DoNotSchedule constraints) */
+    if (pf && pf->n_hard > 0) {
+        int lo = tb->spread_hard_off[p->cls];
+        for (int i = 0; i < pf->n_hard; i++) {
+            int t = tb->spread_hard_idx[lo + i];
+            int d = term_dom(nd, tb, t, j);
+            if (d < 0) return SIMON_FAIL_SPREAD_LABEL;                            /* :300-304 */
+            int64_t self = tb->spread_hard_self[lo + i] ? 1 : 0;                 /* :306-309 */
+            int64_t match = pf->reg[i][d] ? s->cnt_match[t][d] : 0;              /* :321-324 (nil pair -> 0) */
+            int64_t skew = match + self - pf->min_match[i];                      /* :325 */
+            if (skew > tb->spread_hard_skew[lo + i]) return SIMON_FAIL_SPREAD;
+        }
+    }
+    /* InterPodAffinity.Filter (interpodaffinity/filtering.go:379-401): satisfyPodAffinity (:348-377), then
+     * satisfyPodAntiAffinity (:334-346), then satisfyExistingPodsAntiAffinity (:319-332). */
     if (tb && tb->n_terms > 0) {
-        for (int e = tb->anti_off[p->cls]; e < tb->anti_off[p->cls + 1]; e++) {
+        int alo = csr_lo(tb->aff_off, p->cls), ahi = csr_hi(tb->aff_off, p->cls);
+        if (ahi > alo) {
+            int pods_exist = 1;
+            for (int e = alo; e < ahi; e++) {
+                int t = tb->aff_idx[e];
+                int d = term_dom(nd, tb, t, j);
+                if (d < 0) return SIMON_FAIL_AFFINITY;             /* all topology labels must exist (:357-360) */
+                if (s->cnt_match[t][d] <= 0) pods_exist = 0;
+            }
+            if (!pods_exist) {                                     /* first pod of a self-affine series (:363-374) */
+                int64_t total = 0;
+                for (int e = alo; e < ahi; e++) total += s->term_total[tb->aff_idx[e]];
+                int self = tb->class_flags && (tb->class_flags[p->cls] & SIMON_CLASS_AFF_SELF);
+                if (!(total == 0 && self)) return SIMON_FAIL_AFFINITY;
+            }
+        }
+        for (int e = csr_lo(tb->anti_off, p->cls); e < csr_hi(tb->anti_off, p->cls); e++) {
             int t = tb->anti_idx[e];
-            int d = nd->topo_dom[(size_t)tb->term_topo_key[t] * N + j];
+            int d = term_dom(nd, tb, t, j);
             if (d >= 0 && s->cnt_match[t][d] > 0) return SIMON_FAIL_ANTI_INCOMING;
         }
-        for (int e = tb->match_off[p->cls]; e < tb->match_off[p->cls + 1]; e++) {
+        for (int e = csr_lo(tb->match_off, p->cls); e < csr_hi(tb->match_off, p->cls); e++) {
             int t = tb->match_idx[e];
-            int d = nd->topo_dom[(size_t)tb->term_topo_key[t] * N + j];
+            int d = term_dom(nd, tb, t, j);
             if (d >= 0 && s->cnt_owner[t][d] > 0) return SIMON_FAIL_ANTI_EXISTING;
         }
     }
@@ -203,7 +283,9 @@ static void la_ba(const simon_nodes_soa* nd, const state_t* s, const pod_t* p, i
 
 /* NodeInfo.AddPod, V/framework/types.go:482-508 (+ Reserve of Open-Gpu-Share,
  * open-gpu-share.go:147-188 -> DeviceInfo.GetUsedGpuMemory deviceinfo.go:45-67; + the topology
- * counters InterPodAffinity.PreFilter would rebuild from NodeInfo.Pods, filtering.go:166-239) */
+ * counters the InterPodAffinity / PodTopologySpread PreFilter+PreScore would rebuild from
+ * NodeInfo.Pods every cycle: interpodaffinity/filtering.go:166-239, scoring.go:87-131,
+ * podtopologyspread/filtering.go:253-268, scoring.go:129-160) */
 static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, state_t* s, const pod_t* p, int j,
                     int with_gpu) {
     int N = nd->n_nodes, K = nd->n_scalar;
@@ -212,15 +294,21 @@ static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, sta
     s->nz_cpu[j] += p->nz_cpu; s->nz_mem[j] += p->nz_mem;
     s->npods[j] += 1;
     if (tb && tb->n_terms > 0) {
-        for (int e = tb->match_off[p->cls]; e < tb->match_off[p->cls + 1]; e++) {
+        for (int e = csr_lo(tb->match_off, p->cls); e < csr_hi(tb->match_off, p->cls); e++) {
             int t = tb->match_idx[e];
-            int d = nd->topo_dom[(size_t)tb->term_topo_key[t] * N + j];
-            if (d >= 0) s->cnt_match[t][d] += 1;   /* updateWithAntiAffinityTerms :133-148 (label must exist) */
+            if (!in_node_set(tb, N, tb->term_node_set ? tb->term_node_set[t] : -1, j)) continue;
+            int d = term_dom(nd, tb, t, j);
+            if (d >= 0) { s->cnt_match[t][d] += 1; s->term_total[t] += 1; }  /* label must exist (:133-148) */
         }
-        for (int e = tb->anti_off[p->cls]; e < tb->anti_off[p->cls + 1]; e++) {
+        for (int e = csr_lo(tb->anti_off, p->cls); e < csr_hi(tb->anti_off, p->cls); e++) {
             int t = tb->anti_idx[e];
-            int d = nd->topo_dom[(size_t)tb->term_topo_key[t] * N + j];
+            int d = term_dom(nd, tb, t, j);
             if (d >= 0) s->cnt_owner[t][d] += 1;
+        }
+        for (int e = csr_lo(tb->own_off, p->cls); e < csr_hi(tb->own_off, p->cls); e++) {
+            int t = tb->own_idx[e];
+            int d = term_dom(nd, tb, t, j);
+            if (d >= 0) s->w_owner[t][d] += tb->own_w[e];
         }
     }
     if (with_gpu && p->gpu_mem > 0) {
@@ -231,49 +319,156 @@ static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, sta
     }
 }
 
+/* InterPodAffinity.Score raw value of one node (interpodaffinity/scoring.go:87-131,211-236) */
+static int64_t ipa_raw(const simon_nodes_soa* nd, const simon_class_tables* tb, const state_t* s, const pod_t* p, int j) {
+    int64_t sc = 0;
+    for (int e = csr_lo(tb->pref_off, p->cls); e < csr_hi(tb->pref_off, p->cls); e++) {
+        int t = tb->pref_idx[e];
+        int d = term_dom(nd, tb, t, j);
+        if (d >= 0) sc += (int64_t)tb->pref_w[e] * s->cnt_match[t][d];
+    }
+    for (int e = csr_lo(tb->match_off, p->cls); e < csr_hi(tb->match_off, p->cls); e++) {
+        int t = tb->match_idx[e];
+        int d = term_dom(nd, tb, t, j);
+        if (d >= 0) sc += s->w_owner[t][d];
+    }
+    return sc;
+}
+
+static int64_t class_cell(const int64_t* table, const simon_nodes_soa* nd, const simon_class_tables* tb, const pod_t* p, int j) {
+    if (!table) return 0;
+    return table[(size_t)p->cls * tb->n_node_classes + (nd->node_class ? nd->node_class[j] : 0)];
+}
+
 /* One scheduling cycle for pod p over nodes [0,n): genericScheduler.Schedule
  * (V/core/generic_scheduler.go:131-186): findNodesThatFitPod (:237) with
  * percentageOfNodesToScore=100 (pkg/simulator/utils.go:370), prioritizeNodes (:470),
  * selectHost (:188) determinised to the first maximum.  Returns the node or -1.
- * scratch: feasible/total arrays of n int64 (total may be NULL when only the choice is needed). */
+ * codes: [n] scratch (required); o_*: optional per-node score breakdown. */
 static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb, const state_t* s,
-                        const pod_t* p, int n, uint16_t* codes /*[n] or NULL*/, int64_t* o_feasible,
+                        const pod_t* p, int n, uint16_t* codes /*[n]*/, int64_t* o_feasible,
                         int64_t* o_la, int64_t* o_ba, int64_t* o_sn, int64_t* o_total) {
-    int Cn = tb ? tb->n_node_classes : 1;
     int n_feasible = 0, first = -1;
     int64_t lo = INT64_MAX, hi = -INT64_MAX; /* simon.go:78-79 */
+    int64_t na_max = 0, tt_max = 0;          /* DefaultNormalizeScore: maxCount starts at 0 (helper/normalize_score.go:27-33) */
+    prefilter_t pf;
+    spread_prefilter(nd, tb, s, p, n, &pf);
     for (int j = 0; j < n; j++) {
-        uint16_t c = filter_node(nd, tb, s, p, j);
-        if (codes) codes[j] = c;
+        uint16_t c = filter_node(nd, tb, s, p, &pf, j);
+        codes[j] = c;
         if (o_feasible) o_feasible[j] = (c == 0);
         if (c) continue;
         if (first < 0) first = j;
         n_feasible++;
-        int64_t raw = tb && tb->simon_raw ? tb->simon_raw[(size_t)p->cls * Cn + (nd->node_class ? nd->node_class[j] : 0)] : 0;
+        int64_t raw = tb ? class_cell(tb->simon_raw, nd, tb, p, j) : 0;
         if (raw > hi) hi = raw;
         if (raw < lo) lo = raw;
+        if (tb) {
+            int64_t v = class_cell(tb->node_affinity_raw, nd, tb, p, j);
+            if (v > na_max) na_max = v;
+            v = class_cell(tb->taint_prefer_raw, nd, tb, p, j);
+            if (v > tt_max) tt_max = v;
+        }
     }
+    prefilter_free(&pf);
     if (n_feasible == 0) return -1;
     if (n_feasible == 1 && !o_total) return first;           /* generic_scheduler.go:159-165 */
+
+    /* InterPodAffinity PreScore/Score (scoring.go:133-236): raw per feasible node, min/max from 0 (:247-256) */
+    int has_ipa = tb && tb->n_terms > 0 && (tb->pref_off || tb->own_off);
+    int64_t* ipa = NULL; int64_t ipa_min = 0, ipa_max = 0;
+    if (has_ipa) {
+        ipa = xcalloc(n, 8);
+        for (int j = 0; j < n; j++) {
+            if (codes[j]) continue;
+            ipa[j] = ipa_raw(nd, tb, s, p, j);
+            if (ipa[j] > ipa_max) ipa_max = ipa[j];
+            if (ipa[j] < ipa_min) ipa_min = ipa[j];
+        }
+    }
+    /* PodTopologySpread PreScore/Score (podtopologyspread/scoring.go:60-214) for the soft constraints */
+    int slo = tb ? csr_lo(tb->spread_soft_off, p->cls) : 0, shi = tb ? csr_hi(tb->spread_soft_off, p->cls) : 0;
+    int n_soft = shi - slo;
+    int64_t* pts = NULL; uint8_t* ignored = NULL; int64_t pts_min = INT64_MAX, pts_max = 0;
+    if (n_soft > 0) {
+        pts = xcalloc(n, 8); ignored = xcalloc(n, 1);
+        int scored = 0;
+        for (int j = 0; j < n; j++) {                         /* IgnoredNodes: a constraint key is missing (:80-85) */
+            if (codes[j]) continue;
+            for (int e = slo; e < shi; e++) if (term_dom(nd, tb, tb->spread_soft_idx[e], j) < 0) ignored[j] = 1;
+            if (!ignored[j]) scored++;
+        }
+        double weight[SIMON_MAX_SPREAD];
+        for (int e = slo; e < shi; e++) {                     /* TopologyNormalizingWeight (:98-106) */
+            int t = tb->spread_soft_idx[e], key = tb->term_topo_key[t], sz;
+            if (tb->topo_is_hostname && tb->topo_is_hostname[key]) {
+                sz = scored;                                  /* len(filteredNodes) - len(IgnoredNodes) */
+            } else {                                          /* distinct topology values among the scored nodes (:86-96) */
+                int ndom = nd->topo_n_dom[key];
+                uint8_t* seen = xcalloc(ndom, 1);
+                sz = 0;
+                for (int j = 0; j < n; j++) {
+                    if (codes[j] || ignored[j]) continue;
+                    int d = term_dom(nd, tb, t, j);
+                    if (!seen[d]) { seen[d] = 1; sz++; }
+                }
+                free(seen);
+            }
+            weight[e - slo] = tb->spread_log[sz];             /* math.Log(float64(size + 2)) (:279-281) */
+        }
+        for (int j = 0; j < n; j++) {
+            if (codes[j] || ignored[j]) continue;
+            double score = 0;                                 /* :187-199, scoreForCount :287-289 */
+            for (int e = slo; e < shi; e++) {
+                int t = tb->spread_soft_idx[e];
+                int64_t cnt = s->cnt_match[t][term_dom(nd, tb, t, j)];
+                score += (double)cnt * weight[e - slo] + (double)(tb->spread_soft_skew[e] - 1);
+            }
+            pts[j] = (int64_t)score;
+            if (pts[j] < pts_min) pts_min = pts[j];
+            if (pts[j] > pts_max) pts_max = pts[j];
+        }
+    }
+
     int best = -1; int64_t best_total = 0;
     int64_t konst = tb && tb->const_score ? tb->const_score[p->cls] : 0;
     for (int j = 0; j < n; j++) {
-        if (codes ? codes[j] : filter_node(nd, tb, s, p, j)) {
+        if (codes[j]) {
             if (o_total) { o_la[j] = o_ba[j] = o_sn[j] = o_total[j] = 0; }
             continue;
         }
         int64_t la, ba;
         la_ba(nd, s, p, j, &la, &ba);
-        int64_t raw = tb && tb->simon_raw ? tb->simon_raw[(size_t)p->cls * Cn + (nd->node_class ? nd->node_class[j] : 0)] : 0;
+        int64_t raw = tb ? class_cell(tb->simon_raw, nd, tb, p, j) : 0;
         /* SimonPlugin.NormalizeScore == GpuSharePlugin.NormalizeScore, simon.go:76-101 */
         int64_t old_range = hi - lo, sn;
         if (old_range == 0) sn = 0; else sn = ((raw - lo) * MAX_NODE_SCORE / old_range) + 0;
-        /* weights: every plugin 1 except constants (registry.go:118-131, utils.go:321-333);
-         * Simon and Open-Gpu-Share contribute the same normalised value each */
+        /* weights: every plugin 1 except NodePreferAvoidPods 10000 and PodTopologySpread 2 (registry.go:118-131,
+         * utils.go:321-333); Simon and Open-Gpu-Share contribute the same normalised value each */
         int64_t total = ba + la + 2 * sn + konst;
+        if (tb && tb->node_affinity_raw)                      /* DefaultNormalizeScore(100, false) */
+            total += na_max == 0 ? 0 : MAX_NODE_SCORE * class_cell(tb->node_affinity_raw, nd, tb, p, j) / na_max;
+        if (tb && tb->taint_prefer_raw)                       /* DefaultNormalizeScore(100, true) */
+            total += tt_max == 0 ? MAX_NODE_SCORE
+                                 : MAX_NODE_SCORE - MAX_NODE_SCORE * class_cell(tb->taint_prefer_raw, nd, tb, p, j) / tt_max;
+        if (tb) total += class_cell(tb->static_add, nd, tb, p, j);
+        if (has_ipa) {                                        /* interpodaffinity/scoring.go:258-271 */
+            int64_t diff = ipa_max - ipa_min;
+            double f = 0;
+            if (diff > 0) f = (double)MAX_NODE_SCORE * ((double)(ipa[j] - ipa_min) / (double)diff);
+            total += (int64_t)f;
+        }
+        if (n_soft > 0) {                                     /* podtopologyspread/scoring.go:217-256, weight 2 */
+            int64_t v;
+            if (ignored[j]) v = 0;
+            else if (pts_max == 0) v = MAX_NODE_SCORE;
+            else v = MAX_NODE_SCORE * (pts_max + pts_min - pts[j]) / pts_max;
+            total += 2 * v;
+        }
         if (o_total) { o_la[j] = la; o_ba[j] = ba; o_sn[j] = sn; o_total[j] = total; }
         if (best < 0 || total > best_total) { best = j; best_total = total; }   /* first max */
     }
+    free(ipa); free(pts); free(ignored);
     return best;
 }
 
@@ -285,6 +480,32 @@ int simon_oracle_score_pod(const simon_nodes_soa* nodes, const simon_pods_soa* p
     pod_t p = pod_row(pods, nodes->n_scalar, pod);
     uint16_t* codes = xcalloc(n_nodes, 2);
     int r = schedule_one(nodes, tables, &s, &p, n_nodes, codes, feasible, la, ba, sn, total);
+    free(codes);
+    state_free(&s, tables ? tables->n_terms : 0);
+    return r;
+}
+
+/* Score breakdown of pod `pod` after the first n_before pods of `order` went through the
+ * scheduling loop (placed by the oracle itself; preset pods are bound): lets the tests probe the
+ * placement-dependent plugins (InterPodAffinity, PodTopologySpread) on a known cluster state. */
+int simon_oracle_score_pod_after(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
+                                 const simon_class_tables* tables, int32_t n_nodes, const int32_t* order,
+                                 int32_t n_before, int32_t pod, int64_t* feasible, int64_t* la, int64_t* ba,
+                                 int64_t* sn, int64_t* total, uint16_t* codes_out) {
+    state_t s;
+    state_init(&s, nodes, tables);
+    uint16_t* codes = xcalloc(n_nodes, 2);
+    for (int i = 0; i < n_before; i++) {
+        int pid = order ? order[i] : i;
+        pod_t q = pod_row(pods, nodes->n_scalar, pid);
+        if (q.gate >= n_nodes) continue;
+        if (q.preset >= 0) { add_pod(nodes, tables, &s, &q, q.preset, 0); continue; }
+        int j = schedule_one(nodes, tables, &s, &q, n_nodes, codes, NULL, NULL, NULL, NULL, NULL);
+        if (j >= 0) add_pod(nodes, tables, &s, &q, j, 1);
+    }
+    pod_t p = pod_row(pods, nodes->n_scalar, pod);
+    int r = schedule_one(nodes, tables, &s, &p, n_nodes, codes, feasible, la, ba, sn, total);
+    if (codes_out) memcpy(codes_out, codes, (size_t)n_nodes * 2);
     free(codes);
     state_free(&s, tables ? tables->n_terms : 0);
     return r;

@@ -39,6 +39,13 @@ int simon_oracle_score_pod(const simon_nodes_soa* nodes, const simon_pods_soa* p
                            const simon_class_tables* tables, int32_t n_nodes, int32_t pod,
                            int64_t* feasible, int64_t* la, int64_t* ba, int64_t* sn, int64_t* total);
 
+/* Same breakdown after the first n_before pods of `order` (NULL = identity) were scheduled by the
+ * oracle; codes_out (optional, [n_nodes]) receives the per-node SIMON_FAIL_* codes of `pod`. */
+int simon_oracle_score_pod_after(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
+                                 const simon_class_tables* tables, int32_t n_nodes, const int32_t* order,
+                                 int32_t n_before, int32_t pod, int64_t* feasible, int64_t* la, int64_t* ba,
+                                 int64_t* sn, int64_t* total, uint16_t* codes_out);
+
 /* The add-nodes search result over a finished batch (pkg/apply/apply.go:203-259, 689-775). */
 int simon_oracle_min_plan(const simon_nodes_soa* nodes, const simon_scenario* scen, int32_t S,
                           const simon_batch_out* out, int32_t max_cpu_pct, int32_t max_mem_pct,

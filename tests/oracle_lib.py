@@ -33,6 +33,10 @@ def load():
     lib.simon_oracle_score_pod.restype = C.c_int
     lib.simon_oracle_score_pod.argtypes = [C.POINTER(capi.NodesSoA), C.POINTER(capi.PodsSoA),
                                            C.POINTER(capi.ClassTables), C.c_int32, C.c_int32, p64, p64, p64, p64, p64]
+    lib.simon_oracle_score_pod_after.restype = C.c_int
+    lib.simon_oracle_score_pod_after.argtypes = [C.POINTER(capi.NodesSoA), C.POINTER(capi.PodsSoA),
+                                                 C.POINTER(capi.ClassTables), C.c_int32, p32, C.c_int32, C.c_int32,
+                                                 p64, p64, p64, p64, p64, pu16]
     lib.simon_oracle_min_plan.restype = C.c_int
     lib.simon_oracle_min_plan.argtypes = [C.POINTER(capi.NodesSoA), C.POINTER(capi.Scenario), C.c_int32,
                                           C.POINTER(capi.BatchOut), C.c_int32, C.c_int32, C.POINTER(capi.Plan)]
@@ -82,6 +86,22 @@ def score_pod(prob: capi.Problem, n_nodes: int, pod: int):
     best = lib.simon_oracle_score_pod(C.byref(n), C.byref(p), C.byref(t), n_nodes, pod,
                                       *[capi._ptr(a, C.c_int64) for a in arrs])
     return best, dict(zip(["feasible", "la", "ba", "sn", "total"], arrs))
+
+
+def score_pod_after(prob: capi.Problem, n_nodes: int, n_before: int, pod: int, order=None):
+    """Schedule the first n_before pods of `order` (identity by default) on the oracle, then score `pod`."""
+    lib = load()
+    prob.normalise()
+    n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
+    arrs = [np.zeros(n_nodes, np.int64) for _ in range(5)]
+    codes = np.zeros(n_nodes, np.uint16)
+    order = None if order is None else np.ascontiguousarray(order, np.int32)
+    best = lib.simon_oracle_score_pod_after(C.byref(n), C.byref(p), C.byref(t), n_nodes, capi._ptr(order, C.c_int32),
+                                            n_before, pod, *[capi._ptr(a, C.c_int64) for a in arrs],
+                                            capi._ptr(codes, C.c_uint16))
+    out = dict(zip(["feasible", "la", "ba", "sn", "total"], arrs))
+    out["codes"] = codes
+    return best, out
 
 
 def min_plan(prob: capi.Problem, scen, res: capi.BatchResult, max_cpu=100, max_mem=100) -> capi.Plan:

@@ -9,7 +9,8 @@ GiB = 1 << 30
 
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
-                 odd_units=False, n_node_classes=5, n_pod_classes=6):
+                 odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
+                 spread_soft=False, static_scores=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -97,22 +98,96 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
                 for d in range(cnt[j]):
                     used[j, d] = rng.choice([0, 0, 1, 2]) * GiB
             prob.init_gpu_used = used
-    if anti:
-        # two topology keys: hostname (domain = node) and zone (4 zones, some nodes unlabeled)
-        zone = rng.integers(-1, 4, N).astype(np.int32)
-        prob.topo_dom = np.stack([np.arange(N, dtype=np.int32), zone])
-        prob.topo_n_dom = np.array([N, 4], np.int32)
-        T = 4
-        prob.term_topo_key = np.array([0, 1, 0, 1], np.int32)
-        anti_lists, match_lists = [], []
-        for c in range(n_pod_classes):
-            anti_lists.append(sorted(set(rng.choice(T, rng.integers(0, 3)).tolist())) if rng.random() < 0.5 else [])
-            match_lists.append(sorted(set(rng.choice(T, rng.integers(0, 3)).tolist())) if rng.random() < 0.6 else [])
-        prob.anti_off = np.cumsum([0] + [len(x) for x in anti_lists]).astype(np.int32)
-        prob.anti_idx = np.array([t for x in anti_lists for t in x], np.int32)
-        prob.match_off = np.cumsum([0] + [len(x) for x in match_lists]).astype(np.int32)
-        prob.match_idx = np.array([t for x in match_lists for t in x], np.int32)
+    if static_scores:   # NodeAffinity preferred / TaintToleration PreferNoSchedule / NodePreferAvoidPods tables
+        prob.node_affinity_raw = (rng.integers(0, 4, (n_pod_classes, n_node_classes)) * rng.integers(1, 60)).astype(np.int64)
+        prob.taint_prefer_raw = rng.integers(0, 3, (n_pod_classes, n_node_classes)).astype(np.int64)
+        prob.static_add = (rng.integers(0, 2, (n_pod_classes, n_node_classes)) * 1000000).astype(np.int64)
+        if seed % 2:        # all-zero rows exercise the max == 0 branches
+            prob.node_affinity_raw[0] = 0
+            prob.taint_prefer_raw[-1] = 0
+    v2 = aff or ipa or spread_hard or spread_soft
+    if anti or v2:
+        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft)
     return prob.normalise()
+
+
+def _csr(lists):
+    off = np.cumsum([0] + [len(x) for x in lists]).astype(np.int32)
+    flat = [v for x in lists for v in x]
+    return off, np.array(flat if flat else [0], np.int32)
+
+
+def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft):
+    """Two topology keys -- hostname (domain = node) and zone (4 zones, some nodes unlabeled) -- and 8 terms over them;
+    every role list of include/simon_hip.h gets random entries for the enabled features."""
+    zone = rng.integers(-1, 4, N).astype(np.int32)
+    if spread_hard and not anti:
+        zone = np.abs(zone)            # keep hard-spread problems schedulable: every node labeled
+    prob.topo_dom = np.stack([np.arange(N, dtype=np.int32), zone])
+    prob.topo_n_dom = np.array([N, 4], np.int32)
+    prob.topo_is_hostname = np.array([1, 0], np.uint8)
+    T = 8
+    prob.term_topo_key = np.array([0, 1, 0, 1, 1, 0, 1, 1], np.int32)
+    words = (N + 63) // 64
+    sets = np.zeros((2, words), np.uint64)
+    for r in range(2):
+        for j in range(N):
+            if rng.random() < 0.8:
+                sets[r, j // 64] |= np.uint64(1) << np.uint64(j % 64)
+    prob.node_sets = sets
+    tset = np.full(T, -1, np.int32)
+    if spread_soft:
+        tset[6] = 0
+        tset[7] = 1
+    prob.term_node_set = tset
+
+    def pick(cands, p_any, kmax):
+        if rng.random() >= p_any:
+            return []
+        return sorted(set(rng.choice(cands, rng.integers(1, kmax + 1)).tolist()))
+
+    match, antil, affl, pref, prefw, own, ownw, hard, hskew, hself, hset, soft, sskew, flags = ([] for _ in range(14))
+    for c in range(Cp):
+        match.append(pick(np.arange(T), 0.7, 4))
+        antil.append(pick([0, 1, 2, 3], 0.5, 2) if anti else [])
+        a = pick([4, 5], 0.4, 2) if aff else []
+        affl.append(a)
+        flags.append(capi.CLASS_AFF_SELF if a and all(t in match[c] for t in a) else 0)
+        pr = pick([0, 1, 2, 3, 5], 0.6, 3) if ipa else []
+        pref.append(pr)
+        prefw.append([int(rng.integers(1, 101)) * (1 if rng.random() < 0.6 else -1) for _ in pr])
+        ow = pick([0, 1, 2, 3, 4], 0.6, 3) if ipa else []
+        own.append(ow)
+        ownw.append([int(rng.integers(1, 101)) * (1 if rng.random() < 0.7 else -1) for _ in ow])
+        h = pick([1, 3], 0.5, 2) if spread_hard else []
+        hard.append(h)
+        hskew.append([int(rng.integers(1, 4)) for _ in h])
+        hself.append([int(t in match[c]) for t in h])
+        hset.append([int(rng.integers(-1, 2)) for _ in h])
+        so = pick([6, 7, 5], 0.7, 3) if spread_soft else []
+        soft.append(so)
+        sskew.append([int(rng.integers(1, 6)) for _ in so])
+    # make some classes own an affinity term they do not match (exercises the non-escape branch)
+    prob.match_off, prob.match_idx = _csr(match)
+    prob.anti_off, prob.anti_idx = _csr(antil)
+    if aff:
+        prob.aff_off, prob.aff_idx = _csr(affl)
+        prob.class_flags = np.array(flags, np.uint8)
+    if ipa:
+        prob.pref_off, prob.pref_idx = _csr(pref)
+        prob.pref_w = _csr(prefw)[1]
+        prob.own_off, prob.own_idx = _csr(own)
+        prob.own_w = _csr(ownw)[1]
+    if spread_hard:
+        prob.spread_hard_off, prob.spread_hard_idx = _csr(hard)
+        prob.spread_hard_skew = _csr(hskew)[1]
+        prob.spread_hard_self = _csr(hself)[1]
+        prob.spread_hard_set = np.array([v for x in hset for v in x] or [0], np.int32)
+    if spread_soft:
+        from open_simulator_amd.gomath import spread_log_table
+        prob.spread_soft_off, prob.spread_soft_idx = _csr(soft)
+        prob.spread_soft_skew = _csr(sskew)[1]
+        prob.spread_log = spread_log_table(N)
 
 
 def rand_scenarios(seed, prob, S=6, n_orders=3, min_n=None):

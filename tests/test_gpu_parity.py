@@ -173,6 +173,85 @@ def test_random_wide_features(idx):
         assert_same(res, ref)
 
 
+V2_FEATURES = [
+    dict(aff=True), dict(ipa=True), dict(spread_hard=True), dict(spread_soft=True), dict(static_scores=True),
+    dict(aff=True, anti=True, ipa=True), dict(spread_hard=True, spread_soft=True, static_scores=True, static_mask=True),
+    dict(anti=True, aff=True, ipa=True, spread_hard=True, spread_soft=True, static_scores=True, gpu=True, eph=True,
+         scalars=2, presets=True, gates=True, tight_pods=True, static_mask=True, nz_differs=True, init_state=True,
+         zero_pods=True),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(V2_FEATURES)))
+@pytest.mark.parametrize("wg", ["", "64", "1024"])
+def test_random_v2_features(idx, wg):
+    """ABI v2 plugins (required affinity, InterPodAffinity scores, PodTopologySpread filter + score, NodeAffinity /
+    TaintToleration preferred, NodePreferAvoidPods) on random inputs, one-wave and multi-wave workgroups."""
+    feat = V2_FEATURES[idx]
+    for seed in range(3):
+        prob = randprob.rand_problem(3000 + 100 * idx + seed, N=50 + 41 * seed, P=350, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=6)
+        ref = O.run(prob, scen, orders)
+        res, variant = run_gpu(prob, scen, orders, env={"SIMON_WG": wg} if wg else None)
+        assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+
+
+def test_v2_hand_cases_on_gpu():
+    """The hand-derived cases of tests/test_oracle_v2.py through the HIP path."""
+    import test_oracle_v2 as T
+    probs = []
+    orig = T.zero_pods_problem
+
+    def capture(*a, **kw):
+        pr = orig(*a, **kw)
+        probs.append(pr)
+        return pr
+    T.zero_pods_problem = capture
+    try:
+        for name in ("test_spread_soft_upstream_vector_hostname", "test_spread_soft_two_constraints_zone_and_hostname",
+                     "test_spread_soft_ignored_nodes_and_maxskew_offset", "test_spread_soft_counts_only_nodes_of_the_term_node_set",
+                     "test_spread_hard_filter_skew_and_missing_label", "test_spread_hard_minimum_only_over_registered_domains",
+                     "test_required_affinity_first_pod_escape_then_colocation",
+                     "test_interpod_affinity_score_incoming_and_symmetric_terms",
+                     "test_node_affinity_and_taint_prefer_normalisation_and_static_add"):
+            getattr(T, name)()
+    finally:
+        T.zero_pods_problem = orig
+    assert len(probs) >= 9
+    for pr in probs:
+        n, P = pr.n_nodes, pr.n_pods
+        scen, orders = [[n, 0]], np.arange(P, dtype=np.int32)[None]
+        assert_same(run_gpu(pr, scen, orders)[0], O.run(pr, scen, orders))
+
+
+def test_explain_v2_codes_match_oracle():
+    prob = randprob.rand_problem(3777, N=30, P=300, anti=True, aff=True, spread_hard=True, spread_soft=True, ipa=True,
+                                 static_mask=True, tight_pods=True, gpu=True)
+    scen, orders = randprob.rand_scenarios(7, prob, S=2)
+    ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=24)
+    assert nf > 0
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        n, f2, c2 = ctx.explain(int(scen[0, 0]), orders[scen[0, 1]], max_failed=24)
+    assert n == nf and f2.tolist() == failed.tolist()
+    assert (c2 == codes).all()
+
+
+def test_explain_on_a_narrow_problem():
+    """simon_explain stages the all-feature kernel lazily when the batch itself runs on a NARROW kernel."""
+    prob = randprob.rand_problem(11, N=20, P=400, tight_pods=True)
+    scen, orders = randprob.rand_scenarios(3, prob, S=2)
+    ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=16)
+    assert nf > 0
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        assert ctx.stats().kernel_variant == capi.KERNEL_NARROW_CACHE
+        n, f2, c2 = ctx.explain(int(scen[0, 0]), orders[scen[0, 1]], max_failed=16)
+    assert n == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
+
+
 def test_config5_gpushare_style():
     """BASELINE config 5 shape (GPU share + required anti-affinity + taints): small pool, every placement compared;
     then ONE scenario at full size (50k pods x 5k nodes)."""

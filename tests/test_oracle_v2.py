@@ -1,0 +1,203 @@
+"""CPU tests: the oracle's placement-dependent plugins (InterPodAffinity, PodTopologySpread) and the static preferred
+scores against hand-derived answers.  Every pod here requests nothing (req = nz = 0), so LeastAllocated = 100 and
+BalancedAllocation = 100 on every node and `total - 200` isolates the plugin under test.
+
+Anchors: the formulas of vendor/k8s.io/kubernetes/pkg/scheduler/framework/plugins/{interpodaffinity,podtopologyspread,
+nodeaffinity,tainttoleration}; the PodTopologySpread vector 2/1/0/3 -> 40/80/100/0 is the expectation of upstream
+kubernetes v1.20 podtopologyspread/scoring_test.go "one constraint on node, all 4 nodes are candidates" (the vendored
+tree strips *_test.go, so it is restated here)."""
+import numpy as np
+
+import oracle_lib as O
+from open_simulator_amd import capi
+from open_simulator_amd.gomath import go_log, spread_log_table
+
+GiB = 1 << 30
+
+
+def zero_pods_problem(N, P, pod_class, n_pod_classes, preset=None, **kw):
+    prob = capi.Problem(alloc_cpu=[8000] * N, alloc_mem=[16 * GiB] * N, alloc_pods=[110] * N,
+                        req_cpu=[0] * P, req_mem=[0] * P, nz_cpu=[0] * P, nz_mem=[0] * P,
+                        pod_class=pod_class, n_pod_classes=n_pod_classes, n_node_classes=kw.pop("n_node_classes", 1),
+                        preset_node=preset, **kw)
+    return prob.normalise()
+
+
+def csr(lists):
+    off = np.cumsum([0] + [len(x) for x in lists]).astype(np.int32)
+    flat = [v for x in lists for v in x]
+    return off, np.array(flat if flat else [0], np.int32)
+
+
+def test_spread_soft_upstream_vector_hostname():
+    # existing matching pods per node a..d = 2,1,0,3 ; maxSkew 1 on kubernetes.io/hostname
+    preset = [0, 0, 1, 3, 3, 3, -1]
+    so, si = csr([[0]])
+    mo, mi = csr([[0]])
+    prob = zero_pods_problem(4, 7, [0] * 7, 1, preset, topo_dom=np.arange(4)[None], topo_n_dom=[4],
+                             term_topo_key=[0], match_off=mo, match_idx=mi, spread_soft_off=so, spread_soft_idx=si,
+                             spread_soft_skew=[1], topo_is_hostname=[1], spread_log=spread_log_table(4))
+    best, sc = O.score_pod_after(prob, 4, 6, 6)
+    # weight = log(4 + 2); raw = int(cnt * w + 0) = 3, 1, 0, 5 ; 100 * (max + min - s) / max
+    w = go_log(6.0)
+    raw = [int(c * w + 0.0) for c in (2, 1, 0, 3)]
+    assert raw == [3, 1, 0, 5]
+    assert ((sc["total"] - 200) // 2).tolist() == [40, 80, 100, 0]
+    assert best == 2
+
+
+def test_spread_soft_two_constraints_zone_and_hostname():
+    # nodes a,b in zone 0 ; c,d in zone 1 ; counts 2,1,0,3 ; constraints: hostname maxSkew 1, zone maxSkew 1
+    preset = [0, 0, 1, 3, 3, 3, -1]
+    so, si = csr([[0, 1]])
+    mo, mi = csr([[0, 1]])
+    prob = zero_pods_problem(4, 7, [0] * 7, 1, preset, topo_dom=[[0, 1, 2, 3], [0, 0, 1, 1]], topo_n_dom=[4, 2],
+                             term_topo_key=[0, 1], match_off=mo, match_idx=mi, spread_soft_off=so, spread_soft_idx=si,
+                             spread_soft_skew=[1, 1], topo_is_hostname=[1, 0], spread_log=spread_log_table(4))
+    _, sc = O.score_pod_after(prob, 4, 6, 6)
+    wh, wz = go_log(6.0), go_log(4.0)          # 4 scored nodes ; 2 distinct zones
+    raw = [int((h * wh + 0.0) + (z * wz + 0.0)) for h, z in ((2, 3), (1, 3), (0, 3), (3, 3))]
+    assert raw == [7, 5, 4, 9]
+    want = [100 * (9 + 4 - s) // 9 for s in raw]
+    assert want == [66, 88, 100, 44]
+    assert ((sc["total"] - 200) // 2).tolist() == want
+
+
+def test_spread_soft_ignored_nodes_and_maxskew_offset():
+    # node 2 lacks the zone label -> IgnoredNodes: score 0, not part of min/max nor of the topology size
+    preset = [0, 0, 1, -1]
+    so, si = csr([[0]])
+    mo, mi = csr([[0]])
+    prob = zero_pods_problem(3, 4, [0] * 4, 1, preset, topo_dom=[[0, 1, -1]], topo_n_dom=[2],
+                             term_topo_key=[0], match_off=mo, match_idx=mi, spread_soft_off=so, spread_soft_idx=si,
+                             spread_soft_skew=[5], topo_is_hostname=[0], spread_log=spread_log_table(3))
+    _, sc = O.score_pod_after(prob, 3, 3, 3)
+    w = go_log(4.0)                              # 2 distinct zones among the scored nodes
+    raw = [int(2 * w + 4.0), int(1 * w + 4.0)]   # maxSkew - 1 = 4 added
+    assert raw == [6, 5]
+    assert ((sc["total"] - 200) // 2).tolist() == [100 * (6 + 5 - 6) // 6, 100 * (6 + 5 - 5) // 6, 0]
+
+
+def test_spread_soft_counts_only_nodes_of_the_term_node_set():
+    # zone counts exclude pods on nodes outside the incoming pod's nodeSelector/affinity set (scoring.go:137-141)
+    preset = [0, 1, 1, -1]
+    so, si = csr([[0]])
+    mo, mi = csr([[0]])
+    sets = np.array([[0b101]], np.uint64)          # eligible: nodes 0 and 2 (node 1 fails the pod's nodeAffinity)
+    mask = np.array([[0b101]], np.uint64)          # ... and is filtered out statically
+    prob = zero_pods_problem(3, 4, [0] * 4, 1, preset, topo_dom=[[0, 0, 1]], topo_n_dom=[2], term_topo_key=[0],
+                             term_node_set=[0], node_sets=sets, static_mask=mask, match_off=mo, match_idx=mi,
+                             spread_soft_off=so, spread_soft_idx=si, spread_soft_skew=[1], topo_is_hostname=[0],
+                             spread_log=spread_log_table(3))
+    _, sc = O.score_pod_after(prob, 3, 3, 3)
+    assert sc["feasible"].tolist() == [1, 0, 1]
+    w = go_log(4.0)
+    raw = [int(1 * w), int(0 * w)]                 # zone 0 holds ONE counted pod (node 0), the two on node 1 are not counted
+    assert raw == [1, 0]
+    assert ((sc["total"][[0, 2]] - 200) // 2).tolist() == [0, 100]
+
+
+def test_spread_hard_filter_skew_and_missing_label():
+    # zones: n0 z0, n1 z1, n2 z2, n3 unlabeled ; matching pods z0:2 z1:1 z2:1 ; DoNotSchedule maxSkew 1, self-match
+    preset = [0, 0, 1, 2, -1]
+    ho, hi = csr([[0]])
+    mo, mi = csr([[0]])
+    prob = zero_pods_problem(4, 5, [0] * 5, 1, preset, topo_dom=[[0, 1, 2, -1]], topo_n_dom=[3], term_topo_key=[0],
+                             match_off=mo, match_idx=mi, spread_hard_off=ho, spread_hard_idx=hi, spread_hard_skew=[1],
+                             spread_hard_self=[1])
+    best, sc = O.score_pod_after(prob, 4, 4, 4)
+    # min = 1 ; skew z0 = 2+1-1 = 2 > 1 ; z1, z2 = 1+1-1 = 1
+    assert sc["codes"].tolist() == [capi.FAIL_SPREAD, 0, 0, capi.FAIL_SPREAD_LABEL]
+    assert best == 1
+    # without self-match the z0 node passes (2+0-1 = 1)
+    prob.spread_hard_self = np.array([0], np.int32)
+    assert O.score_pod_after(prob, 4, 4, 4)[1]["codes"].tolist() == [0, 0, 0, capi.FAIL_SPREAD_LABEL]
+
+
+def test_spread_hard_minimum_only_over_registered_domains():
+    # node 2 (zone 2, empty) is outside the eligible set: its zone is not registered, the global minimum stays 1,
+    # and a lookup of an unregistered pair counts 0 (filtering.go:236-251, 321-324)
+    preset = [0, 0, 1, -1]
+    ho, hi = csr([[0]])
+    mo, mi = csr([[0]])
+    sets = np.array([[0b011]], np.uint64)
+    prob = zero_pods_problem(3, 4, [0] * 4, 1, preset, topo_dom=[[0, 1, 2]], topo_n_dom=[3], term_topo_key=[0],
+                             node_sets=sets, match_off=mo, match_idx=mi, spread_hard_off=ho, spread_hard_idx=hi,
+                             spread_hard_skew=[1], spread_hard_self=[1], spread_hard_set=[0])
+    _, sc = O.score_pod_after(prob, 3, 3, 3)
+    # min over registered zones {0,1} = 1: z0 -> 2+1-1 = 2 fails ; z1 -> 1 ; z2 unregistered -> 0+1-1 = 0 passes
+    assert sc["codes"].tolist() == [capi.FAIL_SPREAD, 0, 0]
+    prob.spread_hard_set = np.array([-1], np.int32)     # every node registers: min = 0 (zone 2) -> z0: 3, z1: 2 fail
+    assert O.score_pod_after(prob, 3, 3, 3)[1]["codes"].tolist() == [capi.FAIL_SPREAD, capi.FAIL_SPREAD, 0]
+
+
+def test_required_affinity_first_pod_escape_then_colocation():
+    # zones [0, 0, 1, unlabeled]; class 0 = web pods with required affinity to web on zone (derived all-match term 0);
+    # class 1 = db pods with the same required affinity but not matching it themselves
+    ao, ai = csr([[0], [0]])
+    mo, mi = csr([[0], []])
+    kw = dict(topo_dom=[[0, 0, 1, -1]], topo_n_dom=[2], term_topo_key=[0], match_off=mo, match_idx=mi,
+              aff_off=ao, aff_idx=ai, class_flags=[capi.CLASS_AFF_SELF, 0])
+    prob = zero_pods_problem(4, 4, [1, 0, 0, 1], 2, **kw)
+    A = capi.FAIL_AFFINITY
+    # db pod first: nothing matches anywhere and it does not match itself -> every node fails
+    assert O.score_pod_after(prob, 4, 0, 0)[1]["codes"].tolist() == [A, A, A, A]
+    # first web pod: escape on every node that has the topology label (filtering.go:361-371)
+    best, sc = O.score_pod_after(prob, 4, 0, 1)
+    assert sc["codes"].tolist() == [0, 0, 0, A] and best == 0
+    res = O.run(prob, [[4, 0]], np.arange(4)[None])
+    # pod 0 (db) unschedulable; web pods land in zone 0 (node 0 first, then scores tie -> first max); db pod 3 follows
+    assert res.placement[0, 0] == capi.UNSCHEDULED and res.placement[0, 1] == 0
+    assert res.placement[0, 2] in (0, 1) and res.placement[0, 3] in (0, 1)
+    # second web pod: only zone 0 qualifies now
+    assert O.score_pod_after(prob, 4, 2, 2)[1]["codes"].tolist() == [0, 0, A, A]
+
+
+def test_interpod_affinity_score_incoming_and_symmetric_terms():
+    # hostname topology, 3 nodes.  terms: 0 = (app=cache, hostname), 1 = (app=web, hostname)
+    # existing: pod 0 class 1 (cache) on node 1 ; pod 1 class 2 on node 2 owns preferred affinity w=7 to web ;
+    # pod 2 class 3 on node 0 owns a REQUIRED affinity to web (hard weight 1).  incoming pod 3: class 0 = web with
+    # preferred affinity w=10 to cache.
+    mo, mi = csr([[1], [0], [], []])
+    po, pi = csr([[0], [], [], []])
+    oo, oi = csr([[], [], [1], [1]])
+    prob = zero_pods_problem(3, 4, [1, 2, 3, 0], 4, [1, 2, 0, -1], topo_dom=[[0, 1, 2]], topo_n_dom=[3],
+                             term_topo_key=[0, 0], match_off=mo, match_idx=mi, pref_off=po, pref_idx=pi, pref_w=[10],
+                             own_off=oo, own_idx=oi, own_w=[7, 1])
+    best, sc = O.score_pod_after(prob, 3, 3, 3)
+    raw = [1, 10, 7]
+    want = [int(100.0 * (float(s - 0) / float(10 - 0))) for s in raw]
+    assert want == [10, 100, 70]
+    assert (sc["total"] - 200).tolist() == want and best == 1
+    # preferred ANTI-affinity: negative weight; min starts at 0 (scoring.go:247-256)
+    prob.pref_w = np.array([-5], np.int32)
+    _, sc = O.score_pod_after(prob, 3, 3, 3)
+    raw = [1, -5, 7]
+    want = [int(100.0 * (float(s + 5) / float(12))) for s in raw]
+    assert (sc["total"] - 200).tolist() == want == [50, 0, 100]
+
+
+def test_node_affinity_and_taint_prefer_normalisation_and_static_add():
+    prob = zero_pods_problem(3, 1, [0], 1, n_node_classes=3, node_class=[0, 1, 2],
+                             node_affinity_raw=[[0, 3, 5]], taint_prefer_raw=[[2, 0, 1]])
+    _, sc = O.score_pod(prob, 3, 0)
+    # NodeAffinity 100*raw/max = 0, 60, 100 ; TaintToleration 100 - 100*raw/max = 0, 100, 50
+    assert (sc["total"] - 200).tolist() == [0 + 0, 60 + 100, 100 + 50]
+    prob.node_affinity_raw = np.zeros((1, 3), np.int64)        # max 0 -> 0 everywhere
+    prob.taint_prefer_raw = np.zeros((1, 3), np.int64)         # max 0, reverse -> 100 everywhere
+    prob.static_add = np.array([[1000000, 0, 1000000]], np.int64)   # NodePreferAvoidPods x 10000
+    _, sc = O.score_pod(prob, 3, 0)
+    assert (sc["total"] - 200).tolist() == [1000100, 100, 1000100]
+    # normalisation is over FEASIBLE nodes only: mask out the node holding the maximum
+    prob.node_affinity_raw = np.array([[1, 3, 5]], np.int64)
+    prob.static_add = None
+    prob.static_mask = np.array([[0b011]], np.uint64)
+    _, sc = O.score_pod(prob, 3, 0)
+    assert (sc["total"][:2] - 200).tolist() == [100 * 1 // 3 + 100, 100 + 100]
+
+
+def test_go_log_matches_published_values():
+    # spot values of math.Log printed by Go (%v): ln 2, ln 6, ln 10
+    assert go_log(2.0) == 0.6931471805599453
+    assert go_log(10.0) == 2.302585092994046
+    assert abs(go_log(6.0) - 1.791759469228055) < 3e-16
