@@ -733,7 +733,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         }
     } else {
-        T = c->force_T ? c->force_T : (c->max_n <= 512 ? 256 : c->max_n <= 4096 ? 512 : 1024);
+        T = c->force_T ? c->force_T : (c->max_n <= 1024 ? 256 : c->max_n <= 16384 ? 512 : 1024);
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
                           c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p,

@@ -50,9 +50,20 @@ struct WidePod {
     int64_t scalar[SIMON_MAX_SCALAR];
     int32_t cls, preset, gate, gpu_cnt;
     uint32_t flags;  // kPod* bits
-    uint32_t pad[7];
+    int32_t sig;     // request signature: row of the (signature, node) table
+    uint32_t pad[6];
 };
 static_assert(sizeof(WidePod) == 128, "WidePod must be 128 bytes");
+
+// One distinct pod request signature (what NodeResourcesFit + LeastAllocated + BalancedAllocation depend on), 96 B.
+struct WideSig {
+    int64_t req_cpu, req_mem, req_eph, nz_cpu, nz_mem;
+    int64_t scalar[SIMON_MAX_SCALAR];
+    uint32_t flags;  // kPodZero
+    uint32_t pad[5];
+};
+static_assert(sizeof(WideSig) == 96, "WideSig must be 96 bytes");
+constexpr int kMaxWideSigs = 1024;   // more distinct signatures than this: the kernel evaluates every node every cycle
 constexpr uint32_t kPodZero = 1u;      // all-zero request incl. scalars (fit.go:244-249)
 constexpr uint32_t kPodTerms = 2u;     // class touches topology counters (match / anti / aff / own lists non-empty)
 constexpr uint32_t kPodHard = 4u;      // class has DoNotSchedule spread constraints
@@ -63,19 +74,19 @@ struct WideScenario {
     int32_t n_nodes, order_id;
 };
 
-struct WideArgs {
-    int32_t N, P, K, Kt, Cp, Cn, Tm, S;     // S = scenarios in THIS launch (chunk)
-    int32_t mask_words, total_dom, has_gpu, has_mask, has_eph, nzeq, seen_stride;
-    // static node arrays [N] (shared)
-    const int64_t* alloc_cpu; const int64_t* alloc_mem; const int64_t* alloc_eph; const int32_t* alloc_pods;
-    const int32_t* node_class; const int64_t* scalar_alloc /*[K][N]*/;
+// Kernel arguments are split in two: WideArgs (by value, lives in SGPRs: what every cycle touches) and WideCold (a
+// struct in device memory, scalar-loaded on demand by the rarely taken feature paths).  Passing everything by value
+// made the compiler spill ~100 argument SGPRs into VGPR lanes and pay a v_readlane per use.
+struct WideCold {
+    int32_t Kt, Cp, Tm, total_dom, seen_stride, max_failed;
+    const int64_t* alloc_eph; const int64_t* scalar_alloc /*[K][N]*/;
     const int32_t* gpu_cnt; const int64_t* gpu_mem_total;
     const int32_t* topo_dom /*[Kt][N]*/;
     // initial state [N]
     const int64_t* i_req_cpu; const int64_t* i_req_mem; const int64_t* i_req_eph; const int64_t* i_nz_cpu;
     const int64_t* i_nz_mem; const int32_t* i_npods; const int64_t* i_scalar_req; const int64_t* i_gpu_used;
     // tables
-    const uint64_t* static_mask; const uint8_t* static_reason; const int64_t* simon_raw;
+    const uint8_t* static_reason;
     const int64_t* na_raw; const int64_t* tt_raw; const int64_t* static_add;   // [Cp][Cn] or null
     const int32_t* term_key; const int32_t* term_dom_off /*[Tm] offset of term t's counters*/;
     const int32_t* term_set /*[Tm] row of node_sets or -1*/; const uint64_t* node_sets;
@@ -87,18 +98,36 @@ struct WideArgs {
     const int32_t* sh_first_reg /*[E][N]: lowest eligible node index sharing node j's domain, INT_MAX if none*/;
     const int32_t* ss_off; const int32_t* ss_idx; const int32_t* ss_skew;
     const uint8_t* topo_is_hostname; const double* spread_log; const int32_t* key_seen_off /*[Kt]*/;
-    // stream
-    const WidePod* pods; const int32_t* orders; const WideScenario* scen /*[S] of this chunk*/;
-    // per-scenario mutable state, [S_chunk][...]
-    int64_t* st_req_cpu; int64_t* st_req_mem; int64_t* st_req_eph; int64_t* st_nz_cpu; int64_t* st_nz_mem;
-    int32_t* st_npods; int64_t* st_scalar /*[S][K][N]*/; int64_t* st_gpu /*[S][N][8]*/;
+    // per-scenario mutable state of the optional features, [S_chunk][...]
+    int64_t* st_req_eph; int64_t* st_nz_cpu; int64_t* st_nz_mem;
+    int64_t* st_scalar /*[S][K][N]*/; int64_t* st_gpu /*[S][N][8]*/;
     int32_t* st_cnt /*[S][3*total_dom + Tm]: cnt_match, cnt_owner, w_owner, term_total*/;
     int32_t* st_seen /*[S][seen_stride]: distinct-domain stamps of the soft spread constraints*/;
+    // explain outputs (single scenario)
+    int32_t* failed_pods; uint16_t* fail_codes; int32_t* n_failed;
+    // diagnostics (env SIMON_WIDE_PROF): per (scenario, wave) cycle sums of the phases of a cycle, or null
+    unsigned long long* prof;
+};
+
+struct WideArgs {
+    int32_t N, P, K, Cn, S;                 // S = scenarios in THIS launch (chunk)
+    int32_t mask_words, bc_words /*LDS words of base|class*/, n_sigs /*0 = table off*/, tab_nstride /*bytes per table row*/;
+    uint32_t flags;                         // kArg* bits
+    size_t tab_stride /*bytes per scenario*/;
+    // static node arrays [N] (shared)
+    const int64_t* alloc_cpu; const int64_t* alloc_mem; const int32_t* alloc_pods; const int32_t* node_class;
+    const uint64_t* static_mask; const int64_t* simon_raw;
+    // stream
+    const WidePod* pods; const int32_t* orders; const WideScenario* scen /*[S] of this chunk*/; const WideSig* sigs;
+    // per-scenario mutable state every cycle touches, [S_chunk][N]
+    int64_t* st_req_cpu; int64_t* st_req_mem; int32_t* st_npods;
+    unsigned char* st_tab /*[S][n_sigs][tab_nstride]*/;
     // outputs of this chunk
     int32_t* unscheduled; int64_t* used_cpu; int64_t* used_mem; int32_t* placement /*[S][P] or null*/;
-    // explain outputs (single scenario)
-    int32_t* failed_pods; uint16_t* fail_codes; int32_t max_failed; int32_t* n_failed;
+    const WideCold* cold;
 };
+constexpr uint32_t kArgGpu = 1u, kArgMask = 2u, kArgEph = 4u, kArgNzeq = 8u, kArgClassMode = 16u /*Cn <= 64*/,
+                   kArgKey32 = 32u /*32-bit arg-max key*/, kArgProf = 64u, kArgTerms = 128u /*Tm > 0*/;
 
 struct WideDevice {
     void* blobs[80] = {};
@@ -123,6 +152,10 @@ struct WideDevice {
     uint8_t *class_flags = nullptr, *topo_is_hostname = nullptr;
     double* spread_log = nullptr;
     WidePod* pods = nullptr;
+    WideSig* sigs = nullptr;
+    int n_sigs = 0;
+    WideCold* d_cold = nullptr;   // two slots: [0] batch runs, [1] explain
+    unsigned char* st_tab = nullptr;
     // state
     int64_t *st_req_cpu = nullptr, *st_req_mem = nullptr, *st_req_eph = nullptr, *st_nz_cpu = nullptr, *st_nz_mem = nullptr,
             *st_scalar = nullptr, *st_gpu = nullptr;
