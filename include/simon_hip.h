@@ -39,6 +39,8 @@ extern "C" {
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
 #define SIMON_MAX_TERMS_PER_CLASS 8
 #define SIMON_MAX_SPREAD 4  /* PodTopologySpread constraints per pod class and kind */
+#define SIMON_SPREAD_DUP_KEY 0x40000000 /* ORed into spread_soft_skew: an earlier constraint of the same pod already registered this
+                                             (non-hostname) topology key, so initPreScoreState counts size 0 for this one (scoring.go:86-96) */
 #define SIMON_CLASS_AFF_SELF 0x1u /* pods of the class match all of their own required affinity terms (filtering.go:361-371) */
 
 /* error codes */
@@ -193,7 +195,9 @@ typedef struct simon_class_tables {
     /* PodTopologySpread.  hard = DoNotSchedule constraints (filtering.go:283-333): node fails when a key is missing or
      * cnt_match[t][dom] + self - min over the term's domains > maxSkew.  soft = ScheduleAnyway constraints incl. the
      * system defaults maxSkew 3 on hostname / 5 on zone for pods selected by a Service/RC/RS/STS (plugin.go:39-50,
-     * common.go:45-60): Score/NormalizeScore of scoring.go:174-256. */
+     * common.go:45-60): Score/NormalizeScore of scoring.go:174-256.  The plugin counts per topology PAIR: constraints
+     * of one pod that share a topology key must reference ONE term whose match list carries each pod class once per
+     * matching selector (duplicates in match_idx are allowed and meaningful). */
     const int32_t* spread_hard_off;  /* [Cp+1]; optional */
     const int32_t* spread_hard_idx;  /* term */
     const int32_t* spread_hard_skew; /* maxSkew */
@@ -203,7 +207,7 @@ typedef struct simon_class_tables {
                                         -1 = every node carrying this key; NULL = all -1 */
     const int32_t* spread_soft_off;  /* [Cp+1]; optional */
     const int32_t* spread_soft_idx;
-    const int32_t* spread_soft_skew;
+    const int32_t* spread_soft_skew; /* maxSkew, optionally | SIMON_SPREAD_DUP_KEY */
     const uint8_t* topo_is_hostname; /* [Kt] 1 for kubernetes.io/hostname (scoring.go:100-104: size = scored nodes); optional */
     const double* spread_log;        /* [N+1] spread_log[i] = Go math.Log(float64(i+2)) (scoring.go:279-281); the Go host fills
                                         it with its own math.Log so the engine never approximates it; required with soft */

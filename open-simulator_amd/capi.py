@@ -34,6 +34,7 @@ FAIL_SPREAD_LABEL = 0x2011
 FAIL_GPUSHARE = 0x1000
 CLASS_AFF_SELF = 0x1
 MAX_SPREAD = 4
+SPREAD_DUP_KEY = 0x40000000
 
 KERNEL_NARROW = 1
 KERNEL_WIDE = 2

@@ -365,7 +365,7 @@ __device__ __forceinline__ long long pts_raw(const WideArgs& A, const NodeView& 
     for (int e = lo; e < hi; ++e) {
         const int t = COLD(A)->ss_idx[e];
         const long long cnt = v.cnt_match()[COLD(A)->term_dom_off[t] + term_dom(A, t, j)];
-        score += (double)cnt * sel4(weight, e - lo) + (double)(COLD(A)->ss_skew[e] - 1);     // scoreForCount (:287-289)
+        score += (double)cnt * sel4(weight, e - lo) + (double)((COLD(A)->ss_skew[e] & ~SIMON_SPREAD_DUP_KEY) - 1);     // scoreForCount (:287-289)
     }
     return (long long)score;
 }
@@ -759,7 +759,8 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                     for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {   // TopologyNormalizingWeight (:98-106, :279-281)
                         if (q >= n_soft) continue;
                         const int key = COLD(A)->term_key[COLD(A)->ss_idx[slo + q]];
-                        const long long sz = COLD(A)->topo_is_hostname[key] ? scored : r[cm + 1 + q];
+                        const long long sz = (COLD(A)->ss_skew[slo + q] & SIMON_SPREAD_DUP_KEY) ? 0   // pair registered by an earlier constraint
+                                         : COLD(A)->topo_is_hostname[key] ? scored : r[cm + 1 + q];
                         wq[q] = COLD(A)->spread_log[sz];
                     }
                     weight = Weight4{wq[0], wq[1], wq[2], wq[3]};

@@ -19,6 +19,10 @@ FIT_REASONS = [(capi.FIT_PODS, "Too many pods"), (capi.FIT_CPU, "Insufficient cp
 ERR_AFFINITY_NOT_MATCH = "node(s) didn't match pod affinity/anti-affinity"
 ERR_ANTI_AFFINITY_RULES = "node(s) didn't match pod anti-affinity rules"
 ERR_EXISTING_ANTI_AFFINITY = "node(s) didn't satisfy existing pods anti-affinity rules"
+ERR_AFFINITY_RULES = "node(s) didn't match pod affinity rules"
+# V/framework/plugins/podtopologyspread/plugin.go:33-38
+ERR_SPREAD = "node(s) didn't match pod topology spread constraints"
+ERR_SPREAD_LABEL = ERR_SPREAD + " (missing required label)"
 # static plugins (host-defined static_reason ids -> text); the defaults cover the texts that need no parameters
 DEFAULT_STATIC_REASONS = {
     1: "node(s) were unschedulable",                                  # nodeunschedulable/node_unschedulable.go:42
@@ -50,6 +54,12 @@ def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scal
         return [ERR_AFFINITY_NOT_MATCH, ERR_ANTI_AFFINITY_RULES]
     if code == capi.FAIL_ANTI_EXISTING:
         return [ERR_AFFINITY_NOT_MATCH, ERR_EXISTING_ANTI_AFFINITY]
+    if code == capi.FAIL_AFFINITY:
+        return [ERR_AFFINITY_NOT_MATCH, ERR_AFFINITY_RULES]
+    if code == capi.FAIL_SPREAD:
+        return [ERR_SPREAD]
+    if code == capi.FAIL_SPREAD_LABEL:
+        return [ERR_SPREAD_LABEL]
     if code == capi.FAIL_GPUSHARE:
         return ["Node:" + node_name]                                  # pkg/simulator/plugin/open-gpu-share.go:64-78
     raise ValueError(f"unknown failure code {code:#x}")

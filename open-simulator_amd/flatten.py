@@ -1,0 +1,491 @@
+"""Kubernetes objects -> the SoA inputs of include/simon_hip.h (the "flatten" half of the Go shim).
+
+Everything about a (pod, node) pair that does not depend on placements is decided here, once, on the host:
+  * pod request rows (computePodResourceRequest / non-zero requests), Open-Gpu-Share annotations;
+  * pod classes = pods that are indistinguishable for the scheduler (replicas of one workload);
+  * the static filter mask per (pod class, node): NodeUnschedulable, NodeName, TaintToleration, NodeAffinity, with the
+    reason text of the first failing plugin;
+  * node classes = nodes with equal allocatable and equal static scores for every pod class, and the per
+    (pod class, node class) tables: SimonPlugin raw score, NodeAffinity preferred weight sum, intolerable
+    PreferNoSchedule taints, NodePreferAvoidPods;
+  * topology keys / domains and the interned affinity / spread terms with their per-class role lists.
+Each step names the reference code it restates (V/ = vendor/k8s.io/kubernetes/pkg/scheduler/).
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import capi, fiterror, gomath, k8s
+from .quantity import ZERO, Quantity, parse_quantity, simon_raw_score
+
+ZONE_KEY = "topology.kubernetes.io/zone"
+SYSTEM_DEFAULT_SPREAD = ((k8s.LABEL_HOSTNAME, 3), (ZONE_KEY, 5))      # podtopologyspread/plugin.go:39-50
+HARD_POD_AFFINITY_WEIGHT = 1                                           # V/apis/config/v1beta1/defaults.go:179
+ANNO_PREFER_AVOID = "scheduler.alpha.kubernetes.io/preferAvoidPods"
+
+
+class Unsupported(ValueError):
+    """The workload uses a feature the engine does not model: the Go shim must route it to the Go path."""
+
+
+@dataclass
+class Flat:
+    problem: capi.Problem
+    node_names: List[str]
+    pod_refs: List[Tuple[str, str]]                 # (namespace, name) per pod id
+    pods: List[dict]
+    static_reasons: Dict[int, str]
+    scalar_names: List[str]
+    pod_class_of: np.ndarray
+    const_score: np.ndarray
+    info: dict = field(default_factory=dict)
+
+
+def _qcmp(a: Quantity, b: Quantity) -> int:
+    s = min(a.scale, b.scale)
+    x, y = a.value * 10 ** (a.scale - s), b.value * 10 ** (b.scale - s)
+    return (x > y) - (x < y)
+
+
+def pod_requests_quantities(pod: dict) -> Dict[str, Quantity]:
+    """resourcehelper.PodRequestsAndLimits, vendor/k8s.io/kubectl/pkg/util/resource/resource.go:34-58 (requests half)."""
+    spec = pod["spec"]
+    reqs: Dict[str, Quantity] = {}
+    for c in spec.get("containers") or []:
+        for name, q in ((c.get("resources") or {}).get("requests") or {}).items():
+            reqs[name] = reqs[name].add(parse_quantity(str(q))) if name in reqs else parse_quantity(str(q))
+    for c in spec.get("initContainers") or []:
+        for name, q in ((c.get("resources") or {}).get("requests") or {}).items():
+            qq = parse_quantity(str(q))
+            if name not in reqs or _qcmp(qq, reqs[name]) > 0:
+                reqs[name] = qq
+    for name, q in (spec.get("overhead") or {}).items():
+        reqs[name] = reqs[name].add(parse_quantity(str(q))) if name in reqs else parse_quantity(str(q))
+    return reqs
+
+
+def _gpu_annotations(pod: dict) -> Tuple[int, int]:
+    """GetGpuMemoryFromPodAnnotation / GetGpuCountFromPodAnnotation (pkg/type/open-gpu-share/utils/pod.go:56-97)."""
+    a = pod["metadata"].get("annotations") or {}
+    mem = cnt = 0
+    if k8s.GPU_MEM in a:
+        try:
+            mem = parse_quantity(str(a[k8s.GPU_MEM])).int_value()
+        except ValueError:
+            mem = 0
+    if k8s.GPU_COUNT in a:
+        try:
+            cnt = int(str(a[k8s.GPU_COUNT]))
+        except ValueError:
+            cnt = 0
+    if mem > 0 and cnt == 0:
+        cnt = 1
+    return mem, cnt
+
+
+def _term_namespaces(pod: dict, term: dict) -> Tuple[str, ...]:
+    ns = term.get("namespaces") or []
+    return tuple(sorted(ns)) if ns else (pod["metadata"]["namespace"],)      # V/framework/types.go:120-131
+
+
+def _affinity_terms(pod: dict):
+    """NewPodInfo (V/framework/types.go:143-176): required/preferred (anti-)affinity terms of a pod as
+    (namespaces, selector-json, topologyKey[, weight])."""
+    aff = pod["spec"].get("affinity") or {}
+    out = {"req_aff": [], "req_anti": [], "pref_aff": [], "pref_anti": []}
+    for kind, key in (("podAffinity", "aff"), ("podAntiAffinity", "anti")):
+        a = aff.get(kind) or {}
+        for t in a.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
+            out["req_" + key].append((_term_namespaces(pod, t), json.dumps(t.get("labelSelector"), sort_keys=True), t["topologyKey"]))
+        for wt in a.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
+            t = wt["podAffinityTerm"]
+            out["pref_" + key].append((_term_namespaces(pod, t), json.dumps(t.get("labelSelector"), sort_keys=True),
+                                       t["topologyKey"], int(wt["weight"])))
+    return out
+
+
+def _matches_term(pod_ns: str, pod_labels: dict, namespaces, sel_json: str) -> bool:
+    """schedutil.PodMatchesTermsNamespaceAndSelector, V/util/topologies.go:40-49."""
+    return pod_ns in namespaces and k8s.label_selector_matches(json.loads(sel_json), pod_labels)
+
+
+def _default_spread_selector(pod: dict, services, replicasets, statefulsets):
+    """helper.DefaultSelector (V/framework/plugins/helper/spread.go:28-95): merged Service selectors AND the selectors of
+    the matching ReplicaSets / StatefulSets.  Returns a list of LabelSelector dicts to be ANDed (empty = no selector)."""
+    ns, labels = pod["metadata"]["namespace"], pod["metadata"].get("labels") or {}
+    parts = []
+    merged = {}
+    for svc in services:
+        if (svc["metadata"].get("namespace") or "default") != ns:
+            continue
+        sel = svc.get("spec", {}).get("selector")
+        if sel is None:
+            continue
+        if all(labels.get(k) == v for k, v in sel.items()):
+            merged.update(sel)
+    if merged:
+        parts.append({"matchLabels": merged})
+    for coll in (replicasets, statefulsets):
+        if not labels:
+            break                                  # GetPodReplicaSets / GetPodStatefulSets: no labels -> no match
+        for o in coll:
+            if (o["metadata"].get("namespace") or "default") != ns:
+                continue
+            sel = o["spec"].get("selector")
+            if sel is None or k8s.selector_is_empty(sel) or not k8s.label_selector_matches(sel, labels):
+                continue
+            parts.append(sel)
+    return parts
+
+
+def _spread_constraints(pod: dict, services, replicasets, statefulsets):
+    """podtopologyspread: explicit constraints (filterTopologySpreadConstraints, common.go:73-91) or the system
+    defaults over the default selector (buildDefaultConstraints, common.go:45-60).  Returns (hard, soft) lists of
+    (selector-json, topologyKey, maxSkew)."""
+    explicit = pod["spec"].get("topologySpreadConstraints") or []
+    hard, soft = [], []
+    if explicit:
+        for c in explicit:
+            item = (json.dumps([c.get("labelSelector")], sort_keys=True), c["topologyKey"], int(c["maxSkew"]))
+            (hard if c.get("whenUnsatisfiable", "DoNotSchedule") == "DoNotSchedule" else soft).append(item)
+        return hard, soft
+    parts = _default_spread_selector(pod, services, replicasets, statefulsets)
+    if parts:
+        sel = json.dumps(parts, sort_keys=True)
+        soft = [(sel, key, skew) for key, skew in SYSTEM_DEFAULT_SPREAD]
+    return hard, soft
+
+
+def _selectors_match(sel_list_json: str, labels: dict) -> bool:
+    return all(k8s.label_selector_matches(sel, labels) for sel in json.loads(sel_list_json))
+
+
+def _prefer_avoid(node: dict, pod: dict) -> int:
+    """NodePreferAvoidPods.Score (nodepreferavoidpods/node_prefer_avoid_pods.go:58-82): 0 when the node's annotation lists
+    the pod's RC / ReplicaSet controller, else 100."""
+    refs = [r for r in pod["metadata"].get("ownerReferences") or [] if r.get("controller")]
+    if not refs or refs[0].get("kind") not in ("ReplicationController", "ReplicaSet"):
+        return 100
+    anno = (node["metadata"].get("annotations") or {}).get(ANNO_PREFER_AVOID)
+    if not anno:
+        return 100
+    try:
+        avoids = json.loads(anno).get("preferAvoidPods") or []
+    except ValueError:
+        return 100
+    for a in avoids:
+        ctl = (a.get("podSignature") or {}).get("podController") or {}
+        if ctl.get("kind") == refs[0]["kind"] and ctl.get("uid") == refs[0].get("uid"):
+            return 0
+    return 100
+
+
+def _bitmask(flags, words) -> np.ndarray:
+    m = np.zeros(words, np.uint64)
+    for j, f in enumerate(flags):
+        if f:
+            m[j // 64] |= np.uint64(1) << np.uint64(j % 64)
+    return m
+
+
+def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), statefulsets=(),
+            gates: Optional[List[int]] = None) -> Flat:
+    """nodes: the pool in canonical order (cluster nodes, then new-node clones).  pods: the stream in scheduling order;
+    a pod with spec.nodeName is bound without filtering (V/eventhandlers.go:223-236).  gates[p] = node index the pod
+    depends on (DaemonSet pods of new nodes, pkg/simulator/core.go:85-95) or -1."""
+    N, P = len(nodes), len(pods)
+    node_names = [n["metadata"]["name"] for n in nodes]
+    node_index = {name: j for j, name in enumerate(node_names)}
+    if len(node_index) != N:
+        raise ValueError("duplicate node names")
+    words = (N + 63) // 64
+
+    # ---- pods: requests, classes ---------------------------------------------------------------------------
+    reqs = [k8s.pod_request(p) for p in pods]
+    for p in pods:
+        for c in (p["spec"].get("containers") or []) + (p["spec"].get("initContainers") or []):
+            for port in c.get("ports") or []:
+                if port.get("hostPort"):
+                    raise Unsupported("hostPort (NodePorts filter) is not modelled")
+    scalar_names = sorted({name for r in reqs for name, v in r.items()
+                           if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
+    if len(scalar_names) > capi.MAX_SCALAR:
+        raise Unsupported(f"more than {capi.MAX_SCALAR} extended resources requested")
+    req_cpu = np.array([r.get("cpu", 0) for r in reqs], np.int64)
+    req_mem = np.array([r.get("memory", 0) for r in reqs], np.int64)
+    req_eph = np.array([r.get("ephemeral-storage", 0) for r in reqs], np.int64)
+    nz = [k8s.pod_nonzero_request(p) for p in pods]
+    nz_cpu = np.array([a for a, _ in nz], np.int64)
+    nz_mem = np.array([b for _, b in nz], np.int64)
+    scalar_req = np.array([[r.get(name, 0) for r in reqs] for name in scalar_names], np.int64).reshape(len(scalar_names), P)
+    gpu = [_gpu_annotations(p) for p in pods]
+    gpu_mem = np.array([g[0] for g in gpu], np.int64)
+    gpu_cnt = np.array([g[1] for g in gpu], np.int32)
+    preset = np.array([node_index.get(p["spec"].get("nodeName"), -1) if p["spec"].get("nodeName") else -1 for p in pods], np.int32)
+    for i, p in enumerate(pods):
+        if p["spec"].get("nodeName") and preset[i] < 0:
+            raise Unsupported(f"pod {p['metadata']['name']} is bound to unknown node {p['spec']['nodeName']}")
+
+    class_ids: Dict[str, int] = {}
+    class_rep: List[dict] = []
+    pod_class = np.empty(P, np.int32)
+    for i, p in enumerate(pods):
+        spec, md = p["spec"], p["metadata"]
+        owner = [r.get("kind") for r in md.get("ownerReferences") or [] if r.get("controller")]
+        key = json.dumps([md.get("namespace"), md.get("labels") or {}, spec.get("nodeSelector"), spec.get("affinity"),
+                          spec.get("tolerations"), spec.get("topologySpreadConstraints"), owner,
+                          {k: str(v) for k, v in pod_requests_quantities(p).items()}, spec.get("overhead")], sort_keys=True)
+        if key not in class_ids:
+            class_ids[key] = len(class_rep)
+            class_rep.append(p)
+        pod_class[i] = class_ids[key]
+    Cp = len(class_rep)
+
+    # ---- static filters per (pod class, node): first failing plugin in registry order --------------------------
+    reason_ids: Dict[str, int] = {v: k for k, v in fiterror.DEFAULT_STATIC_REASONS.items()}
+
+    def rid(text: str) -> int:
+        if text not in reason_ids:
+            if len(reason_ids) >= 255:
+                raise Unsupported("more than 255 distinct static failure reasons")
+            reason_ids[text] = len(reason_ids) + 1
+        return reason_ids[text]
+    static_ok = np.ones((Cp, N), bool)
+    static_reason = np.zeros((Cp, N), np.uint8)
+    affinity_ok = np.ones((Cp, N), bool)          # PodMatchesNodeSelectorAndAffinityTerms alone (spread eligibility)
+    for c, p in enumerate(class_rep):
+        unsched_tol = {"key": "node.kubernetes.io/unschedulable", "effect": "NoSchedule"}
+        tolerates_unsched = any(k8s.toleration_tolerates(t, unsched_tol) for t in p["spec"].get("tolerations") or [])
+        for j, node in enumerate(nodes):
+            affinity_ok[c, j] = k8s.pod_matches_node_selector_and_affinity(p, node)
+            reason = None
+            if (node.get("spec") or {}).get("unschedulable") and not tolerates_unsched:   # nodeunschedulable/node_unschedulable.go:51-66
+                reason = "node(s) were unschedulable"
+            else:
+                taint = k8s.find_untolerated_taint(node, p)
+                if taint is not None:
+                    reason = fiterror.taint_reason(taint.get("key", ""), taint.get("value", "") or "")
+                elif not affinity_ok[c, j]:
+                    reason = "node(s) didn't match Pod's node affinity"
+            if reason is not None:
+                static_ok[c, j] = False
+                static_reason[c, j] = rid(reason)
+    static_mask = np.stack([_bitmask(static_ok[c], words) for c in range(Cp)])
+
+    # ---- nodes: allocatable, GPU capacity, static scores, classes ---------------------------------------------
+    allocs = [k8s.node_allocatable(n) for n in nodes]
+    alloc_cpu = np.array([a.get("cpu", 0) for a in allocs], np.int64)
+    alloc_mem = np.array([a.get("memory", 0) for a in allocs], np.int64)
+    alloc_eph = np.array([a.get("ephemeral-storage", 0) for a in allocs], np.int64)
+    alloc_pods = np.array([a.get("pods", 0) for a in allocs], np.int32)
+    scalar_alloc = np.array([[a.get(name, 0) for a in allocs] for name in scalar_names], np.int64).reshape(len(scalar_names), N)
+    caps = [(n.get("status") or {}).get("capacity") or {} for n in nodes]
+    node_gpu_cnt = np.array([int(parse_quantity(str(c[k8s.GPU_COUNT])).int_value()) if k8s.GPU_COUNT in c else 0 for c in caps], np.int32)
+    node_gpu_mem = np.array([parse_quantity(str(c[k8s.GPU_MEM])).int_value() if k8s.GPU_MEM in c else 0 for c in caps], np.int64)
+    if (node_gpu_cnt > capi.MAX_GPU_DEV).any():
+        raise Unsupported(f"node with more than {capi.MAX_GPU_DEV} GPU devices")
+    na = np.array([[k8s.node_affinity_preferred_score(p, n) for n in nodes] for p in class_rep], np.int64).reshape(Cp, N)
+    tt = np.array([[k8s.count_intolerable_prefer_no_schedule(n, p) for n in nodes] for p in class_rep], np.int64).reshape(Cp, N)
+    npa = np.array([[_prefer_avoid(n, p) for n in nodes] for p in class_rep], np.int64).reshape(Cp, N)
+    alloc_q = [{name: parse_quantity(str(q)) for name, q in ((n.get("status") or {}).get("allocatable") or {}).items()} for n in nodes]
+    ncls_ids: Dict[str, int] = {}
+    ncls_rep: List[int] = []
+    node_class = np.empty(N, np.int32)
+    for j in range(N):
+        key = json.dumps([{k: [q.value, q.scale, q.format] for k, q in sorted(alloc_q[j].items())},
+                          na[:, j].tolist(), tt[:, j].tolist(), npa[:, j].tolist()])
+        if key not in ncls_ids:
+            ncls_ids[key] = len(ncls_rep)
+            ncls_rep.append(j)
+        node_class[j] = ncls_ids[key]
+    Cn = len(ncls_rep)
+    simon_raw = np.zeros((Cp, Cn), np.int64)
+    for c, p in enumerate(class_rep):
+        rq = pod_requests_quantities(p)
+        for d, j in enumerate(ncls_rep):
+            simon_raw[c, d] = simon_raw_score(rq, alloc_q[j])
+    na_t, tt_t, npa_t = na[:, ncls_rep], tt[:, ncls_rep], npa[:, ncls_rep]
+
+    # constants the engine does not evaluate: ImageLocality 0, and the plugins that score alike on every node
+    const = np.zeros(Cp, np.int64)
+    prob_kw = {}
+    if na_t.any():
+        prob_kw["node_affinity_raw"] = na_t
+    if tt_t.any():
+        prob_kw["taint_prefer_raw"] = tt_t
+    else:
+        const += 100                                   # DefaultNormalizeScore(reverse) of all zeros
+    if (npa_t != 100).any():
+        prob_kw["static_add"] = npa_t * 10000
+    else:
+        const += 100 * 10000
+
+    # ---- topology keys, terms, role lists -------------------------------------------------------------------
+    key_ids: Dict[str, int] = {}
+    term_ids: Dict[tuple, int] = {}
+    terms: List[tuple] = []                        # (kind, namespaces, selector-json, key index, node-set id)
+    set_ids: Dict[bytes, int] = {}
+    node_sets: List[np.ndarray] = []
+
+    def key_id(k: str) -> int:
+        if k not in key_ids:
+            key_ids[k] = len(key_ids)
+        return key_ids[k]
+
+    def set_id(flags) -> int:
+        m = _bitmask(flags, words)
+        b = m.tobytes()
+        if b not in set_ids:
+            set_ids[b] = len(node_sets)
+            node_sets.append(m)
+        return set_ids[b]
+
+    def term_id(kind: str, namespaces, sel_json: str, key: str, nset: int = -1) -> int:
+        t = (kind, tuple(namespaces), sel_json, key_id(key), nset)
+        if t not in term_ids:
+            term_ids[t] = len(terms)
+            terms.append(t)
+        return term_ids[t]
+
+    anti, aff, pref, own, hard, soft, flags = ([[] for _ in range(Cp)] for _ in range(7))
+    pref_w, own_w, hard_skew, hard_self, hard_set, soft_skew = ([[] for _ in range(Cp)] for _ in range(6))
+    const_pts = np.zeros(Cp, np.int64)
+    for c, p in enumerate(class_rep):
+        ns, labels = p["metadata"]["namespace"], p["metadata"].get("labels") or {}
+        at = _affinity_terms(p)
+        for (nss, sel, key) in at["req_anti"]:
+            anti[c].append(term_id("sel", nss, sel, key))
+        if at["req_aff"]:
+            allsel = json.dumps(sorted([list(n_) + [s_] for n_, s_, _ in at["req_aff"]]), sort_keys=True)
+            for (nss, sel, key) in at["req_aff"]:
+                aff[c].append(term_id("all", (), allsel, key))
+                own[c].append(term_id("sel", nss, sel, key))
+                own_w[c].append(HARD_POD_AFFINITY_WEIGHT)
+            flags[c] = all(_matches_term(ns, labels, n_, s_) for n_, s_, _ in at["req_aff"])
+        else:
+            flags[c] = False
+        for (nss, sel, key, w) in at["pref_aff"]:
+            t = term_id("sel", nss, sel, key)
+            pref[c].append(t); pref_w[c].append(w)
+            own[c].append(t); own_w[c].append(w)
+        for (nss, sel, key, w) in at["pref_anti"]:
+            t = term_id("sel", nss, sel, key)
+            pref[c].append(t); pref_w[c].append(-w)
+            own[c].append(t); own_w[c].append(-w)
+        h, s = _spread_constraints(p, services, replicasets, statefulsets)
+        if len(h) > capi.MAX_SPREAD or len(s) > capi.MAX_SPREAD:
+            raise Unsupported(f"more than {capi.MAX_SPREAD} topology spread constraints of one kind")
+        has_all = lambda cons: np.array([all(k in (n["metadata"].get("labels") or {}) for _, k, _ in cons) for n in nodes], bool)
+        # The plugin keeps ONE counter per topology pair (TpPairToMatchNum / TopologyPairToPodCounts are keyed by
+        # (key, value), filtering.go:253-268, scoring.go:129-160): constraints of one pod that share a topology key add
+        # their matches into the same counter.  Such constraints therefore share a term whose selector LIST is matched
+        # with multiplicity (a pod matching two of the selectors is counted twice).  The hostname key of the SOFT
+        # constraints is counted per constraint in Score (scoring.go:190-192) and stays separate.
+        def grouped(cons, merge_hostname):
+            by_key: Dict[str, List[str]] = {}
+            for sel, key, _ in cons:
+                if merge_hostname or key != k8s.LABEL_HOSTNAME:
+                    by_key.setdefault(key, []).append(sel)
+            return by_key
+        if h:
+            elig = set_id(affinity_ok[c] & has_all(h))
+            by_key = grouped(h, True)
+            for (sel, key, skew) in h:
+                hard[c].append(term_id("spread", (ns,), json.dumps(by_key[key]), key))
+                hard_skew[c].append(skew)
+                hard_self[c].append(int(_selectors_match(sel, labels)))
+                hard_set[c].append(elig)
+        if s:
+            elig = set_id(affinity_ok[c] & has_all(s))
+            by_key = grouped(s, False)
+            seen_keys = set()
+            for (sel, key, skew) in s:
+                sels = by_key.get(key, [sel])
+                soft[c].append(term_id("spread", (ns,), json.dumps(sels), key, elig))
+                # initPreScoreState registers a pair once (scoring.go:86-96): only the first constraint of a key gets
+                # the topology size, later ones see size 0
+                dup = key != k8s.LABEL_HOSTNAME and key in seen_keys
+                seen_keys.add(key)
+                soft_skew[c].append(skew | (capi.SPREAD_DUP_KEY if dup else 0))
+        else:
+            const_pts[c] = 100 * 2                       # no constraints: every node scores MaxNodeScore (scoring.go:242-246)
+    const += const_pts
+
+    def class_matches(c: int, t: tuple) -> bool:
+        p = class_rep[c]
+        ns, labels = p["metadata"]["namespace"], p["metadata"].get("labels") or {}
+        kind, nss, sel = t[0], t[1], t[2]
+        if kind == "sel":
+            return _matches_term(ns, labels, nss, sel)
+        if kind == "all":
+            return all(_matches_term(ns, labels, tuple(x[:-1]), x[-1]) for x in json.loads(sel))
+        if ns not in nss:                                           # countPodsMatchSelector: same namespace (common.go:93-105)
+            return 0
+        return sum(1 for s_ in json.loads(sel) if _selectors_match(s_, labels))   # multiplicity, see `grouped` above
+    match = [[t for t in range(len(terms)) for _ in range(int(class_matches(c, terms[t])))] for c in range(Cp)]
+
+    T = len(terms)
+    Kt = len(key_ids)
+    if T:
+        keys = sorted(key_ids, key=key_ids.get)
+        topo_dom = np.full((Kt, N), -1, np.int32)
+        topo_n = np.zeros(Kt, np.int32)
+        for k, key in enumerate(keys):
+            vals: Dict[str, int] = {}
+            for j, n in enumerate(nodes):
+                lab = n["metadata"].get("labels") or {}
+                if key in lab:
+                    topo_dom[k, j] = vals.setdefault(lab[key], len(vals))
+            topo_n[k] = max(len(vals), 1)
+
+        def csr(lists):
+            off = np.cumsum([0] + [len(x) for x in lists]).astype(np.int32)
+            flat = [v for x in lists for v in x]
+            return off, np.array(flat if flat else [0], np.int32)
+        prob_kw.update(topo_dom=topo_dom, topo_n_dom=topo_n, term_topo_key=np.array([t[3] for t in terms], np.int32),
+                       term_node_set=np.array([t[4] for t in terms], np.int32),
+                       topo_is_hostname=np.array([k == k8s.LABEL_HOSTNAME for k in keys], np.uint8))
+        if node_sets:
+            prob_kw["node_sets"] = np.stack(node_sets)
+        prob_kw["match_off"], prob_kw["match_idx"] = csr(match)
+        prob_kw["anti_off"], prob_kw["anti_idx"] = csr(anti)
+        if any(aff):
+            prob_kw["aff_off"], prob_kw["aff_idx"] = csr(aff)
+            prob_kw["class_flags"] = np.array([capi.CLASS_AFF_SELF if f else 0 for f in flags], np.uint8)
+        if any(pref) or any(own):
+            prob_kw["pref_off"], prob_kw["pref_idx"] = csr(pref)
+            prob_kw["pref_w"] = csr(pref_w)[1]
+            prob_kw["own_off"], prob_kw["own_idx"] = csr(own)
+            prob_kw["own_w"] = csr(own_w)[1]
+        if any(hard):
+            prob_kw["spread_hard_off"], prob_kw["spread_hard_idx"] = csr(hard)
+            prob_kw["spread_hard_skew"] = csr(hard_skew)[1]
+            prob_kw["spread_hard_self"] = csr(hard_self)[1]
+            prob_kw["spread_hard_set"] = csr(hard_set)[1]
+        if any(soft):
+            prob_kw["spread_soft_off"], prob_kw["spread_soft_idx"] = csr(soft)
+            prob_kw["spread_soft_skew"] = csr(soft_skew)[1]
+            prob_kw["spread_log"] = gomath.spread_log_table(N)
+    # InterPodAffinity scores 0 everywhere when nobody owns a scoring term; ImageLocality / Open-Local are constants 0
+
+    prob = capi.Problem(
+        alloc_cpu=alloc_cpu, alloc_mem=alloc_mem, alloc_pods=alloc_pods, alloc_eph=alloc_eph if alloc_eph.any() or req_eph.any() else None,
+        node_class=node_class, scalar_alloc=scalar_alloc if scalar_names else None,
+        gpu_cnt=node_gpu_cnt if (node_gpu_cnt.any() or gpu_mem.any()) else None,
+        gpu_mem_total=node_gpu_mem if (node_gpu_cnt.any() or gpu_mem.any()) else None,
+        req_cpu=req_cpu, req_mem=req_mem, req_eph=req_eph if req_eph.any() else None, nz_cpu=nz_cpu, nz_mem=nz_mem,
+        scalar_req=scalar_req if scalar_names else None, pod_class=pod_class,
+        preset_node=preset if (preset >= 0).any() else None,
+        gate_node=np.array(gates, np.int32) if gates is not None and any(g >= 0 for g in gates) else None,
+        gpu_mem=gpu_mem if gpu_mem.any() else None, pod_gpu_cnt=gpu_cnt if gpu_mem.any() else None,
+        n_pod_classes=Cp, n_node_classes=Cn, static_mask=None if static_ok.all() else static_mask,
+        static_reason=None if static_ok.all() else static_reason, simon_raw=simon_raw, const_score=const, **prob_kw).normalise()
+    return Flat(problem=prob, node_names=node_names,
+                pod_refs=[(p["metadata"]["namespace"], p["metadata"]["name"]) for p in pods], pods=pods,
+                static_reasons={v: k for k, v in reason_ids.items()}, scalar_names=scalar_names,
+                pod_class_of=pod_class, const_score=const,
+                info={"n_pod_classes": Cp, "n_node_classes": Cn, "n_terms": T, "n_topology_keys": Kt})

@@ -1,0 +1,205 @@
+"""Python mirror of the reference's Go surface for the hot path: simulator.Simulate (pkg/simulator/core.go:67-125) and
+the add-nodes loop of Applier.Run (pkg/apply/apply.go:103-259), driving the HIP engine through the C-ABI.
+
+The Go host keeps these entry points and swaps their body for flatten -> simon_run_batch -> unflatten;
+this module is that body in Python, so the parity tests read like the reference's own (pkg/simulator/core_test.go).
+The engine is injected: the default is the HIP library (no CPU fallback); tests may pass another object with the same
+two methods (`run`, `explain`).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import yaml
+
+from . import capi, fiterror, flatten as fl, k8s, workloads as wl
+
+
+class HipEngine:
+    """The product engine: libsimon_hip.so on one device."""
+
+    def __init__(self, device_id: int = 0):
+        self.device_id = device_id
+
+    def run(self, prob: capi.Problem, scen, orders, want_placement=True) -> capi.BatchResult:
+        with capi.Context(self.device_id) as ctx:
+            ctx.load_problem(prob)
+            return ctx.run_batch(scen, orders, want_placement)
+
+    def explain(self, prob: capi.Problem, n_nodes: int, order, max_failed: int):
+        with capi.Context(self.device_id) as ctx:
+            ctx.load_problem(prob)
+            return ctx.explain(n_nodes, order, max_failed)
+
+
+@dataclass
+class AppResource:                       # simulator.AppResource (pkg/simulator/core.go:54-57)
+    name: str
+    resource: Dict[str, List[dict]]
+
+
+@dataclass
+class SimulateResult:                    # simulator.SimulateResult (pkg/simulator/core.go:19-36)
+    unscheduled_pods: List[dict] = field(default_factory=list)      # [{"pod": ..., "reason": str}]
+    node_status: List[dict] = field(default_factory=list)           # [{"node": ..., "pods": [...]}]
+
+    def to_json(self) -> dict:
+        return {"unscheduledPods": self.unscheduled_pods, "nodeStatus": self.node_status}
+
+
+def build_stream(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], pool: List[dict], n_cluster: int):
+    """The pod sequence one Simulate() call feeds the scheduler: cluster pods (core.go:85-95 + RunCluster), then each
+    app's pods (ScheduleApp).  DaemonSet pods of new nodes (pool index >= n_cluster) are gated on their node."""
+    index = {n["metadata"]["name"]: j for j, n in enumerate(pool)}
+    pods, gates = [], []
+
+    def gate_of(p: dict) -> int:
+        j = index.get(p.get("_daemon_node"), -1)
+        if j < 0 and p["spec"].get("nodeName"):
+            j = index.get(p["spec"]["nodeName"], -1)
+        return j if j >= n_cluster else -1
+
+    cluster_pods = wl.valid_pods_exclude_daemonset(cluster)
+    for ds in cluster.get("DaemonSet", []):
+        cluster_pods += wl.pods_of_daemonset(ds, pool)
+    for p in cluster_pods:
+        pods.append(p)
+        gates.append(gate_of(p))
+    for app in apps:
+        for p in wl.app_pods(app.name, app.resource, pool):
+            pods.append(p)
+            gates.append(gate_of(p))
+    return pods, gates
+
+
+def _check_prefix_order(pool: List[dict], counts: Sequence[int]):
+    """The engine breaks score ties by pool index; that equals nodeTree.list() order for every prefix only when the
+    zone round-robin (V/internal/cache/node_tree.go:119-143) keeps insertion order."""
+    for n in sorted(set(counts)):
+        if k8s.canonical_node_order(pool[:n]) != list(range(n)):
+            raise fl.Unsupported("nodes span several zone keys: nodeTree order is not a prefix order; simulate each cluster "
+                                 "size separately (simulate()) or route to the Go path")
+
+
+def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict[int, str]) -> SimulateResult:
+    res = SimulateResult()
+    per_node: List[List[dict]] = [[] for _ in range(n_nodes)]
+    for pid, j in enumerate(placement.tolist()):
+        if j == capi.GATED:
+            continue
+        pod = flat.pods[pid]
+        if j == capi.UNSCHEDULED:
+            res.unscheduled_pods.append({"pod": _public(pod), "reason": reasons.get(pid, "")})
+            continue
+        bound = _public(pod)
+        bound["spec"]["nodeName"] = flat.node_names[j]               # SimonPlugin.BindPodToNode (plugin/simon.go:104-121)
+        bound["status"] = {"phase": "Running"}
+        per_node[j].append(bound)
+    return res, per_node
+
+
+def _public(pod: dict) -> dict:
+    p = copy.deepcopy(pod)
+    p.pop("_daemon_node", None)
+    return p
+
+
+def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine=None, new_nodes: Sequence[dict] = ()) -> SimulateResult:
+    """simulator.Simulate for ONE cluster size: cluster["Node"] + new_nodes, canonical nodeTree order."""
+    engine = engine or HipEngine()
+    nodes = list(cluster.get("Node", [])) + list(new_nodes)
+    order = k8s.canonical_node_order(nodes)
+    nodes = [nodes[j] for j in order]
+    pods, _ = build_stream(cluster, apps, nodes, len(nodes))
+    flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []))
+    P = len(pods)
+    scen = np.array([[len(nodes), 0]], np.int32)
+    orders = np.arange(P, dtype=np.int32)[None, :]
+    out = engine.run(flat.problem, scen, orders)
+    reasons = {}
+    if out.unscheduled[0] > 0:
+        nf, failed, codes = engine.explain(flat.problem, len(nodes), orders[0], int(out.unscheduled[0]))
+        for pid, row in zip(failed.tolist(), codes):
+            ns, name = flat.pod_refs[pid]
+            reasons[pid] = fiterror.unscheduled_reason(ns, name, row, node_names=flat.node_names,
+                                                       static_reasons=flat.static_reasons, scalar_names=flat.scalar_names)
+    res, per_node = _unflatten(flat, out.placement[0], len(nodes), reasons)
+    res.node_status = [{"node": copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
+    return res
+
+
+@dataclass
+class SweepResult:
+    counts: List[int]                    # new nodes added per scenario
+    unscheduled: List[int]
+    cpu_pct: List[int]
+    mem_pct: List[int]
+    best: Optional[int]                  # smallest number of new nodes that schedules everything within the caps
+    result: Optional[SimulateResult]     # SimulateResult of that scenario
+
+
+def occupancy_pct(used: int, alloc: int) -> int:
+    """satisfyResourceSetting (pkg/apply/apply.go:737-760): int(float64(used) / float64(alloc) * 100)."""
+    return int(float(used) / float(alloc) * 100) if alloc else 0
+
+
+def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node: Optional[dict], counts: Sequence[int],
+          engine=None, max_cpu: int = 100, max_mem: int = 100) -> SweepResult:
+    """The add-nodes loop of Applier.Run (pkg/apply/apply.go:203-259) as ONE scenario batch: scenario k = the cluster plus
+    counts[k] clones of new_node (utils.NewFakeNodes); the answer is the smallest count with no unscheduled pod whose
+    occupancy satisfies MaxCPU / MaxMemory (satisfyResourceSetting, :689-775)."""
+    engine = engine or HipEngine()
+    counts = list(counts)
+    if max_cpu > 100 or max_cpu < 0:
+        max_cpu = 100
+    if max_mem > 100 or max_mem < 0:
+        max_mem = 100
+    base = list(cluster.get("Node", []))
+    if max(counts) > 0 and new_node is None:
+        raise ValueError("new node is nil when adding node to cluster")          # utils.NewFakeNodes (utils.go:886-888)
+    pool = base + (wl.new_fake_nodes(new_node, max(counts)) if max(counts) > 0 else [])
+    _check_prefix_order(pool, [len(base) + k for k in counts])
+    pods, gates = build_stream(cluster, apps, pool, len(base))
+    flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates)
+    P = len(pods)
+    scen = np.array([[len(base) + k, 0] for k in counts], np.int32)
+    orders = np.arange(P, dtype=np.int32)[None, :]
+    out = engine.run(flat.problem, scen, orders)
+    pc, pm = np.cumsum(flat.problem.alloc_cpu), np.cumsum(flat.problem.alloc_mem)
+    cpu_pct = [occupancy_pct(int(out.used_cpu[s]), int(pc[scen[s, 0] - 1])) for s in range(len(counts))]
+    mem_pct = [occupancy_pct(int(out.used_mem[s]) * 1000, int(pm[scen[s, 0] - 1]) * 1000) for s in range(len(counts))]
+    ok = [s for s in range(len(counts)) if out.unscheduled[s] == 0 and cpu_pct[s] <= max_cpu and mem_pct[s] <= max_mem]
+    best = min(ok, key=lambda s: (counts[s], s)) if ok else None
+    result = None
+    if best is not None:
+        n = int(scen[best, 0])
+        res, per_node = _unflatten(flat, out.placement[best], n, {})
+        res.node_status = [{"node": copy.deepcopy(pool[j]), "pods": per_node[j]} for j in range(n)]
+        result = res
+    return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result)
+
+
+def load_config(path: str, base_dir: str = ".") -> dict:
+    """simon/v1alpha1 Config (pkg/api/v1alpha1/types.go) -> {"cluster": resources, "apps": [AppResource], "new_node": node}.
+    Helm charts and kubeconfig clusters stay on the Go host (chart rendering / client-go): they raise Unsupported."""
+    import os
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    spec = cfg["spec"]
+    cl = spec.get("cluster") or {}
+    if cl.get("kubeConfig"):
+        raise fl.Unsupported("kubeConfig clusters need client-go: Go host only")
+    cluster = k8s.group_resources(k8s.load_objects(os.path.join(base_dir, cl["customConfig"])))
+    apps = []
+    for a in spec.get("appList") or []:
+        if a.get("chart"):
+            raise fl.Unsupported(f"app {a['name']}: Helm chart rendering stays on the Go host")
+        apps.append(AppResource(a["name"], k8s.group_resources(k8s.load_objects(os.path.join(base_dir, a["path"])))))
+    new_node = None
+    if spec.get("newNode"):
+        nodes = k8s.group_resources(k8s.load_objects(os.path.join(base_dir, spec["newNode"])))["Node"]
+        new_node = nodes[0] if nodes else None
+    return {"cluster": cluster, "apps": apps, "new_node": new_node}

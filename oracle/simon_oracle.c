@@ -401,7 +401,9 @@ static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb,
         double weight[SIMON_MAX_SPREAD];
         for (int e = slo; e < shi; e++) {                     /* TopologyNormalizingWeight (:98-106) */
             int t = tb->spread_soft_idx[e], key = tb->term_topo_key[t], sz;
-            if (tb->topo_is_hostname && tb->topo_is_hostname[key]) {
+            if (tb->spread_soft_skew[e] & SIMON_SPREAD_DUP_KEY) {
+                sz = 0;                                       /* the pair was registered by an earlier constraint (:89-95) */
+            } else if (tb->topo_is_hostname && tb->topo_is_hostname[key]) {
                 sz = scored;                                  /* len(filteredNodes) - len(IgnoredNodes) */
             } else {                                          /* distinct topology values among the scored nodes (:86-96) */
                 int ndom = nd->topo_n_dom[key];
@@ -422,7 +424,7 @@ static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb,
             for (int e = slo; e < shi; e++) {
                 int t = tb->spread_soft_idx[e];
                 int64_t cnt = s->cnt_match[t][term_dom(nd, tb, t, j)];
-                score += (double)cnt * weight[e - slo] + (double)(tb->spread_soft_skew[e] - 1);
+                score += (double)cnt * weight[e - slo] + (double)((tb->spread_soft_skew[e] & ~SIMON_SPREAD_DUP_KEY) - 1);
             }
             pts[j] = (int64_t)score;
             if (pts[j] < pts_min) pts_min = pts[j];

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/k8s_*.json: YAML-level cases flattened to SoA inputs, with the placements an INDEPENDENT
+object-level restatement of the reference scheduler (tests/pyref_sched.py) produces for them.
+
+  * k8s_example_*: the reference's own example/ inputs (read from /root/reference/example at generation time; that
+    tree does not travel to the GPU box, the flattened arrays and expected placements do);
+  * k8s_random_*: seeded random clusters from tests/randk8s.py (all v2 plugins active).
+Run from the repo root: python tests/golden/make_golden_k8s.py"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import pyref_sched  # noqa: E402
+import randk8s  # noqa: E402
+from open_simulator_amd import capi, flatten as fl, k8s, simulate as sim, workloads as wl  # noqa: E402
+
+REF = "/root/reference/example"
+ARRAY_FIELDS = [f for f in capi.Problem.__dataclass_fields__ if f not in ("n_pod_classes", "n_node_classes", "_keep")]
+
+
+def dump_problem(prob):
+    d = {"n_pod_classes": prob.n_pod_classes, "n_node_classes": prob.n_node_classes}
+    for f in ARRAY_FIELDS:
+        v = getattr(prob, f)
+        if v is not None:
+            d[f] = np.asarray(v).tolist()
+    return d
+
+
+def one(name, nodes, cluster, apps, note):
+    order = k8s.canonical_node_order(nodes)
+    nodes = [nodes[j] for j in order]
+    pods, _ = sim.build_stream(cluster, apps, nodes, len(nodes))
+    svc, rs, sts = cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", [])
+    flat = fl.flatten(nodes, pods, svc, rs, sts)
+    ref = pyref_sched.Scheduler(nodes, svc, rs, sts).run(pods)
+    idx = {n: j for j, n in enumerate(flat.node_names)}
+    placement = [capi.UNSCHEDULED if r is None else idx[r] for r in ref]
+    out = {"name": name, "note": note, "problem": dump_problem(flat.problem), "n_nodes": len(nodes), "n_pods": len(pods),
+           "node_names": flat.node_names, "pod_names": ["/".join(r) for r in flat.pod_refs],
+           "object_level_placement": placement, "info": flat.info}
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(out, f)
+    print(name, "nodes", len(nodes), "pods", len(pods), "unscheduled", sum(p < 0 for p in placement), flat.info)
+
+
+def example(name, cluster_dir, app_dirs, newnode_dir=None, k=0):
+    cluster = k8s.group_resources(k8s.load_objects(os.path.join(REF, cluster_dir)))
+    apps = [sim.AppResource(os.path.basename(a), k8s.group_resources(k8s.load_objects(os.path.join(REF, a)))) for a in app_dirs]
+    new = []
+    if newnode_dir and k:
+        tmpl = k8s.group_resources(k8s.load_objects(os.path.join(REF, newnode_dir)))["Node"][0]
+        new = wl.new_fake_nodes(tmpl, k)
+    one(name, cluster["Node"] + new, cluster, apps,
+        f"example/{cluster_dir} + {app_dirs} + {k} x example/{newnode_dir}" if k else f"example/{cluster_dir} + {app_dirs}")
+
+
+def rand(name, seed, **kw):
+    nodes, workloads, services = randk8s.rand_cluster(seed, **kw)
+    cluster = {k: [] for k in k8s.KINDS}
+    cluster["Node"], cluster["Service"] = nodes, services
+    cluster["ReplicaSet"] = []
+    res = k8s.group_resources(workloads)
+    if seed % 2:                                    # the cluster also knows the ReplicaSet objects (default spread selectors)
+        cluster["ReplicaSet"] = [w for w in workloads if w["kind"] == "ReplicaSet"]
+    # the objects are only registered (Services / ReplicaSets); their pods come from the app below
+    reg = {k: (v if k in ("Node", "Service") else []) for k, v in cluster.items()}
+    reg_for_selectors = dict(reg, ReplicaSet=cluster["ReplicaSet"])
+    order = k8s.canonical_node_order(nodes)
+    nodes_c = [nodes[j] for j in order]
+    pods, _ = sim.build_stream(reg, [sim.AppResource("app", res)], nodes_c, len(nodes_c))
+    flat = fl.flatten(nodes_c, pods, services, reg_for_selectors["ReplicaSet"], [])
+    ref = pyref_sched.Scheduler(nodes_c, services, reg_for_selectors["ReplicaSet"], []).run(pods)
+    idx = {n: j for j, n in enumerate(flat.node_names)}
+    placement = [capi.UNSCHEDULED if r is None else idx[r] for r in ref]
+    out = {"name": name, "note": f"tests/randk8s.rand_cluster(seed={seed}, {kw})", "problem": dump_problem(flat.problem),
+           "n_nodes": len(nodes_c), "n_pods": len(pods), "node_names": flat.node_names,
+           "pod_names": ["/".join(r) for r in flat.pod_refs], "object_level_placement": placement, "info": flat.info}
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(out, f)
+    print(name, "nodes", len(nodes_c), "pods", len(pods), "unscheduled", sum(p < 0 for p in placement), flat.info)
+
+
+def main():
+    example("k8s_example_simple", "cluster/demo_1", ["application/simple"])
+    example("k8s_example_simple_2new", "cluster/demo_1", ["application/simple"], "newnode/demo_1", 2)
+    example("k8s_example_all_6new", "cluster/demo_1", ["application/simple", "application/complicate", "application/more_pods"],
+            "newnode/demo_1", 6)
+    example("k8s_example_gpushare", "cluster/gpushare", ["application/gpushare"])
+    for seed in (3, 14, 15, 112, 201):
+        rand(f"k8s_random_{seed}", seed, gpu=(seed % 3 == 0))
+    rand("k8s_random_big_7", 7, n_nodes=40, n_workloads=30, max_replicas=12)
+
+
+if __name__ == "__main__":
+    main()

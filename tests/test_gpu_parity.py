@@ -252,6 +252,40 @@ def test_explain_on_a_narrow_problem():
     assert n == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
 
 
+def test_k8s_fixtures_on_gpu():
+    """YAML-level cases (reference example/ inputs and random clusters, tests/golden/k8s_*.json): the HIP path must
+    reproduce the placements of the independent object-level scheduler (tests/pyref_sched.py), no oracle in the loop."""
+    import test_host_mirror as H
+    assert len(H.K8S_FIXTURES) >= 8
+    for name in H.K8S_FIXTURES:
+        d, prob = H.load_k8s_fixture(name)
+        P, n = d["n_pods"], d["n_nodes"]
+        res, variant = run_gpu(prob, [[n, 0]], np.arange(P, dtype=np.int32)[None])
+        assert res.placement[0].tolist() == d["object_level_placement"], name
+
+
+def test_k8s_simulate_and_sweep_through_the_hip_engine():
+    """simulate() / sweep() with the product engine against the object-level scheduler and against the oracle engine."""
+    import pyref_sched
+    import test_host_mirror as H
+    from open_simulator_amd import flatten as fl, simulate as sim
+    for seed in (2, 9, 21):
+        nodes, pods, services, rs = H._random_case(seed, gpu=(seed % 3 == 0), n_nodes=20, n_workloads=16)
+        flat = fl.flatten(nodes, pods, services, rs, [])
+        res, _ = run_gpu(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
+        ref = pyref_sched.Scheduler(nodes, services, rs, []).run(pods)
+        assert [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()] == ref
+    # the add-nodes search of test_host_mirror.test_sweep_finds_the_minimum_node_count on the GPU
+    H_test = H.test_sweep_finds_the_minimum_node_count
+    orig = H.OracleEngine
+    H.OracleEngine = sim.HipEngine
+    try:
+        H_test()
+        H.test_unscheduled_reason_text()
+    finally:
+        H.OracleEngine = orig
+
+
 def test_config5_gpushare_style():
     """BASELINE config 5 shape (GPU share + required anti-affinity + taints): small pool, every placement compared;
     then ONE scenario at full size (50k pods x 5k nodes)."""

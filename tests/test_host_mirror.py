@@ -1,0 +1,197 @@
+"""CPU tests of the host-side mirror (YAML objects -> SoA -> engine -> SimulateResult).
+
+The checker here is tests/pyref_sched.py, an object-level restatement of the reference scheduler that shares no code
+with the SoA path; the engine under test on CPU is the C oracle (injected), on the GPU box the HIP library
+(tests/test_gpu_parity.py::test_k8s_*)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+import pyref_sched
+import randk8s
+from open_simulator_amd import capi, fiterror, flatten as fl, k8s, simulate as sim, workloads as wl
+
+K8S_FIXTURES = sorted(f[:-5] for f in os.listdir(G.GOLDEN) if f.startswith("k8s_") and f.endswith(".json"))
+REF_EXAMPLE = "/root/reference/example"
+
+
+class OracleEngine:
+    """Test-only engine with the HipEngine interface."""
+
+    def run(self, prob, scen, orders, want_placement=True):
+        return O.run(prob, scen, orders, want_placement)
+
+    def explain(self, prob, n_nodes, order, max_failed):
+        _, (nf, failed, codes) = O.run(prob, [[n_nodes, 0]], np.asarray(order)[None], explain_scenario=0, max_failed=max_failed)
+        return nf, failed, codes
+
+
+def load_k8s_fixture(name):
+    with open(os.path.join(G.GOLDEN, name + ".json")) as f:
+        d = json.load(f)
+    pd = dict(d["problem"])
+    u64 = ("static_mask", "node_sets")
+    kw = {k: (np.asarray(v, np.uint64) if k in u64 else np.asarray(v)) for k, v in pd.items()
+          if k not in ("n_pod_classes", "n_node_classes")}
+    prob = capi.Problem(n_pod_classes=pd["n_pod_classes"], n_node_classes=pd["n_node_classes"], **kw).normalise()
+    return d, prob
+
+
+@pytest.mark.parametrize("name", K8S_FIXTURES)
+def test_oracle_reproduces_object_level_placements(name):
+    d, prob = load_k8s_fixture(name)
+    P, n = d["n_pods"], d["n_nodes"]
+    res = O.run(prob, [[n, 0]], np.arange(P, dtype=np.int32)[None])
+    assert res.placement[0].tolist() == d["object_level_placement"]
+
+
+def _random_case(seed, **kw):
+    nodes, workloads, services = randk8s.rand_cluster(seed, **kw)
+    rs = [w for w in workloads if w["kind"] == "ReplicaSet"] if seed % 2 else []
+    nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
+    cluster = {k: [] for k in k8s.KINDS}
+    cluster["Node"], cluster["Service"] = nodes, services
+    pods, _ = sim.build_stream(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], nodes, len(nodes))
+    return nodes, pods, services, rs
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_flatten_plus_oracle_equals_object_level_scheduler(seed):
+    nodes, pods, services, rs = _random_case(seed, gpu=(seed % 3 == 0))
+    flat = fl.flatten(nodes, pods, services, rs, [])
+    res = O.run(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
+    ref = pyref_sched.Scheduler(nodes, services, rs, []).run(pods)
+    got = [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()]
+    assert got == ref
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLE), reason="reference tree not present (GPU box)")
+def test_committed_example_fixtures_match_the_reference_inputs():
+    """The committed k8s_example_* fixtures are what flatten() produces from the reference's example/ YAML today."""
+    cluster = k8s.group_resources(k8s.load_objects(os.path.join(REF_EXAMPLE, "cluster/demo_1")))
+    apps = [sim.AppResource("simple", k8s.group_resources(k8s.load_objects(os.path.join(REF_EXAMPLE, "application/simple"))))]
+    nodes = cluster["Node"]
+    pods, _ = sim.build_stream(cluster, apps, nodes, len(nodes))
+    flat = fl.flatten(nodes, pods, cluster["Service"], cluster["ReplicaSet"], cluster["StatefulSet"])
+    d, prob = load_k8s_fixture("k8s_example_simple")
+    assert d["pod_names"] == ["/".join(r) for r in flat.pod_refs]
+    for f in ("alloc_cpu", "alloc_mem", "req_cpu", "req_mem", "nz_cpu", "nz_mem", "pod_class", "simon_raw", "static_mask"):
+        a, b = getattr(flat.problem, f), getattr(prob, f)
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), f
+    # core_test.go-style expectation on the workload expansion: per-workload pod counts of example/application/simple
+    kinds = {}
+    for p in pods:
+        k = p["metadata"]["annotations"].get(wl.ANNO_WORKLOAD_KIND, "Pod")
+        kinds[k] = kinds.get(k, 0) + 1
+    assert sum(kinds.values()) == len(pods) == 37
+
+
+def test_sweep_equals_one_simulate_per_cluster_size():
+    """The batched add-nodes search (gated DaemonSet pods, prefix node pools) against one Simulate() per size."""
+    nodes, workloads, services = randk8s.rand_cluster(5, n_nodes=6, n_workloads=14, max_replicas=8)
+    for n in nodes:
+        n["metadata"]["labels"].pop(randk8s.ZONE, None)          # single zone key: nodeTree order == insertion order
+    ds = {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "agent", "namespace": "kube-system"},
+          "spec": {"selector": {"matchLabels": {"app": "agent"}},
+                   "template": {"metadata": {"labels": {"app": "agent"}},
+                                "spec": {"containers": [{"name": "a", "image": "x", "resources": {"requests": {"cpu": "200m", "memory": "128Mi"}}}],
+                                         "tolerations": [{"operator": "Exists"}]}}}}
+    cluster = k8s.group_resources(nodes + services + [ds])
+    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd"}},
+                "status": {"allocatable": {"cpu": "16", "memory": "32Gi", "pods": "20"}, "capacity": {"cpu": "16", "memory": "32Gi"}}}
+    eng = OracleEngine()
+    counts = [0, 1, 2, 3, 5]
+    sw = sim.sweep(cluster, apps, template, counts, engine=eng)
+    for k, uns in zip(counts, sw.unscheduled):
+        one = sim.simulate(cluster, apps, engine=eng, new_nodes=wl.new_fake_nodes(template, k))
+        assert len(one.unscheduled_pods) == uns, k
+        if k == sw.best:                                         # same placements, pod for pod, node for node
+            names = lambda r: [(s["node"]["metadata"]["name"], [p["metadata"]["name"] for p in s["pods"]]) for s in r.node_status]
+            assert names(one) == names(sw.result)
+    if sw.best is not None:
+        assert sw.unscheduled[counts.index(sw.best)] == 0 and sw.result is not None
+        n_ds = sum(1 for s in sw.result.node_status for p in s["pods"] if p["metadata"]["name"].startswith("agent-"))
+        assert n_ds == len(nodes) + sw.best                      # one DaemonSet pod per node of the chosen size
+
+
+def test_sweep_finds_the_minimum_node_count():
+    """Applier.Run's loop on a case that needs new nodes: 40 x (1 cpu, 1Gi) + a DaemonSet on 3 x 8-cpu nodes, 16-cpu template."""
+    mk = lambda name: {"apiVersion": "v1", "kind": "Node", "metadata": {"name": name, "labels": {k8s.LABEL_HOSTNAME: name}},
+                       "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "110"}}}
+    deploy = {"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": "web", "namespace": "default"},
+              "spec": {"replicas": 40, "selector": {"matchLabels": {"app": "web"}},
+                       "template": {"metadata": {"labels": {"app": "web"}},
+                                    "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": "1", "memory": "1Gi"}}}]}}}}
+    ds = {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "agent", "namespace": "kube-system"},
+          "spec": {"selector": {"matchLabels": {"app": "agent"}},
+                   "template": {"metadata": {"labels": {"app": "agent"}},
+                                "spec": {"containers": [{"name": "a", "resources": {"requests": {"cpu": "500m", "memory": "128Mi"}}}]}}}}
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"role": "worker"}},
+                "status": {"allocatable": {"cpu": "16", "memory": "32Gi", "pods": "110"}}}
+    cluster = k8s.group_resources([mk("a"), mk("b"), mk("c"), ds])
+    apps = [sim.AppResource("web", k8s.group_resources([deploy]))]
+    eng = OracleEngine()
+    sw = sim.sweep(cluster, apps, template, range(0, 5), engine=eng)
+    # capacity: 3 x floor(8 - 0.5) = 21 pods on the cluster, 15 per new node -> 2 new nodes hold the remaining 19
+    assert sw.unscheduled == [19, 4, 0, 0, 0] and sw.best == 2
+    assert sw.cpu_pct[2] == int((40 * 1000 + 5 * 500) / (3 * 8000 + 2 * 16000) * 100)
+    one = sim.simulate(cluster, apps, engine=eng, new_nodes=wl.new_fake_nodes(template, 2))
+    names = lambda r: [(s["node"]["metadata"]["name"], [p["metadata"]["name"] for p in s["pods"]]) for s in r.node_status]
+    assert names(one) == names(sw.result) and not one.unscheduled_pods
+    assert sum(1 for s in sw.result.node_status for p in s["pods"] if p["metadata"]["name"].startswith("agent-")) == 5
+    assert all(p["spec"]["nodeName"] == s["node"]["metadata"]["name"] and p["status"]["phase"] == "Running"
+               for s in sw.result.node_status for p in s["pods"])
+    # occupancy caps (satisfyResourceSetting): a 60 % CPU cap needs a larger cluster than pure feasibility
+    capped = sim.sweep(cluster, apps, template, range(0, 5), engine=eng, max_cpu=60)
+    assert capped.best == 3 and capped.cpu_pct[3] <= 60 < capped.cpu_pct[2]
+
+
+def test_unscheduled_reason_text():
+    node = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "n0", "labels": {}},
+            "status": {"allocatable": {"cpu": "1", "memory": "1Gi", "pods": "10"}}}
+    tainted = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "n1", "labels": {}},
+               "spec": {"taints": [{"key": "dedicated", "value": "infra", "effect": "NoSchedule"}]},
+               "status": {"allocatable": {"cpu": "8", "memory": "8Gi", "pods": "10"}}}
+    pod = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "big", "namespace": "default"},
+           "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": "2", "memory": "2Gi"}}}]}}
+    cluster = k8s.group_resources([node, tainted, pod])
+    res = sim.simulate(cluster, [], engine=OracleEngine())
+    assert len(res.unscheduled_pods) == 1
+    assert res.unscheduled_pods[0]["reason"] == (
+        "failed to schedule pod (default/big): Unschedulable: 0/2 nodes are available: 1 Insufficient cpu, 1 Insufficient memory, "
+        "1 node(s) had taint {dedicated: infra}, that the pod didn't tolerate.")
+
+
+def test_k8s_helpers():
+    labels = {"app": "web", "tier": "fe"}
+    assert k8s.label_selector_matches({}, labels) and not k8s.label_selector_matches(None, labels)
+    assert k8s.label_selector_matches({"matchExpressions": [{"key": "tier", "operator": "NotIn", "values": ["be"]}]}, labels)
+    assert not k8s.label_selector_matches({"matchExpressions": [{"key": "zone", "operator": "Exists"}]}, labels)
+    node = {"metadata": {"name": "n1", "labels": {"rank": "7", "disk": "ssd"}}}
+    assert k8s.node_selector_term_matches({"matchExpressions": [{"key": "rank", "operator": "Gt", "values": ["4"]}]}, node)
+    assert not k8s.node_selector_term_matches({}, node)                                       # empty term matches nothing
+    assert k8s.node_selector_term_matches({"matchFields": [{"key": "metadata.name", "operator": "In", "values": ["n1"]}]}, node)
+    taint = {"key": "k", "value": "v", "effect": "NoSchedule"}
+    assert k8s.toleration_tolerates({"operator": "Exists"}, taint)
+    assert not k8s.toleration_tolerates({"key": "k", "value": "x"}, taint)
+    assert not k8s.toleration_tolerates({"key": "k", "operator": "Exists", "effect": "NoExecute"}, taint)
+    pod = {"metadata": {}, "spec": {"containers": [{"resources": {"requests": {"cpu": "100m"}}}, {"resources": {"requests": {"cpu": "1.5", "memory": "1Gi"}}}],
+                                    "initContainers": [{"resources": {"requests": {"cpu": "3"}}}], "overhead": {"cpu": "10m"}}}
+    assert k8s.pod_request(pod) == {"cpu": 3010, "memory": 1 << 30}
+    assert k8s.pod_nonzero_request(pod) == (3010, (200 << 20) + (1 << 30))                    # first container: default memory
+    # nodeTree.list(): zones round-robin in first-appearance order
+    mk = lambda name, zone: {"metadata": {"name": name, "labels": ({k8s.LABEL_ZONE: zone} if zone else {})}}
+    nodes = [mk("a", "z1"), mk("b", "z1"), mk("c", "z2"), mk("d", None), mk("e", "z1")]
+    assert [nodes[j]["metadata"]["name"] for j in k8s.canonical_node_order(nodes)] == ["a", "c", "d", "b", "e"]
+
+
+def test_fit_error_strings_of_the_new_codes():
+    msg = fiterror.fit_error([capi.FAIL_AFFINITY, capi.FAIL_SPREAD, capi.FAIL_SPREAD_LABEL, capi.FAIL_SPREAD])
+    assert msg == ("0/4 nodes are available: 1 node(s) didn't match pod affinity rules, 1 node(s) didn't match pod affinity/anti-affinity, "
+                   "1 node(s) didn't match pod topology spread constraints (missing required label), "
+                   "2 node(s) didn't match pod topology spread constraints.")
