@@ -24,6 +24,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+DTYPE = {1: "u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
+         2: "int64 quantities + f64 (BalancedAllocation / normalisations) + u8 (signature, node) score table",
+         3: "f64-resident exact integers (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
+         4: "u8 score table + u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)"}
+_N = ("achieved = algorithmic bytes per step (SURVEY 8d: sum over scenarios of P*(56*n+108), resp. P*((56+64+4)*n+4*G+108) "
+      "with Open-Gpu-Share slots and anti-affinity domains) / HIP-event time of the scenario kernels of one step. ")
+NOTE = {4: _N + "The (signature, node) score table replaces re-reading node state, so the ratio is not bounded by 1 (it is the "
+                "speed-up over a state-streaming formulation); traffic = PMC-measured HBM-side bytes per step (profiles/); the "
+                "binding limit is VALU issue + L2 latency of one wave per scenario, DESIGN.md section 5.3 / profiles/README.md",
+        2: _N + "The all-feature kernel reads one table byte per node per cycle instead of the node's state and refreshes only "
+                "the touched node's column, so the ratio can exceed a state-streaming formulation; binding limit: VALU issue of "
+                "the per-node loop (2 waves per SIMD at 512 threads per scenario), DESIGN.md section 5.4",
+        3: _N + "Node state is register-resident; binding limit: VALU issue, DESIGN.md section 5.1",
+        1: _N + "Node state is register-resident; binding limit: VALU issue, DESIGN.md section 5.1"}
 
 
 def algorithmic_bytes(scen, n_pods, workload="config3", n_groups=50):
@@ -92,10 +106,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # test hook (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu): several ranks on ONE device over gloo, to
+    # exercise the world > 1 code path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("SIMON_BENCH_BACKEND", "nccl")
+    if os.environ.get("SIMON_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_orders = args.orders_per_gpu * world
     seed = synth.SEED + (3 if world == 1 else 4)
@@ -113,7 +135,7 @@ def main():
         ctx.run_loaded(want_placement=bool(args.placement))
         plan = ctx.min_plan()                                 # device-side reduction of this rank's batch
         rec = sweep.plan_record(bool(plan.found), plan.n_nodes, plan.scenario, plan.order_id, rank, world)
-        return sweep.all_gather_plan(rec, device="cuda").as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
+        return sweep.all_gather_plan(rec, device="cuda" if backend == "nccl" else "cpu").as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
 
     def fence():
         if world > 1:
@@ -131,7 +153,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -147,7 +169,7 @@ def main():
             "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),
             "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8 score table + u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE.get(st.kernel_variant, "int64 + f64"), "data": "synthetic",
             "pods_placed_per_sec": round(value * prob.n_pods, 1),
             "config": {"workload": (f"BASELINE config 5-style (gpushare): {prob.n_pods} pods x " if args.workload == "config5" else
                                     f"BASELINE config {'3' if world == 1 else '4-style'}: {prob.n_pods} pods x ") + 
@@ -161,11 +183,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kname, "kernel_ms": round(k_ms, 3), "launches_per_step": st.n_launches,
                          "algorithmic_bytes_per_launch": alg,
-                         "note": "achieved = algorithmic bytes sum_s P*(56*n_s+108) (SURVEY 8d) per step / HIP-event time of "
-                                 "the scenario kernels of one step; the score table replaces re-reading node state, so "
-                                 "the ratio is not bounded by 1 (it is the speed-up over a state-streaming formulation). "
-                                 "traffic = PMC-measured HBM-side bytes per step (profiles/); the binding limit is VALU "
-                                 "issue + L2 latency of one wave per scenario, DESIGN.md section 6"},
+                         "note": NOTE.get(st.kernel_variant, NOTE[4])},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, scen, orders)

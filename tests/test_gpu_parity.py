@@ -390,3 +390,28 @@ def test_errors_are_reported_not_thrown():
             ctx.run_batch([[prob.n_nodes + 1, 0]], orders)
         with pytest.raises(capi.SimonError):
             ctx.run_batch([[5, 3]], orders)
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py's world-size > 1 path (sharding, per-step plan all-gather, max-over-ranks timing) on a single-GPU box:
+    two ranks on device 0 over gloo.  The driver's real multi-GPU runs use one rank per GPU over RCCL."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, SIMON_BENCH_BACKEND="gloo", SIMON_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--counts", "32", "--pods", "2000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["scenarios_per_gpu"] == 32 * 4 and d["value"] > 0
+    assert "8 pod orders = 256 scenarios" in d["config"]["workload"]
+    assert d["config"]["plan"][0] >= 488 or d["config"]["plan"][0] == -1
