@@ -71,6 +71,7 @@ extern "C" {
 #define SIMON_FAIL_AFFINITY 0x2003u        /* "...affinity/anti-affinity" + "node(s) didn't match pod affinity rules" (:388; UnschedulableAndUnresolvable) */
 #define SIMON_FAIL_SPREAD 0x2010u          /* "node(s) didn't match pod topology spread constraints" (podtopologyspread/filtering.go:326) */
 #define SIMON_FAIL_SPREAD_LABEL 0x2011u    /* "... (missing required label)" (:303; UnschedulableAndUnresolvable) */
+#define SIMON_FAIL_PORTS 0x0800u           /* "node(s) didn't have free ports for the requested pod ports" (nodeports/node_ports.go:37) */
 #define SIMON_FAIL_GPUSHARE 0x1000u        /* reason "Node:<name>" (pkg/simulator/plugin/open-gpu-share.go:64-78) */
 
 /* ---------------------------------------------------------------------------------------------
@@ -173,6 +174,13 @@ typedef struct simon_class_tables {
     /* required anti-affinity, both directions (filtering.go:133-148,317-346): terms class c itself REQUIRES */
     const int32_t* anti_off;       /* [Cp+1] */
     const int32_t* anti_idx;
+    /* NodePorts (V/framework/plugins/nodeports/node_ports.go:104-127, HostPortInfo V/framework/types.go:730-823): a port
+     * term = one interned (hostIP, protocol, hostPort) triple on a topology key whose domain IS the node; a class MATCHES
+     * the triples its containers bind and CONFLICTS with (port_*): the same (protocol, port) on 0.0.0.0 or on its own IP,
+     * resp. on any IP when it binds 0.0.0.0.  Node fails when a conflicting term counts a pod on it.  Checked between the
+     * static filters and NodeResourcesFit (registry order). */
+    const int32_t* port_off;       /* [Cp+1]; optional */
+    const int32_t* port_idx;
     /* required affinity (filtering.go:116-131,348-377).  For a RequiredAffinityTerms list L the host interns, per term i,
      * a DERIVED term (pods matching ALL selectors of L, key_i): "existing pod matches all terms" is then one counter.
      * Node passes iff every key exists and every derived counter is > 0; else the first-pod escape: no pod anywhere

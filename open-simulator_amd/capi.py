@@ -32,6 +32,7 @@ FAIL_AFFINITY = 0x2003
 FAIL_SPREAD = 0x2010
 FAIL_SPREAD_LABEL = 0x2011
 FAIL_GPUSHARE = 0x1000
+FAIL_PORTS = 0x0800
 CLASS_AFF_SELF = 0x1
 MAX_SPREAD = 4
 SPREAD_DUP_KEY = 0x40000000
@@ -79,6 +80,7 @@ class ClassTables(C.Structure):
         ("n_terms", C.c_int32), ("term_topo_key", _p32), ("term_node_set", _p32),
         ("n_node_sets", C.c_int32), ("node_sets", _pu64),
         ("match_off", _p32), ("match_idx", _p32), ("anti_off", _p32), ("anti_idx", _p32),
+        ("port_off", _p32), ("port_idx", _p32),
         ("aff_off", _p32), ("aff_idx", _p32), ("class_flags", _pu8),
         ("pref_off", _p32), ("pref_idx", _p32), ("pref_w", _p32),
         ("own_off", _p32), ("own_idx", _p32), ("own_w", _p32),
@@ -187,6 +189,8 @@ class Problem:
     anti_idx: Optional[np.ndarray] = None
     match_off: Optional[np.ndarray] = None
     match_idx: Optional[np.ndarray] = None
+    port_off: Optional[np.ndarray] = None
+    port_idx: Optional[np.ndarray] = None
     aff_off: Optional[np.ndarray] = None
     aff_idx: Optional[np.ndarray] = None
     class_flags: Optional[np.ndarray] = None       # [Cp] uint8
@@ -267,7 +271,7 @@ class Problem:
                 self.node_sets = _arr(self.node_sets, np.uint64)
                 assert self.node_sets.ndim == 2 and self.node_sets.shape[1] == words
             zero_off = np.zeros(Cp + 1, i32)
-            for off, cols in (("match_off", ("match_idx",)), ("anti_off", ("anti_idx",)), ("aff_off", ("aff_idx",)),
+            for off, cols in (("match_off", ("match_idx",)), ("anti_off", ("anti_idx",)), ("port_off", ("port_idx",)), ("aff_off", ("aff_idx",)),
                               ("pref_off", ("pref_idx", "pref_w")), ("own_off", ("own_idx", "own_w")),
                               ("spread_hard_off", ("spread_hard_idx", "spread_hard_skew", "spread_hard_self",
                                                    "spread_hard_set")),
@@ -339,7 +343,7 @@ class Problem:
         s.n_terms = 0 if self.term_topo_key is None else len(self.term_topo_key)
         s.n_node_sets = 0 if self.node_sets is None else int(self.node_sets.shape[0])
         s.node_sets = _ptr(self.node_sets, C.c_uint64)
-        for name in ("term_topo_key", "term_node_set", "match_off", "match_idx", "anti_off", "anti_idx", "aff_off",
+        for name in ("term_topo_key", "term_node_set", "match_off", "match_idx", "anti_off", "anti_idx", "port_off", "port_idx", "aff_off",
                      "aff_idx", "pref_off", "pref_idx", "pref_w", "own_off", "own_idx", "own_w", "spread_hard_off",
                      "spread_hard_idx", "spread_hard_skew", "spread_hard_self", "spread_hard_set", "spread_soft_off",
                      "spread_soft_idx", "spread_soft_skew"):

@@ -481,7 +481,7 @@ int simon_load_class_tables(simon_ctx* c, const simon_class_tables* tb) {
     c->Tm = tb->n_terms;
     if (c->Tm < 0) return fail(c, SIMON_EINVAL, "n_terms < 0");
     c->term_key.clear(); c->term_set.clear(); c->node_sets.clear(); c->R = 0;
-    c->match_off.clear(); c->match_idx.clear(); c->anti_off.clear(); c->anti_idx.clear(); c->aff_off.clear(); c->aff_idx.clear();
+    c->match_off.clear(); c->match_idx.clear(); c->anti_off.clear(); c->anti_idx.clear(); c->aff_off.clear(); c->aff_idx.clear(); c->port_off.clear(); c->port_idx.clear();
     c->class_flags.clear(); c->pref_off.clear(); c->pref_idx.clear(); c->pref_w.clear(); c->own_off.clear(); c->own_idx.clear();
     c->own_w.clear(); c->sh_off.clear(); c->sh_idx.clear(); c->sh_skew.clear(); c->sh_self.clear(); c->sh_set.clear();
     c->ss_off.clear(); c->ss_idx.clear(); c->ss_skew.clear(); c->topo_is_hostname.clear(); c->spread_log.clear();
@@ -502,6 +502,7 @@ int simon_load_class_tables(simon_ctx* c, const simon_class_tables* tb) {
             {"match", tb->match_off, tb->match_idx, &c->match_off, &c->match_idx, 1 << 20},
             {"anti", tb->anti_off, tb->anti_idx, &c->anti_off, &c->anti_idx, SIMON_MAX_TERMS_PER_CLASS * 4},
             {"aff", tb->aff_off, tb->aff_idx, &c->aff_off, &c->aff_idx, SIMON_MAX_TERMS_PER_CLASS * 4},
+            {"port", tb->port_off, tb->port_idx, &c->port_off, &c->port_idx, 1 << 16},
             {"pref", tb->pref_off, tb->pref_idx, &c->pref_off, &c->pref_idx, SIMON_MAX_TERMS_PER_CLASS * 4},
             {"own", tb->own_off, tb->own_idx, &c->own_off, &c->own_idx, SIMON_MAX_TERMS_PER_CLASS * 8},
             {"spread_hard", tb->spread_hard_off, tb->spread_hard_idx, &c->sh_off, &c->sh_idx, SIMON_MAX_SPREAD},

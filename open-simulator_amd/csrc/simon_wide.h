@@ -32,7 +32,7 @@ struct HostInputs {
     // topology terms (InterPodAffinity + PodTopologySpread)
     std::vector<int32_t> term_key, term_set;
     std::vector<uint64_t> node_sets;
-    std::vector<int32_t> match_off, match_idx, anti_off, anti_idx, aff_off, aff_idx;
+    std::vector<int32_t> match_off, match_idx, anti_off, anti_idx, aff_off, aff_idx, port_off, port_idx;
     std::vector<uint8_t> class_flags;
     std::vector<int32_t> pref_off, pref_idx, pref_w, own_off, own_idx, own_w;
     std::vector<int32_t> sh_off, sh_idx, sh_skew, sh_self, sh_set, ss_off, ss_idx, ss_skew;
@@ -40,7 +40,7 @@ struct HostInputs {
     std::vector<double> spread_log;
     bool has_ipa_score = false;   // any pref_* or own_* entry exists
     bool v2_features() const {
-        return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty();
+        return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || !port_idx.empty();
     }
 };
 
@@ -69,6 +69,7 @@ constexpr uint32_t kPodTerms = 2u;     // class touches topology counters (match
 constexpr uint32_t kPodHard = 4u;      // class has DoNotSchedule spread constraints
 constexpr uint32_t kPodSoft = 8u;      // class has ScheduleAnyway spread constraints
 constexpr uint32_t kPodIpa = 16u;      // InterPodAffinity.Score can be non-zero for this class
+constexpr uint32_t kPodPorts = 32u;    // class binds host ports (NodePorts filter)
 
 struct WideScenario {
     int32_t n_nodes, order_id;
@@ -92,6 +93,7 @@ struct WideCold {
     const int32_t* term_set /*[Tm] row of node_sets or -1*/; const uint64_t* node_sets;
     const int32_t* anti_off; const int32_t* anti_idx; const int32_t* match_off; const int32_t* match_idx;
     const int32_t* aff_off; const int32_t* aff_idx; const uint8_t* class_flags;
+    const int32_t* port_off; const int32_t* port_idx;
     const int32_t* pref_off; const int32_t* pref_idx; const int32_t* pref_w;
     const int32_t* own_off; const int32_t* own_idx; const int32_t* own_w;
     const int32_t* sh_off; const int32_t* sh_idx; const int32_t* sh_skew; const int32_t* sh_self; const int32_t* sh_set;
@@ -144,7 +146,7 @@ struct WideDevice {
     uint64_t* static_mask = nullptr; uint8_t* static_reason = nullptr; int64_t* simon_raw = nullptr;
     int64_t *na_raw = nullptr, *tt_raw = nullptr, *static_add = nullptr;
     int32_t *term_key = nullptr, *term_dom_off = nullptr, *term_set = nullptr, *anti_off = nullptr, *anti_idx = nullptr,
-            *match_off = nullptr, *match_idx = nullptr, *aff_off = nullptr, *aff_idx = nullptr, *pref_off = nullptr,
+            *match_off = nullptr, *match_idx = nullptr, *aff_off = nullptr, *aff_idx = nullptr, *port_off = nullptr, *port_idx = nullptr, *pref_off = nullptr,
             *pref_idx = nullptr, *pref_w = nullptr, *own_off = nullptr, *own_idx = nullptr, *own_w = nullptr,
             *sh_off = nullptr, *sh_idx = nullptr, *sh_skew = nullptr, *sh_self = nullptr, *sh_set = nullptr,
             *sh_first_reg = nullptr, *ss_off = nullptr, *ss_idx = nullptr, *ss_skew = nullptr, *key_seen_off = nullptr;

@@ -268,6 +268,16 @@ __device__ __forceinline__ unsigned base_score(const Q& q, const NodeLoads& L) {
     return (unsigned)((la_c + la_m) / 2 + ba);
 }
 
+// NodePorts.Filter (nodeports/node_ports.go:104-127): a conflicting (hostIP, protocol, hostPort) term counts a pod on the node
+__device__ __forceinline__ bool ports_conflict(const WideArgs& A, const NodeView& v, const WidePod& p, int j) {
+    for (int e = COLD(A)->port_off[p.cls]; e < COLD(A)->port_off[p.cls + 1]; ++e) {
+        const int t = COLD(A)->port_idx[e];
+        const int d = term_dom(A, t, j);
+        if (d >= 0 && v.cnt_match()[COLD(A)->term_dom_off[t] + d] > 0) return true;
+    }
+    return false;
+}
+
 // The filters after NodeResourcesFit, in registry order (registry.go:87-104 + pkg/simulator/utils.go:321-333):
 // PodTopologySpread, InterPodAffinity, Open-Gpu-Share.  Each returns a SIMON_FAIL_* code (0 = pass).
 // head_code: PodTopologySpread.Filter + the required-affinity half of InterPodAffinity.Filter.
@@ -338,6 +348,7 @@ __device__ __forceinline__ unsigned filter_code(const WideArgs& A, const NodeVie
     const unsigned fit = fit_bits(A, p, L, load_extra(A, v, j));
     // NodeUnschedulable / NodeName / TaintToleration / NodeAffinity come first in filter order
     if (!mask_ok) return SIMON_FAIL_STATIC | (COLD(A)->static_reason ? COLD(A)->static_reason[(size_t)p.cls * A.N + j] : 0u);
+    if ((p.flags & kPodPorts) && ports_conflict(A, v, p, j)) return SIMON_FAIL_PORTS;
     if (fit) return SIMON_FAIL_FIT | fit;
     return rest_code(A, v, p, j, n, hard_min);
 }
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
             const bool ipa = p.flags & kPodIpa;
             const bool soft = p.flags & kPodSoft;
             const bool extras = ipa || soft || !class_mode;
-            const bool has_rest = (p.flags & (kPodHard | kPodTerms)) || (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0);
+            const bool has_rest = (p.flags & (kPodHard | kPodTerms | kPodPorts)) || (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0);
             const int slo = soft ? COLD(A)->ss_off[p.cls] : 0, n_soft = soft ? COLD(A)->ss_off[p.cls + 1] - slo : 0;
             unsigned feas = 0, ign = 0;
             unsigned long long cmask = 0;
@@ -583,6 +594,11 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                             const int j = tid + (it0 + u) * T;
                             act[u] = j < n && b[u] != 0u && mk[u];
                             jn[u] = j < n ? j : n - 1;
+                        }
+                        if (p.flags & kPodPorts) {
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u)
+                                if (act[u] && ports_conflict(A, v, p, jn[u])) act[u] = false;
                         }
                         if ((p.flags & kPodHard) || ((p.flags & kPodTerms) && COLD(A)->aff_off[p.cls + 1] > COLD(A)->aff_off[p.cls])) {
 #pragma unroll
@@ -970,6 +986,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     c.term_key = w.term_key; c.term_dom_off = w.term_dom_off; c.term_set = w.term_set; c.node_sets = w.node_sets;
     c.anti_off = w.anti_off; c.anti_idx = w.anti_idx; c.match_off = w.match_off; c.match_idx = w.match_idx;
     c.aff_off = w.aff_off; c.aff_idx = w.aff_idx; c.class_flags = w.class_flags;
+    c.port_off = w.port_off; c.port_idx = w.port_idx;
     c.pref_off = w.pref_off; c.pref_idx = w.pref_idx; c.pref_w = w.pref_w;
     c.own_off = w.own_off; c.own_idx = w.own_idx; c.own_w = w.own_w;
     c.sh_off = w.sh_off; c.sh_idx = w.sh_idx; c.sh_skew = w.sh_skew; c.sh_self = w.sh_self; c.sh_set = w.sh_set;
@@ -1047,7 +1064,8 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     w.nzeq = in.i_req_cpu == in.i_nz_cpu && in.i_req_mem == in.i_nz_mem && in.p_req_cpu == in.p_nz_cpu && in.p_req_mem == in.p_nz_mem;
     auto csr = [&](const std::vector<int32_t>& off) { return off.empty() ? std::vector<int32_t>(Cp + 1, 0) : off; };
     const std::vector<int32_t> match_off = csr(in.match_off), anti_off = csr(in.anti_off), aff_off = csr(in.aff_off),
-                               pref_off = csr(in.pref_off), own_off = csr(in.own_off), sh_off = csr(in.sh_off), ss_off = csr(in.ss_off);
+                               pref_off = csr(in.pref_off), own_off = csr(in.own_off), sh_off = csr(in.sh_off), ss_off = csr(in.ss_off),
+                               port_off = csr(in.port_off);
     std::vector<uint8_t> class_flags = in.class_flags;
     class_flags.resize(Cp, 0);
     std::vector<int32_t> term_set = in.term_set;
@@ -1106,6 +1124,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         }
         if (in.Tm > 0 && (some(match_off) || some(anti_off) || some(aff_off) || some(own_off))) r.flags |= kPodTerms;
         if (some(sh_off)) r.flags |= kPodHard;
+        if (in.Tm > 0 && some(port_off)) r.flags |= kPodPorts | kPodTerms;
         if (some(ss_off)) r.flags |= kPodSoft;
         if (in.has_ipa_score && (some(pref_off) || some(match_off))) r.flags |= kPodIpa;
     }
@@ -1122,6 +1141,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     PUT(term_key, in.term_key, 1); PUT(term_dom_off, dom_off, 1); PUT(term_set, term_set, 1); PUT(node_sets, in.node_sets, 1);
     PUT(anti_off, anti_off, 1); PUT(anti_idx, in.anti_idx, 1); PUT(match_off, match_off, 1); PUT(match_idx, in.match_idx, 1);
     PUT(aff_off, aff_off, 1); PUT(aff_idx, in.aff_idx, 1); PUT(class_flags, class_flags, 1);
+    PUT(port_off, port_off, 1); PUT(port_idx, in.port_idx, 1);
     PUT(pref_off, pref_off, 1); PUT(pref_idx, in.pref_idx, 1); PUT(pref_w, in.pref_w, 1);
     PUT(own_off, own_off, 1); PUT(own_idx, in.own_idx, 1); PUT(own_w, in.own_w, 1);
     PUT(sh_off, sh_off, 1); PUT(sh_idx, in.sh_idx, 1); PUT(sh_skew, in.sh_skew, 1); PUT(sh_self, in.sh_self, 1);

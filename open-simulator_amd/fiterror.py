@@ -54,6 +54,8 @@ def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scal
         return [ERR_AFFINITY_NOT_MATCH, ERR_ANTI_AFFINITY_RULES]
     if code == capi.FAIL_ANTI_EXISTING:
         return [ERR_AFFINITY_NOT_MATCH, ERR_EXISTING_ANTI_AFFINITY]
+    if code == capi.FAIL_PORTS:
+        return ["node(s) didn't have free ports for the requested pod ports"]     # nodeports/node_ports.go:37
     if code == capi.FAIL_AFFINITY:
         return [ERR_AFFINITY_NOT_MATCH, ERR_AFFINITY_RULES]
     if code == capi.FAIL_SPREAD:

@@ -184,6 +184,21 @@ def _prefer_avoid(node: dict, pod: dict) -> int:
     return 100
 
 
+NODE_KEY = "\x00node"        # synthetic topology key whose domain is the node itself (NodePorts)
+
+
+def host_ports(pod: dict):
+    """getContainerPorts + HostPortInfo.sanitize (nodeports/node_ports.go:61-73, V/framework/types.go:816-823): the
+    (ip, protocol, port) triples with hostPort > 0 of the pod's containers (init containers are not looked at)."""
+    out = []
+    for c in pod["spec"].get("containers") or []:
+        for port in c.get("ports") or []:
+            hp = int(port.get("hostPort") or 0)
+            if hp > 0:
+                out.append((port.get("hostIP") or "0.0.0.0", port.get("protocol") or "TCP", hp))
+    return out
+
+
 def _bitmask(flags, words) -> np.ndarray:
     m = np.zeros(words, np.uint64)
     for j, f in enumerate(flags):
@@ -206,11 +221,6 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
 
     # ---- pods: requests, classes ---------------------------------------------------------------------------
     reqs = [k8s.pod_request(p) for p in pods]
-    for p in pods:
-        for c in (p["spec"].get("containers") or []) + (p["spec"].get("initContainers") or []):
-            for port in c.get("ports") or []:
-                if port.get("hostPort"):
-                    raise Unsupported("hostPort (NodePorts filter) is not modelled")
     scalar_names = sorted({name for r in reqs for name, v in r.items()
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
     if len(scalar_names) > capi.MAX_SCALAR:
@@ -238,7 +248,8 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         owner = [r.get("kind") for r in md.get("ownerReferences") or [] if r.get("controller")]
         key = json.dumps([md.get("namespace"), md.get("labels") or {}, spec.get("nodeSelector"), spec.get("affinity"),
                           spec.get("tolerations"), spec.get("topologySpreadConstraints"), owner,
-                          {k: str(v) for k, v in pod_requests_quantities(p).items()}, spec.get("overhead")], sort_keys=True)
+                          {k: str(v) for k, v in pod_requests_quantities(p).items()}, spec.get("overhead"), host_ports(p)],
+                         sort_keys=True)
         if key not in class_ids:
             class_ids[key] = len(class_rep)
             class_rep.append(p)
@@ -352,6 +363,16 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         return term_ids[t]
 
     anti, aff, pref, own, hard, soft, flags = ([[] for _ in range(Cp)] for _ in range(7))
+    # NodePorts: one term per (ip, protocol, port) triple in use anywhere, on the node-identity key
+    all_ports = sorted({t for p in class_rep for t in host_ports(p)})
+    port_conf = [[] for _ in range(Cp)]
+    for (ip, proto, hp) in all_ports:
+        term_id("port", (ip, proto, str(hp)), "", NODE_KEY)
+    for c, p in enumerate(class_rep):
+        for (ip, proto, hp) in host_ports(p):
+            for (ip2, proto2, hp2) in all_ports:                      # HostPortInfo.CheckConflict (types.go:784-812)
+                if (proto2, hp2) == (proto, hp) and (ip == "0.0.0.0" or ip2 in ("0.0.0.0", ip)):
+                    port_conf[c].append(term_id("port", (ip2, proto2, str(hp2)), "", NODE_KEY))
     pref_w, own_w, hard_skew, hard_self, hard_set, soft_skew = ([[] for _ in range(Cp)] for _ in range(6))
     const_pts = np.zeros(Cp, np.int64)
     for c, p in enumerate(class_rep):
@@ -419,6 +440,8 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         p = class_rep[c]
         ns, labels = p["metadata"]["namespace"], p["metadata"].get("labels") or {}
         kind, nss, sel = t[0], t[1], t[2]
+        if kind == "port":                                          # HostPortInfo.Add is a set: one count per distinct triple
+            return int((nss[0], nss[1], int(nss[2])) in set(host_ports(p)))
         if kind == "sel":
             return _matches_term(ns, labels, nss, sel)
         if kind == "all":
@@ -438,9 +461,11 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
             vals: Dict[str, int] = {}
             for j, n in enumerate(nodes):
                 lab = n["metadata"].get("labels") or {}
-                if key in lab:
+                if key == NODE_KEY:
+                    topo_dom[k, j] = j
+                elif key in lab:
                     topo_dom[k, j] = vals.setdefault(lab[key], len(vals))
-            topo_n[k] = max(len(vals), 1)
+            topo_n[k] = N if key == NODE_KEY else max(len(vals), 1)
 
         def csr(lists):
             off = np.cumsum([0] + [len(x) for x in lists]).astype(np.int32)
@@ -453,6 +478,8 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
             prob_kw["node_sets"] = np.stack(node_sets)
         prob_kw["match_off"], prob_kw["match_idx"] = csr(match)
         prob_kw["anti_off"], prob_kw["anti_idx"] = csr(anti)
+        if any(port_conf):
+            prob_kw["port_off"], prob_kw["port_idx"] = csr(port_conf)
         if any(aff):
             prob_kw["aff_off"], prob_kw["aff_idx"] = csr(aff)
             prob_kw["class_flags"] = np.array([capi.CLASS_AFF_SELF if f else 0 for f in flags], np.uint8)

@@ -182,6 +182,14 @@ static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables*
             return (uint16_t)(SIMON_FAIL_STATIC | r);
         }
     }
+    /* NodePorts.Filter -> fitsPorts -> HostPortInfo.CheckConflict (nodeports/node_ports.go:104-127, types.go:784-812) */
+    if (tb && tb->n_terms > 0 && tb->port_off) {
+        for (int e = tb->port_off[p->cls]; e < tb->port_off[p->cls + 1]; e++) {
+            int t = tb->port_idx[e];
+            int d = term_dom(nd, tb, t, j);
+            if (d >= 0 && s->cnt_match[t][d] > 0) return SIMON_FAIL_PORTS;
+        }
+    }
     /* NodeResourcesFit: fitsRequest, V/framework/plugins/noderesources/fit.go:230-302 */
     uint16_t fit = 0;
     if (s->npods[j] + 1 > nd->alloc_pods[j]) fit |= SIMON_FIT_PODS;             /* :233-242 */

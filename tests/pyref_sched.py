@@ -30,6 +30,7 @@ class NodeInfo:
         self.gpu_cnt = parse_quantity(str(cap[k8s.GPU_COUNT])).int_value() if k8s.GPU_COUNT in cap else 0
         self.gpu_total = parse_quantity(str(cap[k8s.GPU_MEM])).int_value() if k8s.GPU_MEM in cap else 0
         self.gpu_used = [0] * 8
+        self.used_ports = {}                       # HostPortInfo: ip -> set of (protocol, port)  (V/framework/types.go:730-823)
 
     def add_pod(self, pod):
         for k, v in k8s.pod_request(pod).items():
@@ -38,6 +39,19 @@ class NodeInfo:
         self.nz_cpu += c
         self.nz_mem += m
         self.pods.append(pod)
+        for ip, proto, port in fl.host_ports(pod):
+            self.used_ports.setdefault(ip, set()).add((proto, port))
+
+    def ports_conflict(self, pod):
+        """fitsPorts -> HostPortInfo.CheckConflict (nodeports/node_ports.go:116-127, types.go:784-812)."""
+        for ip, proto, port in fl.host_ports(pod):
+            if ip == "0.0.0.0":
+                if any((proto, port) in m for m in self.used_ports.values()):
+                    return True
+            else:
+                if any((proto, port) in self.used_ports.get(k, ()) for k in ("0.0.0.0", ip)):
+                    return True
+        return False
 
 
 # ---- filters -------------------------------------------------------------------------------------------------
@@ -183,6 +197,8 @@ class Scheduler:
             return "taint"
         if not k8s.pod_matches_node_selector_and_affinity(pod, ni.node):
             return "node_affinity"
+        if ni.ports_conflict(pod):
+            return "ports"
         if fits_request(pod, ni):
             return "fit"
         if hard:

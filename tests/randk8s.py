@@ -59,6 +59,13 @@ def rand_cluster(seed, n_nodes=12, n_workloads=10, gpu=False, max_replicas=6):
         container = {"name": "c", "image": "busybox"}
         if rng.random() < 0.9:
             container["resources"] = {"requests": {"cpu": cpu, "memory": mem} if rng.random() < 0.8 else {"cpu": cpu}}
+        if rng.random() < 0.2:       # host ports: NodePorts filter (wildcard and specific host IPs, TCP default and UDP)
+            hp = {"containerPort": 80, "hostPort": int(rng.choice([8080, 9090]))}
+            if rng.random() < 0.4:
+                hp["hostIP"] = str(rng.choice(["10.0.0.1", "10.0.0.2"]))
+            if rng.random() < 0.3:
+                hp["protocol"] = "UDP"
+            container["ports"] = [hp, {"containerPort": 81}]
         spec = {"containers": [container]}
         affinity = {}
         r = rng.random()

@@ -167,6 +167,30 @@ def test_unscheduled_reason_text():
         "1 node(s) had taint {dedicated: infra}, that the pod didn't tolerate.")
 
 
+def test_node_ports_conflicts_and_reason():
+    """HostPortInfo.CheckConflict (V/framework/types.go:784-812): same (protocol, port) conflicts on the same IP, and a
+    0.0.0.0 binding conflicts with every IP; UDP does not conflict with TCP."""
+    mk = lambda name: {"apiVersion": "v1", "kind": "Node", "metadata": {"name": name, "labels": {}},
+                       "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "10"}}}
+
+    def pod(name, ports):
+        return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "default"},
+                "spec": {"containers": [{"name": "c", "ports": ports, "resources": {"requests": {"cpu": "100m", "memory": "64Mi"}}}]}}
+    pods = [pod("a", [{"containerPort": 80, "hostPort": 8080, "hostIP": "10.0.0.1"}]),          # n0 (tie: first maximum)
+            pod("b", [{"containerPort": 80, "hostPort": 8080, "hostIP": "10.0.0.2"}]),          # n1 (LeastAllocated: emptier node)
+            pod("c", [{"containerPort": 80, "hostPort": 8080}]),                                # 0.0.0.0 conflicts with ANY IP: nowhere
+            pod("d", [{"containerPort": 80, "hostPort": 8080, "protocol": "UDP"}]),             # UDP never conflicts with TCP: n0
+            pod("e", [{"containerPort": 80, "hostPort": 8080, "hostIP": "10.0.0.3"}]),          # no wildcard placed: n1 (emptier)
+            pod("f", [{"containerPort": 80, "hostPort": 8080, "hostIP": "10.0.0.1"}])]          # n0 holds the same IP: n1
+    cluster = k8s.group_resources([mk("n0"), mk("n1")] + pods)
+    res = sim.simulate(cluster, [], engine=OracleEngine())
+    where = {p["metadata"]["name"]: s["node"]["metadata"]["name"] for s in res.node_status for p in s["pods"]}
+    ref = pyref_sched.Scheduler([mk("n0"), mk("n1")]).run([wl.make_valid_pod(p) for p in pods])
+    assert [where.get(n) for n in "abcdef"] == ref == ["n0", "n1", None, "n0", "n1", "n1"]
+    assert res.unscheduled_pods[0]["reason"] == ("failed to schedule pod (default/c): Unschedulable: 0/2 nodes are available: "
+                                                 "2 node(s) didn't have free ports for the requested pod ports.")
+
+
 def test_k8s_helpers():
     labels = {"app": "web", "tier": "fe"}
     assert k8s.label_selector_matches({}, labels) and not k8s.label_selector_matches(None, labels)
