@@ -48,6 +48,28 @@ def algorithmic_bytes(scen, n_pods, workload="config3", n_groups=50):
     return int((n_pods * (per_node * n + extra)).sum())
 
 
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave64 instructions / s: 256 CUs x 4 SIMDs, one wave64 VALU op per 4 cycles at 2.4 GHz
+
+
+def measured_issue(kernel, scenarios, pods, kernel_ms):
+    """The roofline that actually binds these integer / compare / fp64 kernels: VALU issue.  Instruction counts per step
+    come from the committed PMC profile (profiles/traffic.json, SQ_INSTS_VALU), the time is measured live."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for row in json.load(f)["entries"]:
+                if row["kernel"] == kernel and row["scenarios_per_gpu"] == scenarios and row["pods"] == pods:
+                    insts = row["insts_valu_per_dispatch"] * row["dispatches_per_step"]
+                    ach = insts / (kernel_ms * 1e-3)
+                    return {"bound": "valu_issue", "achieved": round(ach / 1e9, 1), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                            "unit": "G wave64-instr/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
+                            "wave_time_split": {"parked_on_waitcnt_or_barrier": round(row["wait_any_per_dispatch"] / row["wave_cycles_per_dispatch"], 3),
+                                                "executing": round(row["active_inst_any_per_dispatch"] / row["wave_cycles_per_dispatch"], 3)},
+                            "source": "SQ_INSTS_VALU / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of profiles/r01d_*_summary.txt"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def measured_traffic(kernel, scenarios, pods):
     """HBM-side bytes per step from the committed PMC profile of this workload (profiles/traffic.json: FETCH_SIZE x 2
     per MI355X_MICROARCH.md + WRITE_SIZE, summed over the kernel's launches of one step); None when no profile of
@@ -183,6 +205,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kname, "kernel_ms": round(k_ms, 3), "launches_per_step": st.n_launches,
                          "algorithmic_bytes_per_launch": alg,
+                         "binding": measured_issue(kname, S_local, prob.n_pods, k_ms),
                          "note": NOTE.get(st.kernel_variant, NOTE[4])},
         }
         if not args.no_cpu_baseline:
