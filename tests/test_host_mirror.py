@@ -90,6 +90,21 @@ def test_committed_example_fixtures_match_the_reference_inputs():
     assert sum(kinds.values()) == len(pods) == 37
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLE), reason="reference tree not present (GPU box)")
+def test_reference_gpushare_config_end_to_end():
+    """`simon apply -f example/simon-gpushare-config.yaml` through the mirror: the cluster alone holds every pod (the
+    expectation the reference documents for this config), so the add-nodes search answers 0 new nodes."""
+    cfg = sim.load_config(os.path.join(REF_EXAMPLE, "simon-gpushare-config.yaml"), base_dir=os.path.dirname(REF_EXAMPLE))
+    assert len(cfg["cluster"]["Node"]) == 2 and [a.name for a in cfg["apps"]] == ["pai_gpu"] and cfg["new_node"] is not None
+    sw = sim.sweep(cfg["cluster"], cfg["apps"], cfg["new_node"], range(0, 3), engine=OracleEngine())
+    assert sw.unscheduled == [0, 0, 0] and sw.best == 0
+    placed = sum(len(s["pods"]) for s in sw.result.node_status)
+    assert placed == 9 and not sw.result.unscheduled_pods
+    # gpu-pod-00 and gpu-pod-02 carry the gpu-mem annotation (gpu-pod-01 has none; the ReplicaSet's sit on the RS object)
+    gpu_pods = [p for s in sw.result.node_status for p in s["pods"] if "alibabacloud.com/gpu-mem" in (p["metadata"].get("annotations") or {})]
+    assert len(gpu_pods) == 2
+
+
 def test_sweep_equals_one_simulate_per_cluster_size():
     """The batched add-nodes search (gated DaemonSet pods, prefix node pools) against one Simulate() per size."""
     nodes, workloads, services = randk8s.rand_cluster(5, n_nodes=6, n_workloads=14, max_replicas=8)
