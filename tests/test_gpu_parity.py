@@ -197,6 +197,23 @@ def test_random_v2_features(idx, wg):
         assert_same(res, ref)
 
 
+@pytest.mark.parametrize("wg", ["64", "256", "512"])
+def test_random_v2_features_many_nodes(wg):
+    """Every ABI v2 plugin at once on a pool large enough that a lane owns several nodes and several load batches
+    (700 nodes: 11 nodes per lane at 64 threads), with gated / preset pods and prefix scenarios."""
+    feat = dict(anti=True, aff=True, ipa=True, spread_hard=True, spread_soft=True, static_scores=True, gpu=True, eph=True,
+                presets=True, gates=True, static_mask=True, nz_differs=True, init_state=True)
+    for seed in (4240, 4254):                     # ~80 % of the pods schedulable: long assume histories
+        prob = randprob.rand_problem(seed, N=700, P=1200, n_pod_classes=14, n_node_classes=9, **feat)
+        scen, orders = randprob.rand_scenarios(5, prob, S=4, min_n=400)
+        ref = O.run(prob, scen, orders)
+        res, variant = run_gpu(prob, scen, orders, env={"SIMON_WG": wg})
+        assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+        res, _ = run_gpu(prob, scen, orders, env={"SIMON_WG": wg, "SIMON_WIDE_NO_TABLE": "1"})     # full per-node evaluation path
+        assert_same(res, ref)
+
+
 def test_v2_hand_cases_on_gpu():
     """The hand-derived cases of tests/test_oracle_v2.py through the HIP path."""
     import test_oracle_v2 as T
