@@ -221,6 +221,10 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
 
     # ---- pods: requests, classes ---------------------------------------------------------------------------
     reqs = [k8s.pod_request(p) for p in pods]
+    for p in pods:        # Open-Local volumes (pkg/simulator/plugin/open-local.go:51-254) are not modelled yet
+        anno = (p["metadata"].get("annotations") or {}).get("simon/pod-local-storage")
+        if anno and json.loads(anno).get("volumes"):
+            raise Unsupported(f"pod {p['metadata']['name']} requests Open-Local volumes")
     scalar_names = sorted({name for r in reqs for name, v in r.items()
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
     if len(scalar_names) > capi.MAX_SCALAR:

@@ -81,13 +81,35 @@ def pods_of_deployment(d: dict) -> List[dict]:
     return pods_of_replicaset(rs)
 
 
+ANNO_POD_LOCAL_STORAGE = "simon/pod-local-storage"      # pkg/type/const.go
+LOCAL_SC_KIND = {"open-local-lvm": "LVM", "yoda-lvm-default": "LVM",
+                 "open-local-device-ssd": "SSD", "open-local-mountpoint-ssd": "SSD", "yoda-mountpoint-ssd": "SSD", "yoda-device-ssd": "SSD",
+                 "open-local-device-hdd": "HDD", "open-local-mountpoint-hdd": "HDD", "yoda-mountpoint-hdd": "HDD", "yoda-device-hdd": "HDD"}
+
+
+def storage_annotation(volume_claim_templates) -> str:
+    """SetStorageAnnotationOnPods (pkg/utils/utils.go:245-262): the Open-Local volumes of a StatefulSet's
+    volumeClaimTemplates as the JSON the Open-Local plugin reads back (GetPodStorage, :565-578)."""
+    import json
+    from .quantity import parse_quantity
+    vols = []
+    for pvc in volume_claim_templates or []:
+        sc = (pvc.get("spec") or {}).get("storageClassName")
+        if sc in LOCAL_SC_KIND:
+            size = parse_quantity(str(pvc["spec"]["resources"]["requests"]["storage"])).int_value()
+            vols.append({"size": str(size), "kind": LOCAL_SC_KIND[sc], "scName": sc})
+    return json.dumps({"volumes": vols})
+
+
 def pods_of_statefulset(ss: dict) -> List[dict]:
     """MakeValidPodsByStatefulSet (pkg/utils/utils.go:217-243); names <sts>-<ordinal>."""
     n = ss["spec"].get("replicas")
     n = 1 if n is None else int(n)
     out = []
+    anno = storage_annotation(ss["spec"].get("volumeClaimTemplates"))
     for i in range(n):
         p = make_valid_pod(_from_template(ss, ss["spec"]["template"], "StatefulSet", f"{ss['metadata']['name']}-{i}"))
+        p["metadata"]["annotations"][ANNO_POD_LOCAL_STORAGE] = anno
         out.append(_workload_info(p, "StatefulSet", ss))
     return out
 
