@@ -39,6 +39,9 @@ extern "C" {
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
 #define SIMON_MAX_TERMS_PER_CLASS 8
 #define SIMON_MAX_SPREAD 4  /* PodTopologySpread constraints per pod class and kind */
+#define SIMON_MAX_VG 4      /* Open-Local volume groups per node */
+#define SIMON_MAX_LDEV 8    /* Open-Local exclusive devices per node */
+#define SIMON_MAX_LVOL 4    /* Open-Local volumes per pod and kind (LVM / SSD / HDD) */
 #define SIMON_SPREAD_DUP_KEY 0x40000000 /* ORed into spread_soft_skew: an earlier constraint of the same pod already registered this
                                              (non-hostname) topology key, so initPreScoreState counts size 0 for this one (scoring.go:86-96) */
 #define SIMON_CLASS_AFF_SELF 0x1u /* pods of the class match all of their own required affinity terms (filtering.go:361-371) */
@@ -71,6 +74,9 @@ extern "C" {
 #define SIMON_FAIL_AFFINITY 0x2003u        /* "...affinity/anti-affinity" + "node(s) didn't match pod affinity rules" (:388; UnschedulableAndUnresolvable) */
 #define SIMON_FAIL_SPREAD 0x2010u          /* "node(s) didn't match pod topology spread constraints" (podtopologyspread/filtering.go:326) */
 #define SIMON_FAIL_SPREAD_LABEL 0x2011u    /* "... (missing required label)" (:303; UnschedulableAndUnresolvable) */
+#define SIMON_FAIL_LOCAL 0x0400u           /* Open-Local: node has no local storage (Unschedulable without reason text, open-local.go:64-69) */
+#define SIMON_FAIL_LOCAL_LVM 0x0401u       /* ... no volume group holds an LVM volume (ProcessLVMPVCPredicate's error text carries sizes) */
+#define SIMON_FAIL_LOCAL_DEV 0x0402u       /* ... not enough free exclusive devices of the requested media type / size */
 #define SIMON_FAIL_PORTS 0x0800u           /* "node(s) didn't have free ports for the requested pod ports" (nodeports/node_ports.go:37) */
 #define SIMON_FAIL_GPUSHARE 0x1000u        /* reason "Node:<name>" (pkg/simulator/plugin/open-gpu-share.go:64-78) */
 
@@ -103,6 +109,17 @@ typedef struct simon_nodes_soa {
     const int32_t* gpu_cnt;        /* [N] node Capacity alibabacloud.com/gpu-count (0 = not a GPU node); optional = feature off */
     const int64_t* gpu_mem_total;  /* [N] node Capacity alibabacloud.com/gpu-mem; per-device total = gpu_mem_total / gpu_cnt */
     const int64_t* init_gpu_used;  /* [N][SIMON_MAX_GPU_DEV] used bytes per device; optional */
+    /* Open-Local storage of a node = its annotation simon/node-local-storage (pkg/utils/utils.go:519-563:
+     * vendor/github.com/alibaba/open-local/pkg/scheduler/algorithm/cache/types.go:52-65).  All optional (feature off). */
+    const int32_t* local_flags;    /* [N] bit0: the node carries the storage annotation */
+    const int32_t* local_vg_cnt;   /* [N] volume groups, <= SIMON_MAX_VG, in annotation order */
+    const int64_t* local_vg_cap;   /* [N][SIMON_MAX_VG] SharedResource.Capacity */
+    const int64_t* init_vg_req;    /* [N][SIMON_MAX_VG] SharedResource.Requested before the stream; optional */
+    const int32_t* local_vg_name;  /* [N][SIMON_MAX_VG] interned VG name (StorageClass parameter vgName selects by name) */
+    const int32_t* local_dev_cnt;  /* [N] exclusive devices, <= SIMON_MAX_LDEV */
+    const int64_t* local_dev_cap;  /* [N][SIMON_MAX_LDEV] ExclusiveResource.Capacity */
+    const int32_t* local_dev_media;/* [N] 2 bits per device: 1 = ssd, 2 = hdd, 0 = other (never offered) */
+    const int32_t* init_dev_alloc; /* [N] bit d: ExclusiveResource.IsAllocated; optional */
     /* topology domains for InterPodAffinity (node label value interned per topology key) */
     int32_t n_topo_keys;           /* Kt */
     const int32_t* topo_dom;       /* [Kt][N] domain id in [0, topo_n_dom[k]) or -1 when the node lacks the label */
@@ -131,6 +148,18 @@ typedef struct simon_pods_soa {
     const int64_t* gpu_mem;        /* [P] annotation alibabacloud.com/gpu-mem, per GPU (pkg/type/open-gpu-share/utils/pod.go:56-67); optional */
     const int32_t* gpu_cnt;        /* [P] annotation alibabacloud.com/gpu-count (:70-81); optional */
 } simon_pods_soa;
+
+/* Open-Local volumes of one pod class (annotation simon/pod-local-storage -> utils.GetPodLocalPVCs,
+ * pkg/utils/utils.go:580-623), pre-sorted the way the plugin processes them:
+ *   lvm_*: PVCs whose StorageClass names a VG first (DivideLVMPVCs, algo/common.go:146-155), then the others, pod order kept;
+ *   ssd_size / hdd_size: ascending (CheckExclusiveResourceMeetsPVCSize sorts them, :290-297). */
+typedef struct simon_local_spec {
+    int32_t n_lvm, n_ssd, n_hdd, pad;
+    int64_t lvm_size[SIMON_MAX_LVOL];
+    int32_t lvm_vg[SIMON_MAX_LVOL];   /* interned VG name or -1 (any VG, Binpack strategy) */
+    int64_t ssd_size[SIMON_MAX_LVOL];
+    int64_t hdd_size[SIMON_MAX_LVOL];
+} simon_local_spec;
 
 /* ---------------------------------------------------------------------------------------------
  * Per pod-class tables: everything about a (pod, node) pair that does not depend on placements.
@@ -216,6 +245,11 @@ typedef struct simon_class_tables {
     const int32_t* spread_soft_off;  /* [Cp+1]; optional */
     const int32_t* spread_soft_idx;
     const int32_t* spread_soft_skew; /* maxSkew, optionally | SIMON_SPREAD_DUP_KEY */
+    /* Open-Local (pkg/simulator/plugin/open-local.go:51-254): filter = ProcessLVMPVCPredicate + ProcessDevicePVC, score =
+     * ScoreLVMVolume + ScoreDeviceVolume (0..20) min-max normalised over the feasible nodes, bind = the allocated units. */
+    const int32_t* local_spec_of;    /* [Cp] index into local_specs or -1; optional (no class requests local volumes) */
+    int32_t n_local_specs;
+    const simon_local_spec* local_specs;
     const uint8_t* topo_is_hostname; /* [Kt] 1 for kubernetes.io/hostname (scoring.go:100-104: size = scored nodes); optional */
     const double* spread_log;        /* [N+1] spread_log[i] = Go math.Log(float64(i+2)) (scoring.go:279-281); the Go host fills
                                         it with its own math.Log so the engine never approximates it; required with soft */
@@ -235,6 +269,7 @@ typedef struct simon_batch_out {
     int64_t* used_cpu;             /* [S] sum over the scenario's nodes of Requested.MilliCPU at the end (for satisfyResourceSetting) */
     int64_t* used_mem;             /* [S] likewise, bytes */
     int32_t* placement;            /* [S][P] indexed by POD ID: node index, SIMON_UNSCHEDULED or SIMON_GATED; optional (NULL = not fetched) */
+    int64_t* used_vg;              /* [S] sum of the nodes' volume-group Requested at the end (MaxVG cap, pkg/apply/apply.go:753-771); optional */
 } simon_batch_out;
 
 /* Result of the add-nodes search (pkg/apply/apply.go:203-259 + satisfyResourceSetting :689-775) */

@@ -35,6 +35,8 @@ FAIL_GPUSHARE = 0x1000
 FAIL_PORTS = 0x0800
 CLASS_AFF_SELF = 0x1
 MAX_SPREAD = 4
+MAX_VG, MAX_LDEV, MAX_LVOL = 4, 8, 4
+FAIL_LOCAL, FAIL_LOCAL_LVM, FAIL_LOCAL_DEV = 0x0400, 0x0401, 0x0402
 SPREAD_DUP_KEY = 0x40000000
 
 KERNEL_NARROW = 1
@@ -59,6 +61,8 @@ class NodesSoA(C.Structure):
         ("node_class", _p32),
         ("n_scalar", C.c_int32), ("scalar_alloc", _p64), ("init_scalar_req", _p64),
         ("gpu_cnt", _p32), ("gpu_mem_total", _p64), ("init_gpu_used", _p64),
+        ("local_flags", _p32), ("local_vg_cnt", _p32), ("local_vg_cap", _p64), ("init_vg_req", _p64), ("local_vg_name", _p32),
+        ("local_dev_cnt", _p32), ("local_dev_cap", _p64), ("local_dev_media", _p32), ("init_dev_alloc", _p32),
         ("n_topo_keys", C.c_int32), ("topo_dom", _p32), ("topo_n_dom", _p32),
     ]
 
@@ -70,6 +74,17 @@ class PodsSoA(C.Structure):
         ("scalar_req", _p64), ("pod_class", _p32), ("preset_node", _p32), ("gate_node", _p32),
         ("gpu_mem", _p64), ("gpu_cnt", _p32),
     ]
+
+
+class LocalSpec(C.Structure):
+    _fields_ = [("n_lvm", C.c_int32), ("n_ssd", C.c_int32), ("n_hdd", C.c_int32), ("pad", C.c_int32),
+                ("lvm_size", C.c_int64 * MAX_LVOL), ("lvm_vg", C.c_int32 * MAX_LVOL),
+                ("ssd_size", C.c_int64 * MAX_LVOL), ("hdd_size", C.c_int64 * MAX_LVOL)]
+
+
+LOCAL_SPEC_DTYPE = np.dtype([("n_lvm", "<i4"), ("n_ssd", "<i4"), ("n_hdd", "<i4"), ("pad", "<i4"), ("lvm_size", "<i8", (MAX_LVOL,)),
+                             ("lvm_vg", "<i4", (MAX_LVOL,)), ("ssd_size", "<i8", (MAX_LVOL,)), ("hdd_size", "<i8", (MAX_LVOL,))])
+assert LOCAL_SPEC_DTYPE.itemsize == C.sizeof(LocalSpec)
 
 
 class ClassTables(C.Structure):
@@ -87,6 +102,7 @@ class ClassTables(C.Structure):
         ("spread_hard_off", _p32), ("spread_hard_idx", _p32), ("spread_hard_skew", _p32),
         ("spread_hard_self", _p32), ("spread_hard_set", _p32),
         ("spread_soft_off", _p32), ("spread_soft_idx", _p32), ("spread_soft_skew", _p32),
+        ("local_spec_of", _p32), ("n_local_specs", C.c_int32), ("local_specs", C.POINTER(LocalSpec)),
         ("topo_is_hostname", _pu8), ("spread_log", _pf64),
     ]
 
@@ -98,7 +114,7 @@ class Scenario(C.Structure):
 class BatchOut(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32),
-        ("unscheduled", _p32), ("used_cpu", _p64), ("used_mem", _p64), ("placement", _p32),
+        ("unscheduled", _p32), ("used_cpu", _p64), ("used_mem", _p64), ("placement", _p32), ("used_vg", _p64),
     ]
 
 
@@ -158,6 +174,15 @@ class Problem:
     gpu_cnt: Optional[np.ndarray] = None
     gpu_mem_total: Optional[np.ndarray] = None
     init_gpu_used: Optional[np.ndarray] = None     # [N][8]
+    local_flags: Optional[np.ndarray] = None       # [N]
+    local_vg_cnt: Optional[np.ndarray] = None
+    local_vg_cap: Optional[np.ndarray] = None      # [N][4]
+    init_vg_req: Optional[np.ndarray] = None
+    local_vg_name: Optional[np.ndarray] = None     # [N][4]
+    local_dev_cnt: Optional[np.ndarray] = None
+    local_dev_cap: Optional[np.ndarray] = None     # [N][8]
+    local_dev_media: Optional[np.ndarray] = None
+    init_dev_alloc: Optional[np.ndarray] = None
     topo_dom: Optional[np.ndarray] = None          # [Kt][N]
     topo_n_dom: Optional[np.ndarray] = None        # [Kt]
     # pods
@@ -208,6 +233,8 @@ class Problem:
     spread_soft_off: Optional[np.ndarray] = None
     spread_soft_idx: Optional[np.ndarray] = None
     spread_soft_skew: Optional[np.ndarray] = None
+    local_spec_of: Optional[np.ndarray] = None     # [Cp]
+    local_specs: Optional[np.ndarray] = None       # structured array LOCAL_SPEC_DTYPE
     topo_is_hostname: Optional[np.ndarray] = None  # [Kt] uint8
     spread_log: Optional[np.ndarray] = None        # [N+1] float64
     _keep: list = field(default_factory=list, repr=False)
@@ -238,6 +265,16 @@ class Problem:
             assert self.scalar_alloc.shape == (K, N) and K <= MAX_SCALAR
         self.init_scalar_req = _arr(self.init_scalar_req, i64, (K, N)) if self.init_scalar_req is not None else None
         self.init_gpu_used = _arr(self.init_gpu_used, i64, (N, MAX_GPU_DEV)) if self.init_gpu_used is not None else None
+        if self.local_flags is not None:
+            self.local_flags = _arr(self.local_flags, i32, (N,))
+            self.local_vg_cnt = _arr(self.local_vg_cnt if self.local_vg_cnt is not None else np.zeros(N), i32, (N,))
+            self.local_vg_cap = _arr(self.local_vg_cap if self.local_vg_cap is not None else np.zeros((N, MAX_VG)), i64, (N, MAX_VG))
+            self.init_vg_req = _arr(self.init_vg_req, i64, (N, MAX_VG)) if self.init_vg_req is not None else None
+            self.local_vg_name = _arr(self.local_vg_name if self.local_vg_name is not None else np.zeros((N, MAX_VG)), i32, (N, MAX_VG))
+            self.local_dev_cnt = _arr(self.local_dev_cnt if self.local_dev_cnt is not None else np.zeros(N), i32, (N,))
+            self.local_dev_cap = _arr(self.local_dev_cap if self.local_dev_cap is not None else np.zeros((N, MAX_LDEV)), i64, (N, MAX_LDEV))
+            self.local_dev_media = _arr(self.local_dev_media if self.local_dev_media is not None else np.zeros(N), i32, (N,))
+            self.init_dev_alloc = _arr(self.init_dev_alloc, i32, (N,)) if self.init_dev_alloc is not None else None
         Kt = 0
         if self.topo_dom is not None:
             self.topo_dom = _arr(self.topo_dom, i32)
@@ -262,6 +299,9 @@ class Problem:
         for name in ("node_affinity_raw", "taint_prefer_raw", "static_add"):
             v = getattr(self, name)
             setattr(self, name, _arr(v, i64, (Cp, Cn)) if v is not None else None)
+        if self.local_spec_of is not None:
+            self.local_spec_of = _arr(self.local_spec_of, i32, (Cp,))
+            self.local_specs = np.ascontiguousarray(self.local_specs, dtype=LOCAL_SPEC_DTYPE)
         if self.term_topo_key is not None:
             self.term_topo_key = _arr(self.term_topo_key, i32)
             T = len(self.term_topo_key)
@@ -310,8 +350,11 @@ class Problem:
                      "init_nz_cpu", "init_nz_mem", "scalar_alloc", "init_scalar_req", "gpu_mem_total",
                      "init_gpu_used"):
             setattr(s, name, _ptr(getattr(self, name), C.c_int64))
-        for name in ("alloc_pods", "init_npods", "node_class", "gpu_cnt", "topo_dom", "topo_n_dom"):
+        for name in ("alloc_pods", "init_npods", "node_class", "gpu_cnt", "topo_dom", "topo_n_dom", "local_flags", "local_vg_cnt",
+                     "local_vg_name", "local_dev_cnt", "local_dev_media", "init_dev_alloc"):
             setattr(s, name, _ptr(getattr(self, name), C.c_int32))
+        for name in ("local_vg_cap", "init_vg_req", "local_dev_cap"):
+            setattr(s, name, _ptr(getattr(self, name), C.c_int64))
         s.n_scalar = 0 if self.scalar_alloc is None else self.scalar_alloc.shape[0]
         s.n_topo_keys = 0 if self.topo_dom is None else self.topo_dom.shape[0]
         return s
@@ -348,6 +391,10 @@ class Problem:
                      "spread_hard_idx", "spread_hard_skew", "spread_hard_self", "spread_hard_set", "spread_soft_off",
                      "spread_soft_idx", "spread_soft_skew"):
             setattr(s, name, _ptr(getattr(self, name) if s.n_terms else None, C.c_int32))
+        s.local_spec_of = _ptr(self.local_spec_of, C.c_int32)
+        s.n_local_specs = 0 if self.local_specs is None else len(self.local_specs)
+        s.local_specs = C.cast(None, C.POINTER(LocalSpec)) if self.local_specs is None else \
+            self.local_specs.ctypes.data_as(C.POINTER(LocalSpec))
         s.class_flags = _ptr(self.class_flags, C.c_uint8)
         s.topo_is_hostname = _ptr(self.topo_is_hostname, C.c_uint8)
         s.spread_log = _ptr(self.spread_log, C.c_double)
@@ -360,6 +407,7 @@ class BatchResult:
     used_cpu: np.ndarray
     used_mem: np.ndarray
     placement: Optional[np.ndarray]
+    used_vg: Optional[np.ndarray] = None
 
     def c_out(self) -> BatchOut:
         o = BatchOut()
@@ -369,12 +417,13 @@ class BatchResult:
         o.used_cpu = _ptr(self.used_cpu, C.c_int64)
         o.used_mem = _ptr(self.used_mem, C.c_int64)
         o.placement = _ptr(self.placement, C.c_int32)
+        o.used_vg = _ptr(self.used_vg, C.c_int64)
         return o
 
     @staticmethod
     def alloc(S: int, P: int, want_placement: bool = True) -> "BatchResult":
         return BatchResult(np.zeros(S, np.int32), np.zeros(S, np.int64), np.zeros(S, np.int64),
-                           np.full((S, P), -9, np.int32) if want_placement else None)
+                           np.full((S, P), -9, np.int32) if want_placement else None, np.zeros(S, np.int64))
 
 
 def scenarios_array(scen: Sequence) -> np.ndarray:

@@ -54,6 +54,11 @@ def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scal
         return [ERR_AFFINITY_NOT_MATCH, ERR_ANTI_AFFINITY_RULES]
     if code == capi.FAIL_ANTI_EXISTING:
         return [ERR_AFFINITY_NOT_MATCH, ERR_EXISTING_ANTI_AFFINITY]
+    if code == capi.FAIL_LOCAL:
+        return []                                  # Unschedulable without a reason (plugin/open-local.go:64-69)
+    if code in (capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL_DEV):
+        # the reference's reason is open-local's error text, which embeds sizes the per-node code does not carry
+        return ["insufficient local storage (LVM)" if code == capi.FAIL_LOCAL_LVM else "insufficient local storage (device)"]
     if code == capi.FAIL_PORTS:
         return ["node(s) didn't have free ports for the requested pod ports"]     # nodeports/node_ports.go:37
     if code == capi.FAIL_AFFINITY:

@@ -184,6 +184,58 @@ def _prefer_avoid(node: dict, pod: dict) -> int:
     return 100
 
 
+ANNO_NODE_LOCAL_STORAGE = "simon/node-local-storage"      # pkg/type/const.go
+ANNO_POD_LOCAL_STORAGE = "simon/pod-local-storage"
+LVM_SC_NAMES = ("open-local-lvm", "yoda-lvm-default")    # pkg/utils/const.go:5,12
+
+
+def node_local_storage(node: dict):
+    """utils.GetNodeStorage (pkg/utils/utils.go:519-531): None without the annotation, else (vgs, devices) with
+    vgs = [(name, capacity, requested)], devices = [(capacity, media, allocated)]; media 1 = ssd, 2 = hdd, 0 = other."""
+    anno = (node["metadata"].get("annotations") or {}).get(ANNO_NODE_LOCAL_STORAGE)
+    if anno is None:
+        return None
+    d = json.loads(anno)
+    vgs = [(v["name"], int(v.get("capacity", 0)), int(v.get("requested", 0) or 0)) for v in d.get("vgs") or []]
+    devs = [(int(x.get("capacity", 0)), {"ssd": 1, "hdd": 2}.get(x.get("mediaType"), 0), str(x.get("isAllocated", "false")).lower() == "true")
+            for x in d.get("devices") or []]
+    return vgs, devs
+
+
+def pod_local_volumes(pod: dict, storage_classes):
+    """utils.GetPodLocalPVCs (pkg/utils/utils.go:580-623) + DivideLVMPVCs / DividePVCAccordingToMediaType (open-local
+    algo/common.go:146-155,247-260): (lvm [(size, vgName or None)] with the VG-named ones first, ssd sizes, hdd sizes)."""
+    anno = (pod["metadata"].get("annotations") or {}).get(ANNO_POD_LOCAL_STORAGE)
+    if not anno:
+        return None
+    vols = json.loads(anno).get("volumes") or []
+    if not vols:
+        return None
+    scs = {sc["metadata"]["name"]: sc for sc in storage_classes}
+    with_vg, without_vg, ssd, hdd = [], [], [], []
+    n_device_pvcs = 0
+    for v in vols:
+        if v.get("kind") not in ("LVM", "HDD", "SSD"):
+            continue
+        size, sc_name = int(v["size"]), v.get("scName", "")
+        if size <= 0:
+            raise Unsupported("Open-Local volume of size 0")
+        params = (scs.get(sc_name) or {}).get("parameters") or {}
+        if sc_name in LVM_SC_NAMES:
+            (with_vg if params.get("vgName") else without_vg).append((size, params.get("vgName") or None))
+        else:
+            n_device_pvcs += 1
+            media = params.get("mediaType")          # a PVC with another / no media type is skipped by the plugin (:247-260)
+            if media == "ssd":
+                ssd.append(size)
+            elif media == "hdd":
+                hdd.append(size)
+    if n_device_pvcs and not (ssd or hdd):
+        # ScoreDevice would divide by zero units (int(NaN) in Go): leave such pods to the Go path
+        raise Unsupported("Open-Local device volumes whose StorageClasses carry no ssd/hdd mediaType")
+    return with_vg + without_vg, sorted(ssd), sorted(hdd)
+
+
 NODE_KEY = "\x00node"        # synthetic topology key whose domain is the node itself (NodePorts)
 
 
@@ -208,7 +260,7 @@ def _bitmask(flags, words) -> np.ndarray:
 
 
 def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), statefulsets=(),
-            gates: Optional[List[int]] = None) -> Flat:
+            gates: Optional[List[int]] = None, storage_classes=()) -> Flat:
     """nodes: the pool in canonical order (cluster nodes, then new-node clones).  pods: the stream in scheduling order;
     a pod with spec.nodeName is bound without filtering (V/eventhandlers.go:223-236).  gates[p] = node index the pod
     depends on (DaemonSet pods of new nodes, pkg/simulator/core.go:85-95) or -1."""
@@ -221,10 +273,6 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
 
     # ---- pods: requests, classes ---------------------------------------------------------------------------
     reqs = [k8s.pod_request(p) for p in pods]
-    for p in pods:        # Open-Local volumes (pkg/simulator/plugin/open-local.go:51-254) are not modelled yet
-        anno = (p["metadata"].get("annotations") or {}).get("simon/pod-local-storage")
-        if anno and json.loads(anno).get("volumes"):
-            raise Unsupported(f"pod {p['metadata']['name']} requests Open-Local volumes")
     scalar_names = sorted({name for r in reqs for name, v in r.items()
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
     if len(scalar_names) > capi.MAX_SCALAR:
@@ -252,8 +300,8 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         owner = [r.get("kind") for r in md.get("ownerReferences") or [] if r.get("controller")]
         key = json.dumps([md.get("namespace"), md.get("labels") or {}, spec.get("nodeSelector"), spec.get("affinity"),
                           spec.get("tolerations"), spec.get("topologySpreadConstraints"), owner,
-                          {k: str(v) for k, v in pod_requests_quantities(p).items()}, spec.get("overhead"), host_ports(p)],
-                         sort_keys=True)
+                          {k: str(v) for k, v in pod_requests_quantities(p).items()}, spec.get("overhead"), host_ports(p),
+                          pod_local_volumes(p, storage_classes)], sort_keys=True)
         if key not in class_ids:
             class_ids[key] = len(class_rep)
             class_rep.append(p)
@@ -502,6 +550,54 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
             prob_kw["spread_soft_skew"] = csr(soft_skew)[1]
             prob_kw["spread_log"] = gomath.spread_log_table(N)
     # InterPodAffinity scores 0 everywhere when nobody owns a scoring term; ImageLocality / Open-Local are constants 0
+
+    # ---- Open-Local: node storage and per-class volume specs -------------------------------------------------
+    vols = [pod_local_volumes(p, storage_classes) for p in class_rep]
+    if any(v is not None for v in vols):
+        storage = [node_local_storage(n) for n in nodes]
+        vg_names: Dict[str, int] = {}
+        lf = np.zeros(N, np.int32); vcnt = np.zeros(N, np.int32); vcap = np.zeros((N, capi.MAX_VG), np.int64)
+        vreq = np.zeros((N, capi.MAX_VG), np.int64); vname = np.full((N, capi.MAX_VG), -1, np.int32)
+        dcnt = np.zeros(N, np.int32); dcap = np.zeros((N, capi.MAX_LDEV), np.int64); dmedia = np.zeros(N, np.int32); dalloc = np.zeros(N, np.int32)
+        for j, st in enumerate(storage):
+            if st is None:
+                continue
+            vgs, devs = st
+            if len(vgs) > capi.MAX_VG or len(devs) > capi.MAX_LDEV:
+                raise Unsupported(f"node {node_names[j]}: more than {capi.MAX_VG} volume groups or {capi.MAX_LDEV} devices")
+            lf[j] = 1
+            vcnt[j], dcnt[j] = len(vgs), len(devs)
+            for v, (name, cap, req) in enumerate(vgs):
+                vcap[j, v], vreq[j, v], vname[j, v] = cap, req, vg_names.setdefault(name, len(vg_names))
+            for d, (cap, media, alloc) in enumerate(devs):
+                dcap[j, d] = cap
+                dmedia[j] |= media << (2 * d)
+                dalloc[j] |= int(alloc) << d
+        spec_ids: Dict[str, int] = {}
+        specs = []
+        spec_of = np.full(Cp, -1, np.int32)
+        for c, v in enumerate(vols):
+            if v is None:
+                continue
+            lvm, ssd, hdd = v
+            if max(len(lvm), len(ssd), len(hdd)) > capi.MAX_LVOL:
+                raise Unsupported(f"more than {capi.MAX_LVOL} Open-Local volumes of one kind in a pod")
+            key = json.dumps(v)
+            if key not in spec_ids:
+                spec_ids[key] = len(specs)
+                row = np.zeros((), capi.LOCAL_SPEC_DTYPE)
+                row["n_lvm"], row["n_ssd"], row["n_hdd"] = len(lvm), len(ssd), len(hdd)
+                row["lvm_vg"][:] = -1
+                for k, (size, name) in enumerate(lvm):
+                    row["lvm_size"][k] = size
+                    row["lvm_vg"][k] = -1 if name is None else vg_names.setdefault(name, len(vg_names))
+                row["ssd_size"][:len(ssd)] = ssd
+                row["hdd_size"][:len(hdd)] = hdd
+                specs.append(row)
+            spec_of[c] = spec_ids[key]
+        prob_kw.update(local_flags=lf, local_vg_cnt=vcnt, local_vg_cap=vcap, init_vg_req=vreq, local_vg_name=vname,
+                       local_dev_cnt=dcnt, local_dev_cap=dcap, local_dev_media=dmedia, init_dev_alloc=dalloc,
+                       local_spec_of=spec_of, local_specs=np.array(specs, capi.LOCAL_SPEC_DTYPE))
 
     prob = capi.Problem(
         alloc_cpu=alloc_cpu, alloc_mem=alloc_mem, alloc_pods=alloc_pods, alloc_eph=alloc_eph if alloc_eph.any() or req_eph.any() else None,

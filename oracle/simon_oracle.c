@@ -26,6 +26,8 @@ typedef struct {
     int32_t** cnt_owner; /* [T] -> [...]: placed pods that REQUIRE anti-affinity term t per domain */
     int64_t** w_owner;   /* [T] -> [...]: summed signed weights of placed pods' scoring terms (own_*) per domain */
     int64_t* term_total; /* [T] sum over domains of cnt_match[t] */
+    int64_t* vg_req;     /* [N][SIMON_MAX_VG] Open-Local SharedResource.Requested */
+    int32_t* dev_alloc;  /* [N] bit d: ExclusiveResource.IsAllocated */
 } state_t;
 
 static void* xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
@@ -37,6 +39,7 @@ static void state_free(state_t* s, int T) {
     if (s->cnt_owner) for (int t = 0; t < T; t++) free(s->cnt_owner[t]);
     if (s->w_owner) for (int t = 0; t < T; t++) free(s->w_owner[t]);
     free(s->cnt_match); free(s->cnt_owner); free(s->w_owner); free(s->term_total);
+    free(s->vg_req); free(s->dev_alloc);
 }
 
 static int state_init(state_t* s, const simon_nodes_soa* nd, const simon_class_tables* tb) {
@@ -61,6 +64,9 @@ static int state_init(state_t* s, const simon_nodes_soa* nd, const simon_class_t
     if (nd->init_npods) memcpy(s->npods, nd->init_npods, (size_t)N * 4);
     if (nd->init_scalar_req) memcpy(s->scalar_req, nd->init_scalar_req, (size_t)K * N * 8);
     if (nd->init_gpu_used) memcpy(s->gpu_used, nd->init_gpu_used, (size_t)N * SIMON_MAX_GPU_DEV * 8);
+    s->vg_req = xcalloc((size_t)N * SIMON_MAX_VG, 8); s->dev_alloc = xcalloc(N, 4);
+    if (nd->local_flags && nd->init_vg_req) memcpy(s->vg_req, nd->init_vg_req, (size_t)N * SIMON_MAX_VG * 8);
+    if (nd->local_flags && nd->init_dev_alloc) memcpy(s->dev_alloc, nd->init_dev_alloc, (size_t)N * 4);
     return 0;
 }
 
@@ -166,6 +172,104 @@ static void spread_prefilter(const simon_nodes_soa* nd, const simon_class_tables
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Open-Local (pkg/simulator/plugin/open-local.go:51-254 over vendor/github.com/alibaba/open-local/ */
+/* pkg/scheduler/algorithm/algo/common.go).  Determinised where the reference iterates Go maps or  */
+/* sorts unstably: equal free sizes / capacities keep annotation order; float sums run in VG order. */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_lvm; int lvm_vg[SIMON_MAX_LVOL]; int64_t lvm_size[SIMON_MAX_LVOL];           /* AllocatedUnit, LVM */
+    int n_dev; int dev_idx[2 * SIMON_MAX_LVOL]; int64_t dev_size[2 * SIMON_MAX_LVOL];  /* AllocatedUnit, Device */
+} local_units_t;
+
+static const simon_local_spec* local_spec_of(const simon_class_tables* tb, int cls) {
+    if (!tb || !tb->local_spec_of || tb->local_spec_of[cls] < 0) return NULL;
+    const simon_local_spec* sp = &tb->local_specs[tb->local_spec_of[cls]];
+    return (sp->n_lvm + sp->n_ssd + sp->n_hdd) > 0 ? sp : NULL;
+}
+
+/* CheckExclusiveResourceMeetsPVCSize (algo/common.go:290-350) on the free devices of one media type:
+ * devices ascending by capacity, PVCs ascending by size, two pointers; fails ONLY when the last device is too
+ * small for the current PVC (a shortfall without that event still "fits", exactly like the reference). */
+static int local_match_devices(const simon_nodes_soa* nd, const state_t* s, int j, int media, int n_pvc, const int64_t* sizes,
+                               local_units_t* u) {
+    int cnt = nd->local_dev_cnt[j], nfree = 0, order[SIMON_MAX_LDEV];
+    const int64_t* cap = nd->local_dev_cap + (size_t)j * SIMON_MAX_LDEV;
+    for (int d = 0; d < cnt; d++)                                               /* GetFreeDevice :367-383 */
+        if (((nd->local_dev_media[j] >> (2 * d)) & 3) == media && !((s->dev_alloc[j] >> d) & 1)) order[nfree++] = d;
+    if (nfree < n_pvc) return 0;                                                /* ProcessDevicePVC :411-417, 428-434 */
+    for (int a = 1; a < nfree; a++)                                             /* stable insertion sort by capacity */
+        for (int b = a; b > 0 && cap[order[b]] < cap[order[b - 1]]; b--) { int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    int i = 0;
+    for (int k = 0; k < nfree; k++) {
+        if (n_pvc == 0) break;
+        if (cap[order[k]] < sizes[i]) { if (k == nfree - 1) return 0; continue; }
+        u->dev_idx[u->n_dev] = order[k]; u->dev_size[u->n_dev] = sizes[i]; u->n_dev++;
+        if (++i == n_pvc) break;
+    }
+    return 1;
+}
+
+/* Filter + allocation of one pod's local volumes on node j: ProcessLVMPVCPredicate (:59-144; identical unit choice to
+ * ProcessLVMPVCPriority/Binpack :511-619) and ProcessDevicePVC (:394-449).  Returns a SIMON_FAIL_LOCAL* code (0 = fits). */
+static uint16_t local_allocate(const simon_nodes_soa* nd, const state_t* s, const simon_local_spec* sp, int j, local_units_t* u) {
+    memset(u, 0, sizeof(*u));
+    if (!nd->local_flags || !(nd->local_flags[j] & 1)) return SIMON_FAIL_LOCAL;  /* open-local.go:58-69 */
+    if (sp->n_lvm > 0) {
+        int nvg = nd->local_vg_cnt[j];
+        if (nvg <= 0) return SIMON_FAIL_LOCAL_LVM;                               /* NewNoAvailableVGError :109-111 */
+        const int64_t* cap = nd->local_vg_cap + (size_t)j * SIMON_MAX_VG;
+        const int32_t* name = nd->local_vg_name + (size_t)j * SIMON_MAX_VG;
+        int64_t req[SIMON_MAX_VG];
+        for (int v = 0; v < nvg; v++) req[v] = s->vg_req[(size_t)j * SIMON_MAX_VG + v];
+        for (int k = 0; k < sp->n_lvm; k++) {
+            int64_t size = sp->lvm_size[k];
+            int pick = -1;
+            if (sp->lvm_vg[k] >= 0) {                                            /* PVC with a VG name :66-97 */
+                for (int v = 0; v < nvg; v++) if (name[v] == sp->lvm_vg[k]) { pick = v; break; }
+                if (pick < 0 || cap[pick] - req[pick] < size) return SIMON_FAIL_LOCAL_LVM;
+            } else {                                                             /* smallest free size that fits :113-141 */
+                for (int v = 0; v < nvg; v++) {
+                    int64_t fr = cap[v] - req[v];
+                    if (fr >= size && (pick < 0 || fr < cap[pick] - req[pick])) pick = v;
+                }
+                if (pick < 0) return SIMON_FAIL_LOCAL_LVM;
+            }
+            req[pick] += size;
+            u->lvm_vg[u->n_lvm] = pick; u->lvm_size[u->n_lvm] = size; u->n_lvm++;
+        }
+    }
+    if (sp->n_ssd + sp->n_hdd > 0) {
+        if (!local_match_devices(nd, s, j, 1, sp->n_ssd, sp->ssd_size, u)) return SIMON_FAIL_LOCAL_DEV;   /* SSD first :409-425 */
+        if (!local_match_devices(nd, s, j, 2, sp->n_hdd, sp->hdd_size, u)) return SIMON_FAIL_LOCAL_DEV;
+    }
+    return 0;
+}
+
+/* LocalPlugin.Score (open-local.go:93-141): ScoreLVM (:660-692, Binpack strategy) + ScoreDevice (:753-762), MaxScore 10 */
+static int64_t local_score(const simon_nodes_soa* nd, int j, const local_units_t* u) {
+    int64_t score = 0;
+    if (u->n_lvm > 0) {
+        int64_t used[SIMON_MAX_VG] = {0};
+        int hit[SIMON_MAX_VG] = {0};
+        for (int k = 0; k < u->n_lvm; k++) { used[u->lvm_vg[k]] += u->lvm_size[k]; hit[u->lvm_vg[k]] = 1; }
+        double f = 0; int count = 0;
+        for (int v = 0; v < SIMON_MAX_VG; v++)                     /* scoreMap: one entry per VG that received a unit */
+            if (hit[v]) {
+                f += (double)used[v] / (double)nd->local_vg_cap[(size_t)j * SIMON_MAX_VG + v];
+                count++;
+            }
+        score += (int64_t)(int)(f / (double)count * 10.0);
+    }
+    if (u->n_dev > 0) {
+        double f = 0;
+        for (int k = 0; k < u->n_dev; k++)
+            f += (double)u->dev_size[k] / (double)nd->local_dev_cap[(size_t)j * SIMON_MAX_LDEV + u->dev_idx[k]];
+        score += (int64_t)(int)(f / (double)u->n_dev * 10.0);
+    }
+    return score;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* One (pod, node) filter evaluation.  Order and early exit: RunFilterPlugins                    */
 /* V/framework/runtime/framework.go:527-552; plugin order V/algorithmprovider/registry.go:87-104 */
 /* + pkg/simulator/utils.go:321-333.  Returns a SIMON_FAIL_* code (0 = feasible).                */
@@ -250,6 +354,13 @@ static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables*
             if (d >= 0 && s->cnt_owner[t][d] > 0) return SIMON_FAIL_ANTI_EXISTING;
         }
     }
+    /* Open-Local.Filter, pkg/simulator/plugin/open-local.go:51-91 */
+    const simon_local_spec* lsp = local_spec_of(tb, p->cls);
+    if (lsp) {
+        local_units_t lu;
+        uint16_t lc = local_allocate(nd, s, lsp, j, &lu);
+        if (lc) return lc;
+    }
     /* Open-Gpu-Share.Filter, pkg/simulator/plugin/open-gpu-share.go:51-81 */
     if (p->gpu_mem > 0) {
         int64_t node_total = nd->gpu_mem_total ? nd->gpu_mem_total[j] : 0;
@@ -324,6 +435,14 @@ static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, sta
         int32_t num = p->gpu_cnt > 64 ? 64 : p->gpu_cnt;
         int got = gpu_allocate(nd, &s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV], j, p->gpu_mem, num, ids);
         for (int i = 0; i < got; i++) s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + ids[i]] += p->gpu_mem;
+    }
+    const simon_local_spec* lsp = with_gpu ? local_spec_of(tb, p->cls) : NULL;   /* LocalPlugin.Bind, open-local.go:180-253 */
+    if (lsp) {
+        local_units_t lu;
+        if (local_allocate(nd, s, lsp, j, &lu) == 0) {
+            for (int k = 0; k < lu.n_lvm; k++) s->vg_req[(size_t)j * SIMON_MAX_VG + lu.lvm_vg[k]] += lu.lvm_size[k];
+            for (int k = 0; k < lu.n_dev; k++) s->dev_alloc[j] |= 1 << lu.dev_idx[k];
+        }
     }
 }
 
@@ -440,6 +559,20 @@ static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb,
         }
     }
 
+    /* LocalPlugin.Score / NormalizeScore (open-local.go:93-166): raw 0..20, min-max over the feasible nodes */
+    const simon_local_spec* lsp = local_spec_of(tb, p->cls);
+    int64_t* lraw = NULL; int64_t l_lo = INT64_MAX, l_hi = -INT64_MAX;
+    if (lsp) {
+        lraw = xcalloc(n, 8);
+        for (int j = 0; j < n; j++) {
+            if (codes[j]) continue;
+            local_units_t lu;
+            local_allocate(nd, s, lsp, j, &lu);
+            lraw[j] = local_score(nd, j, &lu);
+            if (lraw[j] > l_hi) l_hi = lraw[j];
+            if (lraw[j] < l_lo) l_lo = lraw[j];
+        }
+    }
     int best = -1; int64_t best_total = 0;
     int64_t konst = tb && tb->const_score ? tb->const_score[p->cls] : 0;
     for (int j = 0; j < n; j++) {
@@ -475,10 +608,11 @@ static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb,
             else v = MAX_NODE_SCORE * (pts_max + pts_min - pts[j]) / pts_max;
             total += 2 * v;
         }
+        if (lsp) total += (l_hi - l_lo == 0) ? 0 : (lraw[j] - l_lo) * MAX_NODE_SCORE / (l_hi - l_lo);
         if (o_total) { o_la[j] = la; o_ba[j] = ba; o_sn[j] = sn; o_total[j] = total; }
         if (best < 0 || total > best_total) { best = j; best_total = total; }   /* first max */
     }
-    free(ipa); free(pts); free(ignored);
+    free(ipa); free(pts); free(ignored); free(lraw);
     return best;
 }
 
@@ -525,7 +659,7 @@ int simon_oracle_score_pod_after(const simon_nodes_soa* nodes, const simon_pods_
  * pod is deleted (state unchanged) and recorded; preset-NodeName pods bypass the scheduler and
  * reach the cache via addPodToCache (V/eventhandlers.go:223-236 -> AddPod). */
 static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, const simon_class_tables* tb,
-                        int n, const int32_t* order, int32_t* unscheduled, int64_t* used_cpu, int64_t* used_mem,
+                        int n, const int32_t* order, int32_t* unscheduled, int64_t* used_cpu, int64_t* used_mem, int64_t* used_vg,
                         int32_t* placement, int explain, int32_t* failed_pods, uint16_t* fail_codes,
                         int32_t max_failed, int32_t* n_failed_out) {
     int P = pd->n_pods, K = nd->n_scalar, T = tb ? tb->n_terms : 0;
@@ -558,9 +692,14 @@ static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, con
         add_pod(nd, tb, &s, &p, j, 1);
         if (placement) placement[pid] = j;
     }
-    int64_t uc = 0, um = 0;
-    for (int j = 0; j < n; j++) { uc += s.req_cpu[j]; um += s.req_mem[j]; }
+    int64_t uc = 0, um = 0, uv = 0;
+    for (int j = 0; j < n; j++) {
+        uc += s.req_cpu[j]; um += s.req_mem[j];
+        if (nd->local_flags && (nd->local_flags[j] & 1))
+            for (int v = 0; v < nd->local_vg_cnt[j]; v++) uv += s.vg_req[(size_t)j * SIMON_MAX_VG + v];
+    }
     *unscheduled = unsched; *used_cpu = uc; *used_mem = um;
+    if (used_vg) *used_vg = uv;
     if (n_failed_out && explain) *n_failed_out = unsched;
     free(codes);
     state_free(&s, T);
@@ -578,7 +717,7 @@ int simon_oracle_run(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
         const int32_t* ord = orders ? orders + (size_t)scen[s].order_id * P : NULL;
         int explain = (failed_pods && fail_codes && s == explain_scenario);
         int rc = run_scenario(nodes, pods, tables, scen[s].n_nodes, ord, &out->unscheduled[s], &out->used_cpu[s],
-                              &out->used_mem[s], out->placement ? out->placement + (size_t)s * P : NULL, explain,
+                              &out->used_mem[s], out->used_vg ? &out->used_vg[s] : NULL, out->placement ? out->placement + (size_t)s * P : NULL, explain,
                               failed_pods, fail_codes, max_failed, n_failed_out);
         if (rc) return rc;
     }

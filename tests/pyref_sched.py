@@ -31,6 +31,9 @@ class NodeInfo:
         self.gpu_total = parse_quantity(str(cap[k8s.GPU_MEM])).int_value() if k8s.GPU_MEM in cap else 0
         self.gpu_used = [0] * 8
         self.used_ports = {}                       # HostPortInfo: ip -> set of (protocol, port)  (V/framework/types.go:730-823)
+        st = fl.node_local_storage(node)           # utils.GetNodeCache (pkg/utils/utils.go:533-563): None = no annotation
+        self.storage = None if st is None else {"vgs": [{"name": n, "cap": c, "req": r} for n, c, r in st[0]],
+                                                "devs": [{"cap": c, "media": m, "alloc": a} for c, m, a in st[1]]}
 
     def add_pod(self, pod):
         for k, v in k8s.pod_request(pod).items():
@@ -96,6 +99,72 @@ def gpu_allocate(ni, mem, cnt):
     return ids if len(ids) == cnt else None
 
 
+# ---- Open-Local (pkg/simulator/plugin/open-local.go over open-local's algo/common.go), determinised: stable sorts --------
+def local_units(ni, vols):
+    """ProcessLVMPVCPredicate / ProcessLVMPVCPriority+Binpack (:59-144, :511-619) and ProcessDevicePVC (:394-449).
+    Returns None when the node does not fit, else (lvm_units [(vg index, size)], device_units [(device index, size)])."""
+    lvm, ssd, hdd = vols
+    st = ni.storage
+    lvm_units, dev_units = [], []
+    if lvm:
+        vgs = [dict(v) for v in st["vgs"]]                       # GetNodeVGMap: a copy
+        if not vgs:
+            return None
+        for size, name in lvm:
+            if name is not None:                                 # pvcsWithVG come first in `lvm`
+                idx = [i for i, v in enumerate(vgs) if v["name"] == name]
+                if not idx or vgs[idx[0]]["cap"] - vgs[idx[0]]["req"] < size:
+                    return None
+                pick = idx[0]
+            else:                                                # sort by free size ascending, first that fits
+                order = sorted(range(len(vgs)), key=lambda i: vgs[i]["cap"] - vgs[i]["req"])
+                fits = [i for i in order if vgs[i]["cap"] - vgs[i]["req"] >= size]
+                if not fits:
+                    return None
+                pick = fits[0]
+            vgs[pick]["req"] += size
+            lvm_units.append((pick, size))
+    if ssd or hdd:
+        for media, sizes in ((1, ssd), (2, hdd)):
+            free = [i for i, d in enumerate(st["devs"]) if d["media"] == media and not d["alloc"]]
+            if len(free) < len(sizes):
+                return None
+            free.sort(key=lambda i: st["devs"][i]["cap"])        # CheckExclusiveResourceMeetsPVCSize (:290-350)
+            i = 0
+            for k, d in enumerate(free):
+                if not sizes:
+                    break
+                if st["devs"][d]["cap"] < sizes[i]:
+                    if k == len(free) - 1:
+                        return None
+                    continue
+                dev_units.append((d, sizes[i]))
+                i += 1
+                if i == len(sizes):
+                    break
+    return lvm_units, dev_units
+
+
+def local_raw_score(ni, units):
+    """ScoreLVM (:660-692, Binpack) + ScoreDevice (:753-762); MaxScore = 10 (:34)."""
+    lvm_units, dev_units = units
+    score = 0
+    if lvm_units:
+        used = {}
+        for v, size in lvm_units:
+            used[v] = used.get(v, 0) + size
+        f = 0.0
+        for v in sorted(used):
+            f += float(used[v]) / float(ni.storage["vgs"][v]["cap"])
+        score += int(f / float(len(used)) * 10.0)
+    if dev_units:
+        f = 0.0
+        for d, size in dev_units:
+            f += float(size) / float(ni.storage["devs"][d]["cap"])
+        score += int(f / float(len(dev_units)) * 10.0)
+    return score
+
+
 def _terms(pod, which):
     return fl._affinity_terms(pod)[which]
 
@@ -105,9 +174,10 @@ def _matches(pod, namespaces, sel_json):
 
 
 class Scheduler:
-    def __init__(self, nodes, services=(), replicasets=(), statefulsets=()):
+    def __init__(self, nodes, services=(), replicasets=(), statefulsets=(), storage_classes=()):
         self.infos = [NodeInfo(n) for n in nodes]
         self.services, self.replicasets, self.statefulsets = list(services), list(replicasets), list(statefulsets)
+        self.storage_classes = list(storage_classes)
 
     # InterPodAffinity.PreFilter, interpodaffinity/filtering.go:166-274: three topologyPair -> count maps
     def _ipa_prefilter(self, pod):
@@ -208,6 +278,10 @@ class Scheduler:
         r = self._ipa_filter(pod, ni, ipa_st)
         if r:
             return r
+        vols = fl.pod_local_volumes(pod, self.storage_classes)       # LocalPlugin.Filter, plugin/open-local.go:51-91
+        if vols is not None:
+            if ni.storage is None or local_units(ni, vols) is None:
+                return "local"
         mem, cnt = fl._gpu_annotations(pod)
         if mem > 0:                                                # GpuSharePlugin.Filter, plugin/open-gpu-share.go:51-81
             if ni.gpu_total < mem or gpu_allocate(ni, mem, cnt) is None:
@@ -347,9 +421,15 @@ class Scheduler:
         tt_n = [MAX if tt_max == 0 else MAX - MAX * x // tt_max for x in tt]
         ipa = self._ipa_scores(pod, feasible)
         pts = self._pts_scores(pod, feasible, soft)
+        vols = fl.pod_local_volumes(pod, self.storage_classes)       # LocalPlugin.Score / NormalizeScore (:93-166)
+        local = [0] * len(feasible)
+        if vols is not None:
+            raw = [local_raw_score(ni, local_units(ni, vols)) for ni in feasible]
+            lo, hi = min(raw), max(raw)
+            local = [0 if hi == lo else (x - lo) * MAX // (hi - lo) for x in raw]
         best, best_total = None, None
         for i, ni in enumerate(feasible):
-            total = ba[i] + la[i] + 2 * sn[i] + ipa[i] + na_n[i] + 10000 * npa[i] + 2 * pts[i] + tt_n[i]
+            total = ba[i] + la[i] + 2 * sn[i] + ipa[i] + na_n[i] + 10000 * npa[i] + 2 * pts[i] + tt_n[i] + local[i]
             if best is None or total > best_total:
                 best, best_total = ni, total
         return best
@@ -372,6 +452,13 @@ class Scheduler:
             if mem > 0:
                 for d in gpu_allocate(ni, mem, cnt) or []:
                     ni.gpu_used[d] += mem
+            vols = fl.pod_local_volumes(pod, self.storage_classes)   # LocalPlugin.Bind (:180-253)
+            if vols is not None:
+                lvm_units, dev_units = local_units(ni, vols)
+                for v, size in lvm_units:
+                    ni.storage["vgs"][v]["req"] += size
+                for d, _ in dev_units:
+                    ni.storage["devs"][d]["alloc"] = True
             ni.add_pod(pod)
             out.append(ni.node["metadata"]["name"])
         return out

@@ -9,7 +9,21 @@ APPS = ["web", "db", "cache", "batch"]
 TIERS = ["fe", "be"]
 
 
-def rand_cluster(seed, n_nodes=12, n_workloads=10, gpu=False, max_replicas=6):
+GiB = 1 << 30
+# StorageClasses of the Open-Local cases: LVM without / with a VG name, SSD and HDD devices (names the plugin recognises,
+# pkg/utils/const.go:5-16)
+STORAGE_CLASSES = [
+    {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "open-local-lvm"}, "parameters": {"volumeType": "LVM"}},
+    {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "yoda-lvm-default"},
+     "parameters": {"volumeType": "LVM", "vgName": "pool1"}},
+    {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "open-local-device-ssd"},
+     "parameters": {"volumeType": "Device", "mediaType": "ssd"}},
+    {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "open-local-device-hdd"},
+     "parameters": {"volumeType": "Device", "mediaType": "hdd"}},
+]
+
+
+def rand_cluster(seed, n_nodes=12, n_workloads=10, gpu=False, max_replicas=6, local=False):
     rng = np.random.default_rng(seed)
     nodes = []
     for j in range(n_nodes):
@@ -34,6 +48,14 @@ def rand_cluster(seed, n_nodes=12, n_workloads=10, gpu=False, max_replicas=6):
             node["status"]["capacity"]["alibabacloud.com/gpu-count"] = str(cnt)
             node["status"]["capacity"]["alibabacloud.com/gpu-mem"] = f"{cnt * 16}Gi"
             node["status"]["allocatable"]["alibabacloud.com/gpu-count"] = str(cnt)
+        if local and rng.random() < 0.7:       # Open-Local storage annotation (simon/node-local-storage)
+            import json
+            vgs = [{"name": f"pool{v}", "capacity": str(int(rng.choice([50, 100, 100, 200])) * GiB),
+                    "requested": str(int(rng.choice([0, 0, 10])) * GiB)} for v in range(int(rng.integers(0, 4)))]
+            devs = [{"name": f"/dev/vd{chr(98 + d)}", "device": f"/dev/vd{chr(98 + d)}", "capacity": str(int(rng.choice([50, 100, 100, 200])) * GiB),
+                     "mediaType": str(rng.choice(["ssd", "hdd", "hdd"])), "isAllocated": str(rng.random() < 0.15).lower()}
+                    for d in range(int(rng.integers(0, 5)))]
+            node["metadata"]["annotations"] = {"simon/node-local-storage": json.dumps({"vgs": vgs, "devices": devs})}
         nodes.append(node)
 
     def selector(app=None, tier=None, expr=False):
@@ -112,6 +134,8 @@ def rand_cluster(seed, n_nodes=12, n_workloads=10, gpu=False, max_replicas=6):
             md["annotations"] = {"alibabacloud.com/gpu-mem": str(rng.choice(["2Gi", "4Gi", "8Gi"])),
                                  "alibabacloud.com/gpu-count": str(int(rng.choice([1, 1, 2])))}
         kind = str(rng.choice(["Deployment", "StatefulSet", "ReplicaSet", "Job", "Pod"]))
+        if local and rng.random() < 0.35:
+            kind = "StatefulSet"
         name = f"{app}-{tier}-{w}"
         if kind == "Pod":
             workloads.append({"apiVersion": "v1", "kind": "Pod", "metadata": dict(md, name=name, namespace=ns), "spec": spec})
@@ -122,6 +146,13 @@ def rand_cluster(seed, n_nodes=12, n_workloads=10, gpu=False, max_replicas=6):
         else:
             body["replicas"] = int(rng.integers(1, max_replicas + 1))
             body["selector"] = selector(app, tier)
+        if local and kind == "StatefulSet" and rng.random() < 0.8:      # volumeClaimTemplates on Open-Local StorageClasses
+            body["volumeClaimTemplates"] = [
+                {"metadata": {"name": f"v{k}"},
+                 "spec": {"storageClassName": str(rng.choice(["open-local-lvm", "open-local-lvm", "yoda-lvm-default", "open-local-device-ssd",
+                                                             "open-local-device-hdd"])),
+                          "resources": {"requests": {"storage": f"{int(rng.choice([5, 10, 20, 40, 60, 120]))}Gi"}}}}
+                for k in range(int(rng.integers(1, 4)))]
         workloads.append({"apiVersion": "apps/v1", "kind": kind, "metadata": {"name": name, "namespace": ns}, "spec": body})
         if rng.random() < 0.4:       # a Service selecting the app: default (system) spread constraints for its pods
             services.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": f"svc-{w}", "namespace": ns},
