@@ -110,7 +110,7 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_orders, d_perm;
     // outputs
     DevBuf<int32_t> d_unsched, d_place;
-    DevBuf<int64_t> d_used_cpu, d_used_mem;
+    DevBuf<int64_t> d_used_cpu, d_used_mem, d_used_vg;
     DevBuf<unsigned long long> d_plan;
     bool have_results = false, have_placement = false;
     simon_stats stats{};
@@ -429,6 +429,24 @@ int simon_load_nodes(simon_ctx* c, const simon_nodes_soa* nd) {
     copy_opt(c->i_gpu_used, nd->init_gpu_used, (size_t)N * SIMON_MAX_GPU_DEV);
     for (int j = 0; j < N; ++j)
         if (c->gpu_cnt[j] < 0 || c->gpu_cnt[j] > SIMON_MAX_GPU_DEV) return fail(c, SIMON_ERANGE, "node %d: gpu_cnt %d > %d", j, c->gpu_cnt[j], SIMON_MAX_GPU_DEV);
+    c->has_local = nd->local_flags != nullptr;
+    if (c->has_local) {
+        if (!nd->local_vg_cnt || !nd->local_vg_cap || !nd->local_vg_name || !nd->local_dev_cnt || !nd->local_dev_cap || !nd->local_dev_media)
+            return fail(c, SIMON_EINVAL, "Open-Local node arrays missing");
+        copy_opt(c->l_flags, nd->local_flags, N); copy_opt(c->l_vg_cnt, nd->local_vg_cnt, N);
+        copy_opt(c->l_vg_cap, nd->local_vg_cap, (size_t)N * SIMON_MAX_VG); copy_opt(c->l_vg_req, nd->init_vg_req, (size_t)N * SIMON_MAX_VG);
+        copy_opt(c->l_vg_name, nd->local_vg_name, (size_t)N * SIMON_MAX_VG); copy_opt(c->l_dev_cnt, nd->local_dev_cnt, N);
+        copy_opt(c->l_dev_cap, nd->local_dev_cap, (size_t)N * SIMON_MAX_LDEV); copy_opt(c->l_dev_media, nd->local_dev_media, N);
+        copy_opt(c->l_dev_alloc, nd->init_dev_alloc, N);
+        for (int j = 0; j < N; ++j) {
+            if (c->l_vg_cnt[j] < 0 || c->l_vg_cnt[j] > SIMON_MAX_VG || c->l_dev_cnt[j] < 0 || c->l_dev_cnt[j] > SIMON_MAX_LDEV)
+                return fail(c, SIMON_ERANGE, "node %d: more than %d volume groups or %d devices", j, SIMON_MAX_VG, SIMON_MAX_LDEV);
+            for (int v = 0; v < c->l_vg_cnt[j]; ++v)
+                if (c->l_vg_cap[(size_t)j * SIMON_MAX_VG + v] <= 0) return fail(c, SIMON_EINVAL, "node %d: volume group %d without capacity", j, v);
+            for (int d = 0; d < c->l_dev_cnt[j]; ++d)
+                if (c->l_dev_cap[(size_t)j * SIMON_MAX_LDEV + d] <= 0) return fail(c, SIMON_EINVAL, "node %d: device %d without capacity", j, d);
+        }
+    }
     copy_opt(c->topo_dom, nd->topo_dom, (size_t)c->Kt * N); copy_opt(c->topo_n_dom, nd->topo_n_dom, (size_t)c->Kt);
     for (int k = 0; k < c->Kt; ++k)
         for (int j = 0; j < N; ++j) {
@@ -478,6 +496,21 @@ int simon_load_class_tables(simon_ctx* c, const simon_class_tables* tb) {
     for (int64_t x : c->na_raw) if (x < 0 || x >= (1ll << 40)) return fail(c, SIMON_ERANGE, "node_affinity_raw outside [0, 2^40)");
     for (int64_t x : c->tt_raw) if (x < 0 || x >= (1ll << 40)) return fail(c, SIMON_ERANGE, "taint_prefer_raw outside [0, 2^40)");
     for (int64_t x : c->static_add) if (x < 0 || x >= (1ll << 30)) return fail(c, SIMON_ERANGE, "static_add outside [0, 2^30)");
+    c->l_spec_of.clear(); c->l_specs.clear();
+    if (tb->local_spec_of) {
+        if (!c->has_local) return fail(c, SIMON_ESTATE, "local_spec_of given but the nodes carry no Open-Local arrays");
+        if (tb->n_local_specs < 0 || (tb->n_local_specs > 0 && !tb->local_specs)) return fail(c, SIMON_EINVAL, "local_specs missing");
+        copy_opt(c->l_spec_of, tb->local_spec_of, (size_t)c->Cp);
+        c->l_specs.assign(tb->local_specs, tb->local_specs + tb->n_local_specs);
+        for (int32_t x : c->l_spec_of) if (x < -1 || x >= tb->n_local_specs) return fail(c, SIMON_EINVAL, "local_spec_of out of range");
+        for (const simon_local_spec& sp : c->l_specs) {
+            if (sp.n_lvm < 0 || sp.n_lvm > SIMON_MAX_LVOL || sp.n_ssd < 0 || sp.n_ssd > SIMON_MAX_LVOL || sp.n_hdd < 0 || sp.n_hdd > SIMON_MAX_LVOL)
+                return fail(c, SIMON_ERANGE, "more than %d Open-Local volumes of one kind", SIMON_MAX_LVOL);
+            for (int k = 0; k < sp.n_lvm; ++k) if (sp.lvm_size[k] <= 0) return fail(c, SIMON_EINVAL, "Open-Local volume size <= 0");
+            for (int k = 0; k < sp.n_ssd; ++k) if (sp.ssd_size[k] <= 0 || (k && sp.ssd_size[k] < sp.ssd_size[k - 1])) return fail(c, SIMON_EINVAL, "ssd_size must be positive and ascending");
+            for (int k = 0; k < sp.n_hdd; ++k) if (sp.hdd_size[k] <= 0 || (k && sp.hdd_size[k] < sp.hdd_size[k - 1])) return fail(c, SIMON_EINVAL, "hdd_size must be positive and ascending");
+        }
+    }
     c->Tm = tb->n_terms;
     if (c->Tm < 0) return fail(c, SIMON_EINVAL, "n_terms < 0");
     c->term_key.clear(); c->term_set.clear(); c->node_sets.clear(); c->R = 0;
@@ -593,6 +626,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     HIP_TRY(c, c->d_unsched.ensure(S));
     HIP_TRY(c, c->d_used_cpu.ensure(S));
     HIP_TRY(c, c->d_used_mem.ensure(S));
+    HIP_TRY(c, c->d_used_vg.ensure(S));
     HIP_TRY(c, c->d_plan.ensure(1));
     c->h_perm = perm;
     c->cache_perm_ok = false;
@@ -737,7 +771,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         T = c->force_T ? c->force_T : (c->max_n <= 1024 ? 256 : c->max_n <= 16384 ? 512 : 1024);
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
-                          c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p,
+                          c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p, c->d_used_vg.p,
                           want_placement ? c->d_place.p : nullptr, c->stream, c->err);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -766,6 +800,10 @@ int simon_fetch_results(simon_ctx* c, simon_batch_out* out) {
     if (out->unscheduled) HIP_TRY(c, hipMemcpyAsync(out->unscheduled, c->d_unsched.p, S * 4, hipMemcpyDeviceToHost, c->stream));
     if (out->used_cpu) HIP_TRY(c, hipMemcpyAsync(out->used_cpu, c->d_used_cpu.p, S * 8, hipMemcpyDeviceToHost, c->stream));
     if (out->used_mem) HIP_TRY(c, hipMemcpyAsync(out->used_mem, c->d_used_mem.p, S * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out->used_vg) {   // only the all-feature kernel tracks Open-Local volume groups
+        if (c->stats.kernel_variant == SIMON_KERNEL_WIDE) HIP_TRY(c, hipMemcpyAsync(out->used_vg, c->d_used_vg.p, S * 8, hipMemcpyDeviceToHost, c->stream));
+        else memset(out->used_vg, 0, S * 8);
+    }
     if (out->placement) {
         if (!c->have_placement) return fail(c, SIMON_ESTATE, "fetch_results: the last run skipped placements");
         HIP_TRY(c, hipMemcpyAsync(out->placement, c->d_place.p, S * P * 4, hipMemcpyDeviceToHost, c->stream));

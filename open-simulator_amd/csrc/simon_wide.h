@@ -38,9 +38,14 @@ struct HostInputs {
     std::vector<int32_t> sh_off, sh_idx, sh_skew, sh_self, sh_set, ss_off, ss_idx, ss_skew;
     std::vector<uint8_t> topo_is_hostname;
     std::vector<double> spread_log;
+    // Open-Local
+    bool has_local = false;
+    std::vector<int32_t> l_flags, l_vg_cnt, l_vg_name, l_dev_cnt, l_dev_media, l_dev_alloc, l_spec_of;
+    std::vector<int64_t> l_vg_cap, l_vg_req, l_dev_cap;
+    std::vector<simon_local_spec> l_specs;
     bool has_ipa_score = false;   // any pref_* or own_* entry exists
     bool v2_features() const {
-        return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || !port_idx.empty();
+        return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || !port_idx.empty() || has_local;
     }
 };
 
@@ -70,6 +75,7 @@ constexpr uint32_t kPodHard = 4u;      // class has DoNotSchedule spread constra
 constexpr uint32_t kPodSoft = 8u;      // class has ScheduleAnyway spread constraints
 constexpr uint32_t kPodIpa = 16u;      // InterPodAffinity.Score can be non-zero for this class
 constexpr uint32_t kPodPorts = 32u;    // class binds host ports (NodePorts filter)
+constexpr uint32_t kPodLocal = 64u;    // class requests Open-Local volumes
 
 struct WideScenario {
     int32_t n_nodes, order_id;
@@ -100,6 +106,11 @@ struct WideCold {
     const int32_t* sh_first_reg /*[E][N]: lowest eligible node index sharing node j's domain, INT_MAX if none*/;
     const int32_t* ss_off; const int32_t* ss_idx; const int32_t* ss_skew;
     const uint8_t* topo_is_hostname; const double* spread_log; const int32_t* key_seen_off /*[Kt]*/;
+    // Open-Local: node storage (static) and per-class volume specs
+    const int32_t* l_flags; const int32_t* l_vg_cnt; const int64_t* l_vg_cap; const int32_t* l_vg_name; const int64_t* i_vg_req;
+    const int32_t* l_dev_cnt; const int64_t* l_dev_cap; const int32_t* l_dev_media; const int32_t* i_dev_alloc;
+    const int32_t* l_spec_of; const simon_local_spec* l_specs;
+    int64_t* st_vg /*[S][N][SIMON_MAX_VG]*/; int32_t* st_dev /*[S][N]*/;
     // per-scenario mutable state of the optional features, [S_chunk][...]
     int64_t* st_req_eph; int64_t* st_nz_cpu; int64_t* st_nz_mem;
     int64_t* st_scalar /*[S][K][N]*/; int64_t* st_gpu /*[S][N][8]*/;
@@ -125,11 +136,11 @@ struct WideArgs {
     int64_t* st_req_cpu; int64_t* st_req_mem; int32_t* st_npods;
     unsigned char* st_tab /*[S][n_sigs][tab_nstride]*/;
     // outputs of this chunk
-    int32_t* unscheduled; int64_t* used_cpu; int64_t* used_mem; int32_t* placement /*[S][P] or null*/;
+    int32_t* unscheduled; int64_t* used_cpu; int64_t* used_mem; int64_t* used_vg /*or null*/; int32_t* placement /*[S][P] or null*/;
     const WideCold* cold;
 };
 constexpr uint32_t kArgGpu = 1u, kArgMask = 2u, kArgEph = 4u, kArgNzeq = 8u, kArgClassMode = 16u /*Cn <= 64*/,
-                   kArgKey32 = 32u /*32-bit arg-max key*/, kArgProf = 64u, kArgTerms = 128u /*Tm > 0*/;
+                   kArgKey32 = 32u /*32-bit arg-max key*/, kArgProf = 64u, kArgTerms = 128u /*Tm > 0*/, kArgLocal = 256u /*Open-Local*/;
 
 struct WideDevice {
     void* blobs[80] = {};
@@ -156,6 +167,10 @@ struct WideDevice {
     WidePod* pods = nullptr;
     WideSig* sigs = nullptr;
     int n_sigs = 0;
+    int32_t *l_flags = nullptr, *l_vg_cnt = nullptr, *l_vg_name = nullptr, *l_dev_cnt = nullptr, *l_dev_media = nullptr,
+            *i_dev_alloc = nullptr, *l_spec_of = nullptr, *st_dev = nullptr;
+    int64_t *l_vg_cap = nullptr, *i_vg_req = nullptr, *l_dev_cap = nullptr, *st_vg = nullptr;
+    simon_local_spec* l_specs = nullptr;
     WideCold* d_cold = nullptr;   // two slots: [0] batch runs, [1] explain
     unsigned char* st_tab = nullptr;
     // state
@@ -169,7 +184,7 @@ struct WideDevice {
 int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string& err);
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t* h_perm_unused, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
-             int32_t* d_place, hipStream_t st, std::string& err);
+             int64_t* d_used_vg, int32_t* d_place, hipStream_t st, std::string& err);
 int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
                  uint16_t* fail_codes, int32_t max_failed, int T, hipStream_t st, std::string& err);
 

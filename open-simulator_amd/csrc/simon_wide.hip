@@ -42,7 +42,7 @@ namespace {
 #define COLD(A) COLDP((A).cold)
 
 constexpr int kMaxIter = 32;  // nodes per lane: n <= 32 * T
-constexpr int kRed = 11;      // values of one workgroup reduction
+constexpr int kRed = 13;      // values of one workgroup reduction
 
 struct NodeView {  // pointers of ONE scenario's state: the hot ones held, the feature ones derived on use
     int64_t *req_cpu, *req_mem;
@@ -60,6 +60,8 @@ struct NodeView {  // pointers of ONE scenario's state: the hot ones held, the f
     __device__ __forceinline__ int32_t* cnt_owner() const { return cnt_match() + COLDP(Cg)->total_dom; }
     __device__ __forceinline__ int32_t* w_owner() const { return cnt_match() + 2 * COLDP(Cg)->total_dom; }
     __device__ __forceinline__ int32_t* term_total() const { return cnt_match() + 3 * COLDP(Cg)->total_dom; }
+    __device__ __forceinline__ int64_t* st_vg() const { return COLDP(Cg)->st_vg + (size_t)s * N * SIMON_MAX_VG; }
+    __device__ __forceinline__ int32_t* st_dev() const { return COLDP(Cg)->st_dev + (size_t)s * N; }
     __device__ __forceinline__ int32_t* seen() const { return COLDP(Cg)->st_seen + (size_t)s * (COLDP(Cg)->seen_stride > 0 ? COLDP(Cg)->seen_stride : 1); }
 };
 
@@ -76,19 +78,20 @@ __device__ __forceinline__ long long wave_sum_i64w(long long v) {
     return v;
 }
 
-// Workgroup reduction of r[0..cm) by max and r[cm..cm+cs) by sum; every thread gets the result.
+// Workgroup reduction of r[0..cm) by max and r[c0..c0+cs) by sum (c0 >= cm; slots in between are left alone);
+// every thread gets the result.
 // mb is one of two alternating mailboxes (a stage's mailbox is rewritten only two barriers later).
 template <int NW>
-__device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int cs, long long (*mb)[kRed], int wave, int lane) {
+__device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, int cs, long long (*mb)[kRed], int wave, int lane) {
 #pragma unroll
     for (int k = 0; k < kRed; ++k) {
         if (k < cm) r[k] = wave_max_i64(r[k]);
-        else if (k < cm + cs) r[k] = wave_sum_i64w(r[k]);
+        else if (k >= c0 && k < c0 + cs) r[k] = wave_sum_i64w(r[k]);
     }
     if (NW > 1) {
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < kRed; ++k) if (k < cm + cs) mb[wave][k] = r[k];
+            for (int k = 0; k < kRed; ++k) if (k < cm || (k >= c0 && k < c0 + cs)) mb[wave][k] = r[k];
         }
         __syncthreads();
 #pragma unroll
@@ -97,7 +100,7 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int cs, 
                 long long m = mb[0][k];
                 for (int w = 1; w < NW; ++w) m = mb[w][k] > m ? mb[w][k] : m;
                 r[k] = m;
-            } else if (k < cm + cs) {
+            } else if (k >= c0 && k < c0 + cs) {
                 long long m = 0;
                 for (int w = 0; w < NW; ++w) m += mb[w][k];
                 r[k] = m;
@@ -268,6 +271,105 @@ __device__ __forceinline__ unsigned base_score(const Q& q, const NodeLoads& L) {
     return (unsigned)((la_c + la_m) / 2 + ba);
 }
 
+// Open-Local on one node (pkg/simulator/plugin/open-local.go:51-254 over open-local's algo/common.go), determinised like
+// the oracle: equal free sizes / capacities keep annotation order, float sums run in volume-group resp. assignment order.
+//   filter  ProcessLVMPVCPredicate (:59-144) + ProcessDevicePVC (:394-449, CheckExclusiveResourceMeetsPVCSize :290-350)
+//   score   ScoreLVM (Binpack, :660-692) + ScoreDevice (:753-762), MaxScore 10
+//   COMMIT  LocalPlugin.Bind: Requested of the chosen volume groups, IsAllocated of the chosen devices
+struct LocalEval { unsigned code; int score; };
+template <bool COMMIT>
+__device__ LocalEval local_eval(const WideArgs& A, const NodeView& v, const WidePod& p, int j) {
+    const simon_local_spec sp = COLD(A)->l_specs[COLD(A)->l_spec_of[p.cls]];
+    LocalEval out{0u, 0};
+    if (!(COLD(A)->l_flags[j] & 1)) { out.code = SIMON_FAIL_LOCAL; return out; }
+    if (sp.n_lvm > 0) {
+        const int nvg = COLD(A)->l_vg_cnt[j];
+        if (nvg <= 0) { out.code = SIMON_FAIL_LOCAL_LVM; return out; }            // NewNoAvailableVGError (:109-111)
+        int64_t* vg = v.st_vg() + (size_t)j * SIMON_MAX_VG;
+        long long cap[SIMON_MAX_VG], req[SIMON_MAX_VG], used[SIMON_MAX_VG];
+        int name[SIMON_MAX_VG];
+#pragma unroll
+        for (int q = 0; q < SIMON_MAX_VG; ++q) {
+            cap[q] = COLD(A)->l_vg_cap[(size_t)j * SIMON_MAX_VG + q]; req[q] = vg[q]; used[q] = -1;
+            name[q] = COLD(A)->l_vg_name[(size_t)j * SIMON_MAX_VG + q];
+        }
+#pragma unroll
+        for (int k = 0; k < SIMON_MAX_LVOL; ++k) {
+            if (k >= sp.n_lvm) continue;
+            const long long size = sp.lvm_size[k];
+            const int want = sp.lvm_vg[k];
+            int pick = -1;
+            long long pick_free = 0;
+#pragma unroll
+            for (int q = 0; q < SIMON_MAX_VG; ++q) {
+                if (q >= nvg) continue;
+                const long long fr = cap[q] - req[q];
+                if (want >= 0) {                                                    // PVC whose StorageClass names the VG (:66-97)
+                    if (pick < 0 && name[q] == want) { pick = q; pick_free = fr; }
+                } else if (fr >= size && (pick < 0 || fr < pick_free)) {            // smallest free size that fits (:113-141)
+                    pick = q; pick_free = fr;
+                }
+            }
+            if (pick < 0 || pick_free < size) { out.code = SIMON_FAIL_LOCAL_LVM; return out; }
+#pragma unroll
+            for (int q = 0; q < SIMON_MAX_VG; ++q)
+                if (q == pick) { req[q] += size; used[q] = (used[q] < 0 ? 0 : used[q]) + size; }
+        }
+        double f = 0.0;
+        int count = 0;
+#pragma unroll
+        for (int q = 0; q < SIMON_MAX_VG; ++q)
+            if (used[q] >= 0) { f += (double)used[q] / (double)cap[q]; ++count; }   // scoreMap: one entry per VG that got a unit
+        out.score += (int)(f / (double)count * 10.0);
+        if (COMMIT) {
+#pragma unroll
+            for (int q = 0; q < SIMON_MAX_VG; ++q) if (q < nvg) vg[q] = req[q];
+        }
+    }
+    if (sp.n_ssd + sp.n_hdd > 0) {
+        const int cnt = COLD(A)->l_dev_cnt[j], media = COLD(A)->l_dev_media[j];
+        int* alloc_p = v.st_dev() + j;
+        const int alloc = *alloc_p;
+        long long dcap[SIMON_MAX_LDEV];
+#pragma unroll
+        for (int d = 0; d < SIMON_MAX_LDEV; ++d) dcap[d] = COLD(A)->l_dev_cap[(size_t)j * SIMON_MAX_LDEV + d];
+        double f = 0.0;
+        int ndev = 0, newly = 0;
+#pragma unroll
+        for (int m = 1; m <= 2; ++m) {                                              // SSD first, then HDD (:409-447)
+            const int n_pvc = m == 1 ? sp.n_ssd : sp.n_hdd;
+            unsigned free_mask = 0;
+#pragma unroll
+            for (int d = 0; d < SIMON_MAX_LDEV; ++d)
+                if (d < cnt && ((media >> (2 * d)) & 3) == m && !((alloc >> d) & 1)) free_mask |= 1u << d;   // GetFreeDevice (:367-383)
+            const int nfree = __popc(free_mask);
+            if (nfree < n_pvc) { out.code = SIMON_FAIL_LOCAL_DEV; return out; }
+            int i = 0;
+            for (int step = 0; step < nfree && n_pvc > 0; ++step) {                // devices ascending by (capacity, index)
+                int d = -1;
+                long long c = 0;
+#pragma unroll
+                for (int e = 0; e < SIMON_MAX_LDEV; ++e)
+                    if (((free_mask >> e) & 1u) && (d < 0 || dcap[e] < c)) { d = e; c = dcap[e]; }
+                free_mask &= ~(1u << d);
+                const long long size = m == 1 ? (i == 0 ? sp.ssd_size[0] : i == 1 ? sp.ssd_size[1] : i == 2 ? sp.ssd_size[2] : sp.ssd_size[3])
+                                              : (i == 0 ? sp.hdd_size[0] : i == 1 ? sp.hdd_size[1] : i == 2 ? sp.hdd_size[2] : sp.hdd_size[3]);
+                if (c < size) {
+                    if (step == nfree - 1) { out.code = SIMON_FAIL_LOCAL_DEV; return out; }   // only the last device can fail the match
+                    continue;
+                }
+                f += (double)size / (double)c;
+                ++ndev;
+                newly |= 1 << d;
+                if (++i == n_pvc) break;
+            }
+        }
+        if (ndev > 0) out.score += (int)(f / (double)ndev * 10.0);
+        if (COMMIT) *alloc_p = alloc | newly;
+    }
+    return out;
+}
+
 // NodePorts.Filter (nodeports/node_ports.go:104-127): a conflicting (hostIP, protocol, hostPort) term counts a pod on the node
 __device__ __forceinline__ bool ports_conflict(const WideArgs& A, const NodeView& v, const WidePod& p, int j) {
     for (int e = COLD(A)->port_off[p.cls]; e < COLD(A)->port_off[p.cls + 1]; ++e) {
@@ -333,6 +435,10 @@ __device__ __forceinline__ unsigned rest_code(const WideArgs& A, const NodeView&
             if (d >= 0 && v.cnt_owner()[COLD(A)->term_dom_off[t] + d] > 0) return SIMON_FAIL_ANTI_EXISTING;
         }
     }
+    if (p.flags & kPodLocal) {                                                     // Open-Local.Filter
+        const unsigned lc = local_eval<false>(A, v, p, j).code;
+        if (lc) return lc;
+    }
     // Open-Gpu-Share.Filter, pkg/simulator/plugin/open-gpu-share.go:51-81
     if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0) {
         const long long gt = COLD(A)->gpu_mem_total[j];
@@ -381,14 +487,14 @@ __device__ __forceinline__ long long pts_raw(const WideArgs& A, const NodeView& 
     return (long long)score;
 }
 
-template <int T, bool EXPLAIN>
+template <int T, bool EXPLAIN, bool LOCAL>
 __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     constexpr int NW = T / 64;
     __shared__ long long mbox[2][NW][kRed];
     __shared__ unsigned long long mbK[2][NW];
     __shared__ unsigned long long mbO[2][NW];
     __shared__ unsigned mbC[2][NW][8];
-    __shared__ long long red[2][NW];
+    __shared__ long long red[3][NW];
     // dynamic LDS: [max_n] u32 (base | node class << 16), then, in class mode, two alternating copies of the pod
     // class's rows of the four (pod class, node class) tables as int64 [4][Cn]
     extern __shared__ __attribute__((aligned(16))) unsigned s_bc[];
@@ -422,6 +528,13 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
             for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d)
                 v.gpu()[(size_t)j * SIMON_MAX_GPU_DEV + d] = COLD(A)->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d];
     }
+    if (LOCAL && (A.flags & kArgLocal)) {
+        for (int j = tid; j < n; j += T) {
+#pragma unroll
+            for (int q = 0; q < SIMON_MAX_VG; ++q) v.st_vg()[(size_t)j * SIMON_MAX_VG + q] = COLD(A)->i_vg_req[(size_t)j * SIMON_MAX_VG + q];
+            v.st_dev()[j] = COLD(A)->i_dev_alloc[j];
+        }
+    }
     for (int i = tid; i < cnt_stride; i += T) v.cnt_match()[i] = 0;
     for (int i = tid; i < COLD(A)->seen_stride; i += T) v.seen()[i] = 0;
     __syncthreads();
@@ -445,7 +558,8 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     for (int i = 0; i < P; ++i) {
         const int pid = next_pid;
         next_pid = (i + 1 < P) ? order[i + 1] : 0;
-        const WidePod p = A.pods[pid];
+        WidePod p = A.pods[pid];
+        if (!LOCAL) p.flags &= ~kPodLocal;          // the Open-Local code folds away in the variant for problems without it
         if ((A.flags & kArgProf) && p.cls < 0) continue;   // forces the pod row to have arrived before the timestamp
         SIMON_PROF(0);
         if (p.gate >= n) { if (place && tid == 0) place[pid] = SIMON_GATED; continue; }
@@ -501,25 +615,27 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                         r[q] = c > r[q] ? c : r[q];
                     }
                 }
-                wg_reduce<NW>(r, cnt, 0, mbox[buf], wave, lane);
+                wg_reduce<NW>(r, cnt, cnt, 0, mbox[buf], wave, lane);
                 buf ^= 1;
                 hard_min = Hard4{-r[0], -r[1], -r[2], -r[3]};
             }
             // ---------------- stage A: filter + base score + reductions --------------------------------
             const bool ipa = p.flags & kPodIpa;
             const bool soft = p.flags & kPodSoft;
-            const bool extras = ipa || soft || !class_mode;
-            const bool has_rest = (p.flags & (kPodHard | kPodTerms | kPodPorts)) || (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0);
+            const bool local = p.flags & kPodLocal;
+            const bool extras = ipa || soft || local || !class_mode;
+            const bool has_rest = (p.flags & (kPodHard | kPodTerms | kPodPorts | kPodLocal)) || (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0);
             const int slo = soft ? COLD(A)->ss_off[p.cls] : 0, n_soft = soft ? COLD(A)->ss_off[p.cls + 1] - slo : 0;
             unsigned feas = 0, ign = 0;
             unsigned long long cmask = 0;
             long long lo = 0x7fffffffffffffffll, hi = -0x7fffffffffffffffll, na_max = 0, tt_max = 0, ipa_min = 0, ipa_max = 0;
             long long scored = 0, dst0 = 0, dst1 = 0, dst2 = 0, dst3 = 0;
+            long long l_lo = 0x7fffffffffffffffll, l_hi = -0x7fffffffffffffffll;    // LocalPlugin.NormalizeScore (open-local.go:149-159)
             // bookkeeping of one feasible node (shared by both evaluation paths)
             // Single-pass cycle: with <= 8 node classes and no per-node normalised plugin, the best node of a class is
             // the first maximum of the base score inside the class (the class terms are constant there), so ONE
             // reduction of per-class keys replaces stage B and its barrier.
-            const bool fast1 = class_mode && Cn <= 8 && ((A.flags & kArgKey32) != 0u) && !ipa && !soft;
+            const bool fast1 = class_mode && Cn <= 8 && ((A.flags & kArgKey32) != 0u) && !ipa && !soft && !local;
             unsigned kc0 = 0, kc1 = 0, kc2 = 0, kc3 = 0, kc4 = 0, kc5 = 0, kc6 = 0, kc7 = 0;
             auto on_feasible = [&](int j, int it, unsigned base, int nc) {
                 if (fast1) {
@@ -545,6 +661,11 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                     const long long x = ipa_raw(A, v, p, j);
                     ipa_max = x > ipa_max ? x : ipa_max;
                     ipa_min = x < ipa_min ? x : ipa_min;
+                }
+                if (local) {
+                    const long long x = local_eval<false>(A, v, p, j).score;
+                    l_hi = x > l_hi ? x : l_hi;
+                    l_lo = x < l_lo ? x : l_lo;
                 }
                 if (soft) {   // initPreScoreState, podtopologyspread/scoring.go:60-108
                     bool ignored = false;
@@ -629,6 +750,11 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                                 for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
                             }
                         }
+                        if (p.flags & kPodLocal) {                                                                // open-local.go:51-91
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u)
+                                if (act[u] && local_eval<false>(A, v, p, jn[u]).code != 0u) act[u] = false;
+                        }
                         if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0) {                                       // open-gpu-share.go:51-81
                             long long gt[kUT];
                             int gc[kUT];
@@ -666,7 +792,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                     }
                 }
             }
-            const int cm = 6, cs = soft ? 1 + n_soft : 0;
+            const int cm = 8, cs = soft ? 1 + n_soft : 0;      // sums start at slot 8; max slots: 4 base, +2 InterPodAffinity, +2 Open-Local
             SIMON_PROF(5);
             if (refill && tid < Cn) {   // publish the class rows before the stage-A barrier
                 s_rows[tid] = rv0; s_rows[Cn + tid] = rv1; s_rows[2 * Cn + tid] = rv2; s_rows[3 * Cn + tid] = rv3;
@@ -724,10 +850,12 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                 }
                 if (extras) {
                     r[0] = -lo; r[1] = hi; r[2] = na_max; r[3] = tt_max; r[4] = -ipa_min; r[5] = ipa_max;
-                    r[6] = scored; r[7] = dst0; r[8] = dst1; r[9] = dst2; r[10] = dst3;
-                    wg_reduce<NW>(r, cm, cs, mbox[buf], wave, lane);
+                    r[6] = -l_lo; r[7] = l_hi;
+                    r[8] = scored; r[9] = dst0; r[10] = dst1; r[11] = dst2; r[12] = dst3;
+                    wg_reduce<NW>(r, local ? 8 : ipa ? 6 : 4, cm, cs, mbox[buf], wave, lane);
                     buf ^= 1;
                     lo = -r[0]; hi = r[1]; na_max = r[2]; tt_max = r[3]; ipa_min = -r[4]; ipa_max = r[5];
+                    l_lo = -r[6]; l_hi = r[7];
                 } else if (NW > 1) {
                     __syncthreads();
                 }
@@ -788,7 +916,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                         pts_max = x > pts_max ? x : pts_max;
                     }
                     r[0] = -pts_min; r[1] = pts_max;
-                    wg_reduce<NW>(r, 2, 0, mbox[buf], wave, lane);
+                    wg_reduce<NW>(r, 2, 2, 0, mbox[buf], wave, lane);
                     buf ^= 1;
                     pts_min = -r[0]; pts_max = r[1];
                 }
@@ -821,7 +949,9 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                     if (valid) {
                         if (ipa && ipa_diff > 0)                   // interpodaffinity/scoring.go:258-271
                             total += (long long)(100.0 * ((double)(ipa_raw(A, v, p, j) - ipa_min) / (double)ipa_diff));
-                        if (soft) {                                // podtopologyspread/scoring.go:217-256, weight 2
+                        if (local && l_hi != l_lo)                 // open-local.go:155-163
+                        total += divq((local_eval<false>(A, v, p, j).score - l_lo) * 100, l_hi - l_lo);
+                    if (soft) {                                // podtopologyspread/scoring.go:217-256, weight 2
                             long long x;
                             if ((ign >> it) & 1u) x = 0;
                             else if (pts_max == 0) x = 100;
@@ -895,6 +1025,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                 }
                 // Open-Gpu-Share Reserve (open-gpu-share.go:147-188): commit the device ids; preset
                 // pods carry no gpu-index annotation here and are not accounted
+                if ((p.flags & kPodLocal) && p.preset < 0) (void)local_eval<true>(A, v, p, j);      // LocalPlugin.Bind (open-local.go:180-253)
                 if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.preset < 0)
                     gpu_commit(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j], p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt);
                 if (place) place[pid] = j;
@@ -914,18 +1045,23 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     if ((A.flags & kArgProf) && lane == 0)
         for (int k = 0; k < 6; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 8 + k] = pf[k];
 
-    long long uc = 0, um = 0;
-    for (int j = tid; j < n; j += T) { uc += v.req_cpu[j]; um += v.req_mem[j]; }
-    uc = wave_sum_i64w(uc); um = wave_sum_i64w(um);
+    long long uc = 0, um = 0, uv = 0;
+    for (int j = tid; j < n; j += T) {
+        uc += v.req_cpu[j]; um += v.req_mem[j];
+        if (LOCAL && (A.flags & kArgLocal) && (COLD(A)->l_flags[j] & 1))
+            for (int q = 0; q < COLD(A)->l_vg_cnt[j]; ++q) uv += v.st_vg()[(size_t)j * SIMON_MAX_VG + q];
+    }
+    uc = wave_sum_i64w(uc); um = wave_sum_i64w(um); uv = wave_sum_i64w(uv);
     __syncthreads();
-    if (lane == 0) { red[0][wave] = uc; red[1][wave] = um; }
+    if (lane == 0) { red[0][wave] = uc; red[1][wave] = um; red[2][wave] = uv; }
     __syncthreads();
     if (tid == 0) {
-        uc = 0; um = 0;
-        for (int w = 0; w < NW; ++w) { uc += red[0][w]; um += red[1][w]; }
+        uc = 0; um = 0; uv = 0;
+        for (int w = 0; w < NW; ++w) { uc += red[0][w]; um += red[1][w]; uv += red[2][w]; }
         A.unscheduled[s] = unsched;
         A.used_cpu[s] = uc;
         A.used_mem[s] = um;
+        if (A.used_vg) A.used_vg[s] = uv;
         if (EXPLAIN) *COLD(A)->n_failed = unsched;
     }
 }
@@ -935,14 +1071,18 @@ hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
     dim3 grid(a.S);
     const size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 : 0);
     (void)max_n;
+#define WIDE_LAUNCH(TT)                                                                                   \
+    if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, true>), grid, dim3(TT), lds, st, a); \
+    else hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, false>), grid, dim3(TT), lds, st, a)
     switch (T) {
-        case 64: hipLaunchKernelGGL((wide_kernel<64, EXPLAIN>), grid, dim3(64), lds, st, a); break;
-        case 128: hipLaunchKernelGGL((wide_kernel<128, EXPLAIN>), grid, dim3(128), lds, st, a); break;
-        case 256: hipLaunchKernelGGL((wide_kernel<256, EXPLAIN>), grid, dim3(256), lds, st, a); break;
-        case 512: hipLaunchKernelGGL((wide_kernel<512, EXPLAIN>), grid, dim3(512), lds, st, a); break;
-        case 1024: hipLaunchKernelGGL((wide_kernel<1024, EXPLAIN>), grid, dim3(1024), lds, st, a); break;
+        case 64: WIDE_LAUNCH(64); break;
+        case 128: WIDE_LAUNCH(128); break;
+        case 256: WIDE_LAUNCH(256); break;
+        case 512: WIDE_LAUNCH(512); break;
+        case 1024: WIDE_LAUNCH(1024); break;
         default: return hipErrorInvalidValue;
     }
+#undef WIDE_LAUNCH
     return hipGetLastError();
 }
 
@@ -969,7 +1109,8 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     a.N = in.N; a.P = in.P; a.K = in.K; a.Cn = in.Cn;
     a.mask_words = (in.N + 63) / 64;
     a.flags = (in.has_gpu ? kArgGpu : 0u) | (in.has_mask ? kArgMask : 0u) | (w.has_eph ? kArgEph : 0u) | (w.nzeq ? kArgNzeq : 0u) |
-              (in.Cn <= 64 ? kArgClassMode : 0u) | (!in.has_add ? kArgKey32 : 0u) | (in.Tm > 0 ? kArgTerms : 0u);
+              (in.Cn <= 64 ? kArgClassMode : 0u) | (!in.has_add ? kArgKey32 : 0u) | (in.Tm > 0 ? kArgTerms : 0u) |
+              (in.has_local ? kArgLocal : 0u);
     a.alloc_cpu = w.alloc_cpu; a.alloc_mem = w.alloc_mem; a.alloc_pods = w.alloc_pods; a.node_class = w.node_class;
     a.static_mask = w.static_mask; a.simon_raw = w.simon_raw;
     a.pods = w.pods; a.sigs = w.sigs; a.n_sigs = w.n_sigs; a.tab_nstride = (in.N + 63) & ~63;
@@ -994,22 +1135,25 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     c.topo_is_hostname = w.topo_is_hostname; c.spread_log = w.spread_log; c.key_seen_off = w.key_seen_off;
     c.st_req_eph = w.st_req_eph; c.st_nz_cpu = w.st_nz_cpu; c.st_nz_mem = w.st_nz_mem; c.st_scalar = w.st_scalar;
     c.st_gpu = w.st_gpu; c.st_cnt = w.st_cnt; c.st_seen = w.st_seen;
+    c.l_flags = w.l_flags; c.l_vg_cnt = w.l_vg_cnt; c.l_vg_cap = w.l_vg_cap; c.l_vg_name = w.l_vg_name; c.i_vg_req = w.i_vg_req;
+    c.l_dev_cnt = w.l_dev_cnt; c.l_dev_cap = w.l_dev_cap; c.l_dev_media = w.l_dev_media; c.i_dev_alloc = w.i_dev_alloc;
+    c.l_spec_of = w.l_spec_of; c.l_specs = w.l_specs; c.st_vg = w.st_vg; c.st_dev = w.st_dev;
 }
 
 size_t state_bytes_per_scenario(const WideDevice& w, const HostInputs& in) {
     const size_t N = in.N;
     return N * (5 * 8 + 4) + (size_t)std::max(in.K, 1) * N * 8 + (in.has_gpu ? N * SIMON_MAX_GPU_DEV * 8 : 8) +
            (size_t)std::max(3 * w.total_dom + in.Tm, 1) * 4 + (size_t)std::max(w.seen_stride, 1) * 4 +
-           (size_t)std::max(w.n_sigs, 1) * ((N + 63) & ~(size_t)63);
+           (size_t)std::max(w.n_sigs, 1) * ((N + 63) & ~(size_t)63) + (in.has_local ? N * (SIMON_MAX_VG * 8 + 4) : 16);
 }
 
 void** state_slots(WideDevice& w, int i) {
     void** slots[] = {(void**)&w.st_req_cpu, (void**)&w.st_req_mem, (void**)&w.st_req_eph, (void**)&w.st_nz_cpu,
                       (void**)&w.st_nz_mem, (void**)&w.st_npods, (void**)&w.st_scalar, (void**)&w.st_gpu, (void**)&w.st_cnt,
-                      (void**)&w.st_seen, (void**)&w.st_tab};
+                      (void**)&w.st_seen, (void**)&w.st_tab, (void**)&w.st_vg, (void**)&w.st_dev};
     return slots[i];
 }
-constexpr int kStateSlots = 11;
+constexpr int kStateSlots = 13;
 
 int ensure_state(WideDevice& w, const HostInputs& in, int chunk, std::string& err) {
     if (chunk <= w.state_chunk) return 0;
@@ -1020,7 +1164,8 @@ int ensure_state(WideDevice& w, const HostInputs& in, int chunk, std::string& er
                                        C * (in.has_gpu ? N * SIMON_MAX_GPU_DEV * 8 : 8),
                                        C * (size_t)std::max(3 * w.total_dom + in.Tm, 1) * 4,
                                        C * (size_t)std::max(w.seen_stride, 1) * 4,
-                                       C * (size_t)std::max(w.n_sigs, 1) * ((N + 63) & ~(size_t)63)};
+                                       C * (size_t)std::max(w.n_sigs, 1) * ((N + 63) & ~(size_t)63),
+                                       C * (in.has_local ? N * SIMON_MAX_VG * 8 : 8), C * (in.has_local ? N * 4 : 8)};
     for (int i = 0; i < kStateSlots; ++i) {
         hipError_t e = hipMalloc(state_slots(w, i), sizes[i]);
         if (e != hipSuccess) { err = std::string("hipMalloc(state): ") + hipGetErrorString(e); return SIMON_ENOMEM; }
@@ -1125,6 +1270,10 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         if (in.Tm > 0 && (some(match_off) || some(anti_off) || some(aff_off) || some(own_off))) r.flags |= kPodTerms;
         if (some(sh_off)) r.flags |= kPodHard;
         if (in.Tm > 0 && some(port_off)) r.flags |= kPodPorts | kPodTerms;
+        if (in.has_local && !in.l_spec_of.empty() && in.l_spec_of[c] >= 0) {
+            const simon_local_spec& sp = in.l_specs[in.l_spec_of[c]];
+            if (sp.n_lvm + sp.n_ssd + sp.n_hdd > 0) r.flags |= kPodLocal;
+        }
         if (some(ss_off)) r.flags |= kPodSoft;
         if (in.has_ipa_score && (some(pref_off) || some(match_off))) r.flags |= kPodIpa;
     }
@@ -1151,6 +1300,9 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     PUT(pods, rows, 1);
     w.n_sigs = sig_ok ? (int)sigs.size() : 0;
     PUT(sigs, sigs, 1);
+    PUT(l_flags, in.l_flags, 1); PUT(l_vg_cnt, in.l_vg_cnt, 1); PUT(l_vg_cap, in.l_vg_cap, 1); PUT(l_vg_name, in.l_vg_name, 1);
+    PUT(i_vg_req, in.l_vg_req, 1); PUT(l_dev_cnt, in.l_dev_cnt, 1); PUT(l_dev_cap, in.l_dev_cap, 1); PUT(l_dev_media, in.l_dev_media, 1);
+    PUT(i_dev_alloc, in.l_dev_alloc, 1); PUT(l_spec_of, in.l_spec_of, 1); PUT(l_specs, in.l_specs, 1);
 #undef PUT
     if (hipMalloc((void**)&w.d_cold, 2 * sizeof(WideCold)) != hipSuccess) { err = "hipMalloc(cold args)"; return SIMON_ENOMEM; }
     hipError_t e = hipStreamSynchronize(st);
@@ -1162,7 +1314,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
 // chunk is reused by the next one; kernels on one stream serialise).
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t*, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
-             int32_t* d_place, hipStream_t st, std::string& err) {
+             int64_t* d_used_vg, int32_t* d_place, hipStream_t st, std::string& err) {
     if ((long long)max_n > (long long)kMaxIter * T) { err = "wide kernel: more than 32 nodes per lane"; return SIMON_ERANGE; }
     const size_t per = state_bytes_per_scenario(w, in);
     size_t budget = 16ull << 30;  // 16 GiB of 288 GB HBM for scenario state
@@ -1191,7 +1343,7 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     for (int s0 = 0; s0 < S; s0 += chunk) {
         a.S = std::min(chunk, S - s0);
         a.scen = d_scen + s0;
-        a.unscheduled = d_unsched + s0; a.used_cpu = d_used_cpu + s0; a.used_mem = d_used_mem + s0;
+        a.unscheduled = d_unsched + s0; a.used_cpu = d_used_cpu + s0; a.used_mem = d_used_mem + s0; a.used_vg = d_used_vg ? d_used_vg + s0 : nullptr;
         a.placement = d_place ? d_place + (size_t)s0 * in.P : nullptr;
         hipError_t e = launch<false>(a, T, max_n, st);
         if (e != hipSuccess) { err = std::string("wide launch: ") + hipGetErrorString(e); return SIMON_ENODEV; }

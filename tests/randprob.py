@@ -10,7 +10,7 @@ GiB = 1 << 30
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
                  odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
-                 spread_soft=False, static_scores=False):
+                 spread_soft=False, static_scores=False, local=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -105,6 +105,30 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
         if seed % 2:        # all-zero rows exercise the max == 0 branches
             prob.node_affinity_raw[0] = 0
             prob.taint_prefer_raw[-1] = 0
+    if local:           # Open-Local: node storage + per-class volume specs
+        GiB_ = 1 << 30
+        prob.local_flags = (rng.random(N) < 0.75).astype(np.int32)
+        prob.local_vg_cnt = np.where(prob.local_flags > 0, rng.integers(0, capi.MAX_VG + 1, N), 0).astype(np.int32)
+        prob.local_vg_cap = (rng.choice([20, 50, 100, 200], (N, capi.MAX_VG)) * GiB_).astype(np.int64)
+        prob.init_vg_req = (rng.choice([0, 0, 5, 10], (N, capi.MAX_VG)) * GiB_).astype(np.int64)
+        prob.local_vg_name = np.stack([rng.permutation(6)[:capi.MAX_VG] for _ in range(N)]).astype(np.int32)
+        prob.local_dev_cnt = np.where(prob.local_flags > 0, rng.integers(0, capi.MAX_LDEV + 1, N), 0).astype(np.int32)
+        prob.local_dev_cap = (rng.choice([10, 50, 50, 100, 200], (N, capi.MAX_LDEV)) * GiB_).astype(np.int64)
+        media = rng.integers(0, 3, (N, capi.MAX_LDEV))
+        prob.local_dev_media = (media << (2 * np.arange(capi.MAX_LDEV))[None, :]).sum(1).astype(np.int32)
+        prob.init_dev_alloc = ((rng.random((N, capi.MAX_LDEV)) < 0.15) << np.arange(capi.MAX_LDEV)[None, :]).sum(1).astype(np.int32)
+        specs = np.zeros(5, capi.LOCAL_SPEC_DTYPE)
+        for sp in specs:
+            n_named = int(rng.integers(0, 2))
+            sp["n_lvm"] = int(rng.integers(0, capi.MAX_LVOL + 1))
+            sp["lvm_size"][:] = rng.choice([1, 5, 10, 20, 40], capi.MAX_LVOL) * GiB_
+            sp["lvm_vg"][:] = -1
+            sp["lvm_vg"][:min(n_named, sp["n_lvm"])] = rng.integers(0, 6)
+            sp["n_ssd"], sp["n_hdd"] = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            sp["ssd_size"][:] = np.sort(rng.choice([5, 10, 40, 80], capi.MAX_LVOL)) * GiB_
+            sp["hdd_size"][:] = np.sort(rng.choice([5, 10, 40, 80], capi.MAX_LVOL)) * GiB_
+        prob.local_specs = specs
+        prob.local_spec_of = np.where(rng.random(n_pod_classes) < 0.6, rng.integers(0, len(specs), n_pod_classes), -1).astype(np.int32)
     v2 = aff or ipa or spread_hard or spread_soft
     if anti or v2:
         _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft)

@@ -32,6 +32,8 @@ def run_gpu(prob, scen, orders, env=None, want_placement=True):
 
 def assert_same(a: capi.BatchResult, b: capi.BatchResult):
     assert a.unscheduled.tolist() == b.unscheduled.tolist()
+    if a.used_vg is not None and b.used_vg is not None:
+        assert a.used_vg.tolist() == b.used_vg.tolist()
     assert a.used_cpu.tolist() == b.used_cpu.tolist()
     assert a.used_mem.tolist() == b.used_mem.tolist()
     if a.placement is not None and b.placement is not None:
@@ -174,11 +176,12 @@ def test_random_wide_features(idx):
 
 
 V2_FEATURES = [
+    dict(local=True), dict(local=True, init_state=True, presets=True, gates=True, tight_pods=True, static_mask=True),
     dict(aff=True), dict(ipa=True), dict(spread_hard=True), dict(spread_soft=True), dict(static_scores=True),
     dict(aff=True, anti=True, ipa=True), dict(spread_hard=True, spread_soft=True, static_scores=True, static_mask=True),
     dict(anti=True, aff=True, ipa=True, spread_hard=True, spread_soft=True, static_scores=True, gpu=True, eph=True,
          scalars=2, presets=True, gates=True, tight_pods=True, static_mask=True, nz_differs=True, init_state=True,
-         zero_pods=True),
+         zero_pods=True, local=True),
 ]
 
 
@@ -202,7 +205,7 @@ def test_random_v2_features_many_nodes(wg):
     """Every ABI v2 plugin at once on a pool large enough that a lane owns several nodes and several load batches
     (700 nodes: 11 nodes per lane at 64 threads), with gated / preset pods and prefix scenarios."""
     feat = dict(anti=True, aff=True, ipa=True, spread_hard=True, spread_soft=True, static_scores=True, gpu=True, eph=True,
-                presets=True, gates=True, static_mask=True, nz_differs=True, init_state=True)
+                presets=True, gates=True, static_mask=True, nz_differs=True, init_state=True, local=True)
     for seed in (4240, 4254):                     # ~80 % of the pods schedulable: long assume histories
         prob = randprob.rand_problem(seed, N=700, P=1200, n_pod_classes=14, n_node_classes=9, **feat)
         scen, orders = randprob.rand_scenarios(5, prob, S=4, min_n=400)
@@ -286,11 +289,12 @@ def test_k8s_simulate_and_sweep_through_the_hip_engine():
     import pyref_sched
     import test_host_mirror as H
     from open_simulator_amd import flatten as fl, simulate as sim
+    import randk8s
     for seed in (2, 9, 21):
-        nodes, pods, services, rs = H._random_case(seed, gpu=(seed % 3 == 0), n_nodes=20, n_workloads=16)
-        flat = fl.flatten(nodes, pods, services, rs, [])
+        nodes, pods, services, rs = H._random_case(seed, gpu=(seed % 3 == 0), n_nodes=20, n_workloads=16, local=True)
+        flat = fl.flatten(nodes, pods, services, rs, [], storage_classes=randk8s.STORAGE_CLASSES)
         res, _ = run_gpu(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
-        ref = pyref_sched.Scheduler(nodes, services, rs, []).run(pods)
+        ref = pyref_sched.Scheduler(nodes, services, rs, [], randk8s.STORAGE_CLASSES).run(pods)
         assert [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()] == ref
     # the add-nodes search of test_host_mirror.test_sweep_finds_the_minimum_node_count on the GPU
     H_test = H.test_sweep_finds_the_minimum_node_count

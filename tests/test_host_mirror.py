@@ -61,10 +61,10 @@ def _random_case(seed, **kw):
 
 @pytest.mark.parametrize("seed", range(24))
 def test_flatten_plus_oracle_equals_object_level_scheduler(seed):
-    nodes, pods, services, rs = _random_case(seed, gpu=(seed % 3 == 0))
-    flat = fl.flatten(nodes, pods, services, rs, [])
+    nodes, pods, services, rs = _random_case(seed, gpu=(seed % 3 == 0), local=(seed % 2 == 0))
+    flat = fl.flatten(nodes, pods, services, rs, [], storage_classes=randk8s.STORAGE_CLASSES)
     res = O.run(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
-    ref = pyref_sched.Scheduler(nodes, services, rs, []).run(pods)
+    ref = pyref_sched.Scheduler(nodes, services, rs, [], randk8s.STORAGE_CLASSES).run(pods)
     got = [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()]
     assert got == ref
 
