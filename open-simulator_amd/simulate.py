@@ -164,6 +164,7 @@ class SweepResult:
     mem_pct: List[int]
     best: Optional[int]                  # smallest number of new nodes that schedules everything within the caps
     result: Optional[SimulateResult]     # SimulateResult of that scenario
+    vg_pct: Optional[List[int]] = None   # Open-Local volume-group occupancy per scenario (0 without local storage)
 
 
 def occupancy_pct(used: int, alloc: int) -> int:
@@ -212,7 +213,7 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
         res, per_node = _unflatten(flat, out.placement[best], n, {})
         res.node_status = [{"node": copy.deepcopy(pool[j]), "pods": per_node[j]} for j in range(n)]
         result = res
-    return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result)
+    return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
 
 
 def load_config(path: str, base_dir: str = ".") -> dict:

@@ -29,18 +29,20 @@ def dump_problem(prob):
     d = {"n_pod_classes": prob.n_pod_classes, "n_node_classes": prob.n_node_classes}
     for f in ARRAY_FIELDS:
         v = getattr(prob, f)
-        if v is not None:
+        if v is not None and f == "local_specs":          # structured array: one list per field
+            d[f] = {name: np.asarray(v[name]).tolist() for name in v.dtype.names}
+        elif v is not None:
             d[f] = np.asarray(v).tolist()
     return d
 
 
-def one(name, nodes, cluster, apps, note):
+def one(name, nodes, cluster, apps, note, storage_classes=()):
     order = k8s.canonical_node_order(nodes)
     nodes = [nodes[j] for j in order]
     pods, _ = sim.build_stream(cluster, apps, nodes, len(nodes))
     svc, rs, sts = cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", [])
-    flat = fl.flatten(nodes, pods, svc, rs, sts)
-    ref = pyref_sched.Scheduler(nodes, svc, rs, sts).run(pods)
+    flat = fl.flatten(nodes, pods, svc, rs, sts, storage_classes=list(storage_classes))
+    ref = pyref_sched.Scheduler(nodes, svc, rs, sts, list(storage_classes)).run(pods)
     idx = {n: j for j, n in enumerate(flat.node_names)}
     placement = [capi.UNSCHEDULED if r is None else idx[r] for r in ref]
     out = {"name": name, "note": note, "problem": dump_problem(flat.problem), "n_nodes": len(nodes), "n_pods": len(pods),
@@ -51,15 +53,26 @@ def one(name, nodes, cluster, apps, note):
     print(name, "nodes", len(nodes), "pods", len(pods), "unscheduled", sum(p < 0 for p in placement), flat.info)
 
 
-def example(name, cluster_dir, app_dirs, newnode_dir=None, k=0):
+# the two StorageClasses of the yoda chart (example/application/charts/yoda/templates/storage-class.yaml with the chart's
+# values.yaml names) that example/application/open_local refers to; Helm rendering itself stays on the Go host
+YODA_STORAGE_CLASSES = [
+    {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "yoda-lvm-default"}, "parameters": {"volumeType": "LVM", "fsType": "ext4"}},
+    {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "yoda-device-hdd"}, "parameters": {"volumeType": "Device", "mediaType": "hdd"}},
+]
+
+
+def example(name, cluster_dir, app_dirs, newnode_dir=None, k=0, storage_classes=()):
     cluster = k8s.group_resources(k8s.load_objects(os.path.join(REF, cluster_dir)))
+    sim.attach_local_storage(cluster["Node"], os.path.join(REF, cluster_dir))
     apps = [sim.AppResource(os.path.basename(a), k8s.group_resources(k8s.load_objects(os.path.join(REF, a)))) for a in app_dirs]
     new = []
     if newnode_dir and k:
-        tmpl = k8s.group_resources(k8s.load_objects(os.path.join(REF, newnode_dir)))["Node"][0]
-        new = wl.new_fake_nodes(tmpl, k)
+        tmpl = k8s.group_resources(k8s.load_objects(os.path.join(REF, newnode_dir)))["Node"]
+        sim.attach_local_storage(tmpl, os.path.join(REF, newnode_dir))
+        new = wl.new_fake_nodes(tmpl[0], k)
     one(name, cluster["Node"] + new, cluster, apps,
-        f"example/{cluster_dir} + {app_dirs} + {k} x example/{newnode_dir}" if k else f"example/{cluster_dir} + {app_dirs}")
+        f"example/{cluster_dir} + {app_dirs} + {k} x example/{newnode_dir}" if k else f"example/{cluster_dir} + {app_dirs}",
+        list(cluster.get("StorageClass", [])) + list(storage_classes))
 
 
 def rand(name, seed, **kw):
@@ -76,8 +89,8 @@ def rand(name, seed, **kw):
     order = k8s.canonical_node_order(nodes)
     nodes_c = [nodes[j] for j in order]
     pods, _ = sim.build_stream(reg, [sim.AppResource("app", res)], nodes_c, len(nodes_c))
-    flat = fl.flatten(nodes_c, pods, services, reg_for_selectors["ReplicaSet"], [])
-    ref = pyref_sched.Scheduler(nodes_c, services, reg_for_selectors["ReplicaSet"], []).run(pods)
+    flat = fl.flatten(nodes_c, pods, services, reg_for_selectors["ReplicaSet"], [], storage_classes=randk8s.STORAGE_CLASSES)
+    ref = pyref_sched.Scheduler(nodes_c, services, reg_for_selectors["ReplicaSet"], [], randk8s.STORAGE_CLASSES).run(pods)
     idx = {n: j for j, n in enumerate(flat.node_names)}
     placement = [capi.UNSCHEDULED if r is None else idx[r] for r in ref]
     out = {"name": name, "note": f"tests/randk8s.rand_cluster(seed={seed}, {kw})", "problem": dump_problem(flat.problem),
@@ -94,6 +107,11 @@ def main():
     example("k8s_example_all_6new", "cluster/demo_1", ["application/simple", "application/complicate", "application/more_pods"],
             "newnode/demo_1", 6)
     example("k8s_example_gpushare", "cluster/gpushare", ["application/gpushare"])
+    example("k8s_example_open_local", "cluster/demo_1", ["application/open_local"], storage_classes=YODA_STORAGE_CLASSES)
+    example("k8s_example_open_local_3new", "cluster/demo_1", ["application/simple", "application/open_local"], "newnode/demo_1", 3,
+            storage_classes=YODA_STORAGE_CLASSES)
+    for seed in (4, 36, 58):
+        rand(f"k8s_random_local_{seed}", seed, local=True, gpu=(seed % 3 == 0), n_nodes=16, n_workloads=14)
     for seed in (3, 14, 15, 112, 201):
         rand(f"k8s_random_{seed}", seed, gpu=(seed % 3 == 0))
     rand("k8s_random_big_7", 7, n_nodes=40, n_workloads=30, max_replicas=12)

@@ -36,7 +36,13 @@ def load_k8s_fixture(name):
     pd = dict(d["problem"])
     u64 = ("static_mask", "node_sets")
     kw = {k: (np.asarray(v, np.uint64) if k in u64 else np.asarray(v)) for k, v in pd.items()
-          if k not in ("n_pod_classes", "n_node_classes")}
+          if k not in ("n_pod_classes", "n_node_classes", "local_specs")}
+    if "local_specs" in pd:                                  # structured array, stored field by field
+        fields = pd["local_specs"]
+        specs = np.zeros(len(fields["n_lvm"]), capi.LOCAL_SPEC_DTYPE)
+        for name, v in fields.items():
+            specs[name] = np.asarray(v)
+        kw["local_specs"] = specs
     prob = capi.Problem(n_pod_classes=pd["n_pod_classes"], n_node_classes=pd["n_node_classes"], **kw).normalise()
     return d, prob
 
@@ -103,6 +109,38 @@ def test_reference_gpushare_config_end_to_end():
     # gpu-pod-00 and gpu-pod-02 carry the gpu-mem annotation (gpu-pod-01 has none; the ReplicaSet's sit on the RS object)
     gpu_pods = [p for s in sw.result.node_status for p in s["pods"] if "alibabacloud.com/gpu-mem" in (p["metadata"].get("annotations") or {})]
     assert len(gpu_pods) == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLE), reason="reference tree not present (GPU box)")
+def test_reference_open_local_example_end_to_end():
+    """example/application/open_local on example/cluster/demo_1 with example/newnode/demo_1: each nginx-lvm pod needs
+    10Gi + 40Gi of LVM and one 100Gi HDD device; worker-1 and the new-node template own ONE hdd device each, the
+    masters are tainted or carry no local storage -> one pod per storage node, 3 new nodes for the 4 replicas."""
+    root = os.path.dirname(REF_EXAMPLE)
+    cluster = k8s.group_resources(k8s.load_objects(os.path.join(REF_EXAMPLE, "cluster/demo_1")))
+    sim.attach_local_storage(cluster["Node"], os.path.join(REF_EXAMPLE, "cluster/demo_1"))
+    yoda = [{"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "yoda-lvm-default"}, "parameters": {"volumeType": "LVM"}},
+            {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "yoda-device-hdd"},
+             "parameters": {"volumeType": "Device", "mediaType": "hdd"}}]
+    app = sim.AppResource("open_local", k8s.group_resources(k8s.load_objects(os.path.join(REF_EXAMPLE, "application/open_local")) + yoda))
+    tmpl = k8s.group_resources(k8s.load_objects(os.path.join(REF_EXAMPLE, "newnode/demo_1")))["Node"]
+    sim.attach_local_storage(tmpl, os.path.join(REF_EXAMPLE, "newnode/demo_1"))
+    sw = sim.sweep(cluster, [app], tmpl[0], range(0, 5), engine=OracleEngine())
+    assert sw.unscheduled == [3, 2, 1, 0, 0] and sw.best == 3
+    hosts = {s["node"]["metadata"]["name"]: [p["metadata"]["name"] for p in s["pods"] if p["metadata"]["name"].startswith("nginx-lvm")]
+             for s in sw.result.node_status}
+    assert hosts["worker-1"] == ["nginx-lvm-0"] and [hosts[f"simon-{i:05d}"] for i in range(3)] == [["nginx-lvm-1"], ["nginx-lvm-2"], ["nginx-lvm-3"]]
+    # MaxVG (pkg/apply/apply.go:747-771): 4 x 50Gi requested over master-1 + worker-1 (200Gi each) + k x 500Gi
+    assert sw.vg_pct == [int(50 * (1 + min(k, 3)) / (400 + 500 * k) * 100) for k in range(5)]
+    capped = sim.sweep(cluster, [app], tmpl[0], range(0, 7), engine=OracleEngine(), max_vg=9)
+    assert capped.vg_pct[3] == 10 and capped.vg_pct[4] == 8 and capped.best == 4
+    one = sim.simulate(cluster, [app], engine=OracleEngine())
+    assert [u["pod"]["metadata"]["name"] for u in one.unscheduled_pods] == ["nginx-lvm-1", "nginx-lvm-2", "nginx-lvm-3"]
+    # master-1 is tainted, master-2/3 have no storage annotation (Unschedulable without a reason), worker-1's device is taken
+    assert one.unscheduled_pods[0]["reason"].endswith(
+        "0/4 nodes are available: 1 insufficient local storage (device), 1 node(s) had taint {node-role.kubernetes.io/master: }, "
+        "that the pod didn't tolerate.")
+    del root
 
 
 def test_sweep_equals_one_simulate_per_cluster_size():
