@@ -14,6 +14,7 @@ Each step names the reference code it restates (V/ = vendor/k8s.io/kubernetes/pk
 from __future__ import annotations
 
 import json
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -251,12 +252,16 @@ def host_ports(pod: dict):
     return out
 
 
+def _bitmask_rows(flags: np.ndarray, words: int) -> np.ndarray:
+    """bool [R][N] -> uint64 [R][words], node j = bit j % 64 of word j / 64"""
+    R, N = flags.shape
+    padded = np.zeros((R, words * 64), bool)
+    padded[:, :N] = flags
+    return np.packbits(padded, axis=1, bitorder="little").view("<u8").astype(np.uint64).reshape(R, words)
+
+
 def _bitmask(flags, words) -> np.ndarray:
-    m = np.zeros(words, np.uint64)
-    for j, f in enumerate(flags):
-        if f:
-            m[j // 64] |= np.uint64(1) << np.uint64(j % 64)
-    return m
+    return _bitmask_rows(np.asarray(flags, bool)[None, :], words)[0]
 
 
 def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), statefulsets=(),
@@ -272,21 +277,44 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     words = (N + 63) // 64
 
     # ---- pods: requests, classes ---------------------------------------------------------------------------
-    reqs = [k8s.pod_request(p) for p in pods]
+    # Ingest: every per-pod quantity is evaluated once per TEMPLATE.  workloads.py stamps the
+    # replicas of one workload with a `_tmpl` token (identical but for metadata.name), so a 50 000-pod stream costs
+    # one evaluation per workload plus integer gathers; pods without a token are their own template.
+    tok_rep: Dict[int, int] = {}
+    rep_list: List[int] = []                              # pod index of each distinct template
+    tmpl_of = np.empty(P, np.int64)
+    for i, p in enumerate(pods):
+        tok = p.get("_tmpl")
+        if tok is None:
+            tmpl_of[i] = len(rep_list)
+            rep_list.append(i)
+        else:
+            r = tok_rep.get(tok)
+            if r is None:
+                r = tok_rep[tok] = len(rep_list)
+                rep_list.append(i)
+            tmpl_of[i] = r
+    tpods = [pods[i] for i in rep_list]
+    if os.environ.get("SIMON_CHECK_TEMPLATES"):           # debug: the token promise, checked pod by pod
+        for i, p in enumerate(pods):
+            a, b = p, tpods[tmpl_of[i]]
+            assert a["spec"] == b["spec"] and {k: v for k, v in a["metadata"].items() if k != "name"} == \
+                {k: v for k, v in b["metadata"].items() if k != "name"}, f"pod {a['metadata']['name']} differs from its template"
+    reqs = [k8s.pod_request(p) for p in tpods]
     scalar_names = sorted({name for r in reqs for name, v in r.items()
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
     if len(scalar_names) > capi.MAX_SCALAR:
         raise Unsupported(f"more than {capi.MAX_SCALAR} extended resources requested")
-    req_cpu = np.array([r.get("cpu", 0) for r in reqs], np.int64)
-    req_mem = np.array([r.get("memory", 0) for r in reqs], np.int64)
-    req_eph = np.array([r.get("ephemeral-storage", 0) for r in reqs], np.int64)
-    nz = [k8s.pod_nonzero_request(p) for p in pods]
-    nz_cpu = np.array([a for a, _ in nz], np.int64)
-    nz_mem = np.array([b for _, b in nz], np.int64)
-    scalar_req = np.array([[r.get(name, 0) for r in reqs] for name in scalar_names], np.int64).reshape(len(scalar_names), P)
-    gpu = [_gpu_annotations(p) for p in pods]
-    gpu_mem = np.array([g[0] for g in gpu], np.int64)
-    gpu_cnt = np.array([g[1] for g in gpu], np.int32)
+    req_cpu = np.array([r.get("cpu", 0) for r in reqs], np.int64)[tmpl_of]
+    req_mem = np.array([r.get("memory", 0) for r in reqs], np.int64)[tmpl_of]
+    req_eph = np.array([r.get("ephemeral-storage", 0) for r in reqs], np.int64)[tmpl_of]
+    nz = [k8s.pod_nonzero_request(p) for p in tpods]
+    nz_cpu = np.array([a for a, _ in nz], np.int64)[tmpl_of]
+    nz_mem = np.array([b for _, b in nz], np.int64)[tmpl_of]
+    scalar_req = np.array([[r.get(name, 0) for r in reqs] for name in scalar_names], np.int64).reshape(len(scalar_names), len(tpods))[:, tmpl_of]
+    gpu = [_gpu_annotations(p) for p in tpods]
+    gpu_mem = np.array([g[0] for g in gpu], np.int64)[tmpl_of]
+    gpu_cnt = np.array([g[1] for g in gpu], np.int32)[tmpl_of]
     preset = np.array([node_index.get(p["spec"].get("nodeName"), -1) if p["spec"].get("nodeName") else -1 for p in pods], np.int32)
     for i, p in enumerate(pods):
         if p["spec"].get("nodeName") and preset[i] < 0:
@@ -294,21 +322,30 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
 
     class_ids: Dict[str, int] = {}
     class_rep: List[dict] = []
-    pod_class = np.empty(P, np.int32)
-    for i, p in enumerate(pods):
+    rq_of_class: List[Dict[str, Quantity]] = []
+    tmpl_class = np.empty(len(tpods), np.int32)
+    for i, p in enumerate(tpods):
         spec, md = p["spec"], p["metadata"]
         owner = [r.get("kind") for r in md.get("ownerReferences") or [] if r.get("controller")]
+        rq = pod_requests_quantities(p)
         key = json.dumps([md.get("namespace"), md.get("labels") or {}, spec.get("nodeSelector"), spec.get("affinity"),
                           spec.get("tolerations"), spec.get("topologySpreadConstraints"), owner,
-                          {k: str(v) for k, v in pod_requests_quantities(p).items()}, spec.get("overhead"), host_ports(p),
+                          {k: str(v) for k, v in rq.items()}, spec.get("overhead"), host_ports(p),
                           pod_local_volumes(p, storage_classes)], sort_keys=True)
         if key not in class_ids:
             class_ids[key] = len(class_rep)
             class_rep.append(p)
-        pod_class[i] = class_ids[key]
+            rq_of_class.append(rq)
+        tmpl_class[i] = class_ids[key]
+    pod_class = tmpl_class[tmpl_of]          # class ids number the classes by first occurrence in the stream, as before
     Cp = len(class_rep)
 
     # ---- static filters per (pod class, node): first failing plugin in registry order --------------------------
+    # A class looks at a node only through the label keys its nodeSelector / node affinity name, the node's taints,
+    # its unschedulable flag, its preferAvoidPods annotation and -- for matchFields -- whether its name is one of the
+    # listed values.  Nodes are interned by that view ("node signature") and each class is evaluated once per
+    # distinct signature; the (class, node) matrices are gathers.  A DaemonSet's per-node pods (one class each,
+    # pinned by matchFields) cost O(signatures) instead of O(nodes) evaluations each.
     reason_ids: Dict[str, int] = {v: k for k, v in fiterror.DEFAULT_STATIC_REASONS.items()}
 
     def rid(text: str) -> int:
@@ -317,14 +354,62 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 raise Unsupported("more than 255 distinct static failure reasons")
             reason_ids[text] = len(reason_ids) + 1
         return reason_ids[text]
+
+    def intern_col(values) -> np.ndarray:
+        ids: Dict = {}
+        return np.array([ids.setdefault(v, len(ids)) for v in values], np.int64)
+
+    node_labels = [n["metadata"].get("labels") or {} for n in nodes]
+    taint_sig = intern_col(json.dumps((n.get("spec") or {}).get("taints") or [], sort_keys=True) for n in nodes)
+    unsched_sig = np.array([1 if (n.get("spec") or {}).get("unschedulable") else 0 for n in nodes], np.int64)
+    avoid_sig = intern_col((n["metadata"].get("annotations") or {}).get(ANNO_PREFER_AVOID) or "" for n in nodes)
+    fixed_sig = intern_col(zip(taint_sig.tolist(), unsched_sig.tolist(), avoid_sig.tolist()))
+    group_cache: Dict[tuple, tuple] = {}
+
+    def label_group(keys: tuple):
+        """(first node of each signature, signature index per node) for the classes that read exactly `keys`."""
+        g = group_cache.get(keys)
+        if g is None:
+            sig = fixed_sig if not keys else intern_col(zip(fixed_sig.tolist(), *[[lab.get(k) for lab in node_labels] for k in keys]))
+            _, first, inv = np.unique(sig, return_index=True, return_inverse=True)
+            g = group_cache[keys] = (sig, first, inv)
+        return g
+
+    def node_view_of(p: dict):
+        """label keys and metadata.name values the class's node selector / affinity terms mention"""
+        keys = set((p["spec"].get("nodeSelector") or {}).keys())
+        names = []
+        na_ = ((p["spec"].get("affinity") or {}).get("nodeAffinity") or {})
+        terms_ = list((na_.get("requiredDuringSchedulingIgnoredDuringExecution") or {}).get("nodeSelectorTerms") or [])
+        terms_ += [t.get("preference") or {} for t in na_.get("preferredDuringSchedulingIgnoredDuringExecution") or []]
+        for t in terms_:
+            keys.update(r["key"] for r in t.get("matchExpressions") or [])
+            for r in t.get("matchFields") or []:
+                names += [str(v) for v in r.get("values") or []]
+        return tuple(sorted(keys)), names
+
     static_ok = np.ones((Cp, N), bool)
     static_reason = np.zeros((Cp, N), np.uint8)
-    affinity_ok = np.ones((Cp, N), bool)          # PodMatchesNodeSelectorAndAffinityTerms alone (spread eligibility)
+    class_view: List[tuple] = []                   # per class: (first, inv, affinity_ok per signature)
+    part = None                                    # node partition refined by every class that tells nodes apart
+    score_cols: List[tuple] = []                   # per class: (inv, na, tt, npa per signature)
+    unsched_tol = {"key": "node.kubernetes.io/unschedulable", "effect": "NoSchedule"}
     for c, p in enumerate(class_rep):
-        unsched_tol = {"key": "node.kubernetes.io/unschedulable", "effect": "NoSchedule"}
+        keys, names = node_view_of(p)
+        sig, first, inv = label_group(keys)
+        if names:                                  # matchFields: the node's name matters only as "which listed value"
+            extra = np.zeros(N, np.int64)
+            for k, name in enumerate(dict.fromkeys(names)):
+                if name in node_index:
+                    extra[node_index[name]] = k + 1
+            _, first, inv = np.unique(sig * (len(names) + 1) + extra, return_index=True, return_inverse=True)
         tolerates_unsched = any(k8s.toleration_tolerates(t, unsched_tol) for t in p["spec"].get("tolerations") or [])
-        for j, node in enumerate(nodes):
-            affinity_ok[c, j] = k8s.pod_matches_node_selector_and_affinity(p, node)
+        U = len(first)
+        ok_u, reason_u, aff_u = np.ones(U, bool), np.zeros(U, np.uint8), np.ones(U, bool)
+        na_u, tt_u, npa_u = np.zeros(U, np.int64), np.zeros(U, np.int64), np.zeros(U, np.int64)
+        for u, j in enumerate(first.tolist()):
+            node = nodes[j]
+            aff_u[u] = k8s.pod_matches_node_selector_and_affinity(p, node)
             reason = None
             if (node.get("spec") or {}).get("unschedulable") and not tolerates_unsched:   # nodeunschedulable/node_unschedulable.go:51-66
                 reason = "node(s) were unschedulable"
@@ -332,12 +417,23 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 taint = k8s.find_untolerated_taint(node, p)
                 if taint is not None:
                     reason = fiterror.taint_reason(taint.get("key", ""), taint.get("value", "") or "")
-                elif not affinity_ok[c, j]:
+                elif not aff_u[u]:
                     reason = "node(s) didn't match Pod's node affinity"
             if reason is not None:
-                static_ok[c, j] = False
-                static_reason[c, j] = rid(reason)
-    static_mask = np.stack([_bitmask(static_ok[c], words) for c in range(Cp)])
+                ok_u[u] = False
+                reason_u[u] = rid(reason)
+            na_u[u] = k8s.node_affinity_preferred_score(p, node)
+            tt_u[u] = k8s.count_intolerable_prefer_no_schedule(node, p)
+            npa_u[u] = _prefer_avoid(node, p)
+        static_ok[c] = ok_u[inv]
+        static_reason[c] = reason_u[inv]
+        class_view.append((inv, aff_u))
+        score_cols.append((inv, na_u, tt_u, npa_u))
+    static_mask = _bitmask_rows(static_ok, words)
+
+    def affinity_ok_of(c: int) -> np.ndarray:
+        inv, aff_u = class_view[c]
+        return aff_u[inv]
 
     # ---- nodes: allocatable, GPU capacity, static scores, classes ---------------------------------------------
     allocs = [k8s.node_allocatable(n) for n in nodes]
@@ -351,27 +447,47 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     node_gpu_mem = np.array([parse_quantity(str(c[k8s.GPU_MEM])).int_value() if k8s.GPU_MEM in c else 0 for c in caps], np.int64)
     if (node_gpu_cnt > capi.MAX_GPU_DEV).any():
         raise Unsupported(f"node with more than {capi.MAX_GPU_DEV} GPU devices")
-    na = np.array([[k8s.node_affinity_preferred_score(p, n) for n in nodes] for p in class_rep], np.int64).reshape(Cp, N)
-    tt = np.array([[k8s.count_intolerable_prefer_no_schedule(n, p) for n in nodes] for p in class_rep], np.int64).reshape(Cp, N)
-    npa = np.array([[_prefer_avoid(n, p) for n in nodes] for p in class_rep], np.int64).reshape(Cp, N)
     alloc_q = [{name: parse_quantity(str(q)) for name, q in ((n.get("status") or {}).get("allocatable") or {}).items()} for n in nodes]
-    ncls_ids: Dict[str, int] = {}
-    ncls_rep: List[int] = []
-    node_class = np.empty(N, np.int32)
-    for j in range(N):
-        key = json.dumps([{k: [q.value, q.scale, q.format] for k, q in sorted(alloc_q[j].items())},
-                          na[:, j].tolist(), tt[:, j].tolist(), npa[:, j].tolist()])
-        if key not in ncls_ids:
-            ncls_ids[key] = len(ncls_rep)
-            ncls_rep.append(j)
-        node_class[j] = ncls_ids[key]
+    # node classes: nodes with equal allocatable quantities and equal (NodeAffinity, TaintToleration, NodePreferAvoidPods)
+    # raw scores for EVERY pod class.  The partition starts from the allocatable key and is refined by each class whose
+    # scores differ between signatures; classes are numbered by first occurrence in node order.
+    part = intern_col(json.dumps({k: [q.value, q.scale, q.format] for k, q in sorted(a.items())}) for a in alloc_q)
+    for inv, na_u, tt_u, npa_u in score_cols:
+        if (na_u == na_u[0]).all() and (tt_u == tt_u[0]).all() and (npa_u == npa_u[0]).all():
+            continue
+        trip = intern_col(zip(na_u.tolist(), tt_u.tolist(), npa_u.tolist()))
+        _, part = np.unique(part * (int(trip.max()) + 1) + trip[inv], return_inverse=True)
+    _, first, inv = np.unique(part, return_index=True, return_inverse=True)
+    rank = np.empty(len(first), np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(len(first))
+    node_class = rank[inv].astype(np.int32)
+    ncls_rep = np.sort(first).tolist()
     Cn = len(ncls_rep)
+    rep_idx = np.array(ncls_rep, np.int64)
+    na_t, tt_t, npa_t = np.zeros((Cp, Cn), np.int64), np.zeros((Cp, Cn), np.int64), np.zeros((Cp, Cn), np.int64)
+    for c, (inv_, na_u, tt_u, npa_u) in enumerate(score_cols):
+        at = inv_[rep_idx]
+        na_t[c], tt_t[c], npa_t[c] = na_u[at], tt_u[at], npa_u[at]
+    # Simon / Open-Gpu-Share raw score: only the resources the pod requests can raise the max share, so the value is
+    # shared by every (class, node class) pair with the same request quantities and the same allocatable of those names
     simon_raw = np.zeros((Cp, Cn), np.int64)
-    for c, p in enumerate(class_rep):
-        rq = pod_requests_quantities(p)
-        for d, j in enumerate(ncls_rep):
-            simon_raw[c, d] = simon_raw_score(rq, alloc_q[j])
-    na_t, tt_t, npa_t = na[:, ncls_rep], tt[:, ncls_rep], npa[:, ncls_rep]
+    alloc_sub: Dict[tuple, tuple] = {}
+    raw_rows: Dict[str, np.ndarray] = {}
+    for c in range(Cp):
+        rq = rq_of_class[c]
+        rq_key = json.dumps({k: [q.value, q.scale] for k, q in sorted(rq.items())})
+        row = raw_rows.get(rq_key)
+        if row is None:
+            names = tuple(sorted(rq))
+            sub = alloc_sub.get(names)
+            if sub is None:
+                ids = intern_col(tuple((alloc_q[j][k].value, alloc_q[j][k].scale) if k in alloc_q[j] else None for k in names)
+                                 for j in ncls_rep)
+                _, sfirst, sinv = np.unique(ids, return_index=True, return_inverse=True)
+                sub = alloc_sub[names] = (sfirst, sinv)
+            sfirst, sinv = sub
+            row = raw_rows[rq_key] = np.array([simon_raw_score(rq, alloc_q[ncls_rep[d]]) for d in sfirst.tolist()], np.int64)[sinv]
+        simon_raw[c] = row
 
     # constants the engine does not evaluate: ImageLocality 0, and the plugins that score alike on every node
     const = np.zeros(Cp, np.int64)
@@ -427,6 +543,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                     port_conf[c].append(term_id("port", (ip2, proto2, str(hp2)), "", NODE_KEY))
     pref_w, own_w, hard_skew, hard_self, hard_set, soft_skew = ([[] for _ in range(Cp)] for _ in range(6))
     const_pts = np.zeros(Cp, np.int64)
+    has_all_memo: Dict[tuple, np.ndarray] = {}
     for c, p in enumerate(class_rep):
         ns, labels = p["metadata"]["namespace"], p["metadata"].get("labels") or {}
         at = _affinity_terms(p)
@@ -452,7 +569,11 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         h, s = _spread_constraints(p, services, replicasets, statefulsets)
         if len(h) > capi.MAX_SPREAD or len(s) > capi.MAX_SPREAD:
             raise Unsupported(f"more than {capi.MAX_SPREAD} topology spread constraints of one kind")
-        has_all = lambda cons: np.array([all(k in (n["metadata"].get("labels") or {}) for _, k, _ in cons) for n in nodes], bool)
+        def has_all(cons):                            # nodes that carry every topology key of the constraints (memoised per key set)
+            ks = tuple(sorted({k for _, k, _ in cons}))
+            if ks not in has_all_memo:
+                has_all_memo[ks] = np.array([all(k in lab for k in ks) for lab in node_labels], bool)
+            return has_all_memo[ks]
         # The plugin keeps ONE counter per topology pair (TpPairToMatchNum / TopologyPairToPodCounts are keyed by
         # (key, value), filtering.go:253-268, scoring.go:129-160): constraints of one pod that share a topology key add
         # their matches into the same counter.  Such constraints therefore share a term whose selector LIST is matched
@@ -465,7 +586,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                     by_key.setdefault(key, []).append(sel)
             return by_key
         if h:
-            elig = set_id(affinity_ok[c] & has_all(h))
+            elig = set_id(affinity_ok_of(c) & has_all(h))
             by_key = grouped(h, True)
             for (sel, key, skew) in h:
                 hard[c].append(term_id("spread", (ns,), json.dumps(by_key[key]), key))
@@ -473,7 +594,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 hard_self[c].append(int(_selectors_match(sel, labels)))
                 hard_set[c].append(elig)
         if s:
-            elig = set_id(affinity_ok[c] & has_all(s))
+            elig = set_id(affinity_ok_of(c) & has_all(s))
             by_key = grouped(s, False)
             seen_keys = set()
             for (sel, key, skew) in s:
@@ -501,7 +622,13 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         if ns not in nss:                                           # countPodsMatchSelector: same namespace (common.go:93-105)
             return 0
         return sum(1 for s_ in json.loads(sel) if _selectors_match(s_, labels))   # multiplicity, see `grouped` above
-    match = [[t for t in range(len(terms)) for _ in range(int(class_matches(c, terms[t])))] for c in range(Cp)]
+    match_memo: Dict[str, list] = {}                # a class matches terms through its namespace, labels and host ports only
+    match = []
+    for c, p in enumerate(class_rep):
+        mk = json.dumps([p["metadata"]["namespace"], p["metadata"].get("labels") or {}, host_ports(p)], sort_keys=True)
+        if mk not in match_memo:
+            match_memo[mk] = [t for t in range(len(terms)) for _ in range(int(class_matches(c, terms[t])))]
+        match.append(match_memo[mk])
 
     T = len(terms)
     Kt = len(key_ids)

@@ -126,8 +126,11 @@ def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict
 
 
 def _public(pod: dict) -> dict:
-    p = copy.deepcopy(pod)
-    p.pop("_daemon_node", None)
+    """The pod object handed back in a SimulateResult: own top-level / metadata / spec dicts (spec.nodeName and status are
+    set per pod), nested values shared with the input objects like the reference's pointers into its fake cluster."""
+    p = {k: v for k, v in pod.items() if not k.startswith("_")}
+    p["metadata"] = dict(pod["metadata"])
+    p["spec"] = dict(pod["spec"])
     return p
 
 

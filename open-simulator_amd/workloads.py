@@ -12,6 +12,7 @@ Pod names: the reference appends rand.String(10); here `<owner>-<ordinal>` (name
 from __future__ import annotations
 
 import copy
+import itertools
 from typing import Dict, List
 
 from . import k8s
@@ -62,15 +63,26 @@ def _workload_info(pod: dict, kind: str, owner: dict) -> dict:
     return pod
 
 
+_TEMPLATE_TOKENS = itertools.count(1)
+
+
+def _replicate(proto: dict, names: List[str]) -> List[dict]:
+    """The replicas of one validated template (the reference runs DeepCopy + API validation per
+    replica, pkg/utils/utils.go:132-463).  Each replica owns its metadata / labels / annotations / spec dicts (top level);
+    nested values are shared and read-only.  `_tmpl` tells flatten() that the pods are identical but for their name,
+    so every per-pod quantity is evaluated once per template."""
+    token = next(_TEMPLATE_TOKENS)
+    md = proto["metadata"]
+    return [dict(proto, metadata=dict(md, name=name, labels=dict(md["labels"]), annotations=dict(md["annotations"])),
+                 spec=dict(proto["spec"]), status={}, _tmpl=token) for name in names]
+
+
 def pods_of_replicaset(rs: dict, owner_kind: str = "ReplicaSet") -> List[dict]:
     """MakeValidPodsByReplicaSet (pkg/utils/utils.go:137-158); replicas default 1."""
     n = rs["spec"].get("replicas")
     n = 1 if n is None else int(n)
-    out = []
-    for i in range(n):
-        p = make_valid_pod(_from_template(rs, rs["spec"]["template"], owner_kind, f"{rs['metadata']['name']}-{i}"))
-        out.append(_workload_info(p, "ReplicaSet", rs))
-    return out
+    proto = _workload_info(make_valid_pod(_from_template(rs, rs["spec"]["template"], owner_kind, "")), "ReplicaSet", rs)
+    return _replicate(proto, [f"{rs['metadata']['name']}-{i}" for i in range(n)])
 
 
 def pods_of_deployment(d: dict) -> List[dict]:
@@ -105,24 +117,17 @@ def pods_of_statefulset(ss: dict) -> List[dict]:
     """MakeValidPodsByStatefulSet (pkg/utils/utils.go:217-243); names <sts>-<ordinal>."""
     n = ss["spec"].get("replicas")
     n = 1 if n is None else int(n)
-    out = []
-    anno = storage_annotation(ss["spec"].get("volumeClaimTemplates"))
-    for i in range(n):
-        p = make_valid_pod(_from_template(ss, ss["spec"]["template"], "StatefulSet", f"{ss['metadata']['name']}-{i}"))
-        p["metadata"]["annotations"][ANNO_POD_LOCAL_STORAGE] = anno
-        out.append(_workload_info(p, "StatefulSet", ss))
-    return out
+    proto = _workload_info(make_valid_pod(_from_template(ss, ss["spec"]["template"], "StatefulSet", "")), "StatefulSet", ss)
+    proto["metadata"]["annotations"][ANNO_POD_LOCAL_STORAGE] = storage_annotation(ss["spec"].get("volumeClaimTemplates"))
+    return _replicate(proto, [f"{ss['metadata']['name']}-{i}" for i in range(n)])
 
 
 def pods_of_job(job: dict) -> List[dict]:
     """MakeValidPodByJob (pkg/utils/utils.go:178-203); completions default 1."""
     n = job["spec"].get("completions")
     n = 1 if n is None else int(n)
-    out = []
-    for i in range(n):
-        p = make_valid_pod(_from_template(job, job["spec"]["template"], "Job", f"{job['metadata']['name']}-{i}"))
-        out.append(_workload_info(p, "Job", job))
-    return out
+    proto = _workload_info(make_valid_pod(_from_template(job, job["spec"]["template"], "Job", "")), "Job", job)
+    return _replicate(proto, [f"{job['metadata']['name']}-{i}" for i in range(n)])
 
 
 def pods_of_cronjob(cj: dict) -> List[dict]:

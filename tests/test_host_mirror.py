@@ -143,6 +143,53 @@ def test_reference_open_local_example_end_to_end():
     del root
 
 
+def _problem_arrays(prob):
+    out = {}
+    for f in capi.Problem.__dataclass_fields__:
+        v = getattr(prob, f)
+        if f != "_keep" and v is not None:
+            out[f] = np.asarray(v)
+    return out
+
+
+@pytest.mark.parametrize("seed", [3, 8, 21])
+def test_template_interning_equals_per_pod_evaluation(seed):
+    """Ingest: flatten() evaluates each workload template once (`_tmpl` tokens from workloads.py) and
+    each pod class once per node signature.  The result must be the arrays a pod-by-pod evaluation gives: same stream
+    with the tokens stripped (every pod its own template), with DaemonSet pods (matchFields pins) and Open-Local in."""
+    nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=14, n_workloads=12, gpu=(seed % 3 == 0), local=True)
+    ds = {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "agent", "namespace": "kube-system"},
+          "spec": {"selector": {"matchLabels": {"app": "agent"}},
+                   "template": {"metadata": {"labels": {"app": "agent"}},
+                                "spec": {"containers": [{"name": "a", "image": "x", "resources": {"requests": {"cpu": "100m"}}}],
+                                         "nodeSelector": {"disk": "ssd"}}}}}
+    nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
+    cluster = k8s.group_resources(nodes + services + [ds])
+    pods, gates = sim.build_stream(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], nodes, len(nodes))
+    assert any("_tmpl" in p for p in pods) and any("_daemon_node" in p for p in pods)
+    os.environ["SIMON_CHECK_TEMPLATES"] = "1"
+    try:
+        a = fl.flatten(nodes, pods, services, [], [], gates, storage_classes=randk8s.STORAGE_CLASSES)
+    finally:
+        del os.environ["SIMON_CHECK_TEMPLATES"]
+    stripped = [{k: v for k, v in p.items() if k != "_tmpl"} for p in pods]
+    b = fl.flatten(nodes, stripped, services, [], [], gates, storage_classes=randk8s.STORAGE_CLASSES)
+    xa, xb = _problem_arrays(a.problem), _problem_arrays(b.problem)
+    assert xa.keys() == xb.keys()
+    for k in xa:
+        assert xa[k].dtype == xb[k].dtype and xa[k].shape == xb[k].shape and (xa[k] == xb[k]).all(), k
+    # a replica that was edited after expansion breaks the token promise: the debug check names it
+    seen = set()
+    later = [p for p in pods if "_tmpl" in p and (p["_tmpl"] in seen or seen.add(p["_tmpl"]))]      # non-first replicas
+    later[-1]["metadata"]["labels"]["edited"] = "yes"
+    os.environ["SIMON_CHECK_TEMPLATES"] = "1"
+    try:
+        with pytest.raises(AssertionError, match="differs from its template"):
+            fl.flatten(nodes, pods, services, [], [], gates, storage_classes=randk8s.STORAGE_CLASSES)
+    finally:
+        del os.environ["SIMON_CHECK_TEMPLATES"]
+
+
 def test_sweep_equals_one_simulate_per_cluster_size():
     """The batched add-nodes search (gated DaemonSet pods, prefix node pools) against one Simulate() per size."""
     nodes, workloads, services = randk8s.rand_cluster(5, n_nodes=6, n_workloads=14, max_replicas=8)
