@@ -144,7 +144,7 @@ def main():
     n_orders = args.orders_per_gpu * world
     seed = synth.SEED + (3 if world == 1 else 4)
     if args.workload == "config5":
-        prob, scen_all, orders = synth.config5(n_scen=256 * world, n_orders=n_orders)
+        prob, scen_all, orders = synth.config5(n_scen=int(os.environ.get("SIMON_BENCH_C5_SCEN", "256")) * world, n_orders=n_orders)
     else:
         prob, scen_all, orders = synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=seed)
     scen = sweep.shard(scen_all, rank, world)                 # every rank gets every node count

@@ -114,6 +114,7 @@ struct WideCold {
     // per-scenario mutable state of the optional features, [S_chunk][...]
     int64_t* st_req_eph; int64_t* st_nz_cpu; int64_t* st_nz_mem;
     int64_t* st_scalar /*[S][K][N]*/; int64_t* st_gpu /*[S][N][8]*/;
+    int64_t* st_gmax /*[S][N]: largest idle memory over the node's GPU devices (0 without devices)*/;
     int32_t* st_cnt /*[S][3*total_dom + Tm]: cnt_match, cnt_owner, w_owner, term_total*/;
     int32_t* st_seen /*[S][seen_stride]: distinct-domain stamps of the soft spread constraints*/;
     // explain outputs (single scenario)
@@ -130,6 +131,7 @@ struct WideArgs {
     // static node arrays [N] (shared)
     const int64_t* alloc_cpu; const int64_t* alloc_mem; const int32_t* alloc_pods; const int32_t* node_class;
     const uint64_t* static_mask; const int64_t* simon_raw;
+    const uint32_t* mask_lanes /*[Cp][T]: bit it = static mask of node tid + it*T (lane-major copy of static_mask), or null*/;
     // stream
     const WidePod* pods; const int32_t* orders; const WideScenario* scen /*[S] of this chunk*/; const WideSig* sigs;
     // per-scenario mutable state every cycle touches, [S_chunk][N]
@@ -175,7 +177,9 @@ struct WideDevice {
     unsigned char* st_tab = nullptr;
     // state
     int64_t *st_req_cpu = nullptr, *st_req_mem = nullptr, *st_req_eph = nullptr, *st_nz_cpu = nullptr, *st_nz_mem = nullptr,
-            *st_scalar = nullptr, *st_gpu = nullptr;
+            *st_scalar = nullptr, *st_gpu = nullptr, *st_gmax = nullptr;
+    uint32_t* mask_lanes = nullptr;      // lane-major static mask of the last launch's workgroup size
+    int mask_lanes_T = 0;
     int32_t *st_npods = nullptr, *st_cnt = nullptr, *st_seen = nullptr;
     void release();
 };

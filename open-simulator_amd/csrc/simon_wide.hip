@@ -55,6 +55,7 @@ struct NodeView {  // pointers of ONE scenario's state: the hot ones held, the f
     __device__ __forceinline__ int64_t* nz_mem() const { return COLDP(Cg)->st_nz_mem + (size_t)s * N; }
     __device__ __forceinline__ int64_t* scalar() const { return COLDP(Cg)->st_scalar + (size_t)s * (K > 0 ? K : 1) * N; }
     __device__ __forceinline__ int64_t* gpu() const { return COLDP(Cg)->st_gpu + (size_t)s * (gpu_on ? (size_t)N * SIMON_MAX_GPU_DEV : 1); }
+    __device__ __forceinline__ int64_t* gmax() const { return COLDP(Cg)->st_gmax + (size_t)s * (gpu_on ? (size_t)N : 1); }
     __device__ __forceinline__ int cnt_stride() const { return 3 * COLDP(Cg)->total_dom + COLDP(Cg)->Tm; }
     __device__ __forceinline__ int32_t* cnt_match() const { const int cs = cnt_stride(); return COLDP(Cg)->st_cnt + (size_t)s * (cs > 0 ? cs : 1); }
     __device__ __forceinline__ int32_t* cnt_owner() const { return cnt_match() + COLDP(Cg)->total_dom; }
@@ -142,6 +143,15 @@ __device__ bool gpu_feasible(const int64_t* used, int cnt, int64_t node_total, i
         while (idle >= req_mem && got < req_num) { ++got; idle -= req_mem; }
     }
     return got == req_num;
+}
+// Largest idle memory over a node's devices: a one-device request fits iff this is >= its gpu-mem (the req_num == 1
+// branch of gpu_feasible), so Filter reads ONE int64 per node instead of the 64-byte row.
+__device__ int64_t gpu_max_idle(const int64_t* used, int cnt, int64_t node_total) {
+    if (cnt <= 0) return 0;
+    const int64_t dev_total = node_total / cnt;
+    int64_t m = dev_total - used[0];
+    for (int d = 1; d < cnt; ++d) { const int64_t idle = dev_total - used[d]; m = idle > m ? idle : m; }
+    return m;
 }
 __device__ void gpu_commit(int64_t* used, int cnt, int64_t node_total, int64_t req_mem, int req_num) {
     if (!gpu_feasible(used, cnt, node_total, req_mem, req_num)) return;
@@ -524,9 +534,11 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
         if (!((A.flags & kArgNzeq) != 0u)) { v.nz_cpu()[j] = COLD(A)->i_nz_cpu[j]; v.nz_mem()[j] = COLD(A)->i_nz_mem[j]; }
         v.npods[j] = COLD(A)->i_npods[j];
         for (int k = 0; k < K; ++k) v.scalar()[(size_t)k * N + j] = COLD(A)->i_scalar_req[(size_t)k * N + j];
-        if (((A.flags & kArgGpu) != 0u))
+        if (((A.flags & kArgGpu) != 0u)) {
             for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d)
                 v.gpu()[(size_t)j * SIMON_MAX_GPU_DEV + d] = COLD(A)->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d];
+            v.gmax()[j] = gpu_max_idle(COLD(A)->i_gpu_used + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j]);
+        }
     }
     if (LOCAL && (A.flags & kArgLocal)) {
         for (int j = tid; j < n; j += T) {
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     int32_t* place = A.placement ? A.placement + (size_t)s * P : nullptr;
     int next_pid = P > 0 ? order[0] : 0;
 
-    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
 #define SIMON_PROF(slot) do { if (A.flags & kArgProf) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf[slot] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int i = 0; i < P; ++i) {
         const int pid = next_pid;
@@ -620,6 +632,8 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                 hard_min = Hard4{-r[0], -r[1], -r[2], -r[3]};
             }
             // ---------------- stage A: filter + base score + reductions --------------------------------
+            // static filters of this lane's nodes: ONE word of the lane-major mask (bit it = node tid + it*T)
+            const unsigned mbits = A.mask_lanes ? A.mask_lanes[(size_t)p.cls * T + tid] : 0xFFFFFFFFu;
             const bool ipa = p.flags & kPodIpa;
             const bool soft = p.flags & kPodSoft;
             const bool local = p.flags & kPodLocal;
@@ -693,10 +707,11 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                     bool mk[kUT];
 #pragma unroll
                     for (int u = 0; u < kUT; ++u) {
-                        const int j = tid + (it0 + u) * T, jj = j < n ? j : n - 1;
+                        const int j = tid + (it0 + u) * T;
+                        const unsigned jj = (unsigned)(j < n ? j : n - 1);
                         b[u] = trow[jj];
                         ncl[u] = A.node_class[jj];
-                        mk[u] = mask_bit(A, p.cls, jj);
+                        mk[u] = (mbits >> (it0 + u)) & 1u;
                     }
                     if (!has_rest) {
 #pragma unroll
@@ -755,7 +770,13 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                             for (int u = 0; u < kUT; ++u)
                                 if (act[u] && local_eval<false>(A, v, p, jn[u]).code != 0u) act[u] = false;
                         }
-                        if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0) {                                       // open-gpu-share.go:51-81
+                        if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.gpu_cnt == 1) {                    // one device: the summary answers
+                            long long gm[kUT];
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) gm[u] = v.gmax()[(unsigned)jn[u]];
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) act[u] = act[u] && gm[u] >= p.gpu_mem;
+                        } else if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0) {                                // open-gpu-share.go:51-81
                             long long gt[kUT];
                             int gc[kUT];
 #pragma unroll
@@ -781,7 +802,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                         const int j = tid + (it0 + u) * T, jj = j < n ? j : n - 1;
                         L[u] = load_state(A, v, jj);
                         ncl[u] = A.node_class[jj];
-                        mk[u] = mask_bit(A, p.cls, jj);
+                        mk[u] = (mbits >> (it0 + u)) & 1u;
                     }
 #pragma unroll
                     for (int u = 0; u < kU; ++u) {
@@ -793,7 +814,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                 }
             }
             const int cm = 8, cs = soft ? 1 + n_soft : 0;      // sums start at slot 8; max slots: 4 base, +2 InterPodAffinity, +2 Open-Local
-            SIMON_PROF(5);
+            SIMON_PROF(has_rest ? ((p.flags & kPodTerms) ? 7 : 6) : 5);
             if (refill && tid < Cn) {   // publish the class rows before the stage-A barrier
                 s_rows[tid] = rv0; s_rows[Cn + tid] = rv1; s_rows[2 * Cn + tid] = rv2; s_rows[3 * Cn + tid] = rv3;
             }
@@ -1027,7 +1048,10 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                 // pods carry no gpu-index annotation here and are not accounted
                 if ((p.flags & kPodLocal) && p.preset < 0) (void)local_eval<true>(A, v, p, j);      // LocalPlugin.Bind (open-local.go:180-253)
                 if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.preset < 0)
+                {
                     gpu_commit(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j], p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt);
+                    v.gmax()[j] = gpu_max_idle(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j]);
+                }
                 if (place) place[pid] = j;
             }
             if (use_tab) {
@@ -1043,7 +1067,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     }
 #undef SIMON_PROF
     if ((A.flags & kArgProf) && lane == 0)
-        for (int k = 0; k < 6; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 8 + k] = pf[k];
+        for (int k = 0; k < 8; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 8 + k] = pf[k];
 
     long long uc = 0, um = 0, uv = 0;
     for (int j = tid; j < n; j += T) {
@@ -1064,6 +1088,33 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
         if (A.used_vg) A.used_vg[s] = uv;
         if (EXPLAIN) *COLD(A)->n_failed = unsched;
     }
+}
+
+// Lane-major copy of the static mask for workgroup size T: out[cls][tid] bit it = mask bit of node tid + it*T.
+// Stage A then needs one coalesced word per pod and lane instead of one 64-bit mask word per node.
+__global__ void mask_lanes_kernel(const uint64_t* __restrict__ mask, int mask_words, int N, int T, uint32_t* __restrict__ out) {
+    const int cls = blockIdx.x;
+    for (int tid = threadIdx.x; tid < T; tid += blockDim.x) {
+        unsigned bits = 0;
+        for (int it = 0; it < kMaxIter; ++it) {
+            const long long j = tid + (long long)it * T;
+            if (j < N && ((mask[(size_t)cls * mask_words + (j >> 6)] >> (j & 63)) & 1ull)) bits |= 1u << it;
+        }
+        out[(size_t)cls * T + tid] = bits;
+    }
+}
+
+int ensure_mask_lanes(WideDevice& w, const HostInputs& in, int T, hipStream_t st, std::string& err) {
+    if (!in.has_mask) return 0;
+    if (w.mask_lanes && w.mask_lanes_T == T) return 0;
+    if (w.mask_lanes) { (void)hipFree(w.mask_lanes); w.mask_lanes = nullptr; }
+    hipError_t e = hipMalloc((void**)&w.mask_lanes, (size_t)std::max(in.Cp, 1) * T * 4);
+    if (e != hipSuccess) { err = std::string("hipMalloc(mask lanes): ") + hipGetErrorString(e); return SIMON_ENOMEM; }
+    hipLaunchKernelGGL(mask_lanes_kernel, dim3(std::max(in.Cp, 1)), dim3(256), 0, st, w.static_mask, (int)((in.N + 63) / 64), in.N, T, w.mask_lanes);
+    e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("mask lanes launch: ") + hipGetErrorString(e); return SIMON_ENODEV; }
+    w.mask_lanes_T = T;
+    return 0;
 }
 
 template <bool EXPLAIN>
@@ -1112,7 +1163,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
               (in.Cn <= 64 ? kArgClassMode : 0u) | (!in.has_add ? kArgKey32 : 0u) | (in.Tm > 0 ? kArgTerms : 0u) |
               (in.has_local ? kArgLocal : 0u);
     a.alloc_cpu = w.alloc_cpu; a.alloc_mem = w.alloc_mem; a.alloc_pods = w.alloc_pods; a.node_class = w.node_class;
-    a.static_mask = w.static_mask; a.simon_raw = w.simon_raw;
+    a.static_mask = w.static_mask; a.simon_raw = w.simon_raw; a.mask_lanes = nullptr;
     a.pods = w.pods; a.sigs = w.sigs; a.n_sigs = w.n_sigs; a.tab_nstride = (in.N + 63) & ~63;
     a.tab_stride = (size_t)std::max(w.n_sigs, 1) * a.tab_nstride; a.st_tab = w.st_tab;
     a.st_req_cpu = w.st_req_cpu; a.st_req_mem = w.st_req_mem; a.st_npods = w.st_npods;
@@ -1134,7 +1185,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     c.sh_first_reg = w.sh_first_reg; c.ss_off = w.ss_off; c.ss_idx = w.ss_idx; c.ss_skew = w.ss_skew;
     c.topo_is_hostname = w.topo_is_hostname; c.spread_log = w.spread_log; c.key_seen_off = w.key_seen_off;
     c.st_req_eph = w.st_req_eph; c.st_nz_cpu = w.st_nz_cpu; c.st_nz_mem = w.st_nz_mem; c.st_scalar = w.st_scalar;
-    c.st_gpu = w.st_gpu; c.st_cnt = w.st_cnt; c.st_seen = w.st_seen;
+    c.st_gpu = w.st_gpu; c.st_gmax = w.st_gmax; c.st_cnt = w.st_cnt; c.st_seen = w.st_seen;
     c.l_flags = w.l_flags; c.l_vg_cnt = w.l_vg_cnt; c.l_vg_cap = w.l_vg_cap; c.l_vg_name = w.l_vg_name; c.i_vg_req = w.i_vg_req;
     c.l_dev_cnt = w.l_dev_cnt; c.l_dev_cap = w.l_dev_cap; c.l_dev_media = w.l_dev_media; c.i_dev_alloc = w.i_dev_alloc;
     c.l_spec_of = w.l_spec_of; c.l_specs = w.l_specs; c.st_vg = w.st_vg; c.st_dev = w.st_dev;
@@ -1142,7 +1193,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
 
 size_t state_bytes_per_scenario(const WideDevice& w, const HostInputs& in) {
     const size_t N = in.N;
-    return N * (5 * 8 + 4) + (size_t)std::max(in.K, 1) * N * 8 + (in.has_gpu ? N * SIMON_MAX_GPU_DEV * 8 : 8) +
+    return N * (5 * 8 + 4) + (size_t)std::max(in.K, 1) * N * 8 + (in.has_gpu ? N * (SIMON_MAX_GPU_DEV + 1) * 8 : 16) +
            (size_t)std::max(3 * w.total_dom + in.Tm, 1) * 4 + (size_t)std::max(w.seen_stride, 1) * 4 +
            (size_t)std::max(w.n_sigs, 1) * ((N + 63) & ~(size_t)63) + (in.has_local ? N * (SIMON_MAX_VG * 8 + 4) : 16);
 }
@@ -1150,10 +1201,10 @@ size_t state_bytes_per_scenario(const WideDevice& w, const HostInputs& in) {
 void** state_slots(WideDevice& w, int i) {
     void** slots[] = {(void**)&w.st_req_cpu, (void**)&w.st_req_mem, (void**)&w.st_req_eph, (void**)&w.st_nz_cpu,
                       (void**)&w.st_nz_mem, (void**)&w.st_npods, (void**)&w.st_scalar, (void**)&w.st_gpu, (void**)&w.st_cnt,
-                      (void**)&w.st_seen, (void**)&w.st_tab, (void**)&w.st_vg, (void**)&w.st_dev};
+                      (void**)&w.st_seen, (void**)&w.st_tab, (void**)&w.st_vg, (void**)&w.st_dev, (void**)&w.st_gmax};
     return slots[i];
 }
-constexpr int kStateSlots = 13;
+constexpr int kStateSlots = 14;
 
 int ensure_state(WideDevice& w, const HostInputs& in, int chunk, std::string& err) {
     if (chunk <= w.state_chunk) return 0;
@@ -1165,7 +1216,8 @@ int ensure_state(WideDevice& w, const HostInputs& in, int chunk, std::string& er
                                        C * (size_t)std::max(3 * w.total_dom + in.Tm, 1) * 4,
                                        C * (size_t)std::max(w.seen_stride, 1) * 4,
                                        C * (size_t)std::max(w.n_sigs, 1) * ((N + 63) & ~(size_t)63),
-                                       C * (in.has_local ? N * SIMON_MAX_VG * 8 : 8), C * (in.has_local ? N * 4 : 8)};
+                                       C * (in.has_local ? N * SIMON_MAX_VG * 8 : 8), C * (in.has_local ? N * 4 : 8),
+                                       C * (in.has_gpu ? N * 8 : 8)};
     for (int i = 0; i < kStateSlots; ++i) {
         hipError_t e = hipMalloc(state_slots(w, i), sizes[i]);
         if (e != hipSuccess) { err = std::string("hipMalloc(state): ") + hipGetErrorString(e); return SIMON_ENOMEM; }
@@ -1182,6 +1234,8 @@ void WideDevice::release() {
     for (int i = 0; i < kStateSlots; ++i) { void** sl = state_slots(*this, i); if (*sl) { (void)hipFree(*sl); *sl = nullptr; } }
     state_chunk = 0;
     if (d_cold) { (void)hipFree(d_cold); d_cold = nullptr; }
+    if (mask_lanes) { (void)hipFree(mask_lanes); mask_lanes = nullptr; }
+    mask_lanes_T = 0;
 }
 
 int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string& err) {
@@ -1322,9 +1376,12 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     int chunk = (int)std::min<size_t>(S, std::max<size_t>(1, budget / per));
     int rc = ensure_state(w, in, chunk, err);
     if (rc) return rc;
+    rc = ensure_mask_lanes(w, in, T, st, err);
+    if (rc) return rc;
     WideArgs a;
     WideCold c;
     fill_args(w, in, a, c);
+    a.mask_lanes = w.mask_lanes;
     a.orders = d_orders;
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
     unsigned long long* d_prof = nullptr;
@@ -1348,18 +1405,19 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
         hipError_t e = launch<false>(a, T, max_n, st);
         if (e != hipSuccess) { err = std::string("wide launch: ") + hipGetErrorString(e); return SIMON_ENODEV; }
     }
-    if (d_prof) {   // diagnostics: mean s_memtime ticks per cycle and phase (100 MHz constant clock on gfx9)
+    if (d_prof) {   // diagnostics: mean s_memtime ticks per cycle and phase (s_memtime advances at about the shader clock on gfx950: the phase sums match the kernel time at ~2.4 GHz)
         std::vector<unsigned long long> h((size_t)S * 16 * 8);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(d_prof);
-        const char* names[6] = {"pod row", "reduce+barrier", "stage A2", "stage B + reduce", "assume + column", "stage A nodes"};
+        const char* names[8] = {"pod row", "reduce+barrier", "stage A2", "stage B + reduce", "assume + column", "stage A (table only)",
+                                "stage A (node filters)", "stage A (topology terms)"};
         const int NWv = T / 64;
         for (int w : {0, NWv - 1}) {
-            double sum[6] = {0, 0, 0, 0, 0, 0};
-            for (int s = 0; s < S; ++s) for (int k = 0; k < 6; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 8 + k];
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < S; ++s) for (int k = 0; k < 8; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 8 + k];
             fprintf(stderr, "[SIMON_WIDE_PROF] wave %d, ticks per cycle:", w);
-            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
             fprintf(stderr, "\n");
         }
     }
@@ -1387,7 +1445,10 @@ int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t
     TRY(hipMemsetAsync(d_nf, 0, 4, st));
     WideArgs a;
     WideCold c;
+    rc = ensure_mask_lanes(w, in, T, st, err);
+    if (rc) return rc;
     fill_args(w, in, a, c);
+    a.mask_lanes = w.mask_lanes;
     a.S = 1; a.scen = (const WideScenario*)d_scen; a.orders = (const int32_t*)d_order;
     a.bc_words = (std::max(n_nodes, 1) + 3) & ~3;
     a.n_sigs = 0;   // failure codes come from the full per-node evaluation
