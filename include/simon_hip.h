@@ -345,6 +345,13 @@ int simon_run_batch(simon_ctx* ctx, const simon_scenario* scen, int32_t S, const
  * lexicographic minimum. */
 int simon_min_plan(simon_ctx* ctx, int32_t max_cpu_pct, int32_t max_mem_pct, simon_plan* best);
 
+/* The same search with the third cap of satisfyResourceSetting: MaxVG (pkg/apply/apply.go:712-716, 747-771): the
+ * Open-Local volume-group occupancy int(float64(sum requested) / float64(sum capacity) * 100) over the scenario's
+ * storage nodes, checked only when that capacity is non-zero.  vg_pct (may be NULL) receives the winning scenario's
+ * value (0 without local storage).  simon_min_plan == max_vg_pct 100. */
+int simon_min_plan_vg(simon_ctx* ctx, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
+                      int32_t* vg_pct);
+
 /* Re-run ONE scenario and dump, for every pod that ends unscheduled, the per-node failure code
  * (SIMON_FAIL_*), from which the host rebuilds FitError.Error()'s reason histogram
  * (V/core/generic_scheduler.go:72-90).  fail_codes is [max_failed][n_nodes of that scenario];

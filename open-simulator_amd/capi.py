@@ -444,7 +444,7 @@ _LIB = None
 EXPORTS = [
     "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
-    "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_explain",
+    "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain",
     "simon_get_stats", "simon_device_results",
 ]
 
@@ -478,6 +478,7 @@ def load_library(path: Optional[str] = None):
     lib.simon_fetch_placement.argtypes = [vp, C.c_int32, _p32]
     lib.simon_run_batch.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32, C.POINTER(BatchOut)]
     lib.simon_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(Plan)]
+    lib.simon_min_plan_vg.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
     lib.simon_explain.argtypes = [vp, Scenario, _p32, _p32, _pu16, C.c_int32]
     lib.simon_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.simon_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -580,6 +581,13 @@ class Context:
         self._check(self.lib.simon_min_plan(self.h, int(max_cpu_pct), int(max_mem_pct), C.byref(plan)),
                     "simon_min_plan")
         return plan
+
+    def min_plan_vg(self, max_cpu_pct: int = 100, max_mem_pct: int = 100, max_vg_pct: int = 100):
+        """simon_min_plan with the MaxVG cap; returns (Plan, vg_pct of the winning scenario)."""
+        plan, vg = Plan(), C.c_int32(0)
+        self._check(self.lib.simon_min_plan_vg(self.h, int(max_cpu_pct), int(max_mem_pct), int(max_vg_pct), C.byref(plan),
+                                               C.byref(vg)), "simon_min_plan_vg")
+        return plan, int(vg.value)
 
     def explain(self, n_nodes: int, order: np.ndarray, max_failed: int = 64):
         order = np.ascontiguousarray(order, dtype=np.int32)

@@ -101,7 +101,8 @@ struct simon_ctx : simon::HostInputs {
     hipStream_t band_stream[8] = {};
     hipEvent_t band_ev[8] = {}, fork_ev = nullptr;
     DevBuf<uint64_t> d_mask;
-    DevBuf<int64_t> d_prefix_cpu, d_prefix_mem;
+    DevBuf<int64_t> d_prefix_cpu, d_prefix_mem, d_prefix_vg;
+    std::vector<int64_t> prefix_vg;   // [N+1] Open-Local VG capacity of the first n nodes (0 without local storage)
     WideDevice wide;
     // scenarios
     int S = 0, n_orders = 0, max_n = 0;
@@ -313,8 +314,16 @@ int stage(simon_ctx* c) {
     // prefix sums of allocatable for the occupancy caps (satisfyResourceSetting, apply.go:737-760)
     std::vector<int64_t> pc(c->N + 1, 0), pm(c->N + 1, 0);
     for (int j = 0; j < c->N; ++j) { pc[j + 1] = pc[j] + c->alloc_cpu[j]; pm[j + 1] = pm[j] + c->alloc_mem[j]; }
+    c->prefix_vg.assign(c->N + 1, 0);
+    for (int j = 0; j < c->N; ++j) {
+        int64_t cap = 0;
+        if (c->has_local && (c->l_flags[j] & 1))
+            for (int q = 0; q < c->l_vg_cnt[j]; ++q) cap += c->l_vg_cap[(size_t)j * SIMON_MAX_VG + q];
+        c->prefix_vg[j + 1] = c->prefix_vg[j] + cap;
+    }
     HIP_TRY(c, c->d_prefix_cpu.upload(pc, c->stream));
     HIP_TRY(c, c->d_prefix_mem.upload(pm, c->stream));
+    HIP_TRY(c, c->d_prefix_vg.upload(c->prefix_vg, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->wide_staged = false;
     int rc = c->variant == SIMON_KERNEL_NARROW ? stage_narrow(c) : wide_stage(c->wide, *c, c->stream, c->err);
@@ -328,7 +337,8 @@ int stage(simon_ctx* c) {
 __global__ void plan_kernel(const ScenarioDesc* __restrict__ scen, int S, const int32_t* __restrict__ unsched,
                             const int64_t* __restrict__ used_cpu, const int64_t* __restrict__ used_mem,
                             const int64_t* __restrict__ prefix_cpu, const int64_t* __restrict__ prefix_mem, int max_cpu,
-                            int max_mem, unsigned long long* __restrict__ out) {
+                            int max_mem, const int64_t* __restrict__ used_vg, const int64_t* __restrict__ prefix_vg, int max_vg,
+                            unsigned long long* __restrict__ out) {
     unsigned long long best = ~0ull;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += gridDim.x * blockDim.x) {
         if (unsched[s] != 0) continue;
@@ -337,6 +347,8 @@ __global__ void plan_kernel(const ScenarioDesc* __restrict__ scen, int S, const 
         const int cpu = (int)((double)used_cpu[s] / (double)prefix_cpu[n] * 100.0);
         const int mem = (int)((double)(used_mem[s] * 1000) / (double)(prefix_mem[n] * 1000) * 100.0);
         if (cpu > max_cpu || mem > max_mem) continue;
+        if (used_vg && prefix_vg[n] != 0 &&                      // MaxVG, apply.go:767-771
+            (int)((double)used_vg[s] / (double)prefix_vg[n] * 100.0) > max_vg) continue;
         const unsigned long long key = ((unsigned long long)(unsigned)n << 32) | (unsigned)s;
         best = key < best ? key : best;
     }
@@ -768,7 +780,15 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         }
     } else {
-        T = c->force_T ? c->force_T : (c->max_n <= 1024 ? 256 : c->max_n <= 16384 ? 512 : 1024);
+        // Workgroup shape of the all-feature kernel.  A 256-thread group fits twice on a CU (launch bounds 256 x 2: two
+        // independent barrier domains per SIMD), which wins as soon as the batch offers two groups per CU; with fewer
+        // scenarios than that a CU holds ONE group and the 512-thread shape keeps all four SIMDs at two waves.
+        // Measured on config 5 (50 000 pods x 2 500..5 000 nodes): S = 256: 512 threads 536 ms, 256 threads 734 ms;
+        // S = 1 024: 512 threads 2 033 ms, 256 threads 1 611 ms.
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        const bool two_groups = S >= 2 * n_cu && c->max_n <= 8192;          // 32 nodes per lane at most
+        T = c->force_T ? c->force_T : (c->max_n <= 1024 || two_groups ? 256 : c->max_n <= 16384 ? 512 : 1024);
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
                           c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p, c->d_used_vg.p,
@@ -837,7 +857,14 @@ int simon_run_batch(simon_ctx* c, const simon_scenario* scen, int32_t S, const i
 }
 
 int simon_min_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, simon_plan* best) {
+    return simon_min_plan_vg(c, max_cpu_pct, max_mem_pct, 100, best, nullptr);
+}
+
+int simon_min_plan_vg(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
+                      int32_t* vg_pct) {
     if (!c || !best) return SIMON_EINVAL;
+    if (vg_pct) *vg_pct = 0;
+    if (max_vg_pct > 100 || max_vg_pct < 0) max_vg_pct = 100;
     if (!c->have_results) return fail(c, SIMON_ESTATE, "min_plan: nothing has run");
     HIP_TRY(c, hipSetDevice(c->device));
     if (max_cpu_pct > 100 || max_cpu_pct < 0) max_cpu_pct = 100;  // apply.go:698-700
@@ -846,7 +873,7 @@ int simon_min_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, simon
     const int blocks = std::min(64, (c->S + 255) / 256);
     hipLaunchKernelGGL(plan_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scen.p, c->S, c->d_unsched.p,
                        c->d_used_cpu.p, c->d_used_mem.p, c->d_prefix_cpu.p, c->d_prefix_mem.p, max_cpu_pct, max_mem_pct,
-                       c->d_plan.p);
+                       c->has_local ? c->d_used_vg.p : nullptr, c->d_prefix_vg.p, max_vg_pct, c->d_plan.p);
     HIP_TRY(c, hipGetLastError());
     unsigned long long key = 0;
     HIP_TRY(c, hipMemcpyAsync(&key, c->d_plan.p, sizeof key, hipMemcpyDeviceToHost, c->stream));
@@ -865,6 +892,11 @@ int simon_min_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, simon
     best->cpu_pct = (int)((double)uc / (double)ac * 100.0);
     best->mem_pct = (int)((double)(um * 1000) / (double)(am * 1000) * 100.0);
     best->used_cpu = uc; best->used_mem = um;
+    if (vg_pct && c->has_local && c->prefix_vg[n] != 0) {
+        int64_t uv = 0;
+        HIP_TRY(c, hipMemcpy(&uv, c->d_used_vg.p + s, 8, hipMemcpyDeviceToHost));
+        *vg_pct = (int)((double)uv / (double)c->prefix_vg[n] * 100.0);
+    }
     return SIMON_OK;
 }
 

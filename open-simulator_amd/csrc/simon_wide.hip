@@ -498,7 +498,7 @@ __device__ __forceinline__ long long pts_raw(const WideArgs& A, const NodeView& 
 }
 
 template <int T, bool EXPLAIN, bool LOCAL>
-__global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
+__global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArgs A) {
     constexpr int NW = T / 64;
     __shared__ long long mbox[2][NW][kRed];
     __shared__ unsigned long long mbK[2][NW];
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     int32_t* place = A.placement ? A.placement + (size_t)s * P : nullptr;
     int next_pid = P > 0 ? order[0] : 0;
 
-    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
 #define SIMON_PROF(slot) do { if (A.flags & kArgProf) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf[slot] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int i = 0; i < P; ++i) {
         const int pid = next_pid;
@@ -1015,6 +1015,8 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
             const bool owner = (j % T) == tid;
             NodeLoads L = load_state(A, v, j);
             NodeExtra X = load_extra(A, v, j);
+            if ((A.flags & kArgProf) && L.np == -123456789) continue;   // the row has arrived before the timestamp
+            SIMON_PROF(8);
             L.rc += p.req_cpu; L.rm += p.req_mem; L.np += 1;
             if (((A.flags & kArgNzeq) != 0u)) { L.zc = L.rc; L.zm = L.rm; } else { L.zc += p.nz_cpu; L.zm += p.nz_mem; }
             X.re += p.req_eph;
@@ -1054,12 +1056,14 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
                 }
                 if (place) place[pid] = j;
             }
+            SIMON_PROF(9);
             if (use_tab) {
                 for (int k = lane; k < A.n_sigs; k += 64) {
                     const WideSig q = A.sigs[k];
                     tab[(size_t)k * nstride + j] = fit_bits(A, q, L, X) ? 0 : (unsigned char)(1u + base_score(q, L));
                 }
             }
+            SIMON_PROF(10);
         }
         // node rows are private to their owner lane; only the shared topology counters need a barrier
         if (p.flags & kPodTerms) __syncthreads();
@@ -1067,7 +1071,7 @@ __global__ __launch_bounds__(T) void wide_kernel(const WideArgs A) {
     }
 #undef SIMON_PROF
     if ((A.flags & kArgProf) && lane == 0)
-        for (int k = 0; k < 8; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 8 + k] = pf[k];
+        for (int k = 0; k < 12; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 16 + k] = pf[k];
 
     long long uc = 0, um = 0, uv = 0;
     for (int j = tid; j < n; j += T) {
@@ -1386,7 +1390,7 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
     unsigned long long* d_prof = nullptr;
     const bool prof = getenv("SIMON_WIDE_PROF") != nullptr && chunk >= S;
-    if (prof && hipMalloc((void**)&d_prof, (size_t)S * 16 * 8 * 8) == hipSuccess) {
+    if (prof && hipMalloc((void**)&d_prof, (size_t)S * 16 * 16 * 8) == hipSuccess) {
         (void)hipMemsetAsync(d_prof, 0, (size_t)S * 16 * 8 * 8, st);
         c.prof = d_prof;
         a.flags |= kArgProf;
@@ -1406,18 +1410,19 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
         if (e != hipSuccess) { err = std::string("wide launch: ") + hipGetErrorString(e); return SIMON_ENODEV; }
     }
     if (d_prof) {   // diagnostics: mean s_memtime ticks per cycle and phase (s_memtime advances at about the shader clock on gfx950: the phase sums match the kernel time at ~2.4 GHz)
-        std::vector<unsigned long long> h((size_t)S * 16 * 8);
+        std::vector<unsigned long long> h((size_t)S * 16 * 16);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(d_prof);
-        const char* names[8] = {"pod row", "reduce+barrier", "stage A2", "stage B + reduce", "assume + column", "stage A (table only)",
-                                "stage A (node filters)", "stage A (topology terms)"};
+        const char* names[12] = {"pod row", "reduce+barrier", "stage A2", "stage B + reduce", "assume: counter barrier", "stage A (table only)",
+                                 "stage A (node filters)", "stage A (topology terms)", "assume: row load", "assume: row stores + counters",
+                                 "assume: column", "-"};
         const int NWv = T / 64;
         for (int w : {0, NWv - 1}) {
-            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = 0; s < S; ++s) for (int k = 0; k < 8; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 8 + k];
+            double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < S; ++s) for (int k = 0; k < 12; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 16 + k];
             fprintf(stderr, "[SIMON_WIDE_PROF] wave %d, ticks per cycle:", w);
-            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
+            for (int k = 0; k < 11; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
             fprintf(stderr, "\n");
         }
     }

@@ -736,9 +736,22 @@ static int occupancy_pct(int64_t used_milli, int64_t alloc_milli) {
 int simon_oracle_min_plan(const simon_nodes_soa* nodes, const simon_scenario* scen, int32_t S,
                           const simon_batch_out* out, int32_t max_cpu_pct, int32_t max_mem_pct,
                           simon_plan* best) {
+    return simon_oracle_min_plan_vg(nodes, scen, S, out, max_cpu_pct, max_mem_pct, 100, best, NULL);
+}
+
+int simon_oracle_min_plan_vg(const simon_nodes_soa* nodes, const simon_scenario* scen, int32_t S,
+                             const simon_batch_out* out, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct,
+                             simon_plan* best, int32_t* vg_pct) {
     int N = nodes->n_nodes;
-    int64_t* pc = xcalloc(N + 1, 8); int64_t* pm = xcalloc(N + 1, 8);
-    for (int j = 0; j < N; j++) { pc[j + 1] = pc[j] + nodes->alloc_cpu[j]; pm[j + 1] = pm[j] + nodes->alloc_mem[j]; }
+    int64_t* pc = xcalloc(N + 1, 8); int64_t* pm = xcalloc(N + 1, 8); int64_t* pv = xcalloc(N + 1, 8);
+    for (int j = 0; j < N; j++) {
+        pc[j + 1] = pc[j] + nodes->alloc_cpu[j]; pm[j + 1] = pm[j] + nodes->alloc_mem[j];
+        pv[j + 1] = pv[j];
+        if (nodes->local_flags && (nodes->local_flags[j] & 1))        /* totalVGResource.Capacity, apply.go:747-756 */
+            for (int q = 0; q < nodes->local_vg_cnt[j]; q++) pv[j + 1] += nodes->local_vg_cap[(size_t)j * SIMON_MAX_VG + q];
+    }
+    if (vg_pct) *vg_pct = 0;
+    if (max_vg_pct > 100 || max_vg_pct < 0) max_vg_pct = 100;
     memset(best, 0, sizeof(*best));
     best->scenario = -1;
     if (max_cpu_pct > 100 || max_cpu_pct < 0) max_cpu_pct = 100;   /* apply.go:698-700 */
@@ -749,12 +762,15 @@ int simon_oracle_min_plan(const simon_nodes_soa* nodes, const simon_scenario* sc
         int cpu = occupancy_pct(out->used_cpu[s], pc[n]);
         int mem = occupancy_pct(out->used_mem[s] * 1000, pm[n] * 1000);
         if (cpu > max_cpu_pct || mem > max_mem_pct) continue;
+        int vg = (out->used_vg && pv[n] != 0) ? occupancy_pct(out->used_vg[s], pv[n]) : 0;   /* apply.go:767-771 */
+        if (vg > max_vg_pct) continue;
         if (!best->found || n < best->n_nodes) {
             best->found = 1; best->scenario = s; best->n_nodes = n; best->order_id = scen[s].order_id;
             best->cpu_pct = cpu; best->mem_pct = mem; best->used_cpu = out->used_cpu[s]; best->used_mem = out->used_mem[s];
+            if (vg_pct) *vg_pct = vg;
         }
     }
-    free(pc); free(pm);
+    free(pc); free(pm); free(pv);
     return 0;
 }
 

@@ -50,6 +50,10 @@ int simon_oracle_score_pod_after(const simon_nodes_soa* nodes, const simon_pods_
 int simon_oracle_min_plan(const simon_nodes_soa* nodes, const simon_scenario* scen, int32_t S,
                           const simon_batch_out* out, int32_t max_cpu_pct, int32_t max_mem_pct,
                           simon_plan* best);
+/* ... with the MaxVG cap (pkg/apply/apply.go:712-716, 747-771); vg_pct may be NULL. */
+int simon_oracle_min_plan_vg(const simon_nodes_soa* nodes, const simon_scenario* scen, int32_t S,
+                             const simon_batch_out* out, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct,
+                             simon_plan* best, int32_t* vg_pct);
 
 /* apiresource.Quantity as (unscaled int64 value, decimal scale) or (value, binary) -- enough of
  * vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go to restate SimonPlugin.Score. */

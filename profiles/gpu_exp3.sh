@@ -4,7 +4,7 @@ set -u
 TAG=${1:-exp3}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
-export SIMON_WG=512
+export SIMON_WG=${WG:-512}
 SIMON_WIDE_PROF=1 timeout 300 python bench.py --workload config5 --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/prof.json" 2> "$OUT/prof.err"
 grep SIMON_WIDE_PROF "$OUT/prof.err"
 for S in ${SCENS:-256 512 1024}; do

@@ -104,6 +104,19 @@ def score_pod_after(prob: capi.Problem, n_nodes: int, n_before: int, pod: int, o
     return best, out
 
 
+def min_plan_vg(prob: capi.Problem, scen, res: capi.BatchResult, max_cpu=100, max_mem=100, max_vg=100):
+    lib = load()
+    scen = capi.scenarios_array(scen)
+    n = prob.c_nodes()
+    out = res.c_out()
+    plan, vg = capi.Plan(), C.c_int32(0)
+    lib.simon_oracle_min_plan_vg.restype = C.c_int
+    rc = lib.simon_oracle_min_plan_vg(C.byref(n), scen.ctypes.data_as(C.POINTER(capi.Scenario)), C.c_int32(len(scen)),
+                                      C.byref(out), C.c_int32(max_cpu), C.c_int32(max_mem), C.c_int32(max_vg), C.byref(plan), C.byref(vg))
+    assert rc == 0
+    return plan, int(vg.value)
+
+
 def min_plan(prob: capi.Problem, scen, res: capi.BatchResult, max_cpu=100, max_mem=100) -> capi.Plan:
     lib = load()
     scen = capi.scenarios_array(scen)

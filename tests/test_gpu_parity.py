@@ -352,6 +352,25 @@ def test_min_plan_matches_oracle():
             assert a.as_dict() == b.as_dict(), caps
 
 
+def test_min_plan_with_the_vg_cap_matches_oracle():
+    """MaxVG (pkg/apply/apply.go:712-771) on the device: Open-Local problem, node-count sweep, caps from loose to strict."""
+    prob = randprob.rand_problem(7, N=120, P=30, local=True, tight_pods=False)
+    scen = np.array([[n, 0] for n in range(16, 121, 8)], np.int32)
+    orders = np.arange(prob.n_pods, dtype=np.int32)[None]
+    ref = O.run(prob, scen, orders, want_placement=False)
+    seen = set()
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders, want_placement=False)
+        assert_same(res, ref)
+        for vg_cap in (100, 30, 8, 7, 6, 5, 4, 0):
+            (a, va), (b, vb) = ctx.min_plan_vg(100, 100, vg_cap), O.min_plan_vg(prob, scen, ref, 100, 100, vg_cap)
+            assert a.as_dict() == b.as_dict() and va == vb, vg_cap
+            seen.add((a.found, a.n_nodes))
+        assert ctx.min_plan(100, 100).as_dict() == O.min_plan(prob, scen, ref).as_dict()
+    assert len(seen) >= 2, "the caps never changed the answer: the test does not exercise MaxVG"
+
+
 def test_size_independent_properties_full_batch():
     """Whole config-3 batch (4096 scenarios): properties that hold without the oracle."""
     prob, scen, orders = synth.config3()

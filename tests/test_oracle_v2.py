@@ -201,3 +201,30 @@ def test_go_log_matches_published_values():
     assert go_log(2.0) == 0.6931471805599453
     assert go_log(10.0) == 2.302585092994046
     assert abs(go_log(6.0) - 1.791759469228055) < 3e-16
+
+
+def test_min_plan_vg_cap_rule():
+    """satisfyResourceSetting's third cap (pkg/apply/apply.go:747-771): requested / capacity of the volume groups of the
+    scenario's storage nodes, int(float64 * 100), skipped when the capacity is 0."""
+    GiB = 1 << 30
+    N = 4
+    prob = capi.Problem(alloc_cpu=np.full(N, 8000, np.int64), alloc_mem=np.full(N, 16 * GiB, np.int64), alloc_pods=np.full(N, 10, np.int32),
+                        node_class=np.zeros(N, np.int32), req_cpu=np.array([100], np.int64), req_mem=np.array([GiB], np.int64),
+                        pod_class=np.zeros(1, np.int32), n_pod_classes=1, n_node_classes=1, simon_raw=np.zeros((1, 1), np.int64),
+                        const_score=np.zeros(1, np.int64),
+                        local_flags=np.array([1, 1, 0, 1], np.int32), local_vg_cnt=np.array([1, 2, 0, 1], np.int32),
+                        local_vg_cap=np.array([[100, 0, 0, 0], [100, 100, 0, 0], [0, 0, 0, 0], [700, 0, 0, 0]], np.int64) * GiB,
+                        init_vg_req=np.array([[90, 0, 0, 0], [30, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], np.int64) * GiB,
+                        local_vg_name=np.zeros((N, capi.MAX_VG), np.int32), local_dev_cnt=np.zeros(N, np.int32),
+                        local_dev_cap=np.zeros((N, capi.MAX_LDEV), np.int64), local_dev_media=np.zeros(N, np.int32),
+                        init_dev_alloc=np.zeros(N, np.int32), local_spec_of=np.full(1, -1, np.int32),
+                        local_specs=np.zeros(1, capi.LOCAL_SPEC_DTYPE)).normalise()
+    scen = np.array([[1, 0], [2, 0], [3, 0], [4, 0]], np.int32)
+    res = O.run(prob, scen, np.zeros((1, 1), np.int32))
+    assert res.unscheduled.tolist() == [0, 0, 0, 0]
+    assert res.used_vg.tolist() == [90 * GiB, 120 * GiB, 120 * GiB, 120 * GiB]          # requested of the annotation counts
+    # occupancy: 90/100 = 90, 120/300 = 40, 120/300 = 40 (node 2 has no storage), 120/1000 = 12
+    for cap, want_n, want_pct in ((100, 1, 90), (89, 2, 40), (40, 2, 40), (39, 4, 12), (11, None, 0)):
+        plan, pct = O.min_plan_vg(prob, scen, res, 100, 100, cap)
+        assert (plan.n_nodes if plan.found else None) == want_n and pct == want_pct, cap
+    assert O.min_plan(prob, scen, res).n_nodes == 1
