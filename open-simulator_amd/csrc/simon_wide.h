@@ -49,6 +49,15 @@ struct HostInputs {
     }
 };
 
+// Static half of a node's resource row, one 32-byte load: allocatable cpu / memory and their correctly rounded
+// reciprocals RN(1 / alloc) (host IEEE division), from which the kernel forms the exact quotients req / alloc of
+// BalancedAllocation with two Markstein corrections (simon_device.h: div_by_rcp) instead of an IEEE division sequence.
+struct WideNodeStatic {
+    int64_t alloc_cpu, alloc_mem;
+    double rcp_cpu, rcp_mem;
+};
+static_assert(sizeof(WideNodeStatic) == 32, "WideNodeStatic must be 32 bytes");
+
 // One pod of the stream, WIDE layout (128 B).
 struct WidePod {
     int64_t req_cpu, req_mem, req_eph, nz_cpu, nz_mem, gpu_mem;
@@ -129,7 +138,7 @@ struct WideArgs {
     uint32_t flags;                         // kArg* bits
     size_t tab_stride /*bytes per scenario*/;
     // static node arrays [N] (shared)
-    const int64_t* alloc_cpu; const int64_t* alloc_mem; const int32_t* alloc_pods; const int32_t* node_class;
+    const WideNodeStatic* node_static; const int32_t* alloc_pods; const int32_t* node_class;
     const uint64_t* static_mask; const int64_t* simon_raw;
     const uint32_t* mask_lanes /*[Cp][T]: bit it = static mask of node tid + it*T (lane-major copy of static_mask), or null*/;
     // stream
@@ -151,7 +160,8 @@ struct WideDevice {
     int total_dom = 0, seen_stride = 0;
     bool has_eph = false, nzeq = false;
     // typed views
-    int64_t *alloc_cpu = nullptr, *alloc_mem = nullptr, *alloc_eph = nullptr, *scalar_alloc = nullptr, *gpu_mem_total = nullptr;
+    WideNodeStatic* node_static = nullptr;
+    int64_t *alloc_eph = nullptr, *scalar_alloc = nullptr, *gpu_mem_total = nullptr;
     int32_t *alloc_pods = nullptr, *node_class = nullptr, *gpu_cnt = nullptr, *topo_dom = nullptr;
     int64_t *i_req_cpu = nullptr, *i_req_mem = nullptr, *i_req_eph = nullptr, *i_nz_cpu = nullptr, *i_nz_mem = nullptr,
             *i_scalar_req = nullptr, *i_gpu_used = nullptr;

@@ -213,6 +213,7 @@ __device__ __forceinline__ long long la_from_frac(long long cap, long long req, 
 struct NodeLoads {
     int np, ap;
     long long rc, rm, ac, am, zc, zm;
+    double kc, km;     // RN(1 / ac), RN(1 / am)
 };
 // Ephemeral storage and extended resources: loaded only when the problem uses them.
 struct NodeExtra {
@@ -224,7 +225,8 @@ __device__ __forceinline__ NodeLoads load_state(const WideArgs& A, const NodeVie
     NodeLoads L;
     L.np = v.npods[j]; L.ap = A.alloc_pods[j];
     L.rc = v.req_cpu[j]; L.rm = v.req_mem[j];
-    L.ac = A.alloc_cpu[j]; L.am = A.alloc_mem[j];
+    const WideNodeStatic ns = A.node_static[j];
+    L.ac = ns.alloc_cpu; L.am = ns.alloc_mem; L.kc = ns.rcp_cpu; L.km = ns.rcp_mem;
     L.zc = L.rc; L.zm = L.rm;
     if (!((A.flags & kArgNzeq) != 0u)) { L.zc = v.nz_cpu()[j]; L.zm = v.nz_mem()[j]; }
     return L;
@@ -272,8 +274,10 @@ template <class Q>
 __device__ __forceinline__ unsigned base_score(const Q& q, const NodeLoads& L) {
     const long long ac = L.ac, am = L.am;
     const long long r_c = L.zc + q.nz_cpu, r_m = L.zm + q.nz_mem;
-    const double cf = ac == 0 ? 1.0 : (double)r_c / (double)ac;
-    const double mf = am == 0 ? 1.0 : (double)r_m / (double)am;
+    // correctly rounded r / alloc from the node's stored reciprocal (exact for every int64 operand pair below 2^53:
+    // oracle/../tests check it against '/', and 2e8 random + adversarial pairs on the CPU)
+    const double cf = ac == 0 ? 1.0 : div_by_rcp((double)r_c, (double)ac, L.kc);
+    const double mf = am == 0 ? 1.0 : div_by_rcp((double)r_m, (double)am, L.km);
     const long long la_c = (ac == 0 || r_c > ac) ? 0 : la_from_frac(ac, r_c, cf);
     const long long la_m = (am == 0 || r_m > am) ? 0 : la_from_frac(am, r_m, mf);
     long long ba = 0;
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             if (use_tab) {
                 // NodeResourcesFit + LeastAllocated + BalancedAllocation come from the table row of the pod's signature
                 const unsigned char* trow = tab + (size_t)p.sig * nstride;
+                if (!has_rest) SIMON_PROF(11);               // cycle setup of a table-only pod (class rows, flags)
                 for (int it0 = 0; it0 * T < n; it0 += kUT) {
                     unsigned b[kUT];
                     int ncl[kUT];
@@ -714,6 +719,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         mk[u] = (mbits >> (it0 + u)) & 1u;
                     }
                     if (!has_rest) {
+                        if ((A.flags & kArgProf) && (b[0] + b[kUT - 1] + (unsigned)ncl[kUT - 1] + mbits == 0xFFFFFFF1u)) continue;   // batch has arrived
+                        SIMON_PROF(2);
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) {
                             const int j = tid + (it0 + u) * T;
@@ -1166,7 +1173,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     a.flags = (in.has_gpu ? kArgGpu : 0u) | (in.has_mask ? kArgMask : 0u) | (w.has_eph ? kArgEph : 0u) | (w.nzeq ? kArgNzeq : 0u) |
               (in.Cn <= 64 ? kArgClassMode : 0u) | (!in.has_add ? kArgKey32 : 0u) | (in.Tm > 0 ? kArgTerms : 0u) |
               (in.has_local ? kArgLocal : 0u);
-    a.alloc_cpu = w.alloc_cpu; a.alloc_mem = w.alloc_mem; a.alloc_pods = w.alloc_pods; a.node_class = w.node_class;
+    a.node_static = w.node_static; a.alloc_pods = w.alloc_pods; a.node_class = w.node_class;
     a.static_mask = w.static_mask; a.simon_raw = w.simon_raw; a.mask_lanes = nullptr;
     a.pods = w.pods; a.sigs = w.sigs; a.n_sigs = w.n_sigs; a.tab_nstride = (in.N + 63) & ~63;
     a.tab_stride = (size_t)std::max(w.n_sigs, 1) * a.tab_nstride; a.st_tab = w.st_tab;
@@ -1337,7 +1344,13 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     }
     int rc = 0;
 #define PUT(field, vec, minc) if ((rc = put(w, w.field, vec, minc, st, err))) return rc
-    PUT(alloc_cpu, in.alloc_cpu, N); PUT(alloc_mem, in.alloc_mem, N); PUT(alloc_eph, in.alloc_eph, N);
+    {
+        std::vector<WideNodeStatic> ns(N);
+        for (size_t j = 0; j < N; ++j)
+            ns[j] = WideNodeStatic{in.alloc_cpu[j], in.alloc_mem[j], 1.0 / (double)in.alloc_cpu[j], 1.0 / (double)in.alloc_mem[j]};
+        PUT(node_static, ns, N);
+    }
+    PUT(alloc_eph, in.alloc_eph, N);
     PUT(alloc_pods, in.alloc_pods, N); PUT(node_class, in.node_class, N); PUT(scalar_alloc, in.scalar_alloc, 1);
     PUT(gpu_cnt, in.gpu_cnt, N); PUT(gpu_mem_total, in.gpu_mem_total, N); PUT(topo_dom, in.topo_dom, 1);
     PUT(i_req_cpu, in.i_req_cpu, N); PUT(i_req_mem, in.i_req_mem, N); PUT(i_req_eph, in.i_req_eph, N);
@@ -1414,15 +1427,15 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(d_prof);
-        const char* names[12] = {"pod row", "reduce+barrier", "stage A2", "stage B + reduce", "assume: counter barrier", "stage A (table only)",
+        const char* names[12] = {"pod row", "reduce+barrier", "stage A2 | table-only: batch wait", "stage B + reduce", "assume: counter barrier", "stage A (table only)",
                                  "stage A (node filters)", "stage A (topology terms)", "assume: row load", "assume: row stores + counters",
-                                 "assume: column", "-"};
+                                 "assume: column", "table-only: setup"};
         const int NWv = T / 64;
         for (int w : {0, NWv - 1}) {
             double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int s = 0; s < S; ++s) for (int k = 0; k < 12; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 16 + k];
             fprintf(stderr, "[SIMON_WIDE_PROF] wave %d, ticks per cycle:", w);
-            for (int k = 0; k < 11; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
+            for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
             fprintf(stderr, "\n");
         }
     }

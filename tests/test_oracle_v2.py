@@ -6,6 +6,8 @@ Anchors: the formulas of vendor/k8s.io/kubernetes/pkg/scheduler/framework/plugin
 nodeaffinity,tainttoleration}; the PodTopologySpread vector 2/1/0/3 -> 40/80/100/0 is the expectation of upstream
 kubernetes v1.20 podtopologyspread/scoring_test.go "one constraint on node, all 4 nodes are candidates" (the vendored
 tree strips *_test.go, so it is restated here)."""
+import os
+
 import numpy as np
 
 import oracle_lib as O
@@ -228,3 +230,15 @@ def test_min_plan_vg_cap_rule():
         plan, pct = O.min_plan_vg(prob, scen, res, 100, 100, cap)
         assert (plan.n_nodes if plan.found else None) == want_n and pct == want_pct, cap
     assert O.min_plan(prob, scen, res).n_nodes == 1
+
+
+def test_reciprocal_division_is_the_ieee_quotient():
+    """The kernels form req / alloc from a stored reciprocal (div_by_rcp); oracle/div_by_rcp_check.c compares it with the
+    IEEE division on int64-range operands (random, aligned, near 1, tiny, far above 1, all-ones significands)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "div_by_rcp_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "div_by_rcp_check"])
+    out = subprocess.run([exe, "150000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert " 0 mismatches" in out.stdout
