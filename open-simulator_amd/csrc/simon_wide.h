@@ -151,7 +151,8 @@ struct WideArgs {
     const WideCold* cold;
 };
 constexpr uint32_t kArgGpu = 1u, kArgMask = 2u, kArgEph = 4u, kArgNzeq = 8u, kArgClassMode = 16u /*Cn <= 64*/,
-                   kArgKey32 = 32u /*32-bit arg-max key*/, kArgProf = 64u, kArgTerms = 128u /*Tm > 0*/, kArgLocal = 256u /*Open-Local*/;
+                   kArgKey32 = 32u /*32-bit arg-max key*/, kArgProf = 64u, kArgTerms = 128u /*Tm > 0*/, kArgLocal = 256u /*Open-Local*/,
+                   kArgLean = 512u /*no spread constraint, scoring term, host port, required affinity or local volume anywhere*/;
 
 struct WideDevice {
     void* blobs[80] = {};

@@ -501,7 +501,9 @@ __device__ __forceinline__ long long pts_raw(const WideArgs& A, const NodeView& 
     return (long long)score;
 }
 
-template <int T, bool EXPLAIN, bool LOCAL>
+// VAR: 0 = lean (pod flags beyond kPodZero | kPodTerms cannot occur: their code folds away and with it ~40 VGPRs of
+// spills), 1 = every plugin except Open-Local, 2 = every plugin
+template <int T, bool EXPLAIN, int VAR>
 __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArgs A) {
     constexpr int NW = T / 64;
     __shared__ long long mbox[2][NW][kRed];
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             v.gmax()[j] = gpu_max_idle(COLD(A)->i_gpu_used + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j]);
         }
     }
+    constexpr bool LOCAL = VAR == 2;
     if (LOCAL && (A.flags & kArgLocal)) {
         for (int j = tid; j < n; j += T) {
 #pragma unroll
@@ -575,7 +578,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
         const int pid = next_pid;
         next_pid = (i + 1 < P) ? order[i + 1] : 0;
         WidePod p = A.pods[pid];
-        if (!LOCAL) p.flags &= ~kPodLocal;          // the Open-Local code folds away in the variant for problems without it
+        if (!LOCAL) p.flags &= ~kPodLocal;          // the Open-Local code folds away in the variants for problems without it
+        if (VAR == 0) p.flags &= (kPodZero | kPodTerms);
         if ((A.flags & kArgProf) && p.cls < 0) continue;   // forces the pod row to have arrived before the timestamp
         SIMON_PROF(0);
         if (p.gate >= n) { if (place && tid == 0) place[pid] = SIMON_GATED; continue; }
@@ -1134,8 +1138,9 @@ hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
     const size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 : 0);
     (void)max_n;
 #define WIDE_LAUNCH(TT)                                                                                   \
-    if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, true>), grid, dim3(TT), lds, st, a); \
-    else hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, false>), grid, dim3(TT), lds, st, a)
+    if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 2>), grid, dim3(TT), lds, st, a);    \
+    else if (!EXPLAIN && (a.flags & kArgLean)) hipLaunchKernelGGL((wide_kernel<TT, false, 0>), grid, dim3(TT), lds, st, a); \
+    else hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 1>), grid, dim3(TT), lds, st, a)
     switch (T) {
         case 64: WIDE_LAUNCH(64); break;
         case 128: WIDE_LAUNCH(128); break;
@@ -1172,7 +1177,9 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     a.mask_words = (in.N + 63) / 64;
     a.flags = (in.has_gpu ? kArgGpu : 0u) | (in.has_mask ? kArgMask : 0u) | (w.has_eph ? kArgEph : 0u) | (w.nzeq ? kArgNzeq : 0u) |
               (in.Cn <= 64 ? kArgClassMode : 0u) | (!in.has_add ? kArgKey32 : 0u) | (in.Tm > 0 ? kArgTerms : 0u) |
-              (in.has_local ? kArgLocal : 0u);
+              (in.has_local ? kArgLocal : 0u) |
+              ((in.sh_idx.empty() && in.ss_idx.empty() && !in.has_ipa_score && in.port_idx.empty() && in.aff_idx.empty() && !in.has_local &&
+                !getenv("SIMON_WIDE_NO_LEAN")) ? kArgLean : 0u);
     a.node_static = w.node_static; a.alloc_pods = w.alloc_pods; a.node_class = w.node_class;
     a.static_mask = w.static_mask; a.simon_raw = w.simon_raw; a.mask_lanes = nullptr;
     a.pods = w.pods; a.sigs = w.sigs; a.n_sigs = w.n_sigs; a.tab_nstride = (in.N + 63) & ~63;
