@@ -436,7 +436,8 @@ def _pkg_dir() -> str:
 
 
 def library_path() -> str:
-    return os.path.join(_pkg_dir(), "csrc", "libsimon_hip.so")
+    """In-tree libsimon_hip.so; SIMON_HIP_LIB names another build of the SAME library (kernel A/B runs, profile builds)."""
+    return os.environ.get("SIMON_HIP_LIB") or os.path.join(_pkg_dir(), "csrc", "libsimon_hip.so")
 
 
 _LIB = None

@@ -572,15 +572,23 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     int32_t* place = A.placement ? A.placement + (size_t)s * P : nullptr;
     int next_pid = P > 0 ? order[0] : 0;
 
+    // Phase profiler: compiled in only with -DSIMON_WIDE_PROFILE (profiles/build_variant.sh); its 12 counters and the
+    // probes that force loads to complete cost registers and waits the product build must not pay.
+#ifdef SIMON_WIDE_PROFILE
+    constexpr bool kProfile = true;
     unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
 #define SIMON_PROF(slot) do { if (A.flags & kArgProf) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf[slot] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+    constexpr bool kProfile = false;
+#define SIMON_PROF(slot) do { } while (0)
+#endif
     for (int i = 0; i < P; ++i) {
         const int pid = next_pid;
         next_pid = (i + 1 < P) ? order[i + 1] : 0;
         WidePod p = A.pods[pid];
         if (!LOCAL) p.flags &= ~kPodLocal;          // the Open-Local code folds away in the variants for problems without it
         if (VAR == 0) p.flags &= (kPodZero | kPodTerms);
-        if ((A.flags & kArgProf) && p.cls < 0) continue;   // forces the pod row to have arrived before the timestamp
+        if (kProfile && (A.flags & kArgProf) && p.cls < 0) continue;   // forces the pod row to have arrived before the timestamp
         SIMON_PROF(0);
         if (p.gate >= n) { if (place && tid == 0) place[pid] = SIMON_GATED; continue; }
         int jstar;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         mk[u] = (mbits >> (it0 + u)) & 1u;
                     }
                     if (!has_rest) {
-                        if ((A.flags & kArgProf) && (b[0] + b[kUT - 1] + (unsigned)ncl[kUT - 1] + mbits == 0xFFFFFFF1u)) continue;   // batch has arrived
+                        if (kProfile && (A.flags & kArgProf) && (b[0] + b[kUT - 1] + (unsigned)ncl[kUT - 1] + mbits == 0xFFFFFFF1u)) continue;   // batch has arrived
                         SIMON_PROF(2);
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) {
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             const bool owner = (j % T) == tid;
             NodeLoads L = load_state(A, v, j);
             NodeExtra X = load_extra(A, v, j);
-            if ((A.flags & kArgProf) && L.np == -123456789) continue;   // the row has arrived before the timestamp
+            if (kProfile && (A.flags & kArgProf) && L.np == -123456789) continue;   // the row has arrived before the timestamp
             SIMON_PROF(8);
             L.rc += p.req_cpu; L.rm += p.req_mem; L.np += 1;
             if (((A.flags & kArgNzeq) != 0u)) { L.zc = L.rc; L.zm = L.rm; } else { L.zc += p.nz_cpu; L.zm += p.nz_mem; }
@@ -1081,8 +1089,10 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
         SIMON_PROF(4);
     }
 #undef SIMON_PROF
+#ifdef SIMON_WIDE_PROFILE
     if ((A.flags & kArgProf) && lane == 0)
         for (int k = 0; k < 12; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 16 + k] = pf[k];
+#endif
 
     long long uc = 0, um = 0, uv = 0;
     for (int j = tid; j < n; j += T) {
@@ -1409,7 +1419,12 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     a.orders = d_orders;
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
     unsigned long long* d_prof = nullptr;
+#ifdef SIMON_WIDE_PROFILE
     const bool prof = getenv("SIMON_WIDE_PROF") != nullptr && chunk >= S;
+#else
+    const bool prof = false;
+    if (getenv("SIMON_WIDE_PROF")) fprintf(stderr, "[SIMON_WIDE_PROF] this build has no phase profiler: bash profiles/build_variant.sh prof -DSIMON_WIDE_PROFILE\n");
+#endif
     if (prof && hipMalloc((void**)&d_prof, (size_t)S * 16 * 16 * 8) == hipSuccess) {
         (void)hipMemsetAsync(d_prof, 0, (size_t)S * 16 * 8 * 8, st);
         c.prof = d_prof;
