@@ -153,27 +153,36 @@ __device__ int64_t gpu_max_idle(const int64_t* used, int cnt, int64_t node_total
     for (int d = 1; d < cnt; ++d) { const int64_t idle = dev_total - used[d]; m = idle > m ? idle : m; }
     return m;
 }
-__device__ void gpu_commit(int64_t* used, int cnt, int64_t node_total, int64_t req_mem, int req_num) {
-    if (!gpu_feasible(used, cnt, node_total, req_mem, req_num)) return;
+// Reserve (open-gpu-share.go:147-188) on a register copy of the node's row (u[d] with static indices only).
+__device__ __forceinline__ void gpu_commit_regs(int64_t (&u)[SIMON_MAX_GPU_DEV], int cnt, int64_t node_total, int64_t req_mem, int req_num) {
+    if (req_mem <= 0 || req_num <= 0 || cnt <= 0) return;
     const int64_t dev_total = node_total / cnt;
     if (req_num == 1) {                                   // tightest fit, lowest id on ties (:255-267)
         int cand = -1;
         int64_t cand_mem = 0;
-        for (int d = 0; d < cnt; ++d) {
-            const int64_t idle = dev_total - used[d];
-            if (idle >= req_mem && (cand < 0 || idle < cand_mem)) { cand = d; cand_mem = idle; }
+#pragma unroll
+        for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) {
+            const int64_t idle = dev_total - u[d];
+            if (d < cnt && idle >= req_mem && (cand < 0 || idle < cand_mem)) { cand = d; cand_mem = idle; }
         }
-        used[cand] += req_mem;
+#pragma unroll
+        for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) u[d] += (d == cand) ? req_mem : 0;
         return;
     }
-    int dev = 0, got = 0;                                 // the feasible walk again, committing each slice
-    int64_t idle = dev_total - used[0];
-    while (dev < cnt && got < req_num) {
-        if (idle >= req_mem) { ++got; idle -= req_mem; used[dev] += req_mem; }
-        else { ++dev; if (dev < cnt) idle = dev_total - used[dev]; }
+    int64_t w[SIMON_MAX_GPU_DEV];                         // two-pointer greedy (:268-287) on a copy, kept only when it completes
+    int got = 0;
+#pragma unroll
+    for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) {
+        w[d] = u[d];
+        if (d >= cnt) continue;
+        int64_t idle = dev_total - w[d];
+        while (idle >= req_mem && got < req_num) { ++got; idle -= req_mem; w[d] += req_mem; }
+    }
+    if (got == req_num) {
+#pragma unroll
+        for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) u[d] = w[d];
     }
 }
-
 __device__ __forceinline__ bool in_set(const WideArgs& A, int set, int j) {
     if (set < 0) return true;
     return (COLD(A)->node_sets[(size_t)set * A.mask_words + (j >> 6)] >> (j & 63)) & 1ull;
@@ -515,11 +524,17 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     // class's rows of the four (pod class, node class) tables as int64 [4][Cn]
     extern __shared__ __attribute__((aligned(16))) unsigned s_bc[];
     int64_t* const s_rows2 = (int64_t*)(s_bc + A.bc_words);
+    // per-thread per-class best keys of the single-pass cycle: s_kc[c * T + tid], updated with an LDS max (one LDS
+    // instruction per feasible node instead of a compare/select chain over the classes; -4 % on config 5), swapped out
+    // against 0 once per cycle
+    unsigned* const s_kc = (unsigned*)(s_rows2 + (((A.flags & kArgClassMode) != 0u) ? 2 * 4 * A.Cn : 0));
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int s = blockIdx.x;
     const int n = A.scen[s].n_nodes;
     const int N = A.N, P = A.P, K = A.K, Cn = A.Cn;
+    if (((A.flags & kArgClassMode) != 0u) && Cn <= 8)
+        for (int c = 0; c < Cn; ++c) s_kc[c * T + tid] = 0u;
     const int32_t* order = A.orders + (size_t)A.scen[s].order_id * P;
     const bool class_mode = ((A.flags & kArgClassMode) != 0u);
     const bool use_tab = !EXPLAIN && A.n_sigs > 0;
@@ -666,14 +681,10 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             // the first maximum of the base score inside the class (the class terms are constant there), so ONE
             // reduction of per-class keys replaces stage B and its barrier.
             const bool fast1 = class_mode && Cn <= 8 && ((A.flags & kArgKey32) != 0u) && !ipa && !soft && !local;
-            unsigned kc0 = 0, kc1 = 0, kc2 = 0, kc3 = 0, kc4 = 0, kc5 = 0, kc6 = 0, kc7 = 0;
             auto on_feasible = [&](int j, int it, unsigned base, int nc) {
                 if (fast1) {
                     const unsigned kk = (base << 22) | (0x3FFFFFu - (unsigned)j);
-                    kc0 = (nc == 0 && kk > kc0) ? kk : kc0; kc1 = (nc == 1 && kk > kc1) ? kk : kc1;
-                    kc2 = (nc == 2 && kk > kc2) ? kk : kc2; kc3 = (nc == 3 && kk > kc3) ? kk : kc3;
-                    kc4 = (nc == 4 && kk > kc4) ? kk : kc4; kc5 = (nc == 5 && kk > kc5) ? kk : kc5;
-                    kc6 = (nc == 6 && kk > kc6) ? kk : kc6; kc7 = (nc == 7 && kk > kc7) ? kk : kc7;
+                    (void)__hip_atomic_fetch_max(&s_kc[nc * T + tid], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     return;
                 }
                 feas |= 1u << it;
@@ -841,9 +852,10 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             bool none;
             if (fast1) {
                 // per-class first maxima of (base, canonical index): wave DPP max, then one mailbox row per wave
-                const unsigned w0 = wave_max_u32(kc0), w1 = Cn > 1 ? wave_max_u32(kc1) : 0u, w2 = Cn > 2 ? wave_max_u32(kc2) : 0u,
-                               w3 = Cn > 3 ? wave_max_u32(kc3) : 0u, w4 = Cn > 4 ? wave_max_u32(kc4) : 0u, w5 = Cn > 5 ? wave_max_u32(kc5) : 0u,
-                               w6 = Cn > 6 ? wave_max_u32(kc6) : 0u, w7 = Cn > 7 ? wave_max_u32(kc7) : 0u;
+                auto take = [&](int c) { return __hip_atomic_exchange(&s_kc[c * T + tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+                const unsigned w0 = wave_max_u32(take(0)), w1 = Cn > 1 ? wave_max_u32(take(1)) : 0u, w2 = Cn > 2 ? wave_max_u32(take(2)) : 0u,
+                               w3 = Cn > 3 ? wave_max_u32(take(3)) : 0u, w4 = Cn > 4 ? wave_max_u32(take(4)) : 0u, w5 = Cn > 5 ? wave_max_u32(take(5)) : 0u,
+                               w6 = Cn > 6 ? wave_max_u32(take(6)) : 0u, w7 = Cn > 7 ? wave_max_u32(take(7)) : 0u;
                 const int c = lane & 7;                      // this lane's class in the final combine (8 replicas per wave)
                 unsigned m = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : c == 3 ? w3 : c == 4 ? w4 : c == 5 ? w5 : c == 6 ? w6 : w7;
                 if (NW > 1) {
@@ -1027,26 +1039,57 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
         SIMON_PROF(3);
         // ---------------- assume, NodeInfo.AddPod V/framework/types.go:482-508 ---------------------------
         // The owner's WAVE loads the node's row (uniform address), adds the pod in registers, the owner LANE stores it;
-        // then lane k of that wave refreshes signature k's byte of the node's table column.  Only this wave ever
-        // touches the row and the column, and a wave's memory accesses are served in order.
+        // lane k of that wave refreshes signature k's byte of the node's table column.  Only this wave ever touches
+        // the row and the column, and a wave's memory accesses are served in order.  The wave is the critical path of
+        // the cycle (the others wait for it at the next barrier): all its loads are issued up front as one round trip
+        // and Open-Gpu-Share's Reserve runs on a register copy of the device row (-5 % on config 5).
         if (wave == ((jstar % T) >> 6)) {
             const int j = jstar;
             const bool owner = (j % T) == tid;
+            // every load of the cycle is issued before its first use (uniform addresses, one round trip): signature
+            // row of this lane, the node's GPU device row, the node's load row
+            const bool gpu_pod = ((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.preset < 0;
+            WideSig q0 = {};
+            if (use_tab && lane < A.n_sigs) q0 = A.sigs[lane];
+            int64_t gu[SIMON_MAX_GPU_DEV] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int g_cnt = 0;
+            int64_t g_total = 0;
+            if (gpu_pod) {
+#pragma unroll
+                for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) gu[d] = v.gpu()[(size_t)j * SIMON_MAX_GPU_DEV + d];
+                g_cnt = COLD(A)->gpu_cnt[j]; g_total = COLD(A)->gpu_mem_total[j];
+            }
             NodeLoads L = load_state(A, v, j);
             NodeExtra X = load_extra(A, v, j);
-            if (kProfile && (A.flags & kArgProf) && L.np == -123456789) continue;   // the row has arrived before the timestamp
-            SIMON_PROF(8);
             L.rc += p.req_cpu; L.rm += p.req_mem; L.np += 1;
             if (((A.flags & kArgNzeq) != 0u)) { L.zc = L.rc; L.zm = L.rm; } else { L.zc += p.nz_cpu; L.zm += p.nz_mem; }
             X.re += p.req_eph;
 #pragma unroll
             for (int k = 0; k < SIMON_MAX_SCALAR; ++k) X.sr[k] += p.scalar[k];
+            if (gpu_pod) gpu_commit_regs(gu, g_cnt, g_total, p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt);
+            if (use_tab && lane < A.n_sigs)
+                tab[(size_t)lane * nstride + j] = fit_bits(A, q0, L, X) ? 0 : (unsigned char)(1u + base_score(q0, L));
             if (owner) {
                 v.req_cpu[j] = L.rc; v.req_mem[j] = L.rm; v.npods[j] = L.np;
                 if (!((A.flags & kArgNzeq) != 0u)) { v.nz_cpu()[j] = L.zc; v.nz_mem()[j] = L.zm; }
                 if (((A.flags & kArgEph) != 0u)) v.req_eph()[j] = X.re;
 #pragma unroll
                 for (int k = 0; k < SIMON_MAX_SCALAR; ++k) if (k < K) v.scalar()[(size_t)k * N + j] = X.sr[k];
+                if (gpu_pod) {
+                    int64_t m = 0;
+                    if (g_cnt > 0) {
+                        const int64_t dev_total = g_total / g_cnt;
+                        m = dev_total - gu[0];
+#pragma unroll
+                        for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) {
+                            v.gpu()[(size_t)j * SIMON_MAX_GPU_DEV + d] = gu[d];
+                            const int64_t idle = dev_total - gu[d];
+                            m = (d < g_cnt && idle > m) ? idle : m;
+                        }
+                    }
+                    v.gmax()[j] = m;
+                }
+                if (place) place[pid] = j;
                 if (p.flags & kPodTerms) {
                     for (int e = COLD(A)->match_off[p.cls]; e < COLD(A)->match_off[p.cls + 1]; ++e) {
                         const int t = COLD(A)->match_idx[e];
@@ -1065,24 +1108,14 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         if (d >= 0) v.w_owner()[COLD(A)->term_dom_off[t] + d] += COLD(A)->own_w[e];
                     }
                 }
-                // Open-Gpu-Share Reserve (open-gpu-share.go:147-188): commit the device ids; preset
-                // pods carry no gpu-index annotation here and are not accounted
                 if ((p.flags & kPodLocal) && p.preset < 0) (void)local_eval<true>(A, v, p, j);      // LocalPlugin.Bind (open-local.go:180-253)
-                if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.preset < 0)
-                {
-                    gpu_commit(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j], p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt);
-                    v.gmax()[j] = gpu_max_idle(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], COLD(A)->gpu_mem_total[j]);
-                }
-                if (place) place[pid] = j;
             }
-            SIMON_PROF(9);
             if (use_tab) {
-                for (int k = lane; k < A.n_sigs; k += 64) {
+                for (int k = lane + 64; k < A.n_sigs; k += 64) {
                     const WideSig q = A.sigs[k];
                     tab[(size_t)k * nstride + j] = fit_bits(A, q, L, X) ? 0 : (unsigned char)(1u + base_score(q, L));
                 }
             }
-            SIMON_PROF(10);
         }
         // node rows are private to their owner lane; only the shared topology counters need a barrier
         if (p.flags & kPodTerms) __syncthreads();
@@ -1145,7 +1178,7 @@ int ensure_mask_lanes(WideDevice& w, const HostInputs& in, int T, hipStream_t st
 template <bool EXPLAIN>
 hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
     dim3 grid(a.S);
-    const size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 : 0);
+    const size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 + (a.Cn <= 8 ? (size_t)a.Cn * T * 4 : 0) : 0);
     (void)max_n;
 #define WIDE_LAUNCH(TT)                                                                                   \
     if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 2>), grid, dim3(TT), lds, st, a);    \
