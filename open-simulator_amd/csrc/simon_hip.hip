@@ -694,7 +694,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
         bool use_cache = c->cache_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kCacheMaxNodes;
-        auto lds_of = [&](int ni) { return cache_lds_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq); };
+        // SIMON_CACHE_LDS_PAD (bytes): occupancy experiment knob -- extra LDS per workgroup lowers the waves per CU
+        static const size_t lds_pad = getenv("SIMON_CACHE_LDS_PAD") ? (size_t)atol(getenv("SIMON_CACHE_LDS_PAD")) : 0;
+        auto lds_of = [&](int ni) { return cache_lds_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad; };
         auto ws_of = [&](int ni) { return cache_ws_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq); };
         if (use_cache) {
             int ni_top = 0;
