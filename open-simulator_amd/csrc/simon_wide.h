@@ -79,7 +79,8 @@ struct WideSig {
 static_assert(sizeof(WideSig) == 96, "WideSig must be 96 bytes");
 constexpr int kMaxWideSigs = 1024;   // more distinct signatures than this: the kernel evaluates every node every cycle
 constexpr uint32_t kPodZero = 1u;      // all-zero request incl. scalars (fit.go:244-249)
-constexpr uint32_t kPodTerms = 2u;     // class touches topology counters (match / anti / aff / own lists non-empty)
+constexpr uint32_t kPodTerms = 2u;     // class touches topology counters at assume (match / anti / aff / own lists non-empty)
+constexpr uint32_t kPodFilt = 128u;    // class has an InterPodAffinity FILTER to evaluate per node (anti, owned-anti match or required affinity)
 constexpr uint32_t kPodHard = 4u;      // class has DoNotSchedule spread constraints
 constexpr uint32_t kPodSoft = 8u;      // class has ScheduleAnyway spread constraints
 constexpr uint32_t kPodIpa = 16u;      // InterPodAffinity.Score can be non-zero for this class
@@ -107,6 +108,9 @@ struct WideCold {
     const int32_t* term_key; const int32_t* term_dom_off /*[Tm] offset of term t's counters*/;
     const int32_t* term_set /*[Tm] row of node_sets or -1*/; const uint64_t* node_sets;
     const int32_t* anti_off; const int32_t* anti_idx; const int32_t* match_off; const int32_t* match_idx;
+    // match lists restricted to the terms some class OWNS as required anti-affinity (only those have cnt_owner != 0) resp.
+    // as a scoring term (only those have w_owner != 0): what Filter's "existing pods" check and Score's symmetry walk read
+    const int32_t* manti_off; const int32_t* manti_idx; const int32_t* mown_off; const int32_t* mown_idx;
     const int32_t* aff_off; const int32_t* aff_idx; const uint8_t* class_flags;
     const int32_t* port_off; const int32_t* port_idx;
     const int32_t* pref_off; const int32_t* pref_idx; const int32_t* pref_w;
@@ -170,7 +174,7 @@ struct WideDevice {
     uint64_t* static_mask = nullptr; uint8_t* static_reason = nullptr; int64_t* simon_raw = nullptr;
     int64_t *na_raw = nullptr, *tt_raw = nullptr, *static_add = nullptr;
     int32_t *term_key = nullptr, *term_dom_off = nullptr, *term_set = nullptr, *anti_off = nullptr, *anti_idx = nullptr,
-            *match_off = nullptr, *match_idx = nullptr, *aff_off = nullptr, *aff_idx = nullptr, *port_off = nullptr, *port_idx = nullptr, *pref_off = nullptr,
+            *match_off = nullptr, *match_idx = nullptr, *manti_off = nullptr, *manti_idx = nullptr, *mown_off = nullptr, *mown_idx = nullptr, *aff_off = nullptr, *aff_idx = nullptr, *port_off = nullptr, *port_idx = nullptr, *pref_off = nullptr,
             *pref_idx = nullptr, *pref_w = nullptr, *own_off = nullptr, *own_idx = nullptr, *own_w = nullptr,
             *sh_off = nullptr, *sh_idx = nullptr, *sh_skew = nullptr, *sh_self = nullptr, *sh_set = nullptr,
             *sh_first_reg = nullptr, *ss_off = nullptr, *ss_idx = nullptr, *ss_skew = nullptr, *key_seen_off = nullptr;

@@ -423,7 +423,7 @@ __device__ __forceinline__ unsigned head_code(const WideArgs& A, const NodeView&
         }
     }
     // InterPodAffinity.Filter (interpodaffinity/filtering.go:379-401), satisfyPodAffinity (:348-377)
-    if (p.flags & kPodTerms) {
+    if (p.flags & kPodFilt) {
         const int alo = COLD(A)->aff_off[p.cls], ahi = COLD(A)->aff_off[p.cls + 1];
         if (ahi > alo) {
             bool pods_exist = true;
@@ -445,15 +445,16 @@ __device__ __forceinline__ unsigned rest_code(const WideArgs& A, const NodeView&
                                               const Hard4& hard_min) {
     const unsigned h = head_code(A, v, p, j, n, hard_min);
     if (h) return h;
-    // incoming anti-affinity (filtering.go:334-346), then existing pods' anti-affinity (:319-332)
-    if (p.flags & kPodTerms) {
+    // incoming anti-affinity (filtering.go:334-346), then existing pods' anti-affinity (:319-332; only terms some class owns
+    // as required anti-affinity can have owners: the trimmed list)
+    if (p.flags & kPodFilt) {
         for (int e = COLD(A)->anti_off[p.cls]; e < COLD(A)->anti_off[p.cls + 1]; ++e) {
             const int t = COLD(A)->anti_idx[e];
             const int d = term_dom(A, t, j);
             if (d >= 0 && v.cnt_match()[COLD(A)->term_dom_off[t] + d] > 0) return SIMON_FAIL_ANTI_INCOMING;
         }
-        for (int e = COLD(A)->match_off[p.cls]; e < COLD(A)->match_off[p.cls + 1]; ++e) {
-            const int t = COLD(A)->match_idx[e];
+        for (int e = COLD(A)->manti_off[p.cls]; e < COLD(A)->manti_off[p.cls + 1]; ++e) {
+            const int t = COLD(A)->manti_idx[e];
             const int d = term_dom(A, t, j);
             if (d >= 0 && v.cnt_owner()[COLD(A)->term_dom_off[t] + d] > 0) return SIMON_FAIL_ANTI_EXISTING;
         }
@@ -490,8 +491,8 @@ __device__ __forceinline__ long long ipa_raw(const WideArgs& A, const NodeView& 
         const int d = term_dom(A, t, j);
         if (d >= 0) sc += (long long)COLD(A)->pref_w[e] * v.cnt_match()[COLD(A)->term_dom_off[t] + d];
     }
-    for (int e = COLD(A)->match_off[p.cls]; e < COLD(A)->match_off[p.cls + 1]; ++e) {
-        const int t = COLD(A)->match_idx[e];
+    for (int e = COLD(A)->mown_off[p.cls]; e < COLD(A)->mown_off[p.cls + 1]; ++e) {   // terms with owners' weights only
+        const int t = COLD(A)->mown_idx[e];
         const int d = term_dom(A, t, j);
         if (d >= 0) sc += v.w_owner()[COLD(A)->term_dom_off[t] + d];
     }
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
         next_pid = (i + 1 < P) ? order[i + 1] : 0;
         WidePod p = A.pods[pid];
         if (!LOCAL) p.flags &= ~kPodLocal;          // the Open-Local code folds away in the variants for problems without it
-        if (VAR == 0) p.flags &= (kPodZero | kPodTerms);
+        if (VAR == 0) p.flags &= (kPodZero | kPodTerms | kPodFilt);
         if (kProfile && (A.flags & kArgProf) && p.cls < 0) continue;   // forces the pod row to have arrived before the timestamp
         SIMON_PROF(0);
         if (p.gate >= n) { if (place && tid == 0) place[pid] = SIMON_GATED; continue; }
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             const bool soft = p.flags & kPodSoft;
             const bool local = p.flags & kPodLocal;
             const bool extras = ipa || soft || local || !class_mode;
-            const bool has_rest = (p.flags & (kPodHard | kPodTerms | kPodPorts | kPodLocal)) || (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0);
+            const bool has_rest = (p.flags & (kPodHard | kPodFilt | kPodPorts | kPodLocal)) || (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0);
             const int slo = soft ? COLD(A)->ss_off[p.cls] : 0, n_soft = soft ? COLD(A)->ss_off[p.cls + 1] - slo : 0;
             unsigned feas = 0, ign = 0;
             unsigned long long cmask = 0;
@@ -766,12 +767,12 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             for (int u = 0; u < kUT; ++u)
                                 if (act[u] && ports_conflict(A, v, p, jn[u])) act[u] = false;
                         }
-                        if ((p.flags & kPodHard) || ((p.flags & kPodTerms) && COLD(A)->aff_off[p.cls + 1] > COLD(A)->aff_off[p.cls])) {
+                        if ((p.flags & kPodHard) || ((p.flags & kPodFilt) && COLD(A)->aff_off[p.cls + 1] > COLD(A)->aff_off[p.cls])) {
 #pragma unroll
                             for (int u = 0; u < kUT; ++u)
                                 if (act[u] && head_code(A, v, p, jn[u], n, hard_min) != 0u) act[u] = false;
                         }
-                        if (p.flags & kPodTerms) {
+                        if (p.flags & kPodFilt) {
                             for (int e = COLD(A)->anti_off[p.cls]; e < COLD(A)->anti_off[p.cls + 1]; ++e) {   // filtering.go:334-346
                                 const int t = COLD(A)->anti_idx[e], off = COLD(A)->term_dom_off[t];
                                 const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
@@ -783,8 +784,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                                 for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
                             }
-                            for (int e = COLD(A)->match_off[p.cls]; e < COLD(A)->match_off[p.cls + 1]; ++e) { // filtering.go:319-332
-                                const int t = COLD(A)->match_idx[e], off = COLD(A)->term_dom_off[t];
+                            for (int e = COLD(A)->manti_off[p.cls]; e < COLD(A)->manti_off[p.cls + 1]; ++e) { // filtering.go:319-332
+                                const int t = COLD(A)->manti_idx[e], off = COLD(A)->term_dom_off[t];
                                 const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
                                 int d[kUT], cv[kUT];
 #pragma unroll
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                 }
             }
             const int cm = 8, cs = soft ? 1 + n_soft : 0;      // sums start at slot 8; max slots: 4 base, +2 InterPodAffinity, +2 Open-Local
-            SIMON_PROF(has_rest ? ((p.flags & kPodTerms) ? 7 : 6) : 5);
+            SIMON_PROF(has_rest ? ((p.flags & kPodFilt) ? 7 : 6) : 5);
             if (refill && tid < Cn) {   // publish the class rows before the stage-A barrier
                 s_rows[tid] = rv0; s_rows[Cn + tid] = rv1; s_rows[2 * Cn + tid] = rv2; s_rows[3 * Cn + tid] = rv3;
             }
@@ -1238,6 +1239,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     c.static_add = in.has_add ? w.static_add : nullptr;
     c.term_key = w.term_key; c.term_dom_off = w.term_dom_off; c.term_set = w.term_set; c.node_sets = w.node_sets;
     c.anti_off = w.anti_off; c.anti_idx = w.anti_idx; c.match_off = w.match_off; c.match_idx = w.match_idx;
+    c.manti_off = w.manti_off; c.manti_idx = w.manti_idx; c.mown_off = w.mown_off; c.mown_idx = w.mown_idx;
     c.aff_off = w.aff_off; c.aff_idx = w.aff_idx; c.class_flags = w.class_flags;
     c.port_off = w.port_off; c.port_idx = w.port_idx;
     c.pref_off = w.pref_off; c.pref_idx = w.pref_idx; c.pref_w = w.pref_w;
@@ -1328,6 +1330,22 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
                                port_off = csr(in.port_off);
     std::vector<uint8_t> class_flags = in.class_flags;
     class_flags.resize(Cp, 0);
+    // match lists trimmed by role: only a term some class owns as required anti-affinity can have cnt_owner != 0, only a
+    // term some class owns as a scoring term can have w_owner != 0 (a pod typically matches dozens of terms -- every
+    // spread selector and preferred term naming its labels -- and owns-by-others only a few)
+    std::vector<char> is_anti(std::max(in.Tm, 1), 0), is_own(std::max(in.Tm, 1), 0);
+    for (int e = 0; e < anti_off[Cp]; ++e) is_anti[in.anti_idx[e]] = 1;
+    for (int e = 0; e < own_off[Cp]; ++e) is_own[in.own_idx[e]] = 1;
+    std::vector<int32_t> manti_off(Cp + 1, 0), manti_idx, mown_off(Cp + 1, 0), mown_idx;
+    for (int c = 0; c < Cp; ++c) {
+        for (int e = match_off[c]; e < match_off[c + 1]; ++e) {
+            const int32_t t = in.match_idx[e];
+            if (is_anti[t]) manti_idx.push_back(t);
+            if (is_own[t]) mown_idx.push_back(t);
+        }
+        manti_off[c + 1] = (int32_t)manti_idx.size();
+        mown_off[c + 1] = (int32_t)mown_idx.size();
+    }
     std::vector<int32_t> term_set = in.term_set;
     term_set.resize(std::max(in.Tm, 1), -1);
     std::vector<int32_t> sh_set = in.sh_set;
@@ -1390,7 +1408,8 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
             if (sp.n_lvm + sp.n_ssd + sp.n_hdd > 0) r.flags |= kPodLocal;
         }
         if (some(ss_off)) r.flags |= kPodSoft;
-        if (in.has_ipa_score && (some(pref_off) || some(match_off))) r.flags |= kPodIpa;
+        if (in.Tm > 0 && (some(anti_off) || some(manti_off) || some(aff_off))) r.flags |= kPodFilt;
+        if (in.has_ipa_score && (some(pref_off) || some(mown_off))) r.flags |= kPodIpa;
     }
     int rc = 0;
 #define PUT(field, vec, minc) if ((rc = put(w, w.field, vec, minc, st, err))) return rc
@@ -1410,6 +1429,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     PUT(na_raw, in.na_raw, 1); PUT(tt_raw, in.tt_raw, 1); PUT(static_add, in.static_add, 1);
     PUT(term_key, in.term_key, 1); PUT(term_dom_off, dom_off, 1); PUT(term_set, term_set, 1); PUT(node_sets, in.node_sets, 1);
     PUT(anti_off, anti_off, 1); PUT(anti_idx, in.anti_idx, 1); PUT(match_off, match_off, 1); PUT(match_idx, in.match_idx, 1);
+    PUT(manti_off, manti_off, 1); PUT(manti_idx, manti_idx, 1); PUT(mown_off, mown_off, 1); PUT(mown_idx, mown_idx, 1);
     PUT(aff_off, aff_off, 1); PUT(aff_idx, in.aff_idx, 1); PUT(class_flags, class_flags, 1);
     PUT(port_off, port_off, 1); PUT(port_idx, in.port_idx, 1);
     PUT(pref_off, pref_off, 1); PUT(pref_idx, in.pref_idx, 1); PUT(pref_w, in.pref_w, 1);
