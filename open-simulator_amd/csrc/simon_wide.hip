@@ -767,10 +767,42 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             for (int u = 0; u < kUT; ++u)
                                 if (act[u] && ports_conflict(A, v, p, jn[u])) act[u] = false;
                         }
-                        if ((p.flags & kPodHard) || ((p.flags & kPodFilt) && COLD(A)->aff_off[p.cls + 1] > COLD(A)->aff_off[p.cls])) {
+                        if (p.flags & kPodHard) {          // PodTopologySpread.Filter (filtering.go:283-333), as head_code, batched
+                            const int lo = COLD(A)->sh_off[p.cls], hi = COLD(A)->sh_off[p.cls + 1];
+                            for (int e = lo; e < hi; ++e) {
+                                const int t = COLD(A)->sh_idx[e], off = COLD(A)->term_dom_off[t];
+                                const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
+                                const int32_t* rrow = COLD(A)->sh_first_reg + (size_t)e * N;
+                                const long long slack = (long long)COLD(A)->sh_skew[e] - (COLD(A)->sh_self[e] ? 1 : 0) + sel4(hard_min, e - lo);
+                                int d[kUT], rg[kUT], cv[kUT];
 #pragma unroll
-                            for (int u = 0; u < kUT; ++u)
-                                if (act[u] && head_code(A, v, p, jn[u], n, hard_min) != 0u) act[u] = false;
+                                for (int u = 0; u < kUT; ++u) { d[u] = act[u] ? drow[jn[u]] : -1; rg[u] = act[u] ? rrow[jn[u]] : INT_MAX; }
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) cv[u] = (d[u] >= 0 && rg[u] < n) ? v.cnt_match()[off + d[u]] : 0;
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) act[u] = act[u] && d[u] >= 0 && (long long)cv[u] <= slack;   // match + self - min <= maxSkew
+                            }
+                        }
+                        if ((p.flags & kPodFilt) && COLD(A)->aff_off[p.cls + 1] > COLD(A)->aff_off[p.cls]) {   // satisfyPodAffinity (:348-377)
+                            bool exist[kUT];
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) exist[u] = true;
+                            long long total = 0;
+                            for (int e = COLD(A)->aff_off[p.cls]; e < COLD(A)->aff_off[p.cls + 1]; ++e) {
+                                const int t = COLD(A)->aff_idx[e], off = COLD(A)->term_dom_off[t];
+                                const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
+                                int d[kUT], cv[kUT];
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) d[u] = act[u] ? drow[jn[u]] : -1;
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.cnt_match()[off + d[u]] : 0;
+                                total += v.term_total()[t];
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) { act[u] = act[u] && d[u] >= 0; exist[u] = exist[u] && cv[u] > 0; }
+                            }
+                            const bool escape = total == 0 && (COLD(A)->class_flags[p.cls] & SIMON_CLASS_AFF_SELF);   // first pod of a self-affine series
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) act[u] = act[u] && (exist[u] || escape);
                         }
                         if (p.flags & kPodFilt) {
                             for (int e = COLD(A)->anti_off[p.cls]; e < COLD(A)->anti_off[p.cls + 1]; ++e) {   // filtering.go:334-346
@@ -1091,25 +1123,28 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     v.gmax()[j] = m;
                 }
                 if (place) place[pid] = j;
-                if (p.flags & kPodTerms) {
-                    for (int e = COLD(A)->match_off[p.cls]; e < COLD(A)->match_off[p.cls + 1]; ++e) {
-                        const int t = COLD(A)->match_idx[e];
-                        if (!in_set(A, COLD(A)->term_set[t], j)) continue;
-                        const int d = term_dom(A, t, j);
-                        if (d >= 0) { v.cnt_match()[COLD(A)->term_dom_off[t] + d] += 1; v.term_total()[t] += 1; }
-                    }
-                    for (int e = COLD(A)->anti_off[p.cls]; e < COLD(A)->anti_off[p.cls + 1]; ++e) {
-                        const int t = COLD(A)->anti_idx[e];
-                        const int d = term_dom(A, t, j);
-                        if (d >= 0) v.cnt_owner()[COLD(A)->term_dom_off[t] + d] += 1;
-                    }
-                    for (int e = COLD(A)->own_off[p.cls]; e < COLD(A)->own_off[p.cls + 1]; ++e) {
-                        const int t = COLD(A)->own_idx[e];
-                        const int d = term_dom(A, t, j);
-                        if (d >= 0) v.w_owner()[COLD(A)->term_dom_off[t] + d] += COLD(A)->own_w[e];
-                    }
-                }
                 if ((p.flags & kPodLocal) && p.preset < 0) (void)local_eval<true>(A, v, p, j);      // LocalPlugin.Bind (open-local.go:180-253)
+            }
+            // topology counters of the pod's terms: one list entry per LANE of the owner wave (a pod matches dozens of
+            // terms; walking them on one lane was ~30 k cycles of dependent loads per cycle).  A term can appear twice in
+            // a match list (spread selectors with multiplicity): atomics; nobody reads the counters before the barrier.
+            if (p.flags & kPodTerms) {
+                for (int e = COLD(A)->match_off[p.cls] + lane; e < COLD(A)->match_off[p.cls + 1]; e += 64) {
+                    const int t = COLD(A)->match_idx[e];
+                    if (!in_set(A, COLD(A)->term_set[t], j)) continue;
+                    const int d = term_dom(A, t, j);
+                    if (d >= 0) { atomicAdd(&v.cnt_match()[COLD(A)->term_dom_off[t] + d], 1); atomicAdd(&v.term_total()[t], 1); }
+                }
+                for (int e = COLD(A)->anti_off[p.cls] + lane; e < COLD(A)->anti_off[p.cls + 1]; e += 64) {
+                    const int t = COLD(A)->anti_idx[e];
+                    const int d = term_dom(A, t, j);
+                    if (d >= 0) atomicAdd(&v.cnt_owner()[COLD(A)->term_dom_off[t] + d], 1);
+                }
+                for (int e = COLD(A)->own_off[p.cls] + lane; e < COLD(A)->own_off[p.cls + 1]; e += 64) {
+                    const int t = COLD(A)->own_idx[e];
+                    const int d = term_dom(A, t, j);
+                    if (d >= 0) atomicAdd(&v.w_owner()[COLD(A)->term_dom_off[t] + d], COLD(A)->own_w[e]);
+                }
             }
             if (use_tab) {
                 for (int k = lane + 64; k < A.n_sigs; k += 64) {

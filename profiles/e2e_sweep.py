@@ -29,11 +29,14 @@ def main():
     ap.add_argument("--counts", type=int, default=64)
     ap.add_argument("--daemonsets", type=int, default=1)
     ap.add_argument("--check", type=int, default=0)
+    ap.add_argument("--uniform-pods", action="store_true", help="every node allows 110 pods (fewer node classes: the <= 64 class path)")
     a = ap.parse_args()
     nodes, workloads, services = randk8s.rand_cluster(1, n_nodes=a.nodes, n_workloads=a.workloads, max_replicas=a.max_replicas)
     # prefix pools need ONE zone round-robin order: keep zone labels only on a prefix-stable pattern (all nodes zoned, by index)
     for j, n in enumerate(nodes):
         n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"
+        if a.uniform_pods:
+            n["status"]["allocatable"]["pods"] = "110"
     ds = [{"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": f"agent{i}", "namespace": "kube-system"},
            "spec": {"selector": {"matchLabels": {"app": f"agent{i}"}},
                     "template": {"metadata": {"labels": {"app": f"agent{i}"}},
