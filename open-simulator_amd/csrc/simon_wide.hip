@@ -483,32 +483,59 @@ __device__ __forceinline__ unsigned filter_code(const WideArgs& A, const NodeVie
     return rest_code(A, v, p, j, n, hard_min);
 }
 
-// InterPodAffinity.Score raw value (interpodaffinity/scoring.go:87-131,211-236)
-__device__ __forceinline__ long long ipa_raw(const WideArgs& A, const NodeView& v, const WidePod& p, int j) {
-    long long sc = 0;
+// InterPodAffinity.Score raw value (interpodaffinity/scoring.go:87-131,211-236) and PodTopologySpread.Score raw value
+// (podtopologyspread/scoring.go:174-214), for a batch of kUT nodes
+// every term costs two memory round trips for the WHOLE batch (domain row,
+// then counters) instead of two per node.  m[u] = node u takes part; results only for those.  Same integer sums, same
+// order of the floating-point additions per node as the scalar versions.
+__device__ __forceinline__ void ipa_raw8(const WideArgs& A, const NodeView& v, const WidePod& p, const int (&jn)[kUT], const bool (&m)[kUT],
+                                         long long (&out)[kUT]) {
+#pragma unroll
+    for (int u = 0; u < kUT; ++u) out[u] = 0;
     for (int e = COLD(A)->pref_off[p.cls]; e < COLD(A)->pref_off[p.cls + 1]; ++e) {
-        const int t = COLD(A)->pref_idx[e];
-        const int d = term_dom(A, t, j);
-        if (d >= 0) sc += (long long)COLD(A)->pref_w[e] * v.cnt_match()[COLD(A)->term_dom_off[t] + d];
+        const int t = COLD(A)->pref_idx[e], off = COLD(A)->term_dom_off[t];
+        const long long w = COLD(A)->pref_w[e];
+        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * A.N;
+        int d[kUT], cv[kUT];
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.cnt_match()[off + d[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) out[u] += w * cv[u];
     }
-    for (int e = COLD(A)->mown_off[p.cls]; e < COLD(A)->mown_off[p.cls + 1]; ++e) {   // terms with owners' weights only
-        const int t = COLD(A)->mown_idx[e];
-        const int d = term_dom(A, t, j);
-        if (d >= 0) sc += v.w_owner()[COLD(A)->term_dom_off[t] + d];
+    for (int e = COLD(A)->mown_off[p.cls]; e < COLD(A)->mown_off[p.cls + 1]; ++e) {
+        const int t = COLD(A)->mown_idx[e], off = COLD(A)->term_dom_off[t];
+        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * A.N;
+        int d[kUT], cv[kUT];
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.w_owner()[off + d[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) out[u] += cv[u];
     }
-    return sc;
 }
-
-// PodTopologySpread.Score raw value (podtopologyspread/scoring.go:174-214)
-__device__ __forceinline__ long long pts_raw(const WideArgs& A, const NodeView& v, const WidePod& p, int j, const Weight4& weight) {
+__device__ __forceinline__ void pts_raw8(const WideArgs& A, const NodeView& v, const WidePod& p, const int (&jn)[kUT], const bool (&m)[kUT],
+                                         const Weight4& weight, long long (&out)[kUT]) {
     const int lo = COLD(A)->ss_off[p.cls], hi = COLD(A)->ss_off[p.cls + 1];
-    double score = 0.0;
+    double score[kUT];
+#pragma unroll
+    for (int u = 0; u < kUT; ++u) score[u] = 0.0;
     for (int e = lo; e < hi; ++e) {
-        const int t = COLD(A)->ss_idx[e];
-        const long long cnt = v.cnt_match()[COLD(A)->term_dom_off[t] + term_dom(A, t, j)];
-        score += (double)cnt * sel4(weight, e - lo) + (double)((COLD(A)->ss_skew[e] & ~SIMON_SPREAD_DUP_KEY) - 1);     // scoreForCount (:287-289)
+        const int t = COLD(A)->ss_idx[e], off = COLD(A)->term_dom_off[t];
+        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * A.N;
+        const double w = sel4(weight, e - lo), add = (double)((COLD(A)->ss_skew[e] & ~SIMON_SPREAD_DUP_KEY) - 1);
+        int d[kUT], cv[kUT];
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) cv[u] = m[u] ? v.cnt_match()[off + d[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < kUT; ++u) score[u] += (double)(long long)cv[u] * w + add;     // scoreForCount (:287-289)
     }
-    return (long long)score;
+#pragma unroll
+    for (int u = 0; u < kUT; ++u) out[u] = (long long)score[u];
 }
 
 // VAR: 0 = lean (pod flags beyond kPodZero | kPodTerms cannot occur: their code folds away and with it ~40 VGPRs of
@@ -699,29 +726,59 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     if (na_row) { const long long x = na_row[nc]; na_max = x > na_max ? x : na_max; }
                     if (tt_row) { const long long x = tt_row[nc]; tt_max = x > tt_max ? x : tt_max; }
                 }
-                if (ipa) {
-                    const long long x = ipa_raw(A, v, p, j);
-                    ipa_max = x > ipa_max ? x : ipa_max;
-                    ipa_min = x < ipa_min ? x : ipa_min;
-                }
                 if (local) {
                     const long long x = local_eval<false>(A, v, p, j).score;
                     l_hi = x > l_hi ? x : l_hi;
                     l_lo = x < l_lo ? x : l_lo;
                 }
+            };
+            // InterPodAffinity raw score range and PodTopologySpread's pre-score bookkeeping of a batch of feasible nodes
+            // (m[u]): loads grouped per term, one round trip per step for the whole batch
+            auto extras8 = [&](const int (&jn)[kUT], const bool (&m)[kUT], int it0) {
+                if (fast1 || !(ipa || soft)) return;
+                if (ipa) {
+                    long long x[kUT];
+                    ipa_raw8(A, v, p, jn, m, x);
+#pragma unroll
+                    for (int u = 0; u < kUT; ++u) {
+                        if (!m[u]) continue;
+                        ipa_max = x[u] > ipa_max ? x[u] : ipa_max;
+                        ipa_min = x[u] < ipa_min ? x[u] : ipa_min;
+                    }
+                }
                 if (soft) {   // initPreScoreState, podtopologyspread/scoring.go:60-108
-                    bool ignored = false;
-                    for (int q = 0; q < n_soft; ++q) ignored = ignored || term_dom(A, COLD(A)->ss_idx[slo + q], j) < 0;
-                    if (ignored) { ign |= 1u << it; return; }
-                    ++scored;
+                    bool ig[kUT];
+                    int dq[SIMON_MAX_SPREAD][kUT];
+#pragma unroll
+                    for (int u = 0; u < kUT; ++u) ig[u] = false;
+#pragma unroll
+                    for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
+                        if (q >= n_soft) continue;
+                        const int t = COLD(A)->ss_idx[slo + q];
+                        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) dq[q][u] = m[u] ? drow[jn[u]] : 0;
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) ig[u] = ig[u] || dq[q][u] < 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUT; ++u) {
+                        if (!m[u]) continue;
+                        if (ig[u]) ign |= 1u << (it0 + u); else ++scored;
+                    }
 #pragma unroll
                     for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
                         if (q >= n_soft) continue;
                         const int t = COLD(A)->ss_idx[slo + q], key = COLD(A)->term_key[t];
                         if (COLD(A)->topo_is_hostname[key]) continue;
                         const int stamp = i * SIMON_MAX_SPREAD + q + 1;
-                        int* slot = v.seen() + (size_t)q * (COLD(A)->seen_stride / SIMON_MAX_SPREAD) + COLD(A)->key_seen_off[key] + term_dom(A, t, j);
-                        const long long fresh = atomicExch(slot, stamp) != stamp ? 1 : 0;
+                        int* base_slot = v.seen() + (size_t)q * (COLD(A)->seen_stride / SIMON_MAX_SPREAD) + COLD(A)->key_seen_off[key];
+                        int old[kUT];
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) old[u] = (m[u] && !ig[u]) ? atomicExch(base_slot + dq[q][u], stamp) : stamp;
+                        long long fresh = 0;
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) fresh += old[u] != stamp ? 1 : 0;
                         if (q == 0) dst0 += fresh; else if (q == 1) dst1 += fresh; else if (q == 2) dst2 += fresh; else dst3 += fresh;
                     }
                 }
@@ -745,12 +802,16 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     if (!has_rest) {
                         if (kProfile && (A.flags & kArgProf) && (b[0] + b[kUT - 1] + (unsigned)ncl[kUT - 1] + mbits == 0xFFFFFFF1u)) continue;   // batch has arrived
                         SIMON_PROF(2);
+                        bool m[kUT];
+                        int jn[kUT];
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) {
                             const int j = tid + (it0 + u) * T;
-                            if (j >= n || b[u] == 0u || !mk[u]) continue;
-                            on_feasible(j, it0 + u, b[u] - 1u, ncl[u]);
+                            m[u] = j < n && b[u] != 0u && mk[u];
+                            jn[u] = j < n ? j : n - 1;
+                            if (m[u]) on_feasible(j, it0 + u, b[u] - 1u, ncl[u]);
                         }
+                        extras8(jn, m, it0);
                     } else {
                         // The remaining filters, evaluated for the whole batch with their loads grouped per step
                         // (topology domain of 8 nodes, then the 8 counters, ...): one round trip per step, not per node.
@@ -853,6 +914,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                         for (int u = 0; u < kUT; ++u)
                             if (act[u]) on_feasible(jn[u], it0 + u, b[u] - 1u, ncl[u]);
+                        extras8(jn, act, it0);
                     }
                 }
             } else {
@@ -867,13 +929,19 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         ncl[u] = A.node_class[jj];
                         mk[u] = (mbits >> (it0 + u)) & 1u;
                     }
+                    bool m[kUT];
+                    int jn[kUT];
+#pragma unroll
+                    for (int u = 0; u < kUT; ++u) { m[u] = false; jn[u] = 0; }
 #pragma unroll
                     for (int u = 0; u < kU; ++u) {
                         const int j = tid + (it0 + u) * T;
                         if (j >= n) continue;
                         if (filter_code(A, v, p, j, n, L[u], mk[u], hard_min) != 0u) continue;
                         on_feasible(j, it0 + u, base_score(p, L[u]), ncl[u]);
+                        m[u] = true; jn[u] = j;
                     }
+                    extras8(jn, m, it0);
                 }
             }
             const int cm = 8, cs = soft ? 1 + n_soft : 0;      // sums start at slot 8; max slots: 4 base, +2 InterPodAffinity, +2 Open-Local
@@ -993,12 +1061,23 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         wq[q] = COLD(A)->spread_log[sz];
                     }
                     weight = Weight4{wq[0], wq[1], wq[2], wq[3]};
-                    int it = 0;
-                    for (int j = tid; j < n; j += T, ++it) {
-                        if (!((feas >> it) & 1u) || ((ign >> it) & 1u)) continue;
-                        const long long x = pts_raw(A, v, p, j, weight);
-                        pts_min = x < pts_min ? x : pts_min;
-                        pts_max = x > pts_max ? x : pts_max;
+                    for (int it0 = 0; it0 * T < n; it0 += kUT) {
+                        int jn[kUT];
+                        bool m[kUT];
+                        long long x[kUT];
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) {
+                            const int j = tid + (it0 + u) * T;
+                            m[u] = j < n && ((feas >> (it0 + u)) & 1u) && !((ign >> (it0 + u)) & 1u);
+                            jn[u] = j < n ? j : n - 1;
+                        }
+                        pts_raw8(A, v, p, jn, m, weight, x);
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) {
+                            if (!m[u]) continue;
+                            pts_min = x[u] < pts_min ? x[u] : pts_min;
+                            pts_max = x[u] > pts_max ? x[u] : pts_max;
+                        }
                     }
                     r[0] = -pts_min; r[1] = pts_max;
                     wg_reduce<NW>(r, 2, 2, 0, mbox[buf], wave, lane);
@@ -1024,26 +1103,52 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                 int my_term = 0;
                 if (class_mode && need_term && lane < Cn && ((cmask >> lane) & 1ull)) my_term = (int)class_term(lane);
                 unsigned long long key = 0;
-                for (int it = 0; it * T < n; ++it) {          // uniform trip count: the shuffle needs every lane
-                    const int j = tid + it * T;
-                    const bool valid = j < n && ((feas >> it) & 1u);
-                    const unsigned bc = valid ? s_bc[j] : 0u;
-                    const int nc = (int)(bc >> 16);
-                    long long total = bc & 0xFFFFu;
-                    if (need_term) total += class_mode ? (long long)__shfl(my_term, nc, 64) : (valid ? class_term(nc) : 0);
-                    if (valid) {
-                        if (ipa && ipa_diff > 0)                   // interpodaffinity/scoring.go:258-271
-                            total += (long long)(100.0 * ((double)(ipa_raw(A, v, p, j) - ipa_min) / (double)ipa_diff));
-                        if (local && l_hi != l_lo)                 // open-local.go:155-163
-                        total += divq((local_eval<false>(A, v, p, j).score - l_lo) * 100, l_hi - l_lo);
-                    if (soft) {                                // podtopologyspread/scoring.go:217-256, weight 2
-                            long long x;
-                            if ((ign >> it) & 1u) x = 0;
-                            else if (pts_max == 0) x = 100;
-                            else x = divq(100 * (pts_max + pts_min - pts_raw(A, v, p, j, weight)), pts_max);
-                            total += 2 * x;
+                for (int it0 = 0; it0 * T < n; it0 += kUT) {   // uniform trip count: the shuffles need every lane
+                    int jn[kUT];
+                    bool val[kUT];
+                    long long total[kUT];
+#pragma unroll
+                    for (int u = 0; u < kUT; ++u) {
+                        const int j = tid + (it0 + u) * T;
+                        val[u] = j < n && ((feas >> (it0 + u)) & 1u);
+                        jn[u] = j < n ? j : n - 1;
+                        const unsigned bc = val[u] ? s_bc[j] : 0u;
+                        const int nc = (int)(bc >> 16);
+                        total[u] = bc & 0xFFFFu;
+                        if (need_term) total[u] += class_mode ? (long long)__shfl(my_term, nc, 64) : (val[u] ? class_term(nc) : 0);
+                    }
+                    if (ipa && ipa_diff > 0) {                     // interpodaffinity/scoring.go:258-271
+                        long long x[kUT];
+                        ipa_raw8(A, v, p, jn, val, x);
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u)
+                            if (val[u]) total[u] += (long long)(100.0 * ((double)(x[u] - ipa_min) / (double)ipa_diff));
+                    }
+                    if (local && l_hi != l_lo) {                   // open-local.go:155-163
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u)
+                            if (val[u]) total[u] += divq((local_eval<false>(A, v, p, jn[u]).score - l_lo) * 100, l_hi - l_lo);
+                    }
+                    if (soft) {                                    // podtopologyspread/scoring.go:217-256, weight 2
+                        bool ms[kUT];
+                        long long x[kUT];
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) { ms[u] = val[u] && !((ign >> (it0 + u)) & 1u) && pts_max != 0; x[u] = 0; }
+                        if (pts_max != 0) pts_raw8(A, v, p, jn, ms, weight, x);
+#pragma unroll
+                        for (int u = 0; u < kUT; ++u) {
+                            if (!val[u]) continue;
+                            long long xx;
+                            if ((ign >> (it0 + u)) & 1u) xx = 0;
+                            else if (pts_max == 0) xx = 100;
+                            else xx = divq(100 * (pts_max + pts_min - x[u]), pts_max);
+                            total[u] += 2 * xx;
                         }
-                        const unsigned long long kk = ((unsigned long long)total << 32) | (0xFFFFFFFFull - (unsigned)j);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUT; ++u) {
+                        if (!val[u]) continue;
+                        const unsigned long long kk = ((unsigned long long)total[u] << 32) | (0xFFFFFFFFull - (unsigned)jn[u]);
                         key = kk > key ? kk : key;
                     }
                 }
