@@ -492,26 +492,33 @@ __device__ __forceinline__ void ipa_raw8(const WideArgs& A, const NodeView& v, c
                                          long long (&out)[kUT]) {
 #pragma unroll
     for (int u = 0; u < kUT; ++u) out[u] = 0;
+    int d[kUT], last_key = -1;          // lists sorted by topology key: one domain-row load per key
     for (int e = COLD(A)->pref_off[p.cls]; e < COLD(A)->pref_off[p.cls + 1]; ++e) {
-        const int t = COLD(A)->pref_idx[e], off = COLD(A)->term_dom_off[t];
+        const int t = COLD(A)->pref_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
         const long long w = COLD(A)->pref_w[e];
-        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * A.N;
-        int d[kUT], cv[kUT];
+        if (key != last_key) {
+            const int32_t* drow = COLD(A)->topo_dom + (size_t)key * A.N;
 #pragma unroll
-        for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : -1;
+            for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
+            last_key = key;
+        }
+        int cv[kUT];
 #pragma unroll
-        for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.cnt_match()[off + d[u]] : 0;
+        for (int u = 0; u < kUT; ++u) cv[u] = (m[u] && d[u] >= 0) ? v.cnt_match()[off + d[u]] : 0;
 #pragma unroll
         for (int u = 0; u < kUT; ++u) out[u] += w * cv[u];
     }
     for (int e = COLD(A)->mown_off[p.cls]; e < COLD(A)->mown_off[p.cls + 1]; ++e) {
-        const int t = COLD(A)->mown_idx[e], off = COLD(A)->term_dom_off[t];
-        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * A.N;
-        int d[kUT], cv[kUT];
+        const int t = COLD(A)->mown_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
+        if (key != last_key) {
+            const int32_t* drow = COLD(A)->topo_dom + (size_t)key * A.N;
 #pragma unroll
-        for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : -1;
+            for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
+            last_key = key;
+        }
+        int cv[kUT];
 #pragma unroll
-        for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.w_owner()[off + d[u]] : 0;
+        for (int u = 0; u < kUT; ++u) cv[u] = (m[u] && d[u] >= 0) ? v.w_owner()[off + d[u]] : 0;
 #pragma unroll
         for (int u = 0; u < kUT; ++u) out[u] += cv[u];
     }
@@ -866,25 +873,34 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             for (int u = 0; u < kUT; ++u) act[u] = act[u] && (exist[u] || escape);
                         }
                         if (p.flags & kPodFilt) {
+                            // the lists are sorted by topology key at stage time: the domain row of the batch is loaded once
+                            // per key, each term then costs ONE round trip (its counters)
+                            int d[kUT], last_key = -1;
                             for (int e = COLD(A)->anti_off[p.cls]; e < COLD(A)->anti_off[p.cls + 1]; ++e) {   // filtering.go:334-346
-                                const int t = COLD(A)->anti_idx[e], off = COLD(A)->term_dom_off[t];
-                                const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
-                                int d[kUT], cv[kUT];
+                                const int t = COLD(A)->anti_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
+                                if (key != last_key) {
+                                    const int32_t* drow = COLD(A)->topo_dom + (size_t)key * N;
 #pragma unroll
-                                for (int u = 0; u < kUT; ++u) d[u] = act[u] ? drow[jn[u]] : -1;
+                                    for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
+                                    last_key = key;
+                                }
+                                int cv[kUT];
 #pragma unroll
-                                for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.cnt_match()[off + d[u]] : 0;
+                                for (int u = 0; u < kUT; ++u) cv[u] = (act[u] && d[u] >= 0) ? v.cnt_match()[off + d[u]] : 0;
 #pragma unroll
                                 for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
                             }
                             for (int e = COLD(A)->manti_off[p.cls]; e < COLD(A)->manti_off[p.cls + 1]; ++e) { // filtering.go:319-332
-                                const int t = COLD(A)->manti_idx[e], off = COLD(A)->term_dom_off[t];
-                                const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
-                                int d[kUT], cv[kUT];
+                                const int t = COLD(A)->manti_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
+                                if (key != last_key) {
+                                    const int32_t* drow = COLD(A)->topo_dom + (size_t)key * N;
 #pragma unroll
-                                for (int u = 0; u < kUT; ++u) d[u] = act[u] ? drow[jn[u]] : -1;
+                                    for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
+                                    last_key = key;
+                                }
+                                int cv[kUT];
 #pragma unroll
-                                for (int u = 0; u < kUT; ++u) cv[u] = d[u] >= 0 ? v.cnt_owner()[off + d[u]] : 0;
+                                for (int u = 0; u < kUT; ++u) cv[u] = (act[u] && d[u] >= 0) ? v.cnt_owner()[off + d[u]] : 0;
 #pragma unroll
                                 for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
                             }
@@ -1485,6 +1501,22 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         }
         manti_off[c + 1] = (int32_t)manti_idx.size();
         mown_off[c + 1] = (int32_t)mown_idx.size();
+        auto by_key = [&](int32_t a, int32_t b) { return in.term_key[a] < in.term_key[b]; };
+        std::stable_sort(manti_idx.begin() + manti_off[c], manti_idx.end(), by_key);
+        std::stable_sort(mown_idx.begin() + mown_off[c], mown_idx.end(), by_key);
+    }
+    // the device copies of the anti / pref lists are sorted by topology key too (their sums and tests do not depend on order)
+    std::vector<int32_t> anti_sorted = in.anti_idx, pref_sorted = in.pref_idx, pref_w_sorted = in.pref_w;
+    for (int c = 0; c < Cp; ++c) {
+        auto by_key = [&](int32_t a, int32_t b) { return in.term_key[a] < in.term_key[b]; };
+        if (anti_off[c + 1] > anti_off[c]) std::stable_sort(anti_sorted.begin() + anti_off[c], anti_sorted.begin() + anti_off[c + 1], by_key);
+        const int lo = pref_off[c], hi = pref_off[c + 1];
+        if (hi > lo) {
+            std::vector<int> ord(hi - lo);
+            for (int k = 0; k < hi - lo; ++k) ord[k] = lo + k;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return in.term_key[in.pref_idx[a]] < in.term_key[in.pref_idx[b]]; });
+            for (int k = 0; k < hi - lo; ++k) { pref_sorted[lo + k] = in.pref_idx[ord[k]]; pref_w_sorted[lo + k] = in.pref_w[ord[k]]; }
+        }
     }
     std::vector<int32_t> term_set = in.term_set;
     term_set.resize(std::max(in.Tm, 1), -1);
@@ -1568,11 +1600,11 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     PUT(static_mask, in.static_mask, 1); PUT(static_reason, in.static_reason, 1); PUT(simon_raw, in.simon_raw, 1);
     PUT(na_raw, in.na_raw, 1); PUT(tt_raw, in.tt_raw, 1); PUT(static_add, in.static_add, 1);
     PUT(term_key, in.term_key, 1); PUT(term_dom_off, dom_off, 1); PUT(term_set, term_set, 1); PUT(node_sets, in.node_sets, 1);
-    PUT(anti_off, anti_off, 1); PUT(anti_idx, in.anti_idx, 1); PUT(match_off, match_off, 1); PUT(match_idx, in.match_idx, 1);
+    PUT(anti_off, anti_off, 1); PUT(anti_idx, anti_sorted, 1); PUT(match_off, match_off, 1); PUT(match_idx, in.match_idx, 1);
     PUT(manti_off, manti_off, 1); PUT(manti_idx, manti_idx, 1); PUT(mown_off, mown_off, 1); PUT(mown_idx, mown_idx, 1);
     PUT(aff_off, aff_off, 1); PUT(aff_idx, in.aff_idx, 1); PUT(class_flags, class_flags, 1);
     PUT(port_off, port_off, 1); PUT(port_idx, in.port_idx, 1);
-    PUT(pref_off, pref_off, 1); PUT(pref_idx, in.pref_idx, 1); PUT(pref_w, in.pref_w, 1);
+    PUT(pref_off, pref_off, 1); PUT(pref_idx, pref_sorted, 1); PUT(pref_w, pref_w_sorted, 1);
     PUT(own_off, own_off, 1); PUT(own_idx, in.own_idx, 1); PUT(own_w, in.own_w, 1);
     PUT(sh_off, sh_off, 1); PUT(sh_idx, in.sh_idx, 1); PUT(sh_skew, in.sh_skew, 1); PUT(sh_self, in.sh_self, 1);
     PUT(sh_set, sh_set, 1); PUT(sh_first_reg, first_reg, 1);
