@@ -94,6 +94,17 @@ def cpu_baseline(prob, scen, orders, budget_s=12.0):
     oracle_lib.load()
     S = len(scen)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:                                               # a container's CPU quota (cgroup v2 / v1) caps the useful thread count
+            if pf is None:
+                quota, period = open(qf).read().split()
+            else:
+                quota, period = open(qf).read().strip(), open(pf).read().strip()
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError):
+            continue
     cores = max(1, int(os.environ.get("SIMON_BENCH_CPU_THREADS", cores)))
     t0 = time.perf_counter()
     oracle_lib.run(prob, scen[[S // 2]], orders, want_placement=False)   # a mid-sized scenario: calibrate the sample size
@@ -106,8 +117,8 @@ def cpu_baseline(prob, scen, orders, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": round(k / dt, 4), "unit": "scenarios/s", "cores": cores, "kind": "port",
             "sample": f"{k} of the {S} scenarios of this rank's batch (evenly spaced over node counts/orders), {dt:.1f} s on "
-                      f"{cores} threads, one scenario per task; one thread alone: {1.0 / per:.2f} scenarios/s (C oracle: restated "
-                      "CPU baseline, not the Go reference binary)"}
+                      f"{cores} threads, one scenario per task (speed-up over one thread {k / dt * per:.1f}x; one thread alone: "
+                      f"{1.0 / per:.2f} scenarios/s; C oracle: restated CPU baseline, not the Go reference binary)"}
 
 
 def main():
