@@ -113,6 +113,11 @@ __global__ __launch_bounds__(64) void cache_kernel(
     int32_t* __restrict__ place_step, unsigned char* ws, const CacheScalars sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
+#ifdef SIMON_CACHE_ABLATION
+    const int ablate = sc.ablate;      // timing experiments (env SIMON_CACHE_ABLATE): results are wrong when non-zero
+#else
+    constexpr int ablate = 0;          // the product build carries no experiment switches (they cost SGPRs in the hot loop)
+#endif
     const Carve cv = carve(K, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ);
     const int nbp = cv.nbp, Kp = cv.Kp;
     unsigned char* const wsb = ws + (size_t)blockIdx.x * (size_t)cv.ws_total;
@@ -329,8 +334,8 @@ __global__ __launch_bounds__(64) void cache_kernel(
             const int blk = pstar >> 4, pos = pstar & 15;
             const int dwi = pos >> 2, sh8 = (pos & 3) * 8;
             uint4* my_row = (uint4*)(g_tile + ((size_t)blk * Kp + kk) * 16);
-            uint4 T = (sc.ablate & 1) ? make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u) : *my_row;
-            uint4 st = (sc.ablate & 4) ? make_uint4(1, 1, 50, 0) : g_state[pstar];
+            uint4 T = (ablate & 1) ? make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u) : *my_row;
+            uint4 st = (ablate & 4) ? make_uint4(1, 1, 50, 0) : g_state[pstar];
             st.x += (unsigned)__builtin_amdgcn_readlane((int)my_add_c, r_sig);
             st.y += (unsigned)__builtin_amdgcn_readlane((int)my_add_m, r_sig);
             st.z -= 1u;
@@ -342,9 +347,9 @@ __global__ __launch_bounds__(64) void cache_kernel(
                 if (lane == 0) g_nz[pstar] = z;
                 nzc = (double)z.x; nzm = (double)z.y;
             }
-            if (lane == 0 && !(sc.ablate & 4)) g_state[pstar] = st;
+            if (lane == 0 && !(ablate & 4)) g_state[pstar] = st;
             const ShapeRow sh = s_shape[st.w & 0xFFFFu];
-            const unsigned nb_raw = (sc.ablate & 16) ? 100u : eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st.x,
+            const unsigned nb_raw = (ablate & 16) ? 100u : eval_node(my_req_c, my_req_m, my_nz_c, my_nz_m, my_zero, (double)st.x,
                                                                         (double)st.y, nzc, nzm, (int)st.z, sh);
             const unsigned wsel = dwi == 0 ? T.x : dwi == 1 ? T.y : dwi == 2 ? T.z : T.w;
             const unsigned old = (wsel >> sh8) & 0xFFu;                // this signature's byte before the cycle
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(64) void cache_kernel(
             // tile row / state row observe these stores (same guarantee the LLVM memory model gives
             // wavefront-scope ordering); no cache maintenance, no wait.
             if (lane < K && nb != old) {
-                if (!(sc.ablate & 2)) ((unsigned char*)my_row)[pos] = (unsigned char)nb;
+                if (!(ablate & 2)) ((unsigned char*)my_row)[pos] = (unsigned char)nb;
                 my_sum[blk] = (unsigned short)block_key16(T);
                 if (!nb) s_cnt[(st.w >> 16) * 64 + lane] -= 1;
             }
