@@ -307,6 +307,37 @@ def test_k8s_simulate_and_sweep_through_the_hip_engine():
         H.OracleEngine = orig
 
 
+def test_k8s_sweep_at_scale_matches_oracle():
+    """The general path at a size where every code path is busy (400 nodes incl. 100 new, ~1 200 pods from 60 random
+    workloads + a DaemonSet, 8 cluster sizes): `simulate.sweep` on the HIP engine, every placement against the oracle."""
+    import randk8s
+    from open_simulator_amd import k8s, simulate as sim, workloads as wl
+    nodes, workloads, services = randk8s.rand_cluster(1, n_nodes=300, n_workloads=60, max_replicas=30)
+    for j, n in enumerate(nodes):
+        n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"
+    ds = {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "agent", "namespace": "kube-system"},
+          "spec": {"selector": {"matchLabels": {"app": "agent"}},
+                   "template": {"metadata": {"labels": {"app": "agent"}},
+                                "spec": {"containers": [{"name": "a", "image": "x", "resources": {"requests": {"cpu": "100m", "memory": "128Mi"}}}],
+                                         "tolerations": [{"operator": "Exists"}]}}}}
+    cluster = k8s.group_resources(nodes + services + [ds])
+    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z0"}},
+                "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "40"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
+
+    class Recording(sim.HipEngine):
+        def run(self, prob, scen, orders, want_placement=True):
+            self.args = (prob, scen, orders)
+            self.out = super().run(prob, scen, orders, want_placement)
+            return self.out
+
+    eng = Recording()
+    sim.sweep(cluster, apps, template, [0, 14, 28, 42, 57, 71, 85, 100], engine=eng)
+    prob, scen, orders = eng.args
+    assert prob.n_pods > 1000 and len(scen) == 8
+    assert_same(eng.out, O.run(prob, scen, orders))
+
+
 def test_config5_gpushare_style():
     """BASELINE config 5 shape (GPU share + required anti-affinity + taints): small pool, every placement compared;
     then ONE scenario at full size (50k pods x 5k nodes)."""
