@@ -64,7 +64,7 @@ def measured_issue(kernel, scenarios, pods, kernel_ms):
                             "unit": "G wave64-instr/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
                             "wave_time_split": {"parked_on_waitcnt_or_barrier": round(row["wait_any_per_dispatch"] / row["wave_cycles_per_dispatch"], 3),
                                                 "executing": round(row["active_inst_any_per_dispatch"] / row["wave_cycles_per_dispatch"], 3)},
-                            "source": "SQ_INSTS_VALU / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of profiles/r01d_*_summary.txt"}
+                            "source": "SQ_INSTS_VALU / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of profiles/r01e_*_summary.txt"}
     except (OSError, KeyError, ValueError):
         pass
     return None
