@@ -190,7 +190,11 @@ __device__ __forceinline__ bool in_set(const WideArgs& A, int set, int j) {
 __device__ __forceinline__ int term_dom(const WideArgs& A, int t, int j) { return COLD(A)->topo_dom[(size_t)COLD(A)->term_key[t] * A.N + j]; }
 
 constexpr int kU = 4;    // nodes per lane per load batch, full evaluation
-constexpr int kUT = 8;   // nodes per lane per load batch, signature-table path
+#ifndef SIMON_KUT
+#define SIMON_KUT 5   // same-box A/B of 4 / 5 / 6 / 8: 8 spills (i64 batch arrays), 5 fits 10 and 20 nodes per lane without a ragged batch
+#endif
+constexpr int kUT = SIMON_KUT;
+static_assert(SIMON_KUT >= 4 && SIMON_KUT <= 8, "the full-evaluation batch (kU = 4) is carried in kUT-wide arrays");   // nodes per lane per load batch, signature-table path
 
 __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
     v |= (unsigned)SIMON_DPP(0, (int)v, 0xB1, 0xF);
