@@ -340,6 +340,18 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     pod_class = tmpl_class[tmpl_of]          # class ids number the classes by first occurrence in the stream, as before
     Cp = len(class_rep)
 
+    # ---- ImageLocality (imagelocality/image_locality.go:53-113) is a constant 0 as long as no node lists an image a pod
+    # runs; otherwise its score depends on the scenario's node count (spread = NumNodes / totalNumNodes): Go path.
+    wanted = set()
+    for p in class_rep:
+        for c in p["spec"].get("containers") or []:
+            name = str(c.get("image") or "")
+            wanted.add(name if name.rfind(":") > name.rfind("/") else name + ":latest")          # normalizedImageName (:120-125)
+    for n in nodes:
+        for img in (n.get("status") or {}).get("images") or []:
+            if wanted.intersection(img.get("names") or []):
+                raise Unsupported(f"node {n['metadata']['name']} lists image(s) the pods run: ImageLocality is not constant")
+
     # ---- static filters per (pod class, node): first failing plugin in registry order --------------------------
     # A class looks at a node only through the label keys its nodeSelector / node affinity name, the node's taints,
     # its unschedulable flag, its preferAvoidPods annotation and -- for matchFields -- whether its name is one of the

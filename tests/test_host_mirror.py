@@ -143,6 +143,19 @@ def test_reference_open_local_example_end_to_end():
     del root
 
 
+def test_image_locality_is_constant_or_refused():
+    """ImageLocality scores 0 everywhere unless a node lists an image some pod runs (imagelocality/image_locality.go:96-113);
+    the mirror then refuses (the score depends on the scenario's node count) instead of silently ignoring the plugin."""
+    nodes, workloads, services = randk8s.rand_cluster(4, n_nodes=6, n_workloads=5)
+    cluster = k8s.group_resources(nodes + services)
+    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    nodes[2].setdefault("status", {})["images"] = [{"names": ["registry.local/other:1.0", "other@sha256:abc"], "sizeBytes": 500 << 20}]
+    sim.simulate(cluster, apps, engine=OracleEngine())                        # unrelated image: still a constant
+    nodes[2]["status"]["images"].append({"names": ["busybox:latest"], "sizeBytes": 300 << 20})      # the pods run "busybox"
+    with pytest.raises(fl.Unsupported, match="ImageLocality"):
+        sim.simulate(cluster, apps, engine=OracleEngine())
+
+
 def _problem_arrays(prob):
     out = {}
     for f in capi.Problem.__dataclass_fields__:
