@@ -340,6 +340,11 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     pod_class = tmpl_class[tmpl_of]          # class ids number the classes by first occurrence in the stream, as before
     Cp = len(class_rep)
 
+    # ---- DefaultPreemption (V/scheduler.go:479, defaultpreemption/default_preemption.go) finds no victims as long as all
+    # pods share one priority; explicit differing spec.priority values could evict placed pods: Go path.
+    if len({int(p["spec"].get("priority") or 0) for p in tpods}) > 1:
+        raise Unsupported("pods with different spec.priority: DefaultPreemption may evict placed pods")
+
     # ---- ImageLocality (imagelocality/image_locality.go:53-113) is a constant 0 as long as no node lists an image a pod
     # runs; otherwise its score depends on the scenario's node count (spread = NumNodes / totalNumNodes): Go path.
     wanted = set()

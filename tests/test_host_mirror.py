@@ -156,6 +156,18 @@ def test_image_locality_is_constant_or_refused():
         sim.simulate(cluster, apps, engine=OracleEngine())
 
 
+def test_differing_priorities_are_refused():
+    """With one priority for all pods DefaultPreemption never finds a victim; explicit differing
+    spec.priority values could evict placed pods in the reference, which the engine does not model."""
+    nodes, workloads, services = randk8s.rand_cluster(6, n_nodes=5, n_workloads=4)
+    extra = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "vip", "namespace": "default"},
+             "spec": {"priority": 1000, "containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"cpu": "100m"}}}]}}
+    cluster = k8s.group_resources(nodes + services)
+    sim.simulate(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], engine=OracleEngine())
+    with pytest.raises(fl.Unsupported, match="DefaultPreemption"):
+        sim.simulate(cluster, [sim.AppResource("app", k8s.group_resources(workloads + [extra]))], engine=OracleEngine())
+
+
 def _problem_arrays(prob):
     out = {}
     for f in capi.Problem.__dataclass_fields__:
