@@ -132,6 +132,8 @@ typedef struct simon_nodes_soa {
  * (V/framework/plugins/noderesources/fit.go:148-165); nz_* is calculateResource's non-zero
  * request (V/framework/types.go:601-636, V/util/non_zero.go:35-84).
  * ------------------------------------------------------------------------------------------- */
+#define SIMON_REASON_NODE_AFFINITY 3      /* static reason id of "node(s) didn't match Pod's node affinity" (host table) */
+
 typedef struct simon_pods_soa {
     uint32_t struct_size;
     int32_t n_pods;                /* P */
@@ -147,6 +149,11 @@ typedef struct simon_pods_soa {
                                       pkg/simulator/core.go:85-95); -1: always. optional */
     const int64_t* gpu_mem;        /* [P] annotation alibabacloud.com/gpu-mem, per GPU (pkg/type/open-gpu-share/utils/pod.go:56-67); optional */
     const int32_t* gpu_cnt;        /* [P] annotation alibabacloud.com/gpu-count (:70-81); optional */
+    const int32_t* pin_node;       /* [P] >= 0: the pod's required node affinity names this ONE node (DaemonSet pods:
+                                      SetDaemonSetPodNodeNameByNodeAffinity, pkg/utils/utils.go:770-815).  The pod's CLASS then
+                                      describes the template without that requirement (one class per DaemonSet, not per
+                                      node); every node but pin_node fails NodeAffinity after the class's own static
+                                      filters (code SIMON_FAIL_STATIC | SIMON_REASON_NODE_AFFINITY).  -1: none. optional */
 } simon_pods_soa;
 
 /* Open-Local volumes of one pod class (annotation simon/pod-local-storage -> utils.GetPodLocalPVCs,

@@ -24,6 +24,7 @@ UNSCHEDULED = -1
 GATED = -2
 
 FAIL_STATIC = 0x8000
+REASON_NODE_AFFINITY = 3
 FAIL_FIT = 0x4000
 FIT_PODS, FIT_CPU, FIT_MEM, FIT_EPH, FIT_SCALAR0 = 0x1, 0x2, 0x4, 0x8, 0x10
 FAIL_ANTI_INCOMING = 0x2001
@@ -72,7 +73,7 @@ class PodsSoA(C.Structure):
         ("struct_size", C.c_uint32), ("n_pods", C.c_int32),
         ("req_cpu", _p64), ("req_mem", _p64), ("req_eph", _p64), ("nz_cpu", _p64), ("nz_mem", _p64),
         ("scalar_req", _p64), ("pod_class", _p32), ("preset_node", _p32), ("gate_node", _p32),
-        ("gpu_mem", _p64), ("gpu_cnt", _p32),
+        ("gpu_mem", _p64), ("gpu_cnt", _p32), ("pin_node", _p32),
     ]
 
 
@@ -195,6 +196,7 @@ class Problem:
     pod_class: Optional[np.ndarray] = None
     preset_node: Optional[np.ndarray] = None
     gate_node: Optional[np.ndarray] = None
+    pin_node: Optional[np.ndarray] = None          # [P] >= 0: the only node the pod's node affinity admits (DaemonSet pods)
     gpu_mem: Optional[np.ndarray] = None
     pod_gpu_cnt: Optional[np.ndarray] = None
     # class tables
@@ -285,7 +287,7 @@ class Problem:
         self.req_mem = _arr(self.req_mem, i64, (P,))
         for name in ("req_eph", "nz_cpu", "nz_mem", "gpu_mem"):
             setattr(self, name, _arr(getattr(self, name), i64, (P,)))
-        for name in ("pod_class", "preset_node", "gate_node", "pod_gpu_cnt"):
+        for name in ("pod_class", "preset_node", "gate_node", "pod_gpu_cnt", "pin_node"):
             setattr(self, name, _arr(getattr(self, name), i32, (P,)))
         self.scalar_req = _arr(self.scalar_req, i64, (K, P)) if self.scalar_req is not None else None
         Cp, Cn = self.n_pod_classes, self.n_node_classes
@@ -366,7 +368,7 @@ class Problem:
         s.n_pods = self.n_pods
         for name in ("req_cpu", "req_mem", "req_eph", "nz_cpu", "nz_mem", "scalar_req", "gpu_mem"):
             setattr(s, name, _ptr(getattr(self, name), C.c_int64))
-        for name in ("pod_class", "preset_node", "gate_node"):
+        for name in ("pod_class", "preset_node", "gate_node", "pin_node"):
             setattr(s, name, _ptr(getattr(self, name), C.c_int32))
         s.gpu_cnt = _ptr(self.pod_gpu_cnt, C.c_int32)
         return s

@@ -280,6 +280,15 @@ __global__ __launch_bounds__(64) void cache_kernel(
         } else if (r_preset >= 0) {                                    // addPodToCache path (V/eventhandlers.go:223-236)
             res = r_preset;
             pstar = __builtin_amdgcn_readfirstlane(s_seg[ncls[r_preset]] + rank[r_preset]);
+        } else if (r_preset <= -2) {                                   // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
+            const int pin = -2 - r_preset;                             // its node affinity admits ONE node; the table byte of
+            res = -1;                                                  // (signature, node) holds static filters + fit
+            if (pin < n) {
+                const int pp = __builtin_amdgcn_readfirstlane(s_seg[ncls[pin]] + rank[pin]);
+                const unsigned char byte = g_tile[((size_t)(pp >> 4) * Kp + r_sig) * 16 + (pp & 15)];
+                if (byte != 0) { res = pin; pstar = pp; }
+            }
+            if (res < 0) ++unsched;
         } else {
             const int k = r_sig;
             // -------- which node classes still have a feasible node for this signature --------

@@ -244,7 +244,7 @@ int stage_narrow(simon_ctx* c) {
                 sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = r.cls; sr.flags = r.flags;
                 sigs.push_back(sr);
             }
-            rowsC[p] = PodRowC{it->second, r.preset, r.gate, r.cls};
+            rowsC[p] = PodRowC{it->second, (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, r.cls};
         }
         std::map<std::pair<uint32_t, uint32_t>, int> shape_id;
         std::vector<ShapeRow> shapes;
@@ -484,6 +484,13 @@ int simon_load_pods(simon_ctx* c, const simon_pods_soa* pd) {
     copy_opt(c->p_preset, pd->preset_node, P, (int32_t)-1);
     copy_opt(c->p_gate, pd->gate_node, P, (int32_t)-1);
     copy_opt(c->p_gpu_mem, pd->gpu_mem, P); copy_opt(c->p_gpu_cnt, pd->gpu_cnt, P);
+    copy_opt(c->p_pin, pd->pin_node, P, (int32_t)-1);
+    c->has_pin = false;
+    for (int p = 0; p < P; ++p) {
+        if (c->p_pin[p] >= c->N) return fail(c, SIMON_EINVAL, "pod %d: pin_node %d out of range", p, c->p_pin[p]);
+        if (c->p_pin[p] >= 0 && c->p_preset[p] >= 0) return fail(c, SIMON_EINVAL, "pod %d: both preset_node and pin_node", p);
+        c->has_pin = c->has_pin || c->p_pin[p] >= 0;
+    }
     c->have_pods = true; c->staged = false; c->have_results = false;
     return SIMON_OK;
 }
@@ -683,7 +690,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     if (want_placement) HIP_TRY(c, c->d_place.ensure((size_t)S * P));
     int T = 0, slots = 0, variant_used = c->variant;
     size_t lds = 0;
-    if (c->variant == SIMON_KERNEL_NARROW) {
+    bool run_wide = c->variant != SIMON_KERNEL_NARROW;
+    if (!run_wide) {
         // workgroup shape: T = 256 (4 waves) with up to 8 node slots per lane covers 2048 nodes;
         // larger pools widen the workgroup.  SIMON_WG overrides (tuning knob).
         T = c->force_T ? c->force_T : (c->max_n <= 2048 ? 256 : c->max_n <= 4096 ? 512 : 1024);
@@ -703,7 +711,11 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
             use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
         }
-        if (use_cache) {
+        // pinned pods (pin_node) are known to the cache kernel and the all-feature kernel only
+        if (c->has_pin && !use_cache) run_wide = true;
+        if (run_wide) {
+            // falls through to the all-feature kernel below
+        } else if (use_cache) {
             // Bands: scenarios in LPT order (largest first) are cut into at most max_bands launches of equal
             // scenario count; each band sizes its LDS summary and HBM workspace for its own largest scenario and
             // runs on its own stream (the hardware exposes 4 compute queues; more bands would serialise).
@@ -781,7 +793,14 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             HIP_TRY(c, launch_narrow(a, T, slots, c->has_mask, c->rcp_div, lds, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         }
-    } else {
+    }
+    if (run_wide) {
+        if (!c->wide_staged) {   // a NARROW problem whose batch cannot use the cache kernel but has pinned pods
+            int rcw = wide_stage(c->wide, *c, c->stream, c->err);
+            if (rcw) return rcw;
+            c->wide_staged = true;
+        }
+        variant_used = SIMON_KERNEL_WIDE;
         // Workgroup shape of the all-feature kernel.  A 256-thread group fits twice on a CU (launch bounds 256 x 2: two
         // independent barrier domains per SIMD), which wins as soon as the batch offers two groups per CU; with fewer
         // scenarios than that a CU holds ONE group and the 512-thread shape keeps all four SIMDs at two waves.

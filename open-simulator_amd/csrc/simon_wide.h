@@ -21,7 +21,8 @@ struct HostInputs {
     std::vector<int32_t> gpu_cnt, topo_dom, topo_n_dom;
     bool has_gpu = false;
     std::vector<int64_t> p_req_cpu, p_req_mem, p_req_eph, p_nz_cpu, p_nz_mem, p_scalar, p_gpu_mem;
-    std::vector<int32_t> p_cls, p_preset, p_gate, p_gpu_cnt;
+    std::vector<int32_t> p_cls, p_preset, p_gate, p_gpu_cnt, p_pin;
+    bool has_pin = false;         // some pod is pinned to one node (simon_pods_soa.pin_node)
     std::vector<uint64_t> static_mask;
     std::vector<uint8_t> static_reason;
     std::vector<int64_t> simon_raw, const_score;
@@ -65,7 +66,8 @@ struct WidePod {
     int32_t cls, preset, gate, gpu_cnt;
     uint32_t flags;  // kPod* bits
     int32_t sig;     // request signature: row of the (signature, node) table
-    uint32_t pad[6];
+    int32_t pin;     // >= 0: the only node the pod's node affinity admits (DaemonSet pods); -1: none
+    uint32_t pad[5];
 };
 static_assert(sizeof(WidePod) == 128, "WidePod must be 128 bytes");
 

@@ -482,6 +482,7 @@ __device__ __forceinline__ unsigned filter_code(const WideArgs& A, const NodeVie
     const unsigned fit = fit_bits(A, p, L, load_extra(A, v, j));
     // NodeUnschedulable / NodeName / TaintToleration / NodeAffinity come first in filter order
     if (!mask_ok) return SIMON_FAIL_STATIC | (COLD(A)->static_reason ? COLD(A)->static_reason[(size_t)p.cls * A.N + j] : 0u);
+    if (p.pin >= 0 && j != p.pin) return SIMON_FAIL_STATIC | SIMON_REASON_NODE_AFFINITY;   // pinned pod: NodeAffinity fails elsewhere
     if ((p.flags & kPodPorts) && ports_conflict(A, v, p, j)) return SIMON_FAIL_PORTS;
     if (fit) return SIMON_FAIL_FIT | fit;
     return rest_code(A, v, p, j, n, hard_min);
@@ -703,7 +704,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             }
             // ---------------- stage A: filter + base score + reductions --------------------------------
             // static filters of this lane's nodes: ONE word of the lane-major mask (bit it = node tid + it*T)
-            const unsigned mbits = A.mask_lanes ? A.mask_lanes[(size_t)p.cls * T + tid] : 0xFFFFFFFFu;
+            unsigned mbits = A.mask_lanes ? A.mask_lanes[(size_t)p.cls * T + tid] : 0xFFFFFFFFu;
+            if (p.pin >= 0) mbits = (p.pin < n && tid == p.pin % T) ? (mbits & (1u << (p.pin / T))) : 0u;   // pinned pod: one node of one lane
             const bool ipa = p.flags & kPodIpa;
             const bool soft = p.flags & kPodSoft;
             const bool local = p.flags & kPodLocal;
@@ -1556,6 +1558,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         bool zero = r.req_cpu == 0 && r.req_mem == 0 && r.req_eph == 0;
         for (int k = 0; k < in.K; ++k) { r.scalar[k] = in.p_scalar[(size_t)k * P + p]; zero = zero && r.scalar[k] == 0; }
         r.cls = in.p_cls[p]; r.preset = in.p_preset[p]; r.gate = in.p_gate[p]; r.gpu_cnt = in.p_gpu_cnt[p];
+        r.pin = in.p_pin.empty() ? -1 : in.p_pin[p];
         const int c = r.cls;
         auto some = [&](const std::vector<int32_t>& off) { return off[c + 1] > off[c]; };
         r.flags = zero ? kPodZero : 0u;

@@ -74,7 +74,7 @@ static int state_init(state_t* s, const simon_nodes_soa* nd, const simon_class_t
 typedef struct {
     int64_t req_cpu, req_mem, req_eph, nz_cpu, nz_mem, gpu_mem;
     int64_t scalar[SIMON_MAX_SCALAR];
-    int32_t cls, preset, gate, gpu_cnt;
+    int32_t cls, preset, gate, gpu_cnt, pin;
 } pod_t;
 
 static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
@@ -90,6 +90,7 @@ static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
     r.gate = pd->gate_node ? pd->gate_node[p] : -1;
     r.gpu_mem = pd->gpu_mem ? pd->gpu_mem[p] : 0;
     r.gpu_cnt = pd->gpu_cnt ? pd->gpu_cnt[p] : 0;
+    r.pin = pd->pin_node ? pd->pin_node[p] : -1;
     return r;
 }
 
@@ -286,6 +287,9 @@ static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables*
             return (uint16_t)(SIMON_FAIL_STATIC | r);
         }
     }
+    /* a pod pinned to one node by its required node affinity (DaemonSet pods): NodeAffinity fails everywhere else; it is
+     * the last of the four static plugins, so the class's own reason (unschedulable / taint) wins where the class fails */
+    if (p->pin >= 0 && j != p->pin) return (uint16_t)(SIMON_FAIL_STATIC | SIMON_REASON_NODE_AFFINITY);
     /* NodePorts.Filter -> fitsPorts -> HostPortInfo.CheckConflict (nodeports/node_ports.go:104-127, types.go:784-812) */
     if (tb && tb->n_terms > 0 && tb->port_off) {
         for (int e = tb->port_off[p->cls]; e < tb->port_off[p->cls + 1]; e++) {

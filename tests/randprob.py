@@ -10,7 +10,7 @@ GiB = 1 << 30
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
                  odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
-                 spread_soft=False, static_scores=False, local=False):
+                 spread_soft=False, static_scores=False, local=False, pins=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -105,6 +105,10 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
         if seed % 2:        # all-zero rows exercise the max == 0 branches
             prob.node_affinity_raw[0] = 0
             prob.taint_prefer_raw[-1] = 0
+    if pins:            # DaemonSet-style pods: node affinity admits ONE node (some beyond small scenarios' node counts)
+        prob.pin_node = np.where(rng.random(P) < 0.2, rng.integers(0, N, P), -1).astype(np.int32)
+        if prob.preset_node is not None:
+            prob.pin_node = np.where(np.asarray(prob.preset_node) >= 0, -1, prob.pin_node).astype(np.int32)
     if local:           # Open-Local: node storage + per-class volume specs
         GiB_ = 1 << 30
         prob.local_flags = (rng.random(N) < 0.75).astype(np.int32)

@@ -130,6 +130,7 @@ NARROW_FEATURES = [
     dict(presets=True), dict(gates=True, presets=True), dict(zero_pods=True, nz_differs=True), dict(tight_pods=True),
     dict(odd_units=True), dict(static_mask=True, init_state=True, presets=True, gates=True, tight_pods=True, zero_pods=True,
                                nz_differs=True),
+    dict(pins=True), dict(pins=True, static_mask=True, presets=True, gates=True, tight_pods=True, nz_differs=True),
 ]
 
 
@@ -160,6 +161,7 @@ WIDE_FEATURES = [
     dict(eph=True), dict(scalars=2), dict(gpu=True), dict(anti=True), dict(gpu=True, init_state=True),
     dict(eph=True, scalars=3, gpu=True, anti=True, static_mask=True, init_state=True, presets=True, gates=True,
          nz_differs=True, zero_pods=True, tight_pods=True),
+    dict(gpu=True, anti=True, static_mask=True, pins=True, presets=True),
 ]
 
 
@@ -182,6 +184,7 @@ V2_FEATURES = [
     dict(anti=True, aff=True, ipa=True, spread_hard=True, spread_soft=True, static_scores=True, gpu=True, eph=True,
          scalars=2, presets=True, gates=True, tight_pods=True, static_mask=True, nz_differs=True, init_state=True,
          zero_pods=True, local=True),
+    dict(pins=True, spread_hard=True, spread_soft=True, ipa=True, static_mask=True, static_scores=True),
 ]
 
 
@@ -360,7 +363,7 @@ def test_gpushare_example_and_hand_cases_on_gpu():
 
 def test_explain_codes_match_oracle():
     prob = randprob.rand_problem(7, N=24, P=300, eph=True, scalars=2, gpu=True, anti=True, static_mask=True,
-                                 tight_pods=True)
+                                 tight_pods=True, pins=True)
     scen, orders = randprob.rand_scenarios(7, prob, S=2)
     ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=16)
     assert nf > 0
