@@ -294,12 +294,18 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 r = tok_rep[tok] = len(rep_list)
                 rep_list.append(i)
             tmpl_of[i] = r
-    tpods = [pods[i] for i in rep_list]
+    # a DaemonSet pod is seen through its class affinity (the name requirement holds everywhere); the node it is pinned to
+    # travels separately as pin_node
+    tpods = [pods[i] if "_class_affinity" not in pods[i] else
+             dict(pods[i], spec=dict(pods[i]["spec"], affinity=pods[i]["_class_affinity"])) for i in rep_list]
     if os.environ.get("SIMON_CHECK_TEMPLATES"):           # debug: the token promise, checked pod by pod
         for i, p in enumerate(pods):
             a, b = p, tpods[tmpl_of[i]]
-            assert a["spec"] == b["spec"] and {k: v for k, v in a["metadata"].items() if k != "name"} == \
-                {k: v for k, v in b["metadata"].items() if k != "name"}, f"pod {a['metadata']['name']} differs from its template"
+            skip = ("affinity",) if "_class_affinity" in a else ()       # DaemonSet pods differ in the node their affinity names
+            assert {k: v for k, v in a["spec"].items() if k not in skip} == {k: v for k, v in b["spec"].items() if k not in skip} and \
+                a.get("_class_affinity") == b.get("_class_affinity") and \
+                {k: v for k, v in a["metadata"].items() if k != "name"} == {k: v for k, v in b["metadata"].items() if k != "name"}, \
+                f"pod {a['metadata']['name']} differs from its template"
     reqs = [k8s.pod_request(p) for p in tpods]
     scalar_names = sorted({name for r in reqs for name, v in r.items()
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
@@ -319,6 +325,10 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     for i, p in enumerate(pods):
         if p["spec"].get("nodeName") and preset[i] < 0:
             raise Unsupported(f"pod {p['metadata']['name']} is bound to unknown node {p['spec']['nodeName']}")
+    pin = np.array([node_index.get(p.get("_daemon_node"), -1) if "_class_affinity" in p else -1 for p in pods], np.int32)
+    for i, p in enumerate(pods):
+        if "_class_affinity" in p and (pin[i] < 0 or preset[i] >= 0):
+            raise Unsupported(f"DaemonSet pod {p['metadata']['name']}: node {p.get('_daemon_node')} is not in the pool")
 
     class_ids: Dict[str, int] = {}
     class_rep: List[dict] = []
@@ -752,6 +762,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         scalar_req=scalar_req if scalar_names else None, pod_class=pod_class,
         preset_node=preset if (preset >= 0).any() else None,
         gate_node=np.array(gates, np.int32) if gates is not None and any(g >= 0 for g in gates) else None,
+        pin_node=pin if (pin >= 0).any() else None,
         gpu_mem=gpu_mem if gpu_mem.any() else None, pod_gpu_cnt=gpu_cnt if gpu_mem.any() else None,
         n_pod_classes=Cp, n_node_classes=Cn, static_mask=None if static_ok.all() else static_mask,
         static_reason=None if static_ok.all() else static_reason, simon_raw=simon_raw, const_score=const, **prob_kw).normalise()

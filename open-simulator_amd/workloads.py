@@ -137,9 +137,10 @@ def pods_of_cronjob(cj: dict) -> List[dict]:
     return pods_of_job(job)
 
 
-def _daemon_affinity(affinity, node_name: str):
-    """SetDaemonSetPodNodeNameByNodeAffinity (pkg/utils/utils.go:770-815)."""
-    req = {"key": "metadata.name", "operator": "In", "values": [node_name]}
+def _daemon_affinity(affinity, node_name: str, requirement: dict = None):
+    """SetDaemonSetPodNodeNameByNodeAffinity (pkg/utils/utils.go:770-815).  `requirement` replaces the metadata.name
+    matchFields requirement (used for the class view of a DaemonSet pod, see pods_of_daemonset)."""
+    req = requirement or {"key": "metadata.name", "operator": "In", "values": [node_name]}
     sel = {"nodeSelectorTerms": [{"matchFields": [req]}]}
     if affinity is None:
         return {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": sel}}
@@ -166,15 +167,27 @@ def node_should_run_pod(node: dict, pod: dict) -> bool:
     return k8s.find_untolerated_taint(node, pod) is None
 
 
+ANY_NODE_NAME = {"key": "metadata.name", "operator": "Exists"}     # true on every node: the class view of a DaemonSet pod
+
+
 def pods_of_daemonset(ds: dict, nodes: List[dict]) -> List[dict]:
-    """MakeValidPodsByDaemonset / NewDaemonPod (pkg/utils/utils.go:308-340): one pod per node that should run it."""
+    """MakeValidPodsByDaemonset / NewDaemonPod (pkg/utils/utils.go:308-340): one pod per node that should run it.
+    Ingest: the pods of one DaemonSet differ only in the node their affinity names, so they carry
+    `_daemon_node` (the pinned node: simon_pods_soa.pin_node) and `_class_affinity` -- the same affinity with the name
+    requirement replaced by one that holds everywhere -- and flatten() interns them as ONE class per DaemonSet."""
     out = []
+    base = _from_template(ds, ds["spec"]["template"], "DaemonSet", "")
+    class_affinity = _daemon_affinity(base["spec"].get("affinity"), "", ANY_NODE_NAME)
+    proto = _workload_info(make_valid_pod(base), "DaemonSet", ds)
+    token = next(_TEMPLATE_TOKENS)
     for node in nodes:
         nname = node["metadata"]["name"]
-        p = _from_template(ds, ds["spec"]["template"], "DaemonSet", f"{ds['metadata']['name']}-{nname}")
-        p["spec"]["affinity"] = _daemon_affinity(p["spec"].get("affinity"), nname)
-        p = _workload_info(make_valid_pod(p), "DaemonSet", ds)
+        md = proto["metadata"]
+        p = dict(proto, metadata=dict(md, name=f"{ds['metadata']['name']}-{nname}", labels=dict(md["labels"]), annotations=dict(md["annotations"])),
+                 spec=dict(proto["spec"], affinity=_daemon_affinity(base["spec"].get("affinity"), nname)), status={})
         p["_daemon_node"] = nname
+        p["_class_affinity"] = class_affinity
+        p["_tmpl"] = token
         if node_should_run_pod(node, p):
             out.append(p)
     return out
