@@ -706,6 +706,10 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             // static filters of this lane's nodes: ONE word of the lane-major mask (bit it = node tid + it*T)
             unsigned mbits = A.mask_lanes ? A.mask_lanes[(size_t)p.cls * T + tid] : 0xFFFFFFFFu;
             if (p.pin >= 0) mbits = (p.pin < n && tid == p.pin % T) ? (mbits & (1u << (p.pin / T))) : 0u;   // pinned pod: one node of one lane
+            // ... and only the batch that holds that node is evaluated (nothing at all when the node is outside the scenario)
+            const int itA_lo = p.pin < 0 ? 0 : (p.pin / T / kUT) * kUT, itB_lo = p.pin < 0 ? 0 : (p.pin / T / kU) * kU;
+            const int nA_hi = p.pin < 0 ? n : (p.pin < n ? min(n, (itA_lo + kUT) * T) : 0);
+            const int nB_hi = p.pin < 0 ? n : (p.pin < n ? min(n, (itB_lo + kU) * T) : 0);
             const bool ipa = p.flags & kPodIpa;
             const bool soft = p.flags & kPodSoft;
             const bool local = p.flags & kPodLocal;
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                 // NodeResourcesFit + LeastAllocated + BalancedAllocation come from the table row of the pod's signature
                 const unsigned char* trow = tab + (size_t)p.sig * nstride;
                 if (!has_rest) SIMON_PROF(11);               // cycle setup of a table-only pod (class rows, flags)
-                for (int it0 = 0; it0 * T < n; it0 += kUT) {
+                for (int it0 = itA_lo; it0 * T < nA_hi; it0 += kUT) {
                     unsigned b[kUT];
                     int ncl[kUT];
                     bool mk[kUT];
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     }
                 }
             } else {
-                for (int it0 = 0; it0 * T < n; it0 += kU) {
+                for (int it0 = itB_lo; it0 * T < nB_hi; it0 += kU) {
                     NodeLoads L[kU];
                     int ncl[kU];
                     bool mk[kU];
