@@ -190,7 +190,12 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
     if max(counts) > 0 and new_node is None:
         raise ValueError("new node is nil when adding node to cluster")          # utils.NewFakeNodes (utils.go:886-888)
     pool = base + (wl.new_fake_nodes(new_node, max(counts)) if max(counts) > 0 else [])
-    _check_prefix_order(pool, [len(base) + k for k in counts])
+    try:
+        _check_prefix_order(pool, [len(base) + k for k in counts])
+    except fl.Unsupported:
+        # nodes in several zones: nodeTree order of a cluster size is not a prefix of the next one's, so every size is its
+        # own problem (own canonical node order) -- one scenario per engine call, like the reference's loop
+        return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
     pods, gates = build_stream(cluster, apps, pool, len(base))
     flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates,
                       storage_classes=_storage_classes(cluster, apps))
@@ -217,6 +222,38 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
         res.node_status = [{"node": copy.deepcopy(pool[j]), "pods": per_node[j]} for j in range(n)]
         result = res
     return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
+
+
+def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg) -> SweepResult:
+    base = list(cluster.get("Node", []))
+    if max_vg > 100 or max_vg < 0:
+        max_vg = 100
+    uns, cpu_pct, mem_pct, vg_pct, kept = [], [], [], [], {}
+    for s, k in enumerate(counts):
+        nodes = base + (wl.new_fake_nodes(new_node, k) if k > 0 else [])
+        nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
+        pods, _ = build_stream(cluster, apps, nodes, len(nodes))
+        flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []),
+                          storage_classes=_storage_classes(cluster, apps))
+        out = engine.run(flat.problem, np.array([[len(nodes), 0]], np.int32), np.arange(len(pods), dtype=np.int32)[None, :])
+        uns.append(int(out.unscheduled[0]))
+        cpu_pct.append(occupancy_pct(int(out.used_cpu[0]), int(flat.problem.alloc_cpu.sum())))
+        mem_pct.append(occupancy_pct(int(out.used_mem[0]) * 1000, int(flat.problem.alloc_mem.sum()) * 1000))
+        vg = 0
+        if flat.problem.local_flags is not None and out.used_vg is not None:
+            cap = int((flat.problem.local_vg_cap * (np.arange(capi.MAX_VG)[None, :] < flat.problem.local_vg_cnt[:, None])).sum())
+            vg = occupancy_pct(int(out.used_vg[0]), cap)
+        vg_pct.append(vg)
+        if uns[-1] == 0 and cpu_pct[-1] <= max_cpu and mem_pct[-1] <= max_mem and vg <= max_vg:
+            kept[s] = (flat, out, nodes)
+    best = min(kept, key=lambda s: (counts[s], s)) if kept else None
+    result = None
+    if best is not None:
+        flat, out, nodes = kept[best]
+        res, per_node = _unflatten(flat, out.placement[0], len(nodes), {})
+        res.node_status = [{"node": copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
+        result = res
+    return SweepResult(list(counts), uns, cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
 
 
 def load_config(path: str, base_dir: str = ".") -> dict:
