@@ -331,6 +331,13 @@ int simon_load_class_tables(simon_ctx* ctx, const simon_class_tables* tables);
 int simon_load_scenarios(simon_ctx* ctx, const simon_scenario* scen, int32_t S,
                          const int32_t* orders, int32_t n_orders);
 
+/* Canonical (nodeTree) order per scenario.  By default the canonical order of a scenario's nodes is their pool order.  With
+ * nodes in several zones the nodeTree order of a larger cluster does not extend a smaller one's (zones are visited round
+ * robin, V/internal/cache/node_tree.go:119-143), so the host may supply rank[s][j] = position of pool node j in scenario
+ * s's order (a permutation of 0..n_s-1 over j < n_s; entries j >= n_s are ignored).  Only selectHost's tie-break (first
+ * maximum in canonical order) reads it.  Call after simon_load_scenarios; NULL returns to pool order. */
+int simon_set_node_ranks(simon_ctx* ctx, const int32_t* rank /* [S][N] */);
+
 /* Run every loaded scenario on the device; results stay in HBM.  This is the timed hot path:
  * per scenario, per pod: findNodesThatFitPod -> prioritizeNodes -> selectHost -> assume
  * (V/core/generic_scheduler.go:131-209, V/scheduler.go:371).  want_placement = 0 skips the

@@ -447,7 +447,7 @@ _LIB = None
 EXPORTS = [
     "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
-    "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain",
+    "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain", "simon_set_node_ranks",
     "simon_get_stats", "simon_device_results",
 ]
 
@@ -480,6 +480,7 @@ def load_library(path: Optional[str] = None):
     lib.simon_fetch_results.argtypes = [vp, C.POINTER(BatchOut)]
     lib.simon_fetch_placement.argtypes = [vp, C.c_int32, _p32]
     lib.simon_run_batch.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32, C.POINTER(BatchOut)]
+    lib.simon_set_node_ranks.argtypes = [vp, _p32]
     lib.simon_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(Plan)]
     lib.simon_min_plan_vg.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
     lib.simon_explain.argtypes = [vp, Scenario, _p32, _p32, _pu16, C.c_int32]
@@ -578,6 +579,14 @@ class Context:
         self.S = len(scen)
         self.scen = scen
         return res
+
+    def set_node_ranks(self, ranks) -> None:
+        """Per-scenario nodeTree order: ranks[s][j] = position of pool node j in scenario s's canonical order (None: pool order)."""
+        if ranks is None:
+            self._check(self.lib.simon_set_node_ranks(self.h, None), "simon_set_node_ranks")
+            return
+        r = np.ascontiguousarray(ranks, dtype=np.int32)
+        self._check(self.lib.simon_set_node_ranks(self.h, _ptr(r, C.c_int32)), "simon_set_node_ranks")
 
     def min_plan(self, max_cpu_pct: int = 100, max_mem_pct: int = 100) -> Plan:
         plan = Plan()

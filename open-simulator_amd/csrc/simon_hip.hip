@@ -102,6 +102,8 @@ struct simon_ctx : simon::HostInputs {
     hipEvent_t band_ev[8] = {}, fork_ev = nullptr;
     DevBuf<uint64_t> d_mask;
     DevBuf<int64_t> d_prefix_cpu, d_prefix_mem, d_prefix_vg;
+    DevBuf<int32_t> d_node_rank, d_node_inv;      // [S][N] per-scenario nodeTree ranks (simon_set_node_ranks)
+    bool has_ranks = false;
     std::vector<int64_t> prefix_vg;   // [N+1] Open-Local VG capacity of the first n nodes (0 without local storage)
     WideDevice wide;
     // scenarios
@@ -678,6 +680,33 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.h2d_ms = ms;
     c->S = S; c->n_orders = n_orders; c->max_n = max_n;
+    c->has_ranks = false;
+    c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_set_node_ranks(simon_ctx* c, const int32_t* rank) {
+    if (!c) return SIMON_EINVAL;
+    if (!c->staged || c->S <= 0) return fail(c, SIMON_ESTATE, "set_node_ranks: load scenarios first");
+    if (!rank) { c->has_ranks = false; return SIMON_OK; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t S = c->S, N = c->N;
+    std::vector<int32_t> inv(S * N, 0);
+    for (size_t s = 0; s < S; ++s) {
+        const int n = c->scen[s].n_nodes;
+        std::vector<char> seen(n, 0);
+        for (int j = 0; j < n; ++j) {
+            const int r = rank[s * N + j];
+            if (r < 0 || r >= n || seen[r]) return fail(c, SIMON_EINVAL, "set_node_ranks: scenario %d: not a permutation of 0..%d", (int)s, n - 1);
+            seen[r] = 1;
+            inv[s * N + r] = j;
+        }
+    }
+    std::vector<int32_t> rk(rank, rank + S * N);
+    HIP_TRY(c, c->d_node_rank.upload(rk, c->stream));
+    HIP_TRY(c, c->d_node_inv.upload(inv, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->has_ranks = true;
     c->have_results = false;
     return SIMON_OK;
 }
@@ -690,7 +719,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     if (want_placement) HIP_TRY(c, c->d_place.ensure((size_t)S * P));
     int T = 0, slots = 0, variant_used = c->variant;
     size_t lds = 0;
-    bool run_wide = c->variant != SIMON_KERNEL_NARROW;
+    bool run_wide = c->variant != SIMON_KERNEL_NARROW || c->has_ranks;    // per-scenario node ranks: all-feature kernel only
     if (!run_wide) {
         // workgroup shape: T = 256 (4 waves) with up to 8 node slots per lane covers 2048 nodes;
         // larger pools widen the workgroup.  SIMON_WG overrides (tuning knob).
@@ -813,7 +842,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
                           c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p, c->d_used_vg.p,
-                          want_placement ? c->d_place.p : nullptr, c->stream, c->err);
+                          want_placement ? c->d_place.p : nullptr, c->has_ranks ? c->d_node_rank.p : nullptr,
+                          c->has_ranks ? c->d_node_inv.p : nullptr, c->stream, c->err);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     }
@@ -935,7 +965,12 @@ int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32
         c->wide_staged = true;
     }
     const int T = c->force_T ? c->force_T : (scen.n_nodes <= 512 ? 256 : scen.n_nodes <= 4096 ? 512 : 1024);
-    return wide_explain(c->wide, *c, scen.n_nodes, order, failed_pods, fail_codes, max_failed, T, c->stream, c->err);
+    // with per-scenario node ranks the replay must break ties like the batch did: the ranks of a loaded scenario of this size
+    const int32_t *rk = nullptr, *iv = nullptr;
+    if (c->has_ranks)
+        for (int s = 0; s < c->S; ++s)
+            if (c->scen[s].n_nodes == scen.n_nodes) { rk = c->d_node_rank.p + (size_t)s * c->N; iv = c->d_node_inv.p + (size_t)s * c->N; break; }
+    return wide_explain(c->wide, *c, scen.n_nodes, order, failed_pods, fail_codes, max_failed, T, rk, iv, c->stream, c->err);
 }
 
 int simon_get_stats(simon_ctx* c, simon_stats* st) {

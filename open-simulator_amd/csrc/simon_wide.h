@@ -136,10 +136,14 @@ struct WideCold {
     int32_t* failed_pods; uint16_t* fail_codes; int32_t* n_failed;
     // diagnostics (env SIMON_WIDE_PROF): per (scenario, wave) cycle sums of the phases of a cycle, or null
     unsigned long long* prof;
+    // per-scenario nodeTree order (simon_set_node_ranks), rows of the WHOLE batch [S_total][N]: rank of a pool node / node of a
+    // rank; null = pool order.  Row of this launch's scenario s: (scen_base + s) * N
+    const int32_t* node_rank; const int32_t* node_inv;
 };
 
 struct WideArgs {
     int32_t N, P, K, Cn, S;                 // S = scenarios in THIS launch (chunk)
+    int32_t scen_base;                      // index of this launch's first scenario in the batch
     int32_t mask_words, bc_words /*LDS words of base|class*/, n_sigs /*0 = table off*/, tab_nstride /*bytes per table row*/;
     uint32_t flags;                         // kArg* bits
     size_t tab_stride /*bytes per scenario*/;
@@ -158,6 +162,7 @@ struct WideArgs {
 };
 constexpr uint32_t kArgGpu = 1u, kArgMask = 2u, kArgEph = 4u, kArgNzeq = 8u, kArgClassMode = 16u /*Cn <= 64*/,
                    kArgKey32 = 32u /*32-bit arg-max key*/, kArgProf = 64u, kArgTerms = 128u /*Tm > 0*/, kArgLocal = 256u /*Open-Local*/,
+                   kArgRanked = 1024u /*per-scenario canonical node ranks (simon_set_node_ranks)*/,
                    kArgLean = 512u /*no spread constraint, scoring term, host port, required affinity or local volume anywhere*/;
 
 struct WideDevice {
@@ -205,8 +210,10 @@ struct WideDevice {
 int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string& err);
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t* h_perm_unused, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
-             int64_t* d_used_vg, int32_t* d_place, hipStream_t st, std::string& err);
+             int64_t* d_used_vg, int32_t* d_place, const int32_t* d_node_rank, const int32_t* d_node_inv, hipStream_t st,
+             std::string& err);
 int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
-                 uint16_t* fail_codes, int32_t max_failed, int T, hipStream_t st, std::string& err);
+                 uint16_t* fail_codes, int32_t max_failed, int T, const int32_t* d_rank_row, const int32_t* d_inv_row, hipStream_t st,
+                 std::string& err);
 
 }  // namespace simon

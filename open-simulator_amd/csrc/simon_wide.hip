@@ -578,6 +578,14 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     const int32_t* order = A.orders + (size_t)A.scen[s].order_id * P;
     const bool class_mode = ((A.flags & kArgClassMode) != 0u);
     const bool use_tab = !EXPLAIN && A.n_sigs > 0;
+    // selectHost's tie-break index of a node / node of a tie-break index: pool order unless the host supplied the scenario's
+    // nodeTree ranks (clusters with several zones)
+    auto rank_of = [&](int j) -> unsigned {
+        return (A.flags & kArgRanked) ? (unsigned)COLD(A)->node_rank[(size_t)(A.scen_base + s) * N + j] : (unsigned)j;
+    };
+    auto node_of = [&](int r) -> int {
+        return (A.flags & kArgRanked) ? COLD(A)->node_inv[(size_t)(A.scen_base + s) * N + r] : r;
+    };
 
     NodeView v;
     v.req_cpu = A.st_req_cpu + (size_t)s * N; v.req_mem = A.st_req_mem + (size_t)s * N; v.npods = A.st_npods + (size_t)s * N;
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             const bool fast1 = class_mode && Cn <= 8 && ((A.flags & kArgKey32) != 0u) && !ipa && !soft && !local;
             auto on_feasible = [&](int j, int it, unsigned base, int nc) {
                 if (fast1) {
-                    const unsigned kk = (base << 22) | (0x3FFFFFu - (unsigned)j);
+                    const unsigned kk = (base << 22) | (0x3FFFFFu - rank_of(j));
                     (void)__hip_atomic_fetch_max(&s_kc[nc * T + tid], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     return;
                 }
@@ -1018,7 +1026,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                 }
 #pragma unroll
                 for (int off = 1; off < 8; off <<= 1) { const unsigned x = (unsigned)__shfl_xor((int)key, off, 64); key = x > key ? x : key; }
-                jstar = (int)(0x3FFFFFu - ((unsigned)__builtin_amdgcn_readfirstlane((int)key) & 0x3FFFFFu));
+                jstar = node_of((int)(0x3FFFFFu - ((unsigned)__builtin_amdgcn_readfirstlane((int)key) & 0x3FFFFFu)));
                 SIMON_PROF(1);
             } else {
                 if (class_mode) {   // the set of node classes that still have a feasible node
@@ -1174,7 +1182,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                     for (int u = 0; u < kUT; ++u) {
                         if (!val[u]) continue;
-                        const unsigned long long kk = ((unsigned long long)total[u] << 32) | (0xFFFFFFFFull - (unsigned)jn[u]);
+                        const unsigned long long kk = ((unsigned long long)total[u] << 32) | (0xFFFFFFFFull - rank_of(jn[u]));
                         key = kk > key ? kk : key;
                     }
                 }
@@ -1187,7 +1195,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         for (int w = 0; w < NW; ++w) k32 = (unsigned)mbK[bufK][w] > k32 ? (unsigned)mbK[bufK][w] : k32;
                         bufK ^= 1;
                     }
-                    jstar = (int)(0x3FFFFFu - (k32 & 0x3FFFFFu));
+                    jstar = node_of((int)(0x3FFFFFu - (k32 & 0x3FFFFFu)));
                 } else {
                     key = wave_max_u64(key);
                     if (NW > 1) {
@@ -1196,7 +1204,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         for (int w = 0; w < NW; ++w) key = mbK[bufK][w] > key ? mbK[bufK][w] : key;
                         bufK ^= 1;
                     }
-                    jstar = (int)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
+                    jstar = node_of((int)(0xFFFFFFFFull - (key & 0xFFFFFFFFull)));
                 }
             }
             }
@@ -1638,7 +1646,8 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
 // chunk is reused by the next one; kernels on one stream serialise).
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t*, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
-             int64_t* d_used_vg, int32_t* d_place, hipStream_t st, std::string& err) {
+             int64_t* d_used_vg, int32_t* d_place, const int32_t* d_node_rank, const int32_t* d_node_inv, hipStream_t st,
+             std::string& err) {
     if ((long long)max_n > (long long)kMaxIter * T) { err = "wide kernel: more than 32 nodes per lane"; return SIMON_ERANGE; }
     const size_t per = state_bytes_per_scenario(w, in);
     size_t budget = 16ull << 30;  // 16 GiB of 288 GB HBM for scenario state
@@ -1652,6 +1661,8 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     WideCold c;
     fill_args(w, in, a, c);
     a.mask_lanes = w.mask_lanes;
+    c.node_rank = d_node_rank; c.node_inv = d_node_inv;
+    if (d_node_rank && d_node_inv) a.flags |= kArgRanked;
     a.orders = d_orders;
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
     unsigned long long* d_prof = nullptr;
@@ -1674,6 +1685,7 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     }
     for (int s0 = 0; s0 < S; s0 += chunk) {
         a.S = std::min(chunk, S - s0);
+        a.scen_base = s0;
         a.scen = d_scen + s0;
         a.unscheduled = d_unsched + s0; a.used_cpu = d_used_cpu + s0; a.used_mem = d_used_mem + s0; a.used_vg = d_used_vg ? d_used_vg + s0 : nullptr;
         a.placement = d_place ? d_place + (size_t)s0 * in.P : nullptr;
@@ -1701,7 +1713,8 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
 }
 
 int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
-                 uint16_t* fail_codes, int32_t max_failed, int T, hipStream_t st, std::string& err) {
+                 uint16_t* fail_codes, int32_t max_failed, int T, const int32_t* d_rank_row, const int32_t* d_inv_row, hipStream_t st,
+                 std::string& err) {
     if ((long long)n_nodes > (long long)kMaxIter * T) { err = "wide kernel: more than 32 nodes per lane"; return SIMON_ERANGE; }
     int rc = ensure_state(w, in, 1, err);
     if (rc) return rc;
@@ -1725,6 +1738,8 @@ int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t
     if (rc) return rc;
     fill_args(w, in, a, c);
     a.mask_lanes = w.mask_lanes;
+    c.node_rank = d_rank_row; c.node_inv = d_inv_row;
+    if (d_rank_row && d_inv_row) a.flags |= kArgRanked;
     a.S = 1; a.scen = (const WideScenario*)d_scen; a.orders = (const int32_t*)d_order;
     a.bc_words = (std::max(n_nodes, 1) + 3) & ~3;
     a.n_sigs = 0;   // failure codes come from the full per-node evaluation

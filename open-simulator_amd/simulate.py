@@ -24,10 +24,15 @@ class HipEngine:
     def __init__(self, device_id: int = 0):
         self.device_id = device_id
 
-    def run(self, prob: capi.Problem, scen, orders, want_placement=True) -> capi.BatchResult:
+    def run(self, prob: capi.Problem, scen, orders, want_placement=True, node_ranks=None) -> capi.BatchResult:
         with capi.Context(self.device_id) as ctx:
             ctx.load_problem(prob)
-            return ctx.run_batch(scen, orders, want_placement)
+            if node_ranks is None:
+                return ctx.run_batch(scen, orders, want_placement)
+            ctx.load_scenarios(scen, orders)
+            ctx.set_node_ranks(node_ranks)            # per-scenario nodeTree order (clusters with several zones)
+            ctx.run_loaded(want_placement)
+            return ctx.fetch(want_placement)
 
     def explain(self, prob: capi.Problem, n_nodes: int, order, max_failed: int):
         with capi.Context(self.device_id) as ctx:
@@ -138,9 +143,11 @@ def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine
     """simulator.Simulate for ONE cluster size: cluster["Node"] + new_nodes, canonical nodeTree order."""
     engine = engine or HipEngine()
     nodes = list(cluster.get("Node", [])) + list(new_nodes)
+    # the pod stream follows the INPUT node order (DaemonSet pods are made node by node from cluster.Nodes + new nodes,
+    # pkg/simulator/core.go:85-95); only the engine's node arrays are in nodeTree order
+    pods, _ = build_stream(cluster, apps, nodes, len(nodes))
     order = k8s.canonical_node_order(nodes)
     nodes = [nodes[j] for j in order]
-    pods, _ = build_stream(cluster, apps, nodes, len(nodes))
     flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []),
                       storage_classes=_storage_classes(cluster, apps))
     P = len(pods)
@@ -190,19 +197,26 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
     if max(counts) > 0 and new_node is None:
         raise ValueError("new node is nil when adding node to cluster")          # utils.NewFakeNodes (utils.go:886-888)
     pool = base + (wl.new_fake_nodes(new_node, max(counts)) if max(counts) > 0 else [])
+    node_ranks = None
     try:
         _check_prefix_order(pool, [len(base) + k for k in counts])
     except fl.Unsupported:
-        # nodes in several zones: nodeTree order of a cluster size is not a prefix of the next one's, so every size is its
-        # own problem (own canonical node order) -- one scenario per engine call, like the reference's loop
-        return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
+        # nodes in several zones: the nodeTree order of one cluster size is not a prefix of the next one's.  The pool keeps
+        # its layout (cluster nodes, then clones: every scenario is a prefix SET) and each scenario brings its own
+        # canonical ranks for selectHost's tie-break (simon_set_node_ranks); engines without that run size by size.
+        if not getattr(engine, "supports_node_ranks", True):
+            return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
+        node_ranks = np.zeros((len(counts), len(pool)), np.int32)
+        for s, k in enumerate(counts):
+            order = k8s.canonical_node_order(pool[:len(base) + k])
+            node_ranks[s, order] = np.arange(len(order), dtype=np.int32)
     pods, gates = build_stream(cluster, apps, pool, len(base))
     flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates,
                       storage_classes=_storage_classes(cluster, apps))
     P = len(pods)
     scen = np.array([[len(base) + k, 0] for k in counts], np.int32)
     orders = np.arange(P, dtype=np.int32)[None, :]
-    out = engine.run(flat.problem, scen, orders)
+    out = engine.run(flat.problem, scen, orders) if node_ranks is None else engine.run(flat.problem, scen, orders, node_ranks=node_ranks)
     pc, pm = np.cumsum(flat.problem.alloc_cpu), np.cumsum(flat.problem.alloc_mem)
     cpu_pct = [occupancy_pct(int(out.used_cpu[s]), int(pc[scen[s, 0] - 1])) for s in range(len(counts))]
     mem_pct = [occupancy_pct(int(out.used_mem[s]) * 1000, int(pm[scen[s, 0] - 1]) * 1000) for s in range(len(counts))]
@@ -231,8 +245,8 @@ def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, m
     uns, cpu_pct, mem_pct, vg_pct, kept = [], [], [], [], {}
     for s, k in enumerate(counts):
         nodes = base + (wl.new_fake_nodes(new_node, k) if k > 0 else [])
-        nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
         pods, _ = build_stream(cluster, apps, nodes, len(nodes))
+        nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
         flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []),
                           storage_classes=_storage_classes(cluster, apps))
         out = engine.run(flat.problem, np.array([[len(nodes), 0]], np.int32), np.arange(len(pods), dtype=np.int32)[None, :])

@@ -476,6 +476,9 @@ static int64_t class_cell(const int64_t* table, const simon_nodes_soa* nd, const
  * percentageOfNodesToScore=100 (pkg/simulator/utils.go:370), prioritizeNodes (:470),
  * selectHost (:188) determinised to the first maximum.  Returns the node or -1.
  * codes: [n] scratch (required); o_*: optional per-node score breakdown. */
+/* canonical rank of the pool nodes in the scenario being run (NULL = pool order); only selectHost's tie-break reads it */
+static __thread const int32_t* g_node_rank = NULL;
+
 static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb, const state_t* s,
                         const pod_t* p, int n, uint16_t* codes /*[n]*/, int64_t* o_feasible,
                         int64_t* o_la, int64_t* o_ba, int64_t* o_sn, int64_t* o_total) {
@@ -614,7 +617,9 @@ static int schedule_one(const simon_nodes_soa* nd, const simon_class_tables* tb,
         }
         if (lsp) total += (l_hi - l_lo == 0) ? 0 : (lraw[j] - l_lo) * MAX_NODE_SCORE / (l_hi - l_lo);
         if (o_total) { o_la[j] = la; o_ba[j] = ba; o_sn[j] = sn; o_total[j] = total; }
-        if (best < 0 || total > best_total) { best = j; best_total = total; }   /* first max */
+        if (best < 0 || total > best_total || (g_node_rank && total == best_total && g_node_rank[j] < g_node_rank[best])) {
+            best = j; best_total = total;                                         /* first max in canonical order */
+        }
     }
     free(ipa); free(pts); free(ignored); free(lraw);
     return best;
@@ -715,14 +720,25 @@ int simon_oracle_run(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
                      const int32_t* orders, int32_t n_orders, simon_batch_out* out,
                      int32_t explain_scenario, int32_t* failed_pods, uint16_t* fail_codes,
                      int32_t max_failed, int32_t* n_failed_out) {
+    return simon_oracle_run_ranked(nodes, pods, tables, scen, S, orders, n_orders, NULL, out, explain_scenario, failed_pods,
+                                   fail_codes, max_failed, n_failed_out);
+}
+
+int simon_oracle_run_ranked(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
+                            const simon_class_tables* tables, const simon_scenario* scen, int32_t S,
+                            const int32_t* orders, int32_t n_orders, const int32_t* node_rank /* [S][N] or NULL */,
+                            simon_batch_out* out, int32_t explain_scenario, int32_t* failed_pods, uint16_t* fail_codes,
+                            int32_t max_failed, int32_t* n_failed_out) {
     int P = pods->n_pods;
     for (int s = 0; s < S; s++) {
+        g_node_rank = node_rank ? node_rank + (size_t)s * nodes->n_nodes : NULL;
         if (orders && (scen[s].order_id < 0 || scen[s].order_id >= n_orders)) return SIMON_EINVAL;
         const int32_t* ord = orders ? orders + (size_t)scen[s].order_id * P : NULL;
         int explain = (failed_pods && fail_codes && s == explain_scenario);
         int rc = run_scenario(nodes, pods, tables, scen[s].n_nodes, ord, &out->unscheduled[s], &out->used_cpu[s],
                               &out->used_mem[s], out->used_vg ? &out->used_vg[s] : NULL, out->placement ? out->placement + (size_t)s * P : NULL, explain,
                               failed_pods, fail_codes, max_failed, n_failed_out);
+        g_node_rank = NULL;
         if (rc) return rc;
     }
     return 0;

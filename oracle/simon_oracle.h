@@ -32,6 +32,14 @@ int simon_oracle_run(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
                      int32_t explain_scenario, int32_t* failed_pods, uint16_t* fail_codes,
                      int32_t max_failed, int32_t* n_failed_out);
 
+/* The same with a canonical node order per scenario: node_rank[s][j] = position of pool node j in scenario s's nodeTree
+ * order (V/internal/cache/node_tree.go:119-143); selectHost's first maximum is taken in that order. */
+int simon_oracle_run_ranked(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
+                            const simon_class_tables* tables, const simon_scenario* scen, int32_t S,
+                            const int32_t* orders, int32_t n_orders, const int32_t* node_rank,
+                            simon_batch_out* out, int32_t explain_scenario, int32_t* failed_pods, uint16_t* fail_codes,
+                            int32_t max_failed, int32_t* n_failed_out);
+
 /* Per-node score breakdown for ONE pod against the CURRENT (initial) node state of the first
  * n_nodes pool nodes: feasible[j], la[j], ba[j], sn[j], total[j] (all int64 [n_nodes]).
  * Used to check the hand-derived known-answer vector. */

@@ -50,7 +50,7 @@ def load():
     return lib
 
 
-def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0):
+def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0, node_ranks=None):
     """Run scenarios on the oracle; returns BatchResult (+ (n_failed, failed_pods, codes) when explaining)."""
     lib = load()
     prob.normalise()
@@ -71,6 +71,15 @@ def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=
         assert rc == 0, rc
         k = min(nf.value, max_failed)
         return res, (nf.value, failed[:k], codes[:k])
+    if node_ranks is not None:
+        ranks = np.ascontiguousarray(node_ranks, np.int32)
+        assert ranks.shape == (len(scen), prob.n_nodes)
+        lib.simon_oracle_run_ranked.restype = C.c_int
+        rc = lib.simon_oracle_run_ranked(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
+                                         C.c_int32(len(scen)), capi._ptr(orders, C.c_int32), C.c_int32(orders.shape[0]),
+                                         capi._ptr(ranks, C.c_int32), C.byref(out), C.c_int32(-1), None, None, C.c_int32(0), None)
+        assert rc == 0, rc
+        return res
     rc = lib.simon_oracle_run(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
                               len(scen), capi._ptr(orders, C.c_int32), orders.shape[0], C.byref(out), -1, None, None,
                               0, None)

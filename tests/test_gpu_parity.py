@@ -341,6 +341,54 @@ def test_k8s_sweep_at_scale_matches_oracle():
     assert_same(eng.out, O.run(prob, scen, orders))
 
 
+def _random_ranks(rng, scen, N):
+    ranks = np.zeros((len(scen), N), np.int32)
+    for s, (n, _) in enumerate(np.asarray(scen).tolist()):
+        ranks[s, :n] = rng.permutation(n)
+    return ranks
+
+
+@pytest.mark.parametrize("feat", [dict(), dict(static_mask=True, presets=True, gates=True, pins=True),
+                                  dict(gpu=True, anti=True, static_mask=True),
+                                  dict(ipa=True, spread_soft=True, spread_hard=True, aff=True, static_scores=True, static_mask=True)])
+def test_per_scenario_node_ranks(feat):
+    """simon_set_node_ranks: the tie-break of selectHost follows the scenario's own canonical node order.  Homogeneous
+    pools (every score ties) make the ranks decide almost every placement."""
+    rng = np.random.default_rng(5)
+    for seed, homogeneous in ((0, True), (1, False)):
+        prob = randprob.rand_problem(6000 + seed, N=60 + 50 * seed, P=300, **feat)
+        if homogeneous:
+            prob.alloc_cpu[:] = prob.alloc_cpu[0]; prob.alloc_mem[:] = prob.alloc_mem[0]; prob.alloc_pods[:] = prob.alloc_pods[0]
+            prob.node_class[:] = 0
+        scen, orders = randprob.rand_scenarios(seed, prob, S=6)
+        ranks = _random_ranks(rng, scen, prob.n_nodes)
+        ref = O.run(prob, scen, orders, node_ranks=ranks)
+        assert (ref.placement != O.run(prob, scen, orders).placement).any()          # the ranks matter on this input
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            assert ctx.stats().kernel_variant == capi.KERNEL_WIDE
+            assert_same(ctx.fetch(True), ref)
+            ctx.set_node_ranks(None)                                                  # back to pool order
+            ctx.run_loaded(True)
+            assert_same(ctx.fetch(True), O.run(prob, scen, orders))
+
+
+def test_k8s_sweep_over_several_zones_on_gpu():
+    """tests/test_host_mirror.py::test_sweep_over_several_zones_... with the product engine: one batch with per-scenario
+    nodeTree ranks against one Simulate() per size."""
+    import test_host_mirror as H
+    from open_simulator_amd import simulate as sim
+    orig = H.OracleEngine
+    H.OracleEngine = sim.HipEngine
+    try:
+        H.test_sweep_over_several_zones_runs_every_size_on_its_own()
+    finally:
+        H.OracleEngine = orig
+
+
 def test_config5_gpushare_style():
     """BASELINE config 5 shape (GPU share + required anti-affinity + taints): small pool, every placement compared;
     then ONE scenario at full size (50k pods x 5k nodes)."""
