@@ -54,7 +54,7 @@ __host__ __device__ inline int cache_nbp(int nblk) { return nblk + ((2 - (nblk &
 size_t cache_lds_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
 size_t cache_ws_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
-hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
+hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
                             int32_t* placement, hipStream_t st);
 

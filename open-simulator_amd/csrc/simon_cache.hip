@@ -101,7 +101,9 @@ __host__ __device__ inline Carve carve(int K, int ni_max, int Cn, int Cp, int n_
     return c;
 }
 
-template <bool HAS_MASK, bool NZEQ>
+// HAS_PIN: the stream holds pinned pods (pin_node); a separate instantiation because the extra branch costs the
+// common kernel 2.6 % (same-box A/B)
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN>
 __global__ __launch_bounds__(64) void cache_kernel(
     const int32_t* __restrict__ ncls, const int32_t* __restrict__ rank, const int32_t* __restrict__ shape_of,
     const int32_t* __restrict__ a_pods, const uint32_t* __restrict__ i_rq_cpu, const uint32_t* __restrict__ i_rq_mem,
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64) void cache_kernel(
         } else if (r_preset >= 0) {                                    // addPodToCache path (V/eventhandlers.go:223-236)
             res = r_preset;
             pstar = __builtin_amdgcn_readfirstlane(s_seg[ncls[r_preset]] + rank[r_preset]);
-        } else if (r_preset <= -2) {                                   // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
+        } else if (HAS_PIN && r_preset <= -2) {                        // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
             const int pin = -2 - r_preset;                             // its node affinity admits ONE node; the table byte of
             res = -1;                                                  // (signature, node) holds static filters + fit
             if (pin < n) {
@@ -409,9 +411,9 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restric
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
 }
 
-template <bool M, bool Z>
-static hipError_t launch_mz(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = cache_kernel<M, Z>;
+template <bool M, bool Z, bool PIN>
+static hipError_t launch_mzp(const CacheLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    auto kern = cache_kernel<M, Z, PIN>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.ncls, a.rank, a.shape_of, a.a_pods, a.i_rq_cpu,
@@ -429,9 +431,14 @@ size_t cache_ws_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq
 }
 
 // n_blocks scenarios; scenario of block b = a.perm[b]; a.ws = [n_blocks][cache_ws_bytes]
-hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (has_mask) return nzeq ? launch_mz<true, true>(a, n_blocks, lds_bytes, st) : launch_mz<true, false>(a, n_blocks, lds_bytes, st);
-    return nzeq ? launch_mz<false, true>(a, n_blocks, lds_bytes, st) : launch_mz<false, false>(a, n_blocks, lds_bytes, st);
+template <bool M, bool Z>
+static hipError_t launch_mz(const CacheLaunch& a, int n_blocks, bool has_pin, size_t lds, hipStream_t st) {
+    return has_pin ? launch_mzp<M, Z, true>(a, n_blocks, lds, st) : launch_mzp<M, Z, false>(a, n_blocks, lds, st);
+}
+
+hipError_t launch_cache(const CacheLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
+    if (has_mask) return nzeq ? launch_mz<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_mz<true, false>(a, n_blocks, has_pin, lds_bytes, st);
+    return nzeq ? launch_mz<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_mz<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }
 
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,

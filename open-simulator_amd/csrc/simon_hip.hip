@@ -779,7 +779,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 f.ws = c->d_ws.p + bd.ws_off;
                 f.sc = CacheScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max,
                                     c->ablate, c->g_cpu, c->g_mem};
-                HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, bd.lds, bs));
+                HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, c->has_pin, bd.lds, bs));
                 if (bs != c->stream) {
                     HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
                     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev[bi], 0));
