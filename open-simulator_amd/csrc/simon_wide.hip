@@ -580,11 +580,14 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     const bool use_tab = !EXPLAIN && A.n_sigs > 0;
     // selectHost's tie-break index of a node / node of a tie-break index: pool order unless the host supplied the scenario's
     // nodeTree ranks (clusters with several zones)
+    // (the lean instantiation never sees ranks -- the flag check alone cost it 3 % in a same-box A/B; ranked batches of a
+    // lean problem run the full instantiation)
+    constexpr bool kCanRank = VAR != 0;
     auto rank_of = [&](int j) -> unsigned {
-        return (A.flags & kArgRanked) ? (unsigned)COLD(A)->node_rank[(size_t)(A.scen_base + s) * N + j] : (unsigned)j;
+        return (kCanRank && (A.flags & kArgRanked)) ? (unsigned)COLD(A)->node_rank[(size_t)(A.scen_base + s) * N + j] : (unsigned)j;
     };
     auto node_of = [&](int r) -> int {
-        return (A.flags & kArgRanked) ? COLD(A)->node_inv[(size_t)(A.scen_base + s) * N + r] : r;
+        return (kCanRank && (A.flags & kArgRanked)) ? COLD(A)->node_inv[(size_t)(A.scen_base + s) * N + r] : r;
     };
 
     NodeView v;
@@ -1357,7 +1360,7 @@ hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
     (void)max_n;
 #define WIDE_LAUNCH(TT)                                                                                   \
     if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 2>), grid, dim3(TT), lds, st, a);    \
-    else if (!EXPLAIN && (a.flags & kArgLean)) hipLaunchKernelGGL((wide_kernel<TT, false, 0>), grid, dim3(TT), lds, st, a); \
+    else if (!EXPLAIN && (a.flags & kArgLean) && !(a.flags & kArgRanked)) hipLaunchKernelGGL((wide_kernel<TT, false, 0>), grid, dim3(TT), lds, st, a); \
     else hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 1>), grid, dim3(TT), lds, st, a)
     switch (T) {
         case 64: WIDE_LAUNCH(64); break;
