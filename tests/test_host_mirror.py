@@ -61,6 +61,17 @@ def _random_case(seed, **kw):
     nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
     cluster = {k: [] for k in k8s.KINDS}
     cluster["Node"], cluster["Service"] = nodes, services
+    if seed % 3 != 1:       # DaemonSets: per-node pods pinned by matchFields (one with its own node selector terms and a toleration)
+        spec_a = {"containers": [{"name": "a", "image": "busybox", "resources": {"requests": {"cpu": "100m", "memory": "64Mi"}}}]}
+        spec_b = {"containers": [{"name": "b", "image": "busybox", "resources": {"requests": {"cpu": "200m"}}}],
+                  "tolerations": [{"key": "dedicated", "operator": "Exists"}],
+                  "affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [
+                      {"matchExpressions": [{"key": "disk", "operator": "In", "values": ["ssd"]}]},
+                      {"matchExpressions": [{"key": "rank", "operator": "Exists"}]}]}}}}
+        cluster["DaemonSet"] = [
+            {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": f"ds-{i}", "namespace": "kube-system"},
+             "spec": {"selector": {"matchLabels": {"app": f"ds-{i}"}}, "template": {"metadata": {"labels": {"app": f"ds-{i}"}}, "spec": sp}}}
+            for i, sp in enumerate([spec_a, spec_b][:1 + seed % 2])]
     pods, _ = sim.build_stream(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], nodes, len(nodes))
     return nodes, pods, services, rs
 
