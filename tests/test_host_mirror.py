@@ -179,24 +179,28 @@ def test_differing_priorities_are_refused():
         sim.simulate(cluster, [sim.AppResource("app", k8s.group_resources(workloads + [extra]))], engine=OracleEngine())
 
 
-def test_sweep_over_several_zones_runs_every_size_on_its_own():
+def test_sweep_over_several_zones_runs_every_size_on_its_own(seeds=(11, 31, 47)):
     """With nodes in several zones the nodeTree order of one cluster size is not a prefix of the next (the clones join
-    one zone's round-robin list), so sweep() evaluates each size as its own problem; the answers must be those of one
-    Simulate() per size."""
-    nodes, workloads, services = randk8s.rand_cluster(11, n_nodes=7, n_workloads=12, max_replicas=8)
-    assert len({k8s.zone_key(n) for n in nodes}) > 1
-    cluster = k8s.group_resources(nodes + services)
-    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
-    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z1"}},
-                "status": {"allocatable": {"cpu": "16", "memory": "32Gi", "pods": "20"}, "capacity": {"cpu": "16", "memory": "32Gi"}}}
+    one zone's round-robin list).  sweep() still runs ONE batch -- the pool stays "cluster nodes, then clones" and every
+    scenario brings its canonical ranks (simon_set_node_ranks) -- and must answer like one Simulate() per size."""
     eng = OracleEngine()
-    counts = [0, 1, 2, 4]
-    with pytest.raises(fl.Unsupported):
-        sim._check_prefix_order(cluster["Node"] + wl.new_fake_nodes(template, 4), [len(nodes) + k for k in counts])
-    sw = sim.sweep(cluster, apps, template, counts, engine=eng)
-    for k, uns in zip(counts, sw.unscheduled):
-        one = sim.simulate(cluster, apps, engine=eng, new_nodes=wl.new_fake_nodes(template, k))
-        assert len(one.unscheduled_pods) == uns, k
+    for seed in seeds:
+        nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=7, n_workloads=12, max_replicas=8)
+        assert len({k8s.zone_key(n) for n in nodes}) > 1
+        cluster = k8s.group_resources(nodes + services)
+        apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+        template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z1"}},
+                    "status": {"allocatable": {"cpu": "16", "memory": "32Gi", "pods": "20"}, "capacity": {"cpu": "16", "memory": "32Gi"}}}
+        counts = [0, 1, 2, 4]
+        with pytest.raises(fl.Unsupported):
+            sim._check_prefix_order(cluster["Node"] + wl.new_fake_nodes(template, 4), [len(nodes) + k for k in counts])
+        sw = sim.sweep(cluster, apps, template, counts, engine=eng)
+        for k, uns in zip(counts, sw.unscheduled):
+            one = sim.simulate(cluster, apps, engine=eng, new_nodes=wl.new_fake_nodes(template, k))
+            assert len(one.unscheduled_pods) == uns, (seed, k)
+            if sw.best == k:            # the plan's placements, node by node
+                by_node = lambda res: {st["node"]["metadata"]["name"]: sorted(p["metadata"]["name"] for p in st["pods"]) for st in res.node_status}
+                assert by_node(sw.result) == by_node(one), seed
 
 
 def _problem_arrays(prob):
