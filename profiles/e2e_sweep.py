@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--max-replicas", type=int, default=250)
     ap.add_argument("--counts", type=int, default=64)
     ap.add_argument("--daemonsets", type=int, default=1)
+    ap.add_argument("--own-zone", action="store_true", help="new nodes form a zone of their own: nodeTree order differs per cluster size "
+                    "(per-scenario node ranks, simon_set_node_ranks)")
     ap.add_argument("--uniform-pods", action="store_true", help="every node allows 110 pods (fewer node classes: the <= 64 class path)")
     a = ap.parse_args()
     nodes, workloads, services = randk8s.rand_cluster(1, n_nodes=a.nodes, n_workloads=a.workloads, max_replicas=a.max_replicas)
@@ -44,17 +46,21 @@ def main():
                                           "tolerations": [{"operator": "Exists"}]}}}} for i in range(a.daemonsets)]
     cluster = k8s.group_resources(nodes + services + ds)
     apps = [sim.AppResource("app", k8s.group_resources(workloads))]
-    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z0"}},
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "znew" if a.own_zone else "z0"}},
                 "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "40"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
     counts = np.unique(np.linspace(0, a.new_nodes, a.counts).astype(int)).tolist()
 
     class TimedEngine(sim.HipEngine):
-        def run(self, prob, scen, orders, want_placement=True):
-            self.problem, self.scen, self.orders = prob, scen, orders
+        def run(self, prob, scen, orders, want_placement=True, node_ranks=None):
+            self.problem, self.scen, self.orders, self.ranked = prob, scen, orders, node_ranks is not None
             t0 = time.perf_counter()
             with capi.Context(self.device_id) as ctx:
                 ctx.load_problem(prob)
-                out = ctx.run_batch(scen, orders, want_placement)
+                ctx.load_scenarios(scen, orders)
+                if node_ranks is not None:
+                    ctx.set_node_ranks(node_ranks)
+                ctx.run_loaded(want_placement)
+                out = ctx.fetch(want_placement)
                 self.stats = ctx.stats()
             self.engine_s = time.perf_counter() - t0
             self.out = out
@@ -73,7 +79,7 @@ def main():
            "pod_classes": int(prob.n_pod_classes), "node_classes": int(prob.n_node_classes),
            "total_s": round(total, 2), "engine_s": round(eng.engine_s, 2), "kernel_ms": round(eng.stats.kernel_ms, 1),
            "kernel_variant": int(eng.stats.kernel_variant), "workgroup": int(eng.stats.workgroup_size),
-           "host_s": round(total - eng.engine_s, 2), "best_new_nodes": sw.best, "unscheduled_first_last": [sw.unscheduled[0], sw.unscheduled[-1]]}
+           "host_s": round(total - eng.engine_s, 2), "node_ranks": bool(eng.ranked), "best_new_nodes": sw.best, "unscheduled_first_last": [sw.unscheduled[0], sw.unscheduled[-1]]}
     print(json.dumps(res))
 
 
