@@ -512,6 +512,23 @@ def test_errors_are_reported_not_thrown():
             ctx.run_batch([[prob.n_nodes + 1, 0]], orders)
         with pytest.raises(capi.SimonError):
             ctx.run_batch([[5, 3]], orders)
+        # node ranks must be a permutation of 0..n-1 per scenario; they need loaded scenarios
+        ctx.load_scenarios([[6, 0], [9, 0]], orders)
+        ranks = np.zeros((2, prob.n_nodes), np.int32)
+        ranks[0, :6] = np.arange(6)[::-1]
+        ranks[1, :9] = [0, 1, 2, 3, 4, 5, 6, 7, 7]             # 7 twice, 8 missing
+        with pytest.raises(capi.SimonError, match="permutation"):
+            ctx.set_node_ranks(ranks)
+        ranks[1, :9] = np.arange(9)
+        ctx.set_node_ranks(ranks)
+        ctx.run_loaded(True)
+    # a pinned pod must name a pool node and cannot also be bound
+    bad = randprob.rand_problem(1, N=10, P=20)
+    bad.pin_node = np.full(20, -1, np.int32)
+    bad.pin_node[3] = 10
+    with capi.Context(0) as ctx:
+        with pytest.raises(capi.SimonError, match="pin_node"):
+            ctx.load_problem(bad)
 
 
 def test_bench_two_ranks_share_one_gpu(tmp_path):
