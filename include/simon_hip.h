@@ -17,6 +17,8 @@
  *     ephemeral-storage / gpu-mem in bytes (Quantity.Value), pod counts as int32.
  *   - node order is the canonical snapshot order nodeTree.list() produces
  *     (V/internal/cache/node_tree.go:119-143); a scenario with n_nodes = n uses pool nodes [0, n).
+ *     When that order differs between the cluster sizes of one batch (nodes in several zones), the pool
+ *     stays "cluster nodes, then clones" and simon_set_node_ranks passes each scenario's own order.
  *
  * Semantics are the determinised reference D of DESIGN.md section 2: percentageOfNodesToScore=100,
  * filters in registry order with early exit, scores summed with their weights, selectHost =
