@@ -264,8 +264,48 @@ def _bitmask(flags, words) -> np.ndarray:
     return _bitmask_rows(np.asarray(flags, bool)[None, :], words)[0]
 
 
+def image_states(nodes_in_arrival_order: List[dict]) -> Dict[str, Dict[str, Tuple[int, int]]]:
+    """node name -> {image name: (size, NumNodes)} as schedulerCache.addNodeImageStates leaves NodeInfo.ImageStates
+    (V/internal/cache/cache.go:675-698): the summary of an image is taken when the node ARRIVES, so it counts the nodes that
+    listed the image up to then; the size is the first lister's."""
+    size: Dict[str, int] = {}
+    count: Dict[str, int] = {}
+    out = {}
+    for n in nodes_in_arrival_order:
+        mine = {}
+        for img in (n.get("status") or {}).get("images") or []:
+            for name in img.get("names") or []:
+                if name not in size:
+                    size[name], count[name] = int(img.get("sizeBytes") or 0), 0
+                if name not in mine:
+                    count[name] += 1
+                    mine[name] = None
+        out[n["metadata"]["name"]] = {name: (size[name], count[name]) for name in mine}
+    return out
+
+
+def image_locality_score(pod: dict, states: Dict[str, Tuple[int, int]], total_nodes: int) -> int:
+    """ImageLocality.Score (imagelocality/image_locality.go:53-113): sum over the containers of
+    int64(float64(size) * (float64(NumNodes) / float64(totalNumNodes))), clamped to [23 MB, 1000 MB x containers], scaled to 0..100."""
+    mb = 1024 * 1024
+    conts = pod["spec"].get("containers") or []
+    if not conts:
+        return 0
+    ssum = 0
+    for c in conts:
+        name = str(c.get("image") or "")
+        name = name if name.rfind(":") > name.rfind("/") else name + ":latest"          # normalizedImageName (:120-125)
+        if name in states:
+            sz, cnt = states[name]
+            ssum += int(float(sz) * (float(cnt) / float(total_nodes)))
+    hi = 1000 * mb * len(conts)
+    ssum = min(max(ssum, 23 * mb), hi)
+    return 100 * (ssum - 23 * mb) // (hi - 23 * mb)
+
+
 def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), statefulsets=(),
-            gates: Optional[List[int]] = None, storage_classes=()) -> Flat:
+            gates: Optional[List[int]] = None, storage_classes=(), image_total: Optional[int] = None,
+            node_arrival_order: Optional[List[str]] = None) -> Flat:
     """nodes: the pool in canonical order (cluster nodes, then new-node clones).  pods: the stream in scheduling order;
     a pod with spec.nodeName is bound without filtering (V/eventhandlers.go:223-236).  gates[p] = node index the pod
     depends on (DaemonSet pods of new nodes, pkg/simulator/core.go:85-95) or -1."""
@@ -356,16 +396,23 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         raise Unsupported("pods with different spec.priority: DefaultPreemption may evict placed pods")
 
     # ---- ImageLocality (imagelocality/image_locality.go:53-113) is a constant 0 as long as no node lists an image a pod
-    # runs; otherwise its score depends on the scenario's node count (spread = NumNodes / totalNumNodes): Go path.
+    # runs.  Otherwise its score depends on the cluster size (spread = NumNodes / totalNumNodes): with ONE size
+    # (image_total = the scenario's node count, simulate()) it is a static per (class, node) score that joins static_add;
+    # a batch of different sizes is left to the Go path.
     wanted = set()
     for p in class_rep:
         for c in p["spec"].get("containers") or []:
             name = str(c.get("image") or "")
             wanted.add(name if name.rfind(":") > name.rfind("/") else name + ":latest")          # normalizedImageName (:120-125)
-    for n in nodes:
-        for img in (n.get("status") or {}).get("images") or []:
-            if wanted.intersection(img.get("names") or []):
-                raise Unsupported(f"node {n['metadata']['name']} lists image(s) the pods run: ImageLocality is not constant")
+    img_nodes = [j for j, n in enumerate(nodes)
+                 if any(wanted.intersection(img.get("names") or []) for img in (n.get("status") or {}).get("images") or [])]
+    img_states = None
+    if img_nodes:
+        if image_total is None:
+            raise Unsupported(f"node {node_names[img_nodes[0]]} lists image(s) the pods run: ImageLocality depends on the cluster size")
+        by_name = {n["metadata"]["name"]: n for n in nodes}
+        arrival = [by_name[x] for x in node_arrival_order] if node_arrival_order is not None else nodes
+        img_states = image_states(arrival)
 
     # ---- static filters per (pod class, node): first failing plugin in registry order --------------------------
     # A class looks at a node only through the label keys its nodeSelector / node affinity name, the node's taints,
@@ -484,6 +531,15 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
             continue
         trip = intern_col(zip(na_u.tolist(), tt_u.tolist(), npa_u.tolist()))
         _, part = np.unique(part * (int(trip.max()) + 1) + trip[inv], return_inverse=True)
+    img_cols: Dict[int, np.ndarray] = {}            # class -> ImageLocality score per node (only classes that score somewhere)
+    if img_states is not None:
+        for c, p in enumerate(class_rep):
+            col = np.zeros(N, np.int64)
+            for j in img_nodes:
+                col[j] = image_locality_score(p, img_states[node_names[j]], image_total)
+            if col.any():
+                img_cols[c] = col
+                _, part = np.unique(part * (int(col.max()) + 1) + col, return_inverse=True)
     _, first, inv = np.unique(part, return_index=True, return_inverse=True)
     rank = np.empty(len(first), np.int64)
     rank[np.argsort(first, kind="stable")] = np.arange(len(first))
@@ -525,8 +581,11 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         prob_kw["taint_prefer_raw"] = tt_t
     else:
         const += 100                                   # DefaultNormalizeScore(reverse) of all zeros
-    if (npa_t != 100).any():
-        prob_kw["static_add"] = npa_t * 10000
+    img_t = np.zeros((Cp, Cn), np.int64)
+    for c, col in img_cols.items():
+        img_t[c] = col[rep_idx]
+    if (npa_t != 100).any() or img_t.any():
+        prob_kw["static_add"] = npa_t * 10000 + img_t            # NodePreferAvoidPods x 10000 + ImageLocality x 1, no NormalizeScore
     else:
         const += 100 * 10000
 

@@ -146,10 +146,11 @@ def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine
     # the pod stream follows the INPUT node order (DaemonSet pods are made node by node from cluster.Nodes + new nodes,
     # pkg/simulator/core.go:85-95); only the engine's node arrays are in nodeTree order
     pods, _ = build_stream(cluster, apps, nodes, len(nodes))
+    arrival = [n["metadata"]["name"] for n in nodes]               # order in which the scheduler cache meets the nodes
     order = k8s.canonical_node_order(nodes)
     nodes = [nodes[j] for j in order]
     flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []),
-                      storage_classes=_storage_classes(cluster, apps))
+                      storage_classes=_storage_classes(cluster, apps), image_total=len(nodes), node_arrival_order=arrival)
     P = len(pods)
     scen = np.array([[len(nodes), 0]], np.int32)
     orders = np.arange(P, dtype=np.int32)[None, :]
@@ -211,8 +212,14 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
             order = k8s.canonical_node_order(pool[:len(base) + k])
             node_ranks[s, order] = np.arange(len(order), dtype=np.int32)
     pods, gates = build_stream(cluster, apps, pool, len(base))
-    flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates,
-                      storage_classes=_storage_classes(cluster, apps))
+    try:
+        flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates,
+                          storage_classes=_storage_classes(cluster, apps))
+    except fl.Unsupported as e:
+        if "ImageLocality" not in str(e):
+            raise
+        # ImageLocality scores depend on the cluster size: every size is its own problem with its own static scores
+        return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
     P = len(pods)
     scen = np.array([[len(base) + k, 0] for k in counts], np.int32)
     orders = np.arange(P, dtype=np.int32)[None, :]
@@ -246,9 +253,10 @@ def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, m
     for s, k in enumerate(counts):
         nodes = base + (wl.new_fake_nodes(new_node, k) if k > 0 else [])
         pods, _ = build_stream(cluster, apps, nodes, len(nodes))
+        arrival = [n["metadata"]["name"] for n in nodes]
         nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
         flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []),
-                          storage_classes=_storage_classes(cluster, apps))
+                          storage_classes=_storage_classes(cluster, apps), image_total=len(nodes), node_arrival_order=arrival)
         out = engine.run(flat.problem, np.array([[len(nodes), 0]], np.int32), np.arange(len(pods), dtype=np.int32)[None, :])
         uns.append(int(out.unscheduled[0]))
         cpu_pct.append(occupancy_pct(int(out.used_cpu[0]), int(flat.problem.alloc_cpu.sum())))

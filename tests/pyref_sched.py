@@ -178,6 +178,20 @@ class Scheduler:
         self.infos = [NodeInfo(n) for n in nodes]
         self.services, self.replicasets, self.statefulsets = list(services), list(replicasets), list(statefulsets)
         self.storage_classes = list(storage_classes)
+        # ImageLocality: the cache's imageStates as addNodeImageStates leaves them (V/internal/cache/cache.go:675-698): a node's
+        # summary of an image counts the nodes that listed it UP TO that node's own arrival, the size is the first lister's
+        self.image_states = []
+        size, count = {}, {}
+        for n in nodes:
+            mine = {}
+            for img in (n.get("status") or {}).get("images") or []:
+                for name in img.get("names") or []:
+                    if name not in size:
+                        size[name], count[name] = int(img.get("sizeBytes") or 0), 0
+                    if name not in mine:
+                        count[name] += 1
+                        mine[name] = None
+            self.image_states.append({name: (size[name], count[name]) for name in mine})
 
     # InterPodAffinity.PreFilter, interpodaffinity/filtering.go:166-274: three topologyPair -> count maps
     def _ipa_prefilter(self, pod):
@@ -427,9 +441,25 @@ class Scheduler:
             raw = [local_raw_score(ni, local_units(ni, vols)) for ni in feasible]
             lo, hi = min(raw), max(raw)
             local = [0 if hi == lo else (x - lo) * MAX // (hi - lo) for x in raw]
+        # ImageLocality.Score (imagelocality/image_locality.go:53-113): no NormalizeScore, weight 1
+        mb = 1024 * 1024
+        conts = pod["spec"].get("containers") or []
+        img = []
+        for ni in feasible:
+            states = self.image_states[self.infos.index(ni)]
+            ssum = 0
+            for c in conts:
+                name = str(c.get("image") or "")
+                name = name if name.rfind(":") > name.rfind("/") else name + ":latest"
+                if name in states:
+                    sz, cnt = states[name]
+                    ssum += int(float(sz) * (float(cnt) / float(len(self.infos))))
+            hi_t = 1000 * mb * len(conts)
+            ssum = min(max(ssum, 23 * mb), hi_t) if conts else 23 * mb
+            img.append(MAX * (ssum - 23 * mb) // (hi_t - 23 * mb) if conts else 0)
         best, best_total = None, None
         for i, ni in enumerate(feasible):
-            total = ba[i] + la[i] + 2 * sn[i] + ipa[i] + na_n[i] + 10000 * npa[i] + 2 * pts[i] + tt_n[i] + local[i]
+            total = ba[i] + la[i] + 2 * sn[i] + ipa[i] + na_n[i] + 10000 * npa[i] + 2 * pts[i] + tt_n[i] + local[i] + img[i]
             if best is None or total > best_total:
                 best, best_total = ni, total
         return best

@@ -154,17 +154,55 @@ def test_reference_open_local_example_end_to_end():
     del root
 
 
-def test_image_locality_is_constant_or_refused():
-    """ImageLocality scores 0 everywhere unless a node lists an image some pod runs (imagelocality/image_locality.go:96-113);
-    the mirror then refuses (the score depends on the scenario's node count) instead of silently ignoring the plugin."""
+def _with_images(nodes, seed):
+    """some nodes list the image the random pods run ("busybox" -> "busybox:latest") and an unrelated one"""
+    rng = np.random.default_rng(seed)
+    for n in nodes:
+        if rng.random() < 0.5:
+            n.setdefault("status", {})["images"] = [
+                {"names": ["registry.local/other:1.0", "other@sha256:abc"], "sizeBytes": 500 << 20},
+                {"names": ["busybox:latest", "docker.io/library/busybox@sha256:123"], "sizeBytes": int(rng.integers(30, 2500)) << 20}]
+    return nodes
+
+
+@pytest.mark.parametrize("seed", [2, 5, 9, 14])
+def test_image_locality_single_size(seed):
+    """ImageLocality (imagelocality/image_locality.go:53-113) for ONE cluster size: a static per (class, node) score next to
+    NodePreferAvoidPods in static_add -- against the object-level scheduler, which keeps its own imageStates."""
+    nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=9, n_workloads=10)
+    nodes = _with_images([nodes[j] for j in k8s.canonical_node_order(nodes)], seed)
+    cluster = {k: [] for k in k8s.KINDS}
+    cluster["Node"], cluster["Service"] = nodes, services
+    pods, _ = sim.build_stream(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], nodes, len(nodes))
+    flat = fl.flatten(nodes, pods, services, [], [], image_total=len(nodes))
+    assert flat.problem.static_add is not None and (flat.problem.static_add % 10000 != 0).any()      # the plugin scores somewhere
+    res = O.run(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
+    ref = pyref_sched.Scheduler(nodes, services, [], []).run(pods)
+    assert [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()] == ref
+    without = fl.flatten([dict(n, status={k: v for k, v in n["status"].items() if k != "images"}) for n in nodes], pods, services, [], [])
+    res0 = O.run(without.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
+    assert res0.placement.tolist() != res.placement.tolist()                                            # ... and it matters
+
+
+def test_image_locality_in_a_sweep_runs_size_by_size():
+    """ImageLocality scores 0 everywhere unless a node lists an image some pod runs; then the score depends on the cluster
+    size: one batch over several sizes cannot carry it, sweep() evaluates every size as its own problem."""
     nodes, workloads, services = randk8s.rand_cluster(4, n_nodes=6, n_workloads=5)
+    for n in nodes:
+        n["metadata"]["labels"].pop(randk8s.ZONE, None)
     cluster = k8s.group_resources(nodes + services)
     apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {}},
+                "status": {"allocatable": {"cpu": "16", "memory": "32Gi", "pods": "20"}, "capacity": {"cpu": "16", "memory": "32Gi"}}}
     nodes[2].setdefault("status", {})["images"] = [{"names": ["registry.local/other:1.0", "other@sha256:abc"], "sizeBytes": 500 << 20}]
-    sim.simulate(cluster, apps, engine=OracleEngine())                        # unrelated image: still a constant
+    sim.sweep(cluster, apps, template, [0, 1, 2], engine=OracleEngine())      # unrelated image: still a constant
     nodes[2]["status"]["images"].append({"names": ["busybox:latest"], "sizeBytes": 300 << 20})      # the pods run "busybox"
-    with pytest.raises(fl.Unsupported, match="ImageLocality"):
-        sim.simulate(cluster, apps, engine=OracleEngine())
+    with pytest.raises(fl.Unsupported, match="ImageLocality"):              # one batch over several sizes: not expressible
+        pool = cluster["Node"] + wl.new_fake_nodes(template, 2)
+        fl.flatten(pool, sim.build_stream(cluster, apps, pool, len(nodes))[0], services, [], [])
+    sw = sim.sweep(cluster, apps, template, [0, 1, 2], engine=OracleEngine())   # ... so sweep() runs size by size
+    for k, uns in zip([0, 1, 2], sw.unscheduled):
+        assert len(sim.simulate(cluster, apps, engine=OracleEngine(), new_nodes=wl.new_fake_nodes(template, k)).unscheduled_pods) == uns
 
 
 def test_differing_priorities_are_refused():
