@@ -299,6 +299,16 @@ def test_k8s_simulate_and_sweep_through_the_hip_engine():
         res, _ = run_gpu(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
         ref = pyref_sched.Scheduler(nodes, services, rs, [], randk8s.STORAGE_CLASSES).run(pods)
         assert [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()] == ref
+    for seed in (5, 14):          # ImageLocality as a static score (nodes list the image the pods run)
+        nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=9, n_workloads=10)
+        nodes = H._with_images([nodes[j] for j in H.k8s.canonical_node_order(nodes)], seed)
+        cluster = {k: [] for k in H.k8s.KINDS}
+        cluster["Node"], cluster["Service"] = nodes, services
+        pods, _ = sim.build_stream(cluster, [sim.AppResource("app", H.k8s.group_resources(workloads))], nodes, len(nodes))
+        flat = fl.flatten(nodes, pods, services, [], [], image_total=len(nodes))
+        res, _ = run_gpu(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
+        ref = pyref_sched.Scheduler(nodes, services, [], []).run(pods)
+        assert [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()] == ref
     # the add-nodes search of test_host_mirror.test_sweep_finds_the_minimum_node_count on the GPU
     H_test = H.test_sweep_finds_the_minimum_node_count
     orig = H.OracleEngine
