@@ -1,5 +1,6 @@
 """GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle, bit-exact."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -509,6 +510,17 @@ def test_golden_fixtures_on_gpu():
     assert variant == capi.KERNEL_NARROW_CACHE
     assert r.unscheduled.tolist() == want["unscheduled"] and r.used_cpu.tolist() == want["used_cpu"]
     assert [G.sha(row) for row in r.placement] == want["placement_sha256"]
+
+
+def test_randomised_feature_sweep():
+    """A slice of tests/fuzz_gpu.py (random feature subsets, sizes, node ranks, workgroup sizes) in the regular suite."""
+    import fuzz_gpu
+    old = sys.argv
+    sys.argv = ["fuzz_gpu.py", "80", "5000"]
+    try:
+        assert fuzz_gpu.main() == 0
+    finally:
+        sys.argv = old
 
 
 def test_errors_are_reported_not_thrown():
