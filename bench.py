@@ -3,19 +3,30 @@
 
 A "step" = one pass of the hot path over ONE scenario batch already resident in HBM:
 config 3 of BASELINE.json (10k pods x 488..1511 nodes, 1024 node counts x 4 pod orders = 4096
-scenarios) per GPU.  With N ranks (one process per GPU, launched by torch.distributed.run) every
-rank owns 4096 scenarios of the 1024 x (4N) grid, interleaved so that each rank sees every node
-count (N = 8 is config 4: 32k scenarios); scenarios are independent, so there is no data-path
-collective -- only the per-rank best plan (48 B) is all-gathered over RCCL each step to pick the
-global minimum-node plan.  value = scenarios all ranks completed / max-over-ranks time.
+scenarios) per GPU.  With N ranks (one process per GPU) every rank owns 4096 scenarios of the
+1024 x (4N) grid, interleaved so that each rank sees every node count (N = 8 is config 4: 32k
+scenarios); scenarios are independent, so there is no data-path collective -- only the per-rank
+best plan (32 B) is all-gathered over RCCL each step to pick the global minimum-node plan.
+value = scenarios all ranks completed / max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only for the cpu_baseline leg.
+Launch: `python bench.py --gpus N` starts the N ranks itself (re-exec through torch.distributed.run,
+127.0.0.1 rendezvous) when WORLD_SIZE is not set; under an external torch.distributed.run the ranks
+read RANK / LOCAL_RANK / WORLD_SIZE from the environment as usual.
+
+Prints ONE JSON line on rank 0.  The oracle (oracle/) is only the checker: `cpu_baseline` times it and
+`parity_sample` compares what it computed with the GPU's results of the timed batch (exit code 3 on a
+mismatch).  Nothing under oracle/ is on the timed path.
 """
 import argparse
-import ctypes as C
+import glob
 import json
 import os
+import shutil
+import socket
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,21 +34,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+# ---- chip constants, /opt/skills/guides/MI355X_MICROARCH.md ------------------------------------------------
+HBM_PEAK_GBS = 8000.0            # 8 TB/s HBM3E spec peak
+N_CU, N_SIMD, CLOCK_HZ = 256, 4, 2.4e9
+VALU_ISSUE_PEAK = N_CU * N_SIMD * CLOCK_HZ / 2   # wave64 VALU instructions / s: SIMDs are 32 wide, a wave64 op issues in 2 cycles
+LDS_BYTES_PER_CLK_CU = 128       # ds_read_b32 / b16 rate (the accesses of these kernels are <= 4 B per lane)
+
 DTYPE = {1: "u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
          2: "int64 quantities + f64 (BalancedAllocation / normalisations) + u8 (signature, node) score table",
          3: "f64-resident exact integers (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
          4: "u8 score table + u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)"}
-_N = ("achieved = algorithmic bytes per step (SURVEY 8d: sum over scenarios of P*(56*n+108), resp. P*((56+64+4)*n+4*G+108) "
-      "with Open-Gpu-Share slots and anti-affinity domains) / HIP-event time of the scenario kernels of one step. ")
-NOTE = {4: _N + "The (signature, node) score table replaces re-reading node state, so the ratio is not bounded by 1 (it is the "
-                "speed-up over a state-streaming formulation); traffic = PMC-measured HBM-side bytes per step (profiles/); the "
-                "binding limit is VALU issue + L2 latency of one wave per scenario, DESIGN.md section 5.3 / profiles/README.md",
-        2: _N + "The all-feature kernel reads one table byte per node per cycle instead of the node's state and refreshes only "
-                "the touched node's column, so the ratio can exceed a state-streaming formulation; binding limit: VALU issue of "
-                "the per-node loop (2 waves per SIMD at 512 threads per scenario), DESIGN.md section 5.4",
-        3: _N + "Node state is register-resident; binding limit: VALU issue, DESIGN.md section 5.1",
-        1: _N + "Node state is register-resident; binding limit: VALU issue, DESIGN.md section 5.1"}
+KERNEL_NAME = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::cache_kernel"}
+KERNEL_SHORT = {1: "narrow_v1", 2: "wide", 3: "narrow_fast", 4: "narrow_cache"}
+
+PMC_GROUPS = [                    # one rocprofv3 pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass; 8 SQ slots)
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY",
+     "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY"],
+    ["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU",
+     "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
+]
 
 
 def algorithmic_bytes(scen, n_pods, workload="config3", n_groups=50):
@@ -48,51 +65,136 @@ def algorithmic_bytes(scen, n_pods, workload="config3", n_groups=50):
     return int((n_pods * (per_node * n + extra)).sum())
 
 
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave64 instructions / s: 256 CUs x 4 SIMDs, one wave64 VALU op per 4 cycles at 2.4 GHz
+# ---------------------------------------------------------------------------------------------------------------
+# PMC counters of the dominant kernel: measured live (rocprofv3 passes over a child run of this script), else
+# replayed from the committed profile -- the JSON says which.
+# ---------------------------------------------------------------------------------------------------------------
+def _pmc_pass(counters, child_args, timeout_s):
+    """One `rocprofv3 --kernel-trace --pmc ...` pass over `bench.py --pmc-child`; returns {kernel: {counter: (dispatches,
+    avg per dispatch)}} from the rocpd database, or raises."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="simon_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [rocprof, "--kernel-trace", "--pmc", *counters, "-d", tmp, "-o", "pmc", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", *child_args]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        out = {}
+        for db in glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True):
+            con = sqlite3.connect(db)
+            q = "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"
+            for k, c, n, avg in con.execute(q):
+                out.setdefault(k, {})[c] = (int(n), float(avg))
+            con.close()
+        if not out:
+            raise RuntimeError("no counters in the rocprofv3 output")
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
-def measured_issue(kernel, scenarios, pods, kernel_ms):
-    """The roofline that actually binds these integer / compare / fp64 kernels: VALU issue.  Instruction counts per step
-    come from the committed PMC profile (profiles/traffic.json, SQ_INSTS_VALU), the time is measured live."""
+def pmc_live(kernel_name, child_args, budget_s):
+    """All PMC groups for `kernel_name`; None when rocprofv3 is unavailable or a pass fails / runs out of budget."""
+    merged, t0 = {}, time.perf_counter()
+    short = kernel_name.split("::")[-1]
+    for grp in PMC_GROUPS:
+        left = budget_s - (time.perf_counter() - t0)
+        if left < 20:
+            break
+        try:
+            res = _pmc_pass(grp, child_args, timeout_s=min(left, 150))
+        except Exception as e:                                        # noqa: BLE001 -- any failure means "not measured"
+            print(f"[bench] PMC pass {grp[0]}.. failed: {e}", file=sys.stderr)
+            if not merged:
+                return None
+            continue
+        for k, cs in res.items():
+            if short in k and "unpermute" not in k:
+                merged.update(cs)
+    return merged or None
+
+
+def pmc_replayed(kernel, scenarios, pods):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for row in json.load(f)["entries"]:
                 if row["kernel"] == kernel and row["scenarios_per_gpu"] == scenarios and row["pods"] == pods:
-                    insts = row["insts_valu_per_dispatch"] * row["dispatches_per_step"]
-                    ach = insts / (kernel_ms * 1e-3)
-                    return {"bound": "valu_issue", "achieved": round(ach / 1e9, 1), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
-                            "unit": "G wave64-instr/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
-                            "wave_time_split": {"parked_on_waitcnt_or_barrier": round(row["wait_any_per_dispatch"] / row["wave_cycles_per_dispatch"], 3),
-                                                "executing": round(row["active_inst_any_per_dispatch"] / row["wave_cycles_per_dispatch"], 3)},
-                            "source": "SQ_INSTS_VALU / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of profiles/r01e_*_summary.txt"}
+                    d = row["dispatches_per_step"]
+                    return {"FETCH_SIZE": (d, row["fetch_kb_per_dispatch"]), "WRITE_SIZE": (d, row["write_kb_per_dispatch"]),
+                            "SQ_INSTS_VALU": (d, row["insts_valu_per_dispatch"]), "SQ_INSTS_SALU": (d, row["insts_salu_per_dispatch"]),
+                            "SQ_INSTS_LDS": (d, row["insts_lds_per_dispatch"]), "SQ_WAVE_CYCLES": (d, row["wave_cycles_per_dispatch"]),
+                            "SQ_WAIT_ANY": (d, row["wait_any_per_dispatch"]), "SQ_ACTIVE_INST_ANY": (d, row["active_inst_any_per_dispatch"])}, row.get("source", "profiles/traffic.json")
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
-def measured_traffic(kernel, scenarios, pods):
-    """HBM-side bytes per step from the committed PMC profile of this workload (profiles/traffic.json: FETCH_SIZE x 2
-    per MI355X_MICROARCH.md + WRITE_SIZE, summed over the kernel's launches of one step); None when no profile of
-    this kernel / workload size is committed."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            for row in json.load(f)["entries"]:
-                if row["kernel"] == kernel and row["scenarios_per_gpu"] == scenarios and row["pods"] == pods:
-                    return row["hbm_bytes_per_step"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+def roofline_record(kname, variant, k_ms, launches, alg_bytes, pmc, source, workload):
+    """The roofline of the dominant kernel.  These kernels are integer / compare / fp64 work on an L2-resident score
+    table: the binding resource is VALU issue (plus the dependent latency of one wave per scenario), so `frac` is the VALU
+    issue fraction against the guide's peak (one wave64 VALU op per 2 cycles per SIMD).  The SURVEY 8(d) figure
+    (algorithmic bytes of a state-streaming formulation / time / 8 TB/s) is reported as `algorithmic_ratio` -- it is not
+    bounded by 1 because the table replaces the state sweep it prices -- next to the measured HBM and LDS fractions."""
+    sec = k_ms * 1e-3
+    rec = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave64-instr/s", "frac": None,
+           "kernel": kname, "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
+           "algorithmic_bytes_per_step": alg_bytes,
+           "algorithmic_ratio": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+           "algorithmic_gbs": round(alg_bytes / sec / 1e9, 1),
+           "traffic": None, "measured_hbm_gbs": None, "measured_hbm_frac": None, "lds_frac": None,
+           "peaks": {"hbm_gbs": HBM_PEAK_GBS, "valu_wave64_instr_per_s": VALU_ISSUE_PEAK,
+                     "valu_rule": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op (MI355X_MICROARCH.md)",
+                     "lds_bytes_per_clk_per_cu": LDS_BYTES_PER_CLK_CU},
+           "counters_source": source}
+    if not pmc:
+        rec["note"] = "no PMC counters available (rocprofv3 absent and no committed profile of this workload size): frac unmeasured"
+        return rec
+
+    def tot(name):                      # counter summed over the kernel's dispatches of ONE step
+        if name not in pmc:
+            return None
+        n, avg = pmc[name]
+        return avg * launches
+
+    valu, salu, ldsi = tot("SQ_INSTS_VALU"), tot("SQ_INSTS_SALU"), tot("SQ_INSTS_LDS")
+    if valu:
+        rec["achieved"] = round(valu / sec / 1e9, 1)
+        rec["frac"] = round(valu / sec / VALU_ISSUE_PEAK, 4)
+    fetch, write = tot("FETCH_SIZE"), tot("WRITE_SIZE")
+    if fetch is not None and write is not None:
+        hbm = int(fetch * 1024 * 2 + write * 1024)   # KB per dispatch; FETCH_SIZE doubled per the guide's gfx950 note
+        rec["traffic"] = hbm
+        rec["measured_hbm_gbs"] = round(hbm / sec / 1e9, 1)
+        rec["measured_hbm_frac"] = round(hbm / sec / 1e9 / HBM_PEAK_GBS, 4)
+        rec["traffic_over_algorithmic"] = round(hbm / alg_bytes, 5)
+    lds_act = tot("SQ_LDS_IDX_ACTIVE")
+    if lds_act is not None:
+        # SQ_LDS_IDX_ACTIVE = LDS-array cycles summed over the CUs; the LDS of one CU serves one access group per cycle
+        rec["lds_frac"] = round(lds_act / (N_CU * sec * CLOCK_HZ), 4)
+        rec["lds_bank_conflict_cycles_frac"] = round((tot("SQ_LDS_BANK_CONFLICT") or 0.0) / max(lds_act, 1.0), 4)
+    wc = tot("SQ_WAVE_CYCLES")
+    if wc:
+        split = {}
+        for key, name in (("parked_on_waitcnt_or_barrier", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY"), ("executing", "SQ_ACTIVE_INST_ANY")):
+            v = tot(name)
+            if v is not None:
+                split[key] = round(v / wc, 3)
+        rec["wave_time_split"] = split
+    rec["instructions_per_step"] = {"valu": valu, "salu": salu, "lds": ldsi, "vmem_rd": tot("SQ_INSTS_VMEM_RD"), "vmem_wr": tot("SQ_INSTS_VMEM_WR")}
+    rec["note"] = ("frac = SQ_INSTS_VALU / kernel time / VALU issue peak.  One wave runs one scenario and its pods are strictly sequential, so "
+                   "the kernel sits between issue-bound and bound by the dependent chain of one scheduling cycle (DESIGN.md 5.3); HBM carries "
+                   "only the spill of the per-scenario score tables out of L2 (measured_hbm_frac).")
+    return rec
 
 
-def cpu_baseline(prob, scen, orders, budget_s=12.0):
-    """Time the C oracle on a bounded sample of the same scenarios (rank 0 only): one scenario per task on every host
-    core this process may use (the oracle call releases the GIL; a scenario is sequential, scenarios are independent --
-    the same parallelism the GPU path uses).  The single-thread rate of the calibration run is reported alongside."""
-    from concurrent.futures import ThreadPoolExecutor
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib
-    oracle_lib.load()
-    S = len(scen)
+# ---------------------------------------------------------------------------------------------------------------
+# CPU side: the oracle as baseline AND as checker of the timed batch
+# ---------------------------------------------------------------------------------------------------------------
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
         try:                                               # a container's CPU quota (cgroup v2 / v1) caps the useful thread count
@@ -105,20 +207,136 @@ def cpu_baseline(prob, scen, orders, budget_s=12.0):
             break
         except (OSError, ValueError):
             continue
-    cores = max(1, int(os.environ.get("SIMON_BENCH_CPU_THREADS", cores)))
+    return max(1, int(os.environ.get("SIMON_BENCH_CPU_THREADS", cores)))
+
+
+def oracle_sample(prob, scen, orders, budget_s, min_k=2, max_k=None):
+    """Run the C oracle on a bounded, evenly spaced sample of this rank's scenarios, one scenario per task on every host
+    core this process may use (the oracle call releases the GIL).  Returns (pick, results, timing dict)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.load()
+    S = len(scen)
+    cores = host_cores()
     t0 = time.perf_counter()
     oracle_lib.run(prob, scen[[S // 2]], orders, want_placement=False)   # a mid-sized scenario: calibrate the sample size
     per = max(time.perf_counter() - t0, 1e-6)
-    k = int(max(2, min(S, budget_s * cores / per)))
-    pick = np.linspace(0, S - 1, k).astype(int)            # spread evenly over node counts and orders
+    k = int(max(min_k, min(S, budget_s * cores / per)))
+    if max_k:
+        k = min(k, max_k)
+    pick = np.unique(np.linspace(0, S - 1, k).astype(int))            # spread evenly over node counts and orders
+    k = len(pick)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as pool:
-        list(pool.map(lambda i: oracle_lib.run(prob, scen[[i]], orders, want_placement=False), pick.tolist()))
+        results = list(pool.map(lambda i: oracle_lib.run(prob, scen[[i]], orders, want_placement=True), pick.tolist()))
     dt = time.perf_counter() - t0
-    return {"value": round(k / dt, 4), "unit": "scenarios/s", "cores": cores, "kind": "port",
-            "sample": f"{k} of the {S} scenarios of this rank's batch (evenly spaced over node counts/orders), {dt:.1f} s on "
-                      f"{cores} threads, one scenario per task (speed-up over one thread {k / dt * per:.1f}x; one thread alone: "
-                      f"{1.0 / per:.2f} scenarios/s; C oracle: restated CPU baseline, not the Go reference binary)"}
+    return pick, results, {"k": k, "dt": dt, "cores": cores, "per": per}
+
+
+def parity_check(ctx, pick, results, want_rows):
+    """Compare the GPU results of the batch that was just timed with the oracle's, scenario by scenario: unscheduled count,
+    used cpu / memory, and the full placement row (every pod's node) when the run stored placements."""
+    gpu = ctx.fetch(want_placement=False)
+    bad, rows = [], 0
+    for i, ref in zip(pick.tolist(), results):
+        ok = (int(gpu.unscheduled[i]) == int(ref.unscheduled[0]) and int(gpu.used_cpu[i]) == int(ref.used_cpu[0])
+              and int(gpu.used_mem[i]) == int(ref.used_mem[0]))
+        if ok and want_rows:
+            row = ctx.fetch_placement(i)
+            ok = bool((row == ref.placement[0]).all())
+            rows += 1
+        if not ok:
+            bad.append(int(i))
+    return {"scenarios": len(pick), "placement_rows": rows, "mismatches": len(bad), "first_mismatches": bad[:8],
+            "compared": "unscheduled, used_cpu, used_mem" + (", placement[S][P] rows" if want_rows else ""),
+            "checker": "oracle/simon_oracle.c (C restatement of the determinised reference) on the scenarios of the timed batch"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def build_workload(args, synth, world):
+    n_orders = args.orders_per_gpu * world
+    if args.workload == "config5":
+        return synth.config5(n_scen=int(os.environ.get("SIMON_BENCH_C5_SCEN", "256")) * world, n_orders=n_orders), n_orders
+    if args.workload == "config2":
+        return synth.config2(), 1
+    if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
+        return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
+    seed = synth.SEED + (3 if world == 1 else 4)
+    return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=seed), n_orders
+
+
+def workload_name(args, prob, scen_all, n_orders, S_local, world):
+    head = {"config5": "BASELINE config 5-style (gpushare): ", "config2": "BASELINE config 2: ",
+            "config3sig": f"config 3 variant with {args.sigs} request signatures: "}.get(
+                args.workload, f"BASELINE config {'3' if world == 1 else '4-style'}: ")
+    return (head + f"{prob.n_pods} pods x {int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, "
+            f"{len(set(scen_all[:, 0].tolist()))} node counts x {n_orders} pod orders = {len(scen_all)} scenarios ({S_local} per GPU)")
+
+
+def time_steps(ctx, steps, warmup, placement, fence, after_step=None):
+    for _ in range(warmup):
+        ctx.run_loaded(want_placement=placement)
+        ctx.min_plan()
+    k_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run_loaded(want_placement=placement)
+        plan = ctx.min_plan()
+        if after_step:
+            after_step(plan)
+        k_ms.append(ctx.stats().kernel_ms)
+    fence()
+    return time.perf_counter() - t0, float(np.mean(k_ms))
+
+
+def sub_benchmark(name, capi, synth, torch, steps, warmup, oracle_scen):
+    """Driver-timed record of another BASELINE configuration on the same GPU (rank 0, N = 1): config 2 (one scenario, the
+    latency case) and config 5 (the all-feature kernel), each checked against the oracle on `oracle_scen` scenarios."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    if name == "config2":
+        prob, scen, orders = synth.config2()
+    else:
+        prob, scen, orders = synth.config5(n_scen=int(os.environ.get("SIMON_BENCH_C5_SCEN", "256")), n_orders=4)
+    with capi.Context(torch.cuda.current_device()) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        dt, k_ms = time_steps(ctx, steps, warmup, True, torch.cuda.synchronize)
+        st = ctx.stats()
+        pick = np.unique(np.linspace(0, len(scen) - 1, oracle_scen).astype(int)) if oracle_scen > 0 else np.zeros(0, int)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(len(pick), host_cores()))) as pool:
+            refs = list(pool.map(lambda i: oracle_lib.run(prob, scen[[i]], orders, want_placement=True), pick.tolist()))
+        par = parity_check(ctx, pick, refs, True)
+    wl = "config5" if name == "config5" else "config3"
+    alg = algorithmic_bytes(scen, prob.n_pods, wl)
+    return {"workload": name, "scenarios": len(scen), "pods": prob.n_pods, "nodes": f"{int(scen[:, 0].min())}..{int(scen[:, 0].max())}",
+            "value": round(len(scen) * steps / dt, 3), "unit": "scenarios/s", "pods_placed_per_sec": round(len(scen) * steps / dt * prob.n_pods, 1),
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_ms": round(k_ms, 3), "workgroup": st.workgroup_size,
+            "algorithmic_ratio": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "parity_sample": par}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run on 127.0.0.1."""
+    from open_simulator_amd import capi
+    ndev = capi.load_library().simon_hip_device_count()
+    env = dict(os.environ)
+    if ndev < n:
+        if env.get("SIMON_BENCH_SHARE_DEVICE") != "1":
+            raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible (SIMON_BENCH_SHARE_DEVICE=1 runs the ranks on one device over gloo: test hook)")
+        env.setdefault("SIMON_BENCH_BACKEND", "gloo")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SIMON_BENCH_SELF_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -129,12 +347,21 @@ def main():
     ap.add_argument("--counts", type=int, default=1024, help="node counts in the sweep (1024 = BASELINE config 3/4)")
     ap.add_argument("--pods", type=int, default=10000)
     ap.add_argument("--orders-per-gpu", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["config3", "config5"], default="config3",
+    ap.add_argument("--sigs", type=int, default=100, help="request signatures of --workload config3sig")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity_sample)")
+    ap.add_argument("--no-sub", action="store_true", help="skip the config-2 / config-5 sub-records")
+    ap.add_argument("--pmc", choices=["auto", "live", "replay", "off"], default="auto",
+                    help="PMC counters for the roofline record: live = rocprofv3 passes over a child run (auto: live at N = 1 when "
+                         "rocprofv3 exists, else the committed profile)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
                          "(GPU share + anti-affinity + taints) on the all-feature kernel, 256 scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.pmc_child:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -143,10 +370,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # test hook (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu): several ranks on ONE device over gloo, to
-    # exercise the world > 1 code path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl")
+    # test hook (tests/test_gpu_parity.py::test_bench_*_share_one_gpu): several ranks on ONE device over gloo, to exercise the
+    # world > 1 code path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl")
     backend = os.environ.get("SIMON_BENCH_BACKEND", "nccl")
     if os.environ.get("SIMON_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
@@ -158,51 +387,40 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    n_orders = args.orders_per_gpu * world
-    seed = synth.SEED + (3 if world == 1 else 4)
-    if args.workload == "config5":
-        prob, scen_all, orders = synth.config5(n_scen=int(os.environ.get("SIMON_BENCH_C5_SCEN", "256")) * world, n_orders=n_orders)
-    else:
-        prob, scen_all, orders = synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=seed)
+    (prob, scen_all, orders), n_orders = build_workload(args, synth, world)
     scen = sweep.shard(scen_all, rank, world)                 # every rank gets every node count
     S_local, S_total = len(scen), len(scen_all)
+    placement = bool(args.placement)
 
     ctx = capi.Context(local_rank)
     ctx.load_problem(prob)
     ctx.load_scenarios(scen, orders)                          # inputs resident in HBM before timing
-    def step():
-        ctx.run_loaded(want_placement=bool(args.placement))
-        plan = ctx.min_plan()                                 # device-side reduction of this rank's batch
+    best = [None]
+
+    def after_step(plan):                                     # device-side reduction of this rank's batch, then
         rec = sweep.plan_record(bool(plan.found), plan.n_nodes, plan.scenario, plan.order_id, rank, world)
-        return sweep.all_gather_plan(rec, device="cuda" if backend == "nccl" else "cpu").as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
+        best[0] = sweep.all_gather_plan(rec, device="cuda" if backend == "nccl" else "cpu").as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    kernel_ms = []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        best = step()
-        kernel_ms.append(ctx.stats().kernel_ms)
-    fence()
-    dt = time.perf_counter() - t0
+    dt, k_ms = time_steps(ctx, args.steps, args.warmup, placement, fence, after_step)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if args.pmc_child:                                        # profiled child of pmc_live(): the kernels ran, nothing to print
+        ctx.close()
+        return
 
+    rc = 0
     if rank == 0:
         st = ctx.stats()
-        k_ms = float(np.mean(kernel_ms))
-        alg = algorithmic_bytes(scen, prob.n_pods, args.workload)
-        achieved = alg / (k_ms * 1e-3) / 1e9
-        kname = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::cache_kernel"}.get(st.kernel_variant)
-        traffic = measured_traffic(kname, S_local, prob.n_pods)
+        wl = "config5" if args.workload == "config5" else "config3"
+        alg = algorithmic_bytes(scen, prob.n_pods, wl)
+        kname = KERNEL_NAME.get(st.kernel_variant)
         value = S_total * args.steps / dt
         out = {
             "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),
@@ -210,28 +428,71 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE.get(st.kernel_variant, "int64 + f64"), "data": "synthetic",
             "pods_placed_per_sec": round(value * prob.n_pods, 1),
-            "config": {"workload": (f"BASELINE config 5-style (gpushare): {prob.n_pods} pods x " if args.workload == "config5" else
-                                    f"BASELINE config {'3' if world == 1 else '4-style'}: {prob.n_pods} pods x ") + 
-                                   f"{int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, {len(set(scen_all[:, 0].tolist()))} node counts x "
-                                   f"{n_orders} pod orders = {S_total} scenarios ({S_local} per GPU)",
+            "config": {"workload": workload_name(args, prob, scen_all, n_orders, S_local, world),
                        "scenarios_per_gpu": S_local, "pods": prob.n_pods, "node_pool": prob.n_nodes,
-                       "placement_matrix": bool(args.placement),
-                       "kernel": {1: "narrow_v1", 2: "wide", 3: "narrow_fast", 4: "narrow_cache"}.get(st.kernel_variant, "?"), "workgroup": st.workgroup_size,
-                       "slots_per_lane": st.slots_per_lane, "plan": best},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kname, "kernel_ms": round(k_ms, 3), "launches_per_step": st.n_launches,
-                         "algorithmic_bytes_per_launch": alg,
-                         "binding": measured_issue(kname, S_local, prob.n_pods, k_ms),
-                         "note": NOTE.get(st.kernel_variant, NOTE[4])},
+                       "placement_matrix": placement, "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"),
+                       "workgroup": st.workgroup_size, "slots_per_lane": st.slots_per_lane, "plan": best[0]},
+            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
+                      "backend": (dist.get_backend() if world > 1 else None),
+                      "collective": "all_gather of one 32-byte plan record per rank and step" if world > 1 else None,
+                      "launched_by": "bench.py --gpus N (self-spawned torch.distributed.run)" if os.environ.get("SIMON_BENCH_SELF_SPAWNED") else "external launcher"} if world > 1 else
+                     {"world_size": 1, "backend": None},
         }
+        # ---- roofline of the dominant kernel ---------------------------------------------------------------------
+        pmc, source = None, None
+        mode = args.pmc
+        if mode in ("auto", "live") and world == 1:
+            child = ["--workload", args.workload, "--steps", "1", "--warmup", "0", "--counts", str(args.counts), "--pods", str(args.pods),
+                     "--orders-per-gpu", str(args.orders_per_gpu), "--sigs", str(args.sigs), "--placement", str(args.placement)]
+            ctx.close()                                        # free the device for the profiled children
+            t0 = time.perf_counter()
+            pmc = pmc_live(kname, child, budget_s=float(os.environ.get("SIMON_BENCH_PMC_BUDGET_S", "240")))
+            if pmc:
+                source = (f"measured live in this run: rocprofv3 --kernel-trace --pmc, {len(PMC_GROUPS)} separate passes over a 1-step child run "
+                          f"of the same workload ({time.perf_counter() - t0:.0f} s); per-dispatch averages x launches per step")
+            ctx = capi.Context(local_rank)                     # the parity legs below need the batch's results again
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ctx.run_loaded(want_placement=placement)
+        if pmc is None and mode != "off":
+            pmc, src = pmc_replayed(kname, S_local, prob.n_pods)
+            if pmc:
+                source = f"replayed from the committed profile ({src}), not measured in this run"
+        out["roofline"] = roofline_record(kname, st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl)
+        # ---- the oracle: CPU baseline (N = 1) and parity of the timed batch ---------------------------------------
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prob, scen, orders)
+            if world == 1:
+                pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=float(os.environ.get("SIMON_BENCH_CPU_BUDGET_S", "12")))
+                out["cpu_baseline"] = {
+                    "value": round(tm["k"] / tm["dt"], 4), "unit": "scenarios/s", "cores": tm["cores"], "kind": "port",
+                    "sample": f"{tm['k']} of the {S_local} scenarios of this rank's batch (evenly spaced over node counts/orders), {tm['dt']:.1f} s on "
+                              f"{tm['cores']} threads, one scenario per task (one thread alone: {1.0 / tm['per']:.2f} scenarios/s; C oracle = restated "
+                              f"CPU baseline of the naive per-pod loop over all nodes, not the Go reference binary -- no Go toolchain on this box; the GPU/CPU "
+                              f"ratio is mostly algorithmic: the kernel re-evaluates one table column per cycle, the oracle every node)"}
+            else:
+                pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=4.0, max_k=64)
+            out["parity_sample"] = parity_check(ctx, pick, refs, placement)
+            if out["parity_sample"]["mismatches"]:
+                rc = 3
+        # ---- driver-timed records of the other single-GPU configurations ------------------------------------------
+        if world == 1 and args.workload == "config3" and not args.no_sub:
+            subs = []
+            for name, steps, warm, nchk in (("config2", 20, 2, 1), ("config5", 2, 1, 2)):
+                try:
+                    subs.append(sub_benchmark(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk))
+                    if subs[-1]["parity_sample"]["mismatches"]:
+                        rc = 3
+                except Exception as e:                         # noqa: BLE001
+                    subs.append({"workload": name, "error": repr(e)})
+                    rc = rc or 4
+            out["other_workloads"] = subs
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

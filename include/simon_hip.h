@@ -12,6 +12,9 @@
  *   - one simon_ctx is not thread-safe (the reference calls Simulate serially:
  *     pkg/apply/apply.go:211, pkg/server/server.go:167); distinct contexts may live on distinct
  *     OS threads.  No thread-local device state: every entry does hipSetDevice itself.
+ *   - tuning / experiment environment variables (SIMON_WG, SIMON_FORCE_WIDE, SIMON_NO_CACHE, ... DESIGN.md
+ *     section 8) are read ONCE per context, inside simon_ctx_create; changing them later has no effect on
+ *     a live context, and none of them changes a result.
  *   - all quantities are int64 in the units the kube-scheduler uses internally
  *     (V/framework/types.go:283-292): CPU in milli-cores (Quantity.MilliValue), memory /
  *     ephemeral-storage / gpu-mem in bytes (Quantity.Value), pod counts as int32.
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIMON_HIP_ABI_VERSION 2
+#define SIMON_HIP_ABI_VERSION 3
 
 #define SIMON_MAX_GPU_DEV 8 /* devices per GPU-share node (pkg/type/open-gpu-share/cache/gpunodeinfo.go:34-56) */
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
@@ -375,12 +378,57 @@ int simon_min_plan_vg(simon_ctx* ctx, int32_t max_cpu_pct, int32_t max_mem_pct, 
  * max_failed, in which case only the first max_failed are dumped) or a negative error. */
 int simon_explain(simon_ctx* ctx, simon_scenario scen, const int32_t* order, int32_t* failed_pods,
                   uint16_t* fail_codes, int32_t max_failed);
+/* The same for scenario `scenario` of the LOADED batch: its node count, its order and -- when simon_set_node_ranks is in
+ * effect -- its own nodeTree ranks, so the replay breaks ties exactly as the batch run did.  fail_codes is
+ * [max_failed][n_nodes of that scenario].  With ranks loaded simon_explain refuses (SIMON_ESTATE): an ad-hoc scenario has
+ * no rank row.  (ABI v3) */
+int simon_explain_loaded(simon_ctx* ctx, int32_t scenario, int32_t* failed_pods, uint16_t* fail_codes, int32_t max_failed);
 
 int simon_get_stats(simon_ctx* ctx, simon_stats* stats);
 
 /* Raw device pointers of the last run's per-scenario results (for zero-copy collectives from the
  * host framework, e.g. torch.distributed over RCCL).  Valid until the next load/run/destroy. */
 int simon_device_results(simon_ctx* ctx, void** d_unscheduled, void** d_used_cpu, void** d_used_mem);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device groups (ABI v3): several GPUs of one node behind one handle, for a single-process host such as the Go
+ * `simon apply` binary.  Replaces the SERIAL loop of Applier.Run (pkg/apply/apply.go:203-259: one Simulate per
+ * candidate size) by dealing the independent scenarios of a batch over the devices: scenario s runs on member
+ * s % n_dev (order the batch count-major and every member sees every node count), immutable inputs are replicated,
+ * members run concurrently (one host thread per member during a call), per-scenario outputs come back in the caller's
+ * scenario order, and simon_group_min_plan takes the lexicographic minimum (n_nodes, scenario) of the members' plans
+ * -- the one cross-device exchange of the path (40 bytes per device; with one PROCESS per GPU the same record is
+ * all-gathered over RCCL by the launcher, see bench.py / INTEGRATION.md section 6).
+ * device_ids may name a device more than once (two contexts on one GPU).  A group is not thread-safe; distinct groups
+ * and distinct contexts may be used from distinct OS threads.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct simon_group simon_group;
+
+simon_group* simon_group_create(const int32_t* device_ids, int32_t n_dev);   /* NULL: bad list or a device is unusable */
+void simon_group_destroy(simon_group* g);
+const char* simon_group_last_error(simon_group* g);
+int32_t simon_group_size(simon_group* g);
+simon_ctx* simon_group_member(simon_group* g, int32_t i);   /* member context i (stats, explain); owned by the group */
+
+/* replicated uploads: simon_load_nodes / _pods / _class_tables on every member */
+int simon_group_load_nodes(simon_group* g, const simon_nodes_soa* nodes);
+int simon_group_load_pods(simon_group* g, const simon_pods_soa* pods);
+int simon_group_load_class_tables(simon_group* g, const simon_class_tables* tables);
+
+/* simon_load_scenarios / simon_run_loaded / simon_fetch_results / simon_run_batch over the group; S >= n_dev.
+ * All scenario indices (out arrays, simon_plan.scenario, fetch_placement) are indices into the caller's scen[]. */
+int simon_group_load_scenarios(simon_group* g, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders);
+int simon_group_run_loaded(simon_group* g, int32_t want_placement);
+int simon_group_fetch_results(simon_group* g, simon_batch_out* out);
+int simon_group_run_batch(simon_group* g, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
+                          simon_batch_out* out);
+int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* placement);
+
+/* The add-nodes search over every device: minimum n_nodes among the scenarios of the last run that schedule every pod
+ * within the caps (satisfyResourceSetting, pkg/apply/apply.go:689-775); ties go to the lowest scenario index, exactly
+ * as simon_min_plan_vg on one device running the whole batch.  vg_pct may be NULL. */
+int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
+                         int32_t* vg_pct);
 
 #ifdef __cplusplus
 }

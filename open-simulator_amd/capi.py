@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_GPU_DEV = 8
 MAX_SCALAR = 4
 
@@ -448,7 +448,11 @@ EXPORTS = [
     "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
     "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain", "simon_set_node_ranks",
-    "simon_get_stats", "simon_device_results",
+    "simon_get_stats", "simon_device_results", "simon_explain_loaded",
+    "simon_group_create", "simon_group_destroy", "simon_group_last_error", "simon_group_size", "simon_group_member",
+    "simon_group_load_nodes", "simon_group_load_pods", "simon_group_load_class_tables", "simon_group_load_scenarios",
+    "simon_group_run_loaded", "simon_group_fetch_results", "simon_group_run_batch", "simon_group_fetch_placement",
+    "simon_group_min_plan",
 ]
 
 
@@ -484,12 +488,33 @@ def load_library(path: Optional[str] = None):
     lib.simon_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(Plan)]
     lib.simon_min_plan_vg.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
     lib.simon_explain.argtypes = [vp, Scenario, _p32, _p32, _pu16, C.c_int32]
+    lib.simon_explain_loaded.argtypes = [vp, C.c_int32, _p32, _pu16, C.c_int32]
+    lib.simon_group_create.restype = vp
+    lib.simon_group_create.argtypes = [_p32, C.c_int32]
+    lib.simon_group_destroy.argtypes = [vp]
+    lib.simon_group_destroy.restype = None
+    lib.simon_group_last_error.restype = C.c_char_p
+    lib.simon_group_last_error.argtypes = [vp]
+    lib.simon_group_size.restype = C.c_int32
+    lib.simon_group_size.argtypes = [vp]
+    lib.simon_group_member.restype = vp
+    lib.simon_group_member.argtypes = [vp, C.c_int32]
+    lib.simon_group_load_nodes.argtypes = [vp, C.POINTER(NodesSoA)]
+    lib.simon_group_load_pods.argtypes = [vp, C.POINTER(PodsSoA)]
+    lib.simon_group_load_class_tables.argtypes = [vp, C.POINTER(ClassTables)]
+    lib.simon_group_load_scenarios.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32]
+    lib.simon_group_run_loaded.argtypes = [vp, C.c_int32]
+    lib.simon_group_fetch_results.argtypes = [vp, C.POINTER(BatchOut)]
+    lib.simon_group_run_batch.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32, C.POINTER(BatchOut)]
+    lib.simon_group_fetch_placement.argtypes = [vp, C.c_int32, _p32]
+    lib.simon_group_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
     lib.simon_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.simon_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int or name.startswith(("simon_load", "simon_run", "simon_fetch", "simon_min",
-                                                        "simon_explain", "simon_get", "simon_device")):
+                                                        "simon_explain", "simon_get", "simon_device", "simon_group_load",
+                                                        "simon_group_run", "simon_group_fetch", "simon_group_min")):
             fn.restype = C.c_int
     if lib.simon_hip_version() != ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: library {lib.simon_hip_version()} != binding {ABI_VERSION}")
@@ -611,6 +636,16 @@ class Context:
         k = min(n, max_failed)
         return n, failed[:k], codes[:k]
 
+    def explain_loaded(self, scenario: int, max_failed: int = 64):
+        """simon_explain_loaded: replay scenario `scenario` of the loaded batch (its order, its own node ranks)."""
+        n_nodes = int(self.scen[scenario, 0])
+        failed = np.full(max_failed, -1, np.int32)
+        codes = np.zeros((max_failed, n_nodes), np.uint16)
+        n = self._check(self.lib.simon_explain_loaded(self.h, int(scenario), _ptr(failed, C.c_int32), _ptr(codes, C.c_uint16),
+                                                      int(max_failed)), "simon_explain_loaded")
+        k = min(n, max_failed)
+        return n, failed[:k], codes[:k]
+
     def stats(self) -> Stats:
         st = Stats()
         self._check(self.lib.simon_get_stats(self.h, C.byref(st)), "simon_get_stats")
@@ -621,3 +656,91 @@ class Context:
         self._check(self.lib.simon_device_results(self.h, C.byref(a), C.byref(b), C.byref(c)),
                     "simon_device_results")
         return a.value, b.value, c.value
+
+
+class Group:
+    """RAII wrapper over simon_group: several devices of one node behind one handle (scenario s runs on member
+    s % n_dev; all scenario indices are the caller's)."""
+
+    def __init__(self, device_ids: Sequence[int], lib=None):
+        self.lib = lib or load_library()
+        ids = np.ascontiguousarray(device_ids, np.int32)
+        self.h = self.lib.simon_group_create(_ptr(ids, C.c_int32), len(ids))
+        if not self.h:
+            raise SimonError(f"simon_group_create({list(device_ids)}) failed (no such gfx950 device?)")
+        self.problem: Optional[Problem] = None
+        self.S = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.simon_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            msg = self.lib.simon_group_last_error(self.h)
+            raise SimonError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        return rc
+
+    @property
+    def size(self) -> int:
+        return int(self.lib.simon_group_size(self.h))
+
+    def member_stats(self, i: int) -> Stats:
+        st = Stats()
+        rc = self.lib.simon_get_stats(self.lib.simon_group_member(self.h, int(i)), C.byref(st))
+        if rc < 0:
+            raise SimonError(f"simon_get_stats(member {i}) failed ({rc})")
+        return st
+
+    def load_problem(self, prob: Problem):
+        prob.normalise()
+        n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
+        self._check(self.lib.simon_group_load_nodes(self.h, C.byref(n)), "simon_group_load_nodes")
+        self._check(self.lib.simon_group_load_pods(self.h, C.byref(p)), "simon_group_load_pods")
+        self._check(self.lib.simon_group_load_class_tables(self.h, C.byref(t)), "simon_group_load_class_tables")
+        self.problem = prob
+
+    def load_scenarios(self, scen, orders: np.ndarray):
+        scen = scenarios_array(scen)
+        orders = np.ascontiguousarray(orders, dtype=np.int32).reshape(-1, self.problem.n_pods)
+        self._check(self.lib.simon_group_load_scenarios(self.h, scen.ctypes.data_as(C.POINTER(Scenario)), len(scen),
+                                                        _ptr(orders, C.c_int32), orders.shape[0]), "simon_group_load_scenarios")
+        self.S = len(scen)
+
+    def run_loaded(self, want_placement: bool = True):
+        self._check(self.lib.simon_group_run_loaded(self.h, 1 if want_placement else 0), "simon_group_run_loaded")
+
+    def fetch(self, want_placement: bool = True) -> BatchResult:
+        res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement)
+        out = res.c_out()
+        self._check(self.lib.simon_group_fetch_results(self.h, C.byref(out)), "simon_group_fetch_results")
+        return res
+
+    def run_batch(self, scen, orders: np.ndarray, want_placement: bool = True) -> BatchResult:
+        self.load_scenarios(scen, orders)
+        self.run_loaded(want_placement)
+        return self.fetch(want_placement)
+
+    def fetch_placement(self, scenario: int) -> np.ndarray:
+        row = np.zeros(self.problem.n_pods, np.int32)
+        self._check(self.lib.simon_group_fetch_placement(self.h, int(scenario), _ptr(row, C.c_int32)), "simon_group_fetch_placement")
+        return row
+
+    def min_plan(self, max_cpu_pct: int = 100, max_mem_pct: int = 100, max_vg_pct: int = 100):
+        plan, vg = Plan(), C.c_int32(0)
+        self._check(self.lib.simon_group_min_plan(self.h, int(max_cpu_pct), int(max_mem_pct), int(max_vg_pct), C.byref(plan),
+                                                  C.byref(vg)), "simon_group_min_plan")
+        return plan, int(vg.value)

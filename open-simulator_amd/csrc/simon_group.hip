@@ -1,0 +1,207 @@
+// simon_group.hip -- several devices behind ONE handle (include/simon_hip.h, "device groups").
+//
+// The reference's add-nodes loop calls Simulate once per candidate cluster size, serially
+// (pkg/apply/apply.go:203-259).  Scenarios are independent, so a group deals scenario s of a batch
+// to member s % n_dev (with the batch ordered count-major every member sees every node count:
+// balanced, cost grows with the count), replicates the immutable inputs, runs the members
+// concurrently -- one host thread per member for the duration of a call, every member on its own
+// HIP device and stream -- and reduces the members' minimum plans on the host: in ONE process the
+// "all-gather of the per-device plan" of north_star is a loop over n_dev 40-byte records.  (With
+// one process per GPU the same record travels through RCCL: bench.py / open-simulator_amd/sweep.py.)
+//
+// Built on the public single-device entry points only; holds no HIP state of its own.
+#include "../../include/simon_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct simon_group {
+    std::vector<simon_ctx*> ctx;
+    std::vector<int32_t> device;
+    std::string err;
+    int32_t S = 0, P = 0;                       // last loaded batch: global scenario count; pods
+    std::vector<std::vector<simon_scenario>> part;   // per member: its scenarios, in global order
+    bool have_results = false, have_placement = false;
+};
+
+namespace {
+
+int gfail(simon_group* g, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g) g->err = buf;
+    return code;
+}
+
+// run fn(member) on every member concurrently; first failing member's code + message win
+template <class F>
+int on_all(simon_group* g, const char* what, F fn) {
+    const int n = (int)g->ctx.size();
+    std::vector<int> rc(n, 0);
+    if (n == 1) {
+        rc[0] = fn(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve(n);
+        for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rc[i] = fn(i); });
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < n; ++i)
+        if (rc[i] < 0) return gfail(g, rc[i], "%s: member %d (device %d): %s", what, i, g->device[i], simon_last_error(g->ctx[i]));
+    return SIMON_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+simon_group* simon_group_create(const int32_t* device_ids, int32_t n_dev) {
+    if (!device_ids || n_dev <= 0 || n_dev > 64) return nullptr;
+    simon_group* g = new (std::nothrow) simon_group();
+    if (!g) return nullptr;
+    for (int i = 0; i < n_dev; ++i) {
+        simon_ctx* c = simon_ctx_create(device_ids[i]);
+        if (!c) { simon_group_destroy(g); return nullptr; }
+        g->ctx.push_back(c);
+        g->device.push_back(device_ids[i]);
+    }
+    g->part.resize(n_dev);
+    return g;
+}
+
+void simon_group_destroy(simon_group* g) {
+    if (!g) return;
+    for (simon_ctx* c : g->ctx) simon_ctx_destroy(c);
+    delete g;
+}
+
+const char* simon_group_last_error(simon_group* g) { return g ? g->err.c_str() : "null group"; }
+int32_t simon_group_size(simon_group* g) { return g ? (int32_t)g->ctx.size() : 0; }
+simon_ctx* simon_group_member(simon_group* g, int32_t i) { return (g && i >= 0 && i < (int32_t)g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+int simon_group_load_nodes(simon_group* g, const simon_nodes_soa* nodes) {
+    if (!g || !nodes) return SIMON_EINVAL;
+    g->have_results = false;
+    return on_all(g, "load_nodes", [&](int i) { return simon_load_nodes(g->ctx[i], nodes); });
+}
+
+int simon_group_load_pods(simon_group* g, const simon_pods_soa* pods) {
+    if (!g || !pods) return SIMON_EINVAL;
+    g->have_results = false;
+    g->P = pods->n_pods;
+    return on_all(g, "load_pods", [&](int i) { return simon_load_pods(g->ctx[i], pods); });
+}
+
+int simon_group_load_class_tables(simon_group* g, const simon_class_tables* tables) {
+    if (!g || !tables) return SIMON_EINVAL;
+    g->have_results = false;
+    return on_all(g, "load_class_tables", [&](int i) { return simon_load_class_tables(g->ctx[i], tables); });
+}
+
+int simon_group_load_scenarios(simon_group* g, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders) {
+    if (!g || !scen || S <= 0 || !orders || n_orders <= 0) return g ? gfail(g, SIMON_EINVAL, "group load_scenarios: bad arguments") : SIMON_EINVAL;
+    const int n = (int)g->ctx.size();
+    if (S < n) return gfail(g, SIMON_EINVAL, "group load_scenarios: %d scenarios for %d members (every member needs one)", S, n);
+    for (int i = 0; i < n; ++i) g->part[i].clear();
+    for (int s = 0; s < S; ++s) g->part[s % n].push_back(scen[s]);
+    g->have_results = false;
+    int rc = on_all(g, "load_scenarios", [&](int i) {
+        return simon_load_scenarios(g->ctx[i], g->part[i].data(), (int32_t)g->part[i].size(), orders, n_orders);
+    });
+    if (rc == SIMON_OK) g->S = S;
+    return rc;
+}
+
+int simon_group_run_loaded(simon_group* g, int32_t want_placement) {
+    if (!g) return SIMON_EINVAL;
+    if (g->S <= 0) return gfail(g, SIMON_ESTATE, "group run_loaded: no scenarios loaded");
+    int rc = on_all(g, "run_loaded", [&](int i) { return simon_run_loaded(g->ctx[i], want_placement); });
+    g->have_results = rc == SIMON_OK;
+    g->have_placement = g->have_results && want_placement != 0;
+    return rc;
+}
+
+int simon_group_fetch_results(simon_group* g, simon_batch_out* out) {
+    if (!g || !out) return SIMON_EINVAL;
+    if (out->struct_size != sizeof(simon_batch_out)) return gfail(g, SIMON_EINVAL, "simon_batch_out size mismatch");
+    if (!g->have_results) return gfail(g, SIMON_ESTATE, "group fetch_results: nothing has run");
+    if (out->placement && !g->have_placement) return gfail(g, SIMON_ESTATE, "group fetch_results: the last run skipped placements");
+    const int n = (int)g->ctx.size();
+    const size_t P = (size_t)g->P;
+    return on_all(g, "fetch_results", [&](int i) {
+        const size_t Si = g->part[i].size();
+        std::vector<int32_t> un(Si);
+        std::vector<int64_t> uc(Si), um(Si), uv(out->used_vg ? Si : 0);
+        std::vector<int32_t> pl(out->placement ? Si * P : 0);
+        simon_batch_out o{};
+        o.struct_size = sizeof o;
+        o.unscheduled = un.data(); o.used_cpu = uc.data(); o.used_mem = um.data();
+        o.used_vg = out->used_vg ? uv.data() : nullptr;
+        o.placement = out->placement ? pl.data() : nullptr;
+        int rc = simon_fetch_results(g->ctx[i], &o);
+        if (rc) return rc;
+        for (size_t k = 0; k < Si; ++k) {                       // member-local index k = global scenario k * n + i
+            const size_t s = k * n + i;
+            if (out->unscheduled) out->unscheduled[s] = un[k];
+            if (out->used_cpu) out->used_cpu[s] = uc[k];
+            if (out->used_mem) out->used_mem[s] = um[k];
+            if (out->used_vg) out->used_vg[s] = uv[k];
+            if (out->placement) memcpy(out->placement + s * P, pl.data() + k * P, P * sizeof(int32_t));
+        }
+        return (int)SIMON_OK;
+    });
+}
+
+int simon_group_run_batch(simon_group* g, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
+                          simon_batch_out* out) {
+    if (!g || !out) return SIMON_EINVAL;
+    int rc = simon_group_load_scenarios(g, scen, S, orders, n_orders);
+    if (rc) return rc;
+    rc = simon_group_run_loaded(g, out->placement != nullptr);
+    if (rc) return rc;
+    return simon_group_fetch_results(g, out);
+}
+
+int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* placement) {
+    if (!g || !placement) return SIMON_EINVAL;
+    if (!g->have_results || !g->have_placement) return gfail(g, SIMON_ESTATE, "group fetch_placement: no placements on the devices");
+    if (scenario < 0 || scenario >= g->S) return gfail(g, SIMON_EINVAL, "group fetch_placement: scenario out of range");
+    const int n = (int)g->ctx.size(), i = scenario % n;
+    int rc = simon_fetch_placement(g->ctx[i], scenario / n, placement);
+    return rc ? gfail(g, rc, "fetch_placement: member %d: %s", i, simon_last_error(g->ctx[i])) : SIMON_OK;
+}
+
+int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
+                         int32_t* vg_pct) {
+    if (!g || !best) return SIMON_EINVAL;
+    if (!g->have_results) return gfail(g, SIMON_ESTATE, "group min_plan: nothing has run");
+    const int n = (int)g->ctx.size();
+    std::vector<simon_plan> plans(n);
+    std::vector<int32_t> vg(n, 0);
+    int rc = on_all(g, "min_plan", [&](int i) { return simon_min_plan_vg(g->ctx[i], max_cpu_pct, max_mem_pct, max_vg_pct, &plans[i], &vg[i]); });
+    if (rc) return rc;
+    memset(best, 0, sizeof *best);
+    best->scenario = -1;
+    if (vg_pct) *vg_pct = 0;
+    // lexicographic minimum (n_nodes, global scenario index): the rule of simon_min_plan carried across members
+    for (int i = 0; i < n; ++i) {
+        if (!plans[i].found) continue;
+        const int32_t gs = plans[i].scenario * n + i;
+        if (!best->found || plans[i].n_nodes < best->n_nodes || (plans[i].n_nodes == best->n_nodes && gs < best->scenario)) {
+            *best = plans[i];
+            best->scenario = gs;
+            if (vg_pct) *vg_pct = vg[i];
+        }
+    }
+    return SIMON_OK;
+}
+
+}  // extern "C"

@@ -81,6 +81,8 @@ struct simon_ctx : simon::HostInputs {
     bool rcp_div = true;
     int force_T = 0;  // env SIMON_WG
     bool force_v1 = false;  // env SIMON_NARROW_V1: use simon_narrow.hip even when simon_fast.hip applies
+    bool force_wide = false;  // env SIMON_FORCE_WIDE
+    size_t lds_pad = 0;       // env SIMON_CACHE_LDS_PAD (bytes): occupancy experiment knob -- extra LDS per workgroup
     // ---- device buffers ----
     DevBuf<uint32_t> d_a_cpu, d_a_mem, d_i_rq_cpu, d_i_rq_mem, d_i_nz_cpu, d_i_nz_mem;
     DevBuf<int32_t> d_a_pods, d_ncls, d_i_npods, d_raw32;
@@ -98,6 +100,7 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_rank, d_shape_of, d_clsprefix, d_inv_orders, d_place_step;
     std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn]; padded size of every loaded scenario
     std::vector<int32_t> h_perm;
+    std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
     hipStream_t band_stream[8] = {};
     hipEvent_t band_ev[8] = {}, fork_ev = nullptr;
     DevBuf<uint64_t> d_mask;
@@ -160,7 +163,7 @@ uint64_t gcd_of(std::initializer_list<const std::vector<int64_t>*> vs) {
 void choose_variant(simon_ctx* c) {
     c->variant = SIMON_KERNEL_WIDE;
     c->g_cpu = c->g_mem = 1;
-    if (const char* f = getenv("SIMON_FORCE_WIDE")) if (f[0] == '1') return;
+    if (c->force_wide) return;
     if (c->K > 0 || c->has_gpu || c->Tm > 0 || c->v2_features()) return;
     for (int64_t x : c->alloc_eph) if (x) return;
     for (int64_t x : c->i_req_eph) if (x) return;
@@ -386,12 +389,19 @@ simon_ctx* simon_ctx_create(int device_id) {
         delete c;
         return nullptr;
     }
+    // Tuning / experiment knobs: every environment variable is read HERE, once per context; none changes a result.
     if (const char* e = getenv("SIMON_WG")) c->force_T = atoi(e);
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
     if (const char* e = getenv("SIMON_CACHE_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
+    if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
+    if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
+    c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
+    c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
+    c->wide.knobs.prof = getenv("SIMON_WIDE_PROF") != nullptr;
+    if (const char* e = getenv("SIMON_STATE_BUDGET_MB")) c->wide.knobs.state_budget = (size_t)atoll(e) << 20;
     bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 8 && ok; ++i)
         ok = hipStreamCreateWithFlags(&c->band_stream[i], hipStreamNonBlocking) == hipSuccess &&
@@ -650,6 +660,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     HIP_TRY(c, c->d_used_vg.ensure(S));
     HIP_TRY(c, c->d_plan.ensure(1));
     c->h_perm = perm;
+    c->h_orders.assign(orders, orders + (size_t)n_orders * P);
     c->cache_perm_ok = false;
     if (c->variant == SIMON_KERNEL_NARROW && c->cache_ok) {
         // placements are recorded by scheduling step and gathered back to pod ids through the inverse orders,
@@ -725,14 +736,11 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // larger pools widen the workgroup.  SIMON_WG overrides (tuning knob).
         T = c->force_T ? c->force_T : (c->max_n <= 2048 ? 256 : c->max_n <= 4096 ? 512 : 1024);
         slots = (std::max(c->max_n, 1) + T - 1) / T;
-        if (slots > 8) {  // pool too large for register residency even at T=1024 -> WIDE
-            return fail(c, SIMON_ERANGE, "narrow kernel: %d nodes exceed 8 slots x %d lanes; set SIMON_FORCE_WIDE=1", c->max_n, T);
-        }
+        const bool too_big = slots > 8;   // pool too large for register residency even at T = 1024: the all-feature kernel takes it
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
         bool use_cache = c->cache_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kCacheMaxNodes;
-        // SIMON_CACHE_LDS_PAD (bytes): occupancy experiment knob -- extra LDS per workgroup lowers the waves per CU
-        static const size_t lds_pad = getenv("SIMON_CACHE_LDS_PAD") ? (size_t)atol(getenv("SIMON_CACHE_LDS_PAD")) : 0;
+        const size_t lds_pad = c->lds_pad;
         auto lds_of = [&](int ni) { return cache_lds_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad; };
         auto ws_of = [&](int ni) { return cache_ws_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq); };
         if (use_cache) {
@@ -741,7 +749,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
         }
         // pinned pods (pin_node) are known to the cache kernel and the all-feature kernel only
-        if (c->has_pin && !use_cache) run_wide = true;
+        if ((c->has_pin || too_big) && !use_cache) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
         } else if (use_cache) {
@@ -951,12 +959,11 @@ int simon_min_plan_vg(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, in
     return SIMON_OK;
 }
 
-int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32_t* failed_pods, uint16_t* fail_codes,
-                  int32_t max_failed) {
-    if (!c || !order || !failed_pods || !fail_codes || max_failed <= 0) return c ? fail(c, SIMON_EINVAL, "explain: bad arguments") : SIMON_EINVAL;
+static int explain_impl(simon_ctx* c, int n_nodes, const int32_t* order, int ranked_scenario, int32_t* failed_pods,
+                        uint16_t* fail_codes, int32_t max_failed) {
     int rc = stage(c);
     if (rc) return rc;
-    if (scen.n_nodes < 0 || scen.n_nodes > c->N) return fail(c, SIMON_EINVAL, "explain: n_nodes out of range");
+    if (n_nodes < 0 || n_nodes > c->N) return fail(c, SIMON_EINVAL, "explain: n_nodes out of range");
     for (int i = 0; i < c->P; ++i) if (order[i] < 0 || order[i] >= c->P) return fail(c, SIMON_EINVAL, "explain: bad order");
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->wide_staged) {   // NARROW problem: the failure codes still come from the all-feature kernel
@@ -964,13 +971,31 @@ int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32
         if (rc) return rc;
         c->wide_staged = true;
     }
-    const int T = c->force_T ? c->force_T : (scen.n_nodes <= 512 ? 256 : scen.n_nodes <= 4096 ? 512 : 1024);
-    // with per-scenario node ranks the replay must break ties like the batch did: the ranks of a loaded scenario of this size
+    const int T = c->force_T ? c->force_T : (n_nodes <= 512 ? 256 : n_nodes <= 4096 ? 512 : 1024);
+    // with per-scenario node ranks the replay must break ties exactly like the batch did: the ranks of THAT scenario
     const int32_t *rk = nullptr, *iv = nullptr;
-    if (c->has_ranks)
-        for (int s = 0; s < c->S; ++s)
-            if (c->scen[s].n_nodes == scen.n_nodes) { rk = c->d_node_rank.p + (size_t)s * c->N; iv = c->d_node_inv.p + (size_t)s * c->N; break; }
-    return wide_explain(c->wide, *c, scen.n_nodes, order, failed_pods, fail_codes, max_failed, T, rk, iv, c->stream, c->err);
+    if (ranked_scenario >= 0) {
+        rk = c->d_node_rank.p + (size_t)ranked_scenario * c->N;
+        iv = c->d_node_inv.p + (size_t)ranked_scenario * c->N;
+    }
+    return wide_explain(c->wide, *c, n_nodes, order, failed_pods, fail_codes, max_failed, T, rk, iv, c->stream, c->err);
+}
+
+int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32_t* failed_pods, uint16_t* fail_codes,
+                  int32_t max_failed) {
+    if (!c || !order || !failed_pods || !fail_codes || max_failed <= 0) return c ? fail(c, SIMON_EINVAL, "explain: bad arguments") : SIMON_EINVAL;
+    if (c->has_ranks)   // an ad-hoc scenario has no rank row: which loaded scenario's tie-break order would apply is ambiguous
+        return fail(c, SIMON_ESTATE, "explain: per-scenario node ranks are loaded; use simon_explain_loaded(scenario index)");
+    return explain_impl(c, scen.n_nodes, order, -1, failed_pods, fail_codes, max_failed);
+}
+
+int simon_explain_loaded(simon_ctx* c, int32_t scenario, int32_t* failed_pods, uint16_t* fail_codes, int32_t max_failed) {
+    if (!c || !failed_pods || !fail_codes || max_failed <= 0) return c ? fail(c, SIMON_EINVAL, "explain_loaded: bad arguments") : SIMON_EINVAL;
+    if (!c->staged || c->S <= 0) return fail(c, SIMON_ESTATE, "explain_loaded: no scenarios loaded");
+    if (scenario < 0 || scenario >= c->S) return fail(c, SIMON_EINVAL, "explain_loaded: scenario %d outside [0,%d)", scenario, c->S);
+    const ScenarioDesc& sd = c->scen[scenario];
+    return explain_impl(c, sd.n_nodes, c->h_orders.data() + (size_t)sd.order_id * c->P, c->has_ranks ? scenario : -1,
+                        failed_pods, fail_codes, max_failed);
 }
 
 int simon_get_stats(simon_ctx* c, simon_stats* st) {

@@ -165,7 +165,16 @@ constexpr uint32_t kArgGpu = 1u, kArgMask = 2u, kArgEph = 4u, kArgNzeq = 8u, kAr
                    kArgRanked = 1024u /*per-scenario canonical node ranks (simon_set_node_ranks)*/,
                    kArgLean = 512u /*no spread constraint, scoring term, host port, required affinity or local volume anywhere*/;
 
+// tuning / experiment knobs: environment variables read ONCE, when the context is created (simon_ctx_create)
+struct WideKnobs {
+    bool no_lean = false;            // SIMON_WIDE_NO_LEAN
+    bool no_table = false;           // SIMON_WIDE_NO_TABLE
+    bool prof = false;               // SIMON_WIDE_PROF (only builds with -DSIMON_WIDE_PROFILE act on it)
+    size_t state_budget = 16ull << 30;   // SIMON_STATE_BUDGET_MB: HBM for per-scenario state of the all-feature kernel
+};
+
 struct WideDevice {
+    WideKnobs knobs;
     void* blobs[80] = {};
     int n_blobs = 0;
     int state_chunk = 0;   // scenarios whose state is allocated

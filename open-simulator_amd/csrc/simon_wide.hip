@@ -1400,7 +1400,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
               (in.Cn <= 64 ? kArgClassMode : 0u) | (!in.has_add ? kArgKey32 : 0u) | (in.Tm > 0 ? kArgTerms : 0u) |
               (in.has_local ? kArgLocal : 0u) |
               ((in.sh_idx.empty() && in.ss_idx.empty() && !in.has_ipa_score && in.port_idx.empty() && in.aff_idx.empty() && !in.has_local &&
-                !getenv("SIMON_WIDE_NO_LEAN")) ? kArgLean : 0u);
+                !w.knobs.no_lean) ? kArgLean : 0u);
     a.node_static = w.node_static; a.alloc_pods = w.alloc_pods; a.node_class = w.node_class;
     a.static_mask = w.static_mask; a.simon_raw = w.simon_raw; a.mask_lanes = nullptr;
     a.pods = w.pods; a.sigs = w.sigs; a.n_sigs = w.n_sigs; a.tab_nstride = (in.N + 63) & ~63;
@@ -1564,7 +1564,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     std::vector<WidePod> rows(P);
     std::map<std::vector<int64_t>, int> sig_id;
     std::vector<WideSig> sigs;
-    bool sig_ok = getenv("SIMON_WIDE_NO_TABLE") == nullptr;
+    bool sig_ok = !w.knobs.no_table;
     for (size_t p = 0; p < P; ++p) {
         WidePod& r = rows[p];
         memset(&r, 0, sizeof r);
@@ -1653,8 +1653,7 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
              std::string& err) {
     if ((long long)max_n > (long long)kMaxIter * T) { err = "wide kernel: more than 32 nodes per lane"; return SIMON_ERANGE; }
     const size_t per = state_bytes_per_scenario(w, in);
-    size_t budget = 16ull << 30;  // 16 GiB of 288 GB HBM for scenario state
-    if (const char* e = getenv("SIMON_STATE_BUDGET_MB")) budget = (size_t)atoll(e) << 20;
+    const size_t budget = w.knobs.state_budget;  // default 16 GiB of the 288 GB HBM for scenario state
     int chunk = (int)std::min<size_t>(S, std::max<size_t>(1, budget / per));
     int rc = ensure_state(w, in, chunk, err);
     if (rc) return rc;
@@ -1670,10 +1669,10 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
     unsigned long long* d_prof = nullptr;
 #ifdef SIMON_WIDE_PROFILE
-    const bool prof = getenv("SIMON_WIDE_PROF") != nullptr && chunk >= S;
+    const bool prof = w.knobs.prof && chunk >= S;
 #else
     const bool prof = false;
-    if (getenv("SIMON_WIDE_PROF")) fprintf(stderr, "[SIMON_WIDE_PROF] this build has no phase profiler: bash profiles/build_variant.sh prof -DSIMON_WIDE_PROFILE\n");
+    if (w.knobs.prof) fprintf(stderr, "[SIMON_WIDE_PROF] this build has no phase profiler: bash profiles/build_variant.sh prof -DSIMON_WIDE_PROFILE\n");
 #endif
     if (prof && hipMalloc((void**)&d_prof, (size_t)S * 16 * 16 * 8) == hipSuccess) {
         (void)hipMemsetAsync(d_prof, 0, (size_t)S * 16 * 8 * 8, st);

@@ -55,18 +55,26 @@ def gen_nodes(seed: int, n_het: int, n_total: int):
     return cpu, mem, pods, cls
 
 
-def gen_pods(seed: int, n_pods: int):
+def gen_pods(seed: int, n_pods: int, n_sigs: int = 0):
+    """Pod requests: 6 cpu sizes x 7 memory sizes = 42 distinct request signatures (the C twin
+    simon_oracle_gen_pods draws the same stream).  n_sigs > 42 widens the memory axis (odd multiples of 64 MiB
+    between the powers of two) until 6 x ceil(n_sigs / 6) >= n_sigs signatures exist -- the regime of many
+    distinct workload shapes (no C twin)."""
     rng = SplitMix64(seed ^ 0x504F4453)
     cpu = np.empty(n_pods, np.int64)
     mem = np.empty(n_pods, np.int64)
+    mems = [(128 << m) << 20 for m in range(7)]
+    if n_sigs > 42:
+        extra = [(64 * k) << 20 for k in range(3, 400, 2) if ((64 * k) << 20) not in mems]
+        mems = sorted(mems + extra[:-(-n_sigs // 6) - 7])
     for p in range(n_pods):
         r = rng.next() % 100
         c = 0
         while r >= POD_CPU_CUM[c]:
             c += 1
-        m = rng.next() % 7
+        m = rng.next() % len(mems)
         cpu[p] = POD_CPU[c]
-        mem[p] = (128 << m) << 20
+        mem[p] = mems[m]
     return cpu, mem
 
 
@@ -122,13 +130,13 @@ def make_orders(seed: int, cpu, mem, tot_cpu, tot_mem, n_orders: int) -> np.ndar
     return orders
 
 
-def build_problem(seed: int, n_pods: int, n_het: int, n_total: int, homogeneous: bool = False) -> Problem:
+def build_problem(seed: int, n_pods: int, n_het: int, n_total: int, homogeneous: bool = False, n_sigs: int = 0) -> Problem:
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
     if homogeneous:
         ncls[:] = 3
         cpu[:] = NODE_CPU[3]
         mem[:] = NODE_MEM[3]
-    pcpu, pmem = gen_pods(seed, n_pods)
+    pcpu, pmem = gen_pods(seed, n_pods, n_sigs)
     pcls, shapes = classify_pods(pcpu, pmem)
     prob = Problem(alloc_cpu=cpu, alloc_mem=mem, alloc_pods=pods, node_class=ncls,
                    req_cpu=pcpu, req_mem=pmem, pod_class=pcls,
@@ -147,10 +155,10 @@ def config2(homogeneous: bool = False):
 
 
 def config3(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488,
-            homogeneous: bool = False, seed: int = SEED + 3):
+            homogeneous: bool = False, seed: int = SEED + 3, n_sigs: int = 0):
     """10k pods x ~1k nodes: pool of n_het + n_counts nodes, one scenario per (node count, order)."""
     n_total = n_het + n_counts
-    prob = build_problem(seed, n_pods, n_het, n_total, homogeneous)
+    prob = build_problem(seed, n_pods, n_het, n_total, homogeneous, n_sigs)
     orders = make_orders(seed, prob.req_cpu, prob.req_mem, int(prob.alloc_cpu.sum()), int(prob.alloc_mem.sum()),
                          n_orders)
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)

@@ -51,7 +51,8 @@ def load():
 
 
 def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0, node_ranks=None):
-    """Run scenarios on the oracle; returns BatchResult (+ (n_failed, failed_pods, codes) when explaining)."""
+    """Run scenarios on the oracle; returns BatchResult (+ (n_failed, failed_pods, codes) when explaining).
+    Thread-safe without node_ranks (the ranked entry keeps the current scenario's ranks in a global)."""
     lib = load()
     prob.normalise()
     scen = capi.scenarios_array(scen)
@@ -59,22 +60,24 @@ def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=
     res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement)
     out = res.c_out()
     n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
+    ranks = None
+    if node_ranks is not None:
+        ranks = np.ascontiguousarray(node_ranks, np.int32)
+        assert ranks.shape == (len(scen), prob.n_nodes)
+    lib.simon_oracle_run_ranked.restype = C.c_int
     if explain_scenario >= 0:
         nmax = int(scen[explain_scenario, 0])
         failed = np.full(max_failed, -1, np.int32)
         codes = np.zeros((max_failed, nmax), np.uint16)
         nf = C.c_int32(0)
-        rc = lib.simon_oracle_run(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
-                                  len(scen), capi._ptr(orders, C.c_int32), orders.shape[0], C.byref(out),
-                                  explain_scenario, capi._ptr(failed, C.c_int32), capi._ptr(codes, C.c_uint16),
-                                  max_failed, C.byref(nf))
+        rc = lib.simon_oracle_run_ranked(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
+                                         C.c_int32(len(scen)), capi._ptr(orders, C.c_int32), C.c_int32(orders.shape[0]),
+                                         capi._ptr(ranks, C.c_int32), C.byref(out), C.c_int32(explain_scenario),
+                                         capi._ptr(failed, C.c_int32), capi._ptr(codes, C.c_uint16), C.c_int32(max_failed), C.byref(nf))
         assert rc == 0, rc
         k = min(nf.value, max_failed)
         return res, (nf.value, failed[:k], codes[:k])
-    if node_ranks is not None:
-        ranks = np.ascontiguousarray(node_ranks, np.int32)
-        assert ranks.shape == (len(scen), prob.n_nodes)
-        lib.simon_oracle_run_ranked.restype = C.c_int
+    if ranks is not None:
         rc = lib.simon_oracle_run_ranked(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
                                          C.c_int32(len(scen)), capi._ptr(orders, C.c_int32), C.c_int32(orders.shape[0]),
                                          capi._ptr(ranks, C.c_int32), C.byref(out), C.c_int32(-1), None, None, C.c_int32(0), None)
@@ -136,3 +139,42 @@ def min_plan(prob: capi.Problem, scen, res: capi.BatchResult, max_cpu=100, max_m
                                    C.byref(out), max_cpu, max_mem, C.byref(plan))
     assert rc == 0
     return plan
+
+
+def run_threaded(prob: capi.Problem, scen, orders, want_placement=True, threads=None) -> capi.BatchResult:
+    """The oracle over many scenarios, one scenario per task on `threads` host threads (the C call releases the GIL;
+    scenarios are independent).  Same result layout as run()."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    load()
+    prob.normalise()
+    scen = capi.scenarios_array(scen)
+    threads = threads or host_threads()
+    res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement)
+
+    def one(i):
+        r = run(prob, scen[[i]], orders, want_placement)
+        res.unscheduled[i] = r.unscheduled[0]
+        res.used_cpu[i] = r.used_cpu[0]
+        res.used_mem[i] = r.used_mem[0]
+        if res.used_vg is not None and r.used_vg is not None:
+            res.used_vg[i] = r.used_vg[0]
+        if want_placement:
+            res.placement[i] = r.placement[0]
+    with ThreadPoolExecutor(max(1, threads)) as pool:
+        list(pool.map(one, range(len(scen))))
+    return res
+
+
+def host_threads() -> int:
+    """Host threads worth using: the affinity mask capped by the container's CPU quota."""
+    import os
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for qf in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(qf).read().split()
+            if quota != "max":
+                cores = max(1, min(cores, -(-int(quota) // int(period))))
+        except (OSError, ValueError):
+            pass
+    return max(1, cores)

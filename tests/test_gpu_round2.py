@@ -1,0 +1,288 @@
+"""GPU parity tests, round 2: the BENCHMARKED inputs themselves (every scenario of BASELINE config 3, full-size config-5
+scenarios, config 4's shuffled orders), the multi-device / multi-rank entry points, and the ABI v3 additions."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import randprob
+from open_simulator_amd import capi, sweep, synth
+from cabi_util import build_cabi_smoke
+from test_gpu_parity import assert_same, run_gpu, _random_ranks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config3_every_benchmarked_scenario():
+    """The batch bench.py times (10k pods x 488..1511 nodes, 1024 counts x 4 orders = 4096 scenarios): EVERY scenario's
+    unscheduled count, used cpu / memory and full placement row against the oracle (threaded: ~21 s on 16 host threads;
+    on a box with fewer than 8 usable threads an evenly spaced 512-scenario sample instead)."""
+    prob, scen, orders = synth.config3()
+    pick = np.arange(len(scen)) if O.host_threads() >= 8 else np.unique(np.linspace(0, len(scen) - 1, 512).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(want_placement=True)
+        assert ctx.stats().kernel_variant == capi.KERNEL_NARROW_CACHE
+        res = ctx.fetch(want_placement=True)
+    assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
+    assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist() and res.used_mem[pick].tolist() == ref.used_mem.tolist()
+    bad = np.argwhere(res.placement[pick] != ref.placement)
+    assert len(bad) == 0, f"{len(bad)} placements differ, first (scenario, pod) = {bad[0].tolist()}"
+    assert len(pick) >= 512
+
+
+def test_config4_shuffled_orders_one_rank_of_eight():
+    """BASELINE config 4 = config 3's pool with 32 pod orders (orders 3..31 are seeded Fisher-Yates shuffles), dealt over 8
+    ranks: rank 5's shard, 96 scenarios spread over every order, against the oracle."""
+    prob, scen_all, orders = synth.config3(n_orders=32, seed=synth.SEED + 4)
+    scen = sweep.shard(scen_all, 5, 8)
+    assert len(scen) == 4096 and set(scen[:, 1].tolist()) == {5, 13, 21, 29}      # a rank sees 4 orders of the 32
+    # all 32 orders: take, for every order, three node counts from the unsharded grid
+    pick = np.array([c * 32 + o for o in range(32) for c in (3 + o, 500 + 7 * o, 1023 - o)])
+    sub = scen_all[pick]
+    assert set(sub[:, 1].tolist()) == set(range(32))
+    ref = O.run_threaded(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders)
+    assert variant == capi.KERNEL_NARROW_CACHE
+    assert_same(res, ref)
+    # and the rank's own shard end to end: results of the sharded run equal the unsharded scenarios they came from
+    k = np.unique(np.linspace(0, len(scen) - 1, 64).astype(int))
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(want_placement=True)
+        shard_res = ctx.fetch(want_placement=False)
+        ref2 = O.run_threaded(prob, scen[k], orders)
+        assert shard_res.unscheduled[k].tolist() == ref2.unscheduled.tolist()
+        assert shard_res.used_cpu[k].tolist() == ref2.used_cpu.tolist()
+        for j, s in enumerate(k.tolist()):
+            assert (ctx.fetch_placement(s) == ref2.placement[j]).all(), s
+
+
+def test_config5_sixteen_full_size_scenarios():
+    """BASELINE config 5 at full size (50k pods x 2500..5000 nodes; GPU share + anti-affinity + taints): 16 of the 256
+    benchmarked scenarios, every placement compared."""
+    prob, scen, orders = synth.config5()
+    pick = np.unique(np.linspace(0, len(scen) - 1, 16).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(want_placement=True)
+        assert ctx.stats().kernel_variant == capi.KERNEL_WIDE
+        res = ctx.fetch(want_placement=False)
+        assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
+        assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist() and res.used_mem[pick].tolist() == ref.used_mem.tolist()
+        for j, s in enumerate(pick.tolist()):
+            row = ctx.fetch_placement(s)
+            bad = np.flatnonzero(row != ref.placement[j])
+            assert len(bad) == 0, f"scenario {s}: {len(bad)} placements differ, first pod {bad[0]}"
+
+
+@pytest.mark.parametrize("n_sigs", [64, 100, 128])
+def test_config3_many_signatures(n_sigs):
+    """config 3 with more distinct request signatures than one wave has lanes (the regime behind the 42-signature benchmark)."""
+    prob, scen, orders = synth.config3(n_counts=48, n_orders=3, n_pods=6000, n_sigs=n_sigs)
+    sub = scen[::5]
+    ref = O.run_threaded(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders)
+    assert_same(res, ref)
+    assert variant == capi.KERNEL_NARROW_CACHE, "more than 64 signatures must stay on the score-table kernel"
+
+
+def test_large_pool_stays_on_cache_kernel():
+    """Up to 4095 nodes the cpu+memory path keeps the score-table kernel (it used to stop at 2047)."""
+    prob, scen, orders = synth.config3(n_counts=16, n_orders=2, n_pods=12000, n_het=3000)
+    sub = scen[[0, 7, 15, 16, 31]]
+    ref = O.run_threaded(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders)
+    assert_same(res, ref)
+    assert variant == capi.KERNEL_NARROW_CACHE
+
+
+def test_narrow_problem_beyond_8192_nodes_falls_through_to_the_all_feature_kernel():
+    """a cpu+memory problem with more than 8 x 1024 nodes used to fail with SIMON_ERANGE."""
+    prob, scen, orders = synth.config3(n_counts=4, n_orders=1, n_pods=3000, n_het=8400)
+    sub = scen[[0, 3]]
+    ref = O.run_threaded(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders)
+    assert variant == capi.KERNEL_WIDE
+    assert_same(res, ref)
+
+
+# ---- device groups (ABI v3) ------------------------------------------------------------------------------------
+def test_group_two_members_on_one_device():
+    """simon_group over the device list [0, 0]: two contexts, two host threads, scenario s on member s % 2; results in the
+    caller's order and the cross-member minimum plan equal the single-context run and the oracle."""
+    prob, scen, orders = synth.config3(n_counts=40, n_orders=3, n_pods=3000)
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        one = ctx.run_batch(scen, orders)
+        plan1 = ctx.min_plan(100, 100)
+        plan1_cap = ctx.min_plan(60, 100)
+    with capi.Group([0, 0]) as g:
+        assert g.size == 2
+        g.load_problem(prob)
+        res = g.run_batch(scen, orders)
+        assert_same(res, ref)
+        assert_same(res, one)
+        plan, _ = g.min_plan(100, 100)
+        assert plan.as_dict() == plan1.as_dict() == O.min_plan(prob, scen, ref).as_dict()
+        plan_cap, _ = g.min_plan(60, 100)
+        assert plan_cap.as_dict() == plan1_cap.as_dict() == O.min_plan(prob, scen, ref, 60, 100).as_dict()
+        for s in (0, 1, 57, len(scen) - 1):
+            assert (g.fetch_placement(s) == ref.placement[s]).all()
+        assert g.member_stats(0).kernel_variant == g.member_stats(1).kernel_variant == capi.KERNEL_NARROW_CACHE
+        # error path: fewer scenarios than members
+        with pytest.raises(capi.SimonError):
+            g.run_batch(scen[:1], orders)
+    with pytest.raises(capi.SimonError):
+        capi.Group([0, 99])
+
+
+def test_group_of_three_on_the_all_feature_kernel():
+    prob = randprob.rand_problem(4242, N=90, P=500, gpu=True, anti=True, static_mask=True, eph=True)
+    scen, orders = randprob.rand_scenarios(3, prob, S=11)
+    ref = O.run(prob, scen, orders)
+    with capi.Group([0, 0, 0]) as g:
+        g.load_problem(prob)
+        assert_same(g.run_batch(scen, orders), ref)
+        plan, _ = g.min_plan()
+        assert plan.as_dict() == O.min_plan(prob, scen, ref).as_dict()
+
+
+def test_two_contexts_on_two_os_threads():
+    """The header's promise: distinct contexts may live on distinct OS threads.  Two different problems (score-table
+    kernel / all-feature kernel) run concurrently, several rounds, each checked against the oracle."""
+    pa, sa, oa = synth.config3(n_counts=24, n_orders=2, n_pods=2500)
+    pb = randprob.rand_problem(99, N=120, P=600, gpu=True, anti=True, static_mask=True)
+    sb, ob = randprob.rand_scenarios(9, pb, S=8)
+    ra, rb = O.run_threaded(pa, sa, oa), O.run(pb, sb, ob)
+    errors = []
+
+    def worker(prob, scen, orders, ref, want_variant):
+        try:
+            with capi.Context(0) as ctx:
+                ctx.load_problem(prob)
+                for _ in range(4):
+                    res = ctx.run_batch(scen, orders)
+                    assert ctx.stats().kernel_variant == want_variant
+                    assert_same(res, ref)
+                    assert ctx.min_plan().as_dict() == O.min_plan(prob, scen, ref).as_dict()
+        except BaseException as e:              # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(pa, sa, oa, ra, capi.KERNEL_NARROW_CACHE)),
+          threading.Thread(target=worker, args=(pb, sb, ob, rb, capi.KERNEL_WIDE))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
+def test_explain_loaded_uses_the_scenarios_own_ranks():
+    """Two loaded scenarios of ONE size with different node ranks: the replay of scenario 1 must break ties with scenario
+    1's ranks (round 1 picked the first loaded scenario of that size)."""
+    prob = randprob.rand_problem(6100, N=40, P=400, tight_pods=True, static_mask=True)
+    prob.alloc_cpu[:] = prob.alloc_cpu[0]; prob.alloc_mem[:] = prob.alloc_mem[0]; prob.node_class[:] = 0
+    n = 30
+    scen = np.array([[n, 0], [n, 0], [n, 0]], np.int32)
+    orders = np.arange(prob.n_pods, dtype=np.int32)[None]
+    ranks = _random_ranks(np.random.default_rng(11), scen, prob.n_nodes)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.set_node_ranks(ranks)
+        ctx.run_loaded(True)
+        res = ctx.fetch(True)
+        assert_same(res, O.run(prob, scen, orders, node_ranks=ranks))
+        assert res.unscheduled.min() > 0, "the test needs unscheduled pods"
+        differ = 0
+        for s in range(3):
+            ref, (nf, failed, codes) = O.run(prob, scen, orders, explain_scenario=s, max_failed=32, node_ranks=ranks)
+            k, f2, c2 = ctx.explain_loaded(s, max_failed=32)
+            assert k == nf and f2.tolist() == failed.tolist() and (c2 == codes).all(), s
+            if s:
+                ref0 = O.run(prob, scen, orders, explain_scenario=0, max_failed=32, node_ranks=ranks)[1]
+                differ += int(len(ref0[1]) != len(failed) or (ref0[2] != codes).any() or (ref0[1] != failed).any())
+        assert differ, "scenario 0's ranks would have given the same answer: the test does not discriminate"
+        with pytest.raises(capi.SimonError, match="explain_loaded"):
+            ctx.explain(n, orders[0])                       # ad-hoc scenario while ranks are loaded: refused
+        with pytest.raises(capi.SimonError):
+            ctx.explain_loaded(3)
+        ctx.set_node_ranks(None)
+        k, f2, c2 = ctx.explain_loaded(1, max_failed=32)    # pool order again
+        ref, (nf, failed, codes) = O.run(prob, scen, orders, explain_scenario=1, max_failed=32)
+        assert k == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
+
+
+# ---- bench.py ---------------------------------------------------------------------------------------------------
+def _bench(args, env=None, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=dict(os.environ, **(env or {})),
+                         capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher and WORLD_SIZE unset must run TWO ranks (round 1 parsed the flag and ran
+    one).  On a single-GPU box the ranks share device 0 over gloo (SIMON_BENCH_SHARE_DEVICE=1, test hook)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SIMON_BENCH_SHARE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--counts", "32",
+                          "--pods", "2000"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
+    assert "self-spawned" in d["ranks"]["launched_by"]
+    assert d["config"]["scenarios_per_gpu"] == 32 * 4 and "8 pod orders = 256 scenarios" in d["config"]["workload"]
+    assert d["parity_sample"]["mismatches"] == 0 and d["parity_sample"]["scenarios"] >= 16
+    assert d["parity_sample"]["placement_rows"] == d["parity_sample"]["scenarios"]
+    # without the test hook a box with one GPU must refuse instead of silently running one rank
+    env.pop("SIMON_BENCH_SHARE_DEVICE")
+    if capi.load_library().simon_hip_device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode != 0 and "only 1 GPU" in (out.stderr + out.stdout)
+
+
+def test_bench_line_is_self_verifying():
+    """One reduced single-GPU bench line: roofline fractions are fractions, the parity sample covers placements, the
+    sub-records of config 2 / config 5 are present and checked."""
+    out, d = _bench(["--steps", "2", "--warmup", "1", "--counts", "64", "--pmc", "replay"],
+                    env={"SIMON_BENCH_CPU_BUDGET_S": "2", "SIMON_BENCH_C5_SCEN": "16"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["kernel"] == "narrow_cache"
+    ps = d["parity_sample"]
+    assert ps["mismatches"] == 0 and ps["scenarios"] >= 16 and ps["placement_rows"] == ps["scenarios"]
+    r = d["roofline"]
+    assert r["bound"] == "valu_issue" and r["peak"] == pytest.approx(1228.8)
+    assert r["frac"] is None or 0 < r["frac"] < 1                # replayed counters only exist for the full-size workload
+    assert r["algorithmic_ratio"] > 0
+    names = [w["workload"] for w in d["other_workloads"]]
+    assert names == ["config2", "config5"]
+    for w in d["other_workloads"]:
+        assert "error" not in w, w
+        assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+# ---- a non-Python consumer of the C-ABI -------------------------------------------------------------------------
+def test_c_consumer_of_the_abi(tmp_path):
+    """tests/cabi/cabi_smoke.c, built with plain gcc against include/simon_hip.h: load -> run_batch -> min_plan -> explain /
+    explain_loaded, the device group, and two contexts on two pthreads, against the committed binary fixtures."""
+    exe = build_cabi_smoke(tmp_path)
+    fx = [os.path.join(ROOT, "tests", "golden", n) for n in ("cabi_kav.bin", "cabi_config2_sweep.bin")]
+    out = subprocess.run([exe, *fx], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "cabi_smoke ok" in out.stdout and out.stdout.count("group of 2 members") == 2

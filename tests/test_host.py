@@ -82,3 +82,33 @@ def test_quantity_value_is_ceil():
     assert pq("1500m").int_value() == 2 and pq("0.5").milli_value() == 500
     assert pq("16Gi").int_value() == 16 * GiB and pq("256000Mi").int_value() == 256000 << 20
     assert pq("1n").milli_value() == 1
+
+
+def test_c_consumer_builds_and_links_against_the_header(tmp_path):
+    """tests/cabi/cabi_smoke.c compiles with plain gcc against include/simon_hip.h and links libsimon_hip.so; without a
+    GPU it stops after the version handshake (exit code 77).  The GPU suite runs it against the fixtures."""
+    import subprocess
+    from cabi_util import build_cabi_smoke
+    exe = build_cabi_smoke(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "cabi_kav.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode in (0, 77), out.stdout + out.stderr
+    assert "ABI 3" in out.stdout or "cabi_smoke ok" in out.stdout
+
+
+def test_cabi_fixtures_match_the_oracle():
+    """The committed binary fixtures of the C consumer are what the oracle computes today."""
+    import struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle import kav_problem
+    prob, _ = kav_problem(n_pods=10)
+    raw = open(os.path.join(root, "tests", "golden", "cabi_kav.bin"), "rb").read()
+    assert raw[:8] == b"SIMONFX1"
+    N, P, Cp, Cn, S, n_orders = struct.unpack("<6i", raw[8:32])
+    assert (N, P, S, n_orders) == (2, 10, 2, 1)
+    ref = O.run(prob, [[2, 0], [1, 0]], np.arange(10, dtype=np.int32)[None])
+    off = 32 + N * 8 * 2 + N * 4 * 2 + P * 8 * 2 + P * 4 + Cp * Cn * 8 + S * 8 + n_orders * P * 4
+    un = np.frombuffer(raw, "<i4", S, off)
+    pl = np.frombuffer(raw, "<i4", S * P, off + S * 4 + S * 16).reshape(S, P)
+    assert un.tolist() == ref.unscheduled.tolist() == [0, 2]
+    assert (pl == ref.placement).all() and pl[0, :2].tolist() == [0, 0]      # SURVEY 8(c): the first two pods land on node A
