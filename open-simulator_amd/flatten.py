@@ -351,6 +351,13 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
     if len(scalar_names) > capi.MAX_SCALAR:
         raise Unsupported(f"more than {capi.MAX_SCALAR} extended resources requested")
+    # fitsRequest's shortcut tests len(podRequest.ScalarResources) == 0 (fit.go:244-249), the engine tests the VALUES: a pod
+    # that names an extended resource with quantity 0 and requests no cpu / memory / ephemeral-storage still runs the
+    # resource checks in Go (it can fail on a node preset pods over-committed).  Not modelled: refuse.
+    for r, p in zip(reqs, tpods):
+        named_zero = any(v == 0 for name, v in r.items() if name not in ("cpu", "memory", "ephemeral-storage"))
+        if named_zero and not any(v for v in r.values()):
+            raise Unsupported(f"pod {p['metadata'].get('name')}: names an extended resource with quantity 0 and requests nothing else")
     req_cpu = np.array([r.get("cpu", 0) for r in reqs], np.int64)[tmpl_of]
     req_mem = np.array([r.get("memory", 0) for r in reqs], np.int64)[tmpl_of]
     req_eph = np.array([r.get("ephemeral-storage", 0) for r in reqs], np.int64)[tmpl_of]
@@ -558,13 +565,14 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     raw_rows: Dict[str, np.ndarray] = {}
     for c in range(Cp):
         rq = rq_of_class[c]
-        rq_key = json.dumps({k: [q.value, q.scale] for k, q in sorted(rq.items())})
+        # Quantity.AsApproximateFloat64 scales BinarySI by 2^(10*scale) and DecimalSI by 10^scale: the format is part of the value
+        rq_key = json.dumps({k: [q.value, q.scale, q.format] for k, q in sorted(rq.items())})
         row = raw_rows.get(rq_key)
         if row is None:
             names = tuple(sorted(rq))
             sub = alloc_sub.get(names)
             if sub is None:
-                ids = intern_col(tuple((alloc_q[j][k].value, alloc_q[j][k].scale) if k in alloc_q[j] else None for k in names)
+                ids = intern_col(tuple((alloc_q[j][k].value, alloc_q[j][k].scale, alloc_q[j][k].format) if k in alloc_q[j] else None for k in names)
                                  for j in ncls_rep)
                 _, sfirst, sinv = np.unique(ids, return_index=True, return_inverse=True)
                 sub = alloc_sub[names] = (sfirst, sinv)

@@ -180,14 +180,21 @@ def pods_of_daemonset(ds: dict, nodes: List[dict]) -> List[dict]:
     class_affinity = _daemon_affinity(base["spec"].get("affinity"), "", ANY_NODE_NAME)
     proto = _workload_info(make_valid_pod(base), "DaemonSet", ds)
     token = next(_TEMPLATE_TOKENS)
+    # A DoNotSchedule spread constraint looks at the nodes the pod's OWN affinity admits (podtopologyspread/filtering.go:
+    # 236-251): for a DaemonSet pod that is its one node, so only that node's domain registers and the skew never exceeds
+    # `self`.  The class view (name requirement true everywhere) would register every node's domain -- such DaemonSets keep
+    # one class per pod with their real affinity instead of the shared class + pin_node.
+    shareable = not any(c.get("whenUnsatisfiable", "DoNotSchedule") == "DoNotSchedule"
+                        for c in proto["spec"].get("topologySpreadConstraints") or [])
     for node in nodes:
         nname = node["metadata"]["name"]
         md = proto["metadata"]
         p = dict(proto, metadata=dict(md, name=f"{ds['metadata']['name']}-{nname}", labels=dict(md["labels"]), annotations=dict(md["annotations"])),
                  spec=dict(proto["spec"], affinity=_daemon_affinity(base["spec"].get("affinity"), nname)), status={})
-        p["_daemon_node"] = nname
-        p["_class_affinity"] = class_affinity
-        p["_tmpl"] = token
+        p["_daemon_node"] = nname                 # sweeps gate the pod on this node (simulate.build_stream)
+        if shareable:
+            p["_class_affinity"] = class_affinity
+            p["_tmpl"] = token
         if node_should_run_pod(node, p):
             out.append(p)
     return out

@@ -68,6 +68,9 @@ def _random_case(seed, **kw):
                   "affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [
                       {"matchExpressions": [{"key": "disk", "operator": "In", "values": ["ssd"]}]},
                       {"matchExpressions": [{"key": "rank", "operator": "Exists"}]}]}}}}
+        if seed % 4 == 3:   # a DaemonSet with a DoNotSchedule constraint: its pods look only at their own node
+            spec_a = dict(spec_a, topologySpreadConstraints=[{"maxSkew": 1, "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "DoNotSchedule",
+                                                              "labelSelector": {"matchLabels": {"app": "ds-0"}}}])
         cluster["DaemonSet"] = [
             {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": f"ds-{i}", "namespace": "kube-system"},
              "spec": {"selector": {"matchLabels": {"app": f"ds-{i}"}}, "template": {"metadata": {"labels": {"app": f"ds-{i}"}}, "spec": sp}}}
@@ -417,3 +420,47 @@ def test_fit_error_strings_of_the_new_codes():
     assert msg == ("0/4 nodes are available: 1 node(s) didn't match pod affinity rules, 1 node(s) didn't match pod affinity/anti-affinity, "
                    "1 node(s) didn't match pod topology spread constraints (missing required label), "
                    "2 node(s) didn't match pod topology spread constraints.")
+
+
+def test_daemonset_with_hard_spread_constraint_looks_only_at_its_own_node():
+    """4 nodes in zones za x 3 and zb x 1, a DaemonSet with a zone DoNotSchedule maxSkew=1 constraint.
+    A DaemonSet pod's affinity names ONE node, so only that node's domain registers (filtering.go:236-251) and every pod
+    fits; the shared class view registered every zone and left two pods out."""
+    nodes = [{"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"n{i}", "labels": {"kubernetes.io/hostname": f"n{i}", randk8s.ZONE: z}},
+              "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "110"}}} for i, z in enumerate(["za", "za", "za", "zb"])]
+    ds = {"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "ds", "namespace": "default"},
+          "spec": {"selector": {"matchLabels": {"app": "ds"}}, "template": {"metadata": {"labels": {"app": "ds"}}, "spec": {
+              "containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"cpu": "100m", "memory": "64Mi"}}}],
+              "topologySpreadConstraints": [{"maxSkew": 1, "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "DoNotSchedule",
+                                             "labelSelector": {"matchLabels": {"app": "ds"}}}]}}}}
+    cluster = {k: [] for k in k8s.KINDS}
+    cluster["Node"], cluster["DaemonSet"] = nodes, [ds]
+    pods, _ = sim.build_stream(cluster, [], nodes, len(nodes))
+    assert len(pods) == 4 and all("_class_affinity" not in p and p["_daemon_node"] for p in pods)
+    order = k8s.canonical_node_order(nodes)
+    nodes_c = [nodes[j] for j in order]
+    flat = fl.flatten(nodes_c, pods, [], [], [])
+    res = O.run(flat.problem, [[4, 0]], np.arange(4, dtype=np.int32)[None])
+    ref = pyref_sched.Scheduler(nodes_c, [], [], [], randk8s.STORAGE_CLASSES).run(pods)
+    got = [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()]
+    assert got == ref and None not in got and res.unscheduled.tolist() == [0]
+    # the same DaemonSet with a ScheduleAnyway constraint keeps the shared class + pin_node
+    ds["spec"]["template"]["spec"]["topologySpreadConstraints"][0]["whenUnsatisfiable"] = "ScheduleAnyway"
+    pods, _ = sim.build_stream(cluster, [], nodes, len(nodes))
+    assert all("_class_affinity" in p for p in pods)
+    flat = fl.flatten(nodes_c, pods, [], [], [])
+    assert flat.problem.pin_node is not None and flat.problem.n_pod_classes == 1
+    res = O.run(flat.problem, [[4, 0]], np.arange(4, dtype=np.int32)[None])
+    assert [flat.node_names[j] for j in res.placement[0].tolist()] == pyref_sched.Scheduler(nodes_c, [], [], [], randk8s.STORAGE_CLASSES).run(pods)
+
+
+def test_named_zero_extended_resource_with_no_other_request_is_refused():
+    """fit.go:244-249 tests len(ScalarResources) == 0, the engine the values: the one input where they differ is refused."""
+    nodes = [{"apiVersion": "v1", "kind": "Node", "metadata": {"name": "n0", "labels": {"kubernetes.io/hostname": "n0"}},
+              "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "110", "example.com/foo": "4"}}}]
+    pod = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p", "namespace": "default"},
+           "spec": {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"example.com/foo": "0"}}}]}}
+    with pytest.raises(fl.Unsupported, match="quantity 0"):
+        fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
+    pod["spec"]["containers"][0]["resources"]["requests"]["cpu"] = "100m"      # with a real request the shortcut never applies
+    fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
