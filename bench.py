@@ -420,7 +420,7 @@ def main():
         st = ctx.stats()
         wl = "config5" if args.workload == "config5" else "config3"
         alg = algorithmic_bytes(scen, prob.n_pods, wl)
-        kname = KERNEL_NAME.get(st.kernel_variant)
+        kname = "simon::table_kernel" if getattr(st, "kernel_generation", 0) == 4 else KERNEL_NAME.get(st.kernel_variant)
         value = S_total * args.steps / dt
         out = {
             "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),
@@ -430,7 +430,7 @@ def main():
             "pods_placed_per_sec": round(value * prob.n_pods, 1),
             "config": {"workload": workload_name(args, prob, scen_all, n_orders, S_local, world),
                        "scenarios_per_gpu": S_local, "pods": prob.n_pods, "node_pool": prob.n_nodes,
-                       "placement_matrix": placement, "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"),
+                       "placement_matrix": placement, "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_generation": st.kernel_generation,
                        "workgroup": st.workgroup_size, "slots_per_lane": st.slots_per_lane, "plan": best[0]},
             "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
                       "backend": (dist.get_backend() if world > 1 else None),

@@ -305,12 +305,15 @@ typedef struct simon_stats {
     int32_t workgroup_size;
     int32_t slots_per_lane;
     int64_t lds_bytes;
+    int32_t kernel_generation;     /* of the cpu+memory path: 1 register-resident, 2 scalarised, 3 class-major score table
+                                      (simon_cache.hip), 4 pre-keyed score table in canonical order (simon_table.hip) */
+    int32_t reserved;
 } simon_stats;
 
 #define SIMON_KERNEL_NARROW 1  /* cpu+mem+pods only, gcd-normalised 32-bit quantities, register-resident state */
 #define SIMON_KERNEL_WIDE 2    /* every feature, int64 quantities, state streamed from HBM/L2 */
 #define SIMON_KERNEL_NARROW_FAST 3 /* NARROW, second generation: scalarised control flow, fp64-resident state, score cache */
-#define SIMON_KERNEL_NARROW_CACHE 4 /* NARROW, third generation: one wave per scenario, (signature, node) score table in LDS */
+#define SIMON_KERNEL_NARROW_CACHE 4 /* NARROW, one wave per scenario over a (signature, node) score table (generations 3 and 4, see kernel_generation) */
 
 typedef struct simon_ctx simon_ctx;
 

@@ -133,7 +133,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
         ("n_launches", C.c_int32), ("kernel_variant", C.c_int32), ("workgroup_size", C.c_int32),
-        ("slots_per_lane", C.c_int32), ("lds_bytes", C.c_int64),
+        ("slots_per_lane", C.c_int32), ("lds_bytes", C.c_int64), ("kernel_generation", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

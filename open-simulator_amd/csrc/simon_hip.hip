@@ -12,6 +12,7 @@
 #include "simon_device.h"
 #include "simon_wide.h"
 #include "simon_cache.h"
+#include "simon_table.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -91,6 +92,7 @@ struct simon_ctx : simon::HostInputs {
     bool fast_ok = false, nzeq = false;  // simon_fast.hip eligibility
     // ---- simon_cache.hip (LDS score table, one wave per scenario) ----
     bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
+    bool table_ok = false, no_table = false;   // simon_table.hip (generation 4); no_table: env SIMON_TABLE=0 (A/B against generation 3)
     int ablate = 0;
     DevBuf<unsigned char> d_ws;
     int n_sigs = 0, n_shapes = 0, max_bands = 4;
@@ -232,18 +234,21 @@ int stage_narrow(simon_ctx* c) {
         rowsF[p] = PodRowF{(double)r.req_cpu, (double)r.req_mem, (double)r.nz_cpu, (double)r.nz_mem, r.cls, r.preset, r.gate, r.flags};
         if (r.req_cpu != r.nz_cpu || r.req_mem != r.nz_mem) c->nzeq = false;
     }
-    // simon_cache.hip: intern pod request signatures and node shapes
-    c->cache_ok = c->fast_ok && N <= kCacheMaxNodes;
-    if (c->cache_ok) {
+    // simon_table.hip / simon_cache.hip: intern pod request signatures and node shapes
+    bool nozero = true;
+    for (int j = 0; j < N; ++j) if (a_cpu[j] == 0 || a_mem[j] == 0) nozero = false;
+    c->table_ok = nozero && c->Cn <= kTableMaxClasses && N <= kTableMaxNodes;
+    c->cache_ok = false;
+    if (c->table_ok) {
         std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t>, int> sig_id;
         std::vector<SigRow> sigs;
         std::vector<PodRowC> rowsC(P);
-        for (int p = 0; p < P && c->cache_ok; ++p) {
+        for (int p = 0; p < P && c->table_ok; ++p) {
             const PodRowN& r = rows[p];
             auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, r.cls, r.flags);
             auto it = sig_id.find(key);
             if (it == sig_id.end()) {
-                if ((int)sigs.size() == kCacheMaxSigs) { c->cache_ok = false; break; }
+                if ((int)sigs.size() == kTableMaxSigs) { c->table_ok = false; break; }
                 it = sig_id.emplace(key, (int)sigs.size()).first;
                 SigRow sr{};
                 sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = r.cls; sr.flags = r.flags;
@@ -253,12 +258,12 @@ int stage_narrow(simon_ctx* c) {
         }
         std::map<std::pair<uint32_t, uint32_t>, int> shape_id;
         std::vector<ShapeRow> shapes;
-        std::vector<int32_t> shape_of(N), rank(N), prefix((size_t)(N + 1) * c->Cn, 0);
-        for (int j = 0; j < N && c->cache_ok; ++j) {
+        std::vector<int32_t> shape_of(N);
+        for (int j = 0; j < N && c->table_ok; ++j) {
             auto key = std::make_pair(a_cpu[j], a_mem[j]);
             auto it = shape_id.find(key);
             if (it == shape_id.end()) {
-                if ((int)shapes.size() == kCacheMaxShapes) { c->cache_ok = false; break; }
+                if ((int)shapes.size() == kTableMaxShapes) { c->table_ok = false; break; }
                 it = shape_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};
                 sh.cap_c = (double)a_cpu[j]; sh.cap_m = (double)a_mem[j];
@@ -267,20 +272,27 @@ int stage_narrow(simon_ctx* c) {
                 shapes.push_back(sh);
             }
             shape_of[j] = it->second;
-            const int d = c->node_class[j];
-            rank[j] = prefix[(size_t)j * c->Cn + d];
-            for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
         }
-        if (c->cache_ok) {
+        if (c->table_ok) {
             c->n_sigs = (int)sigs.size(); c->n_shapes = (int)shapes.size();
             if (sigs.empty()) sigs.push_back(SigRow{});
-            c->h_clsprefix = prefix;
             HIP_TRY(c, c->d_sigs.upload(sigs, st));
             HIP_TRY(c, c->d_shapes.upload(shapes, st));
             HIP_TRY(c, c->d_podsC.upload(rowsC, st));
-            HIP_TRY(c, c->d_rank.upload(rank, st));
             HIP_TRY(c, c->d_shape_of.upload(shape_of, st));
-            HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
+            // generation 3 (class-major layout): <= 64 signatures, <= 2047 nodes, <= 32 node classes
+            c->cache_ok = c->fast_ok && N <= kCacheMaxNodes && c->n_sigs <= kCacheMaxSigs;
+            if (c->cache_ok) {
+                std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * c->Cn, 0);
+                for (int j = 0; j < N; ++j) {
+                    const int d = c->node_class[j];
+                    rank[j] = prefix[(size_t)j * c->Cn + d];
+                    for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
+                }
+                c->h_clsprefix = prefix;
+                HIP_TRY(c, c->d_rank.upload(rank, st));
+                HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
+            }
             HIP_TRY(c, hipStreamSynchronize(st));
         }
     }
@@ -397,6 +409,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_CACHE_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
+    if (const char* e = getenv("SIMON_TABLE")) c->no_table = e[0] == '0';
     if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
@@ -662,7 +675,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     c->h_perm = perm;
     c->h_orders.assign(orders, orders + (size_t)n_orders * P);
     c->cache_perm_ok = false;
-    if (c->variant == SIMON_KERNEL_NARROW && c->cache_ok) {
+    if (c->variant == SIMON_KERNEL_NARROW && (c->cache_ok || c->table_ok)) {
         // placements are recorded by scheduling step and gathered back to pod ids through the inverse orders,
         // which exist only when every order is a permutation of [0, P)
         std::vector<int32_t> inv((size_t)n_orders * P, -1);
@@ -678,8 +691,8 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             c->cache_perm_ok = true;
         }
-        c->scen_ni.resize(S);
-        for (int s = 0; s < S; ++s) {
+        c->scen_ni.assign(S, 0);
+        for (int s = 0; s < S && c->cache_ok; ++s) {
             int ni = 0;
             for (int d = 0; d < c->Cn; ++d) ni += (c->h_clsprefix[(size_t)scen[s].n_nodes * c->Cn + d] + 15) & ~15;
             c->scen_ni[s] = ni;
@@ -729,6 +742,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     const int S = c->S, P = c->P;
     if (want_placement) HIP_TRY(c, c->d_place.ensure((size_t)S * P));
     int T = 0, slots = 0, variant_used = c->variant;
+    bool table_used = false;
     size_t lds = 0;
     bool run_wide = c->variant != SIMON_KERNEL_NARROW || c->has_ranks;    // per-scenario node ranks: all-feature kernel only
     if (!run_wide) {
@@ -748,10 +762,61 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
             use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
         }
-        // pinned pods (pin_node) are known to the cache kernel and the all-feature kernel only
-        if ((c->has_pin || too_big) && !use_cache) run_wide = true;
+        // generation 4 (simon_table.hip) takes every batch generation 3 takes, and more signatures / nodes / classes
+        auto ni16 = [](int n) { return std::max((n + 15) & ~15, 16); };
+        bool use_table = c->table_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && !c->no_table && c->max_n <= kTableMaxNodes &&
+                         table_lds_bytes(c->n_sigs, ni16(c->max_n), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad <= 64 * 1024;
+        if (use_table) use_cache = false;
+        // pinned pods (pin_node) are known to the score-table kernels and the all-feature kernel only
+        if ((c->has_pin || too_big) && !use_cache && !use_table) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
+        } else if (use_table) {
+            // Bands as for generation 3 (below): scenarios in LPT order cut into launches of equal scenario count, each with the
+            // LDS summary and HBM workspace of its own largest scenario, on its own stream.
+            struct Band { int start, count, ni_max; size_t lds, ws_off; };
+            std::vector<Band> bands;
+            const int nb = std::max(1, std::min(c->max_bands, S));
+            size_t ws_total = 0;
+            for (int bi = 0; bi < nb; ++bi) {
+                const int b = (int)((long long)S * bi / nb), e = (int)((long long)S * (bi + 1) / nb);
+                if (e <= b) continue;
+                const int ni0 = ni16(c->scen[c->h_perm[b]].n_nodes);
+                bands.push_back(Band{b, e - b, ni0, table_lds_bytes(c->n_sigs, ni0, c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad, ws_total});
+                ws_total += table_ws_bytes(c->n_sigs, ni0, c->Cn, c->Cp, c->n_shapes, c->nzeq) * (size_t)(e - b);
+            }
+            HIP_TRY(c, c->d_ws.ensure(ws_total));
+            if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
+            TableLaunch f{};
+            f.ncls = c->d_ncls.p; f.shape_of = c->d_shape_of.p; f.a_pods = c->d_a_pods.p;
+            f.i_rq_cpu = c->d_i_rq_cpu.p; f.i_rq_mem = c->d_i_rq_mem.p; f.i_nz_cpu = c->d_i_nz_cpu.p; f.i_nz_mem = c->d_i_nz_mem.p;
+            f.i_npods = c->d_i_npods.p; f.sigs = c->d_sigs.p; f.shapes = c->d_shapes.p;
+            f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.scen = c->d_scen.p;
+            f.static_mask = c->has_mask ? c->d_mask.p : nullptr; f.simon_raw = c->d_raw32.p;
+            f.unscheduled = c->d_unsched.p; f.used_cpu = c->d_used_cpu.p; f.used_mem = c->d_used_mem.p;
+            f.place_step = want_placement ? c->d_place_step.p : nullptr;
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
+            for (size_t bi = 0; bi < bands.size(); ++bi) {
+                const Band& bd = bands[bi];
+                hipStream_t bs = bands.size() == 1 ? c->stream : c->band_stream[bi];
+                if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
+                f.perm = c->d_perm.p + bd.start;
+                f.ws = c->d_ws.p + bd.ws_off;
+                f.sc = TableScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max, c->g_cpu, c->g_mem};
+                HIP_TRY(c, launch_table(f, bd.count, c->has_mask, c->nzeq, c->has_pin, bd.lds, bs));
+                if (bs != c->stream) {
+                    HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
+                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev[bi], 0));
+                }
+            }
+            if (want_placement)
+                HIP_TRY(c, launch_unpermute(c->d_place_step.p, c->d_inv_orders.p, c->d_scen.p, S, P, c->d_place.p, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            variant_used = SIMON_KERNEL_NARROW_CACHE;
+            T = 64; slots = (ni16(c->max_n) / 16 + 63) / 64; lds = bands[0].lds;
+            c->stats.n_launches = (int)bands.size();
+            table_used = true;
         } else if (use_cache) {
             // Bands: scenarios in LPT order (largest first) are cut into at most max_bands launches of equal
             // scenario count; each band sizes its LDS summary and HBM workspace for its own largest scenario and
@@ -861,6 +926,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     c->stats.kernel_ms = ms;
     if (variant_used != SIMON_KERNEL_NARROW_CACHE) c->stats.n_launches = 1;
     c->stats.kernel_variant = variant_used;
+    c->stats.kernel_generation = table_used ? 4 : variant_used == SIMON_KERNEL_NARROW_CACHE ? 3 : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : 1;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;
     c->stats.lds_bytes = (int64_t)lds;

@@ -87,7 +87,7 @@ def test_config5_sixteen_full_size_scenarios():
             assert len(bad) == 0, f"scenario {s}: {len(bad)} placements differ, first pod {bad[0]}"
 
 
-@pytest.mark.parametrize("n_sigs", [64, 100, 128])
+@pytest.mark.parametrize("n_sigs", [64, 100, 126])
 def test_config3_many_signatures(n_sigs):
     """config 3 with more distinct request signatures than one wave has lanes (the regime behind the 42-signature benchmark)."""
     prob, scen, orders = synth.config3(n_counts=48, n_orders=3, n_pods=6000, n_sigs=n_sigs)
