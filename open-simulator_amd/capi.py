@@ -638,6 +638,8 @@ class Context:
 
     def explain_loaded(self, scenario: int, max_failed: int = 64):
         """simon_explain_loaded: replay scenario `scenario` of the loaded batch (its order, its own node ranks)."""
+        if not (self.scen is not None and 0 <= int(scenario) < len(self.scen)):
+            raise SimonError(f"simon_explain_loaded: scenario {scenario} is not one of the {0 if self.scen is None else len(self.scen)} loaded")
         n_nodes = int(self.scen[scenario, 0])
         failed = np.full(max_failed, -1, np.int32)
         codes = np.zeros((max_failed, n_nodes), np.uint16)

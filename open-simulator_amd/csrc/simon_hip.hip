@@ -94,12 +94,12 @@ struct simon_ctx : simon::HostInputs {
     bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
     bool table_ok = false, no_table = false;   // simon_table.hip (generation 4); no_table: env SIMON_TABLE=0 (A/B against generation 3)
     int ablate = 0;
-    DevBuf<unsigned char> d_ws;
+    DevBuf<unsigned char> d_ws, d_table_cold;
     int n_sigs = 0, n_shapes = 0, max_bands = 4;
     DevBuf<SigRow> d_sigs;
     DevBuf<ShapeRow> d_shapes;
     DevBuf<PodRowC> d_podsC;
-    DevBuf<int32_t> d_rank, d_shape_of, d_clsprefix, d_inv_orders, d_place_step;
+    DevBuf<int32_t> d_rank, d_shape_of, d_clsprefix, d_inv_orders, d_place_step, d_cls_list, d_cls_off;
     std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn]; padded size of every loaded scenario
     std::vector<int32_t> h_perm;
     std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
@@ -280,19 +280,23 @@ int stage_narrow(simon_ctx* c) {
             HIP_TRY(c, c->d_shapes.upload(shapes, st));
             HIP_TRY(c, c->d_podsC.upload(rowsC, st));
             HIP_TRY(c, c->d_shape_of.upload(shape_of, st));
-            // generation 3 (class-major layout): <= 64 signatures, <= 2047 nodes, <= 32 node classes
-            c->cache_ok = c->fast_ok && N <= kCacheMaxNodes && c->n_sigs <= kCacheMaxSigs;
-            if (c->cache_ok) {
-                std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * c->Cn, 0);
-                for (int j = 0; j < N; ++j) {
-                    const int d = c->node_class[j];
-                    rank[j] = prefix[(size_t)j * c->Cn + d];
-                    for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
-                }
-                c->h_clsprefix = prefix;
-                HIP_TRY(c, c->d_rank.upload(rank, st));
-                HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
+            // class-major layout: rank of a node among its class, per-class node lists in canonical order, class counts of
+            // every prefix of the pool (a scenario = a prefix)
+            std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * c->Cn, 0), cls_off(c->Cn + 1, 0), cls_list(N);
+            for (int j = 0; j < N; ++j) {
+                const int d = c->node_class[j];
+                rank[j] = prefix[(size_t)j * c->Cn + d];
+                for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
             }
+            for (int d = 0; d < c->Cn; ++d) cls_off[d + 1] = cls_off[d] + prefix[(size_t)N * c->Cn + d];
+            for (int j = 0; j < N; ++j) cls_list[cls_off[c->node_class[j]] + rank[j]] = j;
+            c->h_clsprefix = prefix;
+            HIP_TRY(c, c->d_rank.upload(rank, st));
+            HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
+            HIP_TRY(c, c->d_cls_list.upload(cls_list, st));
+            HIP_TRY(c, c->d_cls_off.upload(cls_off, st));
+            // generation 3 (simon_cache.hip): <= 64 signatures, <= 2047 nodes, <= 32 node classes
+            c->cache_ok = c->fast_ok && N <= kCacheMaxNodes && c->n_sigs <= kCacheMaxSigs;
             HIP_TRY(c, hipStreamSynchronize(st));
         }
     }
@@ -673,6 +677,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     HIP_TRY(c, c->d_used_vg.ensure(S));
     HIP_TRY(c, c->d_plan.ensure(1));
     c->h_perm = perm;
+    c->scen_ni.assign(S, 0);
     c->h_orders.assign(orders, orders + (size_t)n_orders * P);
     c->cache_perm_ok = false;
     if (c->variant == SIMON_KERNEL_NARROW && (c->cache_ok || c->table_ok)) {
@@ -692,7 +697,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             c->cache_perm_ok = true;
         }
         c->scen_ni.assign(S, 0);
-        for (int s = 0; s < S && c->cache_ok; ++s) {
+        for (int s = 0; s < S && c->table_ok; ++s) {
             int ni = 0;
             for (int d = 0; d < c->Cn; ++d) ni += (c->h_clsprefix[(size_t)scen[s].n_nodes * c->Cn + d] + 15) & ~15;
             c->scen_ni[s] = ni;
@@ -763,9 +768,11 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
         }
         // generation 4 (simon_table.hip) takes every batch generation 3 takes, and more signatures / nodes / classes
-        auto ni16 = [](int n) { return std::max((n + 15) & ~15, 16); };
+        int ni_top = 0;
+        for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
         bool use_table = c->table_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && !c->no_table && c->max_n <= kTableMaxNodes &&
-                         table_lds_bytes(c->n_sigs, ni16(c->max_n), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad <= 64 * 1024;
+                         ni_top <= kTableMaxPadded &&
+                         table_lds_bytes(c->n_sigs, std::max(ni_top, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad <= 64 * 1024;
         if (use_table) use_cache = false;
         // pinned pods (pin_node) are known to the score-table kernels and the all-feature kernel only
         if ((c->has_pin || too_big) && !use_cache && !use_table) run_wide = true;
@@ -781,19 +788,26 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             for (int bi = 0; bi < nb; ++bi) {
                 const int b = (int)((long long)S * bi / nb), e = (int)((long long)S * (bi + 1) / nb);
                 if (e <= b) continue;
-                const int ni0 = ni16(c->scen[c->h_perm[b]].n_nodes);
+                int ni0 = 16;                                  // padded sizes are not monotone in n: the band's own maximum
+                for (int i2 = b; i2 < e; ++i2) ni0 = std::max(ni0, c->scen_ni[c->h_perm[i2]]);
                 bands.push_back(Band{b, e - b, ni0, table_lds_bytes(c->n_sigs, ni0, c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad, ws_total});
                 ws_total += table_ws_bytes(c->n_sigs, ni0, c->Cn, c->Cp, c->n_shapes, c->nzeq) * (size_t)(e - b);
             }
             HIP_TRY(c, c->d_ws.ensure(ws_total));
             if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
+            TableCold cold{};
+            cold.ncls = c->d_ncls.p; cold.rank = c->d_rank.p; cold.shape_of = c->d_shape_of.p; cold.cls_off = c->d_cls_off.p;
+            cold.clsprefix = c->d_clsprefix.p; cold.a_pods = c->d_a_pods.p;
+            cold.i_rq_cpu = c->d_i_rq_cpu.p; cold.i_rq_mem = c->d_i_rq_mem.p; cold.i_nz_cpu = c->d_i_nz_cpu.p; cold.i_nz_mem = c->d_i_nz_mem.p;
+            cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
+            cold.static_mask = c->has_mask ? c->d_mask.p : nullptr; cold.simon_raw = c->d_raw32.p;
+            cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
+            HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
+            HIP_TRY(c, hipMemcpyAsync(c->d_table_cold.p, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));             // `cold` is a stack object
             TableLaunch f{};
-            f.ncls = c->d_ncls.p; f.shape_of = c->d_shape_of.p; f.a_pods = c->d_a_pods.p;
-            f.i_rq_cpu = c->d_i_rq_cpu.p; f.i_rq_mem = c->d_i_rq_mem.p; f.i_nz_cpu = c->d_i_nz_cpu.p; f.i_nz_mem = c->d_i_nz_mem.p;
-            f.i_npods = c->d_i_npods.p; f.sigs = c->d_sigs.p; f.shapes = c->d_shapes.p;
-            f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.scen = c->d_scen.p;
-            f.static_mask = c->has_mask ? c->d_mask.p : nullptr; f.simon_raw = c->d_raw32.p;
-            f.unscheduled = c->d_unsched.p; f.used_cpu = c->d_used_cpu.p; f.used_mem = c->d_used_mem.p;
+            f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
+            f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
@@ -814,7 +828,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 HIP_TRY(c, launch_unpermute(c->d_place_step.p, c->d_inv_orders.p, c->d_scen.p, S, P, c->d_place.p, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
             variant_used = SIMON_KERNEL_NARROW_CACHE;
-            T = 64; slots = (ni16(c->max_n) / 16 + 63) / 64; lds = bands[0].lds;
+            T = 64; slots = (ni_top / 16 + 63) / 64; lds = bands[0].lds;
             c->stats.n_launches = (int)bands.size();
             table_used = true;
         } else if (use_cache) {

@@ -1,40 +1,44 @@
-// simon_table.hip -- cpu+memory scenario kernel, generation 4: one WAVE = one capacity-planning scenario, a
-// PRE-KEYED (signature, node) score table in canonical node order.
+// simon_table.hip -- cpu+memory scenario kernel, generation 4: one WAVE = one capacity-planning scenario over a
+// (signature, node) score table, with the class term folded into the block summaries.
 //
 // What generation 3 (simon_cache.hip) established: a scheduling cycle changes ONE node, pods come from K distinct
-// request signatures, so (feasible, score) of every (signature, node) is a table of which one column changes per
-// cycle, and a per-(signature, block of 16 nodes) summary in LDS answers findNodesThatFitPod + prioritizeNodes +
-// selectHost (V/core/generic_scheduler.go:131-209) with one LDS read per 16 nodes.  Its cycle, measured
-// (profiles/README.md): ~250 dependent instructions and five waits (feasible-class counters, summary row, canonical
-// index of the block's best node, tile row + node state from L2, node shape) -- 4 500 cycles of latency per pod.
+// request signatures, so (feasible, LeastAllocated + BalancedAllocation) of every (signature, node) is a table of
+// bytes of which one column changes per cycle; nodes are laid out class-major (stable in canonical order, every node
+// class padded to 16, so a block of 16 nodes has ONE Simon node class) and a per-(signature, block) summary in LDS
+// answers findNodesThatFitPod + prioritizeNodes + selectHost (V/core/generic_scheduler.go:131-209) with one LDS read
+// per 16 nodes.  Its cycle, measured (profiles/README.md): ~250 dependent instructions and five waits (feasible-class
+// counters, summary row, canonical index of the block's best node, tile row + node state from L2, node shape).
 //
-// This generation removes three of the waits and a third of the instructions by changing WHAT the table holds:
-//   * an entry is the final arg-max key of its node for its signature, ready to be max-reduced:
-//       e = (1 + LeastAllocated + BalancedAllocation + 2 x normalised Simon score) << 4 | (15 - position in block)
-//     (0 = NodeResourcesFit or a static filter fails).  The Simon / Open-Gpu-Share term (pkg/simulator/plugin/simon.go:
-//     76-101: min-max normalised over the FEASIBLE nodes) depends on (signature, node class) and on which node classes
-//     still hold a feasible node for the signature.  That set only ever shrinks (Requested grows, pod slots shrink), so
-//     the term is FOLDED into the entries and a signature's row is re-based in place on the rare cycle after a class
-//     lost its last feasible node (at most Cn - 1 times per signature and scenario);
-//   * nodes stay in canonical nodeTree order (position = node index): the first maximum in canonical order is the
-//     maximum of (e >> 4) << 12 | (4095 - position) -- no class-major permutation, no canonical-index lookup, no
-//     per-class term in the scan;
-//   * the block summary is the plain packed-u16 maximum of the 16 pre-keyed entries (no unpacking of bytes).
-// Per pod: [dirty signature? re-base its row] -> one u16 LDS read per 16 nodes -> 4 VALU -> one DPP wave max -> node.
-// assume (V/scheduler.go:371 -> NodeInfo.AddPod, V/framework/types.go:482-508): the wave loads the node's 16-byte state
-// and lane k the 32-byte table row (signature k, touched block) in ONE memory round trip, overlapped with the LDS reads
-// of the node's shape and class term; lane k re-evaluates signature k with exactly the fp64 sequences of
-// simon_fast.hip / simon_cache.hip, patches its entry, re-reduces its row and stores the summary entry.
+// This generation keeps the byte table (its footprint decides whether 4 096 scenarios stay in the Infinity Cache: a
+// 16-bit table was measured at 39 GB of HBM traffic per step against 6.5 GB) and changes what the SUMMARY holds:
+//   * sum[k][b] = (best byte of the block + class term of (signature k, class of block b)) << 4 | 15 - position.
+//     The Simon / Open-Gpu-Share term (pkg/simulator/plugin/simon.go:76-101: min-max normalised over the FEASIBLE
+//     nodes) depends on (signature, node class) and on which node classes still hold a feasible node for the
+//     signature.  That set only ever shrinks (Requested grows, pod slots shrink), so the term is folded in and a
+//     signature's summary row is re-based -- 2 LDS entries per lane -- on the rare cycle after a class lost its last
+//     feasible node (at most Cn - 1 times per signature and scenario).  The scan needs no class term, no feasible-class
+//     ballot, no counters;
+//   * the arg-max key is total << 12 | 4095 - POSITION.  Inside a class, position order is canonical order; across
+//     classes it is not, so after the reduction the wave checks whether blocks of ANOTHER class tie with the winner
+//     (one compare + ballot) and only then resolves the tie through the canonical indices (static per-class node lists,
+//     L2-hot) -- the canonical index leaves the critical path;
+//   * shape ids live in LDS (one byte per position), so the shape row is fetched while the table row and the node state
+//     are in flight -- one memory round trip per cycle, nothing dependent behind it.
+// Per pod: [dirty signature? re-base its summary row] -> one u16 LDS read per 16 nodes -> 4 VALU -> one DPP wave max
+// -> tie check -> node.  assume (V/scheduler.go:371 -> NodeInfo.AddPod, V/framework/types.go:482-508): the wave loads
+// the node's 12-byte state and lane k the 16-byte table row (signature k, touched block); lane k re-evaluates signature
+// k with exactly the fp64 sequences of simon_fast.hip / simon_cache.hip, patches its byte, re-reduces its row and
+// stores the summary entry.
 //
-// Limits: K <= 128 signatures (two per lane), <= 4095 nodes, <= 64 node classes, <= 256 node shapes, NARROW
-// preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are permutations.
+// Limits: K <= 128 signatures (two per lane), padded scenario size <= 4096 positions (<= 4095 nodes), <= 64 node
+// classes, <= 256 node shapes, NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders
+// are permutations.
 #include "simon_table.h"
 
 #include <algorithm>
 
 namespace simon {
 
-typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x2t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pkmax_t(unsigned a, unsigned b) {
@@ -47,6 +51,21 @@ __device__ __forceinline__ int la_term_t(double r, double rc100) {   // == la_te
     return (int)__builtin_fma(-r, rc100, C);
 }
 
+// max over the 16 bytes of one table row of (byte << 4 | 15 - position)
+__device__ __forceinline__ unsigned block_key16_t(const uint4 R) {
+    const unsigned M8 = 0x00FF00FFu;
+#define SIMON_LO(w, q4) ((((w) & M8) << 4) | (unsigned)((15 - (q4)) | ((15 - ((q4) + 2)) << 16)))
+#define SIMON_HI(w, q4) (((((w) >> 8) & M8) << 4) | (unsigned)((15 - ((q4) + 1)) | ((15 - ((q4) + 3)) << 16)))
+    unsigned m0 = pkmax_t(SIMON_LO(R.x, 0), SIMON_HI(R.x, 0));
+    unsigned m1 = pkmax_t(SIMON_LO(R.y, 4), SIMON_HI(R.y, 4));
+    unsigned m2 = pkmax_t(SIMON_LO(R.z, 8), SIMON_HI(R.z, 8));
+    unsigned m3 = pkmax_t(SIMON_LO(R.w, 12), SIMON_HI(R.w, 12));
+#undef SIMON_LO
+#undef SIMON_HI
+    m0 = pkmax_t(pkmax_t(m0, m1), pkmax_t(m2, m3));
+    return max(m0 & 0xFFFFu, m0 >> 16);
+}
+
 // max over each 16-lane row (result in every lane of the row)
 __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
     v = max(v, (unsigned)SIMON_DPP(0, (int)v, 0xB1, 0xF));
@@ -56,9 +75,11 @@ __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
     return v;
 }
 
+struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
+
 struct TCarve {
-    int sum, node, sn, cnt, raw, shape, tmp, total;   // LDS offsets (multiples of 16)
-    int ws_tile, ws_state, ws_nz, ws_total;           // HBM workspace offsets per scenario
+    int sum, shid, sn, cnt, raw, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
+    int ws_tile, ws_state, ws_nz, ws_total;                // HBM workspace offsets per scenario
     int nbp;
 };
 __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
@@ -68,16 +89,17 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, int Cp, int 
     c.nbp = cache_nbp(nblk);
     int o = 0;
     c.sum = o; o += al(K * c.nbp * 2);
-    c.node = o; o += al(ni_max * 2);
+    c.shid = o; o += al(ni_max);
     c.sn = o; o += al(K * Cn * 2);
     c.cnt = o; o += al(K * Cn * 4);
     c.raw = o; o += al(Cp * Cn * 4);
     c.shape = o; o += n_shapes * 48;
+    c.seg = o; o += 68 * 4;
     c.tmp = o; o += 64 * 4;
     c.total = o;
     int w = 0;
-    c.ws_tile = w; w += (nblk * K * 32 + 127) & ~127;
-    c.ws_state = w; w += (ni_max * 16 + 127) & ~127;
+    c.ws_tile = w; w += (nblk * K * 16 + 127) & ~127;
+    c.ws_state = w; w += (ni_max * 12 + 127) & ~127;
     c.ws_nz = w; w += nzeq ? 0 : ((ni_max * 8 + 127) & ~127);
     c.ws_total = w;
     return c;
@@ -85,44 +107,72 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, int Cp, int 
 
 // KQ: signatures per lane (1: K <= 64, 2: K <= 128).  HAS_PIN: the stream holds pinned pods (own instantiation: the extra
 // branch costs the common kernel time).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ>
+// NBQ: blocks per lane (1, 2 or 4: padded scenario sizes up to 1024 / 2048 / 4096 positions) -- a template parameter so that the
+// scan is straight-line code (as run-time conditions the four reads became four dependent LDS round trips).
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ>
 __global__ __launch_bounds__(64) void table_kernel(
-    const int32_t* __restrict__ ncls, const int32_t* __restrict__ shape_of, const int32_t* __restrict__ a_pods,
-    const uint32_t* __restrict__ i_rq_cpu, const uint32_t* __restrict__ i_rq_mem, const uint32_t* __restrict__ i_nz_cpu,
-    const uint32_t* __restrict__ i_nz_mem, const int32_t* __restrict__ i_npods, const SigRow* __restrict__ sigs,
-    const ShapeRow* __restrict__ shapes, const PodRowC* __restrict__ pods, const int32_t* __restrict__ orders,
-    const ScenarioDesc* __restrict__ scen, const int32_t* __restrict__ perm, const uint64_t* __restrict__ static_mask,
-    const int32_t* __restrict__ simon_raw, int32_t* __restrict__ unscheduled, int64_t* __restrict__ used_cpu,
-    int64_t* __restrict__ used_mem, int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
+    const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list, const PodRowC* __restrict__ pods,
+    const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, int32_t* __restrict__ place_step, unsigned char* ws,
+    const TableScalars sc) {
+    // Pointers the hot loop never touches live in a device-resident struct: as kernel arguments (24 pointers) they kept the
+    // loop at the SGPR limit and spilled into VGPR lanes.
+    const int32_t* __restrict__ const ncls = cold->ncls; const int32_t* __restrict__ const shape_of = cold->shape_of;
+    const int32_t* __restrict__ const cls_off = cold->cls_off; const int32_t* __restrict__ const clsprefix = cold->clsprefix;
+    const int32_t* __restrict__ const a_pods = cold->a_pods; const uint32_t* __restrict__ const i_rq_cpu = cold->i_rq_cpu;
+    const uint32_t* __restrict__ const i_rq_mem = cold->i_rq_mem; const uint32_t* __restrict__ const i_nz_cpu = cold->i_nz_cpu;
+    const uint32_t* __restrict__ const i_nz_mem = cold->i_nz_mem; const int32_t* __restrict__ const i_npods = cold->i_npods;
+    const SigRow* __restrict__ const sigs = cold->sigs; const ShapeRow* __restrict__ const shapes = cold->shapes;
+    const ScenarioDesc* __restrict__ const scen = cold->scen; const uint64_t* __restrict__ const static_mask = cold->static_mask;
+    const int32_t* __restrict__ const simon_raw = cold->simon_raw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
     const TCarve cv = tcarve(K, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ);
     const int nbp = cv.nbp;
     unsigned char* const wsb = ws + (size_t)blockIdx.x * (size_t)cv.ws_total;
-    unsigned short* g_tile = (unsigned short*)(wsb + cv.ws_tile);   // [block][K][16] pre-keyed entries
-    uint4* g_state = (uint4*)(wsb + cv.ws_state);                   // {Requested cpu, mem, free pod slots, unused}
+    unsigned char* g_tile = wsb + cv.ws_tile;                       // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
+    NodeState* g_state = (NodeState*)(wsb + cv.ws_state);
     uint2* g_nz = (uint2*)(wsb + cv.ws_nz);                         // NonZeroRequested {cpu, mem} (only when !NZEQ)
-    unsigned short* s_sum = (unsigned short*)(smem + cv.sum);       // [K][nbp]: max entry of (signature, block)
-    unsigned short* s_node = (unsigned short*)(smem + cv.node);     // [ni]: shape id | node class << 8
+    unsigned short* s_sum = (unsigned short*)(smem + cv.sum);       // [K][nbp]: (best byte + class term) << 4 | 15 - position
+    unsigned char* s_shid = smem + cv.shid;                         // [ni]: shape id of a position
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k
     int* s_raw = (int*)(smem + cv.raw);                             // [Cp][Cn] Simon raw scores
     const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);
+    int* s_seg = (int*)(smem + cv.seg);                             // [Cn + 1]: first position of a class segment
     int* s_tmp = (int*)(smem + cv.tmp);
 
+    const unsigned Krow = (unsigned)K * 16u;                          // bytes of one block's rows
     const int lane = threadIdx.x;
-    const int s = perm[blockIdx.x];
-    const int n = scen[s].n_nodes;
-    const int ni = (n + 15) & ~15, nblk = ni >> 4;
-    const int32_t* __restrict__ order = orders + (size_t)scen[s].order_id * P;
+    const int s = __builtin_amdgcn_readfirstlane(perm[blockIdx.x]);
+    const int n = __builtin_amdgcn_readfirstlane(scen[s].n_nodes);
+    const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
-    // ---- prologue 1: clear, tables -> LDS ----------------------------------------------------
-    for (int i = lane; i < cv.node / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);    // summary
+    // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
+    for (int i = lane; i < cv.shid / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);    // summary
     for (int i = lane; i < K * Cn; i += 64) { s_cnt[i] = 0; s_sn[i] = 0; }
     for (int i = lane; i < Cp * Cn; i += 64) s_raw[i] = simon_raw[i];
     for (int i = lane; i < sc.n_shapes * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
-    for (int p = lane; p < ni; p += 64) s_node[p] = p < n ? (unsigned short)((unsigned)shape_of[p] | ((unsigned)ncls[p] << 8)) : (unsigned short)0;
+    // count of class-d nodes among the first n canonical nodes, padded to 16
+    const int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
+    const int pad_d = (cnt_d + 15) & ~15;
+    int incl = pad_d;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    s_seg[lane] = incl - pad_d;                                       // lanes >= Cn hold ni
+    const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size
+    if (lane == 0) s_seg[64] = ni;
+    const int nblk = ni >> 4;
     __syncthreads();
+
+    // class of a position (segments are contiguous): number of segment ENDS at or below it
+    auto class_of_pos = [&](int p) -> int {
+        int d = 0;
+        for (int e = 1; e <= Cn; ++e) d += (p >= s_seg[e]) ? 1 : 0;
+        return d < Cn ? d : Cn - 1;
+    };
 
     // (feasible, LeastAllocated + BalancedAllocation) of one signature on one node: 0 when NodeResourcesFit fails
     // (fit.go:230-302), else 1 + score.  Same fp64 sequences as simon_fast.hip::eval_slot / simon_cache.hip.
@@ -144,35 +194,38 @@ __global__ __launch_bounds__(64) void table_kernel(
         return ok ? (unsigned)(base + 1) : 0u;
     };
 
-    // ---- prologue 2: node rows, table and summary; lanes = 64 consecutive nodes (4 blocks) --------
+    // ---- prologue 2: node rows, table and summary; lanes = 64 consecutive positions (4 blocks) ----
     for (int p0 = 0; p0 < ni; p0 += 64) {
         const int p = p0 + lane;
-        const bool real = p < n;
-        const int j = real ? p : 0;
-        const unsigned nd = real ? (unsigned)s_node[p] : 0u;
-        const uint4 st = real ? make_uint4(i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j]), 0u) : make_uint4(0, 0, 0, 0);
+        const int d = class_of_pos(p < ni ? p : 0);
+        const int r = p - s_seg[d];
+        const bool real = p < ni && r < __shfl(cnt_d, d, 64);
+        const int j = real ? cls_list[cls_off[d] + r] : 0;            // r-th node of class d in canonical order
+        const unsigned shid = real ? (unsigned)shape_of[j] : 0u;
+        const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
         if (p < ni) {
             g_state[p] = st;
             if (!NZEQ) g_nz[p] = z;
+            s_shid[p] = (unsigned char)shid;
         }
-        const ShapeRow sh = s_shape[nd & 0xFFu];
-        unsigned short* tp = g_tile + ((size_t)(p >> 4) * K) * 16 + (p & 15);
+        const ShapeRow sh = s_shape[shid];
+        unsigned char* tp = g_tile + ((unsigned)(p >> 4) * Krow + (unsigned)(p & 15));
         for (int k = 0; k < K; ++k) {
             const SigRow q = sigs[k];
-            unsigned b = eval_node(q.req_c, q.req_m, q.nz_c, q.nz_m, q.flags & 1u, (double)st.x, (double)st.y, (double)z.x,
-                                   (double)z.y, (int)st.z, sh);
+            unsigned b = eval_node(q.req_c, q.req_m, q.nz_c, q.nz_m, q.flags & 1u, (double)st.rq_c, (double)st.rq_m, (double)z.x,
+                                   (double)z.y, (int)st.freep, sh);
             b = real ? b : 0u;
             if (HAS_MASK) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node)
                 const uint64_t w = static_mask[(size_t)q.cls * sc.mask_words + (j >> 6)];
                 b = ((w >> (j & 63)) & 1ull) ? b : 0u;
             }
-            const unsigned e = b ? ((b << 4) | (unsigned)(15 - (p & 15))) : 0u;   // class term still 0: every signature starts dirty
-            if (p < ni) tp[k * 16] = (unsigned short)e;
-            const unsigned m16 = row16_max_t(e);
+            if (p < ni) tp[k * 16] = (unsigned char)b;
+            // class term still 0: every signature starts dirty and is re-based at its first use
+            const unsigned m16 = row16_max_t(b ? ((b << 4) | (unsigned)(15 - (p & 15))) : 0u);
             if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
-            if (b) atomicAdd(&s_cnt[k * Cn + (int)(nd >> 8)], 1);
+            if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,7 +236,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     bool kvalid[KQ];
     double my_req_c[KQ], my_req_m[KQ], my_nz_c[KQ], my_nz_m[KQ];
     bool my_zero[KQ];
-    unsigned my_add_c[KQ], my_add_m[KQ], my_addz_c[KQ], my_addz_m[KQ];
+    unsigned my_add_c[KQ], my_add_m[KQ], my_addz_c[KQ], my_addz_m[KQ], koff[KQ];
     unsigned my_dirty = 0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
@@ -194,17 +247,34 @@ __global__ __launch_bounds__(64) void table_kernel(
         my_zero[q] = r.flags & 1u;
         my_add_c[q] = (unsigned)r.req_c; my_add_m[q] = (unsigned)r.req_m;
         my_addz_c[q] = (unsigned)r.nz_c; my_addz_m[q] = (unsigned)r.nz_m;
+        koff[q] = (unsigned)kk[q] * 16u;
         if (kvalid[q]) my_dirty |= 1u << q;
     }
-    // per-lane constant of the arg-max key: lane handles blocks lane, lane + 64, ... ; key low field = 4095 - position
-    int cb[4];
+    // this lane's blocks (lane, lane + 64, ...): constant of the arg-max key (low field = 4095 - position), node class, and
+    // offset of the block's class segment into the static per-class node lists (index of position p = boff + p; packed with
+    // the class: one readlane fetches both for the winning block)
+    int cb[NBQ], bcls[NBQ], binfo[NBQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cb[q] = 4080 - 16 * (q * 64 + lane);
-    unsigned koff[KQ];
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) koff[q] = (unsigned)kk[q] * 32u;
+    for (int q = 0; q < NBQ; ++q) {
+        const int b = q * 64 + lane;
+        cb[q] = (255 - b) << 4;                                           // 4095 - position = (255 - b) << 4 | 15 - pos
+        bcls[q] = class_of_pos(b < nblk ? b * 16 : 0);
+        binfo[q] = (cls_off[bcls[q]] - s_seg[bcls[q]] + 8192) | (bcls[q] << 16);
+    }
 
-    // Re-base row k after the set of node classes with a feasible node changed: SimonPlugin / GpuSharePlugin
+    // (offset into cls_list + 8192) | class << 16 of block bw: both candidate lanes are read, a scalar select picks (no branch)
+    auto winner_info = [&](int bw) -> int {
+        const int l = bw & 63, h = bw >> 6;
+        int info = __builtin_amdgcn_readlane(binfo[0], l);
+        if (NBQ > 1) { const int i1 = __builtin_amdgcn_readlane(binfo[NBQ > 1 ? 1 : 0], l); info = h == 1 ? i1 : info; }
+        if (NBQ > 2) {
+            const int i2 = __builtin_amdgcn_readlane(binfo[NBQ > 2 ? 2 : 0], l), i3 = __builtin_amdgcn_readlane(binfo[NBQ > 3 ? 3 : 0], l);
+            info = h == 2 ? i2 : h == 3 ? i3 : info;
+        }
+        return info;
+    };
+
+    // Re-base summary row k after the set of node classes with a feasible node changed: SimonPlugin / GpuSharePlugin
     // NormalizeScore (pkg/simulator/plugin/simon.go:76-101) over the classes present, x 2 (both plugins, weight 1 each).
     auto renormalise = [&](int k, int c) {
         const int dd = lane < Cn ? lane : 0;
@@ -213,28 +283,23 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int rawc = s_raw[c * Cn + dd];
         const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
         const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
-        const bool any = hi >= lo;
-        const int range = any ? hi - lo : 0;
+        const int range = hi >= lo ? hi - lo : 0;
         const double rr = range ? 1.0 / (double)range : 0.0;
         const int sn = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
         if (lane < Cn) {
-            s_tmp[dd] = sn - (int)s_sn[k * Cn + dd];
+            s_tmp[dd] = (sn - (int)s_sn[k * Cn + dd]) * 16;
             s_sn[k * Cn + dd] = (unsigned short)sn;
         }
         __syncthreads();
-        for (int p0 = 0; p0 < ni; p0 += 64) {
-            const int p = p0 + lane;
-            const bool in = p < ni;
-            unsigned short* ep = g_tile + ((size_t)((in ? p : 0) >> 4) * K + k) * 16 + (p & 15);
-            unsigned e = in ? (unsigned)*ep : 0u;
-            if (e) {
-                e = (unsigned)((int)e + s_tmp[s_node[p] >> 8] * 16);
-                *ep = (unsigned short)e;
+        unsigned short* srow = s_sum + k * nbp;
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            const int b = q * 64 + lane;
+            if (b < nblk) {
+                const unsigned m = srow[b];
+                if (m) srow[b] = (unsigned short)((int)m + s_tmp[bcls[q]]);
             }
-            const unsigned m16 = row16_max_t(e);
-            if ((lane & 15) == 0 && in) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
 
@@ -257,18 +322,29 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int r_sig = __builtin_amdgcn_readlane(cur.x, il), r_preset = __builtin_amdgcn_readlane(cur.y, il);
         const int r_gate = __builtin_amdgcn_readlane(cur.z, il), r_cls = __builtin_amdgcn_readlane(cur.w, il);
 
-        int res, pstar = -1;
+        // res: what the placement row records for this step: >= 0 an index into cls_list (turned into the canonical node index
+        // 64 steps at a time, off the critical path), -1 unschedulable, -2 not part of the scenario
+        int res, pstar = -1, dstar = 0;
         if (r_gate >= n) {
             res = -2;                                                  // pod not part of this scenario
         } else if (r_preset >= 0) {                                    // addPodToCache path (V/eventhandlers.go:223-236)
-            res = r_preset;
-            pstar = r_preset;
+            const TableCold* cc = cold;
+            asm volatile("" : "+s"(cc));                               // rare path: fetch its pointers here, not in loop-long SGPRs
+            dstar = __builtin_amdgcn_readfirstlane(cc->ncls[r_preset]);
+            const int rk = __builtin_amdgcn_readfirstlane(cc->rank[r_preset]);
+            pstar = __builtin_amdgcn_readfirstlane(s_seg[dstar]) + rk;
+            res = __builtin_amdgcn_readfirstlane(cc->cls_off[dstar]) + rk;
         } else if (HAS_PIN && r_preset <= -2) {                        // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
-            const int pin = -2 - r_preset;                             // its node affinity admits ONE node; the table entry of
+            const int pin = -2 - r_preset;                             // its node affinity admits ONE node; the table byte of
             res = -1;                                                  // (signature, node) holds static filters + fit
             if (pin < n) {
-                const unsigned short e = g_tile[((size_t)(pin >> 4) * K + r_sig) * 16 + (pin & 15)];
-                if (e != 0) { res = pin; pstar = pin; }
+                const TableCold* cc = cold;
+                asm volatile("" : "+s"(cc));
+                const int dp = __builtin_amdgcn_readfirstlane(cc->ncls[pin]);
+                const int rk = __builtin_amdgcn_readfirstlane(cc->rank[pin]);
+                const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
+                const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
+                if (byte != 0) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
             }
             if (res < 0) ++unsched;
         } else {
@@ -278,57 +354,83 @@ __global__ __launch_bounds__(64) void table_kernel(
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
-            // -------- summary scan: one pre-keyed u16 per block of 16 nodes ---------------------------
+            // -------- summary scan: one u16 per block of 16 nodes ------------------------------------
             const unsigned short* srow = s_sum + k * nbp;
-            unsigned key = 0;
+            unsigned key = 0, m16q[NBQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q == 0 || nblk > 64 * q) {
-                    const int b = q * 64 + lane;
-                    const bool in = b < nblk;
-                    const unsigned m16 = srow[in ? b : 0];
-                    // (total + 1) << 12 | (4095 - position), position = 16 b + 15 - (m16 & 15)
-                    const unsigned kq = ((m16 >> 4) << 12) + (m16 & 15u) + (unsigned)cb[q];
-                    key = max(key, (m16 != 0u && in) ? kq : 0u);
-                }
+            for (int q = 0; q < NBQ; ++q) {
+                const int b = q * 64 + lane;
+                // a lane beyond the last block re-reads block 0: the duplicate ties on the total and loses on the position
+                m16q[q] = srow[b < nblk ? b : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                // (total + 1) << 12 | (255 - b) << 4 | 15 - pos  ==  (total + 1) << 12 | 4095 - position; an entry of 0 (no feasible
+                // node in the block) stays below 4096
+                const unsigned m16 = m16q[q];
+                key = max(key, (((m16 << 8) & 0xFFF000u) | (unsigned)cb[q]) | (m16 & 15u));
             }
             key = wave_max_u32(key);
-            if (key == 0u) {                                           // FitError: pod deleted, state unchanged
+            if (key < 4096u) {                                         // FitError: pod deleted, state unchanged
                 ++unsched;
                 res = -1;
             } else {
-                pstar = 4095 - (int)(key & 4095u);                     // first maximum in canonical order
-                res = pstar;
+                pstar = 4095 - (int)(key & 4095u);                     // first maximum in POSITION order
+                const unsigned top = key >> 12;
+                int bw = pstar >> 4;
+                int info = winner_info(bw);
+                dstar = info >> 16;
+                // Position order is canonical order inside a class only: do blocks of ANOTHER class reach the same total?
+                bool other = false;
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> 4) == top && bcls[q] != dstar);   // duplicates carry block 0's class
+                if (__ballot(other)) {                                 // rare: first maximum in CANONICAL order among the tied blocks
+                    unsigned key2 = 0;
+                    int canon[NBQ];
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) {
+                        const int pq = (q * 64 + lane) * 16 + 15 - (int)(m16q[q] & 15u);
+                        const bool tied = (m16q[q] >> 4) == top && q * 64 + lane < nblk;
+                        canon[q] = tied ? cls_list[(binfo[q] & 0xFFFF) - 8192 + pq] : 4095;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) {
+                        const int pq = (q * 64 + lane) * 16 + 15 - (int)(m16q[q] & 15u);
+                        if ((m16q[q] >> 4) == top && q * 64 + lane < nblk) key2 = max(key2, ((4095u - (unsigned)canon[q]) << 12) | (unsigned)pq);
+                    }
+                    key2 = wave_max_u32(key2);
+                    pstar = (int)(key2 & 4095u);
+                    bw = pstar >> 4;
+                    info = winner_info(bw);
+                    dstar = info >> 16;
+                }
+                res = (info & 0xFFFF) - 8192 + pstar;                  // index into cls_list
             }
         }
         // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column + summary ----
         if (pstar >= 0) {
             const int blk = pstar >> 4, pos = pstar & 15;
-            const int dwi = pos >> 1, sh16 = (pos & 1) * 16;
-            uint4 st = g_state[pstar];
-            // row of (signature kk[q], touched block): uniform block base + this lane's constant byte offset (saddr + voffset)
-            const unsigned char* const blk_base = (const unsigned char*)g_tile + (size_t)blk * (size_t)(K * 32);
-            const uint4* rowp[KQ];
-            uint4 A[KQ], B[KQ];
+            const int dwi = pos >> 2, sh8 = (pos & 3) * 8;
+            NodeState st = g_state[pstar];
+            // row of (signature kk[q], touched block): uniform table base + 32-bit byte offset
+            unsigned char* rowp[KQ];
+            uint4 T[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
-                rowp[q] = (const uint4*)(blk_base + koff[q]);
-                A[q] = rowp[q][0];
-                B[q] = rowp[q][1];
+                rowp[q] = g_tile + ((unsigned)blk * Krow + koff[q]);
+                T[q] = *(const uint4*)rowp[q];
             }
             uint2 z = make_uint2(0, 0);
             if (!NZEQ) z = g_nz[pstar];
-            const unsigned nd = s_node[pstar];
-            const int dcls = (int)(nd >> 8);
-            const ShapeRow sh = s_shape[nd & 0xFFu];
+            const ShapeRow sh = s_shape[s_shid[pstar]];
             unsigned snq[KQ];
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) snq[q] = s_sn[kk[q] * Cn + dcls];
+            for (int q = 0; q < KQ; ++q) snq[q] = s_sn[kk[q] * Cn + dstar];
             const int sl = r_sig & 63;
             const bool hiq = KQ > 1 && (r_sig >> 6);
-            st.x += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_c[0], sl));
-            st.y += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_m[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_m[0], sl));
-            st.z -= 1u;
+            st.rq_c += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_c[0], sl));
+            st.rq_m += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_m[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_m[0], sl));
+            st.freep -= 1u;
             double nzc = 0.0, nzm = 0.0;
             if (!NZEQ) {
                 z.x += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_addz_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_addz_c[0], sl));
@@ -337,26 +439,28 @@ __global__ __launch_bounds__(64) void table_kernel(
                 nzc = (double)z.x; nzm = (double)z.y;
             }
             if (lane == 0) g_state[pstar] = st;
-            const double rq_c = (double)st.x, rq_m = (double)st.y;
+            const double rq_c = (double)st.rq_c, rq_m = (double)st.rq_m;
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const unsigned nb_raw = eval_node(my_req_c[q], my_req_m[q], my_nz_c[q], my_nz_m[q], my_zero[q], rq_c, rq_m, nzc, nzm,
-                                                  (int)st.z, sh);
-                u32x8 T = {A[q].x, A[q].y, A[q].z, A[q].w, B[q].x, B[q].y, B[q].z, B[q].w};
-                const unsigned wsel = T[dwi];
-                const unsigned old16 = (wsel >> sh16) & 0xFFFFu;          // this signature's entry before the cycle
-                const unsigned nb = old16 ? nb_raw : 0u;                  // static mask / monotone infeasibility
-                const unsigned new16 = nb ? (((nb + snq[q]) << 4) | (unsigned)(15 - pos)) : 0u;
+                                                  (int)st.freep, sh);
+                uint4 R = T[q];
+                const unsigned wsel = dwi == 0 ? R.x : dwi == 1 ? R.y : dwi == 2 ? R.z : R.w;
+                const unsigned old = (wsel >> sh8) & 0xFFu;               // this signature's byte before the cycle
+                const unsigned nb = old ? nb_raw : 0u;                    // static mask / monotone infeasibility
                 // One wave: its vector memory accesses are served in order, so the next cycle's loads of this row / state
                 // observe these stores; no cache maintenance, no wait.
-                if (kvalid[q] && new16 != old16) {
-                    ((unsigned short*)rowp[q])[pos] = (unsigned short)new16;
-                    T[dwi] = (wsel & ~(0xFFFFu << sh16)) | (new16 << sh16);
-                    unsigned m = pkmax_t(pkmax_t(pkmax_t(T[0], T[1]), pkmax_t(T[2], T[3])), pkmax_t(pkmax_t(T[4], T[5]), pkmax_t(T[6], T[7])));
-                    m = max(m & 0xFFFFu, m >> 16);
-                    s_sum[kk[q] * nbp + blk] = (unsigned short)m;
+                if (kvalid[q] && nb != old) {
+                    const unsigned wnew = (wsel & ~(0xFFu << sh8)) | (nb << sh8);
+                    R.x = dwi == 0 ? wnew : R.x;
+                    R.y = dwi == 1 ? wnew : R.y;
+                    R.z = dwi == 2 ? wnew : R.z;
+                    R.w = dwi == 3 ? wnew : R.w;
+                    rowp[q][pos] = (unsigned char)nb;
+                    const unsigned m = block_key16_t(R);
+                    s_sum[kk[q] * nbp + blk] = (unsigned short)((m >> 4) ? m + (snq[q] << 4) : 0u);
                     if (!nb) {                                            // the node stopped being feasible for this signature
-                        const int cidx = kk[q] * Cn + dcls;
+                        const int cidx = kk[q] * Cn + dstar;
                         const int left = s_cnt[cidx] - 1;
                         s_cnt[cidx] = left;
                         if (left == 0) my_dirty |= 1u << q;               // the class term of row k changes: re-base before its next use
@@ -367,31 +471,35 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
         plreg = (il == lane) ? res : plreg;
-        if (place && il == 63) place[(i & ~63) + lane] = plreg;
+        if (place && il == 63) place[(i & ~63) + lane] = plreg >= 0 ? cls_list[plreg] : plreg;   // 64 canonical indices per gather
     }
-    if (place && (P & 63) && lane < (P & 63)) place[(P & ~63) + lane] = plreg;
+    if (place && (P & 63) && lane < (P & 63)) place[(P & ~63) + lane] = plreg >= 0 ? cls_list[plreg] : plreg;
 
-    // ---- epilogue: sum of Requested over the scenario's nodes -------------------------------
+    // ---- epilogue: sum of Requested over the scenario's nodes (padding rows hold 0) -----------
     long long uc = 0, um = 0;
-    for (int p = lane; p < n; p += 64) { const uint4 st = g_state[p]; uc += st.x; um += st.y; }
+    for (int p = lane; p < ni; p += 64) { const NodeState st = g_state[p]; uc += st.rq_c; um += st.rq_m; }
     uc = wave_sum_i64(uc);
     um = wave_sum_i64(um);
     if (lane == 0) {
-        unscheduled[s] = unsched;
-        used_cpu[s] = uc * (long long)sc.g_cpu;
-        used_mem[s] = um * (long long)sc.g_mem;
+        cold->unscheduled[s] = unsched;
+        cold->used_cpu[s] = uc * (long long)sc.g_cpu;
+        cold->used_mem[s] = um * (long long)sc.g_mem;
     }
 }
 
-template <bool M, bool Z, bool PIN, int KQ>
-static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = table_kernel<M, Z, PIN, KQ>;
+template <bool M, bool Z, bool PIN, int KQ, int NBQ>
+static hipError_t launch_t5(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.ncls, a.shape_of, a.a_pods, a.i_rq_cpu, a.i_rq_mem,
-                       a.i_nz_cpu, a.i_nz_mem, a.i_npods, a.sigs, a.shapes, a.pods, a.orders, a.scen, a.perm,
-                       a.static_mask, a.simon_raw, a.unscheduled, a.used_cpu, a.used_mem, a.place_step, a.ws, a.sc);
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.place_step, a.ws, a.sc);
     return hipGetLastError();
+}
+template <bool M, bool Z, bool PIN, int KQ>
+static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    const int nblk = a.sc.ni_max / 16;
+    return nblk <= 64 ? launch_t5<M, Z, PIN, KQ, 1>(a, n_blocks, lds, st)
+           : nblk <= 128 ? launch_t5<M, Z, PIN, KQ, 2>(a, n_blocks, lds, st) : launch_t5<M, Z, PIN, KQ, 4>(a, n_blocks, lds, st);
 }
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
