@@ -11,7 +11,6 @@
 #include "../../include/simon_hip.h"
 #include "simon_device.h"
 #include "simon_wide.h"
-#include "simon_cache.h"
 #include "simon_table.h"
 
 #include <algorithm>
@@ -90,21 +89,19 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<PodRowN> d_podsN;
     DevBuf<PodRowF> d_podsF;
     bool fast_ok = false, nzeq = false;  // simon_fast.hip eligibility
-    // ---- simon_cache.hip (LDS score table, one wave per scenario) ----
-    bool cache_ok = false, cache_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE
-    bool table_ok = false, no_table = false;   // simon_table.hip (generation 4); no_table: env SIMON_TABLE=0 (A/B against generation 3)
-    int ablate = 0;
+    // ---- simon_table.hip (score table, one wave per scenario) ----
+    bool table_ok = false, table_perm_ok = false, no_cache = false;  // no_cache: env SIMON_NO_CACHE (run generation 2 instead)
     DevBuf<unsigned char> d_ws, d_table_cold;
-    int n_sigs = 0, n_shapes = 0, max_bands = 4;
+    DevBuf<unsigned long long> d_table_prof, d_ws_off;
+    int n_sigs = 0, Cn_t = 0;                    // request signatures; internal node classes = distinct (node_class, allocatable) pairs
     DevBuf<SigRow> d_sigs;
-    DevBuf<ShapeRow> d_shapes;
+    DevBuf<ShapeRow> d_shapes;                   // [Cn_t]: capacity + reciprocals of an internal class
     DevBuf<PodRowC> d_podsC;
-    DevBuf<int32_t> d_rank, d_shape_of, d_clsprefix, d_inv_orders, d_place_step, d_cls_list, d_cls_off;
-    std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn]; padded size of every loaded scenario
+    DevBuf<int32_t> d_t_ncls, d_rank, d_clsprefix, d_inv_orders, d_place_step, d_cls_list, d_cls_off, d_t_raw;
+    std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn_t]; padded (class-major) size of every loaded scenario
+    size_t ws_total = 0;
     std::vector<int32_t> h_perm;
     std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
-    hipStream_t band_stream[8] = {};
-    hipEvent_t band_ev[8] = {}, fork_ev = nullptr;
     DevBuf<uint64_t> d_mask;
     DevBuf<int64_t> d_prefix_cpu, d_prefix_mem, d_prefix_vg;
     DevBuf<int32_t> d_node_rank, d_node_inv;      // [S][N] per-scenario nodeTree ranks (simon_set_node_ranks)
@@ -125,6 +122,15 @@ struct simon_ctx : simon::HostInputs {
 };
 
 namespace {
+
+bool getenv_once_table_prof() {   // SIMON_TABLE_PROF: phase profile of simon_table.hip (acts only in -DSIMON_TABLE_PROFILE builds)
+#ifdef SIMON_TABLE_PROFILE
+    static const bool on = getenv("SIMON_TABLE_PROF") != nullptr;
+    return on;
+#else
+    return false;
+#endif
+}
 
 int fail(simon_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -234,11 +240,10 @@ int stage_narrow(simon_ctx* c) {
         rowsF[p] = PodRowF{(double)r.req_cpu, (double)r.req_mem, (double)r.nz_cpu, (double)r.nz_mem, r.cls, r.preset, r.gate, r.flags};
         if (r.req_cpu != r.nz_cpu || r.req_mem != r.nz_mem) c->nzeq = false;
     }
-    // simon_table.hip / simon_cache.hip: intern pod request signatures and node shapes
+    // simon_table.hip: intern pod request signatures and internal node classes
     bool nozero = true;
     for (int j = 0; j < N; ++j) if (a_cpu[j] == 0 || a_mem[j] == 0) nozero = false;
-    c->table_ok = nozero && c->Cn <= kTableMaxClasses && N <= kTableMaxNodes;
-    c->cache_ok = false;
+    c->table_ok = nozero && N <= kTableMaxNodes;
     if (c->table_ok) {
         std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t>, int> sig_id;
         std::vector<SigRow> sigs;
@@ -256,47 +261,54 @@ int stage_narrow(simon_ctx* c) {
             }
             rowsC[p] = PodRowC{it->second, (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, r.cls};
         }
-        std::map<std::pair<uint32_t, uint32_t>, int> shape_id;
+        // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
+        // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
+        // does not keeps the kernel's "shape follows from class" exact for any input.
+        std::map<std::tuple<int32_t, uint32_t, uint32_t>, int> cls_id;
         std::vector<ShapeRow> shapes;
-        std::vector<int32_t> shape_of(N);
+        std::vector<int32_t> orig_of, ncls_t(N);
         for (int j = 0; j < N && c->table_ok; ++j) {
-            auto key = std::make_pair(a_cpu[j], a_mem[j]);
-            auto it = shape_id.find(key);
-            if (it == shape_id.end()) {
-                if ((int)shapes.size() == kTableMaxShapes) { c->table_ok = false; break; }
-                it = shape_id.emplace(key, (int)shapes.size()).first;
+            auto key = std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j]);
+            auto it = cls_id.find(key);
+            if (it == cls_id.end()) {
+                if ((int)shapes.size() == kTableMaxClasses) { c->table_ok = false; break; }
+                it = cls_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};
                 sh.cap_c = (double)a_cpu[j]; sh.cap_m = (double)a_mem[j];
                 sh.rc_c = 1.0 / sh.cap_c; sh.rc_m = 1.0 / sh.cap_m;           // IEEE, as the device's correctly rounded '/'
                 sh.rc100_c = 100.0 * sh.rc_c; sh.rc100_m = 100.0 * sh.rc_m;
                 shapes.push_back(sh);
+                orig_of.push_back(c->node_class[j]);
             }
-            shape_of[j] = it->second;
+            ncls_t[j] = it->second;
         }
         if (c->table_ok) {
-            c->n_sigs = (int)sigs.size(); c->n_shapes = (int)shapes.size();
+            const int Ct = (int)shapes.size();
+            c->n_sigs = (int)sigs.size(); c->Cn_t = Ct;
             if (sigs.empty()) sigs.push_back(SigRow{});
+            std::vector<int32_t> raw_t((size_t)c->Cp * Ct);
+            for (int cp = 0; cp < c->Cp; ++cp)
+                for (int d = 0; d < Ct; ++d) raw_t[(size_t)cp * Ct + d] = raw32[(size_t)cp * c->Cn + orig_of[d]];
+            // class-major layout: rank of a node among its class, per-class node lists in canonical order, class counts of
+            // every prefix of the pool (a scenario = a prefix)
+            std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * Ct, 0), cls_off(Ct + 1, 0), cls_list(N);
+            for (int j = 0; j < N; ++j) {
+                const int d = ncls_t[j];
+                rank[j] = prefix[(size_t)j * Ct + d];
+                for (int e = 0; e < Ct; ++e) prefix[(size_t)(j + 1) * Ct + e] = prefix[(size_t)j * Ct + e] + (e == d);
+            }
+            for (int d = 0; d < Ct; ++d) cls_off[d + 1] = cls_off[d] + prefix[(size_t)N * Ct + d];
+            for (int j = 0; j < N; ++j) cls_list[cls_off[ncls_t[j]] + rank[j]] = j;
+            c->h_clsprefix = prefix;
             HIP_TRY(c, c->d_sigs.upload(sigs, st));
             HIP_TRY(c, c->d_shapes.upload(shapes, st));
             HIP_TRY(c, c->d_podsC.upload(rowsC, st));
-            HIP_TRY(c, c->d_shape_of.upload(shape_of, st));
-            // class-major layout: rank of a node among its class, per-class node lists in canonical order, class counts of
-            // every prefix of the pool (a scenario = a prefix)
-            std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * c->Cn, 0), cls_off(c->Cn + 1, 0), cls_list(N);
-            for (int j = 0; j < N; ++j) {
-                const int d = c->node_class[j];
-                rank[j] = prefix[(size_t)j * c->Cn + d];
-                for (int e = 0; e < c->Cn; ++e) prefix[(size_t)(j + 1) * c->Cn + e] = prefix[(size_t)j * c->Cn + e] + (e == d);
-            }
-            for (int d = 0; d < c->Cn; ++d) cls_off[d + 1] = cls_off[d] + prefix[(size_t)N * c->Cn + d];
-            for (int j = 0; j < N; ++j) cls_list[cls_off[c->node_class[j]] + rank[j]] = j;
-            c->h_clsprefix = prefix;
+            HIP_TRY(c, c->d_t_ncls.upload(ncls_t, st));
+            HIP_TRY(c, c->d_t_raw.upload(raw_t, st));
             HIP_TRY(c, c->d_rank.upload(rank, st));
             HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
             HIP_TRY(c, c->d_cls_list.upload(cls_list, st));
             HIP_TRY(c, c->d_cls_off.upload(cls_off, st));
-            // generation 3 (simon_cache.hip): <= 64 signatures, <= 2047 nodes, <= 32 node classes
-            c->cache_ok = c->fast_ok && N <= kCacheMaxNodes && c->n_sigs <= kCacheMaxSigs;
             HIP_TRY(c, hipStreamSynchronize(st));
         }
     }
@@ -410,20 +422,12 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
-    if (const char* e = getenv("SIMON_CACHE_ABLATE")) c->ablate = atoi(e);
-    if (const char* e = getenv("SIMON_CACHE_BANDS")) c->max_bands = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
-    if (const char* e = getenv("SIMON_TABLE")) c->no_table = e[0] == '0';
     if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
     c->wide.knobs.prof = getenv("SIMON_WIDE_PROF") != nullptr;
     if (const char* e = getenv("SIMON_STATE_BUDGET_MB")) c->wide.knobs.state_budget = (size_t)atoll(e) << 20;
-    bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 8 && ok; ++i)
-        ok = hipStreamCreateWithFlags(&c->band_stream[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&c->band_ev[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { simon_ctx_destroy(c); return nullptr; }
     return c;
 }
 
@@ -433,11 +437,6 @@ void simon_ctx_destroy(simon_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
-    for (int i = 0; i < 8; ++i) {
-        if (c->band_stream[i]) { (void)hipStreamSynchronize(c->band_stream[i]); (void)hipStreamDestroy(c->band_stream[i]); }
-        if (c->band_ev[i]) (void)hipEventDestroy(c->band_ev[i]);
-    }
     c->wide.release();
     // DevBuf destructors free device memory
     hipStream_t st = c->stream;
@@ -679,8 +678,8 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
     c->h_perm = perm;
     c->scen_ni.assign(S, 0);
     c->h_orders.assign(orders, orders + (size_t)n_orders * P);
-    c->cache_perm_ok = false;
-    if (c->variant == SIMON_KERNEL_NARROW && (c->cache_ok || c->table_ok)) {
+    c->table_perm_ok = false;
+    if (c->variant == SIMON_KERNEL_NARROW && c->table_ok) {
         // placements are recorded by scheduling step and gathered back to pod ids through the inverse orders,
         // which exist only when every order is a permutation of [0, P)
         std::vector<int32_t> inv((size_t)n_orders * P, -1);
@@ -691,16 +690,22 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
                 if (slot >= 0) { is_perm = false; break; }
                 slot = i;
             }
+        // padded class-major size of every scenario; workspace slice of every workgroup (launch order = perm)
+        const int Ct = c->Cn_t;
+        for (int s = 0; s < S; ++s) {
+            int ni = 0;
+            for (int d = 0; d < Ct; ++d) ni += (c->h_clsprefix[(size_t)scen[s].n_nodes * Ct + d] + 15) & ~15;
+            c->scen_ni[s] = std::max(ni, 16);
+        }
         if (is_perm) {
+            std::vector<unsigned long long> ws_off(S);
+            size_t off = 0;
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq); }
+            c->ws_total = off;
+            HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            c->cache_perm_ok = true;
-        }
-        c->scen_ni.assign(S, 0);
-        for (int s = 0; s < S && c->table_ok; ++s) {
-            int ni = 0;
-            for (int d = 0; d < c->Cn; ++d) ni += (c->h_clsprefix[(size_t)scen[s].n_nodes * c->Cn + d] + 15) & ~15;
-            c->scen_ni[s] = ni;
+            c->table_perm_ok = true;
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -758,126 +763,55 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         const bool too_big = slots > 8;   // pool too large for register residency even at T = 1024: the all-feature kernel takes it
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
-        bool use_cache = c->cache_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kCacheMaxNodes;
-        const size_t lds_pad = c->lds_pad;
-        auto lds_of = [&](int ni) { return cache_lds_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad; };
-        auto ws_of = [&](int ni) { return cache_ws_bytes(c->n_sigs, std::max(ni, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq); };
-        if (use_cache) {
-            int ni_top = 0;
-            for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
-            use_cache = ni_top <= kCacheMaxPadded && lds_of(ni_top) <= kLdsPerCU;
-        }
-        // generation 4 (simon_table.hip) takes every batch generation 3 takes, and more signatures / nodes / classes
-        int ni_top = 0;
+        // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
+        int ni_top = 16;
         for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
-        bool use_table = c->table_ok && c->cache_perm_ok && !c->no_cache && !c->force_v1 && !c->no_table && c->max_n <= kTableMaxNodes &&
-                         ni_top <= kTableMaxPadded &&
-                         table_lds_bytes(c->n_sigs, std::max(ni_top, 16), c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad <= 64 * 1024;
-        if (use_table) use_cache = false;
-        // pinned pods (pin_node) are known to the score-table kernels and the all-feature kernel only
-        if ((c->has_pin || too_big) && !use_cache && !use_table) run_wide = true;
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t) + c->lds_pad : 0;
+        const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kTableMaxNodes &&
+                               ni_top <= kTableMaxPadded && table_lds <= 64 * 1024;
+        // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
+        if ((c->has_pin || too_big) && !use_table) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
         } else if (use_table) {
-            // Bands as for generation 3 (below): scenarios in LPT order cut into launches of equal scenario count, each with the
-            // LDS summary and HBM workspace of its own largest scenario, on its own stream.
-            struct Band { int start, count, ni_max; size_t lds, ws_off; };
-            std::vector<Band> bands;
-            const int nb = std::max(1, std::min(c->max_bands, S));
-            size_t ws_total = 0;
-            for (int bi = 0; bi < nb; ++bi) {
-                const int b = (int)((long long)S * bi / nb), e = (int)((long long)S * (bi + 1) / nb);
-                if (e <= b) continue;
-                int ni0 = 16;                                  // padded sizes are not monotone in n: the band's own maximum
-                for (int i2 = b; i2 < e; ++i2) ni0 = std::max(ni0, c->scen_ni[c->h_perm[i2]]);
-                bands.push_back(Band{b, e - b, ni0, table_lds_bytes(c->n_sigs, ni0, c->Cn, c->Cp, c->n_shapes, c->nzeq) + lds_pad, ws_total});
-                ws_total += table_ws_bytes(c->n_sigs, ni0, c->Cn, c->Cp, c->n_shapes, c->nzeq) * (size_t)(e - b);
-            }
-            HIP_TRY(c, c->d_ws.ensure(ws_total));
+            HIP_TRY(c, c->d_ws.ensure(c->ws_total));
             if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
             TableCold cold{};
-            cold.ncls = c->d_ncls.p; cold.rank = c->d_rank.p; cold.shape_of = c->d_shape_of.p; cold.cls_off = c->d_cls_off.p;
+            cold.ncls = c->d_t_ncls.p; cold.rank = c->d_rank.p; cold.cls_off = c->d_cls_off.p;
             cold.clsprefix = c->d_clsprefix.p; cold.a_pods = c->d_a_pods.p;
             cold.i_rq_cpu = c->d_i_rq_cpu.p; cold.i_rq_mem = c->d_i_rq_mem.p; cold.i_nz_cpu = c->d_i_nz_cpu.p; cold.i_nz_mem = c->d_i_nz_mem.p;
             cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
-            cold.static_mask = c->has_mask ? c->d_mask.p : nullptr; cold.simon_raw = c->d_raw32.p;
+            cold.static_mask = c->has_mask ? c->d_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
+            const bool tprof = getenv_once_table_prof();
+            if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 8)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 64, c->stream)); cold.prof = c->d_table_prof.p; }
             HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
             HIP_TRY(c, hipMemcpyAsync(c->d_table_cold.p, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));             // `cold` is a stack object
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
-            f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p;
+            f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
-            for (size_t bi = 0; bi < bands.size(); ++bi) {
-                const Band& bd = bands[bi];
-                hipStream_t bs = bands.size() == 1 ? c->stream : c->band_stream[bi];
-                if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
-                f.perm = c->d_perm.p + bd.start;
-                f.ws = c->d_ws.p + bd.ws_off;
-                f.sc = TableScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max, c->g_cpu, c->g_mem};
-                HIP_TRY(c, launch_table(f, bd.count, c->has_mask, c->nzeq, c->has_pin, bd.lds, bs));
-                if (bs != c->stream) {
-                    HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
-                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev[bi], 0));
-                }
-            }
+            HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)
                 HIP_TRY(c, launch_unpermute(c->d_place_step.p, c->d_inv_orders.p, c->d_scen.p, S, P, c->d_place.p, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            if (tprof) {     // phase profile: mean ticks per scheduling cycle over the batch (profile builds only)
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                std::vector<unsigned long long> hp((size_t)S * 8);
+                HIP_TRY(c, hipMemcpy(hp.data(), c->d_table_prof.p, hp.size() * 8, hipMemcpyDeviceToHost));
+                double acc[8] = {0};
+                for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 8; ++q) acc[q] += (double)hp[(size_t)s2 * 8 + q];
+                fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | eval+patch+store %.0f\n",
+                        S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[6] / S / P);
+            }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
-            T = 64; slots = (ni_top / 16 + 63) / 64; lds = bands[0].lds;
-            c->stats.n_launches = (int)bands.size();
+            T = 64; slots = (ni_top / 16 + 63) / 64; lds = table_lds;
+            c->stats.n_launches = 1;
             table_used = true;
-        } else if (use_cache) {
-            // Bands: scenarios in LPT order (largest first) are cut into at most max_bands launches of equal
-            // scenario count; each band sizes its LDS summary and HBM workspace for its own largest scenario and
-            // runs on its own stream (the hardware exposes 4 compute queues; more bands would serialise).
-            struct Band { int start, count, ni_max; size_t lds, ws_off; };
-            std::vector<Band> bands;
-            const int nb = std::max(1, std::min(c->max_bands, S));
-            size_t ws_total = 0;
-            for (int bi = 0; bi < nb; ++bi) {
-                const int b = (int)((long long)S * bi / nb), e = (int)((long long)S * (bi + 1) / nb);
-                if (e <= b) continue;
-                const int ni0 = std::max(c->scen_ni[c->h_perm[b]], 16);
-                bands.push_back(Band{b, e - b, ni0, lds_of(ni0), ws_total});
-                ws_total += ws_of(ni0) * (size_t)(e - b);
-            }
-            HIP_TRY(c, c->d_ws.ensure(ws_total));
-            if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
-            CacheLaunch f{};
-            f.ncls = c->d_ncls.p; f.rank = c->d_rank.p; f.shape_of = c->d_shape_of.p; f.a_pods = c->d_a_pods.p;
-            f.i_rq_cpu = c->d_i_rq_cpu.p; f.i_rq_mem = c->d_i_rq_mem.p; f.i_nz_cpu = c->d_i_nz_cpu.p; f.i_nz_mem = c->d_i_nz_mem.p;
-            f.i_npods = c->d_i_npods.p; f.clsprefix = c->d_clsprefix.p; f.sigs = c->d_sigs.p; f.shapes = c->d_shapes.p;
-            f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.scen = c->d_scen.p;
-            f.static_mask = c->has_mask ? c->d_mask.p : nullptr; f.simon_raw = c->d_raw32.p;
-            f.unscheduled = c->d_unsched.p; f.used_cpu = c->d_used_cpu.p; f.used_mem = c->d_used_mem.p;
-            f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
-            for (size_t bi = 0; bi < bands.size(); ++bi) {
-                const Band& bd = bands[bi];
-                hipStream_t bs = bands.size() == 1 ? c->stream : c->band_stream[bi];
-                if (bs != c->stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->fork_ev, 0));
-                f.perm = c->d_perm.p + bd.start;
-                f.ws = c->d_ws.p + bd.ws_off;
-                f.sc = CacheScalars{(c->N + 63) / 64, c->Cn, c->Cp, P, bd.count, c->n_sigs, c->n_shapes, bd.ni_max,
-                                    c->ablate, c->g_cpu, c->g_mem};
-                HIP_TRY(c, launch_cache(f, bd.count, c->has_mask, c->nzeq, c->has_pin, bd.lds, bs));
-                if (bs != c->stream) {
-                    HIP_TRY(c, hipEventRecord(c->band_ev[bi], bs));
-                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev[bi], 0));
-                }
-            }
-            if (want_placement)
-                HIP_TRY(c, launch_unpermute(c->d_place_step.p, c->d_inv_orders.p, c->d_scen.p, S, P, c->d_place.p, c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-            variant_used = SIMON_KERNEL_NARROW_CACHE;
-            T = 64; slots = 2; lds = bands[0].lds;
-            c->stats.n_launches = (int)bands.size();
         } else if (c->fast_ok && !c->force_v1 && T >= 128) {
             lds = ((size_t)c->Cp * c->Cn * 2 * sizeof(int32_t) + 15) & ~(size_t)15;
             FastLaunch f{};
@@ -938,9 +872,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.kernel_ms = ms;
-    if (variant_used != SIMON_KERNEL_NARROW_CACHE) c->stats.n_launches = 1;
+    c->stats.n_launches = 1;
     c->stats.kernel_variant = variant_used;
-    c->stats.kernel_generation = table_used ? 4 : variant_used == SIMON_KERNEL_NARROW_CACHE ? 3 : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : 1;
+    c->stats.kernel_generation = table_used ? 4 : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;
     c->stats.lds_bytes = (int64_t)lds;

@@ -5,39 +5,61 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "simon_cache.h"   // SigRow, ShapeRow, PodRowC, cache_nbp
+#include "simon_device.h"
 
 namespace simon {
 
+struct SigRow {      // one pod request signature (48 B)
+    double req_c, req_m;   // computePodResourceRequest (fit.go:148-165), gcd-normalised, exact
+    double nz_c, nz_m;     // non-zero request (V/framework/types.go:601-636)
+    int32_t cls;           // pod class: row of static_mask / simon_raw
+    uint32_t flags;        // bit0: all-zero request (fit.go:244-249)
+    int32_t pad[2];
+};
+static_assert(sizeof(SigRow) == 48, "SigRow must be 48 bytes");
+
+struct ShapeRow {    // capacity of one internal node class = one distinct (Allocatable.MilliCPU, Allocatable.Memory) pair (48 B)
+    double cap_c, cap_m;
+    double rc_c, rc_m;         // RN(1/cap)
+    double rc100_c, rc100_m;   // RN(100 * rc)
+};
+static_assert(sizeof(ShapeRow) == 48, "ShapeRow must be 48 bytes");
+
+struct PodRowC { int32_t sig, preset, gate, cls; };   // 16 B: signature, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, pod class
+
 struct TableScalars {
-    int32_t mask_words, Cn, Cp, P, S, K, n_shapes;
+    int32_t mask_words, Cn, Cp, P, S, K;
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096)
     uint64_t g_cpu, g_mem;
 };
 
 // pointers only the prologue, the epilogue and the rare paths (preset / pinned pods) use: one device-resident struct
 struct TableCold {
-    const int32_t *ncls, *rank, *shape_of, *cls_off, *clsprefix, *a_pods; const uint32_t *i_rq_cpu, *i_rq_mem, *i_nz_cpu, *i_nz_mem;
+    const int32_t *ncls, *rank, *cls_off, *clsprefix, *a_pods; const uint32_t *i_rq_cpu, *i_rq_mem, *i_nz_cpu, *i_nz_mem;
     const int32_t* i_npods; const SigRow* sigs; const ShapeRow* shapes; const ScenarioDesc* scen; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
+    unsigned long long* prof;   // [S][8] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
 };
 
 struct TableLaunch {
     const TableCold* cold;      // device pointer
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
-    unsigned char* ws;   // HBM workspace [n_blocks][table_ws_bytes]: byte table + node state
+    const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
+    unsigned char* ws;   // HBM workspace: byte table + node state of every scenario of the launch
     TableScalars sc;
 };
 
 constexpr int kTableMaxNodes = 4095;    // canonical index and padded position are 12-bit fields of the arg-max keys
 constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario
 constexpr int kTableMaxSigs = 128;      // two signatures per lane
-constexpr int kTableMaxShapes = 256;    // u8 shape id per node
-constexpr int kTableMaxClasses = 64;    // one lane per node class in the renormalisation; u8 class id per node
+constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
-size_t table_ws_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq);
+size_t table_lds_bytes(int K, int ni_max, int Cn);       // LDS per workgroup for padded scenario sizes up to ni_max
+size_t table_ws_bytes(int K, int ni, bool nzeq);        // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
+// placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)
+hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
+                            int32_t* placement, hipStream_t st);
 
 }  // namespace simon

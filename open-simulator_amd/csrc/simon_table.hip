@@ -37,6 +37,20 @@
 
 #include <algorithm>
 
+// Phase profile of the scheduling cycle (profiles/build_variant.sh ... -DSIMON_TABLE_PROFILE): s_memtime stamps at the phase
+// boundaries, accumulated per wave, written to TableCold::prof ([workgroup][8] ticks).  Not compiled into the product build.
+#ifdef SIMON_TABLE_PROFILE
+#define TPROF_DECL unsigned long long tp_prev = __builtin_readcyclecounter(), tp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TPROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tp_acc[i] += t_ - tp_prev; tp_prev = t_; } while (0)
+#define TPROF_WAIT_LDS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define TPROF_WAIT_MEM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define TPROF_DECL
+#define TPROF(i) do { } while (0)
+#define TPROF_WAIT_LDS do { } while (0)
+#define TPROF_WAIT_MEM do { } while (0)
+#endif
+
 namespace simon {
 
 typedef unsigned short u16x2t __attribute__((ext_vector_type(2)));
@@ -78,31 +92,36 @@ __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, shid, sn, cnt, raw, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
-    int ws_tile, ws_state, ws_nz, ws_total;                // HBM workspace offsets per scenario
+    int sum, sn, cnt, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
-__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
+// summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
+// entries of one block (pitch * 2 bytes apart) spread over the LDS banks (a 2-way conflict on a 16-bit store costs nothing)
+__host__ __device__ inline int table_nbp(int nblk) { return (nblk & 1) || (nblk & 3) == 2 ? nblk : nblk + 1; }
+// LDS per workgroup decides how many scenario waves a CU holds: 160 KB / 16 = 10 KB (measured, profiles/micro/occupancy_probe.hip:
+// 10 240 B -> 16 workgroups per CU, 12 288 B -> 12), so everything but the summary is kept tiny: no per-position arrays (the shape
+// of a node follows from its class), Simon raw scores stay in global memory (read on the rare re-base only).
+__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn) {
     auto al = [](int x) { return (x + 15) & ~15; };
     TCarve c;
-    const int nblk = ni_max / 16;
-    c.nbp = cache_nbp(nblk);
+    c.nbp = table_nbp(ni_max / 16);
     int o = 0;
     c.sum = o; o += al(K * c.nbp * 2);
-    c.shid = o; o += al(ni_max);
     c.sn = o; o += al(K * Cn * 2);
     c.cnt = o; o += al(K * Cn * 4);
-    c.raw = o; o += al(Cp * Cn * 4);
-    c.shape = o; o += n_shapes * 48;
-    c.seg = o; o += 68 * 4;
-    c.tmp = o; o += 64 * 4;
+    c.shape = o; o += Cn * 48;
+    c.seg = o; o += al((Cn + 1) * 4);
+    c.tmp = o; o += al(Cn * 4);
     c.total = o;
-    int w = 0;
-    c.ws_tile = w; w += (nblk * K * 16 + 127) & ~127;
-    c.ws_state = w; w += (ni_max * 12 + 127) & ~127;
-    c.ws_nz = w; w += nzeq ? 0 : ((ni_max * 8 + 127) & ~127);
-    c.ws_total = w;
     return c;
+}
+// HBM workspace of ONE scenario with `ni` padded positions: byte table [ni / 16][K][16], node state [ni] x 12 B, and (when
+// NonZeroRequested differs from Requested) [ni] x 8 B
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq) {
+    size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
+    w += ((size_t)ni * 12 + 127) & ~(size_t)127;
+    if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
+    return w;
 }
 
 // KQ: signatures per lane (1: K <= 64, 2: K <= 128).  HAS_PIN: the stream holds pinned pods (own instantiation: the extra
@@ -112,11 +131,11 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, int Cp, int 
 template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list, const PodRowC* __restrict__ pods,
-    const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, int32_t* __restrict__ place_step, unsigned char* ws,
-    const TableScalars sc) {
+    const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
+    int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
     // Pointers the hot loop never touches live in a device-resident struct: as kernel arguments (24 pointers) they kept the
     // loop at the SGPR limit and spilled into VGPR lanes.
-    const int32_t* __restrict__ const ncls = cold->ncls; const int32_t* __restrict__ const shape_of = cold->shape_of;
+    const int32_t* __restrict__ const ncls = cold->ncls;
     const int32_t* __restrict__ const cls_off = cold->cls_off; const int32_t* __restrict__ const clsprefix = cold->clsprefix;
     const int32_t* __restrict__ const a_pods = cold->a_pods; const uint32_t* __restrict__ const i_rq_cpu = cold->i_rq_cpu;
     const uint32_t* __restrict__ const i_rq_mem = cold->i_rq_mem; const uint32_t* __restrict__ const i_nz_cpu = cold->i_nz_cpu;
@@ -126,18 +145,12 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int32_t* __restrict__ const simon_raw = cold->simon_raw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, Cp, sc.n_shapes, NZEQ);
+    const TCarve cv = tcarve(K, sc.ni_max, Cn);
     const int nbp = cv.nbp;
-    unsigned char* const wsb = ws + (size_t)blockIdx.x * (size_t)cv.ws_total;
-    unsigned char* g_tile = wsb + cv.ws_tile;                       // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
-    NodeState* g_state = (NodeState*)(wsb + cv.ws_state);
-    uint2* g_nz = (uint2*)(wsb + cv.ws_nz);                         // NonZeroRequested {cpu, mem} (only when !NZEQ)
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);       // [K][nbp]: (best byte + class term) << 4 | 15 - position
-    unsigned char* s_shid = smem + cv.shid;                         // [ni]: shape id of a position
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k
-    int* s_raw = (int*)(smem + cv.raw);                             // [Cp][Cn] Simon raw scores
-    const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);
+    const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);   // [Cn]: shape of a node class (a class shares its allocatable)
     int* s_seg = (int*)(smem + cv.seg);                             // [Cn + 1]: first position of a class segment
     int* s_tmp = (int*)(smem + cv.tmp);
 
@@ -145,13 +158,13 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int lane = threadIdx.x;
     const int s = __builtin_amdgcn_readfirstlane(perm[blockIdx.x]);
     const int n = __builtin_amdgcn_readfirstlane(scen[s].n_nodes);
+    unsigned char* const wsb = ws + ws_off[blockIdx.x];
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
-    for (int i = lane; i < cv.shid / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);    // summary
+    for (int i = lane; i < cv.sn / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);      // summary
     for (int i = lane; i < K * Cn; i += 64) { s_cnt[i] = 0; s_sn[i] = 0; }
-    for (int i = lane; i < Cp * Cn; i += 64) s_raw[i] = simon_raw[i];
-    for (int i = lane; i < sc.n_shapes * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
+    for (int i = lane; i < Cn * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
     // count of class-d nodes among the first n canonical nodes, padded to 16
     const int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
     const int pad_d = (cnt_d + 15) & ~15;
@@ -161,10 +174,12 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    s_seg[lane] = incl - pad_d;                                       // lanes >= Cn hold ni
+    if (lane <= Cn) s_seg[lane] = incl - pad_d;                       // lane Cn holds ni (classes beyond Cn add nothing)
     const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size
-    if (lane == 0) s_seg[64] = ni;
     const int nblk = ni >> 4;
+    unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
+    NodeState* g_state = (NodeState*)(wsb + (((size_t)nblk * Krow + 127) & ~(size_t)127));
+    uint2* g_nz = (uint2*)((unsigned char*)g_state + (((size_t)ni * 12 + 127) & ~(size_t)127));   // NonZeroRequested (only when !NZEQ)
     __syncthreads();
 
     // class of a position (segments are contiguous): number of segment ENDS at or below it
@@ -201,16 +216,14 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int r = p - s_seg[d];
         const bool real = p < ni && r < __shfl(cnt_d, d, 64);
         const int j = real ? cls_list[cls_off[d] + r] : 0;            // r-th node of class d in canonical order
-        const unsigned shid = real ? (unsigned)shape_of[j] : 0u;
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
         if (p < ni) {
             g_state[p] = st;
             if (!NZEQ) g_nz[p] = z;
-            s_shid[p] = (unsigned char)shid;
         }
-        const ShapeRow sh = s_shape[shid];
+        const ShapeRow sh = s_shape[d];
         unsigned char* tp = g_tile + ((unsigned)(p >> 4) * Krow + (unsigned)(p & 15));
         for (int k = 0; k < K; ++k) {
             const SigRow q = sigs[k];
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int dd = lane < Cn ? lane : 0;
         const int cn = (lane < Cn) ? s_cnt[k * Cn + dd] : 0;
         const bool inb = cn > 0;
-        const int rawc = s_raw[c * Cn + dd];
+        const int rawc = simon_raw[c * Cn + dd];                      // global: this path runs a handful of times per signature
         const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
         const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
         const int range = hi >= lo ? hi - lo : 0;
@@ -316,9 +329,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     };
     if (P > 0) nxt = load_chunk(0);
 
+    TPROF_DECL
     for (int i = 0; i < P; ++i) {
         const int il = i & 63;
         if (il == 0) { cur = nxt; nxt = load_chunk(i + 64); }
+        TPROF(0);                                                      // loop control, placement flush, pod chunk
         const int r_sig = __builtin_amdgcn_readlane(cur.x, il), r_preset = __builtin_amdgcn_readlane(cur.y, il);
         const int r_gate = __builtin_amdgcn_readlane(cur.z, il), r_cls = __builtin_amdgcn_readlane(cur.w, il);
 
@@ -370,7 +385,9 @@ __global__ __launch_bounds__(64) void table_kernel(
                 const unsigned m16 = m16q[q];
                 key = max(key, (((m16 << 8) & 0xFFF000u) | (unsigned)cb[q]) | (m16 & 15u));
             }
+            TPROF_WAIT_LDS; TPROF(1);                                  // pod row, dirty check, summary row arrived
             key = wave_max_u32(key);
+            TPROF(2);                                                  // key build + wave max
             if (key < 4096u) {                                         // FitError: pod deleted, state unchanged
                 ++unsched;
                 res = -1;
@@ -411,6 +428,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         if (pstar >= 0) {
             const int blk = pstar >> 4, pos = pstar & 15;
             const int dwi = pos >> 2, sh8 = (pos & 3) * 8;
+            TPROF(3);                                                  // winner info, cross-class tie check
             NodeState st = g_state[pstar];
             // row of (signature kk[q], touched block): uniform table base + 32-bit byte offset
             unsigned char* rowp[KQ];
@@ -422,10 +440,12 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             uint2 z = make_uint2(0, 0);
             if (!NZEQ) z = g_nz[pstar];
-            const ShapeRow sh = s_shape[s_shid[pstar]];
+            const ShapeRow sh = s_shape[dstar];
             unsigned snq[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) snq[q] = s_sn[kk[q] * Cn + dstar];
+            TPROF_WAIT_LDS; TPROF(4);                                  // loads issued; shape row and class term arrived (LDS)
+            TPROF_WAIT_MEM; TPROF(5);                                  // node state and table row arrived (L2 / HBM)
             const int sl = r_sig & 63;
             const bool hiq = KQ > 1 && (r_sig >> 6);
             st.rq_c += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_c[0], sl));
@@ -468,6 +488,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            TPROF(6);                                                  // state update, eval, patch, block key, summary store
         }
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
         plreg = (il == lane) ? res : plreg;
@@ -480,6 +501,10 @@ __global__ __launch_bounds__(64) void table_kernel(
     for (int p = lane; p < ni; p += 64) { const NodeState st = g_state[p]; uc += st.rq_c; um += st.rq_m; }
     uc = wave_sum_i64(uc);
     um = wave_sum_i64(um);
+#ifdef SIMON_TABLE_PROFILE
+    if (lane == 0 && cold->prof)
+        for (int q = 0; q < 8; ++q) cold->prof[(size_t)s * 8 + q] = tp_acc[q];
+#endif
     if (lane == 0) {
         cold->unscheduled[s] = unsched;
         cold->used_cpu[s] = uc * (long long)sc.g_cpu;
@@ -487,12 +512,34 @@ __global__ __launch_bounds__(64) void table_kernel(
     }
 }
 
+// placement[s][pod] = place_step[s][inv_order[order_id(s)][pod]]: gather (scattered reads hit L2, stores coalesced)
+__global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restrict__ place_step, const int32_t* __restrict__ inv_orders,
+                                                        const ScenarioDesc* __restrict__ scen, int P, int32_t* __restrict__ placement) {
+    const int s = blockIdx.y;
+    const int32_t* __restrict__ inv = inv_orders + (size_t)scen[s].order_id * P;
+    const int32_t* __restrict__ src = place_step + (size_t)s * P;
+    int32_t* __restrict__ dst = placement + (size_t)s * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
+}
+
+hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
+                            int32_t* placement, hipStream_t st) {
+    if (S <= 0 || P <= 0) return hipSuccess;
+    const int bx = std::min(64, (P + 255) / 256);
+    for (int s0 = 0; s0 < S; s0 += 65535) {   // gridDim.y limit
+        const int ns = std::min(65535, S - s0);
+        hipLaunchKernelGGL(unpermute_kernel, dim3(bx, ns), dim3(256), 0, st, place_step + (size_t)s0 * P, inv_orders, scen + s0, P,
+                           placement + (size_t)s0 * P);
+    }
+    return hipGetLastError();
+}
+
 template <bool M, bool Z, bool PIN, int KQ, int NBQ>
 static hipError_t launch_t5(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     auto kern = table_kernel<M, Z, PIN, KQ, NBQ>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.place_step, a.ws, a.sc);
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
     return hipGetLastError();
 }
 template <bool M, bool Z, bool PIN, int KQ>
@@ -502,12 +549,8 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
            : nblk <= 128 ? launch_t5<M, Z, PIN, KQ, 2>(a, n_blocks, lds, st) : launch_t5<M, Z, PIN, KQ, 4>(a, n_blocks, lds, st);
 }
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
-    return (size_t)tcarve(K, ni_max, Cn, Cp, n_shapes, nzeq).total;
-}
-size_t table_ws_bytes(int K, int ni_max, int Cn, int Cp, int n_shapes, bool nzeq) {
-    return (size_t)tcarve(K, ni_max, Cn, Cp, n_shapes, nzeq).ws_total;
-}
+size_t table_lds_bytes(int K, int ni_max, int Cn) { return (size_t)tcarve(K, ni_max, Cn).total; }
+size_t table_ws_bytes(int K, int ni, bool nzeq) { return table_ws_of(K, ni, nzeq); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
