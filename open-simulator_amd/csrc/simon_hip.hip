@@ -100,6 +100,8 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_t_ncls, d_rank, d_clsprefix, d_inv_orders, d_place_step, d_cls_list, d_cls_off, d_t_raw;
     std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn_t]; padded (class-major) size of every loaded scenario
     size_t ws_total = 0;
+    bool table_sumg = false;                     // summary rows in the HBM workspace instead of LDS (decided per loaded batch)
+    int force_sumg = -1, table_ni_top = 16;      // env SIMON_TABLE_SUMG = 0 / 1 (A/B)
     std::vector<int32_t> h_perm;
     std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
     DevBuf<uint64_t> d_mask;
@@ -423,6 +425,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
+    if (const char* e = getenv("SIMON_TABLE_SUMG")) c->force_sumg = atoi(e) != 0;
     if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
@@ -698,9 +701,18 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             c->scen_ni[s] = std::max(ni, 16);
         }
         if (is_perm) {
+            // Where do the summary rows live?  In LDS -- unless they do not fit a workgroup's 64 KB (128 signatures x 4 000 nodes):
+            // then they go to the scenario's HBM workspace.  (Measured, profiles/README.md: the HBM variant costs +10 % at low
+            // occupancy and +60 % at 4 096 scenarios -- its extra footprint pushes the batch out of the Infinity Cache -- so it is
+            // only the fallback, never the choice for a batch whose LDS summary merely lowers the waves per CU.)
+            int ni_top = 16;
+            for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
+            const size_t lds_full = table_lds_bytes(c->n_sigs, ni_top, Ct, false) + c->lds_pad;
+            c->table_sumg = c->force_sumg >= 0 ? c->force_sumg != 0 : lds_full > 64 * 1024;
+            c->table_ni_top = ni_top;
             std::vector<unsigned long long> ws_off(S);
             size_t off = 0;
-            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq); }
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, c->table_sumg, ni_top); }
             c->ws_total = off;
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
@@ -764,9 +776,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 5) slots = 6;
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
-        int ni_top = 16;
-        for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t) + c->lds_pad : 0;
+        const int ni_top = c->table_ni_top;
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_sumg) + c->lds_pad : 0;
         const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kTableMaxNodes &&
                                ni_top <= kTableMaxPadded && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
@@ -791,7 +802,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.sumg = c->table_sumg;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -805,8 +816,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 HIP_TRY(c, hipMemcpy(hp.data(), c->d_table_prof.p, hp.size() * 8, hipMemcpyDeviceToHost));
                 double acc[8] = {0};
                 for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 8; ++q) acc[q] += (double)hp[(size_t)s2 * 8 + q];
-                fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | eval+patch+store %.0f\n",
-                        S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[6] / S / P);
+                fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | eval+patch+store %.0f | canonical tie-breaks per cycle %.3f\n",
+                        S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[6] / S / P, acc[7] / S / P);
             }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
             T = 64; slots = (ni_top / 16 + 63) / 64; lds = table_lds;

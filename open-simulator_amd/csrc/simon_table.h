@@ -45,17 +45,19 @@ struct TableLaunch {
     const TableCold* cold;      // device pointer
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
-    unsigned char* ws;   // HBM workspace: byte table + node state of every scenario of the launch
+    unsigned char* ws;   // HBM workspace: byte table + node state (+ summary rows when sumg) of every scenario of the launch
+    bool sumg;           // summary rows in the workspace instead of LDS
     TableScalars sc;
 };
 
 constexpr int kTableMaxNodes = 4095;    // canonical index and padded position are 12-bit fields of the arg-max keys
 constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario
 constexpr int kTableMaxSigs = 128;      // two signatures per lane
+constexpr size_t kTableLdsPerCU = 160 * 1024;
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
-size_t table_lds_bytes(int K, int ni_max, int Cn);       // LDS per workgroup for padded scenario sizes up to ni_max
-size_t table_ws_bytes(int K, int ni, bool nzeq);        // HBM workspace of ONE scenario with ni padded positions
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool sumg);          // LDS per workgroup for padded scenario sizes up to ni_max
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool sumg, int ni_max); // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

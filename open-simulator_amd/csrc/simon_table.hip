@@ -80,6 +80,41 @@ __device__ __forceinline__ unsigned block_key16_t(const uint4 R) {
     return max(m0 & 0xFFFFu, m0 >> 16);
 }
 
+// Block key of a table row whose byte at position `pos` is being replaced: the v_perm selectors that expand the row's bytes to
+// u16 pairs take the touched byte from `nb` (selector 4 = byte 0 of the first operand) instead of the row -- the patch costs no
+// instruction.  kSel[pos] = 8 selectors: dword i pair lo (bytes 0, 1), pair hi (bytes 2, 3); 0x0c = constant 0.
+struct SelTab { unsigned v[16][8]; };
+constexpr SelTab make_sel_tab() {
+    SelTab t{};
+    for (int pos = 0; pos < 16; ++pos)
+        for (int i = 0; i < 4; ++i)
+            for (int h = 0; h < 2; ++h) {
+                unsigned b0 = (unsigned)(2 * h), b1 = (unsigned)(2 * h + 1);            // byte indices inside dword i
+                if (pos == 4 * i + 2 * h) b0 = 4;
+                if (pos == 4 * i + 2 * h + 1) b1 = 4;
+                t.v[pos][2 * i + h] = 0x0c000c00u | b0 | (b1 << 16);
+            }
+    return t;
+}
+__device__ __constant__ SelTab kSelTab = make_sel_tab();
+#define kSel (kSelTab.v)
+
+__device__ __forceinline__ unsigned pk_key(unsigned pair, unsigned c) {   // (x << 4) + c on both halves in ONE instruction
+    unsigned d;
+    asm("v_pk_mad_u16 %0, %1, 16, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(pair), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned block_key16_patched(const uint4 R, unsigned nb, const uint4 sa, const uint4 sb) {
+#define SIMON_C(q4) ((unsigned)((15 - (q4)) | ((15 - ((q4) + 1)) << 16)))
+    const unsigned m0 = pkmax_t(pk_key(__builtin_amdgcn_perm(nb, R.x, sa.x), SIMON_C(0)), pk_key(__builtin_amdgcn_perm(nb, R.x, sa.y), SIMON_C(2)));
+    const unsigned m1 = pkmax_t(pk_key(__builtin_amdgcn_perm(nb, R.y, sa.z), SIMON_C(4)), pk_key(__builtin_amdgcn_perm(nb, R.y, sa.w), SIMON_C(6)));
+    const unsigned m2 = pkmax_t(pk_key(__builtin_amdgcn_perm(nb, R.z, sb.x), SIMON_C(8)), pk_key(__builtin_amdgcn_perm(nb, R.z, sb.y), SIMON_C(10)));
+    const unsigned m3 = pkmax_t(pk_key(__builtin_amdgcn_perm(nb, R.w, sb.z), SIMON_C(12)), pk_key(__builtin_amdgcn_perm(nb, R.w, sb.w), SIMON_C(14)));
+#undef SIMON_C
+    const unsigned m = pkmax_t(pkmax_t(m0, m1), pkmax_t(m2, m3));
+    return max(m & 0xFFFFu, m >> 16);
+}
+
 // max over each 16-lane row (result in every lane of the row)
 __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
     v = max(v, (unsigned)SIMON_DPP(0, (int)v, 0xB1, 0xF));
@@ -101,12 +136,12 @@ __host__ __device__ inline int table_nbp(int nblk) { return (nblk & 1) || (nblk 
 // LDS per workgroup decides how many scenario waves a CU holds: 160 KB / 16 = 10 KB (measured, profiles/micro/occupancy_probe.hip:
 // 10 240 B -> 16 workgroups per CU, 12 288 B -> 12), so everything but the summary is kept tiny: no per-position arrays (the shape
 // of a node follows from its class), Simon raw scores stay in global memory (read on the rare re-base only).
-__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn) {
+__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool sumg) {
     auto al = [](int x) { return (x + 15) & ~15; };
     TCarve c;
     c.nbp = table_nbp(ni_max / 16);
     int o = 0;
-    c.sum = o; o += al(K * c.nbp * 2);
+    c.sum = o; o += sumg ? 0 : al(K * c.nbp * 2);     // SUMG: the summary lives in the scenario's HBM workspace instead
     c.sn = o; o += al(K * Cn * 2);
     c.cnt = o; o += al(K * Cn * 4);
     c.shape = o; o += Cn * 48;
@@ -117,10 +152,11 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn) {
 }
 // HBM workspace of ONE scenario with `ni` padded positions: byte table [ni / 16][K][16], node state [ni] x 12 B, and (when
 // NonZeroRequested differs from Requested) [ni] x 8 B
-__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq) {
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool sumg, int nbp) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
+    if (sumg) w += ((size_t)K * nbp * 2 + 127) & ~(size_t)127;
     return w;
 }
 
@@ -128,7 +164,9 @@ __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq) {
 // branch costs the common kernel time).
 // NBQ: blocks per lane (1, 2 or 4: padded scenario sizes up to 1024 / 2048 / 4096 positions) -- a template parameter so that the
 // scan is straight-line code (as run-time conditions the four reads became four dependent LDS round trips).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ>
+// SUMG: the summary rows live in HBM (L2) instead of LDS -- for batches whose LDS summary would not let the CU hold the waves the
+// batch offers (many signatures x many blocks); the scan then costs an L2 round trip instead of an LDS one.
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool SUMG>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -145,9 +183,8 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int32_t* __restrict__ const simon_raw = cold->simon_raw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
-    const TCarve cv = tcarve(K, sc.ni_max, Cn);
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, SUMG);
     const int nbp = cv.nbp;
-    unsigned short* s_sum = (unsigned short*)(smem + cv.sum);       // [K][nbp]: (best byte + class term) << 4 | 15 - position
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k
     const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);   // [Cn]: shape of a node class (a class shares its allocatable)
@@ -162,7 +199,6 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
-    for (int i = lane; i < cv.sn / 16; i += 64) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);      // summary
     for (int i = lane; i < K * Cn; i += 64) { s_cnt[i] = 0; s_sn[i] = 0; }
     for (int i = lane; i < Cn * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
     // count of class-d nodes among the first n canonical nodes, padded to 16
@@ -180,6 +216,14 @@ __global__ __launch_bounds__(64) void table_kernel(
     unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
     NodeState* g_state = (NodeState*)(wsb + (((size_t)nblk * Krow + 127) & ~(size_t)127));
     uint2* g_nz = (uint2*)((unsigned char*)g_state + (((size_t)ni * 12 + 127) & ~(size_t)127));   // NonZeroRequested (only when !NZEQ)
+    // [K][nbp]: (best byte + class term) << 4 | 15 - position -- in LDS, or (SUMG) behind the node state in the workspace.  The two
+    // definitions are compile-time alternatives so that each instantiation addresses ONE address space.
+    unsigned short* s_sum;
+    if constexpr (SUMG) s_sum = (unsigned short*)((unsigned char*)g_nz + (NZEQ ? 0 : (((size_t)ni * 8 + 127) & ~(size_t)127)));
+    else s_sum = (unsigned short*)(smem + cv.sum);
+    for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
+    if (lane == 0 && ((K * nbp) & 1)) s_sum[K * nbp - 1] = 0;
+    if (SUMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // class of a position (segments are contiguous): number of segment ENDS at or below it
@@ -313,55 +357,63 @@ __global__ __launch_bounds__(64) void table_kernel(
                 if (m) srow[b] = (unsigned short)((int)m + s_tmp[bcls[q]]);
             }
         }
+        if (SUMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
 
-    int unsched = 0, plreg = 0;
+    int unsched = 0;
     int32_t* __restrict__ place = place_step ? place_step + (size_t)s * P : nullptr;
 
-    // pod stream: 64 rows per vector load (lane l holds step i0 + l), one chunk ahead
-    int4 cur = make_int4(0, -1, 0x7fffffff, 0), nxt = cur;
+    // pod stream: 64 rows per vector load (lane l holds step i0 + l), one chunk ahead.  x packs what the common path needs into ONE
+    // readlane: signature | pod class << 8, sign bit = "special" (gated out of this scenario, preset or pinned): y = preset, z = gate.
     auto load_chunk = [&](int i0) -> int4 {
         const int idx = i0 + lane;
-        if (idx >= P) return make_int4(0, -1, 0x7fffffff, 0);
+        if (idx >= P) return make_int4((int)0x80000000, -1, 0x7fffffff, 0);
         const PodRowC r = pods[order[idx]];
-        return make_int4(r.sig, r.preset, r.gate, r.cls);
+        const bool special = r.gate >= n || r.preset != -1;
+        return make_int4((r.sig | (r.cls << 8)) | (special ? (int)0x80000000 : 0), r.preset, r.gate, 0);
     };
-    if (P > 0) nxt = load_chunk(0);
+    int4 nxt = load_chunk(0);
 
     TPROF_DECL
-    for (int i = 0; i < P; ++i) {
-        const int il = i & 63;
-        if (il == 0) { cur = nxt; nxt = load_chunk(i + 64); }
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int4 cur = nxt;
+        nxt = load_chunk(i0 + 64);
+        const int steps = P - i0 < 64 ? P - i0 : 64;
+        int plreg = -2;
+        for (int il = 0; il < steps; ++il) {
         TPROF(0);                                                      // loop control, placement flush, pod chunk
-        const int r_sig = __builtin_amdgcn_readlane(cur.x, il), r_preset = __builtin_amdgcn_readlane(cur.y, il);
-        const int r_gate = __builtin_amdgcn_readlane(cur.z, il), r_cls = __builtin_amdgcn_readlane(cur.w, il);
+        const int pk = __builtin_amdgcn_readlane(cur.x, il);
+        const int r_sig = pk & 0xFF, r_cls = (pk >> 8) & 0x7FFFFF;
 
         // res: what the placement row records for this step: >= 0 an index into cls_list (turned into the canonical node index
         // 64 steps at a time, off the critical path), -1 unschedulable, -2 not part of the scenario
         int res, pstar = -1, dstar = 0;
-        if (r_gate >= n) {
-            res = -2;                                                  // pod not part of this scenario
-        } else if (r_preset >= 0) {                                    // addPodToCache path (V/eventhandlers.go:223-236)
+        unsigned top = 0, m16q[NBQ];
+        bool scanned = false;
+        if (pk < 0) {
+            const int r_preset = __builtin_amdgcn_readlane(cur.y, il), r_gate = __builtin_amdgcn_readlane(cur.z, il);
             const TableCold* cc = cold;
-            asm volatile("" : "+s"(cc));                               // rare path: fetch its pointers here, not in loop-long SGPRs
-            dstar = __builtin_amdgcn_readfirstlane(cc->ncls[r_preset]);
-            const int rk = __builtin_amdgcn_readfirstlane(cc->rank[r_preset]);
-            pstar = __builtin_amdgcn_readfirstlane(s_seg[dstar]) + rk;
-            res = __builtin_amdgcn_readfirstlane(cc->cls_off[dstar]) + rk;
-        } else if (HAS_PIN && r_preset <= -2) {                        // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
-            const int pin = -2 - r_preset;                             // its node affinity admits ONE node; the table byte of
-            res = -1;                                                  // (signature, node) holds static filters + fit
-            if (pin < n) {
-                const TableCold* cc = cold;
-                asm volatile("" : "+s"(cc));
-                const int dp = __builtin_amdgcn_readfirstlane(cc->ncls[pin]);
-                const int rk = __builtin_amdgcn_readfirstlane(cc->rank[pin]);
-                const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
-                const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
-                if (byte != 0) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
+            asm volatile("" : "+s"(cc));                               // rare paths: fetch their pointers here, not in loop-long SGPRs
+            if (r_gate >= n) {
+                res = -2;                                              // pod not part of this scenario
+            } else if (r_preset >= 0) {                                // addPodToCache path (V/eventhandlers.go:223-236)
+                dstar = __builtin_amdgcn_readfirstlane(cc->ncls[r_preset]);
+                const int rk = __builtin_amdgcn_readfirstlane(cc->rank[r_preset]);
+                pstar = __builtin_amdgcn_readfirstlane(s_seg[dstar]) + rk;
+                res = __builtin_amdgcn_readfirstlane(cc->cls_off[dstar]) + rk;
+            } else {                                                   // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
+                const int pin = -2 - r_preset;                         // its node affinity admits ONE node; the table byte of
+                res = -1;                                              // (signature, node) holds static filters + fit
+                if (HAS_PIN && pin < n) {
+                    const int dp = __builtin_amdgcn_readfirstlane(cc->ncls[pin]);
+                    const int rk = __builtin_amdgcn_readfirstlane(cc->rank[pin]);
+                    const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
+                    const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
+                    if (byte != 0) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
+                }
+                if (res < 0) ++unsched;
             }
-            if (res < 0) ++unsched;
         } else {
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
@@ -371,7 +423,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             // -------- summary scan: one u16 per block of 16 nodes ------------------------------------
             const unsigned short* srow = s_sum + k * nbp;
-            unsigned key = 0, m16q[NBQ];
+            unsigned key = 0;
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
                 const int b = q * 64 + lane;
@@ -392,16 +444,39 @@ __global__ __launch_bounds__(64) void table_kernel(
                 ++unsched;
                 res = -1;
             } else {
-                pstar = 4095 - (int)(key & 4095u);                     // first maximum in POSITION order
-                const unsigned top = key >> 12;
-                int bw = pstar >> 4;
-                int info = winner_info(bw);
+                pstar = 4095 - (int)(key & 4095u);                     // first maximum in POSITION order (speculative: tie check below)
+                top = key >> 12;
+                const int info = winner_info(pstar >> 4);
                 dstar = info >> 16;
+                res = (info & 0xFFFF) - 8192 + pstar;                  // index into cls_list
+                scanned = true;
+            }
+        }
+        // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column + summary ----
+        if (pstar >= 0) {
+            TPROF(3);                                                  // winner info
+            // the loads of the (speculated) winner go out first; the tie check runs while they are in flight
+            NodeState st = g_state[pstar];
+            unsigned char* rowp[KQ];
+            uint4 T[KQ];
+            unsigned oldq[KQ];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);   // uniform table base + 32-bit byte offset
+                T[q] = *(const uint4*)rowp[q];
+                oldq[q] = rowp[q][pstar & 15];                         // this signature's byte before the cycle (same cache line as the row)
+            }
+            uint2 z = make_uint2(0, 0);
+            if (!NZEQ) z = g_nz[pstar];
+            if (scanned) {
                 // Position order is canonical order inside a class only: do blocks of ANOTHER class reach the same total?
                 bool other = false;
 #pragma unroll
                 for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> 4) == top && bcls[q] != dstar);   // duplicates carry block 0's class
-                if (__ballot(other)) {                                 // rare: first maximum in CANONICAL order among the tied blocks
+                if (__ballot(other)) {                                 // rare (0.2 % of the cycles of config 3): first maximum in CANONICAL order
+#ifdef SIMON_TABLE_PROFILE
+                    tp_acc[7] += 1;                                    // how often the canonical tie-break runs
+#endif
                     unsigned key2 = 0;
                     int canon[NBQ];
 #pragma unroll
@@ -416,34 +491,30 @@ __global__ __launch_bounds__(64) void table_kernel(
                         if ((m16q[q] >> 4) == top && q * 64 + lane < nblk) key2 = max(key2, ((4095u - (unsigned)canon[q]) << 12) | (unsigned)pq);
                     }
                     key2 = wave_max_u32(key2);
-                    pstar = (int)(key2 & 4095u);
-                    bw = pstar >> 4;
-                    info = winner_info(bw);
-                    dstar = info >> 16;
-                }
-                res = (info & 0xFFFF) - 8192 + pstar;                  // index into cls_list
-            }
-        }
-        // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column + summary ----
-        if (pstar >= 0) {
-            const int blk = pstar >> 4, pos = pstar & 15;
-            const int dwi = pos >> 2, sh8 = (pos & 3) * 8;
-            TPROF(3);                                                  // winner info, cross-class tie check
-            NodeState st = g_state[pstar];
-            // row of (signature kk[q], touched block): uniform table base + 32-bit byte offset
-            unsigned char* rowp[KQ];
-            uint4 T[KQ];
+                    const int p2 = (int)(key2 & 4095u);
+                    if (p2 != pstar) {                                 // the speculated winner loses the tie: load the real one
+                        pstar = p2;
+                        const int info = winner_info(pstar >> 4);
+                        dstar = info >> 16;
+                        res = (info & 0xFFFF) - 8192 + pstar;
+                        st = g_state[pstar];
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                rowp[q] = g_tile + ((unsigned)blk * Krow + koff[q]);
-                T[q] = *(const uint4*)rowp[q];
+                        for (int q = 0; q < KQ; ++q) {
+                            rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);
+                            T[q] = *(const uint4*)rowp[q];
+                            oldq[q] = rowp[q][pstar & 15];
+                        }
+                        if (!NZEQ) z = g_nz[pstar];
+                    }
+                }
             }
-            uint2 z = make_uint2(0, 0);
-            if (!NZEQ) z = g_nz[pstar];
+            const int blk = pstar >> 4, pos = pstar & 15;
             const ShapeRow sh = s_shape[dstar];
             unsigned snq[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) snq[q] = s_sn[kk[q] * Cn + dstar];
+            // byte -> u16 expansion selectors of the touched block row with the new byte already in place (kSel, above)
+            const uint4 selA = ((const uint4*)kSel)[pos * 2], selB = ((const uint4*)kSel)[pos * 2 + 1];
             TPROF_WAIT_LDS; TPROF(4);                                  // loads issued; shape row and class term arrived (LDS)
             TPROF_WAIT_MEM; TPROF(5);                                  // node state and table row arrived (L2 / HBM)
             const int sl = r_sig & 63;
@@ -464,20 +535,13 @@ __global__ __launch_bounds__(64) void table_kernel(
             for (int q = 0; q < KQ; ++q) {
                 const unsigned nb_raw = eval_node(my_req_c[q], my_req_m[q], my_nz_c[q], my_nz_m[q], my_zero[q], rq_c, rq_m, nzc, nzm,
                                                   (int)st.freep, sh);
-                uint4 R = T[q];
-                const unsigned wsel = dwi == 0 ? R.x : dwi == 1 ? R.y : dwi == 2 ? R.z : R.w;
-                const unsigned old = (wsel >> sh8) & 0xFFu;               // this signature's byte before the cycle
+                const unsigned old = oldq[q];
                 const unsigned nb = old ? nb_raw : 0u;                    // static mask / monotone infeasibility
                 // One wave: its vector memory accesses are served in order, so the next cycle's loads of this row / state
                 // observe these stores; no cache maintenance, no wait.
                 if (kvalid[q] && nb != old) {
-                    const unsigned wnew = (wsel & ~(0xFFu << sh8)) | (nb << sh8);
-                    R.x = dwi == 0 ? wnew : R.x;
-                    R.y = dwi == 1 ? wnew : R.y;
-                    R.z = dwi == 2 ? wnew : R.z;
-                    R.w = dwi == 3 ? wnew : R.w;
                     rowp[q][pos] = (unsigned char)nb;
-                    const unsigned m = block_key16_t(R);
+                    const unsigned m = block_key16_patched(T[q], nb, selA, selB);
                     s_sum[kk[q] * nbp + blk] = (unsigned short)((m >> 4) ? m + (snq[q] << 4) : 0u);
                     if (!nb) {                                            // the node stopped being feasible for this signature
                         const int cidx = kk[q] * Cn + dstar;
@@ -492,9 +556,9 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
         plreg = (il == lane) ? res : plreg;
-        if (place && il == 63) place[(i & ~63) + lane] = plreg >= 0 ? cls_list[plreg] : plreg;   // 64 canonical indices per gather
+        }
+        if (place && lane < steps) place[i0 + lane] = plreg >= 0 ? cls_list[plreg] : plreg;   // 64 canonical indices per gather
     }
-    if (place && (P & 63) && lane < (P & 63)) place[(P & ~63) + lane] = plreg >= 0 ? cls_list[plreg] : plreg;
 
     // ---- epilogue: sum of Requested over the scenario's nodes (padding rows hold 0) -----------
     long long uc = 0, um = 0;
@@ -534,13 +598,17 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ>
-static hipError_t launch_t5(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ>;
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool SUMG>
+static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, SUMG>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
     return hipGetLastError();
+}
+template <bool M, bool Z, bool PIN, int KQ, int NBQ>
+static hipError_t launch_t5(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sumg ? launch_t6<M, Z, PIN, KQ, NBQ, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, NBQ, false>(a, n_blocks, lds, st);
 }
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
@@ -549,8 +617,8 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
            : nblk <= 128 ? launch_t5<M, Z, PIN, KQ, 2>(a, n_blocks, lds, st) : launch_t5<M, Z, PIN, KQ, 4>(a, n_blocks, lds, st);
 }
 
-size_t table_lds_bytes(int K, int ni_max, int Cn) { return (size_t)tcarve(K, ni_max, Cn).total; }
-size_t table_ws_bytes(int K, int ni, bool nzeq) { return table_ws_of(K, ni, nzeq); }
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool sumg) { return (size_t)tcarve(K, ni_max, Cn, sumg).total; }
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool sumg, int ni_max) { return table_ws_of(K, ni, nzeq, sumg, table_nbp(ni_max / 16)); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {

@@ -586,8 +586,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     auto rank_of = [&](int j) -> unsigned {
         return (kCanRank && (A.flags & kArgRanked)) ? (unsigned)COLD(A)->node_rank[(size_t)(A.scen_base + s) * N + j] : (unsigned)j;
     };
-    auto node_of = [&](int r) -> int {
-        return (kCanRank && (A.flags & kArgRanked)) ? COLD(A)->node_inv[(size_t)(A.scen_base + s) * N + r] : r;
+    auto node_of = [&](int r) -> int {   // r >= N: the arg-max key of a cycle without a feasible node (0) -- never index the rank table with it
+        return (kCanRank && (A.flags & kArgRanked) && (unsigned)r < (unsigned)N) ? COLD(A)->node_inv[(size_t)(A.scen_base + s) * N + r] : r;
     };
 
     NodeView v;
