@@ -140,6 +140,19 @@ __device__ __forceinline__ double div_by_rcp(double num, double den, double rc) 
     return q;
 }
 
+// The same quotient with ONE correction, exact on the score-table kernel's domain: den = b an integer in [1, 2^31), num = a
+// an integer in [0, 2^32), rc = RN(1/b).  q0 = RN(a rc) = (a/b)(1+d1)(1+d2), |d| <= u = 2^-53; the residual e = a - q0 b is
+// exact (fma); q0 + e rc = a/b + (a/b - q0) d1 differs from a/b by at most 2.01 u^2 (a/b), i.e. 2^-105 relative.  A midpoint m
+// between two doubles near a/b is M 2^e with M an odd 54-bit integer and 2^-e an integer (a/b < 2^32): |a/b - m| =
+// |a 2^-e - b M| 2^e / b is a non-zero multiple of 2^e / b (a/b = m would need a >= M > 2^53), so a/b stays at least
+// 2^-84 (relative) away from every midpoint -- the 2^-105 perturbation cannot change the rounding: q1 = RN(a/b).
+// Checked against '/' on 9.3e8 operand pairs of that domain by oracle/div_by_rcp_check.c (0 mismatches).
+__device__ __forceinline__ double div_by_rcp1(double num, double den, double rc) {
+    const double q = num * rc;
+    const double e = __builtin_fma(-q, den, num);
+    return __builtin_fma(e, rc, q);
+}
+
 __device__ __forceinline__ int ba_term_rcp(uint32_t cap_c, uint32_t req_c, double rc_c, uint32_t cap_m,
                                            uint32_t req_m, double rc_m) {
     const double cf = cap_c == 0u ? 1.0 : div_by_rcp((double)req_c, (double)cap_c, rc_c);

@@ -246,8 +246,8 @@ __global__ __launch_bounds__(64) void table_kernel(
         const bool ge_c = r_c >= sh.cap_c, ge_m = r_m >= sh.cap_m;
         const int la_c = ge_c ? 0 : la_term_t(r_c, sh.rc100_c);           // least_allocated.go:108-117
         const int la_m = ge_m ? 0 : la_term_t(r_m, sh.rc100_m);
-        const double cf = div_by_rcp(r_c, sh.cap_c, sh.rc_c);             // balanced_allocation.go:82-119
-        const double mf = div_by_rcp(r_m, sh.cap_m, sh.rc_m);
+        const double cf = div_by_rcp1(r_c, sh.cap_c, sh.rc_c);            // balanced_allocation.go:82-119; operands < 2^31 (simon_device.h)
+        const double mf = div_by_rcp1(r_m, sh.cap_m, sh.rc_m);
         const int bs = (int)((1.0 - __builtin_fabs(cf - mf)) * 100.0);
         const int base = ((la_c + la_m) >> 1) + ((ge_c || ge_m) ? 0 : bs);
         return ok ? (unsigned)(base + 1) : 0u;

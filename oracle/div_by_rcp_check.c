@@ -18,6 +18,13 @@ static double div_by_rcp(double num, double den, double rc) {
     return q;
 }
 
+/* one correction: exact for den < 2^31, num < 2^32 (proof in simon_device.h: div_by_rcp1) -- the score-table kernel's domain */
+static double div_by_rcp1(double num, double den, double rc) {
+    double q = num * rc;
+    double e = fma(-q, den, num);
+    return fma(e, rc, q);
+}
+
 static uint64_t state = 88172645463325252ull;
 static uint64_t rnd(void) { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; }
 
@@ -49,6 +56,26 @@ int main(int argc, char** argv) {
             }
         }
     }
-    printf("checked %ld operand pairs, %ld mismatches\n", n, bad);
-    return bad != 0;
+    /* the one-correction variant on ITS domain: denominators of 1..31 bits (random, 2^k - 1 - {0,1,2}, 2^(k-1) + {0..4}),
+     * numerators up to 2 den + 1, den - {0,1,2}, small, and up to 2^31 */
+    long n1 = 0, bad1 = 0;
+    for (int bits = 1; bits <= 31; bits++) {
+        for (long it = 0; it < iters * 4; it++) {
+            uint64_t den = (rnd() >> (64 - bits)) | 1ull;
+            if (bits > 1 && (it & 3) == 1) den = (1ull << bits) - 1 - (rnd() % 3);
+            if ((it & 3) == 2) den = (1ull << (bits - 1)) + (rnd() % 5);
+            if (den == 0) den = 1;
+            uint64_t num = rnd() % (2 * den + 2);
+            if ((it & 7) == 3) num = den - (rnd() % 3);
+            if ((it & 15) == 5) num = rnd() % 4096;
+            if ((it & 15) == 9) num = rnd() >> 33;
+            double d = (double)den, x = (double)num;
+            n1++;
+            if (div_by_rcp1(x, d, 1.0 / d) != x / d) {
+                if (bad1++ < 10) printf("MISMATCH(one correction) num=%llu den=%llu\n", (unsigned long long)num, (unsigned long long)den);
+            }
+        }
+    }
+    printf("checked %ld operand pairs, %ld mismatches; one-correction variant on its domain: %ld pairs, %ld mismatches\n", n, bad, n1, bad1);
+    return bad != 0 || bad1 != 0;
 }
