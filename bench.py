@@ -133,7 +133,7 @@ def pmc_replayed(kernel, scenarios, pods):
     return None, None
 
 
-def roofline_record(kname, variant, k_ms, launches, alg_bytes, pmc, source, workload):
+def roofline_record(kname, variant, k_ms, launches, alg_bytes, pmc, source, workload, lds_bytes=None, scenarios=None):
     """The roofline of the dominant kernel.  These kernels are integer / compare / fp64 work on an L2-resident score
     table: the binding resource is VALU issue (plus the dependent latency of one wave per scenario), so `frac` is the VALU
     issue fraction against the guide's peak (one wave64 VALU op per 2 cycles per SIMD).  The SURVEY 8(d) figure
@@ -150,6 +150,13 @@ def roofline_record(kname, variant, k_ms, launches, alg_bytes, pmc, source, work
                      "valu_rule": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op (MI355X_MICROARCH.md)",
                      "lds_bytes_per_clk_per_cu": LDS_BYTES_PER_CLK_CU},
            "counters_source": source}
+    if lds_bytes:
+        # one wave (workgroup) per scenario: the LDS it asks for bounds the resident waves per CU (profiles/micro/occupancy_probe.hip)
+        fit = min(32, int(160 * 1024 // max(int(lds_bytes), 1)))
+        rec["lds_bytes_per_workgroup"] = int(lds_bytes)
+        rec["workgroups_per_cu_that_fit"] = fit
+        if scenarios:
+            rec["workgroups_per_cu_offered"] = round(scenarios / N_CU, 2)
     if not pmc:
         rec["note"] = "no PMC counters available (rocprofv3 absent and no committed profile of this workload size): frac unmeasured"
         return rec
@@ -176,6 +183,12 @@ def roofline_record(kname, variant, k_ms, launches, alg_bytes, pmc, source, work
         # SQ_LDS_IDX_ACTIVE = LDS-array cycles summed over the CUs; the LDS of one CU serves one access group per cycle
         rec["lds_frac"] = round(lds_act / (N_CU * sec * CLOCK_HZ), 4)
         rec["lds_bank_conflict_cycles_frac"] = round((tot("SQ_LDS_BANK_CONFLICT") or 0.0) / max(lds_act, 1.0), 4)
+    va = tot("SQ_ACTIVE_INST_VALU")
+    if va is not None:
+        # SQ_ACTIVE_INST_VALU: quad-cycles in which a wave has a VALU instruction executing; one VALU per SIMD
+        rec["valu_pipe_busy_frac"] = round(va * 4 / (N_CU * N_SIMD * sec * CLOCK_HZ), 4)
+        if valu:
+            rec["cycles_per_valu_instruction"] = round(va * 4 / valu, 2)
     wc = tot("SQ_WAVE_CYCLES")
     if wc:
         split = {}
@@ -185,9 +198,11 @@ def roofline_record(kname, variant, k_ms, launches, alg_bytes, pmc, source, work
                 split[key] = round(v / wc, 3)
         rec["wave_time_split"] = split
     rec["instructions_per_step"] = {"valu": valu, "salu": salu, "lds": ldsi, "vmem_rd": tot("SQ_INSTS_VMEM_RD"), "vmem_wr": tot("SQ_INSTS_VMEM_WR")}
-    rec["note"] = ("frac = SQ_INSTS_VALU / kernel time / VALU issue peak.  One wave runs one scenario and its pods are strictly sequential, so "
-                   "the kernel sits between issue-bound and bound by the dependent chain of one scheduling cycle (DESIGN.md 5.3); HBM carries "
-                   "only the spill of the per-scenario score tables out of L2 (measured_hbm_frac).")
+    rec["note"] = ("frac = SQ_INSTS_VALU / kernel time / VALU issue peak (the guide's 2 cycles per wave64 op).  One wave runs one scenario and its "
+                   "pods are strictly sequential; with every scenario of the batch resident (16 waves per CU) the VALU pipe is the busiest "
+                   "resource (valu_pipe_busy_frac: the instruction mix -- fp64, DPP, readlane, v_perm -- averages cycles_per_valu_instruction), "
+                   "the rest is the dependent chain of a scheduling cycle (DESIGN.md 5.3); HBM / Infinity Cache carry the part of the "
+                   "per-scenario byte tables that does not stay in L2 (measured_hbm_frac).")
     return rec
 
 
@@ -458,7 +473,8 @@ def main():
             pmc, src = pmc_replayed(kname, S_local, prob.n_pods)
             if pmc:
                 source = f"replayed from the committed profile ({src}), not measured in this run"
-        out["roofline"] = roofline_record(kname, st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl)
+        out["roofline"] = roofline_record(kname, st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl,
+                                          lds_bytes=st.lds_bytes if st.workgroup_size == 64 else None, scenarios=S_local)
         # ---- the oracle: CPU baseline (N = 1) and parity of the timed batch ---------------------------------------
         if not args.no_cpu_baseline:
             if world == 1:
