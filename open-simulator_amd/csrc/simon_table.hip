@@ -258,7 +258,10 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int p = p0 + lane;
         const int d = class_of_pos(p < ni ? p : 0);
         const int r = p - s_seg[d];
-        const bool real = p < ni && r < __shfl(cnt_d, d, 64);
+        // the cross-lane read runs with EVERY lane active (as the right operand of && it ran only in the lanes with p < ni: in the last,
+        // partial chunk the lane holding class d's count could be inactive and read as 0 -- found by tests/fuzz_table.py)
+        const int cnt_of_d = __shfl(cnt_d, d, 64);
+        const bool real = p < ni && r < cnt_of_d;
         const int j = real ? cls_list[cls_off[d] + r] : 0;            // r-th node of class d in canonical order
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
         uint2 z = make_uint2(0, 0);
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             const unsigned m16 = row16_max_t(b ? ((b << 4) | (unsigned)(15 - (p & 15))) : 0u);
             if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
             if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
+
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -341,6 +345,9 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
         const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
         const int range = hi >= lo ? hi - lo : 0;
+#ifdef SIMON_TABLE_DEBUG
+        { const unsigned long long pm = __ballot(inb); if (lane == 0) printf("DBG s=%d RENORM k=%d c=%d present=%llx lo=%d hi=%d\n", s, k, c, pm, lo, hi); }
+#endif
         const double rr = range ? 1.0 / (double)range : 0.0;
         const int sn = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
         if (lane < Cn) {
@@ -548,12 +555,18 @@ __global__ __launch_bounds__(64) void table_kernel(
                         const int left = s_cnt[cidx] - 1;
                         s_cnt[cidx] = left;
                         if (left == 0) my_dirty |= 1u << q;               // the class term of row k changes: re-base before its next use
+#ifdef SIMON_TABLE_DEBUG
+                        printf("DBG s=%d step=%d CNT k=%d class=%d left=%d\n", s, i0 + il, kk[q], dstar, left);
+#endif
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // state update, eval, patch, block key, summary store
         }
+#ifdef SIMON_TABLE_DEBUG
+        if (lane == 0) printf("DBG s=%d step=%d sig=%d cls=%d pstar=%d dstar=%d res=%d top=%u ni=%d nblk=%d\n", s, i0 + il, r_sig, r_cls, pstar, dstar, res, top, ni, nblk);
+#endif
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
         plreg = (il == lane) ? res : plreg;
         }

@@ -1236,6 +1236,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             }
             NodeLoads L = load_state(A, v, j);
             NodeExtra X = load_extra(A, v, j);
+            if (kProfile && (A.flags & kArgProf) && L.rc + g_total + q0.req_cpu + gu[0] == -12345) continue;   // loads have arrived
+            SIMON_PROF(8);
             L.rc += p.req_cpu; L.rm += p.req_mem; L.np += 1;
             if (((A.flags & kArgNzeq) != 0u)) { L.zc = L.rc; L.zm = L.rm; } else { L.zc += p.nz_cpu; L.zm += p.nz_mem; }
             X.re += p.req_eph;
@@ -1244,6 +1246,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             if (gpu_pod) gpu_commit_regs(gu, g_cnt, g_total, p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt);
             if (use_tab && lane < A.n_sigs)
                 tab[(size_t)lane * nstride + j] = fit_bits(A, q0, L, X) ? 0 : (unsigned char)(1u + base_score(q0, L));
+            SIMON_PROF(10);
             if (owner) {
                 v.req_cpu[j] = L.rc; v.req_mem[j] = L.rm; v.npods[j] = L.np;
                 if (!((A.flags & kArgNzeq) != 0u)) { v.nz_cpu()[j] = L.zc; v.nz_mem()[j] = L.zm; }
@@ -1288,6 +1291,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     if (d >= 0) atomicAdd(&v.w_owner()[COLD(A)->term_dom_off[t] + d], COLD(A)->own_w[e]);
                 }
             }
+            SIMON_PROF(9);
             if (use_tab) {
                 for (int k = lane + 64; k < A.n_sigs; k += 64) {
                     const WideSig q = A.sigs[k];

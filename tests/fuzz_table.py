@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep aimed at the score-table kernel (simon_table.hip): cpu+memory problems at the sizes and shapes its
+templates switch on -- 1 ... 4 095 nodes (1, 2 or 4 blocks per lane), 1 ... 128 request signatures (one or two per lane), 1 ...
+64 internal node classes incl. caller classes that do NOT share their allocatable (the kernel refines them), presets, gates,
+pinned pods, static masks, initial state, NonZeroRequested != Requested, zero requests, tight pod counts, gcd-1 units.
+Not collected by pytest (a slice runs in tests/test_gpu_round2.py); by hand on a GPU box:
+    python tests/fuzz_table.py [n_cases] [first_seed]
+Every placement, unscheduled count and used cpu / memory is compared with the oracle."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conftest  # noqa: E402,F401
+import oracle_lib as O  # noqa: E402
+import randprob  # noqa: E402
+from open_simulator_amd import capi  # noqa: E402
+
+FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units"]
+
+
+def one_case(case):
+    rng = np.random.default_rng(41000 + case)
+    size = case % 4
+    N = int(rng.integers(1, 80)) if size == 0 else int(rng.integers(100, 1100)) if size == 1 else int(rng.integers(1100, 2100)) if size == 2 \
+        else int(rng.integers(2100, 4096))
+    P = int(rng.integers(20, 400 if size == 0 else 2500))
+    feat = {f: True for f in FEATURES if rng.random() < 0.3}
+    n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))
+    n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 65, 100, 128]))
+    if size == 3:                         # static masks are O(Cp N) Python work in the generator
+        feat.pop("static_mask", None)
+    prob = randprob.rand_problem(52000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
+    if rng.random() < 0.3:                # caller classes that do not determine the allocatable: the kernel splits them
+        shapes_c = np.array([4000, 8000, 16000, 32000]) + (rng.integers(0, 5, 4) if "odd_units" in feat else 0)
+        shapes_m = (np.array([8, 16, 64, 128]) << 30) + (rng.integers(0, 7, 4) if "odd_units" in feat else 0)
+        pick = rng.integers(0, 4, N)
+        if n_node_classes * 4 > 64:
+            pick = prob.node_class % 3
+        prob.alloc_cpu = shapes_c[pick].astype(np.int64)
+        prob.alloc_mem = shapes_m[pick].astype(np.int64)
+        if prob.init_req_cpu is not None:
+            prob.init_req_cpu = np.minimum(prob.init_req_cpu, prob.alloc_cpu // 2)
+            prob.init_req_mem = np.minimum(prob.init_req_mem, prob.alloc_mem // 2)
+            prob.init_nz_cpu = np.maximum(prob.init_nz_cpu, prob.init_req_cpu)
+            prob.init_nz_mem = np.maximum(prob.init_nz_mem, prob.init_req_mem)
+    S = int(rng.integers(1, 9))
+    scen, orders = randprob.rand_scenarios(case, prob, S=S, min_n=1 if rng.random() < 0.5 else None)
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        res = ctx.fetch(True)
+        st = ctx.stats()
+    ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
+          res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
+    n_sigs = len({(a, b, c, d, e) for a, b, c, d, e in zip(prob.req_cpu.tolist(), prob.req_mem.tolist(),
+                                                          (prob.nz_cpu if prob.nz_cpu is not None else prob.req_cpu).tolist(),
+                                                          (prob.nz_mem if prob.nz_mem is not None else prob.req_mem).tolist(), prob.pod_class.tolist())})
+    return ok, dict(case=case, N=N, P=P, S=S, classes=n_node_classes, pod_classes=n_pod_classes, sigs=n_sigs, feat=sorted(feat),
+                    variant=st.kernel_variant, generation=st.kernel_generation)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad, on_table = 0, 0
+    for case in range(first, first + n_cases):
+        ok, info = one_case(case)
+        on_table += info["generation"] == 4
+        if not ok:
+            bad += 1
+            print("MISMATCH", info, flush=True)
+    print(f"fuzz_table: {n_cases} cases from {first}, {on_table} on the score-table kernel, mismatches {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

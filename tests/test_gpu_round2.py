@@ -286,3 +286,17 @@ def test_c_consumer_of_the_abi(tmp_path):
     out = subprocess.run([exe, *fx], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "cabi_smoke ok" in out.stdout and out.stdout.count("group of 2 members") == 2
+
+
+def test_score_table_kernel_randomised_slice():
+    """A slice of tests/fuzz_table.py (random sizes up to 4 095 nodes, up to 128 signatures, caller classes that do not share
+    their allocatable, every cpu+memory feature) in the regular suite."""
+    import fuzz_table
+    bad, on_table = [], 0
+    for case in range(0, 24):
+        ok, info = fuzz_table.one_case(case)
+        on_table += info["generation"] == 4
+        if not ok:
+            bad.append(info)
+    assert not bad, bad
+    assert on_table >= 12, "the slice should mostly run on the score-table kernel"
