@@ -305,8 +305,9 @@ typedef struct simon_stats {
     int32_t workgroup_size;
     int32_t slots_per_lane;
     int64_t lds_bytes;
-    int32_t kernel_generation;     /* of the cpu+memory path: 1 register-resident, 2 scalarised, 3 class-major score table
-                                      (simon_cache.hip), 4 pre-keyed score table in canonical order (simon_table.hip) */
+    int32_t kernel_generation;     /* of the cpu+memory path: 1 register-resident, 2 scalarised, 4 class-major (signature, node)
+                                      score table with block summaries in LDS (simon_table.hip), 5 the same with a two-level
+                                      summary (64-position entries in LDS, 16-position entries in HBM) for many signatures */
     int32_t reserved;
 } simon_stats;
 

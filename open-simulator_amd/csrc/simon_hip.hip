@@ -82,6 +82,7 @@ struct simon_ctx : simon::HostInputs {
     int force_T = 0;  // env SIMON_WG
     bool force_v1 = false;  // env SIMON_NARROW_V1: use simon_narrow.hip even when simon_fast.hip applies
     bool force_wide = false;  // env SIMON_FORCE_WIDE
+    int n_cus = 256;          // compute units of the device (simon_ctx_create)
     size_t lds_pad = 0;       // env SIMON_CACHE_LDS_PAD (bytes): occupancy experiment knob -- extra LDS per workgroup
     // ---- device buffers ----
     DevBuf<uint32_t> d_a_cpu, d_a_mem, d_i_rq_cpu, d_i_rq_mem, d_i_nz_cpu, d_i_nz_mem;
@@ -100,8 +101,8 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_t_ncls, d_rank, d_clsprefix, d_inv_orders, d_place_step, d_cls_list, d_cls_off, d_t_raw;
     std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn_t]; padded (class-major) size of every loaded scenario
     size_t ws_total = 0;
-    bool table_sumg = false;                     // summary rows in the HBM workspace instead of LDS (decided per loaded batch)
-    int force_sumg = -1, table_ni_top = 16;      // env SIMON_TABLE_SUMG = 0 / 1 (A/B)
+    bool table_coarse = false;                   // two-level summary (simon_table.hip: COARSE), decided per loaded batch
+    int force_coarse = -1, table_ni_top = 16;    // env SIMON_TABLE_COARSE = 0 / 1 (A/B)
     std::vector<int32_t> h_perm;
     std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
     DevBuf<uint64_t> d_mask;
@@ -419,13 +420,14 @@ simon_ctx* simon_ctx_create(int device_id) {
         delete c;
         return nullptr;
     }
+    { int n_cu = 0; if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && n_cu > 0) c->n_cus = n_cu; }
     // Tuning / experiment knobs: every environment variable is read HERE, once per context; none changes a result.
     if (const char* e = getenv("SIMON_WG")) c->force_T = atoi(e);
     if (const char* e = getenv("SIMON_RCP_DIV")) c->rcp_div = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NARROW_V1")) c->force_v1 = atoi(e) != 0;
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
-    if (const char* e = getenv("SIMON_TABLE_SUMG")) c->force_sumg = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
@@ -695,24 +697,43 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             }
         // padded class-major size of every scenario; workspace slice of every workgroup (launch order = perm)
         const int Ct = c->Cn_t;
+        std::vector<int> ni16(S), ni64(S);
+        int top16 = 16, top64 = 64;
         for (int s = 0; s < S; ++s) {
-            int ni = 0;
-            for (int d = 0; d < Ct; ++d) ni += (c->h_clsprefix[(size_t)scen[s].n_nodes * Ct + d] + 15) & ~15;
-            c->scen_ni[s] = std::max(ni, 16);
+            int a = 0, b = 0;
+            for (int d = 0; d < Ct; ++d) {
+                const int cnt = c->h_clsprefix[(size_t)scen[s].n_nodes * Ct + d];
+                a += (cnt + 15) & ~15; b += (cnt + 63) & ~63;
+            }
+            ni16[s] = std::max(a, 16); ni64[s] = std::max(b, 64);
+            top16 = std::max(top16, ni16[s]); top64 = std::max(top64, ni64[s]);
         }
         if (is_perm) {
-            // Where do the summary rows live?  In LDS -- unless they do not fit a workgroup's 64 KB (128 signatures x 4 000 nodes):
-            // then they go to the scenario's HBM workspace.  (Measured, profiles/README.md: the HBM variant costs +10 % at low
-            // occupancy and +60 % at 4 096 scenarios -- its extra footprint pushes the batch out of the Infinity Cache -- so it is
-            // only the fallback, never the choice for a batch whose LDS summary merely lowers the waves per CU.)
-            int ni_top = 16;
-            for (int s = 0; s < S; ++s) ni_top = std::max(ni_top, c->scen_ni[s]);
-            const size_t lds_full = table_lds_bytes(c->n_sigs, ni_top, Ct, false) + c->lds_pad;
-            c->table_sumg = c->force_sumg >= 0 ? c->force_sumg != 0 : lds_full > 64 * 1024;
+            // One-level or two-level summary (simon_table.hip: tcarve)?  The LDS of a workgroup decides how many scenario waves a CU
+            // holds (allocation granularity 1 280 B, 160 KB, at most 32 single-wave workgroups: profiles/micro/occupancy_probe.hip),
+            // and a batch that offers more runs in rounds.  The two-level form needs a quarter of the LDS but costs an 8-byte load and
+            // ~15 VALU per signature and cycle more (+19 % per wave, measured).  Cost model fitted to profiles/README.md (config 3:
+            // 256 scenarios 7.7 ms, 4 096 14.0 ms, 8 192 27.5 ms one-level / 32.3 ms two-level; 100 signatures 39.5 / 32.1 ms):
+            // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
+            auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
+            const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true) + c->lds_pad;
+            const bool fine_ok = top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
+            const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
+            auto cost = [&](int fits, double factor) {
+                auto round_cost = [](int w) { return 1.0 + 0.055 * (std::min(w, 16) - 1) + 0.11 * std::max(w - 16, 0); };
+                double t = 0;
+                for (int left = per_cu; left > 0; left -= fits) t += round_cost(std::min(left, fits));
+                return t * factor;
+            };
+            bool coarse = coarse_ok && (!fine_ok || cost(std::max(fit(lds64), 1), 1.2) < 0.95 * cost(std::max(fit(lds16), 1), 1.0));
+            if (c->force_coarse >= 0) coarse = c->force_coarse ? coarse_ok : !fine_ok && coarse_ok;
+            c->table_coarse = coarse;
+            for (int s = 0; s < S; ++s) c->scen_ni[s] = coarse ? ni64[s] : ni16[s];
+            const int ni_top = coarse ? top64 : top16;
             c->table_ni_top = ni_top;
             std::vector<unsigned long long> ws_off(S);
             size_t off = 0;
-            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, c->table_sumg, ni_top); }
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct); }
             c->ws_total = off;
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
@@ -777,9 +798,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_sumg) + c->lds_pad : 0;
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse) + c->lds_pad : 0;
         const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kTableMaxNodes &&
-                               ni_top <= kTableMaxPadded && table_lds <= 64 * 1024;
+                               ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         if ((c->has_pin || too_big) && !use_table) run_wide = true;
         if (run_wide) {
@@ -802,7 +823,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.sumg = c->table_sumg;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -820,7 +841,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                         S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[6] / S / P, acc[7] / S / P);
             }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
-            T = 64; slots = (ni_top / 16 + 63) / 64; lds = table_lds;
+            T = 64; slots = (ni_top / (c->table_coarse ? 64 : 16) + 63) / 64; lds = table_lds;
             c->stats.n_launches = 1;
             table_used = true;
         } else if (c->fast_ok && !c->force_v1 && T >= 128) {
@@ -885,7 +906,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     c->stats.kernel_ms = ms;
     c->stats.n_launches = 1;
     c->stats.kernel_variant = variant_used;
-    c->stats.kernel_generation = table_used ? 4 : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
+    c->stats.kernel_generation = table_used ? (c->table_coarse ? 5 : 4) : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;
     c->stats.lds_bytes = (int64_t)lds;

@@ -29,7 +29,7 @@ struct PodRowC { int32_t sig, preset, gate, cls; };   // 16 B: signature, preset
 
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
-    int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096)
+    int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
     uint64_t g_cpu, g_mem;
 };
 
@@ -45,19 +45,20 @@ struct TableLaunch {
     const TableCold* cold;      // device pointer
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
-    unsigned char* ws;   // HBM workspace: byte table + node state (+ summary rows when sumg) of every scenario of the launch
-    bool sumg;           // summary rows in the workspace instead of LDS
+    unsigned char* ws;   // HBM workspace: byte table + node state (+ per-16 summary entries and counters when coarse) of every scenario
+    bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
     TableScalars sc;
 };
 
 constexpr int kTableMaxNodes = 4095;    // canonical index and padded position are 12-bit fields of the arg-max keys
-constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario
+constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario (classes padded to 16)
+constexpr int kTableMaxPaddedCoarse = 8192;   // ... with the two-level summary (classes padded to 64)
 constexpr int kTableMaxSigs = 128;      // two signatures per lane
 constexpr size_t kTableLdsPerCU = 160 * 1024;
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool sumg);          // LDS per workgroup for padded scenario sizes up to ni_max
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool sumg, int ni_max); // HBM workspace of ONE scenario with ni padded positions
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse);        // LDS per workgroup for padded scenario sizes up to ni_max
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn);  // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

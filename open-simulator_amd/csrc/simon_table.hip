@@ -136,27 +136,33 @@ __host__ __device__ inline int table_nbp(int nblk) { return (nblk & 1) || (nblk 
 // LDS per workgroup decides how many scenario waves a CU holds: 160 KB / 16 = 10 KB (measured, profiles/micro/occupancy_probe.hip:
 // 10 240 B -> 16 workgroups per CU, 12 288 B -> 12), so everything but the summary is kept tiny: no per-position arrays (the shape
 // of a node follows from its class), Simon raw scores stay in global memory (read on the rare re-base only).
-__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool sumg) {
+//
+// COARSE (two-level summary): the LDS entry covers 64 positions instead of 16 -- a quarter of the LDS, so that batches with many
+// signatures keep 16+ scenario waves per CU -- and the per-16 entries move to the scenario's HBM workspace, where only the assume
+// reads them (4 entries = 8 bytes per signature, fetched with the table row, off the dependent chain); the feasible-node counters
+// move there too (touched on the rare cycle a node becomes infeasible for a signature).  Classes are then padded to 64 positions.
+__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse) {
     auto al = [](int x) { return (x + 15) & ~15; };
     TCarve c;
-    c.nbp = table_nbp(ni_max / 16);
+    c.nbp = table_nbp(ni_max / (coarse ? 64 : 16));
     int o = 0;
-    c.sum = o; o += sumg ? 0 : al(K * c.nbp * 2);     // SUMG: the summary lives in the scenario's HBM workspace instead
-    c.sn = o; o += al(K * Cn * 2);
-    c.cnt = o; o += al(K * Cn * 4);
+    c.sum = o; o += al(K * c.nbp * 2);
+    c.sn = o; o += al(K * Cn);
+    c.cnt = o; o += coarse ? 0 : al(K * Cn * 4);
     c.shape = o; o += Cn * 48;
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
     c.total = o;
     return c;
 }
-// HBM workspace of ONE scenario with `ni` padded positions: byte table [ni / 16][K][16], node state [ni] x 12 B, and (when
-// NonZeroRequested differs from Requested) [ni] x 8 B
-__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool sumg, int nbp) {
+// HBM workspace of ONE scenario with `ni` padded positions: byte table [ni / 16][K][16], node state [ni] x 12 B, (when
+// NonZeroRequested differs from Requested) [ni] x 8 B, and (COARSE) the per-16 summary entries [ni / 64][K][4] u16 and the
+// feasible-node counters [K][Cn] i32
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
-    if (sumg) w += ((size_t)K * nbp * 2 + 127) & ~(size_t)127;
+    if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
     return w;
 }
 
@@ -164,9 +170,8 @@ __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool sum
 // branch costs the common kernel time).
 // NBQ: blocks per lane (1, 2 or 4: padded scenario sizes up to 1024 / 2048 / 4096 positions) -- a template parameter so that the
 // scan is straight-line code (as run-time conditions the four reads became four dependent LDS round trips).
-// SUMG: the summary rows live in HBM (L2) instead of LDS -- for batches whose LDS summary would not let the CU hold the waves the
-// batch offers (many signatures x many blocks); the scan then costs an L2 round trip instead of an LDS one.
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool SUMG>
+// NBQ counts summary ENTRIES per lane: 16 positions each, or 64 with COARSE (tcarve, above).
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -183,10 +188,15 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int32_t* __restrict__ const simon_raw = cold->simon_raw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, SUMG);
+    constexpr int UB = COARSE ? 6 : 4;                                // log2(positions per summary entry)
+    constexpr int UNIT = 1 << UB;
+    constexpr unsigned UMASK = UNIT - 1;
+    constexpr int KB = COARSE ? 13 : 12;                              // width of the position field of the arg-max key
+    constexpr unsigned PMASK = (1u << KB) - 1u;
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE);
     const int nbp = cv.nbp;
-    unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term currently folded into row k
-    int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k
+    unsigned char* s_sn = smem + cv.sn;                             // [K][Cn]: the class term (<= 200) currently folded into row k
+    int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k (!COARSE)
     const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);   // [Cn]: shape of a node class (a class shares its allocatable)
     int* s_seg = (int*)(smem + cv.seg);                             // [Cn + 1]: first position of a class segment
     int* s_tmp = (int*)(smem + cv.tmp);
@@ -199,11 +209,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
-    for (int i = lane; i < K * Cn; i += 64) { s_cnt[i] = 0; s_sn[i] = 0; }
+    for (int i = lane; i < K * Cn; i += 64) { if (!COARSE) s_cnt[i] = 0; s_sn[i] = 0; }
     for (int i = lane; i < Cn * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
-    // count of class-d nodes among the first n canonical nodes, padded to 16
+    // count of class-d nodes among the first n canonical nodes, padded to 16 (COARSE: to 64, one class per summary entry)
     const int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
-    const int pad_d = (cnt_d + 15) & ~15;
+    const int pad_d = (cnt_d + (UNIT - 1)) & ~(UNIT - 1);
     int incl = pad_d;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -212,18 +222,18 @@ __global__ __launch_bounds__(64) void table_kernel(
     }
     if (lane <= Cn) s_seg[lane] = incl - pad_d;                       // lane Cn holds ni (classes beyond Cn add nothing)
     const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size
-    const int nblk = ni >> 4;
+    const int nblk = ni >> 4, nun = ni >> UB;                         // table blocks (16 positions); summary entries
     unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
     NodeState* g_state = (NodeState*)(wsb + (((size_t)nblk * Krow + 127) & ~(size_t)127));
     uint2* g_nz = (uint2*)((unsigned char*)g_state + (((size_t)ni * 12 + 127) & ~(size_t)127));   // NonZeroRequested (only when !NZEQ)
-    // [K][nbp]: (best byte + class term) << 4 | 15 - position -- in LDS, or (SUMG) behind the node state in the workspace.  The two
-    // definitions are compile-time alternatives so that each instantiation addresses ONE address space.
-    unsigned short* s_sum;
-    if constexpr (SUMG) s_sum = (unsigned short*)((unsigned char*)g_nz + (NZEQ ? 0 : (((size_t)ni * 8 + 127) & ~(size_t)127)));
-    else s_sum = (unsigned short*)(smem + cv.sum);
+    // COARSE: per-16 entries [ni / 64][K][4] u16 and feasible-node counters [K][Cn] behind the node state
+    unsigned short* g_fine = (unsigned short*)((unsigned char*)g_nz + (NZEQ ? 0 : (((size_t)ni * 8 + 127) & ~(size_t)127)));
+    int* g_cnt = (int*)((unsigned char*)g_fine + (((size_t)(ni >> 6) * K * 8 + 127) & ~(size_t)127));
+    // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
+    unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
     if (lane == 0 && ((K * nbp) & 1)) s_sum[K * nbp - 1] = 0;
-    if (SUMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (COARSE) for (int i = lane; i < K * Cn; i += 64) g_cnt[i] = 0;
     __syncthreads();
 
     // class of a position (segments are contiguous): number of segment ENDS at or below it
@@ -284,8 +294,19 @@ __global__ __launch_bounds__(64) void table_kernel(
             if (p < ni) tp[k * 16] = (unsigned char)b;
             // class term still 0: every signature starts dirty and is re-based at its first use
             const unsigned m16 = row16_max_t(b ? ((b << 4) | (unsigned)(15 - (p & 15))) : 0u);
-            if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
-            if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
+            if constexpr (COARSE) {                                   // the 64 lanes are ONE summary entry of ONE class
+                if ((lane & 15) == 0) g_fine[((size_t)(p0 >> 6) * K + k) * 4 + (lane >> 4)] = (unsigned short)m16;
+                const unsigned cand = m16 ? (((m16 & 0xFFF0u) << 2) | ((3u - (unsigned)(lane >> 4)) << 4) | (m16 & 15u)) : 0u;
+                const unsigned c64 = wave_max_u32(cand);
+                const int nfe = __popcll(__ballot(b != 0));
+                if (lane == 0) {
+                    s_sum[k * nbp + (p0 >> 6)] = (unsigned short)c64;
+                    if (nfe) atomicAdd(&g_cnt[k * Cn + d], nfe);
+                }
+            } else {
+                if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
+                if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
+            }
 
         }
     }
@@ -311,15 +332,15 @@ __global__ __launch_bounds__(64) void table_kernel(
         koff[q] = (unsigned)kk[q] * 16u;
         if (kvalid[q]) my_dirty |= 1u << q;
     }
-    // this lane's blocks (lane, lane + 64, ...): constant of the arg-max key (low field = 4095 - position), node class, and
-    // offset of the block's class segment into the static per-class node lists (index of position p = boff + p; packed with
-    // the class: one readlane fetches both for the winning block)
+    // this lane's summary entries (lane, lane + 64, ...): constant of the arg-max key (low field = PMASK - position), node class,
+    // and offset of the entry's class segment into the static per-class node lists (index of position p = boff + p; packed with
+    // the class: one readlane fetches both for the winning entry)
     int cb[NBQ], bcls[NBQ], binfo[NBQ];
 #pragma unroll
     for (int q = 0; q < NBQ; ++q) {
         const int b = q * 64 + lane;
-        cb[q] = (255 - b) << 4;                                           // 4095 - position = (255 - b) << 4 | 15 - pos
-        bcls[q] = class_of_pos(b < nblk ? b * 16 : 0);
+        cb[q] = (((int)(PMASK >> UB)) - b) << UB;                         // PMASK - position = (last entry - b) << UB | UNIT - 1 - pos
+        bcls[q] = class_of_pos(b < nun ? b * UNIT : 0);
         binfo[q] = (cls_off[bcls[q]] - s_seg[bcls[q]] + 8192) | (bcls[q] << 16);
     }
 
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     // NormalizeScore (pkg/simulator/plugin/simon.go:76-101) over the classes present, x 2 (both plugins, weight 1 each).
     auto renormalise = [&](int k, int c) {
         const int dd = lane < Cn ? lane : 0;
-        const int cn = (lane < Cn) ? s_cnt[k * Cn + dd] : 0;
+        const int cn = (lane < Cn) ? (COARSE ? g_cnt[k * Cn + dd] : s_cnt[k * Cn + dd]) : 0;
         const bool inb = cn > 0;
         const int rawc = simon_raw[c * Cn + dd];                      // global: this path runs a handful of times per signature
         const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
@@ -351,20 +372,30 @@ __global__ __launch_bounds__(64) void table_kernel(
         const double rr = range ? 1.0 / (double)range : 0.0;
         const int sn = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
         if (lane < Cn) {
-            s_tmp[dd] = (sn - (int)s_sn[k * Cn + dd]) * 16;
-            s_sn[k * Cn + dd] = (unsigned short)sn;
+            s_tmp[dd] = sn - (int)s_sn[k * Cn + dd];
+            s_sn[k * Cn + dd] = (unsigned char)sn;
         }
         __syncthreads();
         unsigned short* srow = s_sum + k * nbp;
 #pragma unroll
         for (int q = 0; q < NBQ; ++q) {
             const int b = q * 64 + lane;
-            if (b < nblk) {
+            if (b < nun) {
+                const int delta = s_tmp[bcls[q]];
                 const unsigned m = srow[b];
-                if (m) srow[b] = (unsigned short)((int)m + s_tmp[bcls[q]]);
+                if (m) srow[b] = (unsigned short)((int)m + delta * UNIT);
+                if constexpr (COARSE) {                               // the four per-16 entries behind this entry (same class)
+                    uint2* fp = (uint2*)(g_fine + ((size_t)b * K + k) * 4);
+                    uint2 f = *fp;
+                    auto shift2 = [&](unsigned w) -> unsigned {         // both u16 halves: non-zero entries move by delta << 4
+                        const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+                        return ((lo ? (unsigned)((int)lo + delta * 16) : 0u) & 0xFFFFu) | ((hi ? (unsigned)((int)hi + delta * 16) : 0u) << 16);
+                    };
+                    f.x = shift2(f.x); f.y = shift2(f.y);
+                    *fp = f;
+                }
             }
         }
-        if (SUMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
 
@@ -428,32 +459,32 @@ __global__ __launch_bounds__(64) void table_kernel(
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
-            // -------- summary scan: one u16 per block of 16 nodes ------------------------------------
+            // -------- summary scan: one u16 per 16 (COARSE: 64) positions ------------------------------
             const unsigned short* srow = s_sum + k * nbp;
             unsigned key = 0;
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
                 const int b = q * 64 + lane;
-                // a lane beyond the last block re-reads block 0: the duplicate ties on the total and loses on the position
-                m16q[q] = srow[b < nblk ? b : 0];
+                // a lane beyond the last entry re-reads entry 0: the duplicate ties on the total and loses on the position
+                m16q[q] = srow[b < nun ? b : 0];
             }
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
-                // (total + 1) << 12 | (255 - b) << 4 | 15 - pos  ==  (total + 1) << 12 | 4095 - position; an entry of 0 (no feasible
-                // node in the block) stays below 4096
+                // (total + 1) << KB | (last - b) << UB | UNIT - 1 - pos  ==  (total + 1) << KB | PMASK - position; an entry of 0 (no
+                // feasible node behind it) stays below 1 << KB
                 const unsigned m16 = m16q[q];
-                key = max(key, (((m16 << 8) & 0xFFF000u) | (unsigned)cb[q]) | (m16 & 15u));
+                key = max(key, (((m16 << (KB - UB)) & ~PMASK) | (unsigned)cb[q]) | (m16 & UMASK));
             }
             TPROF_WAIT_LDS; TPROF(1);                                  // pod row, dirty check, summary row arrived
             key = wave_max_u32(key);
             TPROF(2);                                                  // key build + wave max
-            if (key < 4096u) {                                         // FitError: pod deleted, state unchanged
+            if (key <= PMASK) {                                        // FitError: pod deleted, state unchanged
                 ++unsched;
                 res = -1;
             } else {
-                pstar = 4095 - (int)(key & 4095u);                     // first maximum in POSITION order (speculative: tie check below)
-                top = key >> 12;
-                const int info = winner_info(pstar >> 4);
+                pstar = (int)(PMASK - (key & PMASK));                  // first maximum in POSITION order (speculative: tie check below)
+                top = key >> KB;
+                const int info = winner_info(pstar >> UB);
                 dstar = info >> 16;
                 res = (info & 0xFFFF) - 8192 + pstar;                  // index into cls_list
                 scanned = true;
@@ -466,12 +497,14 @@ __global__ __launch_bounds__(64) void table_kernel(
             NodeState st = g_state[pstar];
             unsigned char* rowp[KQ];
             uint4 T[KQ];
+            uint2 F[KQ];                                               // COARSE: the four per-16 entries of (signature, touched 64 positions)
             unsigned oldq[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);   // uniform table base + 32-bit byte offset
                 T[q] = *(const uint4*)rowp[q];
                 oldq[q] = rowp[q][pstar & 15];                         // this signature's byte before the cycle (same cache line as the row)
+                if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
             }
             uint2 z = make_uint2(0, 0);
             if (!NZEQ) z = g_nz[pstar];
@@ -479,7 +512,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 // Position order is canonical order inside a class only: do blocks of ANOTHER class reach the same total?
                 bool other = false;
 #pragma unroll
-                for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> 4) == top && bcls[q] != dstar);   // duplicates carry block 0's class
+                for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> UB) == top && bcls[q] != dstar);   // duplicates carry entry 0's class
                 if (__ballot(other)) {                                 // rare (0.2 % of the cycles of config 3): first maximum in CANONICAL order
 #ifdef SIMON_TABLE_PROFILE
                     tp_acc[7] += 1;                                    // how often the canonical tie-break runs
@@ -488,20 +521,20 @@ __global__ __launch_bounds__(64) void table_kernel(
                     int canon[NBQ];
 #pragma unroll
                     for (int q = 0; q < NBQ; ++q) {
-                        const int pq = (q * 64 + lane) * 16 + 15 - (int)(m16q[q] & 15u);
-                        const bool tied = (m16q[q] >> 4) == top && q * 64 + lane < nblk;
+                        const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
+                        const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
                         canon[q] = tied ? cls_list[(binfo[q] & 0xFFFF) - 8192 + pq] : 4095;
                     }
 #pragma unroll
                     for (int q = 0; q < NBQ; ++q) {
-                        const int pq = (q * 64 + lane) * 16 + 15 - (int)(m16q[q] & 15u);
-                        if ((m16q[q] >> 4) == top && q * 64 + lane < nblk) key2 = max(key2, ((4095u - (unsigned)canon[q]) << 12) | (unsigned)pq);
+                        const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
+                        if ((m16q[q] >> UB) == top && q * 64 + lane < nun) key2 = max(key2, ((4095u - (unsigned)canon[q]) << KB) | (unsigned)pq);
                     }
                     key2 = wave_max_u32(key2);
-                    const int p2 = (int)(key2 & 4095u);
+                    const int p2 = (int)(key2 & PMASK);
                     if (p2 != pstar) {                                 // the speculated winner loses the tie: load the real one
                         pstar = p2;
-                        const int info = winner_info(pstar >> 4);
+                        const int info = winner_info(pstar >> UB);
                         dstar = info >> 16;
                         res = (info & 0xFFFF) - 8192 + pstar;
                         st = g_state[pstar];
@@ -510,6 +543,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                             rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);
                             T[q] = *(const uint4*)rowp[q];
                             oldq[q] = rowp[q][pstar & 15];
+                            if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
                         }
                         if (!NZEQ) z = g_nz[pstar];
                     }
@@ -549,11 +583,28 @@ __global__ __launch_bounds__(64) void table_kernel(
                 if (kvalid[q] && nb != old) {
                     rowp[q][pos] = (unsigned char)nb;
                     const unsigned m = block_key16_patched(T[q], nb, selA, selB);
-                    s_sum[kk[q] * nbp + blk] = (unsigned short)((m >> 4) ? m + (snq[q] << 4) : 0u);
+                    const unsigned e16 = (m >> 4) ? m + (snq[q] << 4) : 0u;
+                    if constexpr (COARSE) {
+                        // per-16 entry to the workspace; the entry of the 64 positions = max over its four per-16 entries, each
+                        // re-keyed to total << 6 | 63 - position (a feasible entry is >= 64, the constants alone stay below)
+                        const int j = blk & 3;                            // uniform
+                        g_fine[((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u + (unsigned)j] = (unsigned short)e16;
+                        const unsigned keep = (j & 1) ? 0x0000FFFFu : 0xFFFF0000u, ins = e16 << ((j & 1) * 16);
+                        const unsigned fx = (j & 2) ? F[q].x : ((F[q].x & keep) | ins);
+                        const unsigned fy = (j & 2) ? ((F[q].y & keep) | ins) : F[q].y;
+                        const unsigned cx = (((fx & 0xFFF0FFF0u) << 2) | (fx & 0x000F000Fu)) | 0x00200030u;
+                        const unsigned cy = (((fy & 0xFFF0FFF0u) << 2) | (fy & 0x000F000Fu)) | 0x00000010u;
+                        const unsigned mm = pkmax_t(cx, cy);
+                        const unsigned c64 = max(mm & 0xFFFFu, mm >> 16);
+                        s_sum[kk[q] * nbp + (pstar >> 6)] = (unsigned short)(c64 >= 64u ? c64 : 0u);
+                    } else {
+                        s_sum[kk[q] * nbp + blk] = (unsigned short)e16;
+                    }
                     if (!nb) {                                            // the node stopped being feasible for this signature
                         const int cidx = kk[q] * Cn + dstar;
-                        const int left = s_cnt[cidx] - 1;
-                        s_cnt[cidx] = left;
+                        int left;
+                        if constexpr (COARSE) left = atomicSub(&g_cnt[cidx], 1) - 1;
+                        else { left = s_cnt[cidx] - 1; s_cnt[cidx] = left; }
                         if (left == 0) my_dirty |= 1u << q;               // the class term of row k changes: re-base before its next use
 #ifdef SIMON_TABLE_DEBUG
                         printf("DBG s=%d step=%d CNT k=%d class=%d left=%d\n", s, i0 + il, kk[q], dstar, left);
@@ -611,27 +662,26 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool SUMG>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE>
 static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, SUMG>;
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
     return hipGetLastError();
 }
-template <bool M, bool Z, bool PIN, int KQ, int NBQ>
-static hipError_t launch_t5(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    return a.sumg ? launch_t6<M, Z, PIN, KQ, NBQ, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, NBQ, false>(a, n_blocks, lds, st);
-}
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
+        return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 2, true>(a, n_blocks, lds, st);
+    }
     const int nblk = a.sc.ni_max / 16;
-    return nblk <= 64 ? launch_t5<M, Z, PIN, KQ, 1>(a, n_blocks, lds, st)
-           : nblk <= 128 ? launch_t5<M, Z, PIN, KQ, 2>(a, n_blocks, lds, st) : launch_t5<M, Z, PIN, KQ, 4>(a, n_blocks, lds, st);
+    return nblk <= 64 ? launch_t6<M, Z, PIN, KQ, 1, false>(a, n_blocks, lds, st)
+           : nblk <= 128 ? launch_t6<M, Z, PIN, KQ, 2, false>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 4, false>(a, n_blocks, lds, st);
 }
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool sumg) { return (size_t)tcarve(K, ni_max, Cn, sumg).total; }
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool sumg, int ni_max) { return table_ws_of(K, ni, nzeq, sumg, table_nbp(ni_max / 16)); }
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse) { return (size_t)tcarve(K, ni_max, Cn, coarse).total; }
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn) { return table_ws_of(K, ni, nzeq, coarse, Cn); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {

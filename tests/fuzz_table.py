@@ -2,7 +2,8 @@
 """Randomised parity sweep aimed at the score-table kernel (simon_table.hip): cpu+memory problems at the sizes and shapes its
 templates switch on -- 1 ... 4 095 nodes (1, 2 or 4 blocks per lane), 1 ... 128 request signatures (one or two per lane), 1 ...
 64 internal node classes incl. caller classes that do NOT share their allocatable (the kernel refines them), presets, gates,
-pinned pods, static masks, initial state, NonZeroRequested != Requested, zero requests, tight pod counts, gcd-1 units.
+pinned pods, static masks, initial state, NonZeroRequested != Requested, zero requests, tight pod counts, gcd-1 units.  Every
+third case forces the two-level summary (SIMON_TABLE_COARSE=1: classes padded to 64, per-16 entries in HBM).
 Not collected by pytest (a slice runs in tests/test_gpu_round2.py); by hand on a GPU box:
     python tests/fuzz_table.py [n_cases] [first_seed]
 Every placement, unscheduled count and used cpu / memory is compared with the oracle."""
@@ -20,7 +21,8 @@ from open_simulator_amd import capi  # noqa: E402
 FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units"]
 
 
-def one_case(case):
+def one_case(case, coarse=None):
+    coarse = (case % 3 == 2) if coarse is None else coarse
     rng = np.random.default_rng(41000 + case)
     size = case % 4
     N = int(rng.integers(1, 80)) if size == 0 else int(rng.integers(100, 1100)) if size == 1 else int(rng.integers(1100, 2100)) if size == 2 \
@@ -48,7 +50,15 @@ def one_case(case):
     S = int(rng.integers(1, 9))
     scen, orders = randprob.rand_scenarios(case, prob, S=S, min_n=1 if rng.random() < 0.5 else None)
     ref = O.run_threaded(prob, scen, orders)
-    with capi.Context(0) as ctx:
+    saved = os.environ.get("SIMON_TABLE_COARSE")
+    if saved is None:
+        os.environ["SIMON_TABLE_COARSE"] = "1" if coarse else "0"      # read once, when the context is created
+    try:
+        ctx = capi.Context(0)
+    finally:
+        if saved is None:
+            del os.environ["SIMON_TABLE_COARSE"]
+    with ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
         ctx.run_loaded(True)
@@ -66,14 +76,16 @@ def one_case(case):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, on_table = 0, 0
+    bad, on_table, two_level = 0, 0, 0
     for case in range(first, first + n_cases):
         ok, info = one_case(case)
-        on_table += info["generation"] == 4
+        on_table += info["generation"] in (4, 5)
+        two_level += info["generation"] == 5
         if not ok:
             bad += 1
             print("MISMATCH", info, flush=True)
-    print(f"fuzz_table: {n_cases} cases from {first}, {on_table} on the score-table kernel, mismatches {bad}")
+    print(f"fuzz_table: {n_cases} cases from {first}, {on_table} on the score-table kernel ({two_level} with the two-level summary), "
+          f"mismatches {bad}")
     return 1 if bad else 0
 
 

@@ -292,11 +292,59 @@ def test_score_table_kernel_randomised_slice():
     """A slice of tests/fuzz_table.py (random sizes up to 4 095 nodes, up to 128 signatures, caller classes that do not share
     their allocatable, every cpu+memory feature) in the regular suite."""
     import fuzz_table
-    bad, on_table = [], 0
+    bad, on_table, two_level = [], 0, 0
     for case in range(0, 24):
         ok, info = fuzz_table.one_case(case)
-        on_table += info["generation"] == 4
+        on_table += info["generation"] in (4, 5)
+        two_level += info["generation"] == 5
         if not ok:
             bad.append(info)
     assert not bad, bad
     assert on_table >= 12, "the slice should mostly run on the score-table kernel"
+    assert two_level >= 3, "every third case forces the two-level summary"
+
+
+def _run_two_level(prob, scen, orders, monkeypatch):
+    monkeypatch.setenv("SIMON_TABLE_COARSE", "1")           # read once per context (simon_ctx_create)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        return ctx.fetch(True), ctx.stats()
+
+
+@pytest.mark.parametrize("n_sigs", [42, 100, 126])
+def test_two_level_summary_config3(n_sigs, monkeypatch):
+    """Generation 5 (LDS entries of 64 positions, per-16 entries and counters in the HBM workspace) on config-3 shaped batches."""
+    prob, scen, orders = synth.config3(n_counts=48, n_orders=3, n_pods=6000, n_sigs=n_sigs)
+    sub = scen[1::6]
+    ref = O.run_threaded(prob, sub, orders)
+    res, st = _run_two_level(prob, sub, orders, monkeypatch)
+    assert st.kernel_generation == 5
+    assert_same(res, ref)
+
+
+def test_two_level_summary_large_pool(monkeypatch):
+    prob, scen, orders = synth.config3(n_counts=16, n_orders=2, n_pods=12000, n_het=3000)
+    sub = scen[[1, 8, 15, 17, 30]]
+    ref = O.run_threaded(prob, sub, orders)
+    res, st = _run_two_level(prob, sub, orders, monkeypatch)
+    assert st.kernel_generation == 5
+    assert_same(res, ref)
+
+
+def test_many_signatures_at_batch_scale_pick_the_two_level_summary():
+    """With 100 signatures x 1 464 nodes the one-level summary lets a CU hold 7 scenario waves; a batch that offers 16 per CU
+    switches itself (simon_hip.hip: simon_load_scenarios, cost model)."""
+    prob, scen, orders = synth.config3(n_counts=64, n_orders=64, n_pods=1000, n_sigs=100, n_het=1400)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(False)
+        st = ctx.stats()
+        res = ctx.fetch(False)
+    assert st.kernel_generation == 5 and st.lds_bytes <= 10240
+    pick = np.arange(0, len(scen), 97)
+    ref = O.run_threaded(prob, scen[pick], orders)
+    assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
+    assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist()
