@@ -105,7 +105,7 @@ struct simon_ctx : simon::HostInputs {
     int force_coarse = -1, table_ni_top = 16;    // env SIMON_TABLE_COARSE = 0 / 1 (A/B)
     std::vector<int32_t> h_perm;
     std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
-    DevBuf<uint64_t> d_mask;
+    DevBuf<uint64_t> d_mask, d_t_mask;           // static masks by pod class; by table class (simon_table.hip)
     DevBuf<int64_t> d_prefix_cpu, d_prefix_mem, d_prefix_vg;
     DevBuf<int32_t> d_node_rank, d_node_inv;      // [S][N] per-scenario nodeTree ranks (simon_set_node_ranks)
     bool has_ranks = false;
@@ -246,23 +246,39 @@ int stage_narrow(simon_ctx* c) {
     // simon_table.hip: intern pod request signatures and internal node classes
     bool nozero = true;
     for (int j = 0; j < N; ++j) if (a_cpu[j] == 0 || a_mem[j] == 0) nozero = false;
-    c->table_ok = nozero && N <= kTableMaxNodes;
+    c->table_ok = nozero && N <= kTableMaxNodesCoarse;
     if (c->table_ok) {
+        // Table class of a pod class = its CONTENT: (static-mask row, Simon raw row).  Workload expansion hands over one pod class
+        // per template (thousands with anti-affinity groups or DaemonSets) of which few differ in what this kernel reads, and a
+        // request signature is (requests, table class).
+        const size_t words = (size_t)(N + 63) / 64;
+        std::map<std::pair<std::vector<uint64_t>, std::vector<int32_t>>, int> tc_id;
+        std::vector<int32_t> tc_of(c->Cp), tc_rep;
+        for (int cp = 0; cp < c->Cp; ++cp) {
+            std::vector<uint64_t> mrow;
+            if (c->has_mask) mrow.assign(c->static_mask.begin() + (size_t)cp * words, c->static_mask.begin() + (size_t)(cp + 1) * words);
+            std::vector<int32_t> rrow(raw32.begin() + (size_t)cp * c->Cn, raw32.begin() + (size_t)(cp + 1) * c->Cn);
+            auto it = tc_id.emplace(std::make_pair(std::move(mrow), std::move(rrow)), (int)tc_rep.size());
+            if (it.second) tc_rep.push_back(cp);
+            tc_of[cp] = it.first->second;
+        }
+        const int Ctc = (int)tc_rep.size();
         std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t>, int> sig_id;
         std::vector<SigRow> sigs;
         std::vector<PodRowC> rowsC(P);
         for (int p = 0; p < P && c->table_ok; ++p) {
             const PodRowN& r = rows[p];
-            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, r.cls, r.flags);
+            const int32_t tc = tc_of[r.cls];
+            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, tc, r.flags);
             auto it = sig_id.find(key);
             if (it == sig_id.end()) {
                 if ((int)sigs.size() == kTableMaxSigs) { c->table_ok = false; break; }
                 it = sig_id.emplace(key, (int)sigs.size()).first;
                 SigRow sr{};
-                sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = r.cls; sr.flags = r.flags;
+                sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = tc; sr.flags = r.flags;
                 sigs.push_back(sr);
             }
-            rowsC[p] = PodRowC{it->second, (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, r.cls};
+            rowsC[p] = PodRowC{it->second, (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, tc};
         }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
@@ -289,9 +305,15 @@ int stage_narrow(simon_ctx* c) {
             const int Ct = (int)shapes.size();
             c->n_sigs = (int)sigs.size(); c->Cn_t = Ct;
             if (sigs.empty()) sigs.push_back(SigRow{});
-            std::vector<int32_t> raw_t((size_t)c->Cp * Ct);
-            for (int cp = 0; cp < c->Cp; ++cp)
-                for (int d = 0; d < Ct; ++d) raw_t[(size_t)cp * Ct + d] = raw32[(size_t)cp * c->Cn + orig_of[d]];
+            std::vector<int32_t> raw_t((size_t)Ctc * Ct);
+            for (int tc = 0; tc < Ctc; ++tc)
+                for (int d = 0; d < Ct; ++d) raw_t[(size_t)tc * Ct + d] = raw32[(size_t)tc_rep[tc] * c->Cn + orig_of[d]];
+            if (c->has_mask) {
+                std::vector<uint64_t> mask_t((size_t)Ctc * words);
+                for (int tc = 0; tc < Ctc; ++tc)
+                    std::copy(c->static_mask.begin() + (size_t)tc_rep[tc] * words, c->static_mask.begin() + (size_t)(tc_rep[tc] + 1) * words, mask_t.begin() + (size_t)tc * words);
+                HIP_TRY(c, c->d_t_mask.upload(mask_t, st));
+            }
             // class-major layout: rank of a node among its class, per-class node lists in canonical order, class counts of
             // every prefix of the pool (a scenario = a prefix)
             std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * Ct, 0), cls_off(Ct + 1, 0), cls_list(N);
@@ -717,7 +739,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
             const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true) + c->lds_pad;
-            const bool fine_ok = top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
+            const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
             auto cost = [&](int fits, double factor) {
                 auto round_cost = [](int w) { return 1.0 + 0.055 * (std::min(w, 16) - 1) + 0.11 * std::max(w - 16, 0); };
@@ -799,7 +821,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
         const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse) + c->lds_pad : 0;
-        const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= kTableMaxNodes &&
+        const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         if ((c->has_pin || too_big) && !use_table) run_wide = true;
@@ -813,7 +835,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.clsprefix = c->d_clsprefix.p; cold.a_pods = c->d_a_pods.p;
             cold.i_rq_cpu = c->d_i_rq_cpu.p; cold.i_rq_mem = c->d_i_rq_mem.p; cold.i_nz_cpu = c->d_i_nz_cpu.p; cold.i_nz_mem = c->d_i_nz_mem.p;
             cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
-            cold.static_mask = c->has_mask ? c->d_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
+            cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
             const bool tprof = getenv_once_table_prof();
             if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 8)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 64, c->stream)); cold.prof = c->d_table_prof.p; }

@@ -51,6 +51,7 @@ struct TableLaunch {
 };
 
 constexpr int kTableMaxNodes = 4095;    // canonical index and padded position are 12-bit fields of the arg-max keys
+constexpr int kTableMaxNodesCoarse = 8191;    // ... 13-bit fields with the two-level summary
 constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario (classes padded to 16)
 constexpr int kTableMaxPaddedCoarse = 8192;   // ... with the two-level summary (classes padded to 64)
 constexpr int kTableMaxSigs = 128;      // two signatures per lane

@@ -523,12 +523,12 @@ __global__ __launch_bounds__(64) void table_kernel(
                     for (int q = 0; q < NBQ; ++q) {
                         const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
                         const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
-                        canon[q] = tied ? cls_list[(binfo[q] & 0xFFFF) - 8192 + pq] : 4095;
+                        canon[q] = tied ? cls_list[(binfo[q] & 0xFFFF) - 8192 + pq] : (int)PMASK;
                     }
 #pragma unroll
                     for (int q = 0; q < NBQ; ++q) {
                         const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
-                        if ((m16q[q] >> UB) == top && q * 64 + lane < nun) key2 = max(key2, ((4095u - (unsigned)canon[q]) << KB) | (unsigned)pq);
+                        if ((m16q[q] >> UB) == top && q * 64 + lane < nun) key2 = max(key2, ((PMASK - (unsigned)canon[q]) << KB) | (unsigned)pq);
                     }
                     key2 = wave_max_u32(key2);
                     const int p2 = (int)(key2 & PMASK);

@@ -333,6 +333,42 @@ def test_two_level_summary_large_pool(monkeypatch):
     assert_same(res, ref)
 
 
+def test_pool_of_6000_nodes_runs_on_the_two_level_score_table():
+    """Between 4 096 and 8 191 nodes the cpu+memory path keeps the score-table kernel (13-bit position / canonical fields)."""
+    prob, scen, orders = synth.config3(n_counts=8, n_orders=2, n_pods=9000, n_het=6000)
+    sub = scen[[0, 5, 15]]
+    ref = O.run_threaded(prob, sub, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(sub, orders)
+        ctx.run_loaded(True)
+        res, st = ctx.fetch(True), ctx.stats()
+    assert st.kernel_generation == 5
+    assert_same(res, ref)
+
+
+def test_pod_classes_are_interned_by_content_for_the_score_table():
+    """Thousands of pod classes with identical static-mask and Simon rows (one per workload template) are ONE table class."""
+    prob, scen, orders = synth.config3(n_counts=12, n_orders=2, n_pods=3000)
+    P = len(prob.req_cpu)
+    Cp0 = prob.n_pod_classes
+    rep = 40                                                     # 40 copies of every class row
+    prob.pod_class = (prob.pod_class + Cp0 * (np.arange(P) % rep)).astype(np.int32)
+    prob.simon_raw = np.tile(prob.simon_raw, (rep, 1))
+    if prob.static_mask is not None:
+        prob.static_mask = np.tile(prob.static_mask, (rep, 1))
+    if getattr(prob, "static_reason", None) is not None:
+        prob.static_reason = np.tile(prob.static_reason, (rep, 1))
+    if getattr(prob, "const_score", None) is not None:
+        prob.const_score = np.tile(prob.const_score, rep)
+    prob.n_pod_classes = Cp0 * rep
+    sub = scen[::5]
+    ref = O.run_threaded(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders)
+    assert variant == capi.KERNEL_NARROW_CACHE
+    assert_same(res, ref)
+
+
 def test_many_signatures_at_batch_scale_pick_the_two_level_summary():
     """With 100 signatures x 1 464 nodes the one-level summary lets a CU hold 7 scenario waves; a batch that offers 16 per CU
     switches itself (simon_hip.hip: simon_load_scenarios, cost model)."""
