@@ -435,7 +435,7 @@ def main():
         st = ctx.stats()
         wl = "config5" if args.workload == "config5" else "config3"
         alg = algorithmic_bytes(scen, prob.n_pods, wl)
-        kname = "simon::table_kernel" if getattr(st, "kernel_generation", 0) in (4, 5) else KERNEL_NAME.get(st.kernel_variant)
+        kname = "simon::table_kernel" if getattr(st, "kernel_generation", 0) in (4, 5, 6) else KERNEL_NAME.get(st.kernel_variant)
         value = S_total * args.steps / dt
         out = {
             "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),

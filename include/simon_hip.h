@@ -307,7 +307,8 @@ typedef struct simon_stats {
     int64_t lds_bytes;
     int32_t kernel_generation;     /* of the cpu+memory path: 1 register-resident, 2 scalarised, 4 class-major (signature, node)
                                       score table with block summaries in LDS (simon_table.hip), 5 the same with a two-level
-                                      summary (64-position entries in LDS, 16-position entries in HBM) for many signatures */
+                                      summary (64-position entries in LDS, 16-position entries in HBM) for many signatures,
+                                      6 generation 5 + per-node filters (Open-Gpu-Share, node-level required anti-affinity) */
     int32_t reserved;
 } simon_stats;
 

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <set>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -101,6 +102,14 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_t_ncls, d_rank, d_clsprefix, d_inv_orders, d_place_step, d_cls_list, d_cls_off, d_t_raw;
     std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn_t]; padded (class-major) size of every loaded scenario
     size_t ws_total = 0;
+    // REST path of the score-table kernel (Open-Gpu-Share + node-level required anti-affinity): decided by choose_variant
+    bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
+    bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
+    uint64_t g_gpu = 1;                          // gcd of every GPU memory quantity
+    int rest_M = 0, rest_G = 0;                  // mask rows; GPU signatures
+    DevBuf<int32_t> d_xf_off, d_xf_rows, d_xs_off, d_xs_rows, d_gpu_cnt;
+    DevBuf<uint32_t> d_gpu_devtot, d_i_gused;
+    DevBuf<uint2> d_gsig;
     bool table_coarse = false;                   // two-level summary (simon_table.hip: COARSE), decided per loaded batch
     int force_coarse = -1, table_ni_top = 16;    // env SIMON_TABLE_COARSE = 0 / 1 (A/B)
     std::vector<int32_t> h_perm;
@@ -167,6 +176,55 @@ uint64_t gcd_of(std::initializer_list<const std::vector<int64_t>*> vs) {
     return g ? g : 1;
 }
 
+// Can the score-table kernel's REST path take this problem's GPU-share / topology-term features?  Terms: only required
+// anti-affinity (match + anti lists; everything else is excluded by v2_features) on topology keys that give every node its own
+// domain (kubernetes.io/hostname), counted on every node.  GPU: every quantity a multiple of a gcd with quotients < 2^31, at
+// most kTableMaxGpuSigs distinct (gpu-mem, gpu-count) requests.  Fills g_gpu.
+bool rest_supported(simon_ctx* c) {
+    if (c->no_rest) return false;
+    if (c->Tm > kTableMaxTerms) return false;
+    std::vector<int> key_ok(std::max(c->Kt, 1), -1);
+    for (int t = 0; t < c->Tm; ++t) {
+        if (!c->term_set.empty() && c->term_set[t] >= 0) return false;
+        const int k = c->term_key[t];
+        if (key_ok[k] < 0) {
+            std::vector<char> seen(c->N, 0);
+            key_ok[k] = 1;
+            for (int j = 0; j < c->N && key_ok[k]; ++j) {
+                const int d = c->topo_dom[(size_t)k * c->N + j];
+                if (d < 0 || d >= c->N || seen[d]) key_ok[k] = 0; else seen[d] = 1;
+            }
+        }
+        if (!key_ok[k]) return false;
+    }
+    c->g_gpu = 1;
+    if (c->has_gpu) {
+        uint64_t g = 0;
+        auto take = [&](int64_t x) { if (x < 0) return false; g = gcd_u64(g, (uint64_t)x); return true; };
+        for (int j = 0; j < c->N; ++j) {
+            if (c->gpu_mem_total[j] < 0) return false;
+            if (c->gpu_cnt[j] > 0 && !take(c->gpu_mem_total[j] / c->gpu_cnt[j])) return false;
+            for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) if (!take(c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d])) return false;
+        }
+        for (int p = 0; p < c->P; ++p) if (c->p_gpu_mem[p] > 0) take(c->p_gpu_mem[p]);
+        if (!g) g = 1;
+        const uint64_t lim31 = 1ull << 31;
+        for (int j = 0; j < c->N; ++j) {
+            if (c->gpu_cnt[j] > 0 && (uint64_t)(c->gpu_mem_total[j] / c->gpu_cnt[j]) / g >= lim31) return false;
+            for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) if ((uint64_t)c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d] / g >= lim31) return false;
+        }
+        std::set<std::pair<uint64_t, int>> sigs;
+        for (int p = 0; p < c->P; ++p) {
+            if (c->p_gpu_mem[p] <= 0) continue;
+            if ((uint64_t)c->p_gpu_mem[p] / g >= lim31) return false;
+            sigs.insert({(uint64_t)c->p_gpu_mem[p] / g, std::min(c->p_gpu_cnt[p], 64)});
+            if ((int)sigs.size() > kTableMaxGpuSigs) return false;
+        }
+        c->g_gpu = g;
+    }
+    return true;
+}
+
 // Decide NARROW vs WIDE and compute the gcd normalisation.
 // NARROW needs: cpu+mem+pods only; every quantity non-negative; after dividing by the gcd all
 // node totals and the worst-case accumulated NonZeroRequested stay < 2^31; simon raw scores fit
@@ -175,7 +233,10 @@ void choose_variant(simon_ctx* c) {
     c->variant = SIMON_KERNEL_WIDE;
     c->g_cpu = c->g_mem = 1;
     if (c->force_wide) return;
-    if (c->K > 0 || c->has_gpu || c->Tm > 0 || c->v2_features()) return;
+    c->rest = false;
+    if (c->K > 0 || c->v2_features()) return;
+    const bool wants_rest = c->has_gpu || c->Tm > 0;
+    if (wants_rest && !rest_supported(c)) return;
     for (int64_t x : c->alloc_eph) if (x) return;
     for (int64_t x : c->i_req_eph) if (x) return;
     for (int64_t x : c->p_req_eph) if (x) return;
@@ -199,10 +260,12 @@ void choose_variant(simon_ctx* c) {
     if (!bounded(c->alloc_cpu, c->i_req_cpu, c->i_nz_cpu, c->p_req_cpu, c->p_nz_cpu, gc)) return;
     if (!bounded(c->alloc_mem, c->i_req_mem, c->i_nz_mem, c->p_req_mem, c->p_nz_mem, gm)) return;
     for (int64_t r : c->simon_raw) if (r < 0 || r >= (1ll << 30)) return;
-    if ((size_t)c->Cp * c->Cn * sizeof(int32_t) > 60 * 1024) return;  // simon_raw must fit LDS
+    // generations 1 and 2 keep simon_raw [Cp][Cn] in LDS; the score-table kernel reads it by table class from global memory
+    c->raw_fits_lds = (size_t)c->Cp * c->Cn * sizeof(int32_t) <= 60 * 1024;
     c->variant = SIMON_KERNEL_NARROW;
     c->g_cpu = gc;
     c->g_mem = gm;
+    c->rest = wants_rest;
 }
 
 int stage_narrow(simon_ctx* c) {
@@ -278,7 +341,44 @@ int stage_narrow(simon_ctx* c) {
                 sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = tc; sr.flags = r.flags;
                 sigs.push_back(sr);
             }
-            rowsC[p] = PodRowC{it->second, (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, tc};
+            rowsC[p] = PodRowC{it->second | (tc << 8), (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, 0};
+        }
+        // REST descriptors: term class (which mask rows a pod must find clear / sets) and GPU signature of every pod
+        std::vector<int32_t> xf_off{0, 0}, xf_rows, xs_off{0, 0}, xs_rows;   // term class 0 = no terms
+        std::vector<uint2> gsigs;
+        c->rest_M = c->rest_G = 0;
+        if (c->rest && c->table_ok) {
+            std::map<std::pair<uint32_t, int32_t>, int> gs_id;
+            std::vector<int> gs_of(P, -1);
+            for (int p = 0; p < P; ++p) {
+                if (!c->has_gpu || c->p_gpu_mem[p] <= 0) continue;
+                const auto key = std::make_pair((uint32_t)((uint64_t)c->p_gpu_mem[p] / c->g_gpu), (int32_t)std::min(c->p_gpu_cnt[p], 64));
+                auto it = gs_id.emplace(key, (int)gsigs.size());
+                if (it.second) gsigs.push_back(make_uint2(key.first, (unsigned)key.second));
+                gs_of[p] = it.first->second;
+            }
+            const int G = (int)gsigs.size(), T = c->Tm;
+            c->rest_G = G; c->rest_M = std::max(G + 2 * T, 1);
+            std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;
+            std::vector<int> xc_of(c->Cp, 0);
+            for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
+                std::vector<int32_t> anti(c->anti_idx.begin() + c->anti_off[cp], c->anti_idx.begin() + c->anti_off[cp + 1]);
+                std::vector<int32_t> match(c->match_idx.begin() + c->match_off[cp], c->match_idx.begin() + c->match_off[cp + 1]);
+                std::sort(anti.begin(), anti.end()); anti.erase(std::unique(anti.begin(), anti.end()), anti.end());
+                std::sort(match.begin(), match.end()); match.erase(std::unique(match.begin(), match.end()), match.end());
+                if (anti.empty() && match.empty()) continue;
+                auto it = xc_id.emplace(std::make_pair(anti, match), (int)xf_off.size() - 1);
+                if (it.second) {
+                    // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row G + t), or a placed pod
+                    // REQUIRES a term that matches me (row G + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
+                    for (int t : anti) { xf_rows.push_back(G + t); xs_rows.push_back(G + T + t); }
+                    for (int t : match) { xf_rows.push_back(G + T + t); xs_rows.push_back(G + t); }
+                    xf_off.push_back((int)xf_rows.size()); xs_off.push_back((int)xs_rows.size());
+                }
+                xc_of[cp] = it.first->second;
+                if (xc_of[cp] > 0xFFFF) { c->table_ok = false; break; }
+            }
+            for (int p = 0; p < P; ++p) rowsC[p].rest = xc_of[c->p_cls[p]] | ((gs_of[p] + 1) << 16);
         }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
@@ -334,6 +434,22 @@ int stage_narrow(simon_ctx* c) {
             HIP_TRY(c, c->d_clsprefix.upload(prefix, st));
             HIP_TRY(c, c->d_cls_list.upload(cls_list, st));
             HIP_TRY(c, c->d_cls_off.upload(cls_off, st));
+            if (c->rest) {
+                std::vector<uint32_t> devtot(N, 0), gused((size_t)N * 8, 0);
+                for (int j = 0; j < N && c->has_gpu; ++j) {
+                    if (c->gpu_cnt[j] > 0) devtot[j] = (uint32_t)((uint64_t)(c->gpu_mem_total[j] / c->gpu_cnt[j]) / c->g_gpu);
+                    for (int d = 0; d < 8; ++d) gused[(size_t)j * 8 + d] = (uint32_t)((uint64_t)c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d] / c->g_gpu);
+                }
+                if (gsigs.empty()) gsigs.push_back(make_uint2(0, 0));
+                if (xf_rows.empty()) xf_rows.push_back(0);
+                if (xs_rows.empty()) xs_rows.push_back(0);
+                std::vector<int32_t> gcnt(N, 0);
+                if (c->has_gpu) gcnt = c->gpu_cnt;
+                HIP_TRY(c, c->d_xf_off.upload(xf_off, st)); HIP_TRY(c, c->d_xf_rows.upload(xf_rows, st));
+                HIP_TRY(c, c->d_xs_off.upload(xs_off, st)); HIP_TRY(c, c->d_xs_rows.upload(xs_rows, st));
+                HIP_TRY(c, c->d_gsig.upload(gsigs, st)); HIP_TRY(c, c->d_gpu_cnt.upload(gcnt, st));
+                HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
+            }
             HIP_TRY(c, hipStreamSynchronize(st));
         }
     }
@@ -368,6 +484,8 @@ int stage(simon_ctx* c) {
         if (c->node_class[j] < 0 || c->node_class[j] >= c->Cn) return fail(c, SIMON_EINVAL, "node %d: class out of range", j);
     if (c->has_mask && c->static_mask.size() != (size_t)c->Cp * ((c->N + 63) / 64))
         return fail(c, SIMON_EINVAL, "static_mask size mismatch");
+    if (!c->has_gpu)      // a pod asks for GPU memory in a pool without GPU arrays: every node fails Open-Gpu-Share (:64-67)
+        for (int p = 0; p < c->P; ++p) if (c->p_gpu_mem[p] > 0) { c->has_gpu = true; break; }
     choose_variant(c);
     // prefix sums of allocatable for the occupancy caps (satisfyResourceSetting, apply.go:737-760)
     std::vector<int64_t> pc(c->N + 1, 0), pm(c->N + 1, 0);
@@ -450,6 +568,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_NO_CACHE")) c->no_cache = atoi(e) != 0;
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
+    c->no_rest = getenv("SIMON_NO_REST") != nullptr;
     if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
@@ -738,7 +857,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             // 256 scenarios 7.7 ms, 4 096 14.0 ms, 8 192 27.5 ms one-level / 32.3 ms two-level; 100 signatures 39.5 / 32.1 ms):
             // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
-            const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true) + c->lds_pad;
+            const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest) + c->lds_pad;
             const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
             auto cost = [&](int fits, double factor) {
@@ -749,18 +868,19 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             };
             bool coarse = coarse_ok && (!fine_ok || cost(std::max(fit(lds64), 1), 1.2) < 0.95 * cost(std::max(fit(lds16), 1), 1.0));
             if (c->force_coarse >= 0) coarse = c->force_coarse ? coarse_ok : !fine_ok && coarse_ok;
+            if (c->rest) coarse = coarse_ok;                        // the REST path is built on the two-level layout
             c->table_coarse = coarse;
             for (int s = 0; s < S; ++s) c->scen_ni[s] = coarse ? ni64[s] : ni16[s];
             const int ni_top = coarse ? top64 : top16;
             c->table_ni_top = ni_top;
             std::vector<unsigned long long> ws_off(S);
             size_t off = 0;
-            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct); }
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0); }
             c->ws_total = off;
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            c->table_perm_ok = true;
+            c->table_perm_ok = !c->rest || coarse;
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -820,11 +940,11 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse) + c->lds_pad : 0;
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest) + c->lds_pad : 0;
         const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        if ((c->has_pin || too_big) && !use_table) run_wide = true;
+        if ((c->has_pin || too_big || c->rest || !c->raw_fits_lds) && !use_table) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
         } else if (use_table) {
@@ -837,6 +957,10 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
+            if (c->rest) {
+                cold.xf_off = c->d_xf_off.p; cold.xf_rows = c->d_xf_rows.p; cold.xs_off = c->d_xs_off.p; cold.xs_rows = c->d_xs_rows.p;
+                cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
+            }
             const bool tprof = getenv_once_table_prof();
             if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 8)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 64, c->stream)); cold.prof = c->d_table_prof.p; }
             HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
@@ -845,9 +969,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)
@@ -928,7 +1052,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     c->stats.kernel_ms = ms;
     c->stats.n_launches = 1;
     c->stats.kernel_variant = variant_used;
-    c->stats.kernel_generation = table_used ? (c->table_coarse ? 5 : 4) : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
+    c->stats.kernel_generation = table_used ? (c->rest ? 6 : c->table_coarse ? 5 : 4) : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;
     c->stats.lds_bytes = (int64_t)lds;

@@ -25,10 +25,13 @@ struct ShapeRow {    // capacity of one internal node class = one distinct (Allo
 };
 static_assert(sizeof(ShapeRow) == 48, "ShapeRow must be 48 bytes");
 
-struct PodRowC { int32_t sig, preset, gate, cls; };   // 16 B: signature, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, pod class
+// 16 B: signature | table class << 8, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) term class | (GPU signature + 1) << 16
+// (0 = the pod is decided by the score table alone)
+struct PodRowC { int32_t sigcls, preset, gate, rest; };
 
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
+    int32_t M, G;        // REST: rows of the per-block position masks (G GPU signatures + 2 x terms); GPU signatures
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
     uint64_t g_cpu, g_mem;
 };
@@ -39,6 +42,12 @@ struct TableCold {
     const int32_t* i_npods; const SigRow* sigs; const ShapeRow* shapes; const ScenarioDesc* scen; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
     unsigned long long* prof;   // [S][8] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
+    // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): CSR over term classes of the mask rows a pod
+    // must find clear / sets when it lands; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
+    const int32_t *xf_off, *xf_rows, *xs_off, *xs_rows;
+    const uint2* gsig;              // [G]
+    const int32_t* gpu_cnt;         // [N]
+    const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)
 };
 
 struct TableLaunch {
@@ -46,6 +55,7 @@ struct TableLaunch {
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
     unsigned char* ws;   // HBM workspace: byte table + node state (+ per-16 summary entries and counters when coarse) of every scenario
+    bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
     bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
     TableScalars sc;
 };
@@ -56,10 +66,12 @@ constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one s
 constexpr int kTableMaxPaddedCoarse = 8192;   // ... with the two-level summary (classes padded to 64)
 constexpr int kTableMaxSigs = 128;      // two signatures per lane
 constexpr size_t kTableLdsPerCU = 160 * 1024;
+constexpr int kTableMaxGpuSigs = 32;    // distinct (gpu-mem, gpu-count) requests: one mask row and one lane each
+constexpr int kTableMaxTerms = 120;     // node-level anti-affinity terms: two mask rows each
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse);        // LDS per workgroup for padded scenario sizes up to ni_max
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn);  // HBM workspace of ONE scenario with ni padded positions
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest);        // LDS per workgroup for padded scenario sizes up to ni_max
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M);  // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

@@ -127,7 +127,7 @@ __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, ucls, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -141,7 +141,7 @@ __host__ __device__ inline int table_nbp(int nblk) { return (nblk & 1) || (nblk 
 // signatures keep 16+ scenario waves per CU -- and the per-16 entries move to the scenario's HBM workspace, where only the assume
 // reads them (4 entries = 8 bytes per signature, fetched with the table row, off the dependent chain); the feasible-node counters
 // move there too (touched on the rare cycle a node becomes infeasible for a signature).  Classes are then padded to 64 positions.
-__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse) {
+__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse, bool rest) {
     auto al = [](int x) { return (x + 15) & ~15; };
     TCarve c;
     c.nbp = table_nbp(ni_max / (coarse ? 64 : 16));
@@ -152,18 +152,70 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse)
     c.shape = o; o += Cn * 48;
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
+    c.ucls = o; o += rest ? al(c.nbp) : 0;          // REST: node class of every summary entry (one byte)
     c.total = o;
     return c;
 }
 // HBM workspace of ONE scenario with `ni` padded positions: byte table [ni / 16][K][16], node state [ni] x 12 B, (when
 // NonZeroRequested differs from Requested) [ni] x 8 B, and (COARSE) the per-16 summary entries [ni / 64][K][4] u16 and the
 // feasible-node counters [K][Cn] i32
-__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn) {
+// ... and (REST, M mask rows) the position masks [ni / 16][M] u16 and the GPU devices of every position: used [ni][8], per-device
+// total [ni], device count [ni] (u32 each)
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
+    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * 40;
     return w;
+}
+
+// Open-Gpu-Share on gcd-normalised 32-bit quantities (all < 2^31): GpuNodeInfo.AllocateGpuId, pkg/type/open-gpu-share/cache/
+// gpunodeinfo.go:232-290 -- the feasibility question Filter asks (open-gpu-share.go:74-78) and the commit Reserve performs
+// (:147-188), the same walk as simon_wide.hip::gpu_feasible / gpu_commit_regs.
+__device__ __forceinline__ bool gpu_fits_t(const unsigned (&u)[8], int cnt, unsigned tot, unsigned req, int num) {
+    if (req == 0u || num <= 0 || cnt <= 0) return false;
+    if (num == 1) {                                       // tightest fit exists iff some device has room (:255-267)
+        bool ok = false;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ok = ok || (d < cnt && (int)tot - (int)u[d] >= (int)req);
+        return ok;
+    }
+    int got = 0;                                          // two-pointer greedy (:268-287): device d takes floor(idle / req) slices
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if (d >= cnt) continue;
+        int idle = (int)tot - (int)u[d];
+        while (idle >= (int)req && got < num) { ++got; idle -= (int)req; }
+    }
+    return got == num;
+}
+__device__ __forceinline__ void gpu_commit_t(unsigned (&u)[8], int cnt, unsigned tot, unsigned req, int num) {
+    if (req == 0u || num <= 0 || cnt <= 0) return;
+    if (num == 1) {                                       // tightest fit, lowest id on ties (:255-267)
+        int cand = -1, cand_idle = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int idle = (int)tot - (int)u[d];
+            if (d < cnt && idle >= (int)req && (cand < 0 || idle < cand_idle)) { cand = d; cand_idle = idle; }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) u[d] += (d == cand) ? req : 0u;
+        return;
+    }
+    unsigned w[8];
+    int got = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        w[d] = u[d];
+        if (d >= cnt) continue;
+        int idle = (int)tot - (int)w[d];
+        while (idle >= (int)req && got < num) { ++got; idle -= (int)req; w[d] += req; }
+    }
+    if (got == num) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) u[d] = w[d];
+    }
 }
 
 // KQ: signatures per lane (1: K <= 64, 2: K <= 128).  HAS_PIN: the stream holds pinned pods (own instantiation: the extra
@@ -171,7 +223,15 @@ __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coa
 // NBQ: blocks per lane (1, 2 or 4: padded scenario sizes up to 1024 / 2048 / 4096 positions) -- a template parameter so that the
 // scan is straight-line code (as run-time conditions the four reads became four dependent LDS round trips).
 // NBQ counts summary ENTRIES per lane: 16 positions each, or 64 with COARSE (tcarve, above).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE>
+// REST: some pods carry filters the (signature, node) table cannot hold -- Open-Gpu-Share device memory, required anti-affinity on
+// a node-level topology key (both directions).  Those filters live as per-block POSITION MASKS xm[block][row] (u16, bit = node
+// excluded): one row per GPU signature, two per term (a pod matching the term sits there / a pod requiring it sits there).  A
+// table-only pod takes the summary path unchanged.  A REST pod scans its signature's table rows, 16 positions per lane and step,
+// with the bytes of excluded positions cleared, keeps the best node per class (LDS max), normalises the Simon term over the
+// classes that kept a node (simon.go:76-101 runs on the nodes feasible under ALL filters) and picks the first maximum in
+// canonical order.  assume additionally sets the pod's term rows and, for a GPU pod, commits the devices and refreshes the bit
+// of every GPU signature (lane g = signature g) on that node.
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -193,7 +253,10 @@ __global__ __launch_bounds__(64) void table_kernel(
     constexpr unsigned UMASK = UNIT - 1;
     constexpr int KB = COARSE ? 13 : 12;                              // width of the position field of the arg-max key
     constexpr unsigned PMASK = (1u << KB) - 1u;
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE);
+    static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
+    const int M = REST ? sc.M : 0, G = REST ? sc.G : 0;
+    unsigned char* s_ucls = smem + cv.ucls;                         // REST: [entries] node class of a summary entry
     const int nbp = cv.nbp;
     unsigned char* s_sn = smem + cv.sn;                             // [K][Cn]: the class term (<= 200) currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k (!COARSE)
@@ -229,6 +292,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     // COARSE: per-16 entries [ni / 64][K][4] u16 and feasible-node counters [K][Cn] behind the node state
     unsigned short* g_fine = (unsigned short*)((unsigned char*)g_nz + (NZEQ ? 0 : (((size_t)ni * 8 + 127) & ~(size_t)127)));
     int* g_cnt = (int*)((unsigned char*)g_fine + (((size_t)(ni >> 6) * K * 8 + 127) & ~(size_t)127));
+    // REST: position masks [nblk][M], GPU devices by position
+    unsigned short* g_xm = (unsigned short*)((unsigned char*)g_cnt + (((size_t)K * Cn * 4 + 127) & ~(size_t)127));
+    unsigned* g_gused = (unsigned*)((unsigned char*)g_xm + (((size_t)nblk * M * 2 + 127) & ~(size_t)127));
+    unsigned* g_gtot = g_gused + (size_t)ni * 8;
+    int* g_gcnt = (int*)(g_gtot + ni);
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -308,6 +376,37 @@ __global__ __launch_bounds__(64) void table_kernel(
                 if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
             }
 
+        }
+    }
+    if constexpr (REST) {
+        for (int u = lane; u < nun; u += 64) s_ucls[u] = (unsigned char)class_of_pos(u * UNIT);
+        for (int i = lane; i < nblk * M; i += 64) g_xm[i] = 0;            // no pod placed yet: every term row clear
+        // the pool's GPU devices by position, and the row of every GPU signature: bit set = it does not fit the node now
+        const int32_t* __restrict__ const gpu_cnt = cold->gpu_cnt;
+        const uint32_t* __restrict__ const gpu_devtot = cold->gpu_devtot;
+        const uint32_t* __restrict__ const i_gused = cold->i_gused;
+        const uint2* __restrict__ const gsig = cold->gsig;
+        for (int p0 = 0; p0 < ni; p0 += 64) {
+            const int p = p0 + lane;
+            const int d = class_of_pos(p);
+            const int r = p - s_seg[d];
+            const int cnt_of_d = __shfl(cnt_d, d, 64);
+            const bool real = r < cnt_of_d;
+            const int j = real ? cls_list[cls_off[d] + r] : 0;
+            const int gc = real ? gpu_cnt[j] : 0;
+            const unsigned tot = real ? gpu_devtot[j] : 0u;
+            unsigned u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = real ? i_gused[(size_t)j * 8 + e] : 0u;
+            g_gcnt[p] = gc; g_gtot[p] = tot;
+            *(uint4*)(g_gused + (size_t)p * 8) = make_uint4(u[0], u[1], u[2], u[3]);
+            *(uint4*)(g_gused + (size_t)p * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
+            for (int g = 0; g < G; ++g) {
+                const uint2 sg = gsig[g];
+                const bool fits = real && gpu_fits_t(u, gc, tot, sg.x, (int)sg.y);
+                const unsigned long long bal = __ballot(!fits);
+                if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + g] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -399,6 +498,84 @@ __global__ __launch_bounds__(64) void table_kernel(
         __syncthreads();
     };
 
+    // ---- REST path -------------------------------------------------------------------------------------------------------
+    // OR of the mask rows a pod of term class xc / GPU signature gs must find clear, for block b (any lane-varying b)
+    auto excluded = [&](int b, int xc, int gs) -> unsigned {
+        const unsigned short* xr = g_xm + (size_t)b * M;
+        unsigned bad = gs >= 0 ? (unsigned)xr[gs] : 0u;
+        const int lo = __builtin_amdgcn_readfirstlane(cold->xf_off[xc]), hi = __builtin_amdgcn_readfirstlane(cold->xf_off[xc + 1]);
+        for (int e = lo; e < hi; ++e) bad |= (unsigned)xr[__builtin_amdgcn_readfirstlane(cold->xf_rows[e])];
+        return bad;
+    };
+    // findNodesThatFitPod + prioritizeNodes + selectHost of a REST pod: returns the position (-1: no node), sets dstar / res
+    auto rest_select = [&](int k, int tc, int xc, int gs, int& dstar, int& res) -> int {
+        if (lane < Cn) s_tmp[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            if (b < nblk) {
+                uint4 R = *(const uint4*)(g_tile + ((unsigned)b * Krow + (unsigned)k * 16u));
+                const unsigned bad = excluded(b, xc, gs);
+                // clear the bytes of the excluded positions: 4 mask bits -> 4 byte masks per dword
+                auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
+                R.x = keep(R.x, bad); R.y = keep(R.y, bad >> 4); R.z = keep(R.z, bad >> 8); R.w = keep(R.w, bad >> 12);
+                const unsigned e16 = block_key16_t(R);                // best byte << 4 | 15 - position inside the block
+                if (e16 >> 4) {
+                    const unsigned key = ((e16 >> 4) << KB) | (PMASK - (unsigned)(b * 16 + 15 - (int)(e16 & 15u)));
+                    atomicMax((unsigned*)&s_tmp[s_ucls[b >> 2]], key);   // best node of the class: highest base score, first position
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int dd = lane < Cn ? lane : 0;
+        const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
+        const bool present = cbest != 0u;
+        if (!__ballot(present)) return -1;
+        // SimonPlugin / GpuSharePlugin NormalizeScore over the classes that hold a feasible node (as renormalise, above)
+        const int rawc = simon_raw[tc * Cn + dd];
+        const int lo = wave_min_i32(present ? rawc : 0x7fffffff);
+        const int hi = wave_max_i32(present ? rawc : (int)0x80000000);
+        const int range = hi >= lo ? hi - lo : 0;
+        const double rr = range ? 1.0 / (double)range : 0.0;
+        const int sn = (present && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
+        const int pos = (int)(PMASK - (cbest & PMASK));
+        const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
+        const int canon = present ? cls_list[idx] : 0;
+        const unsigned key = present ? ((((cbest >> KB) + (unsigned)sn) << KB) | (PMASK - (unsigned)canon)) : 0u;
+        const unsigned kmax = wave_max_u32(key);
+        const int wl = __builtin_ctzll(__ballot(present && key == kmax));
+        dstar = wl;
+        res = __builtin_amdgcn_readlane(idx, wl);
+        return __builtin_amdgcn_readlane(pos, wl);
+    };
+    // what assume adds for a REST pod landing on position pstar: its term rows, the GPU commit and the GPU rows of that node
+    auto rest_assume = [&](int pstar, int xc, int gs) {
+        const int blk = pstar >> 4;
+        const unsigned bit = 1u << (pstar & 15);
+        unsigned short* xr = g_xm + (size_t)blk * M;
+        const int lo = __builtin_amdgcn_readfirstlane(cold->xs_off[xc]), hi = __builtin_amdgcn_readfirstlane(cold->xs_off[xc + 1]);
+        for (int e = lo + lane; e < hi; e += 64) { const int row = cold->xs_rows[e]; xr[row] = (unsigned short)(xr[row] | bit); }
+        if (gs >= 0) {
+            const uint2 sg = cold->gsig[gs];
+            const int gc = g_gcnt[pstar];
+            const unsigned tot = g_gtot[pstar];
+            const uint4 a = *(const uint4*)(g_gused + (size_t)pstar * 8), b4 = *(const uint4*)(g_gused + (size_t)pstar * 8 + 4);
+            unsigned u[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+            gpu_commit_t(u, gc, tot, sg.x, (int)sg.y);                    // Reserve (open-gpu-share.go:147-188), every lane alike
+            if (lane == 0) {
+                *(uint4*)(g_gused + (size_t)pstar * 8) = make_uint4(u[0], u[1], u[2], u[3]);
+                *(uint4*)(g_gused + (size_t)pstar * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
+            }
+            if (lane < G) {                                               // lane g: does GPU signature g still fit this node?
+                const uint2 mine = cold->gsig[lane];
+                const bool fits = gpu_fits_t(u, gc, tot, mine.x, (int)mine.y);
+                const unsigned old = xr[lane];
+                xr[lane] = (unsigned short)(fits ? (old & ~bit) : (old | bit));
+            }
+        }
+    };
+
     int unsched = 0;
     int32_t* __restrict__ place = place_step ? place_step + (size_t)s * P : nullptr;
 
@@ -409,7 +586,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         if (idx >= P) return make_int4((int)0x80000000, -1, 0x7fffffff, 0);
         const PodRowC r = pods[order[idx]];
         const bool special = r.gate >= n || r.preset != -1;
-        return make_int4((r.sig | (r.cls << 8)) | (special ? (int)0x80000000 : 0), r.preset, r.gate, 0);
+        return make_int4(r.sigcls | (special ? (int)0x80000000 : 0), r.preset, r.gate, r.rest);
     };
     int4 nxt = load_chunk(0);
 
@@ -423,12 +600,14 @@ __global__ __launch_bounds__(64) void table_kernel(
         TPROF(0);                                                      // loop control, placement flush, pod chunk
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0xFF, r_cls = (pk >> 8) & 0x7FFFFF;
+        const int rw = REST ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST descriptor: term class | (GPU signature + 1) << 16
+        const int r_xc = rw & 0xFFFF, r_gs = (rw >> 16) - 1;
 
         // res: what the placement row records for this step: >= 0 an index into cls_list (turned into the canonical node index
         // 64 steps at a time, off the critical path), -1 unschedulable, -2 not part of the scenario
         int res, pstar = -1, dstar = 0;
         unsigned top = 0, m16q[NBQ];
-        bool scanned = false;
+        bool scanned = false, bound = false;                           // bound: a preset pod (no Reserve: the scheduler never saw it)
         if (pk < 0) {
             const int r_preset = __builtin_amdgcn_readlane(cur.y, il), r_gate = __builtin_amdgcn_readlane(cur.z, il);
             const TableCold* cc = cold;
@@ -436,6 +615,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             if (r_gate >= n) {
                 res = -2;                                              // pod not part of this scenario
             } else if (r_preset >= 0) {                                // addPodToCache path (V/eventhandlers.go:223-236)
+                bound = true;
                 dstar = __builtin_amdgcn_readfirstlane(cc->ncls[r_preset]);
                 const int rk = __builtin_amdgcn_readfirstlane(cc->rank[r_preset]);
                 pstar = __builtin_amdgcn_readfirstlane(s_seg[dstar]) + rk;
@@ -448,10 +628,15 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const int rk = __builtin_amdgcn_readfirstlane(cc->rank[pin]);
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
                     const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
-                    if (byte != 0) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
+                    bool clear = true;
+                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_xc, r_gs)) >> (pp & 15)) & 1u);
+                    if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
                 }
                 if (res < 0) ++unsched;
             }
+        } else if (REST && rw != 0) {
+            pstar = rest_select(r_sig, r_cls, r_xc, r_gs, dstar, res);
+            if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
@@ -612,6 +797,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                     }
                 }
             }
+            if (REST && rw != 0) rest_assume(pstar, r_xc, bound ? -1 : r_gs);
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // state update, eval, patch, block key, summary store
         }
@@ -662,9 +848,9 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false>
 static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE>;
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -672,6 +858,11 @@ static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipS
 }
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (PIN) {                                              // REST rides on the instantiation that knows pinned pods
+        if (a.rest)
+            return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true, true>(a, n_blocks, lds, st)
+                                          : launch_t6<M, Z, PIN, KQ, 2, true, true>(a, n_blocks, lds, st);
+    }
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
         return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 2, true>(a, n_blocks, lds, st);
     }
@@ -680,8 +871,8 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
            : nblk <= 128 ? launch_t6<M, Z, PIN, KQ, 2, false>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 4, false>(a, n_blocks, lds, st);
 }
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse) { return (size_t)tcarve(K, ni_max, Cn, coarse).total; }
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn) { return table_ws_of(K, ni, nzeq, coarse, Cn); }
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest) { return (size_t)tcarve(K, ni_max, Cn, coarse, rest).total; }
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M) { return table_ws_of(K, ni, nzeq, coarse, Cn, M); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
@@ -693,6 +884,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 }
 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
+    has_pin = has_pin || a.rest;
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }

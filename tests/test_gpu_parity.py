@@ -173,8 +173,38 @@ def test_random_wide_features(idx):
         prob = randprob.rand_problem(1000 + 100 * idx + seed, N=50 + 41 * seed, P=350, **feat)
         scen, orders = randprob.rand_scenarios(seed, prob, S=6)
         ref = O.run(prob, scen, orders)
-        res, variant = run_gpu(prob, scen, orders)
+        res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_REST": "1"})
         assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+        res, variant = run_gpu(prob, scen, orders)          # GPU share alone fits the score-table kernel's REST path
+        assert variant == (capi.KERNEL_NARROW_CACHE if set(feat) <= {"gpu", "init_state"} else capi.KERNEL_WIDE)
+        assert_same(res, ref)
+
+
+REST_FEATURES = [
+    dict(gpu=True), dict(anti_host=True), dict(gpu=True, anti_host=True), dict(gpu=True, anti_host=True, init_state=True, static_mask=True),
+    dict(gpu=True, anti_host=True, presets=True, gates=True, pins=True, tight_pods=True, zero_pods=True, nz_differs=True, static_mask=True),
+    dict(anti_host=True, pins=True, presets=True, tight_pods=True),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(REST_FEATURES)))
+def test_random_rest_features(idx):
+    """Open-Gpu-Share and required anti-affinity on node-level topology keys on the score-table kernel (generation 6): position
+    masks per block, per-class best + NormalizeScore over the classes that kept a node; against the oracle and, same inputs, on
+    the all-feature kernel."""
+    feat = REST_FEATURES[idx]
+    for seed in range(4):
+        N = [37, 150, 700, 1500][seed]
+        prob = randprob.rand_problem(7000 + 100 * idx + seed, N=N, P=500 + 300 * seed, n_pod_classes=6 + 5 * seed, n_node_classes=3 + 2 * seed, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=5, min_n=1 if seed == 0 else None)
+        ref = O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ctx.run_loaded(True)
+            res, st = ctx.fetch(True), ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 6
         assert_same(res, ref)
 
 
@@ -405,8 +435,11 @@ def test_config5_gpushare_style():
     then ONE scenario at full size (50k pods x 5k nodes)."""
     prob, scen, orders = synth.config5(n_pods=5000, n_nodes=500, n_scen=16, n_orders=2, n_groups=10, group_size=50)
     ref = O.run(prob, scen, orders)
-    res, variant = run_gpu(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_REST": "1"})
     assert variant == capi.KERNEL_WIDE
+    assert_same(res, ref)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_NARROW_CACHE              # generation 6: the score table + per-node filters
     assert_same(res, ref)
     assert ref.unscheduled.max() > 0 and ref.unscheduled.min() == 0        # the sweep crosses the feasibility boundary
     prob, scen, orders = synth.config5()
