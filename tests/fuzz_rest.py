@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep aimed at generation 6 of the score-table kernel (simon_table.hip, REST path): cpu+memory problems with
+Open-Gpu-Share devices and / or required anti-affinity on node-level topology keys, 1 ... 8 191 nodes, 1 ... 64 internal node
+classes, up to 120 pod classes (term classes, table classes), presets (bound without Reserve), gates, pinned pods, static masks,
+initial node and device state, zero requests, tight pod counts.  Not collected by pytest (a slice runs in
+tests/test_gpu_round2.py); by hand on a GPU box:   python tests/fuzz_rest.py [n_cases] [first_seed]
+Every placement, unscheduled count and used cpu / memory is compared with the oracle."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conftest  # noqa: E402,F401
+import oracle_lib as O  # noqa: E402
+import randprob  # noqa: E402
+from open_simulator_amd import capi  # noqa: E402
+
+FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins"]
+
+
+def one_case(case):
+    rng = np.random.default_rng(61000 + case)
+    size = case % 4
+    N = int(rng.integers(1, 80)) if size == 0 else int(rng.integers(100, 1100)) if size == 1 else int(rng.integers(1100, 4200)) if size == 2 \
+        else int(rng.integers(4200, 8192))
+    P = int(rng.integers(20, 400 if size == 0 else 1800))
+    feat = {f: True for f in FEATURES if rng.random() < 0.3}
+    kind = case % 3
+    if kind != 1:
+        feat["gpu"] = True
+    if kind != 0:
+        feat["anti_host"] = True
+    if size >= 2:                         # static masks are O(Cp N) Python work in the generator
+        feat.pop("static_mask", None)
+    n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))
+    n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 120]))
+    prob = randprob.rand_problem(62000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
+    S = int(rng.integers(1, 7))
+    scen, orders = randprob.rand_scenarios(case, prob, S=S, min_n=1 if rng.random() < 0.5 else None)
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        res = ctx.fetch(True)
+        st = ctx.stats()
+    ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
+          res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
+    return ok, dict(case=case, N=N, P=P, S=S, classes=n_node_classes, pod_classes=n_pod_classes, feat=sorted(feat),
+                    variant=st.kernel_variant, generation=st.kernel_generation, unscheduled=int(ref.unscheduled.sum()))
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad, on_rest = 0, 0
+    for case in range(first, first + n_cases):
+        ok, info = one_case(case)
+        on_rest += info["generation"] == 6
+        if not ok:
+            bad += 1
+            print("MISMATCH", info, flush=True)
+    print(f"fuzz_rest: {n_cases} cases from {first}, {on_rest} on generation 6, mismatches {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -67,9 +67,13 @@ def test_config4_shuffled_orders_one_rank_of_eight():
             assert (ctx.fetch_placement(s) == ref2.placement[j]).all(), s
 
 
-def test_config5_sixteen_full_size_scenarios():
+@pytest.mark.parametrize("engine", ["score_table", "all_feature"])
+def test_config5_sixteen_full_size_scenarios(engine, monkeypatch):
     """BASELINE config 5 at full size (50k pods x 2500..5000 nodes; GPU share + anti-affinity + taints): 16 of the 256
-    benchmarked scenarios, every placement compared."""
+    benchmarked scenarios, every placement compared -- on the score-table kernel's REST path (generation 6, what the bench
+    times) and on the all-feature kernel (SIMON_NO_REST=1)."""
+    if engine == "all_feature":
+        monkeypatch.setenv("SIMON_NO_REST", "1")
     prob, scen, orders = synth.config5()
     pick = np.unique(np.linspace(0, len(scen) - 1, 16).astype(int))
     ref = O.run_threaded(prob, scen[pick], orders)
@@ -77,7 +81,11 @@ def test_config5_sixteen_full_size_scenarios():
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
         ctx.run_loaded(want_placement=True)
-        assert ctx.stats().kernel_variant == capi.KERNEL_WIDE
+        st = ctx.stats()
+        if engine == "all_feature":
+            assert st.kernel_variant == capi.KERNEL_WIDE
+        else:
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 6
         res = ctx.fetch(want_placement=False)
         assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
         assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist() and res.used_mem[pick].tolist() == ref.used_mem.tolist()
@@ -384,3 +392,17 @@ def test_many_signatures_at_batch_scale_pick_the_two_level_summary():
     ref = O.run_threaded(prob, scen[pick], orders)
     assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
     assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist()
+
+
+def test_rest_path_randomised_slice():
+    """A slice of tests/fuzz_rest.py (GPU share and / or node-level anti-affinity, up to 8 191 nodes, many pod classes) in the
+    regular suite."""
+    import fuzz_rest
+    bad, on_rest = [], 0
+    for case in range(0, 24):
+        ok, info = fuzz_rest.one_case(case)
+        on_rest += info["generation"] == 6
+        if not ok:
+            bad.append(info)
+    assert not bad, bad
+    assert on_rest >= 16, "the slice should mostly run on generation 6"
