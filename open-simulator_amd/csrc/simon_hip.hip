@@ -107,7 +107,7 @@ struct simon_ctx : simon::HostInputs {
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1;                          // gcd of every GPU memory quantity
     int rest_M = 0, rest_G = 0;                  // mask rows; GPU signatures
-    DevBuf<int32_t> d_xf_off, d_xf_rows, d_xs_off, d_xs_rows, d_gpu_cnt;
+    DevBuf<int32_t> d_xrows, d_gpu_cnt;
     DevBuf<uint32_t> d_gpu_devtot, d_i_gused;
     DevBuf<uint2> d_gsig;
     bool table_coarse = false;                   // two-level summary (simon_table.hip: COARSE), decided per loaded batch
@@ -344,7 +344,7 @@ int stage_narrow(simon_ctx* c) {
             rowsC[p] = PodRowC{it->second | (tc << 8), (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, 0};
         }
         // REST descriptors: term class (which mask rows a pod must find clear / sets) and GPU signature of every pod
-        std::vector<int32_t> xf_off{0, 0}, xf_rows, xs_off{0, 0}, xs_rows;   // term class 0 = no terms
+        std::vector<int32_t> xrows;           // entries of every term class: filter row | set row << 16
         std::vector<uint2> gsigs;
         c->rest_M = c->rest_G = 0;
         if (c->rest && c->table_ok) {
@@ -359,7 +359,7 @@ int stage_narrow(simon_ctx* c) {
             }
             const int G = (int)gsigs.size(), T = c->Tm;
             c->rest_G = G; c->rest_M = std::max(G + 2 * T, 1);
-            std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;
+            std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;   // -> n | offset << 6
             std::vector<int> xc_of(c->Cp, 0);
             for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
                 std::vector<int32_t> anti(c->anti_idx.begin() + c->anti_off[cp], c->anti_idx.begin() + c->anti_off[cp + 1]);
@@ -367,18 +367,18 @@ int stage_narrow(simon_ctx* c) {
                 std::sort(anti.begin(), anti.end()); anti.erase(std::unique(anti.begin(), anti.end()), anti.end());
                 std::sort(match.begin(), match.end()); match.erase(std::unique(match.begin(), match.end()), match.end());
                 if (anti.empty() && match.empty()) continue;
-                auto it = xc_id.emplace(std::make_pair(anti, match), (int)xf_off.size() - 1);
+                const size_t n = anti.size() + match.size(), off = xrows.size();
+                if (n > 63 || off + n >= (1u << 20)) { c->table_ok = false; break; }   // one lane per entry; 20-bit offsets
+                auto it = xc_id.emplace(std::make_pair(anti, match), (int)(n | (off << 6)));
                 if (it.second) {
                     // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row G + t), or a placed pod
                     // REQUIRES a term that matches me (row G + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
-                    for (int t : anti) { xf_rows.push_back(G + t); xs_rows.push_back(G + T + t); }
-                    for (int t : match) { xf_rows.push_back(G + T + t); xs_rows.push_back(G + t); }
-                    xf_off.push_back((int)xf_rows.size()); xs_off.push_back((int)xs_rows.size());
+                    for (int t : anti) xrows.push_back((G + t) | ((G + T + t) << 16));
+                    for (int t : match) xrows.push_back((G + T + t) | ((G + t) << 16));
                 }
                 xc_of[cp] = it.first->second;
-                if (xc_of[cp] > 0xFFFF) { c->table_ok = false; break; }
             }
-            for (int p = 0; p < P; ++p) rowsC[p].rest = xc_of[c->p_cls[p]] | ((gs_of[p] + 1) << 16);
+            for (int p = 0; p < P; ++p) rowsC[p].rest = (gs_of[p] + 1) | (xc_of[c->p_cls[p]] << 6);
         }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
@@ -441,12 +441,10 @@ int stage_narrow(simon_ctx* c) {
                     for (int d = 0; d < 8; ++d) gused[(size_t)j * 8 + d] = (uint32_t)((uint64_t)c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d] / c->g_gpu);
                 }
                 if (gsigs.empty()) gsigs.push_back(make_uint2(0, 0));
-                if (xf_rows.empty()) xf_rows.push_back(0);
-                if (xs_rows.empty()) xs_rows.push_back(0);
+                if (xrows.empty()) xrows.push_back(0);
                 std::vector<int32_t> gcnt(N, 0);
                 if (c->has_gpu) gcnt = c->gpu_cnt;
-                HIP_TRY(c, c->d_xf_off.upload(xf_off, st)); HIP_TRY(c, c->d_xf_rows.upload(xf_rows, st));
-                HIP_TRY(c, c->d_xs_off.upload(xs_off, st)); HIP_TRY(c, c->d_xs_rows.upload(xs_rows, st));
+                HIP_TRY(c, c->d_xrows.upload(xrows, st));
                 HIP_TRY(c, c->d_gsig.upload(gsigs, st)); HIP_TRY(c, c->d_gpu_cnt.upload(gcnt, st));
                 HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
             }
@@ -958,7 +956,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
             if (c->rest) {
-                cold.xf_off = c->d_xf_off.p; cold.xf_rows = c->d_xf_rows.p; cold.xs_off = c->d_xs_off.p; cold.xs_rows = c->d_xs_rows.p;
+                cold.xrows = c->d_xrows.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
             const bool tprof = getenv_once_table_prof();

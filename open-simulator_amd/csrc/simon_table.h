@@ -25,8 +25,8 @@ struct ShapeRow {    // capacity of one internal node class = one distinct (Allo
 };
 static_assert(sizeof(ShapeRow) == 48, "ShapeRow must be 48 bytes");
 
-// 16 B: signature | table class << 8, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) term class | (GPU signature + 1) << 16
-// (0 = the pod is decided by the score table alone)
+// 16 B: signature | table class << 8, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) GPU signature + 1 | rows << 6 |
+// offset << 12 of the pod's entries in TableCold::xrows (0 = the pod is decided by the score table alone)
 struct PodRowC { int32_t sigcls, preset, gate, rest; };
 
 struct TableScalars {
@@ -42,9 +42,8 @@ struct TableCold {
     const int32_t* i_npods; const SigRow* sigs; const ShapeRow* shapes; const ScenarioDesc* scen; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
     unsigned long long* prof;   // [S][8] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
-    // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): CSR over term classes of the mask rows a pod
-    // must find clear / sets when it lands; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
-    const int32_t *xf_off, *xf_rows, *xs_off, *xs_rows;
+    // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): mask rows per term class; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
+    const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16
     const uint2* gsig;              // [G]
     const int32_t* gpu_cnt;         // [N]
     const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)

@@ -499,49 +499,59 @@ __global__ __launch_bounds__(64) void table_kernel(
     };
 
     // ---- REST path -------------------------------------------------------------------------------------------------------
-    // OR of the mask rows a pod of term class xc / GPU signature gs must find clear, for block b (any lane-varying b)
-    auto excluded = [&](int b, int xc, int gs) -> unsigned {
+    // A REST pod's descriptor (PodRowC::rest) = GPU signature + 1 | rows << 6 | offset << 12 into xrows: entry e < rows packs the
+    // mask row the pod must find clear (low half) and the row it sets when it lands (high half).  Lane e holds entry e (`rowv`,
+    // ONE vector load per pod, issued when the cycle starts); everything else about the pod's filters is register traffic.
+    const uint2 my_gsig = REST ? cold->gsig[lane < G ? lane : 0] : make_uint2(0, 0);    // lane g: GPU signature g
+    // OR of the pod's filter rows for block b (lane-varying b < nblk), all loads independent
+    auto excluded = [&](int b, int nrows, int rowv, int gs) -> unsigned {
         const unsigned short* xr = g_xm + (size_t)b * M;
         unsigned bad = gs >= 0 ? (unsigned)xr[gs] : 0u;
-        const int lo = __builtin_amdgcn_readfirstlane(cold->xf_off[xc]), hi = __builtin_amdgcn_readfirstlane(cold->xf_off[xc + 1]);
-        for (int e = lo; e < hi; ++e) bad |= (unsigned)xr[__builtin_amdgcn_readfirstlane(cold->xf_rows[e])];
+        for (int e = 0; e < nrows; ++e) bad |= (unsigned)xr[__builtin_amdgcn_readlane(rowv, e) & 0xFFFF];
         return bad;
     };
+    // best node of block b's table row k under the excluded positions -> per-class maximum in LDS
+    auto fold_block = [&](int b, uint4 R, unsigned bad) {
+        // clear the bytes of the excluded positions: 4 mask bits -> 4 byte masks per dword
+        auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
+        R.x = keep(R.x, bad); R.y = keep(R.y, bad >> 4); R.z = keep(R.z, bad >> 8); R.w = keep(R.w, bad >> 12);
+        const unsigned e16 = block_key16_t(R);                        // best byte << 4 | 15 - position inside the block
+        if (e16 >> 4) {
+            const unsigned key = ((e16 >> 4) << KB) | (PMASK - (unsigned)(b * 16 + 15 - (int)(e16 & 15u)));
+            atomicMax((unsigned*)&s_tmp[s_ucls[b >> 2]], key);        // best node of the class: highest base score, first position
+        }
+    };
     // findNodesThatFitPod + prioritizeNodes + selectHost of a REST pod: returns the position (-1: no node), sets dstar / res
-    auto rest_select = [&](int k, int tc, int xc, int gs, int& dstar, int& res) -> int {
+    auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int& dstar, int& res) -> int {
+        const int dd = lane < Cn ? lane : 0;
+        const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        for (int b0 = 0; b0 < nblk; b0 += 64) {
-            const int b = b0 + lane;
-            if (b < nblk) {
-                uint4 R = *(const uint4*)(g_tile + ((unsigned)b * Krow + (unsigned)k * 16u));
-                const unsigned bad = excluded(b, xc, gs);
-                // clear the bytes of the excluded positions: 4 mask bits -> 4 byte masks per dword
-                auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
-                R.x = keep(R.x, bad); R.y = keep(R.y, bad >> 4); R.z = keep(R.z, bad >> 8); R.w = keep(R.w, bad >> 12);
-                const unsigned e16 = block_key16_t(R);                // best byte << 4 | 15 - position inside the block
-                if (e16 >> 4) {
-                    const unsigned key = ((e16 >> 4) << KB) | (PMASK - (unsigned)(b * 16 + 15 - (int)(e16 & 15u)));
-                    atomicMax((unsigned*)&s_tmp[s_ucls[b >> 2]], key);   // best node of the class: highest base score, first position
-                }
-            }
+        const unsigned koff16 = (unsigned)k * 16u;
+        for (int b0 = 0; b0 < nblk; b0 += 128) {                          // two blocks per lane and step: their loads fly together
+            const int ba = b0 + lane, bb = b0 + 64 + lane;
+            const bool va = ba < nblk, vb = bb < nblk;
+            const int ca = va ? ba : 0, cb2 = vb ? bb : 0;
+            const uint4 Ra = *(const uint4*)(g_tile + ((unsigned)ca * Krow + koff16));
+            const uint4 Rb = *(const uint4*)(g_tile + ((unsigned)cb2 * Krow + koff16));
+            const unsigned bada = excluded(ca, nrows, rowv, gs), badb = excluded(cb2, nrows, rowv, gs);
+            if (va) fold_block(ba, Ra, bada);
+            if (vb) fold_block(bb, Rb, badb);
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int dd = lane < Cn ? lane : 0;
         const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
         const bool present = cbest != 0u;
         if (!__ballot(present)) return -1;
+        const int pos = (int)(PMASK - (cbest & PMASK));
+        const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
+        const int canon = present ? cls_list[idx] : 0;
         // SimonPlugin / GpuSharePlugin NormalizeScore over the classes that hold a feasible node (as renormalise, above)
-        const int rawc = simon_raw[tc * Cn + dd];
         const int lo = wave_min_i32(present ? rawc : 0x7fffffff);
         const int hi = wave_max_i32(present ? rawc : (int)0x80000000);
         const int range = hi >= lo ? hi - lo : 0;
         const double rr = range ? 1.0 / (double)range : 0.0;
         const int sn = (present && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
-        const int pos = (int)(PMASK - (cbest & PMASK));
-        const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
-        const int canon = present ? cls_list[idx] : 0;
         const unsigned key = present ? ((((cbest >> KB) + (unsigned)sn) << KB) | (PMASK - (unsigned)canon)) : 0u;
         const unsigned kmax = wave_max_u32(key);
         const int wl = __builtin_ctzll(__ballot(present && key == kmax));
@@ -549,29 +559,38 @@ __global__ __launch_bounds__(64) void table_kernel(
         res = __builtin_amdgcn_readlane(idx, wl);
         return __builtin_amdgcn_readlane(pos, wl);
     };
-    // what assume adds for a REST pod landing on position pstar: its term rows, the GPU commit and the GPU rows of that node
-    auto rest_assume = [&](int pstar, int xc, int gs) {
-        const int blk = pstar >> 4;
-        const unsigned bit = 1u << (pstar & 15);
-        unsigned short* xr = g_xm + (size_t)blk * M;
-        const int lo = __builtin_amdgcn_readfirstlane(cold->xs_off[xc]), hi = __builtin_amdgcn_readfirstlane(cold->xs_off[xc + 1]);
-        for (int e = lo + lane; e < hi; e += 64) { const int row = cold->xs_rows[e]; xr[row] = (unsigned short)(xr[row] | bit); }
+    // What assume adds for a REST pod landing on position pstar: its term rows, the GPU commit and the GPU rows of that node.
+    // Two halves: the loads go out with the table-row loads of the cycle, the updates follow the evaluation.
+    struct RestLoads { unsigned xr_set, xr_g, tot; int gc; uint4 ua, ub; };
+    auto rest_assume_load = [&](int pstar, int nrows, int rowv, int gs) -> RestLoads {
+        RestLoads L{};
+        const unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
+        if (lane < nrows) L.xr_set = xr[(unsigned)rowv >> 16];
         if (gs >= 0) {
-            const uint2 sg = cold->gsig[gs];
-            const int gc = g_gcnt[pstar];
-            const unsigned tot = g_gtot[pstar];
-            const uint4 a = *(const uint4*)(g_gused + (size_t)pstar * 8), b4 = *(const uint4*)(g_gused + (size_t)pstar * 8 + 4);
-            unsigned u[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
-            gpu_commit_t(u, gc, tot, sg.x, (int)sg.y);                    // Reserve (open-gpu-share.go:147-188), every lane alike
+            L.gc = g_gcnt[pstar];
+            L.tot = g_gtot[pstar];
+            L.ua = *(const uint4*)(g_gused + (size_t)pstar * 8);
+            L.ub = *(const uint4*)(g_gused + (size_t)pstar * 8 + 4);
+            if (lane < G) L.xr_g = xr[lane];
+        }
+        return L;
+    };
+    auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs) {
+        const unsigned bit = 1u << (pstar & 15);
+        unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
+        if (lane < nrows) xr[(unsigned)rowv >> 16] = (unsigned short)(L.xr_set | bit);
+        if (gs >= 0) {
+            const unsigned greq = (unsigned)__builtin_amdgcn_readlane((int)my_gsig.x, gs);
+            const int gnum = __builtin_amdgcn_readlane((int)my_gsig.y, gs);
+            unsigned u[8] = {L.ua.x, L.ua.y, L.ua.z, L.ua.w, L.ub.x, L.ub.y, L.ub.z, L.ub.w};
+            gpu_commit_t(u, L.gc, L.tot, greq, gnum);                     // Reserve (open-gpu-share.go:147-188), every lane alike
             if (lane == 0) {
                 *(uint4*)(g_gused + (size_t)pstar * 8) = make_uint4(u[0], u[1], u[2], u[3]);
                 *(uint4*)(g_gused + (size_t)pstar * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
             }
             if (lane < G) {                                               // lane g: does GPU signature g still fit this node?
-                const uint2 mine = cold->gsig[lane];
-                const bool fits = gpu_fits_t(u, gc, tot, mine.x, (int)mine.y);
-                const unsigned old = xr[lane];
-                xr[lane] = (unsigned short)(fits ? (old & ~bit) : (old | bit));
+                const bool fits = gpu_fits_t(u, L.gc, L.tot, my_gsig.x, (int)my_gsig.y);
+                xr[lane] = (unsigned short)(fits ? (L.xr_g & ~bit) : (L.xr_g | bit));
             }
         }
     };
@@ -600,8 +619,10 @@ __global__ __launch_bounds__(64) void table_kernel(
         TPROF(0);                                                      // loop control, placement flush, pod chunk
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0xFF, r_cls = (pk >> 8) & 0x7FFFFF;
-        const int rw = REST ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST descriptor: term class | (GPU signature + 1) << 16
-        const int r_xc = rw & 0xFFFF, r_gs = (rw >> 16) - 1;
+        const int rw = REST ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST descriptor (0: the score table alone decides the pod)
+        const int r_gs = (rw & 63) - 1, r_nrows = (rw >> 6) & 63;
+        int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
+        if (REST && lane < r_nrows) rowv = cold->xrows[(rw >> 12) + lane];
 
         // res: what the placement row records for this step: >= 0 an index into cls_list (turned into the canonical node index
         // 64 steps at a time, off the critical path), -1 unschedulable, -2 not part of the scenario
@@ -629,13 +650,13 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
                     const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
                     bool clear = true;
-                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_xc, r_gs)) >> (pp & 15)) & 1u);
+                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs)) >> (pp & 15)) & 1u);
                     if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
                 }
                 if (res < 0) ++unsched;
             }
         } else if (REST && rw != 0) {
-            pstar = rest_select(r_sig, r_cls, r_xc, r_gs, dstar, res);
+            pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, dstar, res);
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
@@ -735,6 +756,8 @@ __global__ __launch_bounds__(64) void table_kernel(
                 }
             }
             const int blk = pstar >> 4, pos = pstar & 15;
+            RestLoads RL{};
+            if (REST && rw != 0) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs);
             const ShapeRow sh = s_shape[dstar];
             unsigned snq[KQ];
 #pragma unroll
@@ -797,7 +820,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                     }
                 }
             }
-            if (REST && rw != 0) rest_assume(pstar, r_xc, bound ? -1 : r_gs);
+            if (REST && rw != 0) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs);
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // state update, eval, patch, block key, summary store
         }
