@@ -527,17 +527,28 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
         __builtin_amdgcn_wave_barrier();
+        // every block of the scenario in ONE pass: 4 NBQ blocks per lane, all loads issued before the first is used (one memory
+        // round trip per pod instead of one per 64 blocks -- the table of a batch lives in the Infinity Cache / HBM, not in L2)
+        constexpr int CH = 4 * NBQ;
         const unsigned koff16 = (unsigned)k * 16u;
-        for (int b0 = 0; b0 < nblk; b0 += 128) {                          // two blocks per lane and step: their loads fly together
-            const int ba = b0 + lane, bb = b0 + 64 + lane;
-            const bool va = ba < nblk, vb = bb < nblk;
-            const int ca = va ? ba : 0, cb2 = vb ? bb : 0;
-            const uint4 Ra = *(const uint4*)(g_tile + ((unsigned)ca * Krow + koff16));
-            const uint4 Rb = *(const uint4*)(g_tile + ((unsigned)cb2 * Krow + koff16));
-            const unsigned bada = excluded(ca, nrows, rowv, gs), badb = excluded(cb2, nrows, rowv, gs);
-            if (va) fold_block(ba, Ra, bada);
-            if (vb) fold_block(bb, Rb, badb);
+        uint4 R[CH];
+        unsigned bad[CH];
+        const unsigned short* xr[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int b = c * 64 + lane, cbk = b < nblk ? b : 0;
+            R[c] = *(const uint4*)(g_tile + ((unsigned)cbk * Krow + koff16));
+            xr[c] = g_xm + (size_t)cbk * M;
+            bad[c] = gs >= 0 ? (unsigned)xr[c][gs] : 0u;
         }
+        for (int e = 0; e < nrows; ++e) {
+            const int row = __builtin_amdgcn_readlane(rowv, e) & 0xFFFF;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) bad[c] |= (unsigned)xr[c][row];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (c * 64 + lane < nblk) fold_block(c * 64 + lane, R[c], bad[c]);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
@@ -657,6 +668,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
         } else if (REST && rw != 0) {
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, dstar, res);
+            TPROF(7);                                                  // REST pods: the whole select (profile builds: slot 7 = ticks here + tie-break count)
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
