@@ -960,7 +960,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
             const bool tprof = getenv_once_table_prof();
-            if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 8)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 64, c->stream)); cold.prof = c->d_table_prof.p; }
+            if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 12)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 96, c->stream)); cold.prof = c->d_table_prof.p; }
             HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
             HIP_TRY(c, hipMemcpyAsync(c->d_table_cold.p, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));             // `cold` is a stack object
@@ -977,12 +977,12 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
             if (tprof) {     // phase profile: mean ticks per scheduling cycle over the batch (profile builds only)
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
-                std::vector<unsigned long long> hp((size_t)S * 8);
+                std::vector<unsigned long long> hp((size_t)S * 12);
                 HIP_TRY(c, hipMemcpy(hp.data(), c->d_table_prof.p, hp.size() * 8, hipMemcpyDeviceToHost));
-                double acc[8] = {0};
-                for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 8; ++q) acc[q] += (double)hp[(size_t)s2 * 8 + q];
-                fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | eval+patch+store %.0f | canonical tie-breaks per cycle %.3f\n",
-                        S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[6] / S / P, acc[7] / S / P);
+                double acc[12] = {0};
+                for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 12; ++q) acc[q] += (double)hp[(size_t)s2 * 12 + q];
+                fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | state update %.0f | eval+patch+store %.0f | REST assume %.0f | REST select %.0f | canonical tie-breaks per cycle %.3f\n",
+                        S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[8] / S / P, acc[9] / S / P, acc[6] / S / P, acc[10] / S / P, acc[7] / S / P);
             }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
             T = 64; slots = (ni_top / (c->table_coarse ? 64 : 16) + 63) / 64; lds = table_lds;

@@ -41,7 +41,7 @@ struct TableCold {
     const int32_t *ncls, *rank, *cls_off, *clsprefix, *a_pods; const uint32_t *i_rq_cpu, *i_rq_mem, *i_nz_cpu, *i_nz_mem;
     const int32_t* i_npods; const SigRow* sigs; const ShapeRow* shapes; const ScenarioDesc* scen; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
-    unsigned long long* prof;   // [S][8] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
+    unsigned long long* prof;   // [S][12] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
     // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): mask rows per term class; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
     const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16
     const uint2* gsig;              // [G]

@@ -38,9 +38,9 @@
 #include <algorithm>
 
 // Phase profile of the scheduling cycle (profiles/build_variant.sh ... -DSIMON_TABLE_PROFILE): s_memtime stamps at the phase
-// boundaries, accumulated per wave, written to TableCold::prof ([workgroup][8] ticks).  Not compiled into the product build.
+// boundaries, accumulated per wave, written to TableCold::prof ([workgroup][12] ticks).  Not compiled into the product build.
 #ifdef SIMON_TABLE_PROFILE
-#define TPROF_DECL unsigned long long tp_prev = __builtin_readcyclecounter(), tp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TPROF_DECL unsigned long long tp_prev = __builtin_readcyclecounter(), tp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define TPROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tp_acc[i] += t_ - tp_prev; tp_prev = t_; } while (0)
 #define TPROF_WAIT_LDS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define TPROF_WAIT_MEM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
         } else if (REST && rw != 0) {
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, dstar, res);
-            TPROF(7);                                                  // REST pods: the whole select (profile builds: slot 7 = ticks here + tie-break count)
+            TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
@@ -792,6 +792,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             if (lane == 0) g_state[pstar] = st;
             const double rq_c = (double)st.rq_c, rq_m = (double)st.rq_m;
+            TPROF(8);                                                  // state update (readlanes of the signature's request), state store
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const unsigned nb_raw = eval_node(my_req_c[q], my_req_m[q], my_nz_c[q], my_nz_m[q], my_zero[q], rq_c, rq_m, nzc, nzm,
@@ -832,9 +833,10 @@ __global__ __launch_bounds__(64) void table_kernel(
                     }
                 }
             }
+            TPROF(9);                                                  // evaluation, patch, block key, summary / table stores
             if (REST && rw != 0) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs);
             __builtin_amdgcn_wave_barrier();
-            TPROF(6);                                                  // state update, eval, patch, block key, summary store
+            TPROF(6);                                                  // REST: term rows, GPU commit and GPU rows
         }
 #ifdef SIMON_TABLE_DEBUG
         if (lane == 0) printf("DBG s=%d step=%d sig=%d cls=%d pstar=%d dstar=%d res=%d top=%u ni=%d nblk=%d\n", s, i0 + il, r_sig, r_cls, pstar, dstar, res, top, ni, nblk);
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     um = wave_sum_i64(um);
 #ifdef SIMON_TABLE_PROFILE
     if (lane == 0 && cold->prof)
-        for (int q = 0; q < 8; ++q) cold->prof[(size_t)s * 8 + q] = tp_acc[q];
+        for (int q = 0; q < 12; ++q) cold->prof[(size_t)s * 12 + q] = tp_acc[q];
 #endif
     if (lane == 0) {
         cold->unscheduled[s] = unsched;
