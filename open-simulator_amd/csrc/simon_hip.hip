@@ -237,7 +237,9 @@ void choose_variant(simon_ctx* c) {
     if (c->K > 0 || c->v2_features()) return;
     const bool wants_rest = c->has_gpu || c->Tm > 0;
     if (wants_rest && !rest_supported(c)) return;
-    for (int64_t x : c->alloc_eph) if (x) return;
+    // ephemeral storage takes part only when somebody requests it: with no request and nothing requested at the start, fitsRequest's
+    // `Allocatable < request + Requested` (fit.go:264-270) is 0-false on every node whatever the allocatable
+    for (int64_t x : c->alloc_eph) if (x < 0) return;
     for (int64_t x : c->i_req_eph) if (x) return;
     for (int64_t x : c->p_req_eph) if (x) return;
     if (c->N >= (1 << 20) - 1) return;

@@ -406,3 +406,15 @@ def test_rest_path_randomised_slice():
             bad.append(info)
     assert not bad, bad
     assert on_rest >= 16, "the slice should mostly run on generation 6"
+
+
+def test_ephemeral_allocatable_without_requests_keeps_the_score_table():
+    """Nodes that advertise ephemeral storage nobody asks for (every real node does) do not push a cpu+memory problem onto the
+    all-feature kernel: `Allocatable < request + Requested` is 0 < 0 on every node (fit.go:264-270)."""
+    prob, scen, orders = synth.config3(n_counts=12, n_orders=2, n_pods=2500)
+    prob.alloc_eph = np.full(len(prob.alloc_cpu), 100 << 30, np.int64)
+    sub = scen[::4]
+    ref = O.run_threaded(prob, sub, orders)
+    res, variant = run_gpu(prob, sub, orders)
+    assert variant == capi.KERNEL_NARROW_CACHE
+    assert_same(res, ref)
