@@ -556,16 +556,21 @@ __global__ __launch_bounds__(64) void table_kernel(
         if (!__ballot(present)) return -1;
         const int pos = (int)(PMASK - (cbest & PMASK));
         const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
-        const int canon = present ? cls_list[idx] : 0;
         // SimonPlugin / GpuSharePlugin NormalizeScore over the classes that hold a feasible node (as renormalise, above)
         const int lo = wave_min_i32(present ? rawc : 0x7fffffff);
         const int hi = wave_max_i32(present ? rawc : (int)0x80000000);
         const int range = hi >= lo ? hi - lo : 0;
         const double rr = range ? 1.0 / (double)range : 0.0;
         const int sn = (present && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
-        const unsigned key = present ? ((((cbest >> KB) + (unsigned)sn) << KB) | (PMASK - (unsigned)canon)) : 0u;
-        const unsigned kmax = wave_max_u32(key);
-        const int wl = __builtin_ctzll(__ballot(present && key == kmax));
+        const unsigned total = present ? (cbest >> KB) + (unsigned)sn : 0u;   // >= 1 when present (the byte is 1 + score)
+        const unsigned tmax = wave_max_u32(total);
+        unsigned long long tied = __ballot(present && total == tmax);
+        int wl = __builtin_ctzll(tied);
+        if (tied & (tied - 1)) {                                          // several classes reach the maximum: first in canonical order
+            const int canon = (present && total == tmax) ? cls_list[idx] : (int)PMASK;
+            const unsigned cmin = wave_max_u32((present && total == tmax) ? PMASK - (unsigned)canon : 0u);
+            wl = __builtin_ctzll(__ballot(present && total == tmax && PMASK - (unsigned)canon == cmin));
+        }
         dstar = wl;
         res = __builtin_amdgcn_readlane(idx, wl);
         return __builtin_amdgcn_readlane(pos, wl);
