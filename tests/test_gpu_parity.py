@@ -306,6 +306,27 @@ def test_explain_on_a_narrow_problem():
     assert n == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
 
 
+def test_explain_on_a_generation_6_problem():
+    """GPU-share / anti-affinity failure codes of a batch that ran on the score-table kernel's REST path: simon_explain and
+    simon_explain_loaded stage the all-feature kernel lazily, the group API shards the same batch over two contexts."""
+    prob = randprob.rand_problem(7421, N=40, P=500, gpu=True, anti_host=True, tight_pods=True, static_mask=True)
+    scen, orders = randprob.rand_scenarios(3, prob, S=4)
+    ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=32)
+    assert nf > 0 and ((codes & 0xF000) == capi.FAIL_GPUSHARE).any()
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        assert ctx.stats().kernel_generation == 6
+        assert_same(res, O.run(prob, scen, orders))
+        n, f2, c2 = ctx.explain(int(scen[0, 0]), orders[scen[0, 1]], max_failed=32)
+        assert n == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
+        n, f2, c2 = ctx.explain_loaded(0, max_failed=32)
+        assert n == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
+    with capi.Group([0, 0]) as g:
+        g.load_problem(prob)
+        assert_same(g.run_batch(scen, orders), O.run(prob, scen, orders))
+
+
 def test_k8s_fixtures_on_gpu():
     """YAML-level cases (reference example/ inputs and random clusters, tests/golden/k8s_*.json): the HIP path must
     reproduce the placements of the independent object-level scheduler (tests/pyref_sched.py), no oracle in the loop."""
