@@ -105,8 +105,10 @@ struct simon_ctx : simon::HostInputs {
     // REST path of the score-table kernel (Open-Gpu-Share + node-level required anti-affinity): decided by choose_variant
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
-    uint64_t g_gpu = 1;                          // gcd of every GPU memory quantity
-    int rest_M = 0, rest_G = 0;                  // mask rows; GPU signatures
+    uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
+    bool xres = false;                           // some pod requests ephemeral storage or an extended resource
+    int rest_M = 0, rest_G = 0, rest_X = 0;      // mask rows; GPU requests; extra-resource requests
+    DevBuf<uint32_t> d_xsig, d_xalloc, d_i_xused;
     DevBuf<int32_t> d_xrows, d_gpu_cnt;
     DevBuf<uint32_t> d_gpu_devtot, d_i_gused;
     DevBuf<uint2> d_gsig;
@@ -197,6 +199,43 @@ bool rest_supported(simon_ctx* c) {
         }
         if (!key_ok[k]) return false;
     }
+    c->g_eph = 1;
+    static_assert(SIMON_MAX_SCALAR == 4, "simon_table.hip keeps ephemeral storage + 4 extended resources in 5 components");
+    if (c->xres) {
+        // Extra resources as mask rows: the rows stand for `Allocatable < request + Requested`, which is also what fitsRequest asks of
+        // pods that request NONE of them (ephemeral storage is compared whatever the request) -- exact as long as Requested never
+        // exceeds Allocatable: nothing over-committed at the start, and no pod bound by Spec.NodeName (no filter) requests any.
+        uint64_t g = 0;
+        const uint64_t lim31 = 1ull << 31;
+        for (int j = 0; j < c->N; ++j) {
+            if (c->i_req_eph[j] < 0 || c->i_req_eph[j] > c->alloc_eph[j]) return false;
+            g = gcd_u64(gcd_u64(g, (uint64_t)c->alloc_eph[j]), (uint64_t)c->i_req_eph[j]);
+            for (int k = 0; k < c->K; ++k) {
+                const int64_t a = c->scalar_alloc[(size_t)k * c->N + j], u = c->i_scalar_req[(size_t)k * c->N + j];
+                if (a < 0 || u < 0 || u > a || (uint64_t)a >= lim31) return false;
+            }
+        }
+        std::set<std::vector<int64_t>> sigs;
+        for (int p = 0; p < c->P; ++p) {
+            std::vector<int64_t> key{c->p_req_eph[p]};
+            bool any = c->p_req_eph[p] != 0;
+            if (c->p_req_eph[p] < 0) return false;
+            for (int k = 0; k < c->K; ++k) {
+                const int64_t q = c->p_scalar[(size_t)k * c->P + p];
+                if (q < 0 || (uint64_t)q >= lim31) return false;
+                key.push_back(q); any = any || q != 0;
+            }
+            if (!any) continue;
+            if (c->p_preset[p] >= 0) return false;
+            g = gcd_u64(g, (uint64_t)c->p_req_eph[p]);
+            sigs.insert(key);
+            if ((int)sigs.size() > kTableMaxXres) return false;
+        }
+        if (!g) g = 1;
+        for (int j = 0; j < c->N; ++j) if ((uint64_t)c->alloc_eph[j] / g >= lim31) return false;
+        for (int p = 0; p < c->P; ++p) if ((uint64_t)c->p_req_eph[p] / g >= lim31) return false;
+        c->g_eph = g;
+    }
     c->g_gpu = 1;
     if (c->has_gpu) {
         uint64_t g = 0;
@@ -234,14 +273,17 @@ void choose_variant(simon_ctx* c) {
     c->g_cpu = c->g_mem = 1;
     if (c->force_wide) return;
     c->rest = false;
-    if (c->K > 0 || c->v2_features()) return;
-    const bool wants_rest = c->has_gpu || c->Tm > 0;
-    if (wants_rest && !rest_supported(c)) return;
-    // ephemeral storage takes part only when somebody requests it: with no request and nothing requested at the start, fitsRequest's
-    // `Allocatable < request + Requested` (fit.go:264-270) is 0-false on every node whatever the allocatable
+    if (c->v2_features()) return;
+    // Ephemeral storage and extended resources take part only when somebody requests them: with no request and nothing requested at
+    // the start, fitsRequest's `Allocatable < request + Requested` (fit.go:264-299) is 0-false on every node whatever the allocatable.
     for (int64_t x : c->alloc_eph) if (x < 0) return;
-    for (int64_t x : c->i_req_eph) if (x) return;
-    for (int64_t x : c->p_req_eph) if (x) return;
+    c->xres = false;
+    for (int64_t x : c->i_req_eph) if (x) c->xres = true;
+    for (int64_t x : c->p_req_eph) if (x) c->xres = true;
+    for (int64_t x : c->i_scalar_req) if (x) c->xres = true;
+    for (int64_t x : c->p_scalar) if (x) c->xres = true;
+    const bool wants_rest = c->has_gpu || c->Tm > 0 || c->xres;
+    if (wants_rest && !rest_supported(c)) return;
     if (c->N >= (1 << 20) - 1) return;
     const uint64_t gc = gcd_of({&c->alloc_cpu, &c->i_req_cpu, &c->i_nz_cpu, &c->p_req_cpu, &c->p_nz_cpu});
     const uint64_t gm = gcd_of({&c->alloc_mem, &c->i_req_mem, &c->i_nz_mem, &c->p_req_mem, &c->p_nz_mem});
@@ -291,7 +333,9 @@ int stage_narrow(simon_ctx* c) {
         r.cls = c->p_cls[p];
         r.preset = c->p_preset[p];
         r.gate = c->p_gate[p];
-        r.flags = (c->p_req_cpu[p] == 0 && c->p_req_mem[p] == 0) ? 1u : 0u;
+        bool no_xres = c->p_req_eph[p] == 0;                     // fit.go:244-249: the early return needs EVERY request to be zero
+        for (int k = 0; k < c->K && no_xres; ++k) no_xres = c->p_scalar[(size_t)k * c->P + p] == 0;
+        r.flags = (c->p_req_cpu[p] == 0 && c->p_req_mem[p] == 0 && no_xres) ? 1u : 0u;
     }
     std::vector<int32_t> raw32(c->simon_raw.begin(), c->simon_raw.end());
     hipStream_t st = c->stream;
@@ -348,7 +392,8 @@ int stage_narrow(simon_ctx* c) {
         // REST descriptors: term class (which mask rows a pod must find clear / sets) and GPU signature of every pod
         std::vector<int32_t> xrows;           // entries of every term class: filter row | set row << 16
         std::vector<uint2> gsigs;
-        c->rest_M = c->rest_G = 0;
+        std::vector<uint32_t> xsigs;          // [X][8]
+        c->rest_M = c->rest_G = c->rest_X = 0;
         if (c->rest && c->table_ok) {
             std::map<std::pair<uint32_t, int32_t>, int> gs_id;
             std::vector<int> gs_of(P, -1);
@@ -359,8 +404,21 @@ int stage_narrow(simon_ctx* c) {
                 if (it.second) gsigs.push_back(make_uint2(key.first, (unsigned)key.second));
                 gs_of[p] = it.first->second;
             }
-            const int G = (int)gsigs.size(), T = c->Tm;
-            c->rest_G = G; c->rest_M = std::max(G + 2 * T, 1);
+            std::map<std::vector<uint32_t>, int> xs_id;
+            std::vector<int> xs_of(P, -1);
+            for (int p = 0; p < P && c->xres; ++p) {
+                std::vector<uint32_t> key(8, 0);
+                key[0] = (uint32_t)((uint64_t)c->p_req_eph[p] / c->g_eph);
+                bool any = key[0] != 0;
+                for (int k = 0; k < c->K; ++k) { key[1 + k] = (uint32_t)c->p_scalar[(size_t)k * P + p]; any = any || key[1 + k] != 0; }
+                if (!any) continue;
+                auto it = xs_id.emplace(key, (int)xs_id.size());
+                if (it.second) xsigs.insert(xsigs.end(), key.begin(), key.end());
+                xs_of[p] = it.first->second;
+            }
+            const int Xn = (int)xs_id.size();
+            const int G = (int)gsigs.size(), T = c->Tm, B = G + Xn;          // term rows start behind the request rows
+            c->rest_G = G; c->rest_X = Xn; c->rest_M = std::max(B + 2 * T, 1);
             std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;   // -> n | offset << 6
             std::vector<int> xc_of(c->Cp, 0);
             for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
@@ -370,17 +428,17 @@ int stage_narrow(simon_ctx* c) {
                 std::sort(match.begin(), match.end()); match.erase(std::unique(match.begin(), match.end()), match.end());
                 if (anti.empty() && match.empty()) continue;
                 const size_t n = anti.size() + match.size(), off = xrows.size();
-                if (n > 63 || off + n >= (1u << 20)) { c->table_ok = false; break; }   // one lane per entry; 20-bit offsets
+                if (n > 63 || off + n >= (1u << 14)) { c->table_ok = false; break; }   // one lane per entry; 14-bit offsets
                 auto it = xc_id.emplace(std::make_pair(anti, match), (int)(n | (off << 6)));
                 if (it.second) {
-                    // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row G + t), or a placed pod
-                    // REQUIRES a term that matches me (row G + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
-                    for (int t : anti) xrows.push_back((G + t) | ((G + T + t) << 16));
-                    for (int t : match) xrows.push_back((G + T + t) | ((G + t) << 16));
+                    // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row B + t), or a placed pod
+                    // REQUIRES a term that matches me (row B + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
+                    for (int t : anti) xrows.push_back((B + t) | ((B + T + t) << 16));
+                    for (int t : match) xrows.push_back((B + T + t) | ((B + t) << 16));
                 }
                 xc_of[cp] = it.first->second;
             }
-            for (int p = 0; p < P; ++p) rowsC[p].rest = (gs_of[p] + 1) | (xc_of[c->p_cls[p]] << 6);
+            for (int p = 0; p < P; ++p) rowsC[p].rest = (gs_of[p] + 1) | ((xs_of[p] + 1) << 6) | (int)((unsigned)xc_of[c->p_cls[p]] << 12);
         }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
@@ -447,6 +505,17 @@ int stage_narrow(simon_ctx* c) {
                 std::vector<int32_t> gcnt(N, 0);
                 if (c->has_gpu) gcnt = c->gpu_cnt;
                 HIP_TRY(c, c->d_xrows.upload(xrows, st));
+                std::vector<uint32_t> xalloc((size_t)N * 8, 0), xused((size_t)N * 8, 0);
+                for (int j = 0; j < N && c->xres; ++j) {
+                    xalloc[(size_t)j * 8] = (uint32_t)((uint64_t)c->alloc_eph[j] / c->g_eph);
+                    xused[(size_t)j * 8] = (uint32_t)((uint64_t)c->i_req_eph[j] / c->g_eph);
+                    for (int k = 0; k < c->K; ++k) {
+                        xalloc[(size_t)j * 8 + 1 + k] = (uint32_t)c->scalar_alloc[(size_t)k * N + j];
+                        xused[(size_t)j * 8 + 1 + k] = (uint32_t)c->i_scalar_req[(size_t)k * N + j];
+                    }
+                }
+                if (xsigs.empty()) xsigs.assign(8, 0);
+                HIP_TRY(c, c->d_xsig.upload(xsigs, st)); HIP_TRY(c, c->d_xalloc.upload(xalloc, st)); HIP_TRY(c, c->d_i_xused.upload(xused, st));
                 HIP_TRY(c, c->d_gsig.upload(gsigs, st)); HIP_TRY(c, c->d_gpu_cnt.upload(gcnt, st));
                 HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
             }
@@ -958,7 +1027,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
             if (c->rest) {
-                cold.xrows = c->d_xrows.p;
+                cold.xrows = c->d_xrows.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
             const bool tprof = getenv_once_table_prof();
@@ -971,7 +1040,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

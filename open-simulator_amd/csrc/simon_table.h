@@ -1,5 +1,6 @@
-// simon_table.h -- host/device interface of simon_table.hip (generation 4 of the cpu+memory scenario kernel:
-// one wave per scenario over a (signature, node) byte table, class term folded into the block summaries).
+// simon_table.h -- host/device interface of simon_table.hip (generations 4 to 6 of the cpu+memory scenario kernel:
+// one wave per scenario over a (signature, node) byte table, class term folded into the block summaries; 5: two-level
+// summary; 6: + Open-Gpu-Share and node-level anti-affinity as per-block position masks).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,13 +26,13 @@ struct ShapeRow {    // capacity of one internal node class = one distinct (Allo
 };
 static_assert(sizeof(ShapeRow) == 48, "ShapeRow must be 48 bytes");
 
-// 16 B: signature | table class << 8, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) GPU signature + 1 | rows << 6 |
-// offset << 12 of the pod's entries in TableCold::xrows (0 = the pod is decided by the score table alone)
+// 16 B: signature | table class << 8, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) GPU request + 1 | extra-resource
+// request + 1 << 6 | entries << 12 | offset << 18 of the pod's entries in TableCold::xrows (0 = the score table alone decides the pod)
 struct PodRowC { int32_t sigcls, preset, gate, rest; };
 
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
-    int32_t M, G;        // REST: rows of the per-block position masks (G GPU signatures + 2 x terms); GPU signatures
+    int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
     uint64_t g_cpu, g_mem;
 };
@@ -45,6 +46,9 @@ struct TableCold {
     // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): mask rows per term class; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
     const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16
     const uint2* gsig;              // [G]
+    // extra resources = ephemeral storage (gcd units) + SIMON_MAX_SCALAR extended resources: requests [X][8], the pool's
+    // allocatable and Requested at the start [N][8] (component 0 = ephemeral storage, 1.. = extended resources)
+    const uint32_t *xsig, *xalloc, *i_xused;
     const int32_t* gpu_cnt;         // [N]
     const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)
 };
@@ -66,6 +70,7 @@ constexpr int kTableMaxPaddedCoarse = 8192;   // ... with the two-level summary 
 constexpr int kTableMaxSigs = 128;      // two signatures per lane
 constexpr size_t kTableLdsPerCU = 160 * 1024;
 constexpr int kTableMaxGpuSigs = 32;    // distinct (gpu-mem, gpu-count) requests: one mask row and one lane each
+constexpr int kTableMaxXres = 32;       // distinct (ephemeral-storage, extended-resource) requests: one mask row and one lane each
 constexpr int kTableMaxTerms = 120;     // node-level anti-affinity terms: two mask rows each
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 

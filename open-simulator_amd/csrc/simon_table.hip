@@ -1,4 +1,4 @@
-// simon_table.hip -- cpu+memory scenario kernel, generation 4: one WAVE = one capacity-planning scenario over a
+// simon_table.hip -- cpu+memory scenario kernel, generations 4 to 6: one WAVE = one capacity-planning scenario over a
 // (signature, node) score table, with the class term folded into the block summaries.
 //
 // What generation 3 (simon_cache.hip) established: a scheduling cycle changes ONE node, pods come from K distinct
@@ -30,9 +30,14 @@
 // k with exactly the fp64 sequences of simon_fast.hip / simon_cache.hip, patches its byte, re-reduces its row and
 // stores the summary entry.
 //
-// Limits: K <= 128 signatures (two per lane), padded scenario size <= 4096 positions (<= 4095 nodes), <= 64 node
-// classes, <= 256 node shapes, NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders
-// are permutations.
+// Generation 5 (template COARSE, see tcarve): two-level summary -- 64-position entries in LDS, per-16 entries and the
+// feasible-node counters in HBM -- for batches whose one-level summary would starve the CU of waves (many signatures).
+// Generation 6 (template REST, see table_kernel): pods with per-node filters the table cannot hold (Open-Gpu-Share devices,
+// required anti-affinity on node-level topology keys) scan their signature's rows under per-block position masks.
+//
+// Limits: K <= 128 signatures (two per lane), padded scenario size <= 4096 positions (<= 4095 nodes; two-level: 8192 /
+// 8191), <= 64 node classes, NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are
+// permutations; REST: <= 32 GPU requests, <= 120 terms, <= 63 mask rows per pod.
 #include "simon_table.h"
 
 #include <algorithm>
@@ -160,13 +165,13 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
 // NonZeroRequested differs from Requested) [ni] x 8 B, and (COARSE) the per-16 summary entries [ni / 64][K][4] u16 and the
 // feasible-node counters [K][Cn] i32
 // ... and (REST, M mask rows) the position masks [ni / 16][M] u16 and the GPU devices of every position: used [ni][8], per-device
-// total [ni], device count [ni] (u32 each)
+// total [ni], device count [ni] (u32 each), extra-resource Requested [ni][8] and allocatable [ni][8]
 __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
-    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * 40;
+    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64);
     return w;
 }
 
@@ -222,6 +227,15 @@ __device__ __forceinline__ void gpu_commit_t(unsigned (&u)[8], int cnt, unsigned
 // branch costs the common kernel time).
 // NBQ: blocks per lane (1, 2 or 4: padded scenario sizes up to 1024 / 2048 / 4096 positions) -- a template parameter so that the
 // scan is straight-line code (as run-time conditions the four reads became four dependent LDS round trips).
+// fitsRequest's ephemeral-storage and extended-resource checks (fit.go:264-299) of one request on one node: component 0 is checked
+// whatever the request, an extended resource only when the pod names it (non-zero)
+__device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsigned (&used)[5], const unsigned (&alloc)[5]) {
+    bool ok = !(alloc[0] < req[0] + used[0]);
+#pragma unroll
+    for (int r = 1; r < 5; ++r) ok = ok && !(req[r] != 0u && alloc[r] < req[r] + used[r]);
+    return ok;
+}
+
 // NBQ counts summary ENTRIES per lane: 16 positions each, or 64 with COARSE (tcarve, above).
 // REST: some pods carry filters the (signature, node) table cannot hold -- Open-Gpu-Share device memory, required anti-affinity on
 // a node-level topology key (both directions).  Those filters live as per-block POSITION MASKS xm[block][row] (u16, bit = node
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     constexpr unsigned PMASK = (1u << KB) - 1u;
     static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
-    const int M = REST ? sc.M : 0, G = REST ? sc.G : 0;
+    const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0;
     unsigned char* s_ucls = smem + cv.ucls;                         // REST: [entries] node class of a summary entry
     const int nbp = cv.nbp;
     unsigned char* s_sn = smem + cv.sn;                             // [K][Cn]: the class term (<= 200) currently folded into row k
@@ -297,6 +311,8 @@ __global__ __launch_bounds__(64) void table_kernel(
     unsigned* g_gused = (unsigned*)((unsigned char*)g_xm + (((size_t)nblk * M * 2 + 127) & ~(size_t)127));
     unsigned* g_gtot = g_gused + (size_t)ni * 8;
     int* g_gcnt = (int*)(g_gtot + ni);
+    unsigned* g_xused = (unsigned*)(g_gcnt + ni);                     // [ni][8]: Requested ephemeral storage, extended resources
+    unsigned* g_xalloc = g_xused + (size_t)ni * 8;                    // [ni][8]: their allocatable
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -407,6 +423,22 @@ __global__ __launch_bounds__(64) void table_kernel(
                 const unsigned long long bal = __ballot(!fits);
                 if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + g] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
             }
+            if (X > 0) {                                                  // extra resources of the position, row of every request
+                const uint4 a0 = real ? *(const uint4*)(cold->xalloc + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
+                const unsigned a4 = real ? cold->xalloc[(size_t)j * 8 + 4] : 0u;
+                const uint4 u0 = real ? *(const uint4*)(cold->i_xused + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
+                const unsigned u4 = real ? cold->i_xused[(size_t)j * 8 + 4] : 0u;
+                *(uint4*)(g_xalloc + (size_t)p * 8) = a0; *(uint4*)(g_xalloc + (size_t)p * 8 + 4) = make_uint4(a4, 0, 0, 0);
+                *(uint4*)(g_xused + (size_t)p * 8) = u0; *(uint4*)(g_xused + (size_t)p * 8 + 4) = make_uint4(u4, 0, 0, 0);
+                const unsigned al[5] = {a0.x, a0.y, a0.z, a0.w, a4}, us[5] = {u0.x, u0.y, u0.z, u0.w, u4};
+                for (int x = 0; x < X; ++x) {
+                    const uint4 q0 = *(const uint4*)(cold->xsig + (size_t)x * 8);
+                    const unsigned rq[5] = {q0.x, q0.y, q0.z, q0.w, cold->xsig[(size_t)x * 8 + 4]};
+                    const bool fits = real && xres_fits_t(rq, us, al);
+                    const unsigned long long bal = __ballot(!fits);
+                    if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + G + x] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
+                }
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,14 +531,21 @@ __global__ __launch_bounds__(64) void table_kernel(
     };
 
     // ---- REST path -------------------------------------------------------------------------------------------------------
-    // A REST pod's descriptor (PodRowC::rest) = GPU signature + 1 | rows << 6 | offset << 12 into xrows: entry e < rows packs the
+    // A REST pod's descriptor (PodRowC::rest) = GPU request + 1 | extra-resource request + 1 << 6 | rows << 12 | offset << 18 into xrows: entry e < rows packs the
     // mask row the pod must find clear (low half) and the row it sets when it lands (high half).  Lane e holds entry e (`rowv`,
     // ONE vector load per pod, issued when the cycle starts); everything else about the pod's filters is register traffic.
     const uint2 my_gsig = REST ? cold->gsig[lane < G ? lane : 0] : make_uint2(0, 0);    // lane g: GPU signature g
+    unsigned my_xsig[5] = {0, 0, 0, 0, 0};                                              // lane 32 + x: extra-resource request x
+    if (REST && X > 0) {
+        const int x = (lane >= 32 && lane - 32 < X) ? lane - 32 : 0;
+        const uint4 q0 = *(const uint4*)(cold->xsig + (size_t)x * 8);
+        my_xsig[0] = q0.x; my_xsig[1] = q0.y; my_xsig[2] = q0.z; my_xsig[3] = q0.w; my_xsig[4] = cold->xsig[(size_t)x * 8 + 4];
+    }
     // OR of the pod's filter rows for block b (lane-varying b < nblk), all loads independent
-    auto excluded = [&](int b, int nrows, int rowv, int gs) -> unsigned {
+    auto excluded = [&](int b, int nrows, int rowv, int gs, int xs) -> unsigned {
         const unsigned short* xr = g_xm + (size_t)b * M;
         unsigned bad = gs >= 0 ? (unsigned)xr[gs] : 0u;
+        if (xs >= 0) bad |= (unsigned)xr[G + xs];
         for (int e = 0; e < nrows; ++e) bad |= (unsigned)xr[__builtin_amdgcn_readlane(rowv, e) & 0xFFFF];
         return bad;
     };
@@ -522,7 +561,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
     };
     // findNodesThatFitPod + prioritizeNodes + selectHost of a REST pod: returns the position (-1: no node), sets dstar / res
-    auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int& dstar, int& res) -> int {
+    auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int xs, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
@@ -540,6 +579,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             R[c] = *(const uint4*)(g_tile + ((unsigned)cbk * Krow + koff16));
             xr[c] = g_xm + (size_t)cbk * M;
             bad[c] = gs >= 0 ? (unsigned)xr[c][gs] : 0u;
+            if (xs >= 0) bad[c] |= (unsigned)xr[c][G + xs];
         }
         for (int e = 0; e < nrows; ++e) {
             const int row = __builtin_amdgcn_readlane(rowv, e) & 0xFFFF;
@@ -577,8 +617,8 @@ __global__ __launch_bounds__(64) void table_kernel(
     };
     // What assume adds for a REST pod landing on position pstar: its term rows, the GPU commit and the GPU rows of that node.
     // Two halves: the loads go out with the table-row loads of the cycle, the updates follow the evaluation.
-    struct RestLoads { unsigned xr_set, xr_g, tot; int gc; uint4 ua, ub; };
-    auto rest_assume_load = [&](int pstar, int nrows, int rowv, int gs) -> RestLoads {
+    struct RestLoads { unsigned xr_set, xr_g, xr_x, tot, xu4, xa4; int gc; uint4 ua, ub, xu, xa; };
+    auto rest_assume_load = [&](int pstar, int nrows, int rowv, int gs, int xs) -> RestLoads {
         RestLoads L{};
         const unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
         if (lane < nrows) L.xr_set = xr[(unsigned)rowv >> 16];
@@ -589,9 +629,14 @@ __global__ __launch_bounds__(64) void table_kernel(
             L.ub = *(const uint4*)(g_gused + (size_t)pstar * 8 + 4);
             if (lane < G) L.xr_g = xr[lane];
         }
+        if (xs >= 0) {
+            L.xu = *(const uint4*)(g_xused + (size_t)pstar * 8); L.xu4 = g_xused[(size_t)pstar * 8 + 4];
+            L.xa = *(const uint4*)(g_xalloc + (size_t)pstar * 8); L.xa4 = g_xalloc[(size_t)pstar * 8 + 4];
+            if (lane >= 32 && lane - 32 < X) L.xr_x = xr[G + lane - 32];
+        }
         return L;
     };
-    auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs) {
+    auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs, int xs) {
         const unsigned bit = 1u << (pstar & 15);
         unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
         if (lane < nrows) xr[(unsigned)rowv >> 16] = (unsigned short)(L.xr_set | bit);
@@ -607,6 +652,20 @@ __global__ __launch_bounds__(64) void table_kernel(
             if (lane < G) {                                               // lane g: does GPU signature g still fit this node?
                 const bool fits = gpu_fits_t(u, L.gc, L.tot, my_gsig.x, (int)my_gsig.y);
                 xr[lane] = (unsigned short)(fits ? (L.xr_g & ~bit) : (L.xr_g | bit));
+            }
+        }
+        if (xs >= 0) {                                                    // Requested += the pod's ephemeral storage / extended resources
+            unsigned us[5] = {L.xu.x, L.xu.y, L.xu.z, L.xu.w, L.xu4};
+            const unsigned al[5] = {L.xa.x, L.xa.y, L.xa.z, L.xa.w, L.xa4};
+#pragma unroll
+            for (int r = 0; r < 5; ++r) us[r] += (unsigned)__builtin_amdgcn_readlane((int)my_xsig[r], 32 + xs);
+            if (lane == 0) {
+                *(uint4*)(g_xused + (size_t)pstar * 8) = make_uint4(us[0], us[1], us[2], us[3]);
+                g_xused[(size_t)pstar * 8 + 4] = us[4];
+            }
+            if (lane >= 32 && lane - 32 < X) {                            // lane 32 + x: does request x still fit this node?
+                const bool fits = xres_fits_t(my_xsig, us, al);
+                xr[G + lane - 32] = (unsigned short)(fits ? (L.xr_x & ~bit) : (L.xr_x | bit));
             }
         }
     };
@@ -636,9 +695,9 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0xFF, r_cls = (pk >> 8) & 0x7FFFFF;
         const int rw = REST ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST descriptor (0: the score table alone decides the pod)
-        const int r_gs = (rw & 63) - 1, r_nrows = (rw >> 6) & 63;
+        const int r_gs = (rw & 63) - 1, r_xs = ((rw >> 6) & 63) - 1, r_nrows = (rw >> 12) & 63;
         int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
-        if (REST && lane < r_nrows) rowv = cold->xrows[(rw >> 12) + lane];
+        if (REST && lane < r_nrows) rowv = cold->xrows[((unsigned)rw >> 18) + lane];
 
         // res: what the placement row records for this step: >= 0 an index into cls_list (turned into the canonical node index
         // 64 steps at a time, off the critical path), -1 unschedulable, -2 not part of the scenario
@@ -666,13 +725,13 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
                     const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
                     bool clear = true;
-                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs)) >> (pp & 15)) & 1u);
+                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs, r_xs)) >> (pp & 15)) & 1u);
                     if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
                 }
                 if (res < 0) ++unsched;
             }
         } else if (REST && rw != 0) {
-            pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, dstar, res);
+            pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
@@ -774,7 +833,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             const int blk = pstar >> 4, pos = pstar & 15;
             RestLoads RL{};
-            if (REST && rw != 0) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs);
+            if (REST && rw != 0) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
             const ShapeRow sh = s_shape[dstar];
             unsigned snq[KQ];
 #pragma unroll
@@ -839,7 +898,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 }
             }
             TPROF(9);                                                  // evaluation, patch, block key, summary / table stores
-            if (REST && rw != 0) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs);
+            if (REST && rw != 0) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // REST: term rows, GPU commit and GPU rows
         }

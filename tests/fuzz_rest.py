@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep aimed at generation 6 of the score-table kernel (simon_table.hip, REST path): cpu+memory problems with
-Open-Gpu-Share devices and / or required anti-affinity on node-level topology keys, 1 ... 8 191 nodes, 1 ... 64 internal node
+Open-Gpu-Share devices and / or required anti-affinity on node-level topology keys, ephemeral storage, extended resources, 1 ... 8 191 nodes, 1 ... 64 internal node
 classes, up to 120 pod classes (term classes, table classes), presets (bound without Reserve), gates, pinned pods, static masks,
 initial node and device state, zero requests, tight pod counts.  Not collected by pytest (a slice runs in
 tests/test_gpu_round2.py); by hand on a GPU box:   python tests/fuzz_rest.py [n_cases] [first_seed]
@@ -31,6 +31,10 @@ def one_case(case):
         feat["gpu"] = True
     if kind != 0:
         feat["anti_host"] = True
+    if rng.random() < 0.3:                # ephemeral storage / extended resources (on generation 6 unless presets or initial
+        feat["eph"] = True                # state over-commit a node: then the all-feature kernel takes the case)
+    if rng.random() < 0.3:
+        feat["scalars"] = int(rng.integers(1, 5))
     if size >= 2:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
     n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))
