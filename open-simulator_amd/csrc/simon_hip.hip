@@ -273,7 +273,7 @@ void choose_variant(simon_ctx* c) {
     c->g_cpu = c->g_mem = 1;
     if (c->force_wide) return;
     c->rest = false;
-    if (c->v2_features()) return;
+    if (c->v2_features_but_ports()) return;
     // Ephemeral storage and extended resources take part only when somebody requests them: with no request and nothing requested at
     // the start, fitsRequest's `Allocatable < request + Requested` (fit.go:264-299) is 0-false on every node whatever the allocatable.
     for (int64_t x : c->alloc_eph) if (x < 0) return;
@@ -418,23 +418,31 @@ int stage_narrow(simon_ctx* c) {
             }
             const int Xn = (int)xs_id.size();
             const int G = (int)gsigs.size(), T = c->Tm, B = G + Xn;          // term rows start behind the request rows
-            c->rest_G = G; c->rest_X = Xn; c->rest_M = std::max(B + 2 * T, 1);
+            c->rest_G = G; c->rest_X = Xn; c->rest_M = B + 2 * T + 1;             // + one scratch row (set by port entries, never read)
             std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;   // -> n | offset << 6
             std::vector<int> xc_of(c->Cp, 0);
             for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
                 std::vector<int32_t> anti(c->anti_idx.begin() + c->anti_off[cp], c->anti_idx.begin() + c->anti_off[cp + 1]);
                 std::vector<int32_t> match(c->match_idx.begin() + c->match_off[cp], c->match_idx.begin() + c->match_off[cp + 1]);
+                std::vector<int32_t> port;     // NodePorts (node_ports.go:104-127): port terms this class CONFLICTS with
+                if (!c->port_off.empty()) port.assign(c->port_idx.begin() + c->port_off[cp], c->port_idx.begin() + c->port_off[cp + 1]);
                 std::sort(anti.begin(), anti.end()); anti.erase(std::unique(anti.begin(), anti.end()), anti.end());
                 std::sort(match.begin(), match.end()); match.erase(std::unique(match.begin(), match.end()), match.end());
-                if (anti.empty() && match.empty()) continue;
-                const size_t n = anti.size() + match.size(), off = xrows.size();
+                std::sort(port.begin(), port.end()); port.erase(std::unique(port.begin(), port.end()), port.end());
+                if (anti.empty() && match.empty() && port.empty()) continue;
+                const size_t n = anti.size() + match.size() + port.size(), off = xrows.size();
                 if (n > 63 || off + n >= (1u << 14)) { c->table_ok = false; break; }   // one lane per entry; 14-bit offsets
-                auto it = xc_id.emplace(std::make_pair(anti, match), (int)(n | (off << 6)));
+                std::vector<int32_t> anti_key = anti;       // key: (anti list, -1, port list), match list
+                anti_key.push_back(-1); anti_key.insert(anti_key.end(), port.begin(), port.end());
+                auto it = xc_id.emplace(std::make_pair(anti_key, match), (int)(n | (off << 6)));
                 if (it.second) {
                     // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row B + t), or a placed pod
                     // REQUIRES a term that matches me (row B + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
                     for (int t : anti) xrows.push_back((B + t) | ((B + T + t) << 16));
                     for (int t : match) xrows.push_back((B + T + t) | ((B + t) << 16));
+                    // a conflicting port is in use on the node: a placed pod MATCHES (binds) port term t; nothing to set -- the
+                    // entry's set-row repeats a row the class sets anyway, or a scratch row behind the last term row
+                    for (int t : port) xrows.push_back((B + t) | ((B + 2 * T) << 16));
                 }
                 xc_of[cp] = it.first->second;
             }

@@ -45,6 +45,10 @@ struct HostInputs {
     std::vector<int64_t> l_vg_cap, l_vg_req, l_dev_cap;
     std::vector<simon_local_spec> l_specs;
     bool has_ipa_score = false;   // any pref_* or own_* entry exists
+    // everything of v2_features() but NodePorts (port terms are node-level by construction: the score-table kernel's REST path takes them)
+    bool v2_features_but_ports() const {
+        return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || has_local;
+    }
     bool v2_features() const {
         return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || !port_idx.empty() || has_local;
     }

@@ -35,6 +35,8 @@ def one_case(case):
         feat["eph"] = True                # state over-commit a node: then the all-feature kernel takes the case)
     if rng.random() < 0.3:
         feat["scalars"] = int(rng.integers(1, 5))
+    if rng.random() < 0.25:
+        feat["ports"] = True              # NodePorts: port terms on the hostname key
     if size >= 2:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
     n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))

@@ -10,7 +10,7 @@ GiB = 1 << 30
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
                  odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
-                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False):
+                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -136,8 +136,8 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
     v2 = aff or ipa or spread_hard or spread_soft
     if anti or v2:
         _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft)
-    elif anti_host:
-        _topology_host(prob, rng, N, n_pod_classes)
+    elif anti_host or ports:
+        _topology_host(prob, rng, N, n_pod_classes, anti_host, ports)
     return prob.normalise()
 
 
@@ -147,24 +147,35 @@ def _csr(lists):
     return off, np.array(flat if flat else [0], np.int32)
 
 
-def _topology_host(prob, rng, N, Cp):
+def _topology_host(prob, rng, N, Cp, anti=True, ports=False):
     """Required anti-affinity on node-level topology keys only (kubernetes.io/hostname and a second key that also gives every
-    node its own domain): the shape the score-table kernel's REST path takes.  10 terms; classes match up to 4, require up to 3."""
+    node its own domain) and / or host ports: the shape the score-table kernel's REST path takes.  Terms 0..9: selectors (classes
+    match up to 4, require up to 3); terms 10..15: (hostIP, protocol, port) triples a class binds (= matches) and conflicts with."""
     prob.topo_dom = np.stack([np.arange(N, dtype=np.int32), rng.permutation(N).astype(np.int32)])
     prob.topo_n_dom = np.array([N, N], np.int32)
     prob.topo_is_hostname = np.array([1, 0], np.uint8)
-    T = 10
-    prob.term_topo_key = rng.integers(0, 2, T).astype(np.int32)
-    match, antil = [], []
+    T = 16 if ports else 10
+    keys = rng.integers(0, 2, T).astype(np.int32)
+    keys[10:] = 0                                          # port terms live on the hostname key
+    prob.term_topo_key = keys
+    match, antil, portl = [], [], []
     for c in range(Cp):
-        m = sorted(set(rng.choice(T, rng.integers(1, 5)).tolist())) if rng.random() < 0.6 else []
-        a = sorted(set(rng.choice(T, rng.integers(1, 4)).tolist())) if rng.random() < 0.5 else []
+        m = sorted(set(rng.choice(10, rng.integers(1, 5)).tolist())) if anti and rng.random() < 0.6 else []
+        a = sorted(set(rng.choice(10, rng.integers(1, 4)).tolist())) if anti and rng.random() < 0.5 else []
         if a and rng.random() < 0.5:
             m = sorted(set(m) | {a[0]})                    # self anti-affinity: one pod of the class per node
+        pl = []
+        if ports and rng.random() < 0.5:
+            bound = sorted(set((10 + rng.choice(6, rng.integers(1, 3))).tolist()))
+            m = sorted(set(m) | set(bound))                # the class binds these triples ...
+            pl = sorted(set(bound) | ({int(10 + rng.integers(0, 6))} if rng.random() < 0.5 else set()))   # ... and conflicts with them (+ a wildcard twin)
         match.append(m)
         antil.append(a)
+        portl.append(pl)
     prob.match_off, prob.match_idx = _csr(match)
     prob.anti_off, prob.anti_idx = _csr(antil)
+    if ports:
+        prob.port_off, prob.port_idx = _csr(portl)
 
 
 def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft):

@@ -187,6 +187,7 @@ REST_FEATURES = [
     dict(gpu=True, anti_host=True, presets=True, gates=True, pins=True, tight_pods=True, zero_pods=True, nz_differs=True, static_mask=True),
     dict(anti_host=True, pins=True, presets=True, tight_pods=True),
     dict(eph=True), dict(scalars=2), dict(eph=True, scalars=4, zero_pods=True, tight_pods=True),
+    dict(ports=True), dict(ports=True, anti_host=True, gpu=True, presets=True, pins=True, static_mask=True),
     dict(eph=True, scalars=3, gpu=True, anti_host=True, static_mask=True, zero_pods=True, tight_pods=True, gates=True, pins=True, nz_differs=True),
 ]
 
