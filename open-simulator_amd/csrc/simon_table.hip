@@ -566,29 +566,31 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        // every block of the scenario in ONE pass: 4 NBQ blocks per lane, all loads issued before the first is used (one memory
-        // round trip per pod instead of one per 64 blocks -- the table of a batch lives in the Infinity Cache / HBM, not in L2)
-        constexpr int CH = 4 * NBQ;
+        // 4 (NBQ = 2: 6) blocks per lane and pass, every load of a pass issued before the first is used: one memory round trip per
+        // 4 096 (6 144) positions -- the table of a batch lives in the Infinity Cache / HBM, not in L2.  Not 8 per lane: the 48
+        // registers that takes cost EVERY pod of the batch a wave per SIMD (measured: 4 096 table-only scenarios 21.8 vs 16.0 ms).
+        constexpr int CH = NBQ == 1 ? 4 : 6;
         const unsigned koff16 = (unsigned)k * 16u;
-        uint4 R[CH];
-        unsigned bad[CH];
-        const unsigned short* xr[CH];
+        for (int b0 = 0; b0 < nblk; b0 += CH * 64) {
+            uint4 R[CH];
+            unsigned bad[CH], xo[CH];                                     // xo: entry offset of the block's mask rows (32 bits)
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int b = c * 64 + lane, cbk = b < nblk ? b : 0;
-            R[c] = *(const uint4*)(g_tile + ((unsigned)cbk * Krow + koff16));
-            xr[c] = g_xm + (size_t)cbk * M;
-            bad[c] = gs >= 0 ? (unsigned)xr[c][gs] : 0u;
-            if (xs >= 0) bad[c] |= (unsigned)xr[c][G + xs];
+            for (int c = 0; c < CH; ++c) {
+                const int b = b0 + c * 64 + lane, cbk = b < nblk ? b : 0;
+                R[c] = *(const uint4*)(g_tile + ((unsigned)cbk * Krow + koff16));
+                xo[c] = (unsigned)cbk * (unsigned)M;
+                bad[c] = gs >= 0 ? (unsigned)g_xm[xo[c] + (unsigned)gs] : 0u;
+                if (xs >= 0) bad[c] |= (unsigned)g_xm[xo[c] + (unsigned)(G + xs)];
+            }
+            for (int e = 0; e < nrows; ++e) {
+                const unsigned row = (unsigned)__builtin_amdgcn_readlane(rowv, e) & 0xFFFFu;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) bad[c] |= (unsigned)g_xm[xo[c] + row];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (b0 + c * 64 + lane < nblk) fold_block(b0 + c * 64 + lane, R[c], bad[c]);
         }
-        for (int e = 0; e < nrows; ++e) {
-            const int row = __builtin_amdgcn_readlane(rowv, e) & 0xFFFF;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) bad[c] |= (unsigned)xr[c][row];
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-            if (c * 64 + lane < nblk) fold_block(c * 64 + lane, R[c], bad[c]);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
