@@ -103,6 +103,9 @@ struct simon_ctx : simon::HostInputs {
     std::vector<int32_t> h_clsprefix, scen_ni;   // [(N+1)][Cn_t]; padded (class-major) size of every loaded scenario
     size_t ws_total = 0;
     // REST path of the score-table kernel (Open-Gpu-Share + node-level required anti-affinity): decided by choose_variant
+    std::vector<int32_t> h_ncls_t, h_cls_off;    // internal node class of every node; class offsets into the per-class node lists
+    DevBuf<int32_t> d_rk_ids, d_rk_pos;          // per-scenario node order for the score-table kernel (simon_set_node_ranks)
+    bool table_ranks_ok = false;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
@@ -493,6 +496,7 @@ int stage_narrow(simon_ctx* c) {
             for (int d = 0; d < Ct; ++d) cls_off[d + 1] = cls_off[d] + prefix[(size_t)N * Ct + d];
             for (int j = 0; j < N; ++j) cls_list[cls_off[ncls_t[j]] + rank[j]] = j;
             c->h_clsprefix = prefix;
+            c->h_ncls_t = ncls_t; c->h_cls_off = cls_off;
             HIP_TRY(c, c->d_sigs.upload(sigs, st));
             HIP_TRY(c, c->d_shapes.upload(shapes, st));
             HIP_TRY(c, c->d_podsC.upload(rowsC, st));
@@ -991,6 +995,25 @@ int simon_set_node_ranks(simon_ctx* c, const int32_t* rank) {
     std::vector<int32_t> rk(rank, rank + S * N);
     HIP_TRY(c, c->d_node_rank.upload(rk, c->stream));
     HIP_TRY(c, c->d_node_inv.upload(inv, c->stream));
+    // the score-table kernel's view of a scenario's own node order: per-class node lists in rank order (class segments at the
+    // pool's class offsets; a scenario fills the first clsprefix[n][d] entries of segment d) and a node's index inside its class
+    c->table_ranks_ok = false;
+    if (c->variant == SIMON_KERNEL_NARROW && c->table_ok && c->table_perm_ok) {
+        const int Ct = c->Cn_t;
+        std::vector<int32_t> ids(S * N, 0), pos(S * N, 0), fill(Ct);
+        for (size_t s = 0; s < S; ++s) {
+            const int n = c->scen[s].n_nodes;
+            std::fill(fill.begin(), fill.end(), 0);
+            for (int r = 0; r < n; ++r) {                       // nodes in rank order
+                const int j = inv[s * N + r], d = c->h_ncls_t[j];
+                pos[s * N + j] = fill[d];
+                ids[s * N + c->h_cls_off[d] + fill[d]++] = j;
+            }
+        }
+        HIP_TRY(c, c->d_rk_ids.upload(ids, c->stream));
+        HIP_TRY(c, c->d_rk_pos.upload(pos, c->stream));
+        c->table_ranks_ok = true;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_ranks = true;
     c->have_results = false;
@@ -1006,7 +1029,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     int T = 0, slots = 0, variant_used = c->variant;
     bool table_used = false;
     size_t lds = 0;
-    bool run_wide = c->variant != SIMON_KERNEL_NARROW || c->has_ranks;    // per-scenario node ranks: all-feature kernel only
+    // per-scenario node ranks: the score-table kernel (own per-class lists) or the all-feature kernel
+    bool run_wide = c->variant != SIMON_KERNEL_NARROW || (c->has_ranks && !c->table_ranks_ok);
     if (!run_wide) {
         // workgroup shape: T = 256 (4 waves) with up to 8 node slots per lane covers 2048 nodes;
         // larger pools widen the workgroup.  SIMON_WG overrides (tuning knob).
@@ -1021,7 +1045,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        if ((c->has_pin || too_big || c->rest || !c->raw_fits_lds) && !use_table) run_wide = true;
+        if ((c->has_pin || too_big || c->rest || !c->raw_fits_lds || c->has_ranks) && !use_table) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
         } else if (use_table) {
@@ -1034,6 +1058,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
+            cold.N = c->N;
+            if (c->has_ranks) { cold.rk_ids = c->d_rk_ids.p; cold.rk_pos = c->d_rk_pos.p; cold.rk_rank = c->d_node_rank.p; }
             if (c->rest) {
                 cold.xrows = c->d_xrows.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;

@@ -43,6 +43,10 @@ struct TableCold {
     const int32_t* i_npods; const SigRow* sigs; const ShapeRow* shapes; const ScenarioDesc* scen; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
     unsigned long long* prof;   // [S][12] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
+    // per-scenario node order (simon_set_node_ranks), null without: [S][N] node ids per class in rank order (class segments at
+    // cls_off, first clsprefix[n][d] entries valid), a node's index inside its class, the rank itself (canonical index of ties)
+    const int32_t *rk_ids, *rk_pos, *rk_rank;
+    int32_t N;
     // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): mask rows per term class; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
     const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16
     const uint2* gsig;              // [G]

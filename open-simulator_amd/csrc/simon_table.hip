@@ -247,7 +247,7 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
 // of every GPU signature (lane g = signature g) on that node.
 template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST>
 __global__ __launch_bounds__(64) void table_kernel(
-    const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list, const PodRowC* __restrict__ pods,
+    const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
     int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
     // Pointers the hot loop never touches live in a device-resident struct: as kernel arguments (24 pointers) they kept the
@@ -282,6 +282,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int lane = threadIdx.x;
     const int s = __builtin_amdgcn_readfirstlane(perm[blockIdx.x]);
     const int n = __builtin_amdgcn_readfirstlane(scen[s].n_nodes);
+    // Per-scenario node order (simon_set_node_ranks: the scenario's own nodeTree order): the per-class node lists, a node's index
+    // inside its class and the canonical index used by tie-breaks come from the scenario's own arrays; the kernel is otherwise
+    // unchanged (positions are class-major in RANK order, so position order inside a class is still canonical order).
+    const bool ranked = cold->rk_ids != nullptr;
+    const int32_t* __restrict__ const cls_list = ranked ? cold->rk_ids + (size_t)s * (size_t)cold->N : cls_list_pool;
     unsigned char* const wsb = ws + ws_off[blockIdx.x];
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
@@ -609,7 +614,8 @@ __global__ __launch_bounds__(64) void table_kernel(
         unsigned long long tied = __ballot(present && total == tmax);
         int wl = __builtin_ctzll(tied);
         if (tied & (tied - 1)) {                                          // several classes reach the maximum: first in canonical order
-            const int canon = (present && total == tmax) ? cls_list[idx] : (int)PMASK;
+            int canon = (present && total == tmax) ? cls_list[idx] : (int)PMASK;
+            if (ranked && present && total == tmax) canon = cold->rk_rank[(size_t)s * (size_t)cold->N + canon];
             const unsigned cmin = wave_max_u32((present && total == tmax) ? PMASK - (unsigned)canon : 0u);
             wl = __builtin_ctzll(__ballot(present && total == tmax && PMASK - (unsigned)canon == cmin));
         }
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             } else if (r_preset >= 0) {                                // addPodToCache path (V/eventhandlers.go:223-236)
                 bound = true;
                 dstar = __builtin_amdgcn_readfirstlane(cc->ncls[r_preset]);
-                const int rk = __builtin_amdgcn_readfirstlane(cc->rank[r_preset]);
+                const int rk = __builtin_amdgcn_readfirstlane(ranked ? cc->rk_pos[(size_t)s * (size_t)cc->N + r_preset] : cc->rank[r_preset]);
                 pstar = __builtin_amdgcn_readfirstlane(s_seg[dstar]) + rk;
                 res = __builtin_amdgcn_readfirstlane(cc->cls_off[dstar]) + rk;
             } else {                                                   // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 res = -1;                                              // (signature, node) holds static filters + fit
                 if (HAS_PIN && pin < n) {
                     const int dp = __builtin_amdgcn_readfirstlane(cc->ncls[pin]);
-                    const int rk = __builtin_amdgcn_readfirstlane(cc->rank[pin]);
+                    const int rk = __builtin_amdgcn_readfirstlane(ranked ? cc->rk_pos[(size_t)s * (size_t)cc->N + pin] : cc->rank[pin]);
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
                     const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
                     bool clear = true;
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                         const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
                         const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
                         canon[q] = tied ? cls_list[(binfo[q] & 0xFFFF) - 8192 + pq] : (int)PMASK;
+                        if (ranked && tied) canon[q] = cold->rk_rank[(size_t)s * (size_t)cold->N + canon[q]];
                     }
 #pragma unroll
                     for (int q = 0; q < NBQ; ++q) {

@@ -44,10 +44,17 @@ def one_case(case):
     prob = randprob.rand_problem(62000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
     S = int(rng.integers(1, 7))
     scen, orders = randprob.rand_scenarios(case, prob, S=S, min_n=1 if rng.random() < 0.5 else None)
-    ref = O.run_threaded(prob, scen, orders)
+    ranks = None
+    if case % 5 == 4:                     # per-scenario node order (simon_set_node_ranks)
+        ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+        for s, (n, _) in enumerate(np.asarray(scen).tolist()):
+            ranks[s, :n] = rng.permutation(n)
+    ref = O.run_threaded(prob, scen, orders) if ranks is None else O.run(prob, scen, orders, node_ranks=ranks)
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
+        if ranks is not None:
+            ctx.set_node_ranks(ranks)
         ctx.run_loaded(True)
         res = ctx.fetch(True)
         st = ctx.stats()

@@ -49,7 +49,12 @@ def one_case(case, coarse=None):
             prob.init_nz_mem = np.maximum(prob.init_nz_mem, prob.init_req_mem)
     S = int(rng.integers(1, 9))
     scen, orders = randprob.rand_scenarios(case, prob, S=S, min_n=1 if rng.random() < 0.5 else None)
-    ref = O.run_threaded(prob, scen, orders)
+    ranks = None
+    if case % 5 == 4:                     # per-scenario node order (simon_set_node_ranks): own class lists per scenario
+        ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+        for s, (n, _) in enumerate(np.asarray(scen).tolist()):
+            ranks[s, :n] = rng.permutation(n)
+    ref = O.run_threaded(prob, scen, orders) if ranks is None else O.run(prob, scen, orders, node_ranks=ranks)
     saved = os.environ.get("SIMON_TABLE_COARSE")
     if saved is None:
         os.environ["SIMON_TABLE_COARSE"] = "1" if coarse else "0"      # read once, when the context is created
@@ -61,6 +66,8 @@ def one_case(case, coarse=None):
     with ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
+        if ranks is not None:
+            ctx.set_node_ranks(ranks)
         ctx.run_loaded(True)
         res = ctx.fetch(True)
         st = ctx.stats()

@@ -415,7 +415,7 @@ def _random_ranks(rng, scen, N):
 
 
 @pytest.mark.parametrize("feat", [dict(), dict(static_mask=True, presets=True, gates=True, pins=True),
-                                  dict(gpu=True, anti=True, static_mask=True),
+                                  dict(gpu=True, anti=True, static_mask=True), dict(gpu=True, anti_host=True, ports=True, presets=True, pins=True),
                                   dict(ipa=True, spread_soft=True, spread_hard=True, aff=True, static_scores=True, static_mask=True)])
 def test_per_scenario_node_ranks(feat):
     """simon_set_node_ranks: the tie-break of selectHost follows the scenario's own canonical node order.  Homogeneous
@@ -435,7 +435,9 @@ def test_per_scenario_node_ranks(feat):
             ctx.load_scenarios(scen, orders)
             ctx.set_node_ranks(ranks)
             ctx.run_loaded(True)
-            assert ctx.stats().kernel_variant == capi.KERNEL_WIDE
+            # cpu+memory problems keep the score-table kernel (per-scenario class lists in rank order); the rest: all-feature kernel
+            narrow = set(feat) <= {"static_mask", "presets", "gates", "pins", "gpu", "anti_host", "ports"}
+            assert ctx.stats().kernel_variant == (capi.KERNEL_NARROW_CACHE if narrow else capi.KERNEL_WIDE)
             assert_same(ctx.fetch(True), ref)
             ctx.set_node_ranks(None)                                                  # back to pool order
             ctx.run_loaded(True)
