@@ -109,6 +109,9 @@ struct simon_ctx : simon::HostInputs {
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
+    std::vector<int> zone_keys;                  // topology keys of terms that are not node-level (REST: a domain = many positions)
+    std::vector<int> key_zslot;                  // [Kt] index into zone_keys or -1 (node-level / unused)
+    DevBuf<int32_t> d_zdom;
     bool xres = false;                           // some pod requests ephemeral storage or an extended resource
     int rest_M = 0, rest_G = 0, rest_X = 0;      // mask rows; GPU requests; extra-resource requests
     DevBuf<uint32_t> d_xsig, d_xalloc, d_i_xused;
@@ -188,19 +191,28 @@ uint64_t gcd_of(std::initializer_list<const std::vector<int64_t>*> vs) {
 bool rest_supported(simon_ctx* c) {
     if (c->no_rest) return false;
     if (c->Tm > kTableMaxTerms) return false;
-    std::vector<int> key_ok(std::max(c->Kt, 1), -1);
+    // a term's topology key is node-level (every node its own domain: kubernetes.io/hostname) or zone-like (a domain = several
+    // nodes, some nodes without the label): at most 6 of the latter, domain ids below 65 535
+    std::vector<int> key_kind(std::max(c->Kt, 1), -1);   // 1 node-level, 0 zone-like
+    c->zone_keys.clear();
+    c->key_zslot.assign(std::max(c->Kt, 1), -1);
     for (int t = 0; t < c->Tm; ++t) {
         if (!c->term_set.empty() && c->term_set[t] >= 0) return false;
         const int k = c->term_key[t];
-        if (key_ok[k] < 0) {
+        if (key_kind[k] < 0) {
             std::vector<char> seen(c->N, 0);
-            key_ok[k] = 1;
-            for (int j = 0; j < c->N && key_ok[k]; ++j) {
+            key_kind[k] = 1;
+            for (int j = 0; j < c->N; ++j) {
                 const int d = c->topo_dom[(size_t)k * c->N + j];
-                if (d < 0 || d >= c->N || seen[d]) key_ok[k] = 0; else seen[d] = 1;
+                if (d < -1 || d >= 65535) return false;
+                if (d < 0 || d >= c->N || seen[d]) key_kind[k] = 0; else seen[d] = 1;
+            }
+            if (!key_kind[k]) {
+                if (c->zone_keys.size() == 6) return false;
+                c->key_zslot[k] = (int)c->zone_keys.size();
+                c->zone_keys.push_back(k);
             }
         }
-        if (!key_ok[k]) return false;
     }
     c->g_eph = 1;
     static_assert(SIMON_MAX_SCALAR == 4, "simon_table.hip keeps ephemeral storage + 4 extended resources in 5 components");
@@ -441,8 +453,10 @@ int stage_narrow(simon_ctx* c) {
                 if (it.second) {
                     // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row B + t), or a placed pod
                     // REQUIRES a term that matches me (row B + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
-                    for (int t : anti) xrows.push_back((B + t) | ((B + T + t) << 16));
-                    for (int t : match) xrows.push_back((B + T + t) | ((B + t) << 16));
+                    // bits 28..30: zone key + 1 of the term (the set-row then covers every position of the pod's domain)
+                    auto zs = [&](int t) { return (unsigned)(c->key_zslot[c->term_key[t]] + 1) << 28; };
+                    for (int t : anti) xrows.push_back((int)((unsigned)(B + t) | ((unsigned)(B + T + t) << 16) | zs(t)));
+                    for (int t : match) xrows.push_back((int)((unsigned)(B + T + t) | ((unsigned)(B + t) << 16) | zs(t)));
                     // a conflicting port is in use on the node: a placed pod MATCHES (binds) port term t; nothing to set -- the
                     // entry's set-row repeats a row the class sets anyway, or a scratch row behind the last term row
                     for (int t : port) xrows.push_back((B + t) | ((B + 2 * T) << 16));
@@ -517,6 +531,10 @@ int stage_narrow(simon_ctx* c) {
                 std::vector<int32_t> gcnt(N, 0);
                 if (c->has_gpu) gcnt = c->gpu_cnt;
                 HIP_TRY(c, c->d_xrows.upload(xrows, st));
+                std::vector<int32_t> zdom(std::max<size_t>(c->zone_keys.size(), 1) * N, -1);
+                for (size_t z = 0; z < c->zone_keys.size(); ++z)
+                    std::copy(c->topo_dom.begin() + (size_t)c->zone_keys[z] * N, c->topo_dom.begin() + (size_t)(c->zone_keys[z] + 1) * N, zdom.begin() + z * N);
+                HIP_TRY(c, c->d_zdom.upload(zdom, st));
                 std::vector<uint32_t> xalloc((size_t)N * 8, 0), xused((size_t)N * 8, 0);
                 for (int j = 0; j < N && c->xres; ++j) {
                     xalloc[(size_t)j * 8] = (uint32_t)((uint64_t)c->alloc_eph[j] / c->g_eph);
@@ -956,7 +974,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             c->table_ni_top = ni_top;
             std::vector<unsigned long long> ws_off(S);
             size_t off = 0;
-            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0); }
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0, c->rest ? (int)c->zone_keys.size() : 0); }
             c->ws_total = off;
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
@@ -1061,7 +1079,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.N = c->N;
             if (c->has_ranks) { cold.rk_ids = c->d_rk_ids.p; cold.rk_pos = c->d_rk_pos.p; cold.rk_rank = c->d_node_rank.p; }
             if (c->rest) {
-                cold.xrows = c->d_xrows.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
+                cold.xrows = c->d_xrows.p; cold.zdom = c->d_zdom.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
             const bool tprof = getenv_once_table_prof();
@@ -1074,7 +1092,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

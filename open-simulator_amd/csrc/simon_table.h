@@ -32,6 +32,7 @@ struct PodRowC { int32_t sigcls, preset, gate, rest; };
 
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
+    int32_t NZ;          // REST: topology keys that are NOT node-level (a term on one marks every position of the pod's domain)
     int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
     uint64_t g_cpu, g_mem;
@@ -48,11 +49,12 @@ struct TableCold {
     const int32_t *rk_ids, *rk_pos, *rk_rank;
     int32_t N;
     // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): mask rows per term class; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
-    const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16
+    const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16 | (zone key + 1) << 28
     const uint2* gsig;              // [G]
     // extra resources = ephemeral storage (gcd units) + SIMON_MAX_SCALAR extended resources: requests [X][8], the pool's
     // allocatable and Requested at the start [N][8] (component 0 = ephemeral storage, 1.. = extended resources)
     const uint32_t *xsig, *xalloc, *i_xused;
+    const int32_t* zdom;            // [NZ][N] domain of a node under a zone-like key (-1: no label)
     const int32_t* gpu_cnt;         // [N]
     const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)
 };
@@ -79,7 +81,7 @@ constexpr int kTableMaxTerms = 120;     // node-level anti-affinity terms: two m
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest);        // LDS per workgroup for padded scenario sizes up to ni_max
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M);  // HBM workspace of ONE scenario with ni padded positions
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ);  // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

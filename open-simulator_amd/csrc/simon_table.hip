@@ -165,13 +165,14 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
 // NonZeroRequested differs from Requested) [ni] x 8 B, and (COARSE) the per-16 summary entries [ni / 64][K][4] u16 and the
 // feasible-node counters [K][Cn] i32
 // ... and (REST, M mask rows) the position masks [ni / 16][M] u16 and the GPU devices of every position: used [ni][8], per-device
-// total [ni], device count [ni] (u32 each), extra-resource Requested [ni][8] and allocatable [ni][8]
-__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M) {
+// total [ni], device count [ni] (u32 each), extra-resource Requested [ni][8] and allocatable [ni][8], and the topology domain of every
+// position under the NZ keys that are not node-level [NZ][ni] u16
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
-    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64);
+    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2;
     return w;
 }
 
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     constexpr unsigned PMASK = (1u << KB) - 1u;
     static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
-    const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0;
+    const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     unsigned char* s_ucls = smem + cv.ucls;                         // REST: [entries] node class of a summary entry
     const int nbp = cv.nbp;
     unsigned char* s_sn = smem + cv.sn;                             // [K][Cn]: the class term (<= 200) currently folded into row k
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     int* g_gcnt = (int*)(g_gtot + ni);
     unsigned* g_xused = (unsigned*)(g_gcnt + ni);                     // [ni][8]: Requested ephemeral storage, extended resources
     unsigned* g_xalloc = g_xused + (size_t)ni * 8;                    // [ni][8]: their allocatable
+    unsigned short* g_pdom = (unsigned short*)(g_xalloc + (size_t)ni * 8);   // [NZ][ni]: domain under a zone-like key, 0xFFFF = no label
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -443,6 +445,10 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const unsigned long long bal = __ballot(!fits);
                     if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + G + x] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
                 }
+            }
+            for (int z = 0; z < NZ; ++z) {
+                const int dz = real ? cold->zdom[(size_t)z * cold->N + j] : -1;
+                g_pdom[(size_t)z * ni + p] = (unsigned short)(dz >= 0 ? dz : 0xFFFF);
             }
         }
     }
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     auto rest_assume_load = [&](int pstar, int nrows, int rowv, int gs, int xs) -> RestLoads {
         RestLoads L{};
         const unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
-        if (lane < nrows) L.xr_set = xr[(unsigned)rowv >> 16];
+        if (lane < nrows) L.xr_set = xr[((unsigned)rowv >> 16) & 0xFFFu];
         if (gs >= 0) {
             L.gc = g_gcnt[pstar];
             L.tot = g_gtot[pstar];
@@ -647,7 +653,33 @@ __global__ __launch_bounds__(64) void table_kernel(
     auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs, int xs) {
         const unsigned bit = 1u << (pstar & 15);
         unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
-        if (lane < nrows) xr[(unsigned)rowv >> 16] = (unsigned short)(L.xr_set | bit);
+        // node-level term: the pod's own position; a term on a zone-like key marks every position of the pod's domain (below)
+        if (lane < nrows && ((unsigned)rowv >> 28) == 0u) xr[((unsigned)rowv >> 16) & 0xFFFu] = (unsigned short)(L.xr_set | bit);
+        if (NZ > 0 && __ballot(lane < nrows && ((unsigned)rowv >> 28) != 0u)) {
+            for (int e = 0; e < nrows; ++e) {
+                const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
+                if ((ent >> 28) == 0u) continue;
+                const unsigned short* pd = g_pdom + (size_t)((ent >> 28) - 1u) * ni;
+                const unsigned z = __builtin_amdgcn_readfirstlane((unsigned)pd[pstar]);
+                if (z == 0xFFFFu) continue;                               // the node lacks the label: nothing is counted (:133-148)
+                const unsigned srow = (ent >> 16) & 0xFFFu;
+                const unsigned zz = z * 0x00010001u;
+                for (int b0 = 0; b0 < nblk; b0 += 64) {
+                    const int b = b0 + lane;
+                    if (b < nblk) {
+                        const uint4 d0 = *(const uint4*)(pd + (size_t)b * 16), d1 = *(const uint4*)(pd + (size_t)b * 16 + 8);
+                        const unsigned w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                        unsigned m = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const unsigned x = w[i] ^ zz;                 // a zero half = a position of domain z
+                            m |= ((x & 0xFFFFu) == 0u ? 1u : 0u) << (2 * i) | ((x >> 16) == 0u ? 2u : 0u) << (2 * i);
+                        }
+                        if (m) { unsigned short* q = g_xm + (size_t)b * M + srow; *q = (unsigned short)(*q | m); }
+                    }
+                }
+            }
+        }
         if (gs >= 0) {
             const unsigned greq = (unsigned)__builtin_amdgcn_readlane((int)my_gsig.x, gs);
             const int gnum = __builtin_amdgcn_readlane((int)my_gsig.y, gs);
@@ -982,7 +1014,7 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
 }
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest) { return (size_t)tcarve(K, ni_max, Cn, coarse, rest).total; }
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M) { return table_ws_of(K, ni, nzeq, coarse, Cn, M); }
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ) { return table_ws_of(K, ni, nzeq, coarse, Cn, M, NZ); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {

@@ -30,7 +30,7 @@ def one_case(case):
     if kind != 1:
         feat["gpu"] = True
     if kind != 0:
-        feat["anti_host"] = True
+        feat["anti" if case % 4 == 1 else "anti_host"] = True          # anti: terms on a zone-like key too (4 zones, unlabeled nodes)
     if rng.random() < 0.3:                # ephemeral storage / extended resources (on generation 6 unless presets or initial
         feat["eph"] = True                # state over-commit a node: then the all-feature kernel takes the case)
     if rng.random() < 0.3:

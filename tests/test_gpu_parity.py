@@ -188,6 +188,7 @@ REST_FEATURES = [
     dict(anti_host=True, pins=True, presets=True, tight_pods=True),
     dict(eph=True), dict(scalars=2), dict(eph=True, scalars=4, zero_pods=True, tight_pods=True),
     dict(ports=True), dict(ports=True, anti_host=True, gpu=True, presets=True, pins=True, static_mask=True),
+    dict(anti=True), dict(anti=True, gpu=True, presets=True, pins=True, gates=True, static_mask=True, tight_pods=True),
     dict(eph=True, scalars=3, gpu=True, anti_host=True, static_mask=True, zero_pods=True, tight_pods=True, gates=True, pins=True, nz_differs=True),
 ]
 
@@ -436,7 +437,7 @@ def test_per_scenario_node_ranks(feat):
             ctx.set_node_ranks(ranks)
             ctx.run_loaded(True)
             # cpu+memory problems keep the score-table kernel (per-scenario class lists in rank order); the rest: all-feature kernel
-            narrow = set(feat) <= {"static_mask", "presets", "gates", "pins", "gpu", "anti_host", "ports"}
+            narrow = set(feat) <= {"static_mask", "presets", "gates", "pins", "gpu", "anti", "anti_host", "ports"}
             assert ctx.stats().kernel_variant == (capi.KERNEL_NARROW_CACHE if narrow else capi.KERNEL_WIDE)
             assert_same(ctx.fetch(True), ref)
             ctx.set_node_ranks(None)                                                  # back to pool order

@@ -172,7 +172,7 @@ def test_two_contexts_on_two_os_threads():
     """The header's promise: distinct contexts may live on distinct OS threads.  Two different problems (score-table
     kernel / all-feature kernel) run concurrently, several rounds, each checked against the oracle."""
     pa, sa, oa = synth.config3(n_counts=24, n_orders=2, n_pods=2500)
-    pb = randprob.rand_problem(99, N=120, P=600, gpu=True, anti=True, static_mask=True)
+    pb = randprob.rand_problem(99, N=120, P=600, gpu=True, anti=True, ipa=True, static_mask=True)
     sb, ob = randprob.rand_scenarios(9, pb, S=8)
     ra, rb = O.run_threaded(pa, sa, oa), O.run(pb, sb, ob)
     errors = []
