@@ -106,6 +106,8 @@ struct simon_ctx : simon::HostInputs {
     std::vector<int32_t> h_ncls_t, h_cls_off;    // internal node class of every node; class offsets into the per-class node lists
     DevBuf<int32_t> d_rk_ids, d_rk_pos;          // per-scenario node order for the score-table kernel (simon_set_node_ranks)
     bool table_ranks_ok = false;
+    bool has_static = false;                     // static score tables present (score-table kernel: class term; else all-feature kernel)
+    DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
@@ -288,7 +290,17 @@ void choose_variant(simon_ctx* c) {
     c->g_cpu = c->g_mem = 1;
     if (c->force_wide) return;
     c->rest = false;
-    if (c->v2_features_but_ports()) return;
+    c->has_static = c->has_na || c->has_tt || c->has_add;
+    if (c->v2_features_but_ports_and_static()) return;
+    if (c->has_static) {
+        // The class term of the score-table kernel takes them if byte (<= 201) + 2 x Simon (<= 200) + NodeAffinity (<= 100) +
+        // TaintToleration (<= 100) + the largest addition stays within the 10 bits the two-level summary gives a total.
+        int64_t add_max = 0;
+        for (int64_t x : c->na_raw) if (x < 0 || x >= (1ll << 30)) return;
+        for (int64_t x : c->tt_raw) if (x < 0 || x >= (1ll << 30)) return;
+        for (int64_t x : c->static_add) { if (x < 0) return; add_max = std::max(add_max, x); }
+        if (201 + 200 + (c->has_na ? 100 : 0) + (c->has_tt ? 100 : 0) + add_max > 1023) return;
+    }
     // Ephemeral storage and extended resources take part only when somebody requests them: with no request and nothing requested at
     // the start, fitsRequest's `Allocatable < request + Requested` (fit.go:264-299) is 0-false on every node whatever the allocatable.
     for (int64_t x : c->alloc_eph) if (x < 0) return;
@@ -382,6 +394,8 @@ int stage_narrow(simon_ctx* c) {
             std::vector<uint64_t> mrow;
             if (c->has_mask) mrow.assign(c->static_mask.begin() + (size_t)cp * words, c->static_mask.begin() + (size_t)(cp + 1) * words);
             std::vector<int32_t> rrow(raw32.begin() + (size_t)cp * c->Cn, raw32.begin() + (size_t)(cp + 1) * c->Cn);
+            for (const std::vector<int64_t>* tab : {&c->na_raw, &c->tt_raw, &c->static_add})       // static score rows are content too
+                if (!tab->empty()) rrow.insert(rrow.end(), tab->begin() + (size_t)cp * c->Cn, tab->begin() + (size_t)(cp + 1) * c->Cn);
             auto it = tc_id.emplace(std::make_pair(std::move(mrow), std::move(rrow)), (int)tc_rep.size());
             if (it.second) tc_rep.push_back(cp);
             tc_of[cp] = it.first->second;
@@ -493,6 +507,13 @@ int stage_narrow(simon_ctx* c) {
             std::vector<int32_t> raw_t((size_t)Ctc * Ct);
             for (int tc = 0; tc < Ctc; ++tc)
                 for (int d = 0; d < Ct; ++d) raw_t[(size_t)tc * Ct + d] = raw32[(size_t)tc_rep[tc] * c->Cn + orig_of[d]];
+            for (auto [tab, buf] : {std::make_pair(&c->na_raw, &c->d_t_na), std::make_pair(&c->tt_raw, &c->d_t_tt), std::make_pair(&c->static_add, &c->d_t_add)}) {
+                if (tab->empty()) continue;
+                std::vector<int32_t> t((size_t)Ctc * Ct);
+                for (int tc = 0; tc < Ctc; ++tc)
+                    for (int d = 0; d < Ct; ++d) t[(size_t)tc * Ct + d] = (int32_t)(*tab)[(size_t)tc_rep[tc] * c->Cn + orig_of[d]];
+                HIP_TRY(c, buf->upload(t, st));
+            }
             if (c->has_mask) {
                 std::vector<uint64_t> mask_t((size_t)Ctc * words);
                 for (int tc = 0; tc < Ctc; ++tc)
@@ -1063,7 +1084,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        if ((c->has_pin || too_big || c->rest || !c->raw_fits_lds || c->has_ranks) && !use_table) run_wide = true;
+        if ((c->has_pin || too_big || c->rest || !c->raw_fits_lds || c->has_ranks || c->has_static) && !use_table) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
         } else if (use_table) {
@@ -1077,6 +1098,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
             cold.N = c->N;
+            cold.na_raw = c->has_na ? c->d_t_na.p : nullptr; cold.tt_raw = c->has_tt ? c->d_t_tt.p : nullptr; cold.add_raw = c->has_add ? c->d_t_add.p : nullptr;
             if (c->has_ranks) { cold.rk_ids = c->d_rk_ids.p; cold.rk_pos = c->d_rk_pos.p; cold.rk_rank = c->d_node_rank.p; }
             if (c->rest) {
                 cold.xrows = c->d_xrows.p; cold.zdom = c->d_zdom.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;

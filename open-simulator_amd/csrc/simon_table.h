@@ -43,6 +43,9 @@ struct TableCold {
     const int32_t *ncls, *rank, *cls_off, *clsprefix, *a_pods; const uint32_t *i_rq_cpu, *i_rq_mem, *i_nz_cpu, *i_nz_mem;
     const int32_t* i_npods; const SigRow* sigs; const ShapeRow* shapes; const ScenarioDesc* scen; const uint64_t* static_mask;
     const int32_t* simon_raw; int32_t* unscheduled; int64_t *used_cpu, *used_mem;
+    // static score tables by (table class, internal node class), null when the plugin scores every node alike:
+    // NodeAffinity preferred terms, TaintToleration PreferNoSchedule, already weighted additions (include/simon_hip.h, ABI v2)
+    const int32_t *na_raw, *tt_raw, *add_raw;
     unsigned long long* prof;   // [S][12] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
     // per-scenario node order (simon_set_node_ranks), null without: [S][N] node ids per class in rank order (class segments at
     // cls_off, first clsprefix[n][d] entries valid), a node's index inside its class, the rank itself (canonical index of ties)

@@ -152,7 +152,7 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.nbp = table_nbp(ni_max / (coarse ? 64 : 16));
     int o = 0;
     c.sum = o; o += al(K * c.nbp * 2);
-    c.sn = o; o += al(K * Cn);
+    c.sn = o; o += al(K * Cn * 2);
     c.cnt = o; o += coarse ? 0 : al(K * Cn * 4);
     c.shape = o; o += Cn * 48;
     c.seg = o; o += al((Cn + 1) * 4);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     unsigned char* s_ucls = smem + cv.ucls;                         // REST: [entries] node class of a summary entry
     const int nbp = cv.nbp;
-    unsigned char* s_sn = smem + cv.sn;                             // [K][Cn]: the class term (<= 200) currently folded into row k
+    unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k (!COARSE)
     const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);   // [Cn]: shape of a node class (a class shares its allocatable)
     int* s_seg = (int*)(smem + cv.seg);                             // [Cn + 1]: first position of a class segment
@@ -498,24 +498,46 @@ __global__ __launch_bounds__(64) void table_kernel(
         return info;
     };
 
-    // Re-base summary row k after the set of node classes with a feasible node changed: SimonPlugin / GpuSharePlugin
-    // NormalizeScore (pkg/simulator/plugin/simon.go:76-101) over the classes present, x 2 (both plugins, weight 1 each).
+    // The part of a pod's score that depends on (table class c, node class of lane dd) and on WHICH classes hold a feasible node
+    // (`inb`), every lane calling:
+    //   2 x SimonPlugin / GpuSharePlugin NormalizeScore (pkg/simulator/plugin/simon.go:76-101: min-max over the feasible nodes)
+    //   + NodeAffinity preferred terms   (DefaultNormalizeScore(100, false), helper/normalize_score.go:27-54: 100 raw / max)
+    //   + TaintToleration PreferNoSchedule (DefaultNormalizeScore(100, true): 100 - 100 raw / max, 100 everywhere when max = 0)
+    //   + already weighted static scores (NodePreferAvoidPods), small ones only (simon_hip.hip: static_tables_fit).
+    // floor(100 x / m) = (int)fma(100 x, 1/m, 0.5/m) for 0 <= x <= m < 2^30 (the la_term argument, simon_device.h).
+    auto class_term = [&](bool inb, int rawc, int c, int dd) -> int {
+        const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
+        const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
+        const int range = hi >= lo ? hi - lo : 0;
+        const double rr = range ? 1.0 / (double)range : 0.0;
+        int term = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
+        const TableCold* cc = cold;
+        asm volatile("" : "+s"(cc));                                  // rare path: its pointers are fetched here
+        if (cc->na_raw) {
+            const int v = cc->na_raw[c * Cn + dd];
+            const int mx = wave_max_i32(inb ? v : 0);
+            const double r = mx ? 1.0 / (double)mx : 0.0;
+            term += (inb && mx) ? (int)__builtin_fma((double)v * 100.0, r, 0.5 * r) : 0;
+        }
+        if (cc->tt_raw) {
+            const int v = cc->tt_raw[c * Cn + dd];
+            const int mx = wave_max_i32(inb ? v : 0);
+            const double r = mx ? 1.0 / (double)mx : 0.0;
+            term += inb ? (mx ? 100 - (int)__builtin_fma((double)v * 100.0, r, 0.5 * r) : 100) : 0;
+        }
+        if (cc->add_raw) term += inb ? cc->add_raw[c * Cn + dd] : 0;
+        return term;
+    };
+    // Re-base summary row k after the set of node classes with a feasible node changed.
     auto renormalise = [&](int k, int c) {
         const int dd = lane < Cn ? lane : 0;
         const int cn = (lane < Cn) ? (COARSE ? g_cnt[k * Cn + dd] : s_cnt[k * Cn + dd]) : 0;
         const bool inb = cn > 0;
         const int rawc = simon_raw[c * Cn + dd];                      // global: this path runs a handful of times per signature
-        const int lo = wave_min_i32(inb ? rawc : 0x7fffffff);
-        const int hi = wave_max_i32(inb ? rawc : (int)0x80000000);
-        const int range = hi >= lo ? hi - lo : 0;
-#ifdef SIMON_TABLE_DEBUG
-        { const unsigned long long pm = __ballot(inb); if (lane == 0) printf("DBG s=%d RENORM k=%d c=%d present=%llx lo=%d hi=%d\n", s, k, c, pm, lo, hi); }
-#endif
-        const double rr = range ? 1.0 / (double)range : 0.0;
-        const int sn = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
+        const int sn = class_term(inb, rawc, c, dd);
         if (lane < Cn) {
             s_tmp[dd] = sn - (int)s_sn[k * Cn + dd];
-            s_sn[k * Cn + dd] = (unsigned char)sn;
+            s_sn[k * Cn + dd] = (unsigned short)sn;
         }
         __syncthreads();
         unsigned short* srow = s_sum + k * nbp;
@@ -609,12 +631,8 @@ __global__ __launch_bounds__(64) void table_kernel(
         if (!__ballot(present)) return -1;
         const int pos = (int)(PMASK - (cbest & PMASK));
         const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
-        // SimonPlugin / GpuSharePlugin NormalizeScore over the classes that hold a feasible node (as renormalise, above)
-        const int lo = wave_min_i32(present ? rawc : 0x7fffffff);
-        const int hi = wave_max_i32(present ? rawc : (int)0x80000000);
-        const int range = hi >= lo ? hi - lo : 0;
-        const double rr = range ? 1.0 / (double)range : 0.0;
-        const int sn = (present && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
+        // the class term over the classes that hold a feasible node (as renormalise does for the summaries)
+        const int sn = class_term(present, rawc, tc, dd);
         const unsigned total = present ? (cbest >> KB) + (unsigned)sn : 0u;   // >= 1 when present (the byte is 1 + score)
         const unsigned tmax = wave_max_u32(total);
         unsigned long long tied = __ballot(present && total == tmax);

@@ -10,7 +10,7 @@ GiB = 1 << 30
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
                  odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
-                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False):
+                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False, static_small=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -105,6 +105,18 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
         if seed % 2:        # all-zero rows exercise the max == 0 branches
             prob.node_affinity_raw[0] = 0
             prob.taint_prefer_raw[-1] = 0
+    if static_small:    # the same tables with additions small enough for the score-table kernel's class term (no NodePreferAvoidPods)
+        prob.node_affinity_raw = (rng.integers(0, 4, (n_pod_classes, n_node_classes)) * rng.integers(1, 60)).astype(np.int64)
+        prob.taint_prefer_raw = rng.integers(0, 3, (n_pod_classes, n_node_classes)).astype(np.int64)
+        if seed % 3 == 0:
+            prob.static_add = rng.choice([0, 7, 40, 300], (n_pod_classes, n_node_classes)).astype(np.int64)
+        if seed % 2:        # all-zero rows exercise the max == 0 branches
+            prob.node_affinity_raw[0] = 0
+            prob.taint_prefer_raw[-1] = 0
+        if seed % 5 == 1:
+            prob.node_affinity_raw = None
+        if seed % 5 == 2:
+            prob.taint_prefer_raw = None
     if pins:            # DaemonSet-style pods: node affinity admits ONE node (some beyond small scenarios' node counts)
         prob.pin_node = np.where(rng.random(P) < 0.2, rng.integers(0, N, P), -1).astype(np.int32)
         if prob.preset_node is not None:

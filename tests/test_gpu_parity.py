@@ -189,6 +189,7 @@ REST_FEATURES = [
     dict(eph=True), dict(scalars=2), dict(eph=True, scalars=4, zero_pods=True, tight_pods=True),
     dict(ports=True), dict(ports=True, anti_host=True, gpu=True, presets=True, pins=True, static_mask=True),
     dict(anti=True), dict(anti=True, gpu=True, presets=True, pins=True, gates=True, static_mask=True, tight_pods=True),
+    dict(static_small=True), dict(static_small=True, static_mask=True, gpu=True, anti_host=True, tight_pods=True, pins=True),
     dict(eph=True, scalars=3, gpu=True, anti_host=True, static_mask=True, zero_pods=True, tight_pods=True, gates=True, pins=True, nz_differs=True),
 ]
 
@@ -209,7 +210,7 @@ def test_random_rest_features(idx):
             ctx.run_loaded(True)
             res, st = ctx.fetch(True), ctx.stats()
         if feat.get("scalars", 0) <= 2:                    # more extended resources: more than 32 distinct requests may appear
-            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 6
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == (6 if set(feat) - {"static_small"} else 4)
         assert_same(res, ref)
 
 
