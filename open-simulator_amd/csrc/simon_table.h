@@ -32,6 +32,8 @@ struct PodRowC { int32_t sigcls, preset, gate, rest; };
 
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
+    int32_t rk_stride;   // 0: cls_list = the pool's per-class node lists; N: per-scenario lists in rank order (simon_set_node_ranks)
+    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present
     int32_t NZ;          // REST: topology keys that are NOT node-level (a term on one marks every position of the pod's domain)
     int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
@@ -47,9 +49,10 @@ struct TableCold {
     // NodeAffinity preferred terms, TaintToleration PreferNoSchedule, already weighted additions (include/simon_hip.h, ABI v2)
     const int32_t *na_raw, *tt_raw, *add_raw;
     unsigned long long* prof;   // [S][12] phase ticks (builds with -DSIMON_TABLE_PROFILE and env SIMON_TABLE_PROF), else null
-    // per-scenario node order (simon_set_node_ranks), null without: [S][N] node ids per class in rank order (class segments at
-    // cls_off, first clsprefix[n][d] entries valid), a node's index inside its class, the rank itself (canonical index of ties)
-    const int32_t *rk_ids, *rk_pos, *rk_rank;
+    // per-scenario node order (simon_set_node_ranks), [S][N] each: a node's index inside its class in rank order, the rank itself
+    // (canonical index of ties); the per-class node lists in rank order (class segments at cls_off, first clsprefix[n][d]
+    // entries valid) replace TableLaunch::cls_list
+    const int32_t *rk_pos, *rk_rank;    // (the lists themselves travel as TableLaunch::cls_list)
     int32_t N;
     // REST (Open-Gpu-Share + required anti-affinity on node-level topology keys): mask rows per term class; GPU signatures (gpu-mem per device in gcd units, device count); the pool's devices
     const int32_t* xrows;           // per term class, <= 63 entries: mask row that must be clear | mask row the pod sets << 16 | (zone key + 1) << 28

@@ -246,7 +246,9 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
 // classes that kept a node (simon.go:76-101 runs on the nodes feasible under ALL filters) and picks the first maximum in
 // canonical order.  assume additionally sets the pod's term rows and, for a GPU pod, commits the devices and refreshes the bit
 // of every GPU signature (lane g = signature g) on that node.
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST>
+// RANKED: per-scenario node order (simon_set_node_ranks).  A template parameter although it only touches rare paths (tie-breaks,
+// preset pods, the 64-step placement flush): as a run-time flag it cost config 5 4 % (same-box A/B, profiles/README.md).
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -286,8 +288,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     // Per-scenario node order (simon_set_node_ranks: the scenario's own nodeTree order): the per-class node lists, a node's index
     // inside its class and the canonical index used by tie-breaks come from the scenario's own arrays; the kernel is otherwise
     // unchanged (positions are class-major in RANK order, so position order inside a class is still canonical order).
-    const bool ranked = cold->rk_ids != nullptr;
-    const int32_t* __restrict__ const cls_list = ranked ? cold->rk_ids + (size_t)s * (size_t)cold->N : cls_list_pool;
+    // (the launch passes the scenario-major array and its stride N, or the pool's lists and stride 0: one kernel argument either way)
+    // (the launch passes the scenario-major array and its stride N, or the pool's lists: one kernel argument either way)
+    constexpr bool ranked = RANKED;
+    const unsigned rk_off = RANKED ? (unsigned)s * (unsigned)sc.rk_stride : 0u;
+    const int32_t* __restrict__ const cls_list = cls_list_pool;
     unsigned char* const wsb = ws + ws_off[blockIdx.x];
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         // partial chunk the lane holding class d's count could be inactive and read as 0 -- found by tests/fuzz_table.py)
         const int cnt_of_d = __shfl(cnt_d, d, 64);
         const bool real = p < ni && r < cnt_of_d;
-        const int j = real ? cls_list[cls_off[d] + r] : 0;            // r-th node of class d in canonical order
+        const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;   // r-th node of class d in canonical order
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             const int r = p - s_seg[d];
             const int cnt_of_d = __shfl(cnt_d, d, 64);
             const bool real = r < cnt_of_d;
-            const int j = real ? cls_list[cls_off[d] + r] : 0;
+            const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;
             const int gc = real ? gpu_cnt[j] : 0;
             const unsigned tot = real ? gpu_devtot[j] : 0u;
             unsigned u[8];
@@ -512,20 +517,20 @@ __global__ __launch_bounds__(64) void table_kernel(
         const double rr = range ? 1.0 / (double)range : 0.0;
         int term = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
         const TableCold* cc = cold;
-        asm volatile("" : "+s"(cc));                                  // rare path: its pointers are fetched here
-        if (cc->na_raw) {
+        asm volatile("" : "+s"(cc));                                  // rare path: its pointers are fetched here, and only when present
+        if (sc.static_tables & 1) {
             const int v = cc->na_raw[c * Cn + dd];
             const int mx = wave_max_i32(inb ? v : 0);
             const double r = mx ? 1.0 / (double)mx : 0.0;
             term += (inb && mx) ? (int)__builtin_fma((double)v * 100.0, r, 0.5 * r) : 0;
         }
-        if (cc->tt_raw) {
+        if (sc.static_tables & 2) {
             const int v = cc->tt_raw[c * Cn + dd];
             const int mx = wave_max_i32(inb ? v : 0);
             const double r = mx ? 1.0 / (double)mx : 0.0;
             term += inb ? (mx ? 100 - (int)__builtin_fma((double)v * 100.0, r, 0.5 * r) : 100) : 0;
         }
-        if (cc->add_raw) term += inb ? cc->add_raw[c * Cn + dd] : 0;
+        if (sc.static_tables & 4) term += inb ? cc->add_raw[c * Cn + dd] : 0;
         return term;
     };
     // Re-base summary row k after the set of node classes with a feasible node changed.
@@ -637,8 +642,8 @@ __global__ __launch_bounds__(64) void table_kernel(
         const unsigned tmax = wave_max_u32(total);
         unsigned long long tied = __ballot(present && total == tmax);
         int wl = __builtin_ctzll(tied);
-        if (tied & (tied - 1)) {                                          // several classes reach the maximum: first in canonical order
-            int canon = (present && total == tmax) ? cls_list[idx] : (int)PMASK;
+        if (__builtin_expect((tied & (tied - 1)) != 0, 0)) {              // several classes reach the maximum: first in canonical order
+            int canon = (present && total == tmax) ? cls_list[rk_off + (unsigned)idx] : (int)PMASK;
             if (ranked && present && total == tmax) canon = cold->rk_rank[(size_t)s * (size_t)cold->N + canon];
             const unsigned cmin = wave_max_u32((present && total == tmax) ? PMASK - (unsigned)canon : 0u);
             wl = __builtin_ctzll(__ballot(present && total == tmax && PMASK - (unsigned)canon == cmin));
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         int res, pstar = -1, dstar = 0;
         unsigned top = 0, m16q[NBQ];
         bool scanned = false, bound = false;                           // bound: a preset pod (no Reserve: the scheduler never saw it)
-        if (pk < 0) {
+        if (__builtin_expect(pk < 0, 0)) {
             const int r_preset = __builtin_amdgcn_readlane(cur.y, il), r_gate = __builtin_amdgcn_readlane(cur.z, il);
             const TableCold* cc = cold;
             asm volatile("" : "+s"(cc));                               // rare paths: fetch their pointers here, not in loop-long SGPRs
@@ -788,14 +793,14 @@ __global__ __launch_bounds__(64) void table_kernel(
                 }
                 if (res < 0) ++unsched;
             }
-        } else if (REST && rw != 0) {
+        } else if (REST && __builtin_expect(rw != 0, 0)) {                 // (cold for the register allocator: spills belong here)
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
-            if ((dq >> (k >> 6)) & 1u) {                               // a node class lost its last feasible node for k (or first use)
+            if (__builtin_expect((dq >> (k >> 6)) & 1u, 0)) {          // a node class lost its last feasible node for k (or first use)
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             TPROF_WAIT_LDS; TPROF(1);                                  // pod row, dirty check, summary row arrived
             key = wave_max_u32(key);
             TPROF(2);                                                  // key build + wave max
-            if (key <= PMASK) {                                        // FitError: pod deleted, state unchanged
+            if (__builtin_expect(key <= PMASK, 0)) {                   // FitError: pod deleted, state unchanged
                 ++unsched;
                 res = -1;
             } else {
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 bool other = false;
 #pragma unroll
                 for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> UB) == top && bcls[q] != dstar);   // duplicates carry entry 0's class
-                if (__ballot(other)) {                                 // rare (0.2 % of the cycles of config 3): first maximum in CANONICAL order
+                if (__builtin_expect(__ballot(other) != 0, 0)) {       // rare (0.2 % of the cycles of config 3): first maximum in CANONICAL order
 #ifdef SIMON_TABLE_PROFILE
                     tp_acc[7] += 1;                                    // how often the canonical tie-break runs
 #endif
@@ -863,7 +868,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                     for (int q = 0; q < NBQ; ++q) {
                         const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
                         const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
-                        canon[q] = tied ? cls_list[(binfo[q] & 0xFFFF) - 8192 + pq] : (int)PMASK;
+                        canon[q] = tied ? cls_list[rk_off + (unsigned)((binfo[q] & 0xFFFF) - 8192 + pq)] : (int)PMASK;
                         if (ranked && tied) canon[q] = cold->rk_rank[(size_t)s * (size_t)cold->N + canon[q]];
                     }
 #pragma unroll
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             const int blk = pstar >> 4, pos = pstar & 15;
             RestLoads RL{};
-            if (REST && rw != 0) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
+            if (REST && __builtin_expect(rw != 0, 0)) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
             const ShapeRow sh = s_shape[dstar];
             unsigned snq[KQ];
 #pragma unroll
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 }
             }
             TPROF(9);                                                  // evaluation, patch, block key, summary / table stores
-            if (REST && rw != 0) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
+            if (REST && __builtin_expect(rw != 0, 0)) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // REST: term rows, GPU commit and GPU rows
         }
@@ -967,7 +972,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
         plreg = (il == lane) ? res : plreg;
         }
-        if (place && lane < steps) place[i0 + lane] = plreg >= 0 ? cls_list[plreg] : plreg;   // 64 canonical indices per gather
+        if (place && lane < steps) place[i0 + lane] = plreg >= 0 ? cls_list[rk_off + (unsigned)plreg] : plreg;   // 64 canonical indices per gather
     }
 
     // ---- epilogue: sum of Requested over the scenario's nodes (padding rows hold 0) -----------
@@ -1008,13 +1013,18 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false>
-static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST>;
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED>
+static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
     return hipGetLastError();
+}
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false>
+static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, true>(a, n_blocks, lds, st)
+                               : launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, false>(a, n_blocks, lds, st);
 }
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
