@@ -477,7 +477,14 @@ int stage_narrow(simon_ctx* c) {
                 }
                 xc_of[cp] = it.first->second;
             }
-            for (int p = 0; p < P; ++p) rowsC[p].rest = (gs_of[p] + 1) | ((xs_of[p] + 1) << 6) | (int)((unsigned)xc_of[c->p_cls[p]] << 12);
+            bool any_rest = false;
+            for (int p = 0; p < P; ++p) {
+                rowsC[p].rest = (gs_of[p] + 1) | ((xs_of[p] + 1) << 6) | (int)((unsigned)xc_of[c->p_cls[p]] << 12);
+                any_rest = any_rest || rowsC[p].rest != 0;
+            }
+            // GPU nodes without a GPU pod, terms no pod of the stream carries: nothing for the REST path to do -- generations 4 / 5
+            // run the batch (their cycle is 17 % shorter than the REST instantiation's, profiles/README.md)
+            if (!any_rest && c->table_ok) { c->rest = false; c->rest_M = c->rest_G = c->rest_X = 0; }
         }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
