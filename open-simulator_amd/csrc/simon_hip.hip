@@ -447,22 +447,32 @@ int stage_narrow(simon_ctx* c) {
             }
             const int Xn = (int)xs_id.size();
             const int G = (int)gsigs.size(), T = c->Tm, B = G + Xn;          // term rows start behind the request rows
-            c->rest_G = G; c->rest_X = Xn; c->rest_M = B + 2 * T + 1;             // + one scratch row (set by port entries, never read)
+            const int NZk = (int)c->zone_keys.size(), SCR = B + 2 * T, LBL = SCR + 1;
+            // rows: requests | "a pod MATCHING t is here" | "a pod REQUIRING t is here" | scratch (set by entries that set nothing,
+            // never read) | per zone-like key "the node lacks the label"
+            c->rest_G = G; c->rest_X = Xn; c->rest_M = LBL + NZk;
             std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;   // -> n | offset << 6
             std::vector<int> xc_of(c->Cp, 0);
             for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
                 std::vector<int32_t> anti(c->anti_idx.begin() + c->anti_off[cp], c->anti_idx.begin() + c->anti_off[cp + 1]);
                 std::vector<int32_t> match(c->match_idx.begin() + c->match_off[cp], c->match_idx.begin() + c->match_off[cp + 1]);
+                std::vector<int32_t> aff;      // required affinity (filtering.go:348-377): DERIVED terms, in the class's order
+                if (!c->aff_off.empty()) aff.assign(c->aff_idx.begin() + c->aff_off[cp], c->aff_idx.begin() + c->aff_off[cp + 1]);
+                std::sort(aff.begin(), aff.end()); aff.erase(std::unique(aff.begin(), aff.end()), aff.end());
+                const bool aff_self = !aff.empty() && !c->class_flags.empty() && (c->class_flags[cp] & SIMON_CLASS_AFF_SELF);
                 std::vector<int32_t> port;     // NodePorts (node_ports.go:104-127): port terms this class CONFLICTS with
                 if (!c->port_off.empty()) port.assign(c->port_idx.begin() + c->port_off[cp], c->port_idx.begin() + c->port_off[cp + 1]);
                 std::sort(anti.begin(), anti.end()); anti.erase(std::unique(anti.begin(), anti.end()), anti.end());
                 std::sort(match.begin(), match.end()); match.erase(std::unique(match.begin(), match.end()), match.end());
                 std::sort(port.begin(), port.end()); port.erase(std::unique(port.begin(), port.end()), port.end());
-                if (anti.empty() && match.empty() && port.empty()) continue;
-                const size_t n = anti.size() + match.size() + port.size(), off = xrows.size();
+                if (anti.empty() && match.empty() && port.empty() && aff.empty()) continue;
+                size_t n_lbl = 0;              // one label entry per zone-like key among the affinity terms
+                { std::set<int> zk; for (int t : aff) if (c->key_zslot[c->term_key[t]] >= 0) zk.insert(c->key_zslot[c->term_key[t]]); n_lbl = zk.size(); }
+                const size_t n = anti.size() + match.size() + port.size() + aff.size() + n_lbl, off = xrows.size();
                 if (n > 63 || off + n >= (1u << 14)) { c->table_ok = false; break; }   // one lane per entry; 14-bit offsets
                 std::vector<int32_t> anti_key = anti;       // key: (anti list, -1, port list), match list
                 anti_key.push_back(-1); anti_key.insert(anti_key.end(), port.begin(), port.end());
+                anti_key.push_back(aff_self ? -3 : -2); anti_key.insert(anti_key.end(), aff.begin(), aff.end());
                 auto it = xc_id.emplace(std::make_pair(anti_key, match), (int)(n | (off << 6)));
                 if (it.second) {
                     // filter (filtering.go:319-346): a placed pod MATCHES one of my anti terms (row B + t), or a placed pod
@@ -473,7 +483,15 @@ int stage_narrow(simon_ctx* c) {
                     for (int t : match) xrows.push_back((int)((unsigned)(B + T + t) | ((unsigned)(B + t) << 16) | zs(t)));
                     // a conflicting port is in use on the node: a placed pod MATCHES (binds) port term t; nothing to set -- the
                     // entry's set-row repeats a row the class sets anyway, or a scratch row behind the last term row
-                    for (int t : port) xrows.push_back((B + t) | ((B + 2 * T) << 16));
+                    for (int t : port) xrows.push_back((B + t) | (SCR << 16));
+                    // required affinity: row B + t must be SET (bit 31; bit 27: the class matches its own terms -- the first-pod
+                    // escape); on a zone-like key the node must carry the label whatever the escape says (label row, plain entry)
+                    std::set<int> zk;
+                    for (int t : aff) {
+                        xrows.push_back((int)((unsigned)(B + t) | ((unsigned)SCR << 16) | (aff_self ? 1u << 27 : 0u) | (1u << 31)));
+                        const int z = c->key_zslot[c->term_key[t]];
+                        if (z >= 0 && zk.insert(z).second) xrows.push_back((LBL + z) | (SCR << 16));
+                    }
                 }
                 xc_of[cp] = it.first->second;
             }
@@ -1119,7 +1137,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

@@ -70,6 +70,7 @@ struct TableLaunch {
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
     unsigned char* ws;   // HBM workspace: byte table + node state (+ per-16 summary entries and counters when coarse) of every scenario
+    bool aff;            // some pod class carries required-affinity entries (REST)
     bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
     bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
     TableScalars sc;

@@ -172,7 +172,7 @@ __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coa
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
-    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2;
+    if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2 + (((size_t)M * 4 + 127) & ~(size_t)127);
     return w;
 }
 
@@ -248,7 +248,9 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
 // of every GPU signature (lane g = signature g) on that node.
 // RANKED: per-scenario node order (simon_set_node_ranks).  A template parameter although it only touches rare paths (tie-breaks,
 // preset pods, the 64-step placement flush): as a run-time flag it cost config 5 4 % (same-box A/B, profiles/README.md).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED>
+// AFF: some pod class carries required-affinity entries (REST only; own instantiation for the same reason: +5.7 % on config 5 as
+// run-time tests of the entries' bit 31).
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     unsigned* g_xused = (unsigned*)(g_gcnt + ni);                     // [ni][8]: Requested ephemeral storage, extended resources
     unsigned* g_xalloc = g_xused + (size_t)ni * 8;                    // [ni][8]: their allocatable
     unsigned short* g_pdom = (unsigned short*)(g_xalloc + (size_t)ni * 8);   // [NZ][ni]: domain under a zone-like key, 0xFFFF = no label
+    unsigned* g_rowtot = (unsigned*)(g_pdom + (size_t)NZ * ni);       // [M]: pods that set the row so far (term totals of required affinity)
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     if constexpr (REST) {
         for (int u = lane; u < nun; u += 64) s_ucls[u] = (unsigned char)class_of_pos(u * UNIT);
         for (int i = lane; i < nblk * M; i += 64) g_xm[i] = 0;            // no pod placed yet: every term row clear
+        for (int i = lane; i < M; i += 64) g_rowtot[i] = 0u;
         // the pool's GPU devices by position, and the row of every GPU signature: bit set = it does not fit the node now
         const int32_t* __restrict__ const gpu_cnt = cold->gpu_cnt;
         const uint32_t* __restrict__ const gpu_devtot = cold->gpu_devtot;
@@ -454,6 +458,10 @@ __global__ __launch_bounds__(64) void table_kernel(
             for (int z = 0; z < NZ; ++z) {
                 const int dz = real ? cold->zdom[(size_t)z * cold->N + j] : -1;
                 g_pdom[(size_t)z * ni + p] = (unsigned short)(dz >= 0 ? dz : 0xFFFF);
+                // the key's label row (the last NZ rows): bit set = the node lacks the label -- required affinity fails there whatever
+                // has been placed (filtering.go:357-360)
+                const unsigned long long bal = __ballot(dz < 0);
+                if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + (M - NZ + z)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
             }
         }
     }
@@ -580,12 +588,26 @@ __global__ __launch_bounds__(64) void table_kernel(
         my_xsig[0] = q0.x; my_xsig[1] = q0.y; my_xsig[2] = q0.z; my_xsig[3] = q0.w; my_xsig[4] = cold->xsig[(size_t)x * 8 + 4];
     }
     // OR of the pod's filter rows for block b (lane-varying b < nblk), all loads independent
-    auto excluded = [&](int b, int nrows, int rowv, int gs, int xs) -> unsigned {
+    // An entry with bit 31 is a required-affinity term: its row must be SET (a pod matching the term sits in the node's domain) --
+    // unless the first-pod escape holds (`esc`: no pod anywhere matches any of the class's terms and the class matches them itself,
+    // filtering.go:361-374), which switches those entries off.
+    auto excluded = [&](int b, int nrows, int rowv, int gs, int xs, bool esc) -> unsigned {
         const unsigned short* xr = g_xm + (size_t)b * M;
         unsigned bad = gs >= 0 ? (unsigned)xr[gs] : 0u;
         if (xs >= 0) bad |= (unsigned)xr[G + xs];
-        for (int e = 0; e < nrows; ++e) bad |= (unsigned)xr[__builtin_amdgcn_readlane(rowv, e) & 0xFFFF];
+        for (int e = 0; e < nrows; ++e) {
+            const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
+            const unsigned v = (unsigned)xr[ent & 0xFFFFu];
+            bad |= (AFF && (ent >> 31)) ? (esc ? 0u : (~v & 0xFFFFu)) : v;
+        }
         return bad;
+    };
+    // the escape of a pod's required-affinity entries: lane e holds the total of entry e's row (`rtv`, loaded with `rowv`)
+    auto aff_escape = [&](int nrows, int rowv, unsigned rtv) -> bool {
+        if (!AFF) return false;
+        const bool inv = lane < nrows && ((unsigned)rowv >> 31);
+        const bool self = __ballot(inv && (((unsigned)rowv >> 27) & 1u)) != 0ull;
+        return self && __ballot(inv && rtv != 0u) == 0ull;
     };
     // best node of block b's table row k under the excluded positions -> per-class maximum in LDS
     auto fold_block = [&](int b, uint4 R, unsigned bad) {
@@ -599,7 +621,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
     };
     // findNodesThatFitPod + prioritizeNodes + selectHost of a REST pod: returns the position (-1: no node), sets dstar / res
-    auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int xs, int& dstar, int& res) -> int {
+    auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int xs, bool esc, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
@@ -621,9 +643,17 @@ __global__ __launch_bounds__(64) void table_kernel(
                 if (xs >= 0) bad[c] |= (unsigned)g_xm[xo[c] + (unsigned)(G + xs)];
             }
             for (int e = 0; e < nrows; ++e) {
-                const unsigned row = (unsigned)__builtin_amdgcn_readlane(rowv, e) & 0xFFFFu;
+                const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
+                const unsigned row = ent & 0xFFFFu;
+                if (AFF && (ent >> 31)) {                                 // required affinity: the row must be set (see excluded)
+                    if (!esc) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) bad[c] |= (unsigned)g_xm[xo[c] + row];
+                        for (int c = 0; c < CH; ++c) bad[c] |= ~(unsigned)g_xm[xo[c] + row] & 0xFFFFu;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) bad[c] |= (unsigned)g_xm[xo[c] + row];
+                }
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -654,11 +684,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     };
     // What assume adds for a REST pod landing on position pstar: its term rows, the GPU commit and the GPU rows of that node.
     // Two halves: the loads go out with the table-row loads of the cycle, the updates follow the evaluation.
-    struct RestLoads { unsigned xr_set, xr_g, xr_x, tot, xu4, xa4; int gc; uint4 ua, ub, xu, xa; };
+    struct RestLoads { unsigned xr_set, rt_set, xr_g, xr_x, tot, xu4, xa4; int gc; uint4 ua, ub, xu, xa; };
     auto rest_assume_load = [&](int pstar, int nrows, int rowv, int gs, int xs) -> RestLoads {
         RestLoads L{};
         const unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
-        if (lane < nrows) L.xr_set = xr[((unsigned)rowv >> 16) & 0xFFFu];
+        if (lane < nrows) { L.xr_set = xr[((unsigned)rowv >> 16) & 0x7FFu]; if (AFF) L.rt_set = g_rowtot[((unsigned)rowv >> 16) & 0x7FFu]; }
         if (gs >= 0) {
             L.gc = g_gcnt[pstar];
             L.tot = g_gtot[pstar];
@@ -677,15 +707,19 @@ __global__ __launch_bounds__(64) void table_kernel(
         const unsigned bit = 1u << (pstar & 15);
         unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
         // node-level term: the pod's own position; a term on a zone-like key marks every position of the pod's domain (below)
-        if (lane < nrows && ((unsigned)rowv >> 28) == 0u) xr[((unsigned)rowv >> 16) & 0xFFFu] = (unsigned short)(L.xr_set | bit);
-        if (NZ > 0 && __ballot(lane < nrows && ((unsigned)rowv >> 28) != 0u)) {
+        if (lane < nrows && (((unsigned)rowv >> 28) & 7u) == 0u) {
+            xr[((unsigned)rowv >> 16) & 0x7FFu] = (unsigned short)(L.xr_set | bit);
+            if (AFF) g_rowtot[((unsigned)rowv >> 16) & 0x7FFu] = L.rt_set + 1u;   // term total (several entries never share a counted row)
+        }
+        if (NZ > 0 && __ballot(lane < nrows && (((unsigned)rowv >> 28) & 7u) != 0u)) {
             for (int e = 0; e < nrows; ++e) {
                 const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
-                if ((ent >> 28) == 0u) continue;
-                const unsigned short* pd = g_pdom + (size_t)((ent >> 28) - 1u) * ni;
+                if (((ent >> 28) & 7u) == 0u) continue;
+                const unsigned short* pd = g_pdom + (size_t)(((ent >> 28) & 7u) - 1u) * ni;
                 const unsigned z = __builtin_amdgcn_readfirstlane((unsigned)pd[pstar]);
                 if (z == 0xFFFFu) continue;                               // the node lacks the label: nothing is counted (:133-148)
-                const unsigned srow = (ent >> 16) & 0xFFFu;
+                const unsigned srow = (ent >> 16) & 0x7FFu;
+                if (AFF && lane == 0) g_rowtot[srow] += 1u;
                 const unsigned zz = z * 0x00010001u;
                 for (int b0 = 0; b0 < nblk; b0 += 64) {
                     const int b = b0 + lane;
@@ -761,6 +795,8 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int r_gs = (rw & 63) - 1, r_xs = ((rw >> 6) & 63) - 1, r_nrows = (rw >> 12) & 63;
         int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
         if (REST && lane < r_nrows) rowv = cold->xrows[((unsigned)rw >> 18) + lane];
+        unsigned rtv = 0;                                                  // lane e: placed pods counted on entry e's row (required affinity)
+        if (REST && AFF && lane < r_nrows && ((unsigned)rowv >> 31)) rtv = g_rowtot[(unsigned)rowv & 0xFFFFu];
 
         // res: what the placement row records for this step: >= 0 an index into cls_list (turned into the canonical node index
         // 64 steps at a time, off the critical path), -1 unschedulable, -2 not part of the scenario
@@ -788,13 +824,13 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
                     const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
                     bool clear = true;
-                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs, r_xs)) >> (pp & 15)) & 1u);
+                    if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv))) >> (pp & 15)) & 1u);
                     if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
                 }
                 if (res < 0) ++unsched;
             }
         } else if (REST && __builtin_expect(rw != 0, 0)) {                 // (cold for the register allocator: spills belong here)
-            pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, dstar, res);
+            pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv), dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
@@ -1013,9 +1049,12 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false>
 static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED>;
+    if constexpr (REST && !AFF) {
+        if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true>(a, n_blocks, lds, st);
+    }
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);

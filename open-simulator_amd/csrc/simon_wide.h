@@ -51,8 +51,8 @@ struct HostInputs {
     }
     // ... and but the static score tables (NodeAffinity preferred, TaintToleration PreferNoSchedule, weighted additions), which the
     // score-table kernel folds into its class term
-    bool v2_features_but_ports_and_static() const {
-        return !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || has_local;
+    bool v2_features_but_ports_and_static() const {      // ... and but required affinity (REST path: rows that must be SET)
+        return has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || has_local;
     }
     bool v2_features() const {
         return has_na || has_tt || has_add || !aff_idx.empty() || has_ipa_score || !sh_idx.empty() || !ss_idx.empty() || !port_idx.empty() || has_local;

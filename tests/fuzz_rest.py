@@ -37,6 +37,8 @@ def one_case(case):
         feat["scalars"] = int(rng.integers(1, 5))
     if rng.random() < 0.25:
         feat["ports"] = True              # NodePorts: port terms on the hostname key
+    if "anti" in feat and rng.random() < 0.5:
+        feat["aff"] = True                # required affinity (derived terms, first-pod escape) beside the anti-affinity terms
     if size >= 2:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
     n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))

@@ -190,6 +190,7 @@ REST_FEATURES = [
     dict(ports=True), dict(ports=True, anti_host=True, gpu=True, presets=True, pins=True, static_mask=True),
     dict(anti=True), dict(anti=True, gpu=True, presets=True, pins=True, gates=True, static_mask=True, tight_pods=True),
     dict(static_small=True), dict(static_small=True, static_mask=True, gpu=True, anti_host=True, tight_pods=True, pins=True),
+    dict(aff=True), dict(aff=True, anti=True, gpu=True, presets=True, pins=True, static_mask=True, tight_pods=True),
     dict(eph=True, scalars=3, gpu=True, anti_host=True, static_mask=True, zero_pods=True, tight_pods=True, gates=True, pins=True, nz_differs=True),
 ]
 
@@ -235,7 +236,10 @@ def test_random_v2_features(idx, wg):
         prob = randprob.rand_problem(3000 + 100 * idx + seed, N=50 + 41 * seed, P=350, **feat)
         scen, orders = randprob.rand_scenarios(seed, prob, S=6)
         ref = O.run(prob, scen, orders)
-        res, variant = run_gpu(prob, scen, orders, env={"SIMON_WG": wg} if wg else None)
+        env = {"SIMON_WG": wg} if wg else {}
+        if set(feat) <= {"aff", "anti"}:                    # required (anti-)affinity alone fits the score-table kernel: keep the
+            env["SIMON_NO_REST"] = "1"                      # all-feature kernel's coverage of it here
+        res, variant = run_gpu(prob, scen, orders, env=env or None)
         assert variant == capi.KERNEL_WIDE
         assert_same(res, ref)
 
