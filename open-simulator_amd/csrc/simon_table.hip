@@ -1,7 +1,7 @@
 // simon_table.hip -- cpu+memory scenario kernel, generations 4 to 6: one WAVE = one capacity-planning scenario over a
 // (signature, node) score table, with the class term folded into the block summaries.
 //
-// What generation 3 (simon_cache.hip) established: a scheduling cycle changes ONE node, pods come from K distinct
+// What generation 3 (round 1's simon_cache.hip, since replaced by this file) established: a scheduling cycle changes ONE node, pods come from K distinct
 // request signatures, so (feasible, LeastAllocated + BalancedAllocation) of every (signature, node) is a table of
 // bytes of which one column changes per cycle; nodes are laid out class-major (stable in canonical order, every node
 // class padded to 16, so a block of 16 nodes has ONE Simon node class) and a per-(signature, block) summary in LDS
@@ -27,7 +27,7 @@
 // Per pod: [dirty signature? re-base its summary row] -> one u16 LDS read per 16 nodes -> 4 VALU -> one DPP wave max
 // -> tie check -> node.  assume (V/scheduler.go:371 -> NodeInfo.AddPod, V/framework/types.go:482-508): the wave loads
 // the node's 12-byte state and lane k the 16-byte table row (signature k, touched block); lane k re-evaluates signature
-// k with exactly the fp64 sequences of simon_fast.hip / simon_cache.hip, patches its byte, re-reduces its row and
+// k with exactly the fp64 sequences of simon_fast.hip, patches its byte, re-reduces its row and
 // stores the summary entry.
 //
 // Generation 5 (template COARSE, see tcarve): two-level summary -- 64-position entries in LDS, per-16 entries and the
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     };
 
     // (feasible, LeastAllocated + BalancedAllocation) of one signature on one node: 0 when NodeResourcesFit fails
-    // (fit.go:230-302), else 1 + score.  Same fp64 sequences as simon_fast.hip::eval_slot / simon_cache.hip.
+    // (fit.go:230-302), else 1 + score.  Same fp64 sequences as simon_fast.hip::eval_slot.
     auto eval_node = [&](double q_req_c, double q_req_m, double q_nz_c, double q_nz_m, bool q_zero, double rq_c, double rq_m,
                          double nzs_c, double nzs_m, int freep, const ShapeRow& sh) -> unsigned {
         const double t_c = rq_c + q_req_c, t_m = rq_m + q_req_m;
