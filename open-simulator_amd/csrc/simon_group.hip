@@ -41,21 +41,35 @@ int gfail(simon_group* g, int code, const char* fmt, ...) {
     return code;
 }
 
-// run fn(member) on every member concurrently; first failing member's code + message win
+// run fn(member) on every member concurrently; first failing member's code + message win.  Nothing C++ crosses the C ABI: a
+// member body that throws (bad_alloc of its staging vectors) reports SIMON_ENOMEM, and a thread that cannot be started
+// (std::system_error) makes the caller run that member itself.
 template <class F>
 int on_all(simon_group* g, const char* what, F fn) {
     const int n = (int)g->ctx.size();
-    std::vector<int> rc(n, 0);
+    int rcs[64] = {0};                                       // simon_group_create admits at most 64 members
+    auto guarded = [&](int i) {
+        try { rcs[i] = fn(i); }
+        catch (const std::bad_alloc&) { rcs[i] = SIMON_ENOMEM; }
+        catch (...) { rcs[i] = SIMON_ENOMEM; }
+    };
     if (n == 1) {
-        rc[0] = fn(0);
+        guarded(0);
     } else {
-        std::vector<std::thread> th;
-        th.reserve(n);
-        for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rc[i] = fn(i); });
-        for (auto& t : th) t.join();
+        std::thread th[64];
+        bool started[64] = {false};
+        for (int i = 0; i < n; ++i) {
+            try { th[i] = std::thread(guarded, i); started[i] = true; }
+            catch (...) { started[i] = false; }
+        }
+        for (int i = 0; i < n; ++i) if (!started[i]) guarded(i);
+        for (int i = 0; i < n; ++i) if (started[i]) th[i].join();
     }
     for (int i = 0; i < n; ++i)
-        if (rc[i] < 0) return gfail(g, rc[i], "%s: member %d (device %d): %s", what, i, g->device[i], simon_last_error(g->ctx[i]));
+        if (rcs[i] < 0) {
+            const char* why = rcs[i] == SIMON_ENOMEM ? "out of host memory" : simon_last_error(g->ctx[i]);
+            return gfail(g, rcs[i], "%s: member %d (device %d): %s", what, i, g->device[i], why);
+        }
     return SIMON_OK;
 }
 
@@ -67,13 +81,17 @@ simon_group* simon_group_create(const int32_t* device_ids, int32_t n_dev) {
     if (!device_ids || n_dev <= 0 || n_dev > 64) return nullptr;
     simon_group* g = new (std::nothrow) simon_group();
     if (!g) return nullptr;
+    try {
+        g->ctx.reserve(n_dev);
+        g->device.reserve(n_dev);
+        g->part.resize(n_dev);
+    } catch (...) { delete g; return nullptr; }
     for (int i = 0; i < n_dev; ++i) {
         simon_ctx* c = simon_ctx_create(device_ids[i]);
         if (!c) { simon_group_destroy(g); return nullptr; }
-        g->ctx.push_back(c);
+        g->ctx.push_back(c);                                // capacity reserved above: cannot throw
         g->device.push_back(device_ids[i]);
     }
-    g->part.resize(n_dev);
     return g;
 }
 
@@ -110,9 +128,17 @@ int simon_group_load_scenarios(simon_group* g, const simon_scenario* scen, int32
     if (!g || !scen || S <= 0 || !orders || n_orders <= 0) return g ? gfail(g, SIMON_EINVAL, "group load_scenarios: bad arguments") : SIMON_EINVAL;
     const int n = (int)g->ctx.size();
     if (S < n) return gfail(g, SIMON_EINVAL, "group load_scenarios: %d scenarios for %d members (every member needs one)", S, n);
-    for (int i = 0; i < n; ++i) g->part[i].clear();
-    for (int s = 0; s < S; ++s) g->part[s % n].push_back(scen[s]);
+    // the previous batch is gone as soon as one member may hold the new one: a failed load leaves the group without scenarios
+    // (run_loaded / fetch_results then refuse) instead of members holding a mix of old and new batches
+    g->S = 0;
     g->have_results = false;
+    g->have_placement = false;
+    try {
+        for (int i = 0; i < n; ++i) g->part[i].clear();
+        for (int s = 0; s < S; ++s) g->part[s % n].push_back(scen[s]);
+    } catch (...) {
+        return gfail(g, SIMON_ENOMEM, "group load_scenarios: out of host memory");
+    }
     int rc = on_all(g, "load_scenarios", [&](int i) {
         return simon_load_scenarios(g->ctx[i], g->part[i].data(), (int32_t)g->part[i].size(), orders, n_orders);
     });
@@ -184,8 +210,9 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
     if (!g || !best) return SIMON_EINVAL;
     if (!g->have_results) return gfail(g, SIMON_ESTATE, "group min_plan: nothing has run");
     const int n = (int)g->ctx.size();
-    std::vector<simon_plan> plans(n);
-    std::vector<int32_t> vg(n, 0);
+    simon_plan plans[64];                                   // at most 64 members (simon_group_create)
+    int32_t vg[64] = {0};
+    memset(plans, 0, sizeof plans);
     int rc = on_all(g, "min_plan", [&](int i) { return simon_min_plan_vg(g->ctx[i], max_cpu_pct, max_mem_pct, max_vg_pct, &plans[i], &vg[i]); });
     if (rc) return rc;
     memset(best, 0, sizeof *best);

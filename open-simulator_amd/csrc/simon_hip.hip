@@ -109,6 +109,7 @@ struct simon_ctx : simon::HostInputs {
     bool has_static = false;                     // static score tables present (score-table kernel: class term; else all-feature kernel)
     DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
+    bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
     std::vector<int> zone_keys;                  // topology keys of terms that are not node-level (REST: a domain = many positions)
@@ -144,15 +145,6 @@ struct simon_ctx : simon::HostInputs {
 };
 
 namespace {
-
-bool getenv_once_table_prof() {   // SIMON_TABLE_PROF: phase profile of simon_table.hip (acts only in -DSIMON_TABLE_PROFILE builds)
-#ifdef SIMON_TABLE_PROFILE
-    static const bool on = getenv("SIMON_TABLE_PROF") != nullptr;
-    return on;
-#else
-    return false;
-#endif
-}
 
 int fail(simon_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -507,11 +499,20 @@ int stage_narrow(simon_ctx* c) {
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
         // does not keeps the kernel's "shape follows from class" exact for any input.
-        std::map<std::tuple<int32_t, uint32_t, uint32_t>, int> cls_id;
+        // With GPU requests in the stream (REST) a class is also split into its nodes with and without devices when that fits: a GPU
+        // request then excludes the units of a device-less class as a whole (one compare per 64 positions in rest_select) and a
+        // class with devices holds candidates only.
+        std::map<std::tuple<int32_t, uint32_t, uint32_t, int>, int> cls_id;
         std::vector<ShapeRow> shapes;
         std::vector<int32_t> orig_of, ncls_t(N);
+        bool split_gpu = c->rest && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty();
+        if (split_gpu) {
+            std::set<std::tuple<int32_t, uint32_t, uint32_t, int>> keys;
+            for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
+            split_gpu = (int)keys.size() <= kTableMaxClasses;
+        }
         for (int j = 0; j < N && c->table_ok; ++j) {
-            auto key = std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j]);
+            auto key = std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
                 if ((int)shapes.size() == kTableMaxClasses) { c->table_ok = false; break; }
@@ -629,7 +630,10 @@ int stage(simon_ctx* c) {
         if (c->node_class[j] < 0 || c->node_class[j] >= c->Cn) return fail(c, SIMON_EINVAL, "node %d: class out of range", j);
     if (c->has_mask && c->static_mask.size() != (size_t)c->Cp * ((c->N + 63) / 64))
         return fail(c, SIMON_EINVAL, "static_mask size mismatch");
-    if (!c->has_gpu)      // a pod asks for GPU memory in a pool without GPU arrays: every node fails Open-Gpu-Share (:64-67)
+    // derived per staging, never carried over from an earlier pod set: the pool's own GPU arrays, or a pod that asks for GPU memory
+    // in a pool without them (every node then fails Open-Gpu-Share, :64-67)
+    c->has_gpu = c->has_gpu_nodes;
+    if (!c->has_gpu)
         for (int p = 0; p < c->P; ++p) if (c->p_gpu_mem[p] > 0) { c->has_gpu = true; break; }
     choose_variant(c);
     // prefix sums of allocatable for the occupancy caps (satisfyResourceSetting, apply.go:737-760)
@@ -714,6 +718,9 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
+#ifdef SIMON_TABLE_PROFILE
+    c->table_prof = getenv("SIMON_TABLE_PROF") != nullptr;   // phase profile of simon_table.hip: profiling builds only
+#endif
     if (const char* e = getenv("SIMON_CACHE_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
@@ -754,7 +761,7 @@ int simon_load_nodes(simon_ctx* c, const simon_nodes_soa* nd) {
     copy_opt(c->node_class, nd->node_class, N);
     copy_opt(c->scalar_alloc, nd->scalar_alloc, (size_t)c->K * N);
     copy_opt(c->i_scalar_req, nd->init_scalar_req, (size_t)c->K * N);
-    c->has_gpu = nd->gpu_cnt != nullptr;
+    c->has_gpu_nodes = c->has_gpu = nd->gpu_cnt != nullptr;
     if (c->has_gpu && !nd->gpu_mem_total) return fail(c, SIMON_EINVAL, "gpu_mem_total missing");
     copy_opt(c->gpu_cnt, nd->gpu_cnt, N); copy_opt(c->gpu_mem_total, nd->gpu_mem_total, N);
     copy_opt(c->i_gpu_used, nd->init_gpu_used, (size_t)N * SIMON_MAX_GPU_DEV);
@@ -1129,7 +1136,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 cold.xrows = c->d_xrows.p; cold.zdom = c->d_zdom.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
-            const bool tprof = getenv_once_table_prof();
+            const bool tprof = c->table_prof;
             if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 12)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 96, c->stream)); cold.prof = c->d_table_prof.p; }
             HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
             HIP_TRY(c, hipMemcpyAsync(c->d_table_cold.p, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));

@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, ucls, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -157,7 +157,7 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.shape = o; o += Cn * 48;
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
-    c.ucls = o; o += rest ? al(c.nbp) : 0;          // REST: node class of every summary entry (one byte)
+    (void)rest;
     c.total = o;
     return c;
 }
@@ -275,7 +275,6 @@ __global__ __launch_bounds__(64) void table_kernel(
     static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
-    unsigned char* s_ucls = smem + cv.ucls;                         // REST: [entries] node class of a summary entry
     const int nbp = cv.nbp;
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k (!COARSE)
@@ -310,8 +309,9 @@ __global__ __launch_bounds__(64) void table_kernel(
         const int o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    if (lane <= Cn) s_seg[lane] = incl - pad_d;                       // lane Cn holds ni (classes beyond Cn add nothing)
-    const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size
+    const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size (classes beyond Cn add nothing)
+    if (lane < Cn) s_seg[lane] = incl - pad_d;
+    if (lane == 0) s_seg[Cn] = ni;                                    // the sentinel: with Cn == 64 no lane Cn exists to write it
     const int nblk = ni >> 4, nun = ni >> UB;                         // table blocks (16 positions); summary entries
     unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
     NodeState* g_state = (NodeState*)(wsb + (((size_t)nblk * Krow + 127) & ~(size_t)127));
@@ -410,7 +410,6 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
     }
     if constexpr (REST) {
-        for (int u = lane; u < nun; u += 64) s_ucls[u] = (unsigned char)class_of_pos(u * UNIT);
         for (int i = lane; i < nblk * M; i += 64) g_xm[i] = 0;            // no pod placed yet: every term row clear
         for (int i = lane; i < M; i += 64) g_rowtot[i] = 0u;
         // the pool's GPU devices by position, and the row of every GPU signature: bit set = it does not fit the node now
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 const uint2 sg = gsig[g];
                 const bool fits = real && gpu_fits_t(u, gc, tot, sg.x, (int)sg.y);
                 const unsigned long long bal = __ballot(!fits);
-                if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + g] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
+                if ((lane & 15) == 0) g_xm[(size_t)g * nblk + (p >> 4)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
             }
             if (X > 0) {                                                  // extra resources of the position, row of every request
                 const uint4 a0 = real ? *(const uint4*)(cold->xalloc + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const unsigned rq[5] = {q0.x, q0.y, q0.z, q0.w, cold->xsig[(size_t)x * 8 + 4]};
                     const bool fits = real && xres_fits_t(rq, us, al);
                     const unsigned long long bal = __ballot(!fits);
-                    if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + G + x] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
+                    if ((lane & 15) == 0) g_xm[(size_t)(G + x) * nblk + (p >> 4)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
                 }
             }
             for (int z = 0; z < NZ; ++z) {
@@ -461,7 +460,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 // the key's label row (the last NZ rows): bit set = the node lacks the label -- required affinity fails there whatever
                 // has been placed (filtering.go:357-360)
                 const unsigned long long bal = __ballot(dz < 0);
-                if ((lane & 15) == 0) g_xm[(size_t)(p >> 4) * M + (M - NZ + z)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
+                if ((lane & 15) == 0) g_xm[(size_t)(M - NZ + z) * nblk + (p >> 4)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
             }
         }
     }
@@ -592,12 +591,12 @@ __global__ __launch_bounds__(64) void table_kernel(
     // unless the first-pod escape holds (`esc`: no pod anywhere matches any of the class's terms and the class matches them itself,
     // filtering.go:361-374), which switches those entries off.
     auto excluded = [&](int b, int nrows, int rowv, int gs, int xs, bool esc) -> unsigned {
-        const unsigned short* xr = g_xm + (size_t)b * M;
-        unsigned bad = gs >= 0 ? (unsigned)xr[gs] : 0u;
-        if (xs >= 0) bad |= (unsigned)xr[G + xs];
+        const unsigned short* xr = g_xm + b;                          // row r of block b: xr[r * nblk]
+        unsigned bad = gs >= 0 ? (unsigned)xr[(size_t)gs * nblk] : 0u;
+        if (xs >= 0) bad |= (unsigned)xr[(size_t)(G + xs) * nblk];
         for (int e = 0; e < nrows; ++e) {
             const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
-            const unsigned v = (unsigned)xr[ent & 0xFFFFu];
+            const unsigned v = (unsigned)xr[(size_t)(ent & 0xFFFFu) * nblk];
             bad |= (AFF && (ent >> 31)) ? (esc ? 0u : (~v & 0xFFFFu)) : v;
         }
         return bad;
@@ -609,56 +608,87 @@ __global__ __launch_bounds__(64) void table_kernel(
         const bool self = __ballot(inv && (((unsigned)rowv >> 27) & 1u)) != 0ull;
         return self && __ballot(inv && rtv != 0u) == 0ull;
     };
-    // best node of block b's table row k under the excluded positions -> per-class maximum in LDS
-    auto fold_block = [&](int b, uint4 R, unsigned bad) {
-        // clear the bytes of the excluded positions: 4 mask bits -> 4 byte masks per dword
-        auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
-        R.x = keep(R.x, bad); R.y = keep(R.y, bad >> 4); R.z = keep(R.z, bad >> 8); R.w = keep(R.w, bad >> 12);
-        const unsigned e16 = block_key16_t(R);                        // best byte << 4 | 15 - position inside the block
-        if (e16 >> 4) {
-            const unsigned key = ((e16 >> 4) << KB) | (PMASK - (unsigned)(b * 16 + 15 - (int)(e16 & 15u)));
-            atomicMax((unsigned*)&s_tmp[s_ucls[b >> 2]], key);        // best node of the class: highest base score, first position
-        }
-    };
-    // findNodesThatFitPod + prioritizeNodes + selectHost of a REST pod: returns the position (-1: no node), sets dstar / res
+    // findNodesThatFitPod + prioritizeNodes + selectHost of a REST pod: returns the position (-1: no node), sets dstar / res.
+    //
+    // Summary first.  s_sum[k][u] already names the best table byte of unit u (64 positions) and WHERE it sits -- the first maximum in
+    // position order.  If that position is not excluded by the pod's filter rows it is also the best of the unit's admitted positions
+    // (an admitted earlier position with the same byte would have been the summary's choice), so a unit costs one LDS read and one
+    // 64-bit word per filter row (rows are stored row-major: a lane's words of one row are contiguous -- one cache line per 16
+    // units instead of one per block).  Only a unit whose best position IS excluded (and which is not excluded as a whole: a GPU
+    // request on the units of a class without devices) reads its four table rows and looks for the best admitted byte.  The class
+    // term folded into the summary entry is taken out again (s_sn: whatever is folded in right now, current or not): the term of a
+    // REST pod is normalised over the classes that keep a node under ALL filters (simon.go:76-101), which is computed below.
     auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int xs, bool esc, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        // 4 (NBQ = 2: 6) blocks per lane and pass, every load of a pass issued before the first is used: one memory round trip per
-        // 4 096 (6 144) positions -- the table of a batch lives in the Infinity Cache / HBM, not in L2.  Not 8 per lane: the 48
-        // registers that takes cost EVERY pod of the batch a wave per SIMD (measured: 4 096 table-only scenarios 21.8 vs 16.0 ms).
-        constexpr int CH = NBQ == 1 ? 4 : 6;
-        const unsigned koff16 = (unsigned)k * 16u;
-        for (int b0 = 0; b0 < nblk; b0 += CH * 64) {
-            uint4 R[CH];
-            unsigned bad[CH], xo[CH];                                     // xo: entry offset of the block's mask rows (32 bits)
+        const unsigned short* srow = s_sum + k * nbp;
+        const uint2* xw = (const uint2*)g_xm;                             // [row][nun] words of 64 positions
+        uint2 badw[NBQ];
+        unsigned e64[NBQ], snu[NBQ];
+        unsigned uu[NBQ];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int b = b0 + c * 64 + lane, cbk = b < nblk ? b : 0;
-                R[c] = *(const uint4*)(g_tile + ((unsigned)cbk * Krow + koff16));
-                xo[c] = (unsigned)cbk * (unsigned)M;
-                bad[c] = gs >= 0 ? (unsigned)g_xm[xo[c] + (unsigned)gs] : 0u;
-                if (xs >= 0) bad[c] |= (unsigned)g_xm[xo[c] + (unsigned)(G + xs)];
-            }
-            for (int e = 0; e < nrows; ++e) {
-                const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
-                const unsigned row = ent & 0xFFFFu;
-                if (AFF && (ent >> 31)) {                                 // required affinity: the row must be set (see excluded)
-                    if (!esc) {
-#pragma unroll
-                        for (int c = 0; c < CH; ++c) bad[c] |= ~(unsigned)g_xm[xo[c] + row] & 0xFFFFu;
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) bad[c] |= (unsigned)g_xm[xo[c] + row];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (b0 + c * 64 + lane < nblk) fold_block(b0 + c * 64 + lane, R[c], bad[c]);
+        for (int q = 0; q < NBQ; ++q) {
+            const int u = q * 64 + lane;
+            uu[q] = (unsigned)(u < nun ? u : 0);
+            badw[q] = gs >= 0 ? xw[(unsigned)gs * (unsigned)nun + uu[q]] : make_uint2(0u, 0u);
+            if (xs >= 0) { const uint2 v = xw[(unsigned)(G + xs) * (unsigned)nun + uu[q]]; badw[q].x |= v.x; badw[q].y |= v.y; }
+            e64[q] = u < nun ? (unsigned)srow[u] : 0u;
+            snu[q] = (unsigned)s_sn[k * Cn + bcls[q]];
         }
+        for (int e = 0; e < nrows; ++e) {
+            const unsigned ent = (unsigned)__builtin_amdgcn_readlane(rowv, e);
+            const unsigned row = (ent & 0xFFFFu) * (unsigned)nun;
+            if (AFF && (ent >> 31)) {                                     // required affinity: the row must be set (see excluded)
+                if (!esc) {
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) { const uint2 v = xw[row + uu[q]]; badw[q].x |= ~v.x; badw[q].y |= ~v.y; }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) { const uint2 v = xw[row + uu[q]]; badw[q].x |= v.x; badw[q].y |= v.y; }
+            }
+        }
+        // candidate of a unit: byte << 6 | 63 - position inside the unit (0: nothing admitted), class term taken out
+        unsigned cand[NBQ];
+        bool need[NBQ];
+        bool any_need = false;
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            const unsigned long long bad = ((unsigned long long)badw[q].y << 32) | badw[q].x;
+            const unsigned pos = 63u - (e64[q] & 63u);
+            const bool hit = (bad >> pos) & 1ull;
+            cand[q] = (e64[q] != 0u && !hit) ? e64[q] - (snu[q] << 6) : 0u;
+            need[q] = e64[q] != 0u && hit && bad != ~0ull;
+            any_need = any_need || need[q];
+        }
+        if (__ballot(any_need)) {                                         // some unit's best position is excluded: its 4 x 16 table bytes
+            const unsigned koff16 = (unsigned)k * 16u;
+            auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                if (!need[q]) continue;
+                uint4 R[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R[j] = *(const uint4*)(g_tile + ((uu[q] * 4u + (unsigned)j) * Krow + koff16));
+                unsigned best = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned b16 = ((j & 2) ? badw[q].y : badw[q].x) >> ((j & 1) * 16);
+                    R[j].x = keep(R[j].x, b16); R[j].y = keep(R[j].y, b16 >> 4); R[j].z = keep(R[j].z, b16 >> 8); R[j].w = keep(R[j].w, b16 >> 12);
+                    const unsigned e16 = block_key16_t(R[j]);             // best byte << 4 | 15 - position inside the block
+                    if (e16 >> 4) best = max(best, ((e16 >> 4) << 6) | ((3u - (unsigned)j) << 4) | (e16 & 15u));
+                }
+                cand[q] = best;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q)
+            if (cand[q]) {                                                // best node of the class: highest base score, first position
+                const unsigned key = ((cand[q] >> 6) << KB) | (PMASK - (uu[q] * 64u + 63u - (cand[q] & 63u)));
+                atomicMax((unsigned*)&s_tmp[bcls[q]], key);
+            }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
@@ -687,28 +717,28 @@ __global__ __launch_bounds__(64) void table_kernel(
     struct RestLoads { unsigned xr_set, rt_set, xr_g, xr_x, tot, xu4, xa4; int gc; uint4 ua, ub, xu, xa; };
     auto rest_assume_load = [&](int pstar, int nrows, int rowv, int gs, int xs) -> RestLoads {
         RestLoads L{};
-        const unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
-        if (lane < nrows) { L.xr_set = xr[((unsigned)rowv >> 16) & 0x7FFu]; if (AFF) L.rt_set = g_rowtot[((unsigned)rowv >> 16) & 0x7FFu]; }
+        const unsigned short* xr = g_xm + (pstar >> 4);               // row r of the touched block: xr[r * nblk]
+        if (lane < nrows) { L.xr_set = xr[(size_t)(((unsigned)rowv >> 16) & 0x7FFu) * nblk]; if (AFF) L.rt_set = g_rowtot[((unsigned)rowv >> 16) & 0x7FFu]; }
         if (gs >= 0) {
             L.gc = g_gcnt[pstar];
             L.tot = g_gtot[pstar];
             L.ua = *(const uint4*)(g_gused + (size_t)pstar * 8);
             L.ub = *(const uint4*)(g_gused + (size_t)pstar * 8 + 4);
-            if (lane < G) L.xr_g = xr[lane];
+            if (lane < G) L.xr_g = xr[(size_t)lane * nblk];
         }
         if (xs >= 0) {
             L.xu = *(const uint4*)(g_xused + (size_t)pstar * 8); L.xu4 = g_xused[(size_t)pstar * 8 + 4];
             L.xa = *(const uint4*)(g_xalloc + (size_t)pstar * 8); L.xa4 = g_xalloc[(size_t)pstar * 8 + 4];
-            if (lane >= 32 && lane - 32 < X) L.xr_x = xr[G + lane - 32];
+            if (lane >= 32 && lane - 32 < X) L.xr_x = xr[(size_t)(G + lane - 32) * nblk];
         }
         return L;
     };
     auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs, int xs) {
         const unsigned bit = 1u << (pstar & 15);
-        unsigned short* xr = g_xm + (size_t)(pstar >> 4) * M;
+        unsigned short* xr = g_xm + (pstar >> 4);
         // node-level term: the pod's own position; a term on a zone-like key marks every position of the pod's domain (below)
         if (lane < nrows && (((unsigned)rowv >> 28) & 7u) == 0u) {
-            xr[((unsigned)rowv >> 16) & 0x7FFu] = (unsigned short)(L.xr_set | bit);
+            xr[(size_t)(((unsigned)rowv >> 16) & 0x7FFu) * nblk] = (unsigned short)(L.xr_set | bit);
             if (AFF) g_rowtot[((unsigned)rowv >> 16) & 0x7FFu] = L.rt_set + 1u;   // term total (several entries never share a counted row)
         }
         if (NZ > 0 && __ballot(lane < nrows && (((unsigned)rowv >> 28) & 7u) != 0u)) {
@@ -732,7 +762,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                             const unsigned x = w[i] ^ zz;                 // a zero half = a position of domain z
                             m |= ((x & 0xFFFFu) == 0u ? 1u : 0u) << (2 * i) | ((x >> 16) == 0u ? 2u : 0u) << (2 * i);
                         }
-                        if (m) { unsigned short* q = g_xm + (size_t)b * M + srow; *q = (unsigned short)(*q | m); }
+                        if (m) { unsigned short* q = g_xm + (size_t)srow * nblk + b; *q = (unsigned short)(*q | m); }
                     }
                 }
             }
@@ -748,7 +778,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             if (lane < G) {                                               // lane g: does GPU signature g still fit this node?
                 const bool fits = gpu_fits_t(u, L.gc, L.tot, my_gsig.x, (int)my_gsig.y);
-                xr[lane] = (unsigned short)(fits ? (L.xr_g & ~bit) : (L.xr_g | bit));
+                xr[(size_t)lane * nblk] = (unsigned short)(fits ? (L.xr_g & ~bit) : (L.xr_g | bit));
             }
         }
         if (xs >= 0) {                                                    // Requested += the pod's ephemeral storage / extended resources
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             if (lane >= 32 && lane - 32 < X) {                            // lane 32 + x: does request x still fit this node?
                 const bool fits = xres_fits_t(my_xsig, us, al);
-                xr[G + lane - 32] = (unsigned short)(fits ? (L.xr_x & ~bit) : (L.xr_x | bit));
+                xr[(size_t)(G + lane - 32) * nblk] = (unsigned short)(fits ? (L.xr_x & ~bit) : (L.xr_x | bit));
             }
         }
     };

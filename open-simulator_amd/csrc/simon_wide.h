@@ -19,7 +19,8 @@ struct HostInputs {
     std::vector<int32_t> alloc_pods, i_npods, node_class;
     std::vector<int64_t> scalar_alloc, i_scalar_req, gpu_mem_total, i_gpu_used;
     std::vector<int32_t> gpu_cnt, topo_dom, topo_n_dom;
-    bool has_gpu = false;
+    bool has_gpu = false;            // derived per staging: has_gpu_nodes, or some pod requests GPU memory
+    bool has_gpu_nodes = false;      // the loaded pool carries GPU arrays (simon_load_nodes)
     std::vector<int64_t> p_req_cpu, p_req_mem, p_req_eph, p_nz_cpu, p_nz_mem, p_scalar, p_gpu_mem;
     std::vector<int32_t> p_cls, p_preset, p_gate, p_gpu_cnt, p_pin;
     bool has_pin = false;         // some pod is pinned to one node (simon_pods_soa.pin_node)

@@ -1,0 +1,69 @@
+"""GPU parity tests, round 3: the limits of the score-table kernel hit exactly (64 internal node classes), EVERY benchmarked
+config-5 scenario, and the round's ABI additions."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import randprob
+from open_simulator_amd import capi, synth
+from test_gpu_parity import assert_same, run_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("coarse", ["0", "1"])
+@pytest.mark.parametrize("n_classes", [63, 64])
+def test_exactly_64_internal_node_classes(n_classes, coarse, monkeypatch):
+    """with exactly 64 internal node classes no lane `Cn` exists, so the class-segment sentinel s_seg[Cn]
+    was never written and class_of_pos read stale LDS.  16 caller classes x 4 allocatable shapes, every pair present."""
+    monkeypatch.setenv("SIMON_TABLE_COARSE", coarse)
+    rng = np.random.default_rng(640 + n_classes)
+    N, P = 900, 1500
+    prob = randprob.rand_problem(6400 + n_classes, N=N, P=P, n_node_classes=16, n_pod_classes=12, tight_pods=True)
+    shapes_c = np.array([4000, 8000, 16000, 32000])
+    shapes_m = np.array([8, 16, 64, 128]) << 30
+    pair = np.concatenate([np.arange(n_classes), rng.integers(0, n_classes, N - n_classes)])
+    rng.shuffle(pair)
+    prob.node_class = (pair // 4).astype(np.int32)
+    prob.alloc_cpu = shapes_c[pair % 4].astype(np.int64)
+    prob.alloc_mem = shapes_m[pair % 4].astype(np.int64)
+    assert len({(a, b, c) for a, b, c in zip(prob.node_class.tolist(), prob.alloc_cpu.tolist(), prob.alloc_mem.tolist())}) == n_classes
+    scen, orders = randprob.rand_scenarios(64, prob, S=6)
+    scen[0, 0] = N                                   # one scenario holds every class
+    ref = O.run_threaded(prob, scen, orders)
+    for _ in range(3):                               # stale LDS differs from launch to launch
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ctx.run_loaded(True)
+            st = ctx.stats()
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation in (4, 5)
+            assert_same(ctx.fetch(True), ref)
+
+
+def test_config5_every_benchmarked_scenario():
+    """BASELINE config 5 at full size (50 000 pods x 2 500..5 000 nodes; GPU share + anti-affinity + taints): ALL 256
+    benchmarked scenarios on generation 6 of the score-table kernel, every placement row against the oracle (threaded:
+    one scenario costs the oracle about a second per host thread)."""
+    prob, scen, orders = synth.config5()
+    assert len(scen) == 256
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(want_placement=True)
+        st = ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 6
+        res = ctx.fetch(want_placement=False)
+        assert res.unscheduled.tolist() == ref.unscheduled.tolist()
+        assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
+        bad_rows = []
+        for s in range(len(scen)):
+            row = ctx.fetch_placement(s)
+            bad = np.flatnonzero(row != ref.placement[s])
+            if len(bad):
+                bad_rows.append((s, len(bad), int(bad[0])))
+        assert not bad_rows, f"{len(bad_rows)} scenarios differ, first (scenario, count, pod) = {bad_rows[0]}"
