@@ -109,6 +109,7 @@ struct simon_ctx : simon::HostInputs {
     bool has_static = false;                     // static score tables present (score-table kernel: class term; else all-feature kernel)
     DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
+    bool no_gpu_split = false;
     bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
@@ -505,7 +506,7 @@ int stage_narrow(simon_ctx* c) {
         std::map<std::tuple<int32_t, uint32_t, uint32_t, int>, int> cls_id;
         std::vector<ShapeRow> shapes;
         std::vector<int32_t> orig_of, ncls_t(N);
-        bool split_gpu = c->rest && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty();
+        bool split_gpu = c->rest && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty() && !c->no_gpu_split;
         if (split_gpu) {
             std::set<std::tuple<int32_t, uint32_t, uint32_t, int>> keys;
             for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
@@ -718,6 +719,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
+    c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
     c->table_prof = getenv("SIMON_TABLE_PROF") != nullptr;   // phase profile of simon_table.hip: profiling builds only
 #endif

@@ -273,6 +273,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     constexpr int KB = COARSE ? 13 : 12;                              // width of the position field of the arg-max key
     constexpr unsigned PMASK = (1u << KB) - 1u;
     static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
+#ifdef SIMON_TIE_SPECULATE
+    constexpr bool TIE_FIRST = false;                                 // A/B builds: every instantiation speculates
+#else
+    constexpr bool TIE_FIRST = REST;
+#endif
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
@@ -904,7 +909,48 @@ __global__ __launch_bounds__(64) void table_kernel(
         // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column + summary ----
         if (pstar >= 0) {
             TPROF(3);                                                  // winner info
-            // the loads of the (speculated) winner go out first; the tie check runs while they are in flight
+            // Position order is canonical order inside a class only: do entries of ANOTHER class reach the same total?  Then the
+            // first maximum in CANONICAL order decides (static per-class node lists, L2-hot).
+            auto tie_with_other_class = [&]() -> bool {
+                bool other = false;
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> UB) == top && bcls[q] != dstar);   // duplicates carry entry 0's class
+                return __ballot(other) != 0;
+            };
+            auto canonical_first = [&]() -> int {
+#ifdef SIMON_TABLE_PROFILE
+                tp_acc[7] += 1;                                        // how often the canonical tie-break runs
+#endif
+                unsigned key2 = 0;
+                int canon[NBQ];
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) {
+                    const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
+                    const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
+                    canon[q] = tied ? cls_list[rk_off + (unsigned)((binfo[q] & 0xFFFF) - 8192 + pq)] : (int)PMASK;
+                    if (ranked && tied) canon[q] = cold->rk_rank[(size_t)s * (size_t)cold->N + canon[q]];
+                }
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) {
+                    const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
+                    if ((m16q[q] >> UB) == top && q * 64 + lane < nun) key2 = max(key2, ((PMASK - (unsigned)canon[q]) << KB) | (unsigned)pq);
+                }
+                key2 = wave_max_u32(key2);
+                return (int)(key2 & PMASK);
+            };
+            // Generations 4 / 5 speculate: the loads of the first maximum in POSITION order go out first and the tie check runs while
+            // they are in flight (it fires on 0.2 % of the cycles of config 3).  The REST instantiation resolves the tie BEFORE it
+            // loads: its problems split node classes into nodes with / without devices -- twin classes of one shape that tie on
+            // every other cycle (config 5: 49 %), and a lost speculation costs a second round trip to the scenario's workspace.
+            if (TIE_FIRST && scanned && __builtin_expect(tie_with_other_class(), 0)) {
+                const int p2 = canonical_first();
+                if (p2 != pstar) {
+                    pstar = p2;
+                    const int info = winner_info(pstar >> UB);
+                    dstar = info >> 16;
+                    res = (info & 0xFFFF) - 8192 + pstar;
+                }
+            }
             NodeState st = g_state[pstar];
             unsigned char* rowp[KQ];
             uint4 T[KQ];
@@ -919,46 +965,22 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             uint2 z = make_uint2(0, 0);
             if (!NZEQ) z = g_nz[pstar];
-            if (scanned) {
-                // Position order is canonical order inside a class only: do blocks of ANOTHER class reach the same total?
-                bool other = false;
+            if (!TIE_FIRST && scanned && __builtin_expect(tie_with_other_class(), 0)) {   // rare: first maximum in CANONICAL order
+                const int p2 = canonical_first();
+                if (p2 != pstar) {                                     // the speculated winner loses the tie: load the real one
+                    pstar = p2;
+                    const int info = winner_info(pstar >> UB);
+                    dstar = info >> 16;
+                    res = (info & 0xFFFF) - 8192 + pstar;
+                    st = g_state[pstar];
 #pragma unroll
-                for (int q = 0; q < NBQ; ++q) other = other || ((m16q[q] >> UB) == top && bcls[q] != dstar);   // duplicates carry entry 0's class
-                if (__builtin_expect(__ballot(other) != 0, 0)) {       // rare (0.2 % of the cycles of config 3): first maximum in CANONICAL order
-#ifdef SIMON_TABLE_PROFILE
-                    tp_acc[7] += 1;                                    // how often the canonical tie-break runs
-#endif
-                    unsigned key2 = 0;
-                    int canon[NBQ];
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) {
-                        const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
-                        const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
-                        canon[q] = tied ? cls_list[rk_off + (unsigned)((binfo[q] & 0xFFFF) - 8192 + pq)] : (int)PMASK;
-                        if (ranked && tied) canon[q] = cold->rk_rank[(size_t)s * (size_t)cold->N + canon[q]];
+                    for (int q = 0; q < KQ; ++q) {
+                        rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);
+                        T[q] = *(const uint4*)rowp[q];
+                        oldq[q] = rowp[q][pstar & 15];
+                        if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
                     }
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) {
-                        const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
-                        if ((m16q[q] >> UB) == top && q * 64 + lane < nun) key2 = max(key2, ((PMASK - (unsigned)canon[q]) << KB) | (unsigned)pq);
-                    }
-                    key2 = wave_max_u32(key2);
-                    const int p2 = (int)(key2 & PMASK);
-                    if (p2 != pstar) {                                 // the speculated winner loses the tie: load the real one
-                        pstar = p2;
-                        const int info = winner_info(pstar >> UB);
-                        dstar = info >> 16;
-                        res = (info & 0xFFFF) - 8192 + pstar;
-                        st = g_state[pstar];
-#pragma unroll
-                        for (int q = 0; q < KQ; ++q) {
-                            rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);
-                            T[q] = *(const uint4*)rowp[q];
-                            oldq[q] = rowp[q][pstar & 15];
-                            if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
-                        }
-                        if (!NZEQ) z = g_nz[pstar];
-                    }
+                    if (!NZEQ) z = g_nz[pstar];
                 }
             }
             const int blk = pstar >> 4, pos = pstar & 15;

@@ -11,5 +11,5 @@ echo "== rocm-smi"; rocm-smi --showproductname 2>&1 | head -20
 echo "== devices"; python -c "import torch; print(torch.cuda.device_count(), torch.cuda.get_device_name(0))"
 } > gpurun_out/r02_go_probe.txt 2>&1
 cat gpurun_out/r02_go_probe.txt
-python bench.py > gpurun_out/r02_bench_start.json 2> gpurun_out/r02_bench_start.err
-cat gpurun_out/r02_bench_start.json
+# round 3: any box that DOES have Go (and a reference tree: REF=...) closes SURVEY 8(c) by itself -- the determinised-reference job
+bash oracle/run_ref.sh 2>&1 | tee gpurun_out/go_parity.txt
