@@ -13,7 +13,11 @@ Launch: `python bench.py --gpus N` starts the N ranks itself (re-exec through to
 127.0.0.1 rendezvous) when WORLD_SIZE is not set; under an external torch.distributed.run the ranks
 read RANK / LOCAL_RANK / WORLD_SIZE from the environment as usual.
 
-Prints ONE JSON line on rank 0.  The oracle (oracle/) is only the checker: `cpu_baseline` times it and
+`python bench.py --group N` is the one-process variant: N devices behind simon_group_* (what a Go host does).
+
+Prints ONE JSON line on rank 0: the headline record (config 3) with `roofline` + `cpu_baseline` + `parity_sample`, an `end_to_end`
+leg from host buffers, and `other_workloads` -- config 2 and config 5 (at 256 scenarios and at the saturating batch size), each with
+its OWN live-PMC roofline, CPU baseline and parity sample.  The oracle (oracle/) is only the checker: `cpu_baseline` times it and
 `parity_sample` compares what it computed with the GPU's results of the timed batch (exit code 3 on a
 mismatch).  Nothing under oracle/ is on the timed path.
 """
@@ -44,8 +48,9 @@ DTYPE = {1: "u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
          2: "int64 quantities + f64 (BalancedAllocation / normalisations) + u8 (signature, node) score table",
          3: "f64-resident exact integers (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
          4: "u8 score table + u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)"}
-KERNEL_NAME = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::cache_kernel"}
-KERNEL_SHORT = {1: "narrow_v1", 2: "wide", 3: "narrow_fast", 4: "narrow_cache"}
+KERNEL_NAME = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::table_kernel"}
+KERNEL_SHORT = {1: "narrow_v1", 2: "wide (all-feature kernel)", 3: "narrow_fast", 4: "score_table"}
+C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
 
 PMC_GROUPS = [                    # one rocprofv3 pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass; 8 SQ slots)
     ["FETCH_SIZE"],
@@ -269,10 +274,14 @@ def parity_check(ctx, pick, results, want_rows):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def c5_scenarios(args):
+    return int(args.c5_scenarios or os.environ.get("SIMON_BENCH_C5_SCEN", "256"))
+
+
 def build_workload(args, synth, world):
     n_orders = args.orders_per_gpu * world
     if args.workload == "config5":
-        return synth.config5(n_scen=int(os.environ.get("SIMON_BENCH_C5_SCEN", "256")) * world, n_orders=n_orders), n_orders
+        return synth.config5(n_scen=c5_scenarios(args) * world, n_orders=n_orders), n_orders
     if args.workload == "config2":
         return synth.config2(), 1
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
@@ -306,33 +315,161 @@ def time_steps(ctx, steps, warmup, placement, fence, after_step=None):
     return time.perf_counter() - t0, float(np.mean(k_ms))
 
 
-def sub_benchmark(name, capi, synth, torch, steps, warmup, oracle_scen):
-    """Driver-timed record of another BASELINE configuration on the same GPU (rank 0, N = 1): config 2 (one scenario, the
-    latency case) and config 5 (the all-feature kernel), each checked against the oracle on `oracle_scen` scenarios."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib
+def kernel_of(st):
+    return "simon::table_kernel" if getattr(st, "kernel_generation", 0) in (4, 5, 6) else KERNEL_NAME.get(st.kernel_variant)
+
+
+def cpu_baseline_record(tm, S_local, what):
+    return {"value": round(tm["k"] / tm["dt"], 4), "unit": "scenarios/s", "cores": tm["cores"], "kind": "port",
+            "sample": f"{tm['k']} of the {S_local} scenarios of {what} (evenly spaced over node counts/orders), {tm['dt']:.1f} s on "
+                      f"{tm['cores']} threads, one scenario per task (one thread alone: {1.0 / tm['per']:.2f} scenarios/s; C oracle = restated "
+                      f"CPU baseline of the naive per-pod loop over all nodes, not the Go reference binary -- no Go toolchain on this box; the GPU/CPU "
+                      f"ratio is mostly algorithmic: the kernel re-evaluates one table column per cycle, the oracle every node)"}
+
+
+def end_to_end(capi, torch, prob, scen, orders, device):
+    """What a host that starts from HOST buffers waits for (Applier.Run's loop as one batch): simon_load_* (H2D + staging), then
+    simon_load_scenarios + simon_run_loaded + the per-scenario counts + simon_min_plan + simon_fetch_placement of the WINNING
+    scenario's row -- never the [S][P] matrix.  A fresh context; wall clock around the calls."""
+    torch.cuda.synchronize()
+    with capi.Context(device) as ctx:
+        t0 = time.perf_counter()
+        ctx.load_problem(prob)
+        t1 = time.perf_counter()
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(want_placement=True)
+        res = ctx.fetch(want_placement=False)
+        plan = ctx.min_plan()
+        row = ctx.fetch_placement(plan.scenario if plan.found else 0)
+        t2 = time.perf_counter()
+        st = ctx.stats()
+    return {"load_problem_ms": round((t1 - t0) * 1e3, 3), "batch_ms": round((t2 - t1) * 1e3, 3), "kernel_ms": round(st.kernel_ms, 3),
+            "h2d_ms": round(st.h2d_ms, 3), "d2h_ms": round(st.d2h_ms, 3), "scenarios": len(scen),
+            "scenarios_per_s": round(len(scen) / (t2 - t0), 1), "plan_found": bool(plan.found),
+            "placed_in_winning_row": int((row >= 0).sum()), "unscheduled_min": int(res.unscheduled.min()),
+            "calls": "simon_load_nodes/pods/class_tables | simon_load_scenarios, simon_run_loaded, simon_fetch_results (counts), "
+                     "simon_min_plan, simon_fetch_placement(winning scenario)"}
+
+
+def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_scen=256, cpu_budget_s=6.0):
+    """Driver-timed record of another BASELINE configuration on the same GPU (rank 0, N = 1), measured like the headline one: HIP-event
+    kernel time, live PMC roofline of ITS kernel (same code path: child runs of this script), the oracle as CPU baseline on a sample
+    of ITS scenarios, and the parity of exactly that sample (every placement row)."""
     if name == "config2":
         prob, scen, orders = synth.config2()
+        child = ["--workload", "config2"]
+        wl, label = "config3", "BASELINE config 2"
     else:
-        prob, scen, orders = synth.config5(n_scen=int(os.environ.get("SIMON_BENCH_C5_SCEN", "256")), n_orders=4)
-    with capi.Context(torch.cuda.current_device()) as ctx:
+        prob, scen, orders = synth.config5(n_scen=c5_scen, n_orders=4)
+        child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
+        wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
+    device = torch.cuda.current_device()
+    rec = {"workload": name if name == "config2" else f"config5_S{c5_scen}"}
+    with capi.Context(device) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
         dt, k_ms = time_steps(ctx, steps, warmup, True, torch.cuda.synchronize)
         st = ctx.stats()
-        pick = np.unique(np.linspace(0, len(scen) - 1, oracle_scen).astype(int)) if oracle_scen > 0 else np.zeros(0, int)
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max(1, min(len(pick), host_cores()))) as pool:
-            refs = list(pool.map(lambda i: oracle_lib.run(prob, scen[[i]], orders, want_placement=True), pick.tolist()))
-        par = parity_check(ctx, pick, refs, True)
-    wl = "config5" if name == "config5" else "config3"
+        rec.update({"scenarios": len(scen), "pods": prob.n_pods, "nodes": f"{int(scen[:, 0].min())}..{int(scen[:, 0].max())}",
+                    "value": round(len(scen) * steps / dt, 3), "unit": "scenarios/s",
+                    "pods_placed_per_sec": round(len(scen) * steps / dt * prob.n_pods, 1),
+                    "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+                    "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_generation": st.kernel_generation,
+                    "kernel_ms": round(k_ms, 3), "workgroup": st.workgroup_size})
+        if oracle_k > 0:
+            pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=cpu_budget_s, min_k=min(oracle_k, len(scen)), max_k=max(oracle_k, 1))
+            rec["cpu_baseline"] = cpu_baseline_record(tm, len(scen), label)
+            rec["parity_sample"] = parity_check(ctx, pick, refs, True)
     alg = algorithmic_bytes(scen, prob.n_pods, wl)
-    return {"workload": name, "scenarios": len(scen), "pods": prob.n_pods, "nodes": f"{int(scen[:, 0].min())}..{int(scen[:, 0].max())}",
-            "value": round(len(scen) * steps / dt, 3), "unit": "scenarios/s", "pods_placed_per_sec": round(len(scen) * steps / dt * prob.n_pods, 1),
-            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-            "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_ms": round(k_ms, 3), "workgroup": st.workgroup_size,
-            "algorithmic_ratio": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "parity_sample": par}
+    pmc, source = None, None
+    if pmc_mode in ("auto", "live"):
+        t0 = time.perf_counter()
+        pmc = pmc_live(kernel_of(st), child + ["--steps", "1", "--warmup", "0"], budget_s=float(os.environ.get("SIMON_BENCH_PMC_BUDGET_S", "240")) / 2)
+        if pmc:
+            source = (f"measured live in this run: rocprofv3 --kernel-trace --pmc, {len(PMC_GROUPS)} separate passes over a 1-step child run of "
+                      f"this workload ({time.perf_counter() - t0:.0f} s)")
+    rec["roofline"] = roofline_record(kernel_of(st), st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl,
+                                      lds_bytes=st.lds_bytes if st.workgroup_size == 64 else None, scenarios=len(scen))
+    return rec
+
+
+def multi_rank_selfcheck(torch, dist, world, rank, local_rank, backend):
+    """What must hold when N ranks claim N GPUs (the nccl branch has never met hardware: the line states what it saw).  Unless the
+    one-device test hook is set: enough visible devices, and every rank on its own device (all-gather of the device identity)."""
+    shared = os.environ.get("SIMON_BENCH_SHARE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    props = torch.cuda.get_device_properties(local_rank)
+    ident = str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', -1)}:{local_rank}"
+    idents = [None] * world
+    dist.all_gather_object(idents, (rank, local_rank, ident))
+    distinct = len({i[2] for i in idents})
+    if not shared:
+        if ndev < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {ndev} visible device(s)")
+        if distinct != world:
+            raise SystemExit(f"bench.py: {world} ranks share {distinct} device(s): {idents}")
+    info = {"visible_devices": ndev, "distinct_devices_over_ranks": distinct, "one_device_test_hook": shared,
+            "devices": [f"rank {r}: local_rank {lr}" for r, lr, _ in idents]}
+    if backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:                                     # noqa: BLE001
+            info["rccl_version"] = f"unavailable ({e!r})"
+    return info
+
+
+def run_group(args, capi, synth, torch):
+    """`--group N`: ONE process, N devices behind simon_group_* -- what a Go host is (integration/go/hipengine).  The library deals
+    scenario s to member s % N, replicates the inputs, runs the members concurrently and reduces their plans on the host; the same
+    BASELINE config 3 / 4 grid as the multi-rank launch."""
+    n = args.group
+    ndev = capi.load_library().simon_hip_device_count()
+    shared = os.environ.get("SIMON_BENCH_SHARE_DEVICE") == "1"
+    if ndev < n and not shared:
+        raise SystemExit(f"bench.py --group {n}: only {ndev} GPU(s) visible (SIMON_BENCH_SHARE_DEVICE=1 puts the members on device 0: test hook)")
+    devices = [i % max(ndev, 1) for i in range(n)] if ndev < n else list(range(n))
+    (prob, scen, orders), n_orders = build_workload(args, synth, n)
+    with capi.Group(devices) as g:
+        g.load_problem(prob)
+        g.load_scenarios(scen, orders)
+        for _ in range(args.warmup):
+            g.run_loaded(True)
+            g.min_plan()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.run_loaded(True)
+            plan, _ = g.min_plan()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+        dt = time.perf_counter() - t0
+        sts = [g.member_stats(i) for i in range(n)]
+        par = None
+        if not args.no_cpu_baseline:
+            pick, refs, _ = oracle_sample(prob, scen, orders, budget_s=4.0, max_k=48)
+            res = g.fetch(False)
+            bad = [int(i) for i, ref in zip(pick.tolist(), refs)
+                   if not (int(res.unscheduled[i]) == int(ref.unscheduled[0]) and int(res.used_cpu[i]) == int(ref.used_cpu[0])
+                           and bool((g.fetch_placement(int(i)) == ref.placement[0]).all()))]
+            par = {"scenarios": len(pick), "placement_rows": len(pick), "mismatches": len(bad), "first_mismatches": bad[:8],
+                   "checker": "oracle/simon_oracle.c on scenarios of the timed batch (global indices through the group)"}
+    value = len(scen) * args.steps / dt
+    st0 = sts[0]
+    out = {"metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3), "unit": "scenarios/s", "n_gpus": n,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": DTYPE.get(st0.kernel_variant, "int64 + f64"), "data": "synthetic",
+           "pods_placed_per_sec": round(value * prob.n_pods, 1),
+           "config": {"workload": workload_name(args, prob, scen, n_orders, len(scen) // n, n), "scenarios_per_gpu": len(scen) // n,
+                      "pods": prob.n_pods, "node_pool": prob.n_nodes, "kernel": KERNEL_SHORT.get(st0.kernel_variant, "?"),
+                      "kernel_generation": st0.kernel_generation, "plan": plan.as_dict()},
+           "ranks": {"mode": "one process, simon_group over the device list (no collective: the per-device plans are reduced on the host)",
+                     "devices": devices, "one_device_test_hook": shared and ndev < n,
+                     "member_kernel_ms": [round(s.kernel_ms, 3) for s in sts]}}
+    if par is not None:
+        out["parity_sample"] = par
+    print(json.dumps(out), flush=True)
+    if par and par["mismatches"]:
+        raise SystemExit(3)
 
 
 def spawn_ranks(n, argv):
@@ -363,17 +500,27 @@ def main():
     ap.add_argument("--pods", type=int, default=10000)
     ap.add_argument("--orders-per-gpu", type=int, default=4)
     ap.add_argument("--sigs", type=int, default=100, help="request signatures of --workload config3sig")
+    ap.add_argument("--c5-scenarios", type=int, default=0, help="scenarios per GPU of --workload config5 (default 256; env SIMON_BENCH_C5_SCEN)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity_sample)")
-    ap.add_argument("--no-sub", action="store_true", help="skip the config-2 / config-5 sub-records")
+    ap.add_argument("--no-sub", action="store_true", help="skip the config-2 / config-5 sub-records and the end-to-end leg")
     ap.add_argument("--pmc", choices=["auto", "live", "replay", "off"], default="auto",
-                    help="PMC counters for the roofline record: live = rocprofv3 passes over a child run (auto: live at N = 1 when "
+                    help="PMC counters for the roofline records: live = rocprofv3 passes over child runs (auto: live at N = 1 when "
                          "rocprofv3 exists, else the committed profile)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
-                         "(GPU share + anti-affinity + taints) on the all-feature kernel, 256 scenarios per GPU")
+                         "(GPU share + anti-affinity + taints) on generation 6 of the score-table kernel, --c5-scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
+    ap.add_argument("--group", type=int, default=0, help="N > 0: ONE process driving N devices through simon_group_* (the Go-host shape) "
+                                                          "instead of one rank per GPU")
     args = ap.parse_args()
+
+    if args.group > 0:
+        import torch
+        from open_simulator_amd import capi, synth
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        return run_group(args, capi, synth, torch)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.pmc_child:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -395,12 +542,14 @@ def main():
     if os.environ.get("SIMON_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    selfcheck = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        selfcheck = multi_rank_selfcheck(torch, dist, world, rank, local_rank, backend)
 
     (prob, scen_all, orders), n_orders = build_workload(args, synth, world)
     scen = sweep.shard(scen_all, rank, world)                 # every rank gets every node count
@@ -411,10 +560,13 @@ def main():
     ctx.load_problem(prob)
     ctx.load_scenarios(scen, orders)                          # inputs resident in HBM before timing
     best = [None]
+    gather_s = [0.0]
 
     def after_step(plan):                                     # device-side reduction of this rank's batch, then
         rec = sweep.plan_record(bool(plan.found), plan.n_nodes, plan.scenario, plan.order_id, rank, world)
+        t0 = time.perf_counter()
         best[0] = sweep.all_gather_plan(rec, device="cuda" if backend == "nccl" else "cpu").as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
+        gather_s[0] += time.perf_counter() - t0
 
     def fence():
         if world > 1:
@@ -435,7 +587,7 @@ def main():
         st = ctx.stats()
         wl = "config5" if args.workload == "config5" else "config3"
         alg = algorithmic_bytes(scen, prob.n_pods, wl)
-        kname = "simon::table_kernel" if getattr(st, "kernel_generation", 0) in (4, 5, 6) else KERNEL_NAME.get(st.kernel_variant)
+        kname = kernel_of(st)
         value = S_total * args.steps / dt
         out = {
             "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),
@@ -450,6 +602,8 @@ def main():
             "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
                       "backend": (dist.get_backend() if world > 1 else None),
                       "collective": "all_gather of one 32-byte plan record per rank and step" if world > 1 else None,
+                      "all_gather_ms_per_step": round(gather_s[0] / max(args.steps, 1) * 1e3, 4) if world > 1 else None,
+                      "selfcheck": selfcheck,
                       "launched_by": "bench.py --gpus N (self-spawned torch.distributed.run)" if os.environ.get("SIMON_BENCH_SELF_SPAWNED") else "external launcher"} if world > 1 else
                      {"world_size": 1, "backend": None},
         }
@@ -458,7 +612,8 @@ def main():
         mode = args.pmc
         if mode in ("auto", "live") and world == 1:
             child = ["--workload", args.workload, "--steps", "1", "--warmup", "0", "--counts", str(args.counts), "--pods", str(args.pods),
-                     "--orders-per-gpu", str(args.orders_per_gpu), "--sigs", str(args.sigs), "--placement", str(args.placement)]
+                     "--orders-per-gpu", str(args.orders_per_gpu), "--sigs", str(args.sigs), "--placement", str(args.placement),
+                     "--c5-scenarios", str(c5_scenarios(args))]
             ctx.close()                                        # free the device for the profiled children
             t0 = time.perf_counter()
             pmc = pmc_live(kname, child, budget_s=float(os.environ.get("SIMON_BENCH_PMC_BUDGET_S", "240")))
@@ -479,31 +634,31 @@ def main():
         if not args.no_cpu_baseline:
             if world == 1:
                 pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=float(os.environ.get("SIMON_BENCH_CPU_BUDGET_S", "12")))
-                out["cpu_baseline"] = {
-                    "value": round(tm["k"] / tm["dt"], 4), "unit": "scenarios/s", "cores": tm["cores"], "kind": "port",
-                    "sample": f"{tm['k']} of the {S_local} scenarios of this rank's batch (evenly spaced over node counts/orders), {tm['dt']:.1f} s on "
-                              f"{tm['cores']} threads, one scenario per task (one thread alone: {1.0 / tm['per']:.2f} scenarios/s; C oracle = restated "
-                              f"CPU baseline of the naive per-pod loop over all nodes, not the Go reference binary -- no Go toolchain on this box; the GPU/CPU "
-                              f"ratio is mostly algorithmic: the kernel re-evaluates one table column per cycle, the oracle every node)"}
+                out["cpu_baseline"] = cpu_baseline_record(tm, S_local, "this rank's batch")
             else:
                 pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=4.0, max_k=64)
             out["parity_sample"] = parity_check(ctx, pick, refs, placement)
             if out["parity_sample"]["mismatches"]:
                 rc = 3
-        # ---- driver-timed records of the other single-GPU configurations ------------------------------------------
+        ctx.close()
+        # ---- driver-timed records of the other single-GPU configurations, each a measurement of its own --------------
         if world == 1 and args.workload == "config3" and not args.no_sub:
+            out["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, local_rank)
             subs = []
-            for name, steps, warm, nchk in (("config2", 20, 2, 1), ("config5", 2, 1, 2)):
+            nchk5 = int(os.environ.get("SIMON_BENCH_C5_CHECK", "32"))
+            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
+                                                 ("config5", 2, 1, nchk5, C5_SATURATING)):
                 try:
-                    subs.append(sub_benchmark(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk))
-                    if subs[-1]["parity_sample"]["mismatches"]:
+                    subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))
+                    if subs[-1].get("parity_sample", {}).get("mismatches"):
                         rc = 3
                 except Exception as e:                         # noqa: BLE001
                     subs.append({"workload": name, "error": repr(e)})
                     rc = rc or 4
             out["other_workloads"] = subs
         print(json.dumps(out), flush=True)
-    ctx.close()
+    else:
+        ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

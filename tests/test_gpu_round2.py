@@ -253,6 +253,10 @@ def test_bench_gpus_flag_spawns_the_ranks_itself():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
     assert "self-spawned" in d["ranks"]["launched_by"]
+    # the multi-rank self-check: what the ranks saw (the hook is stated, so a one-device run cannot pass for a multi-GPU one)
+    sc = d["ranks"]["selfcheck"]
+    assert sc["one_device_test_hook"] is True and sc["distinct_devices_over_ranks"] == 1 and len(sc["devices"]) == 2
+    assert d["ranks"]["all_gather_ms_per_step"] > 0
     assert d["config"]["scenarios_per_gpu"] == 32 * 4 and "8 pod orders = 256 scenarios" in d["config"]["workload"]
     assert d["parity_sample"]["mismatches"] == 0 and d["parity_sample"]["scenarios"] >= 16
     assert d["parity_sample"]["placement_rows"] == d["parity_sample"]["scenarios"]
@@ -265,24 +269,45 @@ def test_bench_gpus_flag_spawns_the_ranks_itself():
 
 
 def test_bench_line_is_self_verifying():
-    """One reduced single-GPU bench line: roofline fractions are fractions, the parity sample covers placements, the
-    sub-records of config 2 / config 5 are present and checked."""
+    """One reduced single-GPU bench line: roofline fractions are fractions, the parity sample covers placements, the end-to-end leg
+    ran, and every sub-record (config 2, config 5 at the small and at the saturating batch size) is a measurement of its own:
+    roofline record, CPU baseline, parity sample."""
     out, d = _bench(["--steps", "2", "--warmup", "1", "--counts", "64", "--pmc", "replay"],
-                    env={"SIMON_BENCH_CPU_BUDGET_S": "2", "SIMON_BENCH_C5_SCEN": "16"})
+                    env={"SIMON_BENCH_CPU_BUDGET_S": "2", "SIMON_BENCH_C5_SCEN": "16", "SIMON_BENCH_C5_CHECK": "3"})
     assert out.returncode == 0, out.stderr[-3000:]
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["kernel"] == "narrow_cache"
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["kernel"] == "score_table"
     ps = d["parity_sample"]
     assert ps["mismatches"] == 0 and ps["scenarios"] >= 16 and ps["placement_rows"] == ps["scenarios"]
     r = d["roofline"]
     assert r["bound"] == "valu_issue" and r["peak"] == pytest.approx(1228.8)
     assert r["frac"] is None or 0 < r["frac"] < 1                # replayed counters only exist for the full-size workload
-    assert r["algorithmic_ratio"] > 0
+    assert r["algorithmic_ratio"] > 0 and r["kernel"] == "simon::table_kernel"
+    e2e = d["end_to_end"]
+    assert e2e["batch_ms"] > e2e["kernel_ms"] > 0 and e2e["load_problem_ms"] > 0 and e2e["scenarios"] == d["config"]["scenarios_per_gpu"]
     names = [w["workload"] for w in d["other_workloads"]]
-    assert names == ["config2", "config5"]
+    assert names == ["config2", "config5_S16", "config5_S2048"]
     for w in d["other_workloads"]:
         assert "error" not in w, w
         assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
+        assert w["parity_sample"]["placement_rows"] == w["parity_sample"]["scenarios"] >= 1
+        assert w["cpu_baseline"]["kind"] == "port" and w["cpu_baseline"]["value"] > 0
+        assert w["roofline"]["kernel_ms"] > 0 and w["roofline"]["kernel"] == "simon::table_kernel"
+    assert d["other_workloads"][1]["kernel_generation"] == 6 and d["other_workloads"][2]["scenarios"] == 2048
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_group_mode_one_process_two_members():
+    """`bench.py --group 2`: ONE process, simon_group over two members (both on device 0 under the test hook): the Go-host shape."""
+    out, d = _bench(["--group", "2", "--steps", "2", "--warmup", "1", "--counts", "32", "--pods", "2000"],
+                    env={"SIMON_BENCH_SHARE_DEVICE": "1", "SIMON_BENCH_CPU_BUDGET_S": "2"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["ranks"]["devices"] == [0, 0] and "simon_group" in d["ranks"]["mode"]
+    assert d["config"]["scenarios_per_gpu"] == 32 * 4 and len(d["ranks"]["member_kernel_ms"]) == 2
+    assert d["parity_sample"]["mismatches"] == 0 and d["parity_sample"]["scenarios"] >= 8
+    if capi.load_library().simon_hip_device_count() < 2:          # without the hook: refuse, do not fold the members onto one device
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "2", "--steps", "1"], capture_output=True, text=True,
+                             timeout=300, env={k: v for k, v in os.environ.items() if k != "SIMON_BENCH_SHARE_DEVICE"})
+        assert out.returncode != 0 and "only 1 GPU" in (out.stderr + out.stdout)
 
 
 # ---- a non-Python consumer of the C-ABI -------------------------------------------------------------------------
