@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIMON_HIP_ABI_VERSION 3
+#define SIMON_HIP_ABI_VERSION 4
 
 #define SIMON_MAX_GPU_DEV 8 /* devices per GPU-share node (pkg/type/open-gpu-share/cache/gpunodeinfo.go:34-56) */
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
@@ -159,6 +159,11 @@ typedef struct simon_pods_soa {
                                       describes the template without that requirement (one class per DaemonSet, not per
                                       node); every node but pin_node fails NodeAffinity after the class's own static
                                       filters (code SIMON_FAIL_STATIC | SIMON_REASON_NODE_AFFINITY).  -1: none. optional */
+    const uint32_t* gpu_index;     /* [P] ABI v4: annotation alibabacloud.com/gpu-index the pod ARRIVES with ("2", "0-0-1"), packed: nibble i =
+                                      1 + i-th device id, 0 ends the list (<= 8 ids, ids 0..7); 0 = no annotation.  A valid list short-cuts
+                                      GpuNodeInfo.AllocateGpuId (pkg/type/open-gpu-share/cache/gpunodeinfo.go:247-253): every node with devices and
+                                      enough total gpu-mem passes the filter, Reserve books the pod on the listed devices (ids the node lacks are
+                                      skipped, :127-135).  optional */
 } simon_pods_soa;
 
 /* Open-Local volumes of one pod class (annotation simon/pod-local-storage -> utils.GetPodLocalPVCs,
@@ -282,6 +287,11 @@ typedef struct simon_batch_out {
     int64_t* used_mem;             /* [S] likewise, bytes */
     int32_t* placement;            /* [S][P] indexed by POD ID: node index, SIMON_UNSCHEDULED or SIMON_GATED; optional (NULL = not fetched) */
     int64_t* used_vg;              /* [S] sum of the nodes' volume-group Requested at the end (MaxVG cap, pkg/apply/apply.go:753-771); optional */
+    uint64_t* gpu_slices;          /* [S][P] ABI v4, by POD ID: byte d = how many gpu-mem slices of the pod Reserve booked on device d of its node --
+                                      the content of the alibabacloud.com/gpu-index annotation the plugin writes (AllocateGpuId builds the id string in
+                                      ascending device order, "0-0-1" = bytes {2, 1, 0, ...}; pkg/type/open-gpu-share/utils/pod.go:117-127) and what
+                                      simon/node-gpu-share is summed from (open-gpu-share.go:171-175).  0 for pods without a GPU request, unplaced pods and
+                                      pods bound by Spec.NodeName (they never reach Reserve).  optional (NULL = not recorded / not fetched) */
 } simon_batch_out;
 
 /* Result of the add-nodes search (pkg/apply/apply.go:203-259 + satisfyResourceSetting :689-775) */
@@ -350,14 +360,20 @@ int simon_set_node_ranks(simon_ctx* ctx, const int32_t* rank /* [S][N] */);
 
 /* Run every loaded scenario on the device; results stay in HBM.  This is the timed hot path:
  * per scenario, per pod: findNodesThatFitPod -> prioritizeNodes -> selectHost -> assume
- * (V/core/generic_scheduler.go:131-209, V/scheduler.go:371).  want_placement = 0 skips the
- * [S][P] placement store. */
+ * (V/core/generic_scheduler.go:131-209, V/scheduler.go:371).  want_placement: bit 0 (SIMON_WANT_PLACEMENT) stores the
+ * [S][P] placement matrix, bit 1 (SIMON_WANT_GPU_SLICES, ABI v4) additionally records the devices Reserve booked for every
+ * placed GPU pod (simon_batch_out.gpu_slices / simon_fetch_gpu_slices); 0 skips both stores. */
+#define SIMON_WANT_PLACEMENT 1
+#define SIMON_WANT_GPU_SLICES 2
 int simon_run_loaded(simon_ctx* ctx, int32_t want_placement);
 
 /* Copy results of the last run to caller buffers (out->placement may be NULL). */
 int simon_fetch_results(simon_ctx* ctx, simon_batch_out* out);
 /* Copy one scenario's placement row ([P], by pod id). */
 int simon_fetch_placement(simon_ctx* ctx, int32_t scenario, int32_t* placement);
+/* Copy one scenario's GPU device row ([P], by pod id; simon_batch_out.gpu_slices): needs a run with SIMON_WANT_GPU_SLICES.  Replaces
+ * reading alibabacloud.com/gpu-index back from the bound pods (pkg/type/open-gpu-share/utils/pod.go:117-127). */
+int simon_fetch_gpu_slices(simon_ctx* ctx, int32_t scenario, uint64_t* slices);
 
 /* load_scenarios + run_loaded + fetch_results in one call: the batched Simulate(). */
 int simon_run_batch(simon_ctx* ctx, const simon_scenario* scen, int32_t S, const int32_t* orders,
@@ -428,6 +444,7 @@ int simon_group_fetch_results(simon_group* g, simon_batch_out* out);
 int simon_group_run_batch(simon_group* g, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
                           simon_batch_out* out);
 int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* placement);
+int simon_group_fetch_gpu_slices(simon_group* g, int32_t scenario, uint64_t* slices);   /* simon_fetch_gpu_slices on the member that ran it */
 
 /* The add-nodes search over every device: minimum n_nodes among the scenarios of the last run that schedule every pod
  * within the caps (satisfyResourceSetting, pkg/apply/apply.go:689-775); ties go to the lowest scenario index, exactly

@@ -41,7 +41,23 @@ type BatchOut struct {
 	UsedMem     []int64 // [S]
 	UsedVG      []int64 // [S] Open-Local volume-group bytes requested (MaxVG cap)
 	Placement   []int32 // [S][P] by pod id: node index, -1 unscheduled, -2 not part of the scenario; nil when not asked for
+	GpuSlices   []uint64 // [S][P] by pod id (ABI v4): byte d = gpu-mem slices Reserve booked on device d; nil when not asked for
 	P           int
+}
+
+// GpuIDs spells out one GpuSlices entry the way GpuNodeInfo.AllocateGpuId builds the id string: ascending device ids, one per slice
+// ("0-0-1"; pkg/type/open-gpu-share/cache/gpunodeinfo.go:268-287).  "" = nothing booked.
+func GpuIDs(slices uint64) string {
+	id := ""
+	for d := 0; d < C.SIMON_MAX_GPU_DEV; d++ {
+		for k := uint64(0); k < (slices>>(8*uint(d)))&0xFF; k++ {
+			if id != "" {
+				id += "-"
+			}
+			id += fmt.Sprintf("%d", d)
+		}
+	}
+	return id
 }
 
 // Plan is simon_plan: the result of the add-nodes search over a batch.
@@ -57,12 +73,23 @@ type Plan struct {
 // Scenario mirrors simon_scenario: the first NNodes pool nodes, pods fed in order OrderID.
 type Scenario struct{ NNodes, OrderID int32 }
 
-func newBatchOut(S, P int, wantPlacement bool) *BatchOut {
+func newBatchOut(S, P int, wantPlacement, wantGpu bool) *BatchOut {
 	out := &BatchOut{Unscheduled: make([]int32, S), UsedCPU: make([]int64, S), UsedMem: make([]int64, S), UsedVG: make([]int64, S), P: P}
 	if wantPlacement {
 		out.Placement = make([]int32, S*P)
 	}
+	if wantGpu {
+		out.GpuSlices = make([]uint64, S*P)
+	}
 	return out
+}
+
+// GpuRow returns scenario s's device row (nil when the batch did not ask for it).
+func (o *BatchOut) GpuRow(s int) []uint64 {
+	if o.GpuSlices == nil {
+		return nil
+	}
+	return o.GpuSlices[s*o.P : (s+1)*o.P]
 }
 
 // Row returns scenario s's placement row.
@@ -109,6 +136,14 @@ func (a *cArena) u64(s []uint64) *C.uint64_t {
 	copy((*[1 << 27]uint64)(p)[:len(s):len(s)], s)
 	return (*C.uint64_t)(p)
 }
+func (a *cArena) u32(s []uint32) *C.uint32_t {
+	if len(s) == 0 {
+		return nil
+	}
+	p := a.alloc(len(s) * 4)
+	copy((*[1 << 28]uint32)(p)[:len(s):len(s)], s)
+	return (*C.uint32_t)(p)
+}
 func (a *cArena) u8(s []uint8) *C.uint8_t {
 	if len(s) == 0 {
 		return nil
@@ -132,10 +167,14 @@ func (o *BatchOut) cOut(a *cArena) (c C.simon_batch_out, back func()) {
 	c = C.simon_batch_out{struct_size: C.uint32_t(unsafe.Sizeof(C.simon_batch_out{}))}
 	un, uc, um, uv := a.alloc(S*4), a.alloc(S*8), a.alloc(S*8), a.alloc(S*8)
 	c.unscheduled, c.used_cpu, c.used_mem, c.used_vg = (*C.int32_t)(un), (*C.int64_t)(uc), (*C.int64_t)(um), (*C.int64_t)(uv)
-	var pl unsafe.Pointer
+	var pl, gs unsafe.Pointer
 	if o.Placement != nil {
 		pl = a.alloc(len(o.Placement) * 4)
 		c.placement = (*C.int32_t)(pl)
+	}
+	if o.GpuSlices != nil {
+		gs = a.alloc(len(o.GpuSlices) * 8)
+		c.gpu_slices = (*C.uint64_t)(gs)
 	}
 	back = func() {
 		copy(o.Unscheduled, (*[1 << 28]int32)(un)[:S:S])
@@ -144,6 +183,9 @@ func (o *BatchOut) cOut(a *cArena) (c C.simon_batch_out, back func()) {
 		copy(o.UsedVG, (*[1 << 27]int64)(uv)[:S:S])
 		if pl != nil {
 			copy(o.Placement, (*[1 << 28]int32)(pl)[:len(o.Placement):len(o.Placement)])
+		}
+		if gs != nil {
+			copy(o.GpuSlices, (*[1 << 27]uint64)(gs)[:len(o.GpuSlices):len(o.GpuSlices)])
 		}
 	}
 	return c, back
@@ -209,8 +251,8 @@ func (c *Ctx) Load(f *Flat) error {
 func cScen(scen []Scenario) *C.simon_scenario { return (*C.simon_scenario)(unsafe.Pointer(&scen[0])) }
 
 // RunBatch = S x Simulate: simon_run_batch.  orders is [nOrders][P] row-major.
-func (c *Ctx) RunBatch(scen []Scenario, orders []int32, nOrders, P int, wantPlacement bool) (*BatchOut, error) {
-	out := newBatchOut(len(scen), P, wantPlacement)
+func (c *Ctx) RunBatch(scen []Scenario, orders []int32, nOrders, P int, wantPlacement, wantGpu bool) (*BatchOut, error) {
+	out := newBatchOut(len(scen), P, wantPlacement, wantGpu)
 	var a cArena
 	defer a.free()
 	o, back := out.cOut(&a)
@@ -227,16 +269,19 @@ func (c *Ctx) LoadScenarios(scen []Scenario, orders []int32, nOrders int) error 
 	return c.check(C.simon_load_scenarios(c.h, cScen(scen), C.int32_t(len(scen)), (*C.int32_t)(unsafe.Pointer(&orders[0])), C.int32_t(nOrders)), "simon_load_scenarios")
 }
 
-func (c *Ctx) RunLoaded(wantPlacement bool) error {
+func (c *Ctx) RunLoaded(wantPlacement, wantGpu bool) error {
 	w := C.int32_t(0)
 	if wantPlacement {
-		w = 1
+		w |= C.SIMON_WANT_PLACEMENT
+	}
+	if wantGpu {
+		w |= C.SIMON_WANT_GPU_SLICES
 	}
 	return c.check(C.simon_run_loaded(c.h, w), "simon_run_loaded")
 }
 
-func (c *Ctx) Fetch(S, P int, wantPlacement bool) (*BatchOut, error) {
-	out := newBatchOut(S, P, wantPlacement)
+func (c *Ctx) Fetch(S, P int, wantPlacement, wantGpu bool) (*BatchOut, error) {
+	out := newBatchOut(S, P, wantPlacement, wantGpu)
 	var a cArena
 	defer a.free()
 	o, back := out.cOut(&a)
@@ -251,6 +296,12 @@ func (c *Ctx) Fetch(S, P int, wantPlacement bool) (*BatchOut, error) {
 func (c *Ctx) FetchPlacement(scenario, P int) ([]int32, error) {
 	row := make([]int32, P)
 	return row, c.check(C.simon_fetch_placement(c.h, C.int32_t(scenario), (*C.int32_t)(unsafe.Pointer(&row[0]))), "simon_fetch_placement")
+}
+
+// FetchGpuSlices copies one scenario's device row (a run with wantGpu).
+func (c *Ctx) FetchGpuSlices(scenario, P int) ([]uint64, error) {
+	row := make([]uint64, P)
+	return row, c.check(C.simon_fetch_gpu_slices(c.h, C.int32_t(scenario), (*C.uint64_t)(unsafe.Pointer(&row[0]))), "simon_fetch_gpu_slices")
 }
 
 // SetNodeRanks passes every scenario's nodeTree order ([S][N] row-major rank of each pool node) when the zone round
@@ -352,8 +403,8 @@ func (g *Group) Load(f *Flat) error {
 }
 
 // RunBatch deals the scenarios over the members, runs them concurrently, and returns results in the caller's order.
-func (g *Group) RunBatch(scen []Scenario, orders []int32, nOrders, P int, wantPlacement bool) (*BatchOut, error) {
-	out := newBatchOut(len(scen), P, wantPlacement)
+func (g *Group) RunBatch(scen []Scenario, orders []int32, nOrders, P int, wantPlacement, wantGpu bool) (*BatchOut, error) {
+	out := newBatchOut(len(scen), P, wantPlacement, wantGpu)
 	var a cArena
 	defer a.free()
 	o, back := out.cOut(&a)
@@ -376,4 +427,9 @@ func (g *Group) MinPlan(maxCPU, maxMem, maxVG int) (Plan, error) {
 func (g *Group) FetchPlacement(scenario, P int) ([]int32, error) {
 	row := make([]int32, P)
 	return row, g.check(C.simon_group_fetch_placement(g.h, C.int32_t(scenario), (*C.int32_t)(unsafe.Pointer(&row[0]))), "simon_group_fetch_placement")
+}
+
+func (g *Group) FetchGpuSlices(scenario, P int) ([]uint64, error) {
+	row := make([]uint64, P)
+	return row, g.check(C.simon_group_fetch_gpu_slices(g.h, C.int32_t(scenario), (*C.uint64_t)(unsafe.Pointer(&row[0]))), "simon_group_fetch_gpu_slices")
 }

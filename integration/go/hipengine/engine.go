@@ -14,8 +14,8 @@ package hipengine
 // unscheduled pod that passes satisfyResourceSetting).
 //
 // Scope of this file: the inputs whose plugins are per-node and static or NodeResourcesFit-like -- cpu / memory /
-// ephemeral-storage / pod-count requests, NodeUnschedulable, NodeName, TaintToleration, NodeAffinity (required),
-// Open-Gpu-Share -- i.e. BASELINE configs 1-5.  Supports() answers false (the Go path runs) for everything whose tables
+// ephemeral-storage / extended-resource / pod-count requests, NodeUnschedulable, NodeName, TaintToleration, NodeAffinity
+// (required), Open-Gpu-Share incl. pods that arrive with a gpu-index annotation -- i.e. BASELINE configs 1-5.  Supports() answers false (the Go path runs) for everything whose tables
 // this Go flattening does not fill yet: pod (anti-)affinity, topology spread constraints, preferred node affinity /
 // PreferNoSchedule taints, host ports, Open-Local volumes, scheduler configs / extra registries.  The engine itself
 // evaluates all of those (ABI v2 tables); the complete object -> table code is open-simulator_amd/flatten.py, whose
@@ -26,6 +26,10 @@ import (
 	"os"
 	"sort"
 	"strconv"
+	"strings"
+
+	"github.com/pquerna/ffjson/ffjson"
+	metav1 "k8s.io/apimachinery/pkg/apis/meta/v1"
 
 	corev1 "k8s.io/api/core/v1"
 	"k8s.io/apimachinery/pkg/api/resource"
@@ -36,6 +40,8 @@ import (
 
 	"github.com/alibaba/open-simulator/pkg/algo"
 	"github.com/alibaba/open-simulator/pkg/simulator"
+	simontype "github.com/alibaba/open-simulator/pkg/type"
+	gpusharecache "github.com/alibaba/open-simulator/pkg/type/open-gpu-share/cache"
 	gpushareutils "github.com/alibaba/open-simulator/pkg/type/open-gpu-share/utils"
 	"github.com/alibaba/open-simulator/pkg/utils"
 )
@@ -54,6 +60,14 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 	pods, err := podStream(cluster, apps, cluster.Nodes)
 	if err != nil {
 		return false
+	}
+	if _, ok := scalarNames(cluster.Nodes, pods); !ok { // more extended resources than the ABI tracks (SIMON_MAX_SCALAR)
+		return false
+	}
+	for _, p := range pods {
+		if _, ok := gpuIndexOf(p); !ok { // an arriving gpu-index list the ABI cannot pack
+			return false
+		}
 	}
 	var prio *int32
 	for _, p := range pods {
@@ -139,13 +153,21 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 	N, P := len(pool), len(pods)
 	index := map[string]int32{}
 	// ---- nodes: framework.NewResource(node.Status.Allocatable) (V/framework/types.go:295-326) ----
-	type nodeKey struct {
-		cpu, mem, eph int64
-		pods          int32
-		gpuCnt        int32
-		gpuMem        int64
+	// extended ("scalar") resources: framework.Resource.ScalarResources (V/framework/types.go:283-292), at most SIMON_MAX_SCALAR names
+	names, ok := scalarNames(pool, pods)
+	if !ok {
+		return nil, fmt.Errorf("more than %d extended resources", maxScalar)
 	}
-	nodeClassOf := map[nodeKey]int32{}
+	f.ScalarNames = names
+	f.NScalar = len(names)
+	K := len(names)
+	if K > 0 {
+		f.ScalarAlloc = make([]int64, K*N)
+		f.ScalarReq = make([]int64, K*P)
+	}
+	// node class = the node's WHOLE allocatable list (SimonPlugin.Score iterates every allocatable resource,
+	// pkg/simulator/plugin/simon.go:57-66) + its GPU capacity: nodes of one class share a simon_raw column
+	nodeClassOf := map[string]int32{}
 	var classRep []*corev1.Node
 	for j, n := range pool {
 		index[n.Name] = int32(j)
@@ -154,11 +176,14 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		f.AllocMem = append(f.AllocMem, r.Memory)
 		f.AllocEph = append(f.AllocEph, r.EphemeralStorage)
 		f.AllocPods = append(f.AllocPods, int32(r.AllowedPodNumber))
+		for k, name := range names {
+			f.ScalarAlloc[k*N+j] = r.ScalarResources[corev1.ResourceName(name)]
+		}
 		gc := int32(gpushareutils.GetGpuCountInNode(n))
 		gm := gpushareutils.GetTotalGpuMemory(n)
 		f.GpuCnt = append(f.GpuCnt, gc)
 		f.GpuMemTotal = append(f.GpuMemTotal, gm)
-		k := nodeKey{r.MilliCPU, r.Memory, r.EphemeralStorage, int32(r.AllowedPodNumber), gc, gm}
+		k := fmt.Sprintf("%s|%d|%d", resourceListKey(n.Status.Allocatable), gc, gm)
 		c, ok := nodeClassOf[k]
 		if !ok {
 			c = int32(len(classRep))
@@ -177,8 +202,18 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 	f.StaticReasons = []string{"", "node(s) were unschedulable", "node(s) didn't match the requested hostname",
 		"node(s) didn't match Pod's node affinity"} // id 3 = SIMON_REASON_NODE_AFFINITY; taint messages are appended below
 	taintReason := map[string]uint8{}
-	for _, p := range pods {
+	anyIndex := false
+	for pi, p := range pods {
 		req := podRequest(p)
+		for k, name := range names {
+			f.ScalarReq[k*P+pi] = req.ScalarResources[corev1.ResourceName(name)]
+		}
+		gi, _ := gpuIndexOf(p) // Supports() has refused the lists that do not pack
+		if gpushareutils.GetGpuMemoryFromPodAnnotation(p) <= 0 {
+			gi = 0
+		}
+		f.PodGpuIndex = append(f.PodGpuIndex, gi)
+		anyIndex = anyIndex || gi != 0
 		f.ReqCPU = append(f.ReqCPU, req.MilliCPU)
 		f.ReqMem = append(f.ReqMem, req.Memory)
 		f.ReqEph = append(f.ReqEph, req.EphemeralStorage)
@@ -187,7 +222,7 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		f.NzMem = append(f.NzMem, nzm)
 		f.PodGpuMem = append(f.PodGpuMem, gpushareutils.GetGpuMemoryFromPodAnnotation(p))
 		f.PodGpuCnt = append(f.PodGpuCnt, int32(gpushareutils.GetGpuCountFromPodAnnotation(p)))
-		preset, gate := int32(-1), int32(-1)
+		preset, gate, pin := int32(-1), int32(-1), int32(-1)
 		if p.Spec.NodeName != "" {
 			j, ok := index[p.Spec.NodeName]
 			if !ok {
@@ -195,23 +230,37 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 			}
 			preset = j
 		}
-		if name := daemonNodeOf(p); name != "" { // a DaemonSet pod made for a clone exists only when the clone does
-			if j, ok := index[name]; ok && int(j) >= nCluster {
-				gate = j
+		// A DaemonSet's per-node pods differ only in the node their affinity names (SetDaemonSetPodNodeNameByNodeAffinity,
+		// pkg/utils/utils.go:770-815): they share ONE class -- the pod with that requirement replaced by one that holds on every
+		// node -- and carry the node as pin_node (the kernels then test the pod on that node only; include/simon_hip.h).  One class
+		// per DaemonSet instead of one per (DaemonSet, node): the O(Cp x N) static-filter loop below stays O(workloads x N).
+		classPod := p
+		if name := daemonNodeOf(p); name != "" && preset < 0 {
+			if j, ok := index[name]; ok {
+				pin = j
+				if int(j) >= nCluster { // a DaemonSet pod made for a clone exists only when the clone does
+					gate = j
+				}
+				classPod = withAnyNodeName(p)
 			}
 		}
 		f.Preset = append(f.Preset, preset)
 		f.Gate = append(f.Gate, gate)
-		// pod class = everything the static filters and the Simon score see
-		key := classKey(fmt.Sprintf("%v|%v|%v|%s|%d/%d/%d", p.Spec.Tolerations, p.Spec.NodeSelector, p.Spec.Affinity, p.Spec.NodeName,
-			req.MilliCPU, req.Memory, req.EphemeralStorage))
+		f.Pin = append(f.Pin, pin)
+		// pod class = everything the static filters and the Simon score see: tolerations, node selector / affinity, a preset
+		// node, and the WHOLE request list (simon.go:49-66 reads every requested resource)
+		key := classKey(fmt.Sprintf("%v|%v|%v|%s|%s", classPod.Spec.Tolerations, classPod.Spec.NodeSelector, classPod.Spec.Affinity,
+			classPod.Spec.NodeName, resourceListKey(requestList(p))))
 		c, ok := classOf[key]
 		if !ok {
 			c = int32(len(classPods))
 			classOf[key] = c
-			classPods = append(classPods, p)
+			classPods = append(classPods, classPod)
 		}
 		f.PodClass = append(f.PodClass, c)
+	}
+	if !anyIndex {
+		f.PodGpuIndex = nil
 	}
 	f.Cp = len(classPods)
 	// ---- class tables: static filters once per (pod class, node), Simon raw score per (pod class, node class) ----
@@ -369,6 +418,123 @@ func resourcehelperPodRequestsAndLimits(p *corev1.Pod) (corev1.ResourceList, cor
 
 var _ = resource.Quantity{} // Quantity methods used above come from this package
 
+const maxScalar = 4 // SIMON_MAX_SCALAR
+
+// scalarNames interns the extended resources some pod REQUESTS (non-zero entries of framework.Resource.ScalarResources: everything but
+// cpu / memory / ephemeral-storage, V/framework/types.go:295-326), sorted; ok = false beyond SIMON_MAX_SCALAR.  What nodes merely
+// advertise (the gpu-share nodes' alibabacloud.com/gpu-mem, gpu-count) never reaches fitsRequest, which walks the POD's scalar
+// requests (fit.go:286-299) -- the same rule as open-simulator_amd/flatten.py.
+func scalarNames(nodes []*corev1.Node, pods []*corev1.Pod) ([]string, bool) {
+	seen := map[string]bool{}
+	for _, p := range pods {
+		for name, v := range podRequest(p).ScalarResources {
+			if v != 0 {
+				seen[string(name)] = true
+			}
+		}
+	}
+	names := make([]string, 0, len(seen))
+	for name := range seen {
+		names = append(names, name)
+	}
+	sort.Strings(names)
+	return names, len(names) <= maxScalar
+}
+
+// resourceListKey is a canonical spelling of a ResourceList: sorted "name=quantity" (equal lists -> equal keys).
+func resourceListKey(rl corev1.ResourceList) string {
+	parts := make([]string, 0, len(rl))
+	for name, q := range rl {
+		parts = append(parts, fmt.Sprintf("%s=%s", name, q.String()))
+	}
+	sort.Strings(parts)
+	return strings.Join(parts, ",")
+}
+
+func requestList(p *corev1.Pod) corev1.ResourceList {
+	reqs, _ := resourcehelperPodRequestsAndLimits(p)
+	return reqs
+}
+
+// gpuIndexOf packs the device ids of the gpu-index annotation a pod ARRIVES with (GetGpuIdFromAnnotation + GpuIdStrToIntList;
+// a valid list short-cuts GpuNodeInfo.AllocateGpuId, pkg/type/open-gpu-share/cache/gpunodeinfo.go:247-253).  (0, true) = no
+// annotation or an invalid one (the reference warns and allocates normally); ok = false = valid but not packable.
+func gpuIndexOf(p *corev1.Pod) (uint32, bool) {
+	id := gpushareutils.GetGpuIdFromAnnotation(p)
+	if id == "" {
+		return 0, true
+	}
+	idl, err := gpushareutils.GpuIdStrToIntList(id)
+	if err != nil || len(idl) == 0 {
+		return 0, true
+	}
+	return PackGpuIndex(idl)
+}
+
+// withAnyNodeName returns a copy of a DaemonSet pod whose metadata.name matchFields requirement holds on EVERY node (NotIn [""]):
+// the class view of the pod, shared by the DaemonSet's pods of all nodes.
+func withAnyNodeName(p *corev1.Pod) *corev1.Pod {
+	c := p.DeepCopy()
+	req := c.Spec.Affinity.NodeAffinity.RequiredDuringSchedulingIgnoredDuringExecution
+	for i := range req.NodeSelectorTerms {
+		for k := range req.NodeSelectorTerms[i].MatchFields {
+			if req.NodeSelectorTerms[i].MatchFields[k].Key == "metadata.name" {
+				req.NodeSelectorTerms[i].MatchFields[k] = corev1.NodeSelectorRequirement{Key: "metadata.name", Operator: corev1.NodeSelectorOpNotIn, Values: []string{""}}
+			}
+		}
+	}
+	return c
+}
+
+// gpuNodeStatus is what GpuSharePlugin.Reserve leaves on a node it booked GPU pods on (pkg/simulator/plugin/open-gpu-share.go:160-186):
+// annotation simon/node-gpu-share = NodeGpuInfo as JSON (ExportGpuNodeInfoAsNodeGpuInfo, gpunodeinfo.go:345-368) and allocatable
+// gpu-count = devices that are not full.  pods: the GPU pods bound to the node, already carrying their gpu-index annotation.
+func gpuNodeStatus(node *corev1.Node, pods []*corev1.Pod) *corev1.Node {
+	n := node.DeepCopy()
+	cnt := gpushareutils.GetGpuCountInNode(n)
+	total := gpushareutils.GetTotalGpuMemory(n)
+	if cnt <= 0 {
+		return n
+	}
+	per := total / int64(cnt)
+	mi := func(b int64) resource.Quantity { q, _ := resource.ParseQuantity(fmt.Sprintf("%dMi", b/(1024*1024))); return q }
+	info := &gpusharecache.NodeGpuInfo{DevsBrief: map[int]*gpusharecache.DeviceInfoBrief{}, GpuCount: cnt, GpuAllocatable: cnt,
+		GpuModel: gpushareutils.GetGpuModel(n), GpuTotalMemory: mi(total)}
+	for d := 0; d < cnt; d++ {
+		var list []string
+		var used int64
+		for _, p := range pods {
+			idl, err := gpushareutils.GetGpuIdListFromAnnotation(p)
+			if err != nil {
+				continue
+			}
+			on := false
+			for _, id := range idl {
+				if id == d {
+					used += gpushareutils.GetGpuMemoryFromPodAnnotation(p) // DeviceInfo.GetUsedGpuMemory, deviceinfo.go:45-67
+					on = true
+				}
+			}
+			if on {
+				list = append(list, fmt.Sprintf("%s:%s", p.Namespace, p.Name))
+			}
+		}
+		if used >= per {
+			info.GpuAllocatable--
+		}
+		info.DevsBrief[d] = &gpusharecache.DeviceInfoBrief{PodList: list, GpuTotalMemory: mi(per), GpuUsedMemory: mi(used)}
+		info.NumPods += len(list)
+	}
+	if data, err := ffjson.Marshal(info); err == nil {
+		metav1.SetMetaDataAnnotation(&n.ObjectMeta, simontype.AnnoNodeGpuShare, string(data))
+	}
+	if q, ok := n.Status.Allocatable[gpushareutils.CountName]; ok && q.Value() != int64(info.GpuAllocatable) {
+		q.Set(int64(info.GpuAllocatable))
+		n.Status.Allocatable[gpushareutils.CountName] = q
+	}
+	return n
+}
+
 // Simulate = simulator.Simulate for ONE cluster size on device 0.
 func Simulate(cluster simulator.ResourceTypes, apps []simulator.AppResource) (*simulator.SimulateResult, error) {
 	res, _, err := SimulateBatch(cluster, apps, nil, []int{0}, []int32{0})
@@ -429,7 +595,7 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 		if err = g.Load(f); err != nil {
 			return nil, -1, err
 		}
-		if out, err = g.RunBatch(scen, order, 1, P, true); err != nil {
+		if out, err = g.RunBatch(scen, order, 1, P, true, f.PodGpuMem != nil); err != nil {
 			return nil, -1, err
 		}
 		if plan, err = g.MinPlan(maxCPU, maxMem, maxVG); err != nil {
@@ -445,7 +611,7 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 		return nil, -1, err
 	}
 	if out == nil {
-		if out, err = c.RunBatch(scen, order, 1, P, true); err != nil {
+		if out, err = c.RunBatch(scen, order, 1, P, true, f.PodGpuMem != nil); err != nil {
 			return nil, -1, err
 		}
 		if plan, err = c.MinPlan(maxCPU, maxMem, maxVG); err != nil {
@@ -470,16 +636,32 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 				reasons[pid] = FitErrorString(pods[pid], codes[i], f)
 			}
 		}
+		gpuRow := out.GpuRow(s)
+		gpuPods := map[int32][]*corev1.Pod{}
 		for pid, j := range out.Row(s) {
 			switch {
 			case j >= 0: // what SimonPlugin.Bind writes (plugin/simon.go:112-114)
 				p := pods[pid].DeepCopy()
+				scheduled := p.Spec.NodeName == "" // pods bound by Spec.NodeName never reach Reserve
 				p.Spec.NodeName = pool[j].Name
 				p.Status.Phase = corev1.PodRunning
+				if scheduled && gpuRow != nil && gpushareutils.GetGpuMemoryFromPodAnnotation(p) > 0 {
+					// GpuSharePlugin.Reserve / Bind: gpu-index + assume-time (GetUpdatedPodAnnotationSpec, utils/pod.go:117-127);
+					// a pod that arrived with a valid list keeps its own string (AllocateGpuId returns it as is)
+					id := GpuIDs(gpuRow[pid])
+					if own := gpushareutils.GetGpuIdFromAnnotation(p); f.PodGpuIndex != nil && f.PodGpuIndex[pid] != 0 {
+						id = own
+					}
+					p = gpushareutils.GetUpdatedPodAnnotationSpec(p, id)
+					gpuPods[j] = append(gpuPods[j], p)
+				}
 				res.NodeStatus[j].Pods = append(res.NodeStatus[j].Pods, p)
 			case j == -1:
 				res.UnscheduledPods = append(res.UnscheduledPods, simulator.UnscheduledPod{Pod: pods[pid], Reason: reasons[int32(pid)]})
 			}
+		}
+		for j, list := range gpuPods { // simon/node-gpu-share + allocatable gpu-count of the nodes Reserve touched
+			res.NodeStatus[j].Node = gpuNodeStatus(pool[j], list)
 		}
 		results[s] = res
 	}

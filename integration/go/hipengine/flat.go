@@ -36,6 +36,7 @@ type Flat struct {
 	PodClass, Preset, Gate, Pin                       []int32 // [P]
 	PodGpuMem                                         []int64
 	PodGpuCnt                                         []int32
+	PodGpuIndex                                       []uint32 // [P] gpu-index annotation the pod arrives with, packed (PackGpuIndex); nil = none
 	// ---- simon_class_tables ----
 	Cp, Cn                                            int
 	StaticMask                                        []uint64 // [Cp][ceil(N/64)]
@@ -97,6 +98,7 @@ func (f *Flat) cPods(a *cArena) C.simon_pods_soa {
 	p.nz_cpu, p.nz_mem, p.scalar_req = a.i64(f.NzCPU), a.i64(f.NzMem), a.i64(f.ScalarReq)
 	p.pod_class, p.preset_node, p.gate_node, p.pin_node = a.i32(f.PodClass), a.i32(f.Preset), a.i32(f.Gate), a.i32(f.Pin)
 	p.gpu_mem, p.gpu_cnt = a.i64(f.PodGpuMem), a.i32(f.PodGpuCnt)
+	p.gpu_index = a.u32(f.PodGpuIndex)
 	return p
 }
 
@@ -140,4 +142,20 @@ func (f *Flat) fillTermTables(t *C.simon_class_tables, a *cArena) {
 	t.spread_soft_off, t.spread_soft_idx, t.spread_soft_skew = a.i32(f.SpreadSoftOff), a.i32(f.SpreadSoftIdx), a.i32(f.SpreadSoftSkew)
 	t.topo_is_hostname = a.u8(f.TopoIsHostname)
 	t.spread_log = a.f64(f.SpreadLog)
+}
+
+// PackGpuIndex packs the device ids of an alibabacloud.com/gpu-index annotation the way simon_pods_soa.gpu_index wants them: nibble i
+// = 1 + i-th id, 0 ends the list.  ok = false when the list does not fit (more than 8 ids, an id beyond SIMON_MAX_GPU_DEV - 1): the
+// caller keeps the Go path.
+func PackGpuIndex(ids []int) (packed uint32, ok bool) {
+	if len(ids) == 0 || len(ids) > 8 {
+		return 0, false
+	}
+	for i, id := range ids {
+		if id < 0 || id >= C.SIMON_MAX_GPU_DEV {
+			return 0, false
+		}
+		packed |= uint32(id+1) << (4 * uint(i))
+	}
+	return packed, true
 }

@@ -12,11 +12,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_GPU_DEV = 8
 MAX_SCALAR = 4
 
@@ -73,7 +73,7 @@ class PodsSoA(C.Structure):
         ("struct_size", C.c_uint32), ("n_pods", C.c_int32),
         ("req_cpu", _p64), ("req_mem", _p64), ("req_eph", _p64), ("nz_cpu", _p64), ("nz_mem", _p64),
         ("scalar_req", _p64), ("pod_class", _p32), ("preset_node", _p32), ("gate_node", _p32),
-        ("gpu_mem", _p64), ("gpu_cnt", _p32), ("pin_node", _p32),
+        ("gpu_mem", _p64), ("gpu_cnt", _p32), ("pin_node", _p32), ("gpu_index", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -116,6 +116,7 @@ class BatchOut(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32),
         ("unscheduled", _p32), ("used_cpu", _p64), ("used_mem", _p64), ("placement", _p32), ("used_vg", _p64),
+        ("gpu_slices", _pu64),
     ]
 
 
@@ -199,6 +200,7 @@ class Problem:
     pin_node: Optional[np.ndarray] = None          # [P] >= 0: the only node the pod's node affinity admits (DaemonSet pods)
     gpu_mem: Optional[np.ndarray] = None
     pod_gpu_cnt: Optional[np.ndarray] = None
+    gpu_index: Optional[np.ndarray] = None         # [P] uint32: gpu-index annotation the pod arrives with, packed (pack_gpu_index)
     # class tables
     n_pod_classes: int = 1
     n_node_classes: int = 1
@@ -289,6 +291,7 @@ class Problem:
             setattr(self, name, _arr(getattr(self, name), i64, (P,)))
         for name in ("pod_class", "preset_node", "gate_node", "pod_gpu_cnt", "pin_node"):
             setattr(self, name, _arr(getattr(self, name), i32, (P,)))
+        self.gpu_index = _arr(self.gpu_index, np.uint32, (P,))
         self.scalar_req = _arr(self.scalar_req, i64, (K, P)) if self.scalar_req is not None else None
         Cp, Cn = self.n_pod_classes, self.n_node_classes
         words = (N + 63) // 64
@@ -371,6 +374,7 @@ class Problem:
         for name in ("pod_class", "preset_node", "gate_node", "pin_node"):
             setattr(s, name, _ptr(getattr(self, name), C.c_int32))
         s.gpu_cnt = _ptr(self.pod_gpu_cnt, C.c_int32)
+        s.gpu_index = _ptr(self.gpu_index, C.c_uint32)
         return s
 
     def c_tables(self) -> ClassTables:
@@ -410,6 +414,7 @@ class BatchResult:
     used_mem: np.ndarray
     placement: Optional[np.ndarray]
     used_vg: Optional[np.ndarray] = None
+    gpu_slices: Optional[np.ndarray] = None        # [S][P] uint64: byte d = gpu-mem slices booked on device d (gpu_ids_of)
 
     def c_out(self) -> BatchOut:
         o = BatchOut()
@@ -420,12 +425,34 @@ class BatchResult:
         o.used_mem = _ptr(self.used_mem, C.c_int64)
         o.placement = _ptr(self.placement, C.c_int32)
         o.used_vg = _ptr(self.used_vg, C.c_int64)
+        o.gpu_slices = _ptr(self.gpu_slices, C.c_uint64)
         return o
 
     @staticmethod
-    def alloc(S: int, P: int, want_placement: bool = True) -> "BatchResult":
+    def alloc(S: int, P: int, want_placement: bool = True, want_gpu_slices: bool = False) -> "BatchResult":
         return BatchResult(np.zeros(S, np.int32), np.zeros(S, np.int64), np.zeros(S, np.int64),
-                           np.full((S, P), -9, np.int32) if want_placement else None, np.zeros(S, np.int64))
+                           np.full((S, P), -9, np.int32) if want_placement else None, np.zeros(S, np.int64),
+                           np.zeros((S, P), np.uint64) if want_gpu_slices else None)
+
+
+WANT_PLACEMENT, WANT_GPU_SLICES = 1, 2
+
+
+def pack_gpu_index(ids: Sequence[int]) -> int:
+    """simon_pods_soa.gpu_index: device ids of an alibabacloud.com/gpu-index annotation ("0-0-1" -> [0, 0, 1]) as nibbles, low first."""
+    ids = list(ids)
+    if not 0 < len(ids) <= 8 or any(not 0 <= i < MAX_GPU_DEV for i in ids):
+        raise ValueError(f"gpu-index {ids}: 1..8 ids in 0..{MAX_GPU_DEV - 1} can be packed")
+    return sum((i + 1) << (4 * k) for k, i in enumerate(ids))
+
+
+def gpu_ids_of(slices: int) -> List[int]:
+    """Device ids of one simon_batch_out.gpu_slices entry, in the order GpuNodeInfo.AllocateGpuId lists them (ascending, an id once
+    per slice): the content of the alibabacloud.com/gpu-index annotation ("-".join)."""
+    out = []
+    for d in range(MAX_GPU_DEV):
+        out += [d] * ((int(slices) >> (8 * d)) & 0xFF)
+    return out
 
 
 def scenarios_array(scen: Sequence) -> np.ndarray:
@@ -447,11 +474,11 @@ _LIB = None
 EXPORTS = [
     "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
-    "simon_fetch_results", "simon_fetch_placement", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain", "simon_set_node_ranks",
+    "simon_fetch_results", "simon_fetch_placement", "simon_fetch_gpu_slices", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain", "simon_set_node_ranks",
     "simon_get_stats", "simon_device_results", "simon_explain_loaded",
     "simon_group_create", "simon_group_destroy", "simon_group_last_error", "simon_group_size", "simon_group_member",
     "simon_group_load_nodes", "simon_group_load_pods", "simon_group_load_class_tables", "simon_group_load_scenarios",
-    "simon_group_run_loaded", "simon_group_fetch_results", "simon_group_run_batch", "simon_group_fetch_placement",
+    "simon_group_run_loaded", "simon_group_fetch_results", "simon_group_run_batch", "simon_group_fetch_placement", "simon_group_fetch_gpu_slices",
     "simon_group_min_plan",
 ]
 
@@ -483,6 +510,7 @@ def load_library(path: Optional[str] = None):
     lib.simon_run_loaded.argtypes = [vp, C.c_int32]
     lib.simon_fetch_results.argtypes = [vp, C.POINTER(BatchOut)]
     lib.simon_fetch_placement.argtypes = [vp, C.c_int32, _p32]
+    lib.simon_fetch_gpu_slices.argtypes = [vp, C.c_int32, _pu64]
     lib.simon_run_batch.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32, C.POINTER(BatchOut)]
     lib.simon_set_node_ranks.argtypes = [vp, _p32]
     lib.simon_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(Plan)]
@@ -507,6 +535,7 @@ def load_library(path: Optional[str] = None):
     lib.simon_group_fetch_results.argtypes = [vp, C.POINTER(BatchOut)]
     lib.simon_group_run_batch.argtypes = [vp, C.POINTER(Scenario), C.c_int32, _p32, C.c_int32, C.POINTER(BatchOut)]
     lib.simon_group_fetch_placement.argtypes = [vp, C.c_int32, _p32]
+    lib.simon_group_fetch_gpu_slices.argtypes = [vp, C.c_int32, _pu64]
     lib.simon_group_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
     lib.simon_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.simon_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -578,14 +607,20 @@ class Context:
         self.S = len(scen)
         self.scen = scen
 
-    def run_loaded(self, want_placement: bool = True):
-        self._check(self.lib.simon_run_loaded(self.h, 1 if want_placement else 0), "simon_run_loaded")
+    def run_loaded(self, want_placement: bool = True, want_gpu_slices: bool = False):
+        flags = (WANT_PLACEMENT if want_placement else 0) | (WANT_GPU_SLICES if want_gpu_slices else 0)
+        self._check(self.lib.simon_run_loaded(self.h, flags), "simon_run_loaded")
 
-    def fetch(self, want_placement: bool = True) -> BatchResult:
-        res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement)
+    def fetch(self, want_placement: bool = True, want_gpu_slices: bool = False) -> BatchResult:
+        res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement, want_gpu_slices)
         out = res.c_out()
         self._check(self.lib.simon_fetch_results(self.h, C.byref(out)), "simon_fetch_results")
         return res
+
+    def fetch_gpu_slices(self, scenario: int) -> np.ndarray:
+        row = np.zeros(self.problem.n_pods, np.uint64)
+        self._check(self.lib.simon_fetch_gpu_slices(self.h, int(scenario), _ptr(row, C.c_uint64)), "simon_fetch_gpu_slices")
+        return row
 
     def fetch_placement(self, scenario: int) -> np.ndarray:
         row = np.zeros(self.problem.n_pods, np.int32)
@@ -593,10 +628,10 @@ class Context:
                     "simon_fetch_placement")
         return row
 
-    def run_batch(self, scen, orders: np.ndarray, want_placement: bool = True) -> BatchResult:
+    def run_batch(self, scen, orders: np.ndarray, want_placement: bool = True, want_gpu_slices: bool = False) -> BatchResult:
         scen = scenarios_array(scen)
         orders = np.ascontiguousarray(orders, dtype=np.int32).reshape(-1, self.problem.n_pods)
-        res = BatchResult.alloc(len(scen), self.problem.n_pods, want_placement)
+        res = BatchResult.alloc(len(scen), self.problem.n_pods, want_placement, want_gpu_slices)
         out = res.c_out()
         self._check(self.lib.simon_run_batch(self.h, scen.ctypes.data_as(C.POINTER(Scenario)), len(scen),
                                              _ptr(orders, C.c_int32), orders.shape[0], C.byref(out)),
@@ -722,8 +757,9 @@ class Group:
                                                         _ptr(orders, C.c_int32), orders.shape[0]), "simon_group_load_scenarios")
         self.S = len(scen)
 
-    def run_loaded(self, want_placement: bool = True):
-        self._check(self.lib.simon_group_run_loaded(self.h, 1 if want_placement else 0), "simon_group_run_loaded")
+    def run_loaded(self, want_placement: bool = True, want_gpu_slices: bool = False):
+        flags = (WANT_PLACEMENT if want_placement else 0) | (WANT_GPU_SLICES if want_gpu_slices else 0)
+        self._check(self.lib.simon_group_run_loaded(self.h, flags), "simon_group_run_loaded")
 
     def fetch(self, want_placement: bool = True) -> BatchResult:
         res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement)
@@ -739,6 +775,11 @@ class Group:
     def fetch_placement(self, scenario: int) -> np.ndarray:
         row = np.zeros(self.problem.n_pods, np.int32)
         self._check(self.lib.simon_group_fetch_placement(self.h, int(scenario), _ptr(row, C.c_int32)), "simon_group_fetch_placement")
+        return row
+
+    def fetch_gpu_slices(self, scenario: int) -> np.ndarray:
+        row = np.zeros(self.problem.n_pods, np.uint64)
+        self._check(self.lib.simon_group_fetch_gpu_slices(self.h, int(scenario), _ptr(row, C.c_uint64)), "simon_group_fetch_gpu_slices")
         return row
 
     def min_plan(self, max_cpu_pct: int = 100, max_mem_pct: int = 100, max_vg_pct: int = 100):

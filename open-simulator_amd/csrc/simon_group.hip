@@ -26,7 +26,7 @@ struct simon_group {
     std::string err;
     int32_t S = 0, P = 0;                       // last loaded batch: global scenario count; pods
     std::vector<std::vector<simon_scenario>> part;   // per member: its scenarios, in global order
-    bool have_results = false, have_placement = false;
+    bool have_results = false, have_placement = false, have_slices = false;
 };
 
 namespace {
@@ -151,7 +151,8 @@ int simon_group_run_loaded(simon_group* g, int32_t want_placement) {
     if (g->S <= 0) return gfail(g, SIMON_ESTATE, "group run_loaded: no scenarios loaded");
     int rc = on_all(g, "run_loaded", [&](int i) { return simon_run_loaded(g->ctx[i], want_placement); });
     g->have_results = rc == SIMON_OK;
-    g->have_placement = g->have_results && want_placement != 0;
+    g->have_placement = g->have_results && (want_placement & SIMON_WANT_PLACEMENT) != 0;
+    g->have_slices = g->have_results && (want_placement & SIMON_WANT_GPU_SLICES) != 0;
     return rc;
 }
 
@@ -167,11 +168,13 @@ int simon_group_fetch_results(simon_group* g, simon_batch_out* out) {
         std::vector<int32_t> un(Si);
         std::vector<int64_t> uc(Si), um(Si), uv(out->used_vg ? Si : 0);
         std::vector<int32_t> pl(out->placement ? Si * P : 0);
+        std::vector<uint64_t> gs(out->gpu_slices ? Si * P : 0);
         simon_batch_out o{};
         o.struct_size = sizeof o;
         o.unscheduled = un.data(); o.used_cpu = uc.data(); o.used_mem = um.data();
         o.used_vg = out->used_vg ? uv.data() : nullptr;
         o.placement = out->placement ? pl.data() : nullptr;
+        o.gpu_slices = out->gpu_slices ? gs.data() : nullptr;
         int rc = simon_fetch_results(g->ctx[i], &o);
         if (rc) return rc;
         for (size_t k = 0; k < Si; ++k) {                       // member-local index k = global scenario k * n + i
@@ -181,6 +184,7 @@ int simon_group_fetch_results(simon_group* g, simon_batch_out* out) {
             if (out->used_mem) out->used_mem[s] = um[k];
             if (out->used_vg) out->used_vg[s] = uv[k];
             if (out->placement) memcpy(out->placement + s * P, pl.data() + k * P, P * sizeof(int32_t));
+            if (out->gpu_slices) memcpy(out->gpu_slices + s * P, gs.data() + k * P, P * sizeof(uint64_t));
         }
         return (int)SIMON_OK;
     });
@@ -191,7 +195,7 @@ int simon_group_run_batch(simon_group* g, const simon_scenario* scen, int32_t S,
     if (!g || !out) return SIMON_EINVAL;
     int rc = simon_group_load_scenarios(g, scen, S, orders, n_orders);
     if (rc) return rc;
-    rc = simon_group_run_loaded(g, out->placement != nullptr);
+    rc = simon_group_run_loaded(g, (out->placement ? SIMON_WANT_PLACEMENT : 0) | (out->gpu_slices ? SIMON_WANT_GPU_SLICES : 0));
     if (rc) return rc;
     return simon_group_fetch_results(g, out);
 }
@@ -203,6 +207,15 @@ int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* place
     const int n = (int)g->ctx.size(), i = scenario % n;
     int rc = simon_fetch_placement(g->ctx[i], scenario / n, placement);
     return rc ? gfail(g, rc, "fetch_placement: member %d: %s", i, simon_last_error(g->ctx[i])) : SIMON_OK;
+}
+
+int simon_group_fetch_gpu_slices(simon_group* g, int32_t scenario, uint64_t* slices) {
+    if (!g || !slices) return SIMON_EINVAL;
+    if (!g->have_results) return gfail(g, SIMON_ESTATE, "group fetch_gpu_slices: nothing has run");
+    if (scenario < 0 || scenario >= g->S) return gfail(g, SIMON_EINVAL, "group fetch_gpu_slices: scenario out of range");
+    const int n = (int)g->ctx.size(), i = scenario % n;
+    int rc = simon_fetch_gpu_slices(g->ctx[i], scenario / n, slices);
+    return rc ? gfail(g, rc, "fetch_gpu_slices: member %d: %s", i, simon_last_error(g->ctx[i])) : SIMON_OK;
 }
 
 int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,

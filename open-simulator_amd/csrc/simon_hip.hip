@@ -141,7 +141,8 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_unsched, d_place;
     DevBuf<int64_t> d_used_cpu, d_used_mem, d_used_vg;
     DevBuf<unsigned long long> d_plan;
-    bool have_results = false, have_placement = false;
+    bool have_results = false, have_placement = false, have_slices = false;
+    DevBuf<uint64_t> d_gpu_slices;      // [S][P] devices Reserve booked (simon_batch_out.gpu_slices), recorded on request
     simon_stats stats{};
 };
 
@@ -185,6 +186,7 @@ uint64_t gcd_of(std::initializer_list<const std::vector<int64_t>*> vs) {
 // most kTableMaxGpuSigs distinct (gpu-mem, gpu-count) requests.  Fills g_gpu.
 bool rest_supported(simon_ctx* c) {
     if (c->no_rest) return false;
+    if (c->has_gpu_index) return false;   // pods that arrive with a gpu-index annotation (their own filter and Reserve rule): all-feature kernel
     if (c->Tm > kTableMaxTerms) return false;
     // a term's topology key is node-level (every node its own domain: kubernetes.io/hostname) or zone-like (a domain = several
     // nodes, some nodes without the label): at most 6 of the latter, domain ids below 65 535
@@ -813,6 +815,19 @@ int simon_load_pods(simon_ctx* c, const simon_pods_soa* pd) {
     copy_opt(c->p_gate, pd->gate_node, P, (int32_t)-1);
     copy_opt(c->p_gpu_mem, pd->gpu_mem, P); copy_opt(c->p_gpu_cnt, pd->gpu_cnt, P);
     copy_opt(c->p_pin, pd->pin_node, P, (int32_t)-1);
+    copy_opt(c->p_gpu_index, pd->gpu_index, P);
+    c->has_gpu_index = false;
+    for (int p = 0; p < P; ++p) {
+        const uint32_t w = c->p_gpu_index[p];
+        if (!w) continue;
+        c->has_gpu_index = true;
+        bool ended = false;                            // nibbles: 1 + device id, 0 ends the list; ids 0 .. SIMON_MAX_GPU_DEV - 1
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t nib = (w >> (4 * i)) & 15u;
+            if (!nib) ended = true;
+            else if (ended || nib > SIMON_MAX_GPU_DEV) return fail(c, SIMON_EINVAL, "pod %d: gpu_index 0x%x is not a packed device-id list", p, w);
+        }
+    }
     c->has_pin = false;
     for (int p = 0; p < P; ++p) {
         if (c->p_pin[p] >= c->N) return fail(c, SIMON_EINVAL, "pod %d: pin_node %d out of range", p, c->p_pin[p]);
@@ -1098,6 +1113,14 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     if (!c->staged || c->S <= 0) return fail(c, SIMON_ESTATE, "run_loaded: no scenarios loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     const int S = c->S, P = c->P;
+    // bit 1: also record the devices Reserve books for every placed GPU pod (only problems with GPU requests have any)
+    const bool want_slices = (want_placement & SIMON_WANT_GPU_SLICES) != 0 && c->has_gpu;
+    want_placement &= SIMON_WANT_PLACEMENT;
+    c->have_slices = false;
+    if (want_slices) {
+        HIP_TRY(c, c->d_gpu_slices.ensure((size_t)S * P));
+        HIP_TRY(c, hipMemsetAsync(c->d_gpu_slices.p, 0, (size_t)S * P * 8, c->stream));
+    }
     if (want_placement) HIP_TRY(c, c->d_place.ensure((size_t)S * P));
     int T = 0, slots = 0, variant_used = c->variant;
     bool table_used = false;
@@ -1132,6 +1155,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
             cold.N = c->N;
+            cold.gpu_slices = want_slices ? reinterpret_cast<unsigned long long*>(c->d_gpu_slices.p) : nullptr;
             cold.na_raw = c->has_na ? c->d_t_na.p : nullptr; cold.tt_raw = c->has_tt ? c->d_t_tt.p : nullptr; cold.add_raw = c->has_add ? c->d_t_add.p : nullptr;
             if (c->has_ranks) { cold.rk_pos = c->d_rk_pos.p; cold.rk_rank = c->d_node_rank.p; }
             if (c->rest) {
@@ -1148,7 +1172,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)
@@ -1219,7 +1243,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
                           c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p, c->d_used_vg.p,
                           want_placement ? c->d_place.p : nullptr, c->has_ranks ? c->d_node_rank.p : nullptr,
-                          c->has_ranks ? c->d_node_inv.p : nullptr, c->stream, c->err);
+                          c->has_ranks ? c->d_node_inv.p : nullptr, want_slices ? c->d_gpu_slices.p : nullptr, c->stream, c->err);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     }
@@ -1235,6 +1259,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     c->stats.lds_bytes = (int64_t)lds;
     c->have_results = true;
     c->have_placement = want_placement != 0;
+    c->have_slices = want_slices;
+    // generations 1 / 2 never see a GPU request (has_gpu routes the problem to generation 6 or the all-feature kernel)
     return SIMON_OK;
 }
 
@@ -1256,6 +1282,11 @@ int simon_fetch_results(simon_ctx* c, simon_batch_out* out) {
         if (!c->have_placement) return fail(c, SIMON_ESTATE, "fetch_results: the last run skipped placements");
         HIP_TRY(c, hipMemcpyAsync(out->placement, c->d_place.p, S * P * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    if (out->gpu_slices) {
+        if (c->have_slices) HIP_TRY(c, hipMemcpyAsync(out->gpu_slices, c->d_gpu_slices.p, S * P * 8, hipMemcpyDeviceToHost, c->stream));
+        else if (!c->has_gpu) memset(out->gpu_slices, 0, S * P * 8);      // no GPU request anywhere: nothing was ever booked
+        else return fail(c, SIMON_ESTATE, "fetch_results: the last run did not record GPU devices (SIMON_WANT_GPU_SLICES)");
+    }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -1274,12 +1305,24 @@ int simon_fetch_placement(simon_ctx* c, int32_t scenario, int32_t* placement) {
     return SIMON_OK;
 }
 
+int simon_fetch_gpu_slices(simon_ctx* c, int32_t scenario, uint64_t* slices) {
+    if (!c || !slices) return SIMON_EINVAL;
+    if (!c->have_results) return fail(c, SIMON_ESTATE, "fetch_gpu_slices: nothing has run");
+    if (scenario < 0 || scenario >= c->S) return fail(c, SIMON_EINVAL, "fetch_gpu_slices: scenario out of range");
+    if (!c->has_gpu) { memset(slices, 0, (size_t)c->P * 8); return SIMON_OK; }
+    if (!c->have_slices) return fail(c, SIMON_ESTATE, "fetch_gpu_slices: the last run did not record GPU devices (SIMON_WANT_GPU_SLICES)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(slices, c->d_gpu_slices.p + (size_t)scenario * c->P, (size_t)c->P * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIMON_OK;
+}
+
 int simon_run_batch(simon_ctx* c, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
                     simon_batch_out* out) {
     if (!c || !out) return SIMON_EINVAL;
     int rc = simon_load_scenarios(c, scen, S, orders, n_orders);
     if (rc) return rc;
-    rc = simon_run_loaded(c, out->placement != nullptr);
+    rc = simon_run_loaded(c, (out->placement ? SIMON_WANT_PLACEMENT : 0) | (out->gpu_slices ? SIMON_WANT_GPU_SLICES : 0));
     if (rc) return rc;
     return simon_fetch_results(c, out);
 }

@@ -33,7 +33,7 @@ struct PodRowC { int32_t sigcls, preset, gate, rest; };
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
     int32_t rk_stride;   // 0: cls_list = the pool's per-class node lists; N: per-scenario lists in rank order (simon_set_node_ranks)
-    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present
+    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present; bit 3: record TableCold::gpu_slices
     int32_t NZ;          // REST: topology keys that are NOT node-level (a term on one marks every position of the pod's domain)
     int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
@@ -61,6 +61,7 @@ struct TableCold {
     // allocatable and Requested at the start [N][8] (component 0 = ephemeral storage, 1.. = extended resources)
     const uint32_t *xsig, *xalloc, *i_xused;
     const int32_t* zdom;            // [NZ][N] domain of a node under a zone-like key (-1: no label)
+    unsigned long long* gpu_slices; // [S][P] by pod id: devices Reserve booked (simon_batch_out.gpu_slices), written when TableScalars::static_tables & 8
     const int32_t* gpu_cnt;         // [N]
     const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)
 };

@@ -196,8 +196,10 @@ __device__ __forceinline__ bool gpu_fits_t(const unsigned (&u)[8], int cnt, unsi
     }
     return got == num;
 }
-__device__ __forceinline__ void gpu_commit_t(unsigned (&u)[8], int cnt, unsigned tot, unsigned req, int num) {
-    if (req == 0u || num <= 0 || cnt <= 0) return;
+// Returns the booking as simon_batch_out.gpu_slices wants it: byte d = slices on device d (the gpu-index annotation the plugin writes,
+// pkg/type/open-gpu-share/utils/pod.go:117-127: ids ascending, one per slice).
+__device__ __forceinline__ unsigned long long gpu_commit_t(unsigned (&u)[8], int cnt, unsigned tot, unsigned req, int num) {
+    if (req == 0u || num <= 0 || cnt <= 0) return 0ull;
     if (num == 1) {                                       // tightest fit, lowest id on ties (:255-267)
         int cand = -1, cand_idle = 0;
 #pragma unroll
@@ -207,21 +209,24 @@ __device__ __forceinline__ void gpu_commit_t(unsigned (&u)[8], int cnt, unsigned
         }
 #pragma unroll
         for (int d = 0; d < 8; ++d) u[d] += (d == cand) ? req : 0u;
-        return;
+        return cand >= 0 ? 1ull << (8 * cand) : 0ull;
     }
     unsigned w[8];
     int got = 0;
+    unsigned long long slices = 0;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         w[d] = u[d];
         if (d >= cnt) continue;
         int idle = (int)tot - (int)w[d];
-        while (idle >= (int)req && got < num) { ++got; idle -= (int)req; w[d] += req; }
+        while (idle >= (int)req && got < num) { ++got; idle -= (int)req; w[d] += req; slices += 1ull << (8 * d); }
     }
     if (got == num) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) u[d] = w[d];
+        return slices;
     }
+    return 0ull;
 }
 
 // KQ: signatures per lane (1: K <= 64, 2: K <= 128).  HAS_PIN: the stream holds pinned pods (own instantiation: the extra
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
         return L;
     };
-    auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs, int xs) {
+    auto rest_assume_store = [&](const RestLoads& L, int pstar, int nrows, int rowv, int gs, int xs, int step) {
         const unsigned bit = 1u << (pstar & 15);
         unsigned short* xr = g_xm + (pstar >> 4);
         // node-level term: the pod's own position; a term on a zone-like key marks every position of the pod's domain (below)
@@ -776,7 +781,11 @@ __global__ __launch_bounds__(64) void table_kernel(
             const unsigned greq = (unsigned)__builtin_amdgcn_readlane((int)my_gsig.x, gs);
             const int gnum = __builtin_amdgcn_readlane((int)my_gsig.y, gs);
             unsigned u[8] = {L.ua.x, L.ua.y, L.ua.z, L.ua.w, L.ub.x, L.ub.y, L.ub.z, L.ub.w};
-            gpu_commit_t(u, L.gc, L.tot, greq, gnum);                     // Reserve (open-gpu-share.go:147-188), every lane alike
+            const unsigned long long booked = gpu_commit_t(u, L.gc, L.tot, greq, gnum);   // Reserve (open-gpu-share.go:147-188), every lane alike
+            if (__builtin_expect(sc.static_tables & 8, 0)) {              // the caller wants the devices (simon_batch_out.gpu_slices), by pod id
+                const int pid = __builtin_amdgcn_readfirstlane(order[step]);
+                if (lane == 0) cold->gpu_slices[(size_t)s * (size_t)P + (size_t)pid] = booked;
+            }
             if (lane == 0) {
                 *(uint4*)(g_gused + (size_t)pstar * 8) = make_uint4(u[0], u[1], u[2], u[3]);
                 *(uint4*)(g_gused + (size_t)pstar * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
@@ -1050,7 +1059,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 }
             }
             TPROF(9);                                                  // evaluation, patch, block key, summary / table stores
-            if (REST && __builtin_expect(rw != 0, 0)) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
+            if (REST && __builtin_expect(rw != 0, 0)) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs, i0 + il);
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // REST: term rows, GPU commit and GPU rows
         }

@@ -20,9 +20,11 @@ struct HostInputs {
     std::vector<int64_t> scalar_alloc, i_scalar_req, gpu_mem_total, i_gpu_used;
     std::vector<int32_t> gpu_cnt, topo_dom, topo_n_dom;
     bool has_gpu = false;            // derived per staging: has_gpu_nodes, or some pod requests GPU memory
+    bool has_gpu_index = false;      // some pod arrives with a gpu-index annotation (simon_pods_soa.gpu_index)
     bool has_gpu_nodes = false;      // the loaded pool carries GPU arrays (simon_load_nodes)
     std::vector<int64_t> p_req_cpu, p_req_mem, p_req_eph, p_nz_cpu, p_nz_mem, p_scalar, p_gpu_mem;
     std::vector<int32_t> p_cls, p_preset, p_gate, p_gpu_cnt, p_pin;
+    std::vector<uint32_t> p_gpu_index;   // packed preset device ids (simon_pods_soa.gpu_index), 0 = none
     bool has_pin = false;         // some pod is pinned to one node (simon_pods_soa.pin_node)
     std::vector<uint64_t> static_mask;
     std::vector<uint8_t> static_reason;
@@ -77,7 +79,8 @@ struct WidePod {
     uint32_t flags;  // kPod* bits
     int32_t sig;     // request signature: row of the (signature, node) table
     int32_t pin;     // >= 0: the only node the pod's node affinity admits (DaemonSet pods); -1: none
-    uint32_t pad[5];
+    uint32_t gpu_index;   // packed device ids of the gpu-index annotation the pod arrives with (simon_pods_soa.gpu_index), 0 = none
+    uint32_t pad[4];
 };
 static_assert(sizeof(WidePod) == 128, "WidePod must be 128 bytes");
 
@@ -149,6 +152,8 @@ struct WideCold {
     // per-scenario nodeTree order (simon_set_node_ranks), rows of the WHOLE batch [S_total][N]: rank of a pool node / node of a
     // rank; null = pool order.  Row of this launch's scenario s: (scen_base + s) * N
     const int32_t* node_rank; const int32_t* node_inv;
+    // devices Reserve booked for every placed GPU pod (simon_batch_out.gpu_slices), rows of the WHOLE batch [S_total][P]; null = not recorded
+    uint64_t* gpu_slices;
 };
 
 struct WideArgs {
@@ -229,8 +234,8 @@ struct WideDevice {
 int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string& err);
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t* h_perm_unused, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
-             int64_t* d_used_vg, int32_t* d_place, const int32_t* d_node_rank, const int32_t* d_node_inv, hipStream_t st,
-             std::string& err);
+             int64_t* d_used_vg, int32_t* d_place, const int32_t* d_node_rank, const int32_t* d_node_inv, uint64_t* d_gpu_slices,
+             hipStream_t st, std::string& err);
 int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
                  uint16_t* fail_codes, int32_t max_failed, int T, const int32_t* d_rank_row, const int32_t* d_inv_row, hipStream_t st,
                  std::string& err);

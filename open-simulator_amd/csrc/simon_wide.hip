@@ -123,8 +123,9 @@ __device__ __forceinline__ long long divq(long long num, long long den) {
 // GpuNodeInfo.AllocateGpuId, pkg/type/open-gpu-share/cache/gpunodeinfo.go:232-290, split into the feasibility
 // question Filter asks (open-gpu-share.go:74-78) and the commit Reserve performs (:147-188): the same walk, so no
 // device-id list has to be materialised.  used: this node's 8 device counters.
-__device__ bool gpu_feasible(const int64_t* used, int cnt, int64_t node_total, int64_t req_mem, int req_num) {
+__device__ bool gpu_feasible(const int64_t* used, int cnt, int64_t node_total, int64_t req_mem, int req_num, uint32_t preset) {
     if (req_mem <= 0 || req_num <= 0 || cnt <= 0) return false;
+    if (preset) return true;                              // the pod arrives with a valid gpu-index annotation: returned as is (:247-253)
     const int64_t dev_total = node_total / cnt;          // gpunodeinfo.go:40
     int64_t u[SIMON_MAX_GPU_DEV];                         // the node's row is 64 contiguous bytes: all loads in flight at once
 #pragma unroll
@@ -153,10 +154,22 @@ __device__ int64_t gpu_max_idle(const int64_t* used, int cnt, int64_t node_total
     for (int d = 1; d < cnt; ++d) { const int64_t idle = dev_total - used[d]; m = idle > m ? idle : m; }
     return m;
 }
-// Reserve (open-gpu-share.go:147-188) on a register copy of the node's row (u[d] with static indices only).
-__device__ __forceinline__ void gpu_commit_regs(int64_t (&u)[SIMON_MAX_GPU_DEV], int cnt, int64_t node_total, int64_t req_mem, int req_num) {
-    if (req_mem <= 0 || req_num <= 0 || cnt <= 0) return;
+// Reserve (open-gpu-share.go:147-188) on a register copy of the node's row (u[d] with static indices only).  Returns the booking
+// as simon_batch_out.gpu_slices wants it: byte d = slices on device d (the gpu-index annotation, pod.go:117-127).
+__device__ __forceinline__ uint64_t gpu_commit_regs(int64_t (&u)[SIMON_MAX_GPU_DEV], int cnt, int64_t node_total, int64_t req_mem, int req_num,
+                                                    uint32_t preset) {
+    if (req_mem <= 0 || req_num <= 0 || cnt <= 0) return 0;
     const int64_t dev_total = node_total / cnt;
+    uint64_t slices = 0;
+    if (preset) {                                         // the listed devices, whatever is idle; ids the node lacks are skipped (:127-135)
+        for (uint32_t w = preset; w & 15u; w >>= 4) {
+            const int id = (int)(w & 15u) - 1;
+#pragma unroll
+            for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d)
+                if (d == id && d < cnt) { u[d] += req_mem; slices += 1ull << (8 * d); }
+        }
+        return slices;
+    }
     if (req_num == 1) {                                   // tightest fit, lowest id on ties (:255-267)
         int cand = -1;
         int64_t cand_mem = 0;
@@ -167,7 +180,7 @@ __device__ __forceinline__ void gpu_commit_regs(int64_t (&u)[SIMON_MAX_GPU_DEV],
         }
 #pragma unroll
         for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) u[d] += (d == cand) ? req_mem : 0;
-        return;
+        return cand >= 0 ? 1ull << (8 * cand) : 0ull;
     }
     int64_t w[SIMON_MAX_GPU_DEV];                         // two-pointer greedy (:268-287) on a copy, kept only when it completes
     int got = 0;
@@ -176,12 +189,14 @@ __device__ __forceinline__ void gpu_commit_regs(int64_t (&u)[SIMON_MAX_GPU_DEV],
         w[d] = u[d];
         if (d >= cnt) continue;
         int64_t idle = dev_total - w[d];
-        while (idle >= req_mem && got < req_num) { ++got; idle -= req_mem; w[d] += req_mem; }
+        while (idle >= req_mem && got < req_num) { ++got; idle -= req_mem; w[d] += req_mem; slices += 1ull << (8 * d); }
     }
     if (got == req_num) {
 #pragma unroll
         for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) u[d] = w[d];
+        return slices;
     }
+    return 0;
 }
 __device__ __forceinline__ bool in_set(const WideArgs& A, int set, int j) {
     if (set < 0) return true;
@@ -470,7 +485,7 @@ __device__ __forceinline__ unsigned rest_code(const WideArgs& A, const NodeView&
     // Open-Gpu-Share.Filter, pkg/simulator/plugin/open-gpu-share.go:51-81
     if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0) {
         const long long gt = COLD(A)->gpu_mem_total[j];
-        if (gt < p.gpu_mem || !gpu_feasible(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], gt, p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt))
+        if (gt < p.gpu_mem || !gpu_feasible(v.gpu() + (size_t)j * SIMON_MAX_GPU_DEV, COLD(A)->gpu_cnt[j], gt, p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt, p.gpu_index))
             return SIMON_FAIL_GPUSHARE;
     }
     return SIMON_FAIL_NONE;
@@ -931,7 +946,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             for (int u = 0; u < kUT; ++u)
                                 if (act[u] && local_eval<false>(A, v, p, jn[u]).code != 0u) act[u] = false;
                         }
-                        if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.gpu_cnt == 1) {                    // one device: the summary answers
+                        if (((A.flags & kArgGpu) != 0u) && p.gpu_mem > 0 && p.gpu_cnt == 1 && p.gpu_index == 0u) {   // one device: the summary answers
                             long long gm[kUT];
 #pragma unroll
                             for (int u = 0; u < kUT; ++u) gm[u] = v.gmax()[(unsigned)jn[u]];
@@ -945,7 +960,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                             for (int u = 0; u < kUT; ++u)
                                 if (act[u] && (gt[u] < p.gpu_mem ||
-                                               !gpu_feasible(v.gpu() + (size_t)jn[u] * SIMON_MAX_GPU_DEV, gc[u], gt[u], p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt)))
+                                               !gpu_feasible(v.gpu() + (size_t)jn[u] * SIMON_MAX_GPU_DEV, gc[u], gt[u], p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt, p.gpu_index)))
                                     act[u] = false;
                         }
 #pragma unroll
@@ -1243,7 +1258,8 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             X.re += p.req_eph;
 #pragma unroll
             for (int k = 0; k < SIMON_MAX_SCALAR; ++k) X.sr[k] += p.scalar[k];
-            if (gpu_pod) gpu_commit_regs(gu, g_cnt, g_total, p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt);
+            uint64_t g_slices = 0;
+            if (gpu_pod) g_slices = gpu_commit_regs(gu, g_cnt, g_total, p.gpu_mem, p.gpu_cnt > 64 ? 64 : p.gpu_cnt, p.gpu_index);
             if (use_tab && lane < A.n_sigs)
                 tab[(size_t)lane * nstride + j] = fit_bits(A, q0, L, X) ? 0 : (unsigned char)(1u + base_score(q0, L));
             SIMON_PROF(10);
@@ -1266,6 +1282,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         }
                     }
                     v.gmax()[j] = m;
+                    if (COLD(A)->gpu_slices) COLD(A)->gpu_slices[(size_t)(A.scen_base + s) * P + pid] = g_slices;
                 }
                 if (place) place[pid] = j;
                 if ((p.flags & kPodLocal) && p.preset < 0) (void)local_eval<true>(A, v, p, j);      // LocalPlugin.Bind (open-local.go:180-253)
@@ -1577,6 +1594,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         bool zero = r.req_cpu == 0 && r.req_mem == 0 && r.req_eph == 0;
         for (int k = 0; k < in.K; ++k) { r.scalar[k] = in.p_scalar[(size_t)k * P + p]; zero = zero && r.scalar[k] == 0; }
         r.cls = in.p_cls[p]; r.preset = in.p_preset[p]; r.gate = in.p_gate[p]; r.gpu_cnt = in.p_gpu_cnt[p];
+        r.gpu_index = in.p_gpu_index.empty() ? 0u : in.p_gpu_index[p];
         r.pin = in.p_pin.empty() ? -1 : in.p_pin[p];
         const int c = r.cls;
         auto some = [&](const std::vector<int32_t>& off) { return off[c + 1] > off[c]; };
@@ -1653,7 +1671,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
 // chunk is reused by the next one; kernels on one stream serialise).
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t*, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,
-             int64_t* d_used_vg, int32_t* d_place, const int32_t* d_node_rank, const int32_t* d_node_inv, hipStream_t st,
+             int64_t* d_used_vg, int32_t* d_place, const int32_t* d_node_rank, const int32_t* d_node_inv, uint64_t* d_gpu_slices, hipStream_t st,
              std::string& err) {
     if ((long long)max_n > (long long)kMaxIter * T) { err = "wide kernel: more than 32 nodes per lane"; return SIMON_ERANGE; }
     const size_t per = state_bytes_per_scenario(w, in);
@@ -1668,6 +1686,7 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     fill_args(w, in, a, c);
     a.mask_lanes = w.mask_lanes;
     c.node_rank = d_node_rank; c.node_inv = d_node_inv;
+    c.gpu_slices = d_gpu_slices;
     if (d_node_rank && d_node_inv) a.flags |= kArgRanked;
     a.orders = d_orders;
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;

@@ -83,9 +83,26 @@ def _gpu_annotations(pod: dict) -> Tuple[int, int]:
             cnt = int(str(a[k8s.GPU_COUNT]))
         except ValueError:
             cnt = 0
-    if mem > 0 and cnt == 0:
-        cnt = 1
-    return mem, cnt
+    # no defaulting: without a gpu-count annotation reqGpuNum is 0 and AllocateGpuId finds nothing (gpunodeinfo.go:238-240) -- a pod that
+    # asks for gpu-mem alone is unschedulable in the reference
+    return mem, cnt if cnt >= 0 else 0
+
+
+def gpu_index_annotation(pod: dict):
+    """GetGpuIdFromAnnotation + GpuIdStrToIntList (pkg/type/open-gpu-share/utils/pod.go:35-53,100-115): the device ids of an
+    alibabacloud.com/gpu-index annotation the pod ARRIVES with ("2", "0-0-1"), or None when it has none or an invalid one (the
+    reference logs a warning and allocates normally, gpunodeinfo.go:247-253)."""
+    a = pod["metadata"].get("annotations") or {}
+    text = a.get(k8s.GPU_INDEX)
+    if not text:
+        return None
+    ids = []
+    for part in str(text).split("-"):
+        try:
+            ids.append(int(part))                     # strconv.Atoi: optional sign, decimal digits
+        except ValueError:
+            return None
+    return ids or None
 
 
 def _term_namespaces(pod: dict, term: dict) -> Tuple[str, ...]:
@@ -368,6 +385,16 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     gpu = [_gpu_annotations(p) for p in tpods]
     gpu_mem = np.array([g[0] for g in gpu], np.int64)[tmpl_of]
     gpu_cnt = np.array([g[1] for g in gpu], np.int32)[tmpl_of]
+    gpu_index = np.zeros(len(tpods), np.uint32)
+    for t, p in enumerate(tpods):
+        ids = gpu_index_annotation(p)
+        if ids is None or gpu[t][0] <= 0:
+            continue
+        try:
+            gpu_index[t] = capi.pack_gpu_index(ids)
+        except ValueError as e:
+            raise Unsupported(f"pod {p['metadata'].get('name')}: {e}") from None
+    gpu_index = gpu_index[tmpl_of]
     preset = np.array([node_index.get(p["spec"].get("nodeName"), -1) if p["spec"].get("nodeName") else -1 for p in pods], np.int32)
     for i, p in enumerate(pods):
         if p["spec"].get("nodeName") and preset[i] < 0:
@@ -831,6 +858,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         gate_node=np.array(gates, np.int32) if gates is not None and any(g >= 0 for g in gates) else None,
         pin_node=pin if (pin >= 0).any() else None,
         gpu_mem=gpu_mem if gpu_mem.any() else None, pod_gpu_cnt=gpu_cnt if gpu_mem.any() else None,
+        gpu_index=gpu_index if gpu_index.any() else None,
         n_pod_classes=Cp, n_node_classes=Cn, static_mask=None if static_ok.all() else static_mask,
         static_reason=None if static_ok.all() else static_reason, simon_raw=simon_raw, const_score=const, **prob_kw).normalise()
     return Flat(problem=prob, node_names=node_names,

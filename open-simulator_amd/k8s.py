@@ -24,6 +24,10 @@ DEFAULT_MEMORY_REQUEST = 200 * 1024 * 1024
 
 GPU_MEM = "alibabacloud.com/gpu-mem"            # pkg/type/open-gpu-share/utils/const.go
 GPU_COUNT = "alibabacloud.com/gpu-count"
+GPU_INDEX = "alibabacloud.com/gpu-index"        # device ids of a GPU pod, written at Reserve (utils/pod.go:117-127)
+GPU_ASSUME_TIME = "alibabacloud.com/assume-time"
+GPU_MODEL = "alibabacloud.com/gpu-card-model"
+ANNO_NODE_GPU_SHARE = "simon/node-gpu-share"      # pkg/type/const.go
 
 
 # ---------------------------------------------------------------------------------------------

@@ -24,15 +24,15 @@ class HipEngine:
     def __init__(self, device_id: int = 0):
         self.device_id = device_id
 
-    def run(self, prob: capi.Problem, scen, orders, want_placement=True, node_ranks=None) -> capi.BatchResult:
+    def run(self, prob: capi.Problem, scen, orders, want_placement=True, node_ranks=None, want_gpu_slices=False) -> capi.BatchResult:
         with capi.Context(self.device_id) as ctx:
             ctx.load_problem(prob)
             if node_ranks is None:
-                return ctx.run_batch(scen, orders, want_placement)
+                return ctx.run_batch(scen, orders, want_placement, want_gpu_slices)
             ctx.load_scenarios(scen, orders)
             ctx.set_node_ranks(node_ranks)            # per-scenario nodeTree order (clusters with several zones)
-            ctx.run_loaded(want_placement)
-            return ctx.fetch(want_placement)
+            ctx.run_loaded(want_placement, want_gpu_slices)
+            return ctx.fetch(want_placement, want_gpu_slices)
 
     def explain(self, prob: capi.Problem, n_nodes: int, order, max_failed: int):
         with capi.Context(self.device_id) as ctx:
@@ -113,9 +113,15 @@ def _check_prefix_order(pool: List[dict], counts: Sequence[int]):
                                  "size separately (simulate()) or route to the Go path")
 
 
-def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict[int, str]) -> SimulateResult:
+def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict[int, str], gpu_slices: Optional[np.ndarray] = None):
+    """SimulateResult from one scenario's placement row (+ its simon_batch_out.gpu_slices row): bound pods carry Spec.NodeName and
+    phase Running, GPU pods the annotations GpuSharePlugin.Reserve / Bind write (GetUpdatedPodAnnotationSpec,
+    pkg/type/open-gpu-share/utils/pod.go:117-127).  Returns (result, pods per node, GPU pods per (node, device))."""
+    import time
     res = SimulateResult()
     per_node: List[List[dict]] = [[] for _ in range(n_nodes)]
+    per_dev: Dict[int, Dict[int, List[tuple]]] = {}                  # node -> device -> [(pod ref, slices, gpu-mem per slice)]
+    gmem = flat.problem.gpu_mem
     for pid, j in enumerate(placement.tolist()):
         if j == capi.GATED:
             continue
@@ -126,8 +132,55 @@ def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict
         bound = _public(pod)
         bound["spec"]["nodeName"] = flat.node_names[j]               # SimonPlugin.BindPodToNode (plugin/simon.go:104-121)
         bound["status"] = {"phase": "Running"}
+        if gpu_slices is not None and gmem is not None and gmem[pid] > 0 and not pod["spec"].get("nodeName"):
+            ids = capi.gpu_ids_of(int(gpu_slices[pid]))
+            preset = fl.gpu_index_annotation(pod)
+            text = "-".join(str(i) for i in (preset if preset else ids))   # a pod that arrived with ids keeps its own string
+            bound["metadata"]["annotations"] = dict(bound["metadata"].get("annotations") or {},
+                                                    **{k8s.GPU_INDEX: text, k8s.GPU_ASSUME_TIME: str(time.time_ns())})
+            for d in sorted(set(ids)):
+                per_dev.setdefault(j, {}).setdefault(d, []).append((f"{bound['metadata'].get('namespace', '')}:{bound['metadata']['name']}",
+                                                                    ids.count(d), int(gmem[pid])))
         per_node[j].append(bound)
-    return res, per_node
+    return res, per_node, per_dev
+
+
+def _mi(n_bytes: int) -> str:
+    """resource.ParseQuantity(fmt.Sprintf("%dMi", bytes/(1024*1024))) marshalled back: the canonical form of a BinarySI quantity."""
+    mi = int(n_bytes) // (1024 * 1024)
+    if mi == 0:
+        return "0"
+    for unit, shift in (("Ti", 20), ("Gi", 10)):
+        if mi % (1 << shift) == 0:
+            return f"{mi >> shift}{unit}"
+    return f"{mi}Mi"
+
+
+def _gpu_node_status(node: dict, per_dev: Dict[int, List[tuple]]) -> dict:
+    """What GpuSharePlugin.Reserve leaves on a node it booked a GPU pod on (pkg/simulator/plugin/open-gpu-share.go:160-186):
+    annotation simon/node-gpu-share = NodeGpuInfo as JSON (ExportGpuNodeInfoAsNodeGpuInfo, gpunodeinfo.go:345-368; the reference
+    lists a device's pods in Go map order, here in scheduling order) and allocatable gpu-count = devices not yet full."""
+    node = copy.deepcopy(node)
+    cap = node.get("status", {}).get("capacity") or {}
+    cnt = int(fl.parse_quantity(str(cap[k8s.GPU_COUNT])).int_value()) if k8s.GPU_COUNT in cap else 0
+    total = fl.parse_quantity(str(cap[k8s.GPU_MEM])).int_value() if k8s.GPU_MEM in cap else 0
+    per = total // cnt if cnt else 0
+    devs, allocatable, n_pods = {}, cnt, 0
+    for d in range(cnt):
+        pods = per_dev.get(d, [])
+        used = sum(k * mem for _, k, mem in pods)
+        if used >= per:
+            allocatable -= 1
+        devs[str(d)] = {"PodList": [ref for ref, _, _ in pods] or None, "GpuTotalMemory": _mi(per), "GpuUsedMemory": _mi(used)}
+        n_pods += len(pods)
+    info = {"DevsBrief": devs, "GpuCount": cnt, "GpuAllocatable": allocatable,
+            "GpuModel": (node["metadata"].get("labels") or {}).get(k8s.GPU_MODEL, "N/A"), "GpuTotalMemory": _mi(total), "NumPods": n_pods}
+    import json
+    md = node["metadata"]
+    md["annotations"] = dict(md.get("annotations") or {}, **{k8s.ANNO_NODE_GPU_SHARE: json.dumps(info, separators=(",", ":"))})
+    alloc = node["status"].setdefault("allocatable", {})
+    alloc[k8s.GPU_COUNT] = str(allocatable)
+    return node
 
 
 def _public(pod: dict) -> dict:
@@ -154,7 +207,8 @@ def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine
     P = len(pods)
     scen = np.array([[len(nodes), 0]], np.int32)
     orders = np.arange(P, dtype=np.int32)[None, :]
-    out = engine.run(flat.problem, scen, orders)
+    want_gpu = flat.problem.gpu_mem is not None
+    out = engine.run(flat.problem, scen, orders, want_gpu_slices=True) if want_gpu else engine.run(flat.problem, scen, orders)
     reasons = {}
     if out.unscheduled[0] > 0:
         nf, failed, codes = engine.explain(flat.problem, len(nodes), orders[0], int(out.unscheduled[0]))
@@ -162,8 +216,8 @@ def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine
             ns, name = flat.pod_refs[pid]
             reasons[pid] = fiterror.unscheduled_reason(ns, name, row, node_names=flat.node_names,
                                                        static_reasons=flat.static_reasons, scalar_names=flat.scalar_names)
-    res, per_node = _unflatten(flat, out.placement[0], len(nodes), reasons)
-    res.node_status = [{"node": copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
+    res, per_node, per_dev = _unflatten(flat, out.placement[0], len(nodes), reasons, out.gpu_slices[0] if want_gpu and out.gpu_slices is not None else None)
+    res.node_status = [{"node": _gpu_node_status(n, per_dev[j]) if j in per_dev else copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
     return res
 
 
@@ -223,7 +277,11 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
     P = len(pods)
     scen = np.array([[len(base) + k, 0] for k in counts], np.int32)
     orders = np.arange(P, dtype=np.int32)[None, :]
-    out = engine.run(flat.problem, scen, orders) if node_ranks is None else engine.run(flat.problem, scen, orders, node_ranks=node_ranks)
+    want_gpu = flat.problem.gpu_mem is not None
+    kw = {"want_gpu_slices": True} if want_gpu else {}
+    if node_ranks is not None:
+        kw["node_ranks"] = node_ranks
+    out = engine.run(flat.problem, scen, orders, **kw)
     pc, pm = np.cumsum(flat.problem.alloc_cpu), np.cumsum(flat.problem.alloc_mem)
     cpu_pct = [occupancy_pct(int(out.used_cpu[s]), int(pc[scen[s, 0] - 1])) for s in range(len(counts))]
     mem_pct = [occupancy_pct(int(out.used_mem[s]) * 1000, int(pm[scen[s, 0] - 1]) * 1000) for s in range(len(counts))]
@@ -239,8 +297,8 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
     result = None
     if best is not None:
         n = int(scen[best, 0])
-        res, per_node = _unflatten(flat, out.placement[best], n, {})
-        res.node_status = [{"node": copy.deepcopy(pool[j]), "pods": per_node[j]} for j in range(n)]
+        res, per_node, per_dev = _unflatten(flat, out.placement[best], n, {}, out.gpu_slices[best] if want_gpu and out.gpu_slices is not None else None)
+        res.node_status = [{"node": _gpu_node_status(pool[j], per_dev[j]) if j in per_dev else copy.deepcopy(pool[j]), "pods": per_node[j]} for j in range(n)]
         result = res
     return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
 
@@ -257,7 +315,9 @@ def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, m
         nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
         flat = fl.flatten(nodes, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []),
                           storage_classes=_storage_classes(cluster, apps), image_total=len(nodes), node_arrival_order=arrival)
-        out = engine.run(flat.problem, np.array([[len(nodes), 0]], np.int32), np.arange(len(pods), dtype=np.int32)[None, :])
+        want_gpu = flat.problem.gpu_mem is not None
+        out = engine.run(flat.problem, np.array([[len(nodes), 0]], np.int32), np.arange(len(pods), dtype=np.int32)[None, :],
+                         **({"want_gpu_slices": True} if want_gpu else {}))
         uns.append(int(out.unscheduled[0]))
         cpu_pct.append(occupancy_pct(int(out.used_cpu[0]), int(flat.problem.alloc_cpu.sum())))
         mem_pct.append(occupancy_pct(int(out.used_mem[0]) * 1000, int(flat.problem.alloc_mem.sum()) * 1000))
@@ -272,8 +332,8 @@ def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, m
     result = None
     if best is not None:
         flat, out, nodes = kept[best]
-        res, per_node = _unflatten(flat, out.placement[0], len(nodes), {})
-        res.node_status = [{"node": copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
+        res, per_node, per_dev = _unflatten(flat, out.placement[0], len(nodes), {}, out.gpu_slices[0] if out.gpu_slices is not None else None)
+        res.node_status = [{"node": _gpu_node_status(n, per_dev[j]) if j in per_dev else copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
         result = res
     return SweepResult(list(counts), uns, cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
 

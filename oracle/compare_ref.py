@@ -182,9 +182,9 @@ def compare_case(case, ref_res, engine):
 class OracleEngine:
     """The C oracle behind the engine interface of simulate.py."""
 
-    def run(self, prob, scen, orders, want_placement=True, node_ranks=None):
+    def run(self, prob, scen, orders, want_placement=True, node_ranks=None, want_gpu_slices=False):
         import oracle_lib
-        return oracle_lib.run(prob, scen, orders, want_placement, node_ranks=node_ranks)
+        return oracle_lib.run(prob, scen, orders, want_placement, node_ranks=node_ranks, want_gpu_slices=want_gpu_slices)
 
     def explain(self, prob, n_nodes, order, max_failed):
         import oracle_lib

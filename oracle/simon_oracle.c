@@ -75,6 +75,7 @@ typedef struct {
     int64_t req_cpu, req_mem, req_eph, nz_cpu, nz_mem, gpu_mem;
     int64_t scalar[SIMON_MAX_SCALAR];
     int32_t cls, preset, gate, gpu_cnt, pin;
+    uint32_t gpu_index;   /* packed preset device ids (include/simon_hip.h: simon_pods_soa.gpu_index) */
 } pod_t;
 
 static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
@@ -91,6 +92,7 @@ static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
     r.gpu_mem = pd->gpu_mem ? pd->gpu_mem[p] : 0;
     r.gpu_cnt = pd->gpu_cnt ? pd->gpu_cnt[p] : 0;
     r.pin = pd->pin_node ? pd->pin_node[p] : -1;
+    r.gpu_index = pd->gpu_index ? pd->gpu_index[p] : 0u;
     return r;
 }
 
@@ -101,11 +103,16 @@ static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
 /* (0 = not found) and their device ids (duplicates allowed for multi-GPU pods).                 */
 /* ------------------------------------------------------------------------------------------- */
 static int gpu_allocate(const simon_nodes_soa* nd, const int64_t* used /*[8]*/, int j, int64_t req_mem,
-                        int32_t req_num, int32_t* ids /*[>= req_num]*/) {
+                        int32_t req_num, uint32_t preset, int32_t* ids /*[>= max(req_num, 8)]*/) {
     if (req_mem <= 0 || req_num <= 0) return 0;            /* :238-240 */
     int cnt = nd->gpu_cnt ? nd->gpu_cnt[j] : 0;
     if (cnt <= 0) return 0;                                /* len(availableGpus) <= 0, :243-245 */
     if (cnt > SIMON_MAX_GPU_DEV) cnt = SIMON_MAX_GPU_DEV;
+    if (preset) {                                          /* the pod arrives with a valid gpu-index annotation: returned as is, :247-253 */
+        int got = 0;
+        for (uint32_t w = preset; (w & 15u) && got < 8; w >>= 4) ids[got++] = (int)(w & 15u) - 1;
+        return got;
+    }
     int64_t dev_total = nd->gpu_mem_total[j] / nd->gpu_cnt[j];
     int64_t idle[SIMON_MAX_GPU_DEV];
     for (int d = 0; d < cnt; d++) idle[d] = dev_total - used[d];
@@ -371,7 +378,7 @@ static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables*
         if (node_total < p->gpu_mem) return SIMON_FAIL_GPUSHARE;                  /* :64-67 */
         int32_t ids[64];
         int32_t num = p->gpu_cnt > 64 ? 64 : p->gpu_cnt;
-        if (!gpu_allocate(nd, &s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV], j, p->gpu_mem, num, ids))
+        if (!gpu_allocate(nd, &s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV], j, p->gpu_mem, num, p->gpu_index, ids))
             return SIMON_FAIL_GPUSHARE;                                           /* :74-78 */
     }
     return SIMON_FAIL_NONE;
@@ -409,8 +416,9 @@ static void la_ba(const simon_nodes_soa* nd, const state_t* s, const pod_t* p, i
  * counters the InterPodAffinity / PodTopologySpread PreFilter+PreScore would rebuild from
  * NodeInfo.Pods every cycle: interpodaffinity/filtering.go:166-239, scoring.go:87-131,
  * podtopologyspread/filtering.go:253-268, scoring.go:129-160) */
-static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, state_t* s, const pod_t* p, int j,
-                    int with_gpu) {
+static uint64_t add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, state_t* s, const pod_t* p, int j,
+                        int with_gpu) {
+    uint64_t slices = 0;   /* byte d = gpu-mem slices booked on device d (simon_batch_out.gpu_slices) */
     int N = nd->n_nodes, K = nd->n_scalar;
     s->req_cpu[j] += p->req_cpu; s->req_mem[j] += p->req_mem; s->req_eph[j] += p->req_eph;
     for (int k = 0; k < K; k++) s->scalar_req[(size_t)k * N + j] += p->scalar[k];
@@ -437,8 +445,13 @@ static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, sta
     if (with_gpu && p->gpu_mem > 0) {
         int32_t ids[64];
         int32_t num = p->gpu_cnt > 64 ? 64 : p->gpu_cnt;
-        int got = gpu_allocate(nd, &s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV], j, p->gpu_mem, num, ids);
-        for (int i = 0; i < got; i++) s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + ids[i]] += p->gpu_mem;
+        int got = gpu_allocate(nd, &s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV], j, p->gpu_mem, num, p->gpu_index, ids);
+        int cnt = nd->gpu_cnt[j] > SIMON_MAX_GPU_DEV ? SIMON_MAX_GPU_DEV : nd->gpu_cnt[j];
+        for (int i = 0; i < got; i++) {
+            if (ids[i] >= cnt) continue;                   /* a preset id the node lacks: GpuNodeInfo.addOrUpdatePod skips it, :127-135 */
+            s->gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + ids[i]] += p->gpu_mem;
+            slices += 1ull << (8 * ids[i]);
+        }
     }
     const simon_local_spec* lsp = with_gpu ? local_spec_of(tb, p->cls) : NULL;   /* LocalPlugin.Bind, open-local.go:180-253 */
     if (lsp) {
@@ -448,6 +461,7 @@ static void add_pod(const simon_nodes_soa* nd, const simon_class_tables* tb, sta
             for (int k = 0; k < lu.n_dev; k++) s->dev_alloc[j] |= 1 << lu.dev_idx[k];
         }
     }
+    return slices;
 }
 
 /* InterPodAffinity.Score raw value of one node (interpodaffinity/scoring.go:87-131,211-236) */
@@ -669,9 +683,10 @@ int simon_oracle_score_pod_after(const simon_nodes_soa* nodes, const simon_pods_
  * reach the cache via addPodToCache (V/eventhandlers.go:223-236 -> AddPod). */
 static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, const simon_class_tables* tb,
                         int n, const int32_t* order, int32_t* unscheduled, int64_t* used_cpu, int64_t* used_mem, int64_t* used_vg,
-                        int32_t* placement, int explain, int32_t* failed_pods, uint16_t* fail_codes,
+                        int32_t* placement, uint64_t* gpu_slices, int explain, int32_t* failed_pods, uint16_t* fail_codes,
                         int32_t max_failed, int32_t* n_failed_out) {
     int P = pd->n_pods, K = nd->n_scalar, T = tb ? tb->n_terms : 0;
+    if (gpu_slices) memset(gpu_slices, 0, (size_t)P * 8);
     if (n < 0 || n > nd->n_nodes) return SIMON_EINVAL;
     state_t s;
     state_init(&s, nd, tb);
@@ -698,8 +713,9 @@ static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, con
             if (placement) placement[pid] = SIMON_UNSCHEDULED;
             continue;
         }
-        add_pod(nd, tb, &s, &p, j, 1);
+        uint64_t sl = add_pod(nd, tb, &s, &p, j, 1);
         if (placement) placement[pid] = j;
+        if (gpu_slices) gpu_slices[pid] = sl;
     }
     int64_t uc = 0, um = 0, uv = 0;
     for (int j = 0; j < n; j++) {
@@ -736,7 +752,8 @@ int simon_oracle_run_ranked(const simon_nodes_soa* nodes, const simon_pods_soa* 
         const int32_t* ord = orders ? orders + (size_t)scen[s].order_id * P : NULL;
         int explain = (failed_pods && fail_codes && s == explain_scenario);
         int rc = run_scenario(nodes, pods, tables, scen[s].n_nodes, ord, &out->unscheduled[s], &out->used_cpu[s],
-                              &out->used_mem[s], out->used_vg ? &out->used_vg[s] : NULL, out->placement ? out->placement + (size_t)s * P : NULL, explain,
+                              &out->used_mem[s], out->used_vg ? &out->used_vg[s] : NULL, out->placement ? out->placement + (size_t)s * P : NULL,
+                              out->gpu_slices ? out->gpu_slices + (size_t)s * P : NULL, explain,
                               failed_pods, fail_codes, max_failed, n_failed_out);
         g_node_rank = NULL;
         if (rc) return rc;

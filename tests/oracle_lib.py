@@ -50,14 +50,14 @@ def load():
     return lib
 
 
-def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0, node_ranks=None):
+def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0, node_ranks=None, want_gpu_slices=False):
     """Run scenarios on the oracle; returns BatchResult (+ (n_failed, failed_pods, codes) when explaining).
     Thread-safe without node_ranks (the ranked entry keeps the current scenario's ranks in a global)."""
     lib = load()
     prob.normalise()
     scen = capi.scenarios_array(scen)
     orders = np.ascontiguousarray(orders, np.int32).reshape(-1, prob.n_pods)
-    res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement)
+    res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement, want_gpu_slices)
     out = res.c_out()
     n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
     ranks = None
@@ -141,7 +141,7 @@ def min_plan(prob: capi.Problem, scen, res: capi.BatchResult, max_cpu=100, max_m
     return plan
 
 
-def run_threaded(prob: capi.Problem, scen, orders, want_placement=True, threads=None) -> capi.BatchResult:
+def run_threaded(prob: capi.Problem, scen, orders, want_placement=True, threads=None, want_gpu_slices=False) -> capi.BatchResult:
     """The oracle over many scenarios, one scenario per task on `threads` host threads (the C call releases the GIL;
     scenarios are independent).  Same result layout as run()."""
     import os
@@ -150,10 +150,12 @@ def run_threaded(prob: capi.Problem, scen, orders, want_placement=True, threads=
     prob.normalise()
     scen = capi.scenarios_array(scen)
     threads = threads or host_threads()
-    res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement)
+    res = capi.BatchResult.alloc(len(scen), prob.n_pods, want_placement, want_gpu_slices)
 
     def one(i):
-        r = run(prob, scen[[i]], orders, want_placement)
+        r = run(prob, scen[[i]], orders, want_placement, want_gpu_slices=want_gpu_slices)
+        if want_gpu_slices:
+            res.gpu_slices[i] = r.gpu_slices[0]
         res.unscheduled[i] = r.unscheduled[0]
         res.used_cpu[i] = r.used_cpu[0]
         res.used_mem[i] = r.used_mem[0]

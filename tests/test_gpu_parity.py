@@ -401,9 +401,9 @@ def test_k8s_sweep_at_scale_matches_oracle():
                 "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "40"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
 
     class Recording(sim.HipEngine):
-        def run(self, prob, scen, orders, want_placement=True):
+        def run(self, prob, scen, orders, want_placement=True, **kw):
             self.args = (prob, scen, orders)
-            self.out = super().run(prob, scen, orders, want_placement)
+            self.out = super().run(prob, scen, orders, want_placement, **kw)
             return self.out
 
     eng = Recording()

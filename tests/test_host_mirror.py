@@ -22,8 +22,8 @@ REF_EXAMPLE = "/root/reference/example"
 class OracleEngine:
     """Test-only engine with the HipEngine interface."""
 
-    def run(self, prob, scen, orders, want_placement=True, node_ranks=None):
-        return O.run(prob, scen, orders, want_placement, node_ranks=node_ranks)
+    def run(self, prob, scen, orders, want_placement=True, node_ranks=None, want_gpu_slices=False):
+        return O.run(prob, scen, orders, want_placement, node_ranks=node_ranks, want_gpu_slices=want_gpu_slices)
 
     def explain(self, prob, n_nodes, order, max_failed):
         _, (nf, failed, codes) = O.run(prob, [[n_nodes, 0]], np.asarray(order)[None], explain_scenario=0, max_failed=max_failed)
