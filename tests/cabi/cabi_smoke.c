@@ -10,6 +10,9 @@
  * order, with caller-owned buffers -- simon_load_* -> simon_run_batch -> simon_min_plan -> simon_explain /
  * simon_explain_loaded, the device group (two members on device 0), and two contexts on two pthreads.
  * Expected values come from the committed fixtures (tests/golden/make_cabi_fixture.py wrote them from the oracle).
+ * A "SIMONFX2" fixture additionally carries every optional array integration/go/hipengine/engine.go fills (ephemeral storage,
+ * extended resources, Open-Gpu-Share nodes / pods incl. arriving gpu-index lists, preset / gate / pin nodes, static masks and
+ * reasons, const scores) and the golden simon_batch_out.gpu_slices: the struct usage of the Go shim, executed from C.
  *
  * Exit codes: 0 ok, 77 no usable GPU (the binary linked and ran: what the CPU-only test checks), 1 mismatch / error.
  */
@@ -28,6 +31,13 @@ typedef struct fixture {
     int32_t plan_found, plan_scenario, plan_n_nodes;
     int32_t ex_scenario, ex_n_failed, *ex_failed;
     uint16_t* ex_codes;
+    /* SIMONFX2 extension (all NULL / 0 for SIMONFX1) */
+    int32_t K, has_gpu, has_mask;
+    int64_t *alloc_eph, *req_eph, *scalar_alloc, *scalar_req, *gpu_mem_total, *pod_gpu_mem, *const_score;
+    int32_t *gpu_cnt, *pod_gpu_cnt, *preset, *gate, *pin;
+    uint32_t* gpu_index;
+    uint64_t *static_mask, *g_slices;
+    uint8_t* static_reason;
 } fixture;
 
 static void* slurp(FILE* f, size_t bytes) {
@@ -40,7 +50,9 @@ static void load_fixture(const char* path, fixture* x) {
     FILE* f = fopen(path, "rb");
     if (!f) { perror(path); exit(1); }
     char magic[8];
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "SIMONFX1", 8)) { fprintf(stderr, "%s: bad magic\n", path); exit(1); }
+    memset(x, 0, sizeof *x);
+    if (fread(magic, 1, 8, f) != 8 || (memcmp(magic, "SIMONFX1", 8) && memcmp(magic, "SIMONFX2", 8))) { fprintf(stderr, "%s: bad magic\n", path); exit(1); }
+    const int ext = magic[7] == '2';
     int32_t hdr[6];
     if (fread(hdr, 4, 6, f) != 6) exit(1);
     x->N = hdr[0]; x->P = hdr[1]; x->Cp = hdr[2]; x->Cn = hdr[3]; x->S = hdr[4]; x->n_orders = hdr[5];
@@ -57,6 +69,22 @@ static void load_fixture(const char* path, fixture* x) {
     x->ex_scenario = t[0]; x->ex_n_failed = t[1];
     x->ex_failed = slurp(f, (size_t)x->ex_n_failed * 4);
     x->ex_codes = slurp(f, (size_t)x->ex_n_failed * (size_t)x->scen[2 * x->ex_scenario] * 2);
+    if (ext) {
+        int32_t h[3];
+        if (fread(h, 4, 3, f) != 3) exit(1);
+        x->K = h[0]; x->has_gpu = h[1]; x->has_mask = h[2];
+        const size_t K = x->K, words = (N + 63) / 64, Cp = x->Cp;
+        x->alloc_eph = slurp(f, N * 8); x->req_eph = slurp(f, P * 8);
+        x->scalar_alloc = slurp(f, K * N * 8); x->scalar_req = slurp(f, K * P * 8);
+        x->preset = slurp(f, P * 4); x->gate = slurp(f, P * 4); x->pin = slurp(f, P * 4);
+        x->const_score = slurp(f, Cp * 8);
+        if (x->has_gpu) {
+            x->gpu_cnt = slurp(f, N * 4); x->gpu_mem_total = slurp(f, N * 8);
+            x->pod_gpu_mem = slurp(f, P * 8); x->pod_gpu_cnt = slurp(f, P * 4); x->gpu_index = slurp(f, P * 4);
+            x->g_slices = slurp(f, S * P * 8);
+        }
+        if (x->has_mask) { x->static_mask = slurp(f, Cp * words * 8); x->static_reason = slurp(f, Cp * N); }
+    }
     fclose(f);
 }
 
@@ -69,6 +97,17 @@ static void fill_inputs(const fixture* x, simon_nodes_soa* nd, simon_pods_soa* p
     pd->struct_size = sizeof *pd; pd->n_pods = x->P;
     pd->req_cpu = x->req_cpu; pd->req_mem = x->req_mem; pd->pod_class = x->pod_class;
     tb->struct_size = sizeof *tb; tb->n_pod_classes = x->Cp; tb->n_node_classes = x->Cn; tb->simon_raw = x->simon_raw;
+    /* the optional arrays of a SIMONFX2 fixture: what Flat.cNodes / cPods / cTables of the Go shim attach */
+    nd->alloc_eph = x->alloc_eph; pd->req_eph = x->req_eph;
+    nd->n_scalar = x->K;
+    if (x->K > 0) { nd->scalar_alloc = x->scalar_alloc; pd->scalar_req = x->scalar_req; }
+    pd->preset_node = x->preset; pd->gate_node = x->gate; pd->pin_node = x->pin;
+    tb->const_score = x->const_score;
+    if (x->has_gpu) {
+        nd->gpu_cnt = x->gpu_cnt; nd->gpu_mem_total = x->gpu_mem_total;
+        pd->gpu_mem = x->pod_gpu_mem; pd->gpu_cnt = x->pod_gpu_cnt; pd->gpu_index = x->gpu_index;
+    }
+    if (x->has_mask) { tb->static_mask = x->static_mask; tb->static_reason = x->static_reason; }
 }
 
 static int compare_batch(const fixture* x, const int32_t* un, const int64_t* uc, const int64_t* um, const int32_t* pl, const char* who) {
@@ -92,14 +131,22 @@ static int run_single(const fixture* x, int device, int rounds, const char* who)
 #define TRY(call) do { int r_ = (call); if (r_ < 0) { fprintf(stderr, "%s: %s -> %d: %s\n", who, #call, r_, simon_last_error(c)); rc = 1; goto done; } } while (0)
     const size_t S = x->S, P = x->P;
     int32_t* un = malloc(S * 4); int64_t* uc = malloc(S * 8); int64_t* um = malloc(S * 8); int32_t* pl = malloc(S * P * 4);
+    uint64_t* gs = x->g_slices ? malloc(S * P * 8) : NULL;
     TRY(simon_load_nodes(c, &nd)); TRY(simon_load_pods(c, &pd)); TRY(simon_load_class_tables(c, &tb));
     for (int r = 0; r < rounds && !rc; ++r) {
         simon_batch_out out; memset(&out, 0, sizeof out);
         out.struct_size = sizeof out; out.unscheduled = un; out.used_cpu = uc; out.used_mem = um; out.placement = pl;
+        out.gpu_slices = gs;                                  /* non-NULL: the run records the devices Reserve books (ABI v4) */
         memset(pl, 0x7f, S * P * 4);
+        if (gs) memset(gs, 0x7f, S * P * 8);
         TRY(simon_run_batch(c, (const simon_scenario*)x->scen, x->S, x->orders, x->n_orders, &out));
         rc = compare_batch(x, un, uc, um, pl, who);
         if (rc) break;
+        if (gs) {                                             /* the whole matrix, and one row through its own entry point */
+            if (memcmp(gs, x->g_slices, S * P * 8)) { fprintf(stderr, "%s: gpu_slices differ from the fixture\n", who); rc = 1; break; }
+            TRY(simon_fetch_gpu_slices(c, 0, gs));
+            if (memcmp(gs, x->g_slices, P * 8)) { fprintf(stderr, "%s: fetch_gpu_slices row differs\n", who); rc = 1; break; }
+        }
         simon_plan plan;
         TRY(simon_min_plan(c, 100, 100, &plan));
         if (plan.found != x->plan_found || (plan.found && (plan.scenario != x->plan_scenario || plan.n_nodes != x->plan_n_nodes))) {
@@ -136,7 +183,7 @@ static int run_single(const fixture* x, int device, int rounds, const char* who)
         printf("%s: %d scenarios x %d pods ok (kernel variant %d, %.3f ms)\n", who, x->S, x->P, st.kernel_variant, st.kernel_ms);
     }
 done:
-    free(un); free(uc); free(um); free(pl);
+    free(un); free(uc); free(um); free(pl); free(gs);
     simon_ctx_destroy(c);
     return rc;
 #undef TRY

@@ -11,6 +11,10 @@ Layout (little endian): "SIMONFX1", int32 N P Cp Cn S n_orders, then
   golden: int32 unscheduled[S], int64 used_cpu[S] used_mem[S], int32 placement[S][P],
   plan (caps 100/100): int32 found scenario n_nodes,
   explain: int32 scenario n_failed, int32 failed[n_failed], uint16 codes[n_failed][n_nodes of that scenario].
+"SIMONFX2" = the same followed by the optional arrays integration/go/hipengine/engine.go fills:
+  int32 K has_gpu has_mask, int64 alloc_eph[N] req_eph[P] scalar_alloc[K][N] scalar_req[K][P], int32 preset[P] gate[P] pin[P],
+  int64 const_score[Cp], (has_gpu) int32 gpu_cnt[N], int64 gpu_mem_total[N] pod_gpu_mem[P], int32 pod_gpu_cnt[P], uint32 gpu_index[P],
+  uint64 golden gpu_slices[S][P], (has_mask) uint64 static_mask[Cp][ceil(N/64)], uint8 static_reason[Cp][N].
 The golden values come from oracle/simon_oracle.c (TEST INFRASTRUCTURE)."""
 import os
 import sys
@@ -24,17 +28,17 @@ import oracle_lib as O  # noqa: E402
 from open_simulator_amd import synth  # noqa: E402
 
 
-def write(path, prob, scen, orders, explain_scenario):
+def write(path, prob, scen, orders, explain_scenario, ext=False):
     prob.normalise()
     scen = np.ascontiguousarray(scen, np.int32)
     orders = np.ascontiguousarray(orders, np.int32)
-    ref = O.run(prob, scen, orders)
+    ref = O.run(prob, scen, orders, want_gpu_slices=ext)
     plan = O.min_plan(prob, scen, ref)
     _, (nf, failed, codes) = O.run(prob, scen, orders, explain_scenario=explain_scenario, max_failed=8)
     assert nf > 0, "pick an explain scenario with unscheduled pods"
     k = len(failed)
     with open(path, "wb") as f:
-        f.write(b"SIMONFX1")
+        f.write(b"SIMONFX2" if ext else b"SIMONFX1")
         f.write(np.array([prob.n_nodes, prob.n_pods, prob.n_pod_classes, prob.n_node_classes, len(scen), len(orders)], "<i4").tobytes())
         pod_class = prob.pod_class if prob.pod_class is not None else np.zeros(prob.n_pods, np.int32)
         node_class = prob.node_class if prob.node_class is not None else np.zeros(prob.n_nodes, np.int32)
@@ -47,6 +51,26 @@ def write(path, prob, scen, orders, explain_scenario):
         f.write(np.array([explain_scenario, k], "<i4").tobytes())
         f.write(failed.astype("<i4").tobytes())
         f.write(codes.astype("<u2").tobytes())
+        if ext:
+            N, P, Cp = prob.n_nodes, prob.n_pods, prob.n_pod_classes
+            K = 0 if prob.scalar_alloc is None else prob.scalar_alloc.shape[0]
+            has_gpu, has_mask = prob.gpu_cnt is not None, prob.static_mask is not None
+
+            def arr(a, t, n):
+                return (np.zeros(n, t) if a is None else np.ascontiguousarray(a).astype(t)).tobytes()
+            f.write(np.array([K, has_gpu, has_mask], "<i4").tobytes())
+            f.write(arr(prob.alloc_eph, "<i8", N)); f.write(arr(prob.req_eph, "<i8", P))
+            f.write(arr(prob.scalar_alloc, "<i8", K * N)); f.write(arr(prob.scalar_req, "<i8", K * P))
+            f.write((np.full(P, -1, "<i4") if prob.preset_node is None else prob.preset_node.astype("<i4")).tobytes())
+            f.write((np.full(P, -1, "<i4") if prob.gate_node is None else prob.gate_node.astype("<i4")).tobytes())
+            f.write((np.full(P, -1, "<i4") if prob.pin_node is None else prob.pin_node.astype("<i4")).tobytes())
+            f.write(arr(prob.const_score, "<i8", Cp))
+            if has_gpu:
+                f.write(arr(prob.gpu_cnt, "<i4", N)); f.write(arr(prob.gpu_mem_total, "<i8", N))
+                f.write(arr(prob.gpu_mem, "<i8", P)); f.write(arr(prob.pod_gpu_cnt, "<i4", P)); f.write(arr(prob.gpu_index, "<u4", P))
+                f.write(ref.gpu_slices.astype("<u8").tobytes())
+            if has_mask:
+                f.write(prob.static_mask.astype("<u8").tobytes()); f.write(arr(prob.static_reason, "u1", Cp * N))
     print(path, os.path.getsize(path), "bytes; unscheduled", ref.unscheduled.tolist(), "plan", plan.as_dict())
 
 
@@ -64,6 +88,20 @@ def main():
     counts = [20, 35, 50, 64, 100, 128]
     scen = [[c, o] for c in counts for o in (0, 1)]
     write(os.path.join(HERE, "cabi_config2_sweep.bin"), prob, scen, orders, 0)
+    # every optional array the Go shim fills: ephemeral storage, two extended resources, GPU share with arriving gpu-index lists,
+    # static masks, presets, gates, pinned pods
+    import randprob
+    from open_simulator_amd import capi
+    prob = randprob.rand_problem(77, N=48, P=400, eph=True, scalars=2, gpu=True, static_mask=True, presets=True, gates=True, pins=True,
+                                 tight_pods=True)
+    rng = np.random.default_rng(77)
+    g = np.zeros(prob.n_pods, np.uint32)
+    for p in np.flatnonzero(prob.gpu_mem > 0)[::4]:
+        g[p] = capi.pack_gpu_index(rng.integers(0, 8, int(rng.integers(1, 3))).tolist())
+    prob.gpu_index = g
+    scen, orders = randprob.rand_scenarios(77, prob, S=6)
+    ref = O.run(prob, scen, orders)
+    write(os.path.join(HERE, "cabi_features.bin"), prob, scen, orders, int(np.argmax(ref.unscheduled)), ext=True)
 
 
 if __name__ == "__main__":

@@ -315,10 +315,12 @@ def test_c_consumer_of_the_abi(tmp_path):
     """tests/cabi/cabi_smoke.c, built with plain gcc against include/simon_hip.h: load -> run_batch -> min_plan -> explain /
     explain_loaded, the device group, and two contexts on two pthreads, against the committed binary fixtures."""
     exe = build_cabi_smoke(tmp_path)
-    fx = [os.path.join(ROOT, "tests", "golden", n) for n in ("cabi_kav.bin", "cabi_config2_sweep.bin")]
+    fx = [os.path.join(ROOT, "tests", "golden", n) for n in ("cabi_kav.bin", "cabi_config2_sweep.bin", "cabi_features.bin")]
     out = subprocess.run([exe, *fx], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "cabi_smoke ok" in out.stdout and out.stdout.count("group of 2 members") == 2
+    # cabi_features.bin: every optional array the Go shim fills (ephemeral storage, extended resources, GPU share with arriving
+    # gpu-index lists, presets / gates / pins, static masks) + the golden gpu_slices, from plain C
+    assert "cabi_smoke ok" in out.stdout and out.stdout.count("group of 2 members") == 3
 
 
 def test_score_table_kernel_randomised_slice():

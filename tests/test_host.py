@@ -112,3 +112,18 @@ def test_cabi_fixtures_match_the_oracle():
     pl = np.frombuffer(raw, "<i4", S * P, off + S * 4 + S * 16).reshape(S, P)
     assert un.tolist() == ref.unscheduled.tolist() == [0, 2]
     assert (pl == ref.placement).all() and pl[0, :2].tolist() == [0, 0]      # the first two pods land on node A
+
+
+def test_cabi_fixtures_are_regenerated_byte_for_byte(tmp_path, monkeypatch):
+    """tests/golden/make_cabi_fixture.py rewrites all three fixtures of the C consumer from today's oracle: identical files (the
+    SIMONFX2 one holds every optional array the Go shim fills and the golden gpu_slices)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_cabi_fixture", os.path.join(root, "tests", "golden", "make_cabi_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "HERE", str(tmp_path))
+    mod.main()
+    for name in ("cabi_kav.bin", "cabi_config2_sweep.bin", "cabi_features.bin"):
+        assert open(tmp_path / name, "rb").read() == open(os.path.join(root, "tests", "golden", name), "rb").read(), name
+    assert open(tmp_path / "cabi_features.bin", "rb").read()[:8] == b"SIMONFX2"
