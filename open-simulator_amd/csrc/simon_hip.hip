@@ -109,7 +109,7 @@ struct simon_ctx : simon::HostInputs {
     bool has_static = false;                     // static score tables present (score-table kernel: class term; else all-feature kernel)
     DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
-    bool no_gpu_split = false;
+    bool no_gpu_split = false, force_table = false;
     bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
@@ -411,7 +411,7 @@ int stage_narrow(simon_ctx* c) {
                 sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = tc; sr.flags = r.flags;
                 sigs.push_back(sr);
             }
-            rowsC[p] = PodRowC{it->second | (tc << 8), (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, 0};
+            rowsC[p] = PodRowC{it->second | (tc << 10), (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, 0};
         }
         // REST descriptors: term class (which mask rows a pod must find clear / sets) and GPU signature of every pod
         std::vector<int32_t> xrows;           // entries of every term class: filter row | set row << 16
@@ -721,7 +721,8 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
-    c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;   // A/B: node classes not split into with / without devices
+    c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
+    c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
     c->table_prof = getenv("SIMON_TABLE_PROF") != nullptr;   // phase profile of simon_table.hip: profiling builds only
 #endif
@@ -1038,6 +1039,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             bool coarse = coarse_ok && (!fine_ok || cost(std::max(fit(lds64), 1), 1.2) < 0.95 * cost(std::max(fit(lds16), 1), 1.0));
             if (c->force_coarse >= 0) coarse = c->force_coarse ? coarse_ok : !fine_ok && coarse_ok;
             if (c->rest) coarse = coarse_ok;                        // the REST path is built on the two-level layout
+            if (c->n_sigs > 128) coarse = coarse_ok;                // ... and so are the signature groups beyond 128 (simon_table.hip: MANY)
             c->table_coarse = coarse;
             for (int s = 0; s < S; ++s) c->scen_ni[s] = coarse ? ni64[s] : ni16[s];
             const int ni_top = coarse ? top64 : top16;
@@ -1049,7 +1051,8 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            c->table_perm_ok = !c->rest || coarse;
+            // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY); else generation 2 / all-feature kernel
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest));
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1138,10 +1141,15 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
         const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest) + c->lds_pad : 0;
-        const bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
+        bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        if ((c->has_pin || too_big || c->rest || !c->raw_fits_lds || c->has_ranks || c->has_static) && !use_table) run_wide = true;
+        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || !c->raw_fits_lds || c->has_ranks || c->has_static;
+        // Beyond 256 signatures generation 2 (register-resident state, every node re-evaluated per cycle: its time does not depend on
+        // the signature count) overtakes the score table (measured, profiles/r03: 300 signatures 124 ms against 119 ms, 384: 169 ms) --
+        // where it is eligible; otherwise the table (K <= 384) still beats the all-feature kernel by far.
+        if (use_table && c->n_sigs > 256 && !needs_table_or_wide && c->fast_ok && !c->force_v1 && T >= 128 && !c->force_table) use_table = false;
+        if (needs_table_or_wide && !use_table) run_wide = true;
         if (run_wide) {
             // falls through to the all-feature kernel below
         } else if (use_table) {

@@ -26,7 +26,7 @@ struct ShapeRow {    // capacity of one internal node class = one distinct (Allo
 };
 static_assert(sizeof(ShapeRow) == 48, "ShapeRow must be 48 bytes");
 
-// 16 B: signature | table class << 8, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) GPU request + 1 | extra-resource
+// 16 B: signature | table class << 10, preset (>= 0) or pinned (<= -2: -2 - node) node, gate, and (REST) GPU request + 1 | extra-resource
 // request + 1 << 6 | entries << 12 | offset << 18 of the pod's entries in TableCold::xrows (0 = the score table alone decides the pod)
 struct PodRowC { int32_t sigcls, preset, gate, rest; };
 
@@ -81,7 +81,7 @@ constexpr int kTableMaxNodes = 4095;    // canonical index and padded position a
 constexpr int kTableMaxNodesCoarse = 8191;    // ... 13-bit fields with the two-level summary
 constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario (classes padded to 16)
 constexpr int kTableMaxPaddedCoarse = 8192;   // ... with the two-level summary (classes padded to 64)
-constexpr int kTableMaxSigs = 128;      // two signatures per lane
+constexpr int kTableMaxSigs = 384;      // two signatures per lane in registers + up to two more groups of 128 read from TableCold::sigs per cycle
 constexpr size_t kTableLdsPerCU = 160 * 1024;
 constexpr int kTableMaxGpuSigs = 32;    // distinct (gpu-mem, gpu-count) requests: one mask row and one lane each
 constexpr int kTableMaxXres = 32;       // distinct (ephemeral-storage, extended-resource) requests: one mask row and one lane each

@@ -35,7 +35,7 @@
 // Generation 6 (template REST, see table_kernel): pods with per-node filters the table cannot hold (Open-Gpu-Share devices,
 // required anti-affinity on node-level topology keys) scan their signature's rows under per-block position masks.
 //
-// Limits: K <= 128 signatures (two per lane), padded scenario size <= 4096 positions (<= 4095 nodes; two-level: 8192 /
+// Limits: K <= 384 signatures (two per lane in registers, further groups of 128 from memory), padded scenario size <= 4096 positions (<= 4095 nodes; two-level: 8192 /
 // 8191), <= 64 node classes, NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are
 // permutations; REST: <= 32 GPU requests, <= 120 terms, <= 63 mask rows per pod.
 #include "simon_table.h"
@@ -255,7 +255,10 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
 // preset pods, the 64-step placement flush): as a run-time flag it cost config 5 4 % (same-box A/B, profiles/README.md).
 // AFF: some pod class carries required-affinity entries (REST only; own instantiation for the same reason: +5.7 % on config 5 as
 // run-time tests of the entries' bit 31).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF>
+// MANY: more than 128 signatures (KQ = 2, two-level summary, no REST): signatures 0 .. 127 live in lane registers as usual, the rest is
+// refreshed from TableCold::sigs in up to two further groups of 128 whose table rows are fetched WITH group 0's (one memory round
+// trip per cycle; own instantiation: the extra rows cost ~40 VGPRs the K <= 128 kernels must not pay).
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -281,8 +284,10 @@ __global__ __launch_bounds__(64) void table_kernel(
 #ifdef SIMON_TIE_SPECULATE
     constexpr bool TIE_FIRST = false;                                 // A/B builds: every instantiation speculates
 #else
-    constexpr bool TIE_FIRST = REST;
+    constexpr bool TIE_FIRST = REST || MANY;                          // MANY: a lost speculation would reload three groups of rows
 #endif
+    static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
+    constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
@@ -494,8 +499,8 @@ __global__ __launch_bounds__(64) void table_kernel(
         my_add_c[q] = (unsigned)r.req_c; my_add_m[q] = (unsigned)r.req_m;
         my_addz_c[q] = (unsigned)r.nz_c; my_addz_m[q] = (unsigned)r.nz_m;
         koff[q] = (unsigned)kk[q] * 16u;
-        if (kvalid[q]) my_dirty |= 1u << q;
     }
+    for (int j = 0; j * 64 + lane < K; ++j) my_dirty |= 1u << j;      // bit j: signature lane + 64 j starts dirty (first use re-bases it)
     // this lane's summary entries (lane, lane + 64, ...): constant of the arg-max key (low field = PMASK - position), node class,
     // and offset of the entry's class segment into the static per-class node lists (index of position p = boff + p; packed with
     // the class: one readlane fetches both for the winning entry)
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     int32_t* __restrict__ place = place_step ? place_step + (size_t)s * P : nullptr;
 
     // pod stream: 64 rows per vector load (lane l holds step i0 + l), one chunk ahead.  x packs what the common path needs into ONE
-    // readlane: signature | pod class << 8, sign bit = "special" (gated out of this scenario, preset or pinned): y = preset, z = gate.
+    // readlane: signature | pod class << 10, sign bit = "special" (gated out of this scenario, preset or pinned): y = preset, z = gate.
     auto load_chunk = [&](int i0) -> int4 {
         const int idx = i0 + lane;
         if (idx >= P) return make_int4((int)0x80000000, -1, 0x7fffffff, 0);
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         for (int il = 0; il < steps; ++il) {
         TPROF(0);                                                      // loop control, placement flush, pod chunk
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
-        const int r_sig = pk & 0xFF, r_cls = (pk >> 8) & 0x7FFFFF;
+        const int r_sig = pk & 0x3FF, r_cls = (pk >> 10) & 0x1FFFFF;
         const int rw = REST ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST descriptor (0: the score table alone decides the pod)
         const int r_gs = (rw & 63) - 1, r_xs = ((rw >> 6) & 63) - 1, r_nrows = (rw >> 12) & 63;
         int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
@@ -972,6 +977,28 @@ __global__ __launch_bounds__(64) void table_kernel(
                 oldq[q] = rowp[q][pstar & 15];                         // this signature's byte before the cycle (same cache line as the row)
                 if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
             }
+            // MANY: the rows of the signatures beyond the register-resident ones, same round trip (uniform group conditions)
+            unsigned char* rowg[NG ? NG : 1][KQ];
+            uint4 Tg[NG ? NG : 1][KQ];
+            uint2 Fg[NG ? NG : 1][KQ];
+            unsigned oldg[NG ? NG : 1][KQ];
+            int kg[NG ? NG : 1][KQ];
+            if constexpr (MANY) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (128 * (g + 1) < K) {
+#pragma unroll
+                        for (int q = 0; q < KQ; ++q) {
+                            const int k = 128 * (g + 1) + 64 * q + lane;
+                            kg[g][q] = k < K ? k : 0;
+                            rowg[g][q] = g_tile + ((unsigned)(pstar >> 4) * Krow + (unsigned)kg[g][q] * 16u);
+                            Tg[g][q] = *(const uint4*)rowg[g][q];
+                            oldg[g][q] = rowg[g][q][pstar & 15];
+                            Fg[g][q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kg[g][q]) * 4u);
+                        }
+                    }
+                }
+            }
             uint2 z = make_uint2(0, 0);
             if (!NZEQ) z = g_nz[pstar];
             if (!TIE_FIRST && scanned && __builtin_expect(tie_with_other_class(), 0)) {   // rare: first maximum in CANONICAL order
@@ -1005,56 +1032,87 @@ __global__ __launch_bounds__(64) void table_kernel(
             TPROF_WAIT_MEM; TPROF(5);                                  // node state and table row arrived (L2 / HBM)
             const int sl = r_sig & 63;
             const bool hiq = KQ > 1 && (r_sig >> 6);
-            st.rq_c += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_c[0], sl));
-            st.rq_m += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_m[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_m[0], sl));
+            unsigned add_c, add_m, addz_c = 0, addz_m = 0;
+            if (MANY && __builtin_expect(r_sig >= 64 * KQ, 0)) {       // a signature beyond the register-resident ones (K > 128): its row
+                const SigRow rs = sigs[r_sig];                         // (uniform index: scalar loads)
+                add_c = (unsigned)rs.req_c; add_m = (unsigned)rs.req_m; addz_c = (unsigned)rs.nz_c; addz_m = (unsigned)rs.nz_m;
+            } else {
+                add_c = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_c[0], sl));
+                add_m = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_add_m[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_add_m[0], sl));
+                if (!NZEQ) {
+                    addz_c = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_addz_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_addz_c[0], sl));
+                    addz_m = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_addz_m[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_addz_m[0], sl));
+                }
+            }
+            st.rq_c += add_c;
+            st.rq_m += add_m;
             st.freep -= 1u;
             double nzc = 0.0, nzm = 0.0;
             if (!NZEQ) {
-                z.x += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_addz_c[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_addz_c[0], sl));
-                z.y += (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_addz_m[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_addz_m[0], sl));
+                z.x += addz_c;
+                z.y += addz_m;
                 if (lane == 0) g_nz[pstar] = z;
                 nzc = (double)z.x; nzm = (double)z.y;
             }
             if (lane == 0) g_state[pstar] = st;
             const double rq_c = (double)st.rq_c, rq_m = (double)st.rq_m;
             TPROF(8);                                                  // state update (readlanes of the signature's request), state store
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                const unsigned nb_raw = eval_node(my_req_c[q], my_req_m[q], my_nz_c[q], my_nz_m[q], my_zero[q], rq_c, rq_m, nzc, nzm,
-                                                  (int)st.freep, sh);
-                const unsigned old = oldq[q];
+            // Signature k's byte of the touched node, its block key, summary entries and feasible-node counter (lane-local k).
+            auto refresh_sig = [&](int k, bool valid, double q_req_c, double q_req_m, double q_nz_c, double q_nz_m, bool q_zero,
+                                   unsigned char* rowk, const uint4 Tk, const uint2 Fk, unsigned old, unsigned snk, int dirty_bit) {
+                const unsigned nb_raw = eval_node(q_req_c, q_req_m, q_nz_c, q_nz_m, q_zero, rq_c, rq_m, nzc, nzm, (int)st.freep, sh);
                 const unsigned nb = old ? nb_raw : 0u;                    // static mask / monotone infeasibility
                 // One wave: its vector memory accesses are served in order, so the next cycle's loads of this row / state
                 // observe these stores; no cache maintenance, no wait.
-                if (kvalid[q] && nb != old) {
-                    rowp[q][pos] = (unsigned char)nb;
-                    const unsigned m = block_key16_patched(T[q], nb, selA, selB);
-                    const unsigned e16 = (m >> 4) ? m + (snq[q] << 4) : 0u;
+                if (valid && nb != old) {
+                    rowk[pos] = (unsigned char)nb;
+                    const unsigned m = block_key16_patched(Tk, nb, selA, selB);
+                    const unsigned e16 = (m >> 4) ? m + (snk << 4) : 0u;
                     if constexpr (COARSE) {
                         // per-16 entry to the workspace; the entry of the 64 positions = max over its four per-16 entries, each
                         // re-keyed to total << 6 | 63 - position (a feasible entry is >= 64, the constants alone stay below)
                         const int j = blk & 3;                            // uniform
-                        g_fine[((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u + (unsigned)j] = (unsigned short)e16;
+                        g_fine[((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)k) * 4u + (unsigned)j] = (unsigned short)e16;
                         const unsigned keep = (j & 1) ? 0x0000FFFFu : 0xFFFF0000u, ins = e16 << ((j & 1) * 16);
-                        const unsigned fx = (j & 2) ? F[q].x : ((F[q].x & keep) | ins);
-                        const unsigned fy = (j & 2) ? ((F[q].y & keep) | ins) : F[q].y;
+                        const unsigned fx = (j & 2) ? Fk.x : ((Fk.x & keep) | ins);
+                        const unsigned fy = (j & 2) ? ((Fk.y & keep) | ins) : Fk.y;
                         const unsigned cx = (((fx & 0xFFF0FFF0u) << 2) | (fx & 0x000F000Fu)) | 0x00200030u;
                         const unsigned cy = (((fy & 0xFFF0FFF0u) << 2) | (fy & 0x000F000Fu)) | 0x00000010u;
                         const unsigned mm = pkmax_t(cx, cy);
                         const unsigned c64 = max(mm & 0xFFFFu, mm >> 16);
-                        s_sum[kk[q] * nbp + (pstar >> 6)] = (unsigned short)(c64 >= 64u ? c64 : 0u);
+                        s_sum[k * nbp + (pstar >> 6)] = (unsigned short)(c64 >= 64u ? c64 : 0u);
                     } else {
-                        s_sum[kk[q] * nbp + blk] = (unsigned short)e16;
+                        s_sum[k * nbp + blk] = (unsigned short)e16;
                     }
                     if (!nb) {                                            // the node stopped being feasible for this signature
-                        const int cidx = kk[q] * Cn + dstar;
+                        const int cidx = k * Cn + dstar;
                         int left;
                         if constexpr (COARSE) left = atomicSub(&g_cnt[cidx], 1) - 1;
                         else { left = s_cnt[cidx] - 1; s_cnt[cidx] = left; }
-                        if (left == 0) my_dirty |= 1u << q;               // the class term of row k changes: re-base before its next use
+                        if (left == 0) my_dirty |= 1u << dirty_bit;       // the class term of row k changes: re-base before its next use
 #ifdef SIMON_TABLE_DEBUG
-                        printf("DBG s=%d step=%d CNT k=%d class=%d left=%d\n", s, i0 + il, kk[q], dstar, left);
+                        printf("DBG s=%d step=%d CNT k=%d class=%d left=%d\n", s, i0 + il, k, dstar, left);
 #endif
+                    }
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+                refresh_sig(kk[q], kvalid[q], my_req_c[q], my_req_m[q], my_nz_c[q], my_nz_m[q], my_zero[q], rowp[q], T[q], COARSE ? F[q] : make_uint2(0u, 0u),
+                            oldq[q], snq[q], q);
+            // MANY: the further groups (their table rows arrived with group 0's; the signature rows of TableCold::sigs are L2-hot)
+            if constexpr (MANY) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (128 * (g + 1) < K) {
+                        SigRow rg[KQ];
+                        unsigned sng[KQ];
+#pragma unroll
+                        for (int q = 0; q < KQ; ++q) { rg[q] = sigs[kg[g][q]]; sng[q] = s_sn[kg[g][q] * Cn + dstar]; }
+#pragma unroll
+                        for (int q = 0; q < KQ; ++q)
+                            refresh_sig(kg[g][q], 128 * (g + 1) + 64 * q + lane < K, rg[q].req_c, rg[q].req_m, rg[q].nz_c, rg[q].nz_m, rg[q].flags & 1u,
+                                        rowg[g][q], Tg[g][q], Fg[g][q], oldg[g][q], sng[q], 2 * (g + 1) + q);
                     }
                 }
             }
@@ -1110,12 +1168,16 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false>
 static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (REST && !AFF) {
         if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true>(a, n_blocks, lds, st);
     }
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF>;
+    if constexpr (KQ == 2 && COARSE && !REST && !MANY) {              // more than 128 signatures: the instantiation with further groups
+        if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, false, true>(a, n_blocks, lds, st);
+    }
+    if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;       // simon_hip.hip keeps such batches away (two-level, no REST)
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep aimed at the score-table kernel (simon_table.hip): cpu+memory problems at the sizes and shapes its
-templates switch on -- 1 ... 4 095 nodes (1, 2 or 4 blocks per lane), 1 ... 128 request signatures (one or two per lane), 1 ...
+templates switch on -- 1 ... 4 095 nodes (1, 2 or 4 blocks per lane), 1 ... 384 request signatures (one or two per lane in registers, further
+groups of 128 from memory), 1 ...
 64 internal node classes incl. caller classes that do NOT share their allocatable (the kernel refines them), presets, gates,
 pinned pods, static masks, initial state, NonZeroRequested != Requested, zero requests, tight pod counts, gcd-1 units.  Every
 third case forces the two-level summary (SIMON_TABLE_COARSE=1: classes padded to 64, per-16 entries in HBM).
@@ -30,7 +31,7 @@ def one_case(case, coarse=None):
     P = int(rng.integers(20, 400 if size == 0 else 2500))
     feat = {f: True for f in FEATURES if rng.random() < 0.3}
     n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))
-    n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 65, 100, 128]))
+    n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 65, 100, 128, 129, 200, 256, 384]))
     if size == 3:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
     prob = randprob.rand_problem(52000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)

@@ -67,3 +67,33 @@ def test_config5_every_benchmarked_scenario():
             if len(bad):
                 bad_rows.append((s, len(bad), int(bad[0])))
         assert not bad_rows, f"{len(bad_rows)} scenarios differ, first (scenario, count, pod) = {bad_rows[0]}"
+
+
+@pytest.mark.parametrize("n_sigs", [129, 200, 300, 384])
+def test_config3_beyond_128_signatures_stays_on_the_score_table(n_sigs, monkeypatch):
+    """129 request signatures used to fall to generation 2 (8x slower).  The score-table kernel now keeps two
+    signatures per lane in registers and refreshes further groups of 128 from TableCold::sigs (K <= 384; beyond 256 the host
+    prefers generation 2 where that is eligible -- SIMON_FORCE_TABLE keeps the table for this test)."""
+    monkeypatch.setenv("SIMON_FORCE_TABLE", "1")
+    prob, scen, orders = synth.config3(n_counts=40, n_orders=3, n_pods=5000, n_sigs=n_sigs)
+    sub = scen[::4]
+    ref = O.run_threaded(prob, sub, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(sub, orders)
+        ctx.run_loaded(True)
+        st = ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation in (4, 5), "must stay on the score-table kernel"
+        assert_same(ctx.fetch(True), ref)
+
+
+@pytest.mark.parametrize("n_sigs", [300, 385])
+def test_many_signatures_fall_back_correctly(n_sigs):
+    """Without the knob: 257 .. 384 signatures of a plain cpu+memory problem take generation 2 (faster there), 385+ always."""
+    prob, scen, orders = synth.config3(n_counts=12, n_orders=2, n_pods=4000, n_sigs=n_sigs)
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        assert ctx.stats().kernel_generation == 2
+    assert_same(res, ref)
