@@ -50,6 +50,7 @@ DTYPE = {1: "u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
          4: "u8 score table + u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)"}
 KERNEL_NAME = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::table_kernel"}
 KERNEL_SHORT = {1: "narrow_v1", 2: "wide (all-feature kernel)", 3: "narrow_fast", 4: "score_table"}
+SIG_RECORD = 200                  # request signatures of the `config3_sigs` sub-record (beyond the 128 two registers per lane hold; the table takes 384)
 C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
 
 PMC_GROUPS = [                    # one rocprofv3 pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass; 8 SQ slots)
@@ -359,12 +360,16 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config2()
         child = ["--workload", "config2"]
         wl, label = "config3", "BASELINE config 2"
+    elif name == "config3sig":                      # config 3 with SIG_RECORD request signatures: the > 128-signature regime as a number
+        prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_RECORD)
+        child = ["--workload", "config3sig", "--sigs", str(SIG_RECORD)]
+        wl, label = "config3", f"config 3 with {SIG_RECORD} request signatures"
     else:
         prob, scen, orders = synth.config5(n_scen=c5_scen, n_orders=4)
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": name if name == "config2" else f"config5_S{c5_scen}"}
+    rec = {"workload": name if name == "config2" else f"config3_sigs{SIG_RECORD}" if name == "config3sig" else f"config5_S{c5_scen}"}
     with capi.Context(device) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
@@ -390,6 +395,8 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                       f"this workload ({time.perf_counter() - t0:.0f} s)")
     rec["roofline"] = roofline_record(kernel_of(st), st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl,
                                       lds_bytes=st.lds_bytes if st.workgroup_size == 64 else None, scenarios=len(scen))
+    if name == "config5" and c5_scen <= 256:          # what a host that starts from HOST buffers waits for at this size (staging included)
+        rec["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, device)
     return rec
 
 
@@ -646,7 +653,7 @@ def main():
             out["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, local_rank)
             subs = []
             nchk5 = int(os.environ.get("SIMON_BENCH_C5_CHECK", "32"))
-            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
+            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", 3, 1, 64, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
                                                  ("config5", 2, 1, nchk5, C5_SATURATING)):
                 try:
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))
