@@ -122,6 +122,15 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_xrows, d_gpu_cnt;
     DevBuf<uint32_t> d_gpu_devtot, d_i_gused;
     DevBuf<uint2> d_gsig;
+    // SPREAD path of the score-table kernel (soft PodTopologySpread constraints, generation 7): decided by choose_variant
+    bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
+    std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
+    std::vector<int> sp_zkeys;                   // topology keys of the zone-like soft terms (<= kSpreadMaxZoneKeys): the class split
+    int sp_TH = 0, sp_TZ = 0;
+    DevBuf<int32_t> d_sp_ent, d_sp_term;
+    DevBuf<double> d_spread_log;
+    DevBuf<uint64_t> d_node_sets;
+    DevBuf<signed char> d_cls_zdom;
     bool table_coarse = false;                   // two-level summary (simon_table.hip: COARSE), decided per loaded batch
     int force_coarse = -1, table_ni_top = 16;    // env SIMON_TABLE_COARSE = 0 / 1 (A/B)
     std::vector<int32_t> h_perm;
@@ -276,6 +285,72 @@ bool rest_supported(simon_ctx* c) {
     return true;
 }
 
+// Can the score-table kernel's SPREAD path (generation 7) take this problem?  Of the ABI v2 features only SOFT PodTopologySpread
+// constraints (+ the static score tables the class term folds in): no hard constraints, no InterPodAffinity terms of any kind, no host
+// ports, no Open-Gpu-Share / extra-resource rows (the REST path), no Open-Local.  Every soft term sits on a hostname-like key (flagged
+// topo_is_hostname, every node its own domain: one counter byte per position) or on a zone-like key (<= 16 domains; <= 3 such keys: the
+// node classes are split by their domains).  Fills sp_kind / sp_row / sp_zslot / sp_zkeys.
+bool spread_supported(simon_ctx* c) {
+    if (c->no_spread || c->ss_idx.empty()) return false;
+    if (c->has_ipa_score || !c->sh_idx.empty() || c->has_local || !c->aff_idx.empty() || !c->anti_idx.empty() || !c->port_idx.empty()) return false;
+    if (c->has_gpu || c->has_gpu_index) return false;
+    if (c->topo_is_hostname.empty() || c->spread_log.size() < (size_t)c->N + 1) return false;
+    for (int32_t x : c->alloc_pods) if (x > 255) return false;            // the per-position counters are bytes
+    if (c->P > 0 && c->N > 0) { /* pre-bound pods (init_npods) carry no labels: nothing to count at the start */ }
+    c->sp_kind.assign(c->Tm, 0); c->sp_row.assign(c->Tm, 0); c->sp_zslot.assign(c->Tm, 0);
+    c->sp_zkeys.clear();
+    c->sp_TH = c->sp_TZ = 0;
+    std::vector<int> key_kind(std::max(c->Kt, 1), -1);                    // 1 hostname-like, 2 zone-like, 0 unusable
+    for (int cp = 0; cp < c->Cp; ++cp) {
+        const int lo = c->ss_off[cp], hi = c->ss_off[cp + 1];
+        int n_host = 0;
+        for (int e = lo; e < hi; ++e) {
+            const int t = c->ss_idx[e];
+            if (t < 0 || t >= c->Tm) return false;
+            const int maxskew = c->ss_skew[e] & ~SIMON_SPREAD_DUP_KEY;
+            if (maxskew < 1 || maxskew >= (1 << 14)) return false;
+            const int k = c->term_key[t];
+            if (key_kind[k] < 0) {
+                key_kind[k] = 0;
+                if (c->topo_is_hostname[k]) {                             // size = scored nodes (scoring.go:100-104): needs one domain per node
+                    std::vector<char> seen(c->N, 0);
+                    bool ok = true;
+                    for (int j = 0; j < c->N && ok; ++j) {
+                        const int d = c->topo_dom[(size_t)k * c->N + j];
+                        ok = d >= 0 && d < c->N && !seen[d];
+                        if (ok) seen[d] = 1;
+                    }
+                    key_kind[k] = ok ? 1 : 0;
+                } else {
+                    bool ok = c->topo_n_dom[k] <= kSpreadMaxZoneDom;
+                    for (int j = 0; j < c->N && ok; ++j) { const int d = c->topo_dom[(size_t)k * c->N + j]; ok = d >= -1 && d < kSpreadMaxZoneDom; }
+                    if (ok && (int)c->sp_zkeys.size() < kSpreadMaxZoneKeys) { key_kind[k] = 2; c->sp_zkeys.push_back(k); }
+                }
+            }
+            if (key_kind[k] == 0) return false;
+            if (c->sp_kind[t] == 0) {
+                c->sp_kind[t] = key_kind[k];
+                if (key_kind[k] == 1) c->sp_row[t] = c->sp_TH++;
+                else {
+                    c->sp_row[t] = c->sp_TZ++;
+                    c->sp_zslot[t] = (int)(std::find(c->sp_zkeys.begin(), c->sp_zkeys.end(), k) - c->sp_zkeys.begin());
+                }
+            }
+            n_host += key_kind[k] == 1;
+        }
+        (void)n_host;
+    }
+    if (c->sp_TH > kSpreadMaxHostTerms || c->sp_TZ > kSpreadMaxZoneTerms || c->R > 4094) return false;
+    // counted terms of a class: the soft-spread terms among its match list, with multiplicity; one lane per distinct term
+    for (int cp = 0; cp < c->Cp && !c->match_off.empty(); ++cp) {
+        std::map<int, int> mult;
+        for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
+        if ((int)mult.size() + (c->ss_off[cp + 1] - c->ss_off[cp]) > 64) return false;
+        for (auto& kv : mult) if (kv.second > 255) return false;
+    }
+    return true;
+}
+
 // Decide NARROW vs WIDE and compute the gcd normalisation.
 // NARROW needs: cpu+mem+pods only; every quantity non-negative; after dividing by the gcd all
 // node totals and the worst-case accumulated NonZeroRequested stay < 2^31; simon raw scores fit
@@ -285,8 +360,12 @@ void choose_variant(simon_ctx* c) {
     c->g_cpu = c->g_mem = 1;
     if (c->force_wide) return;
     c->rest = false;
+    c->spread = false;
     c->has_static = c->has_na || c->has_tt || c->has_add;
-    if (c->v2_features_but_ports_and_static()) return;
+    if (c->v2_features_but_ports_and_static()) {
+        if (!spread_supported(c)) return;                         // only soft spread constraints: generation 7 of the score-table kernel
+        c->spread = true;
+    }
     if (c->has_static) {
         // The class term of the score-table kernel takes them if byte (<= 201) + 2 x Simon (<= 200) + NodeAffinity (<= 100) +
         // TaintToleration (<= 100) + the largest addition stays within the 10 bits the two-level summary gives a total.
@@ -304,7 +383,8 @@ void choose_variant(simon_ctx* c) {
     for (int64_t x : c->p_req_eph) if (x) c->xres = true;
     for (int64_t x : c->i_scalar_req) if (x) c->xres = true;
     for (int64_t x : c->p_scalar) if (x) c->xres = true;
-    const bool wants_rest = c->has_gpu || c->Tm > 0 || c->xres;
+    const bool wants_rest = !c->spread && (c->has_gpu || c->Tm > 0 || c->xres);
+    if (c->spread && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
     if (wants_rest && !rest_supported(c)) return;
     if (c->N >= (1 << 20) - 1) return;
     const uint64_t gc = gcd_of({&c->alloc_cpu, &c->i_req_cpu, &c->i_nz_cpu, &c->p_req_cpu, &c->p_nz_cpu});
@@ -499,23 +579,60 @@ int stage_narrow(simon_ctx* c) {
             // run the batch (their cycle is 17 % shorter than the REST instantiation's, profiles/README.md)
             if (!any_rest && c->table_ok) { c->rest = false; c->rest_M = c->rest_G = c->rest_X = 0; }
         }
+        // SPREAD descriptors: per pod class its soft constraints (term | maxSkew << 16 | dup << 30) followed by the soft-spread terms its
+        // pods are COUNTED on (term | multiplicity << 16), interned by content; PodRowC::rest = soft | counted << 3 | offset << 10
+        std::vector<int32_t> sp_ent;
+        if (c->spread && c->table_ok) {
+            std::map<std::vector<int32_t>, int> sc_id;
+            std::vector<int> desc_of(c->Cp, 0);
+            for (int cp = 0; cp < c->Cp; ++cp) {
+                std::vector<int32_t> ent;
+                const int ns = c->ss_off[cp + 1] - c->ss_off[cp];
+                for (int e = c->ss_off[cp]; e < c->ss_off[cp + 1]; ++e)
+                    ent.push_back(c->ss_idx[e] | ((c->ss_skew[e] & 0x3FFF) << 16) | ((c->ss_skew[e] & SIMON_SPREAD_DUP_KEY) ? 1 << 30 : 0));
+                std::map<int, int> mult;
+                if (!c->match_off.empty())
+                    for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
+                for (auto& kv : mult) ent.push_back(kv.first | (kv.second << 16));
+                if (ent.empty()) continue;
+                std::vector<int32_t> key = ent;                            // (a soft entry and a counted entry can spell the same word)
+                key.push_back(ns);
+                auto it = sc_id.find(key);
+                if (it == sc_id.end()) {
+                    if (sp_ent.size() + ent.size() >= (1u << 21)) { c->table_ok = false; break; }
+                    it = sc_id.emplace(key, ns | ((int)mult.size() << 3) | ((int)sp_ent.size() << 10)).first;
+                    sp_ent.insert(sp_ent.end(), ent.begin(), ent.end());
+                }
+                desc_of[cp] = it->second;
+            }
+            for (int p = 0; p < P && c->table_ok; ++p) rowsC[p].rest = desc_of[c->p_cls[p]];
+            if (c->Tm >= (1 << 16)) c->table_ok = false;
+        }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
         // allocatable by contract (include/simon_hip.h), so normally this IS the caller's partition; splitting a class that
         // does not keeps the kernel's "shape follows from class" exact for any input.
         // With GPU requests in the stream (REST) a class is also split into its nodes with and without devices when that fits: a GPU
         // request then excludes the units of a device-less class as a whole (one compare per 64 positions in rest_select) and a
         // class with devices holds candidates only.
+        // SPREAD: a class is also split by the domains of the zone-like keys of the soft spread terms (sub = the domains, 5 bits each, 0 =
+        // the label is missing): a summary unit then has ONE zone term and "which zones hold a scored node" follows from the feasible-node
+        // counters per (signature, class).
         std::map<std::tuple<int32_t, uint32_t, uint32_t, int>, int> cls_id;
         std::vector<ShapeRow> shapes;
-        std::vector<int32_t> orig_of, ncls_t(N);
+        std::vector<int32_t> orig_of, ncls_t(N), sub_of_class;
         bool split_gpu = c->rest && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty() && !c->no_gpu_split;
         if (split_gpu) {
             std::set<std::tuple<int32_t, uint32_t, uint32_t, int>> keys;
             for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
             split_gpu = (int)keys.size() <= kTableMaxClasses;
         }
+        auto zone_sub = [&](int j) -> int {
+            int sub = 0;
+            for (size_t z = 0; z < c->sp_zkeys.size(); ++z) sub |= (c->topo_dom[(size_t)c->sp_zkeys[z] * N + j] + 1) << (5 * z);
+            return sub;
+        };
         for (int j = 0; j < N && c->table_ok; ++j) {
-            auto key = std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
+            auto key = std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
                 if ((int)shapes.size() == kTableMaxClasses) { c->table_ok = false; break; }
@@ -526,6 +643,7 @@ int stage_narrow(simon_ctx* c) {
                 sh.rc100_c = 100.0 * sh.rc_c; sh.rc100_m = 100.0 * sh.rc_m;
                 shapes.push_back(sh);
                 orig_of.push_back(c->node_class[j]);
+                sub_of_class.push_back(std::get<3>(key));
             }
             ncls_t[j] = it->second;
         }
@@ -599,6 +717,21 @@ int stage_narrow(simon_ctx* c) {
                 HIP_TRY(c, c->d_gsig.upload(gsigs, st)); HIP_TRY(c, c->d_gpu_cnt.upload(gcnt, st));
                 HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
             }
+            if (c->spread) {
+                std::vector<int32_t> sp_term(std::max(c->Tm, 1), 0);
+                for (int t = 0; t < c->Tm; ++t)
+                    sp_term[t] = c->sp_kind[t] | (c->sp_row[t] << 2) | (c->sp_zslot[t] << 16) | ((c->term_set[t] + 1) << 19);
+                const int nzk = (int)c->sp_zkeys.size();
+                std::vector<signed char> zdom((size_t)std::max(nzk, 1) * Ct, 0);
+                for (int z = 0; z < nzk; ++z)
+                    for (int d = 0; d < Ct; ++d) zdom[(size_t)z * Ct + d] = (signed char)(((sub_of_class[d] >> (5 * z)) & 31) - 1);
+                if (sp_ent.empty()) sp_ent.push_back(0);
+                std::vector<uint64_t> sets = c->node_sets;
+                if (sets.empty()) sets.push_back(0);
+                HIP_TRY(c, c->d_sp_ent.upload(sp_ent, st)); HIP_TRY(c, c->d_sp_term.upload(sp_term, st));
+                HIP_TRY(c, c->d_cls_zdom.upload(zdom, st)); HIP_TRY(c, c->d_spread_log.upload(c->spread_log, st));
+                HIP_TRY(c, c->d_node_sets.upload(sets, st));
+            }
             HIP_TRY(c, hipStreamSynchronize(st));
         }
     }
@@ -639,6 +772,7 @@ int stage(simon_ctx* c) {
     if (!c->has_gpu)
         for (int p = 0; p < c->P; ++p) if (c->p_gpu_mem[p] > 0) { c->has_gpu = true; break; }
     choose_variant(c);
+    if (c->variant != SIMON_KERNEL_NARROW) c->spread = false;         // (a later precondition sent the problem to the all-feature kernel)
     // prefix sums of allocatable for the occupancy caps (satisfyResourceSetting, apply.go:737-760)
     std::vector<int64_t> pc(c->N + 1, 0), pm(c->N + 1, 0);
     for (int j = 0; j < c->N; ++j) { pc[j + 1] = pc[j] + c->alloc_cpu[j]; pm[j + 1] = pm[j] + c->alloc_mem[j]; }
@@ -721,6 +855,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
+    c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
@@ -1027,7 +1162,8 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             // 256 scenarios 7.7 ms, 4 096 14.0 ms, 8 192 27.5 ms one-level / 32.3 ms two-level; 100 signatures 39.5 / 32.1 ms):
             // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
-            const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest) + c->lds_pad;
+            const int nzk = c->spread ? (int)c->sp_zkeys.size() : -1;
+            const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest, nzk) + c->lds_pad;
             const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
             auto cost = [&](int fits, double factor) {
@@ -1040,19 +1176,20 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             if (c->force_coarse >= 0) coarse = c->force_coarse ? coarse_ok : !fine_ok && coarse_ok;
             if (c->rest) coarse = coarse_ok;                        // the REST path is built on the two-level layout
             if (c->n_sigs > 128) coarse = coarse_ok;                // ... and so are the signature groups beyond 128 (simon_table.hip: MANY)
+            if (c->spread) coarse = coarse_ok;                      // ... and the SPREAD path (generation 7)
             c->table_coarse = coarse;
             for (int s = 0; s < S; ++s) c->scen_ni[s] = coarse ? ni64[s] : ni16[s];
             const int ni_top = coarse ? top64 : top16;
             c->table_ni_top = ni_top;
             std::vector<unsigned long long> ws_off(S);
             size_t off = 0;
-            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0, c->rest ? (int)c->zone_keys.size() : 0); }
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0, c->rest ? (int)c->zone_keys.size() : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0); }
             c->ws_total = off;
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY); else generation 2 / all-feature kernel
-            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest));
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest && !c->spread)) && (!c->spread || coarse);
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1140,11 +1277,11 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest) + c->lds_pad : 0;
-        bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? (int)c->sp_zkeys.size() : -1) + c->lds_pad : 0;
+        bool use_table = c->table_ok && c->table_perm_ok && !(c->spread && c->has_ranks) && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || !c->raw_fits_lds || c->has_ranks || c->has_static;
+        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || !c->raw_fits_lds || c->has_ranks || c->has_static;
         // Beyond 256 signatures generation 2 (register-resident state, every node re-evaluated per cycle: its time does not depend on
         // the signature count) overtakes the score table (measured, profiles/r03: 300 signatures 124 ms against 119 ms, 384: 169 ms) --
         // where it is eligible; otherwise the table (K <= 384) still beats the all-feature kernel by far.
@@ -1170,6 +1307,10 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 cold.xrows = c->d_xrows.p; cold.zdom = c->d_zdom.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
+            if (c->spread) {
+                cold.sp_ent = c->d_sp_ent.p; cold.sp_term = c->d_sp_term.p; cold.spread_log = c->d_spread_log.p;
+                cold.node_sets = c->d_node_sets.p; cold.set_words = (c->N + 63) / 64; cold.cls_zdom = c->d_cls_zdom.p;
+            }
             const bool tprof = c->table_prof;
             if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 12)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 96, c->stream)); cold.prof = c->d_table_prof.p; }
             HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
@@ -1178,9 +1319,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.aff = c->rest && !c->aff_idx.empty();
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)
@@ -1261,7 +1402,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     c->stats.kernel_ms = ms;
     c->stats.n_launches = 1;
     c->stats.kernel_variant = variant_used;
-    c->stats.kernel_generation = table_used ? (c->rest ? 6 : c->table_coarse ? 5 : 4) : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
+    c->stats.kernel_generation = table_used ? (c->spread ? 7 : c->rest ? 6 : c->table_coarse ? 5 : 4) : variant_used == SIMON_KERNEL_NARROW_FAST ? 2 : variant_used == SIMON_KERNEL_NARROW ? 1 : 0;
     c->stats.workgroup_size = T;
     c->stats.slots_per_lane = slots;
     c->stats.lds_bytes = (int64_t)lds;

@@ -36,6 +36,7 @@ struct TableScalars {
     int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present; bit 3: record TableCold::gpu_slices
     int32_t NZ;          // REST: topology keys that are NOT node-level (a term on one marks every position of the pod's domain)
     int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
+    int32_t TH, TZ, NZK; // SPREAD: hostname-key term rows, zone-key term rows, zone-like topology keys (class split)
     int32_t ni_max;      // padded (class-major) scenario size bound of this launch (multiple of 16, <= 4096; coarse: of 64, <= 8192)
     uint64_t g_cpu, g_mem;
 };
@@ -62,6 +63,14 @@ struct TableCold {
     const uint32_t *xsig, *xalloc, *i_xused;
     const int32_t* zdom;            // [NZ][N] domain of a node under a zone-like key (-1: no label)
     unsigned long long* gpu_slices; // [S][P] by pod id: devices Reserve booked (simon_batch_out.gpu_slices), written when TableScalars::static_tables & 8
+    // SPREAD (soft PodTopologySpread constraints, generation 7): per pod class [soft constraints..., counted terms...] in sp_ent
+    // (soft: term slot | maxSkew << 16 | SIMON_SPREAD_DUP_KEY bit 30; counted: term slot), per term slot kind (1 hostname-like row, 2
+    // zone-like row) | row << 2 | zone key slot << 16 | (node set + 1) << 19; Go's math.Log table; node sets; zone domain of a class
+    const int32_t *sp_ent, *sp_term;
+    const double* spread_log;       // [N + 1] math.Log(float64(i + 2)) (simon_class_tables.spread_log)
+    const uint64_t* node_sets;      // [R][set_words]
+    int32_t set_words;
+    const signed char* cls_zdom;    // [NZK][Cn] domain of an internal node class under zone key slot z (-1: the label is missing)
     const int32_t* gpu_cnt;         // [N]
     const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)
 };
@@ -71,6 +80,7 @@ struct TableLaunch {
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
     unsigned char* ws;   // HBM workspace: byte table + node state (+ per-16 summary entries and counters when coarse) of every scenario
+    bool spread;         // some pod class carries soft spread constraints (generation 7; implies coarse, excludes rest)
     bool aff;            // some pod class carries required-affinity entries (REST)
     bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
     bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
@@ -86,10 +96,12 @@ constexpr size_t kTableLdsPerCU = 160 * 1024;
 constexpr int kTableMaxGpuSigs = 32;    // distinct (gpu-mem, gpu-count) requests: one mask row and one lane each
 constexpr int kTableMaxXres = 32;       // distinct (ephemeral-storage, extended-resource) requests: one mask row and one lane each
 constexpr int kTableMaxTerms = 120;     // node-level anti-affinity terms: two mask rows each
+constexpr int kSpreadMaxZoneDom = 16;    // domains of a zone-like key of a soft spread constraint (one u32 counter each)
+constexpr int kSpreadMaxHostTerms = 4096, kSpreadMaxZoneTerms = 1024, kSpreadMaxZoneKeys = 3;
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest);        // LDS per workgroup for padded scenario sizes up to ni_max
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ);  // HBM workspace of ONE scenario with ni padded positions
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD)
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0);  // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

@@ -129,10 +129,30 @@ __device__ __forceinline__ unsigned row16_max_t(unsigned v) {
     return v;
 }
 
+// wave64 sum / or on the DPP pattern of simon_device.h's wave_max (identity 0 in the lanes a row broadcast does not reach)
+__device__ __forceinline__ int wave_sum_i32_t(int v) {
+    v += SIMON_DPP(0, v, 0xB1, 0xF);
+    v += SIMON_DPP(0, v, 0x4E, 0xF);
+    v += SIMON_DPP(0, v, 0x141, 0xF);
+    v += SIMON_DPP(0, v, 0x140, 0xF);
+    v += SIMON_DPP(0, v, 0x142, 0xA);
+    v += SIMON_DPP(0, v, 0x143, 0xC);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned wave_or_u32_t(unsigned v) {
+    v |= (unsigned)SIMON_DPP(0, (int)v, 0xB1, 0xF);
+    v |= (unsigned)SIMON_DPP(0, (int)v, 0x4E, 0xF);
+    v |= (unsigned)SIMON_DPP(0, (int)v, 0x141, 0xF);
+    v |= (unsigned)SIMON_DPP(0, (int)v, 0x140, 0xF);
+    v |= (unsigned)SIMON_DPP(0, (int)v, 0x142, 0xA);
+    v |= (unsigned)SIMON_DPP(0, (int)v, 0x143, 0xC);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, zdom, az, ucls, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -146,7 +166,7 @@ __host__ __device__ inline int table_nbp(int nblk) { return (nblk & 1) || (nblk 
 // signatures keep 16+ scenario waves per CU -- and the per-16 entries move to the scenario's HBM workspace, where only the assume
 // reads them (4 entries = 8 bytes per signature, fetched with the table row, off the dependent chain); the feasible-node counters
 // move there too (touched on the rare cycle a node becomes infeasible for a signature).  Classes are then padded to 64 positions.
-__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse, bool rest) {
+__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1) {
     auto al = [](int x) { return (x + 15) & ~15; };
     TCarve c;
     c.nbp = table_nbp(ni_max / (coarse ? 64 : 16));
@@ -158,6 +178,11 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
     (void)rest;
+    // SPREAD (nzk >= 0): zone domain of a class per zone-like key, the per-class zone terms of the pod being placed (4 constraints x
+    // Cn doubles), the "ignored" flag of a class and the class of every summary unit
+    c.zdom = o; o += nzk >= 0 ? al((nzk > 0 ? nzk : 1) * Cn) : 0;
+    c.az = o; o += nzk >= 0 ? al(4 * Cn * 8 + Cn) : 0;
+    c.ucls = o; o += nzk >= 0 ? al(c.nbp) : 0;
     c.total = o;
     return c;
 }
@@ -167,12 +192,14 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
 // ... and (REST, M mask rows) the position masks [ni / 16][M] u16 and the GPU devices of every position: used [ni][8], per-device
 // total [ni], device count [ni] (u32 each), extra-resource Requested [ni][8] and allocatable [ni][8], and the topology domain of every
 // position under the NZ keys that are not node-level [NZ][ni] u16
-__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ) {
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
     if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2 + (((size_t)M * 4 + 127) & ~(size_t)127);
+    // SPREAD: matching pods per (hostname-key term, position) u8 [TH][ni], per (zone-key term, domain) u32 [TZ][16]
+    if (TH > 0 || TZ > 0) w += (((size_t)TH * ni + 127) & ~(size_t)127) + (((size_t)TZ * 16 * 4 + 127) & ~(size_t)127);
     return w;
 }
 
@@ -258,7 +285,9 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
 // MANY: more than 128 signatures (KQ = 2, two-level summary, no REST): signatures 0 .. 127 live in lane registers as usual, the rest is
 // refreshed from TableCold::sigs in up to two further groups of 128 whose table rows are fetched WITH group 0's (one memory round
 // trip per cycle; own instantiation: the extra rows cost ~40 VGPRs the K <= 128 kernels must not pay).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY>
+// SPREAD (generation 7): pod classes with soft PodTopologySpread constraints (ScheduleAnyway: the system defaults every pod a Service /
+// ReplicaSet / StatefulSet selects gets, podtopologyspread/plugin.go:39-50) -- see spread_select.
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD>
 __global__ __launch_bounds__(64) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -288,7 +317,13 @@ __global__ __launch_bounds__(64) void table_kernel(
 #endif
     static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST);
+    static_assert(!SPREAD || (COARSE && !REST && !MANY), "SPREAD is built on the two-level layout, without the REST rows");
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? sc.NZK : -1);
+    const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
+    signed char* s_zdom = (signed char*)(smem + cv.zdom);          // SPREAD: [NZK][Cn]
+    double* s_az = (double*)(smem + cv.az);                         // SPREAD: [4][Cn] zone terms of the pod being placed
+    unsigned char* s_ign = smem + cv.az + 4 * Cn * 8;               // SPREAD: [Cn] class lacks a key of the pod's constraints
+    unsigned char* s_ucls = smem + cv.ucls;                         // SPREAD: [units] node class of a summary unit
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
@@ -343,6 +378,9 @@ __global__ __launch_bounds__(64) void table_kernel(
     unsigned* g_xalloc = g_xused + (size_t)ni * 8;                    // [ni][8]: their allocatable
     unsigned short* g_pdom = (unsigned short*)(g_xalloc + (size_t)ni * 8);   // [NZ][ni]: domain under a zone-like key, 0xFFFF = no label
     unsigned* g_rowtot = (unsigned*)(g_pdom + (size_t)NZ * ni);       // [M]: pods that set the row so far (term totals of required affinity)
+    // SPREAD (never together with REST: M == 0, so the block starts where the REST rows would): placed pods a term's selector matches
+    unsigned char* g_hrow = (unsigned char*)g_xm;                     // [TH][ni] per position (hostname-like key: domain = node)
+    unsigned* g_zcnt = (unsigned*)(g_hrow + (((size_t)TH * ni + 127) & ~(size_t)127));   // [TZ][16] per domain of a zone-like key
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -415,7 +453,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 const int nfe = __popcll(__ballot(b != 0));
                 if (lane == 0) {
                     s_sum[k * nbp + (p0 >> 6)] = (unsigned short)c64;
-                    if (nfe) atomicAdd(&g_cnt[k * Cn + d], nfe);
+                    if (nfe) g_cnt[k * Cn + d] += nfe;                     // lane 0 alone, chunk after chunk: plain (see the refresh)
                 }
             } else {
                 if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
@@ -478,6 +516,12 @@ __global__ __launch_bounds__(64) void table_kernel(
                 if ((lane & 15) == 0) g_xm[(size_t)(M - NZ + z) * nblk + (p >> 4)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
             }
         }
+    }
+    if constexpr (SPREAD) {
+        for (int u = lane; u < nun; u += 64) s_ucls[u] = (unsigned char)class_of_pos(u * UNIT);
+        for (int i = lane; i < (NZK > 0 ? NZK : 1) * Cn; i += 64) s_zdom[i] = NZK > 0 ? cold->cls_zdom[i] : (signed char)0;
+        for (size_t i = lane; i < ((size_t)TH * ni + 3) / 4; i += 64) ((unsigned*)g_hrow)[i] = 0u;     // no pod placed yet
+        for (int i = lane; i < TZ * 16; i += 64) g_zcnt[i] = 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -816,6 +860,141 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
     };
 
+    // ---- SPREAD path (generation 7) ---------------------------------------------------------------------------------------
+    // PodTopologySpread, soft (ScheduleAnyway) constraints: PreScore + Score + NormalizeScore (podtopologyspread/scoring.go:60-256).
+    // raw(node) = int64(sum_e count_e[domain_e(node)] * log(size_e + 2) + (maxSkew_e - 1)), score = 100 (max + min - raw) / max over the
+    // feasible nodes that carry every constraint key (the others score 0), weight 2.  The count of a constraint on a hostname-like key
+    // is a byte per position (g_hrow), on a zone-like key a counter per domain (g_zcnt) -- and the internal node classes are split by
+    // zone domain (host), so a summary unit has ONE zone term.  size_e = scored nodes (hostname) or distinct zones among them: both
+    // follow from the feasible-node counters per (signature, class).  The raw score changes on every node of a zone per placement, so
+    // the summaries cannot carry it: a spread pod scans its signature's row, one position per lane, 64 positions per step, twice
+    // (minimum / maximum of the raw scores, then totals), and takes the first maximum in canonical order (the static per-class node
+    // lists give the canonical index of a position).  Everything else about the cycle -- assume, column refresh, summaries -- is the
+    // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | offset << 10 into TableCold::sp_ent; lane e
+    // holds entry e (`spv`).
+    const int sp_N = SPREAD ? cold->N : 0;
+    auto spread_select = [&](int k, int soft_n, int spv, int& dstar, int& res) -> int {
+        const int dd = lane < Cn ? lane : 0;
+        const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
+        int kind[4], rowi[4], zsl[4], skew[4];
+        bool dup[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ent = __builtin_amdgcn_readlane(spv, e);
+            const int ti = e < soft_n ? __builtin_amdgcn_readfirstlane(cold->sp_term[ent & 0xFFFF]) : 0;
+            kind[e] = ti & 3; rowi[e] = (ti >> 2) & 0x3FFF; zsl[e] = (ti >> 16) & 7;
+            skew[e] = (ent >> 16) & 0x3FFF; dup[e] = (ent >> 30) & 1;
+        }
+        bool ign = false;                                                 // IgnoredNodes (:80-85): a constraint key is missing
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < soft_n && kind[e] == 2) ign = ign || s_zdom[zsl[e] * Cn + dd] < 0;
+        const bool scored = lane < Cn && cntd > 0 && !ign;
+        const int F = wave_sum_i32_t(scored ? cntd : 0);                  // len(filteredNodes) - len(IgnoredNodes)
+        double w[4], cst[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                     // TopologyNormalizingWeight (:98-106, :279-281)
+            int size = 0;
+            if (e < soft_n && !dup[e]) {
+                if (kind[e] == 1) size = F;
+                else size = __popc(wave_or_u32_t(scored ? 1u << (s_zdom[zsl[e] * Cn + dd] & 31) : 0u));
+            }
+            w[e] = e < soft_n ? cold->spread_log[size] : 0.0;
+            cst[e] = (double)(skew[e] - 1);
+        }
+        if (lane < Cn) {
+            s_ign[dd] = ign ? 1 : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < soft_n && kind[e] == 2) {
+                    const int zd = s_zdom[zsl[e] * Cn + dd];
+                    const unsigned cz = zd >= 0 ? g_zcnt[rowi[e] * 16 + zd] : 0u;
+                    s_az[e * Cn + dd] = (double)cz * w[e] + cst[e];        // scoreForCount (:287-289) of the class's zone
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned koff16 = (unsigned)k * 16u;
+        // raw score of this lane's position of unit u (class c): the constraints in list order (float addition is not associative)
+        auto raw_of = [&](int u, int c) -> int {
+            double scv = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < soft_n) {
+                    double A;
+                    if (kind[e] == 1) A = (double)g_hrow[(size_t)rowi[e] * ni + (unsigned)(u * 64 + lane)] * w[e] + cst[e];
+                    else A = s_az[e * Cn + c];
+                    scv = scv + A;
+                }
+            return (int)scv;
+        };
+        auto unit_class = [&](int u) -> int { return __builtin_amdgcn_readfirstlane((int)s_ucls[u]); };
+        int pmin = 0x7fffffff, pmax = 0;
+        for (int u = 0; u < nun; ++u) {                                   // pass 1: minimum / maximum over the scored feasible nodes
+            const int c = unit_class(u);
+            const unsigned byte = g_tile[(unsigned)(u * 4 + (lane >> 4)) * Krow + koff16 + (unsigned)(lane & 15)];
+            const int raw = raw_of(u, c);
+            const bool ok = byte != 0u && !s_ign[c];
+            pmin = ok && raw < pmin ? raw : pmin;
+            pmax = ok && raw > pmax ? raw : pmax;
+        }
+        pmin = wave_min_i32(pmin);
+        pmax = wave_max_i32(pmax);
+        const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
+        unsigned bkey = 0;
+        int bpos = 0;
+        for (int u = 0; u < nun; ++u) {                                   // pass 2: totals, first maximum in canonical order
+            const int c = unit_class(u);
+            const unsigned byte = g_tile[(unsigned)(u * 4 + (lane >> 4)) * Krow + koff16 + (unsigned)(lane & 15)];
+            const int raw = raw_of(u, c);
+            const int info = winner_info(u);                              // (offset into cls_list + 8192) | class << 16 of the unit
+            const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);   // (padding positions of the last class point past the lists)
+            const int canon = cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
+            int v = 0;                                                    // NormalizeScore (:217-256); ignored nodes score 0
+            if (!s_ign[c]) v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmax + pmin - raw)), rinv, hrinv);
+            const int total = (int)byte - 1 + (int)s_sn[k * Cn + c] + 2 * v;
+            const unsigned key = byte != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon) : 0u;
+            if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
+        }
+        const unsigned best = wave_max_u32(bkey);
+#ifdef SIMON_SPREAD_DEBUG
+        if (lane == 0) printf("SPD s=%d k=%d soft=%d kind=%d,%d row=%d,%d zsl=%d,%d skew=%d,%d F=%d w=%g,%g pmin=%d pmax=%d best=%u nun=%d Cn=%d\n", s, k, soft_n, kind[0], kind[1], rowi[0], rowi[1],
+                              zsl[0], zsl[1], skew[0], skew[1], F, w[0], w[1], pmin, pmax, best, nun, Cn);
+        if (lane < Cn) printf("SPD   class %d cnt %d ign %d zdom0 %d az0 %g az1 %g sn %d\n", lane, cntd, (int)ign, (int)s_zdom[dd], s_az[dd], s_az[Cn + dd], (int)s_sn[k * Cn + dd]);
+#endif
+        if (best == 0u) return -1;
+        const int wl = __builtin_ctzll(__ballot(bkey == best));
+        const int pstar = __builtin_amdgcn_readlane(bpos, wl);
+        const int info = winner_info(pstar >> 6);
+        dstar = info >> 16;
+        res = (info & 0xFFFF) - 8192 + pstar;
+        return pstar;
+    };
+    // AddPod's side of the counters (podtopologyspread/scoring.go:129-160 counts the pods ON the nodes; here they are counted as
+    // they land): lane soft_n + e holds counted entry e = term slot | multiplicity << 16 (terms are distinct per class: plain
+    // read-modify-writes of distinct bytes / words).  A term counts only on the nodes of its node set (scoring.go:137-141).
+    auto spread_count = [&](int pstar, int dstar, int res, int spv, int soft_n, int match_n) {
+        const int e = lane - soft_n;
+        if (e < 0 || e >= match_n) return;
+        const int ti = cold->sp_term[spv & 0xFFFF];
+        const unsigned mult = ((unsigned)spv >> 16) & 0xFFu;
+        const int kindt = ti & 3, rowt = (ti >> 2) & 0x3FFF, zst = (ti >> 16) & 7, set = ((ti >> 19) & 0xFFF) - 1;
+#ifdef SIMON_SPREAD_DEBUG
+        printf("SPC s=%d lane=%d e=%d spv=%x ti=%x mult=%u kind=%d row=%d set=%d pstar=%d dstar=%d res=%d\n", s, lane, e, spv, ti, mult, kindt, rowt, set, pstar, dstar, res);
+#endif
+        if (set >= 0) {
+            const int jn = cls_list[rk_off + (unsigned)res];              // the node itself (canonical pool index)
+            if (!((cold->node_sets[(size_t)set * cold->set_words + (jn >> 6)] >> (jn & 63)) & 1ull)) return;
+        }
+        if (kindt == 1) {
+            unsigned char* hp = g_hrow + (size_t)rowt * ni + (unsigned)pstar;
+            *hp = (unsigned char)(*hp + mult);
+        } else if (kindt == 2) {
+            const int zd = s_zdom[zst * Cn + dstar];
+            if (zd >= 0) g_zcnt[rowt * 16 + zd] += mult;
+        }
+    };
+
     int unsched = 0;
     int32_t* __restrict__ place = place_step ? place_step + (size_t)s * P : nullptr;
 
@@ -840,8 +1019,11 @@ __global__ __launch_bounds__(64) void table_kernel(
         TPROF(0);                                                      // loop control, placement flush, pod chunk
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0x3FF, r_cls = (pk >> 10) & 0x1FFFFF;
-        const int rw = REST ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST descriptor (0: the score table alone decides the pod)
-        const int r_gs = (rw & 63) - 1, r_xs = ((rw >> 6) & 63) - 1, r_nrows = (rw >> 12) & 63;
+        const int rw = (REST || SPREAD) ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST / SPREAD descriptor (0: the score table alone decides the pod)
+        const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0;
+        int spv = 0;                                                       // SPREAD: lane e holds entry e of the pod's constraint / counted-term list
+        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match) spv = cold->sp_ent[((unsigned)rw >> 10) + lane];
+        const int r_gs = REST ? (rw & 63) - 1 : -1, r_xs = REST ? ((rw >> 6) & 63) - 1 : -1, r_nrows = REST ? (rw >> 12) & 63 : 0;
         int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
         if (REST && lane < r_nrows) rowv = cold->xrows[((unsigned)rw >> 18) + lane];
         unsigned rtv = 0;                                                  // lane e: placed pods counted on entry e's row (required affinity)
@@ -881,6 +1063,15 @@ __global__ __launch_bounds__(64) void table_kernel(
         } else if (REST && __builtin_expect(rw != 0, 0)) {                 // (cold for the register allocator: spills belong here)
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv), dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
+            if (pstar < 0) { ++unsched; res = -1; }
+        } else if (SPREAD && sp_soft != 0) {                               // a pod with soft spread constraints: every node's score moves
+            const int k = r_sig;
+            const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
+            if ((dq >> (k >> 6)) & 1u) {                               // the class terms of row k (s_sn) must be current
+                renormalise(k, r_cls);
+                if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
+            }
+            pstar = spread_select(k, sp_soft, spv, dstar, res);
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
@@ -1087,7 +1278,9 @@ __global__ __launch_bounds__(64) void table_kernel(
                     if (!nb) {                                            // the node stopped being feasible for this signature
                         const int cidx = k * Cn + dstar;
                         int left;
-                        if constexpr (COARSE) left = atomicSub(&g_cnt[cidx], 1) - 1;
+                        // plain read-modify-write (lane-local: a (signature, class) counter belongs to the lane that owns the signature):
+                        // an atomic is performed in L2 and would leave the wave's later plain loads of the counter to a stale L1 line
+                        if constexpr (COARSE) { left = g_cnt[cidx] - 1; g_cnt[cidx] = left; }
                         else { left = s_cnt[cidx] - 1; s_cnt[cidx] = left; }
                         if (left == 0) my_dirty |= 1u << dirty_bit;       // the class term of row k changes: re-base before its next use
 #ifdef SIMON_TABLE_DEBUG
@@ -1118,6 +1311,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             }
             TPROF(9);                                                  // evaluation, patch, block key, summary / table stores
             if (REST && __builtin_expect(rw != 0, 0)) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs, i0 + il);
+            if (SPREAD && sp_match != 0) spread_count(pstar, dstar, res, spv, sp_soft, sp_match);
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // REST: term rows, GPU commit and GPU rows
         }
@@ -1168,16 +1362,16 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false, bool SPREAD = false>
 static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (REST && !AFF) {
         if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true>(a, n_blocks, lds, st);
     }
-    if constexpr (KQ == 2 && COARSE && !REST && !MANY) {              // more than 128 signatures: the instantiation with further groups
+    if constexpr (KQ == 2 && COARSE && !REST && !MANY && !SPREAD) {   // more than 128 signatures: the instantiation with further groups
         if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, false, true>(a, n_blocks, lds, st);
     }
     if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;       // simon_hip.hip keeps such batches away (two-level, no REST)
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY>;
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY, SPREAD>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -1195,6 +1389,11 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
             return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true, true>(a, n_blocks, lds, st)
                                           : launch_t6<M, Z, PIN, KQ, 2, true, true>(a, n_blocks, lds, st);
     }
+    if (a.spread) {                                                   // soft spread constraints: two-level layout, pool order (no per-scenario ranks)
+        if (!a.coarse || a.rest || a.sc.rk_stride != 0) return hipErrorInvalidValue;
+        return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, false, false, false, true>(a, n_blocks, lds, st)
+                                      : launch_t7<M, Z, PIN, KQ, 2, true, false, false, false, false, true>(a, n_blocks, lds, st);
+    }
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
         return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 2, true>(a, n_blocks, lds, st);
     }
@@ -1203,8 +1402,8 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
            : nblk <= 128 ? launch_t6<M, Z, PIN, KQ, 2, false>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 4, false>(a, n_blocks, lds, st);
 }
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest) { return (size_t)tcarve(K, ni_max, Cn, coarse, rest).total; }
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ) { return table_ws_of(K, ni, nzeq, coarse, Cn, M, NZ); }
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk) { return (size_t)tcarve(K, ni_max, Cn, coarse, rest, nzk).total; }
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH, int TZ) { return table_ws_of(K, ni, nzeq, coarse, Cn, M, NZ, TH, TZ); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {

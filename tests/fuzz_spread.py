@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of generation 7 (soft PodTopologySpread constraints on the score-table kernel): random sizes, feature
+subsets and scenario batches; every placement, unscheduled count and used cpu / memory against the oracle.
+Not collected by pytest; by hand on a GPU box:   python tests/fuzz_spread.py [n_cases] [first_seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conftest  # noqa: E402,F401
+import oracle_lib as O  # noqa: E402
+import randprob  # noqa: E402
+from open_simulator_amd import capi  # noqa: E402
+
+FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small"]
+
+
+def one_case(case):
+    rng = np.random.default_rng(88000 + case)
+    size = case % 3
+    N = int(rng.integers(2, 90)) if size == 0 else int(rng.integers(100, 900)) if size == 1 else int(rng.integers(900, 3000))
+    P = int(rng.integers(20, 500 if size == 0 else 2500))
+    feat = {f: True for f in FEATURES if rng.random() < 0.3}
+    if size == 2:
+        feat.pop("static_mask", None)
+    prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=True, n_node_classes=int(rng.choice([1, 2, 4, 9])),
+                                 n_pod_classes=int(rng.choice([1, 3, 8, 30, 60])), **feat)
+    scen, orders = randprob.rand_scenarios(case, prob, S=int(rng.integers(1, 8)), min_n=1 if rng.random() < 0.4 else None)
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        st = ctx.stats()
+    ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
+          res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
+    return ok, dict(case=case, N=N, P=P, S=len(scen), feat=sorted(feat), generation=st.kernel_generation, variant=st.kernel_variant)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = on7 = 0
+    for case in range(first, first + n_cases):
+        ok, info = one_case(case)
+        on7 += info["generation"] == 7
+        if not ok:
+            bad += 1
+            print("MISMATCH", info, flush=True)
+    print(f"fuzz_spread: {n_cases} cases from {first}, {on7} on generation 7, mismatches {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

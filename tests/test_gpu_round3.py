@@ -97,3 +97,29 @@ def test_many_signatures_fall_back_correctly(n_sigs):
         res = ctx.run_batch(scen, orders)
         assert ctx.stats().kernel_generation == 2
     assert_same(res, ref)
+
+
+SPREAD_FEATURES = [dict(), dict(static_mask=True), dict(presets=True, gates=True), dict(pins=True, tight_pods=True), dict(nz_differs=True, init_state=True),
+                   dict(zero_pods=True, odd_units=True), dict(static_small=True)]
+
+
+@pytest.mark.parametrize("idx", range(len(SPREAD_FEATURES)))
+def test_soft_spread_constraints_on_the_score_table_kernel(idx):
+    """Generation 7: pods with soft PodTopologySpread constraints (hostname-like + zone-like keys, node sets, several constraints per
+    class, unlabeled nodes = IgnoredNodes) stay on the score-table kernel; every placement against the oracle, and the same problems on
+    the all-feature kernel (SIMON_NO_SPREAD=1)."""
+    feat = SPREAD_FEATURES[idx]
+    for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500)]):
+        prob = randprob.rand_problem(7000 + 10 * idx + seed, N=N, P=P, spread_soft=True, n_node_classes=4, n_pod_classes=9, **feat)
+        scen, orders = randprob.rand_scenarios(70 + seed, prob, S=5)
+        ref = O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders)
+            st = ctx.stats()
+        if "odd_units" not in feat:          # gcd-1 quantities leave the 31-bit fast path altogether: all-feature kernel, parity only
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7, (st.kernel_variant, st.kernel_generation)
+        assert_same(res, ref)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_SPREAD": "1"})
+    assert variant == capi.KERNEL_WIDE
+    assert_same(res, ref)
