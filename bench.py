@@ -285,6 +285,8 @@ def build_workload(args, synth, world):
         return synth.config5(n_scen=c5_scenarios(args) * world, n_orders=n_orders), n_orders
     if args.workload == "config2":
         return synth.config2(), 1
+    if args.workload == "service":             # config 3's pool and sweep, every pod selected by a Service (system-default soft spread)
+        return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods), n_orders
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
         return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
     seed = synth.SEED + (3 if world == 1 else 4)
@@ -293,6 +295,7 @@ def build_workload(args, synth, world):
 
 def workload_name(args, prob, scen_all, n_orders, S_local, world):
     head = {"config5": "BASELINE config 5-style (gpushare): ", "config2": "BASELINE config 2: ",
+            "service": "config 3 with every pod selected by a Service (system-default soft PodTopologySpread constraints): ",
             "config3sig": f"config 3 variant with {args.sigs} request signatures: "}.get(
                 args.workload, f"BASELINE config {'3' if world == 1 else '4-style'}: ")
     return (head + f"{prob.n_pods} pods x {int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, "
@@ -360,6 +363,10 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config2()
         child = ["--workload", "config2"]
         wl, label = "config3", "BASELINE config 2"
+    elif name == "service":                         # config 3 with every pod behind a Service: soft spread constraints (generation 7)
+        prob, scen, orders = synth.config_service()
+        child = ["--workload", "service"]
+        wl, label = "config3", "config 3 with Service-selected pods"
     elif name == "config3sig":                      # config 3 with SIG_RECORD request signatures: the > 128-signature regime as a number
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_RECORD)
         child = ["--workload", "config3sig", "--sigs", str(SIG_RECORD)]
@@ -369,7 +376,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": name if name == "config2" else f"config3_sigs{SIG_RECORD}" if name == "config3sig" else f"config5_S{c5_scen}"}
+    rec = {"workload": {"config2": "config2", "service": "config3_service", "config3sig": f"config3_sigs{SIG_RECORD}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
@@ -514,7 +521,7 @@ def main():
                     help="PMC counters for the roofline records: live = rocprofv3 passes over child runs (auto: live at N = 1 when "
                          "rocprofv3 exists, else the committed profile)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig"], default="config3",
+    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig", "service"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
                          "(GPU share + anti-affinity + taints) on generation 6 of the score-table kernel, --c5-scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
@@ -653,7 +660,7 @@ def main():
             out["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, local_rank)
             subs = []
             nchk5 = int(os.environ.get("SIMON_BENCH_C5_CHECK", "32"))
-            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", 3, 1, 64, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
+            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", 3, 1, 64, 0), ("service", 2, 1, 64, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
                                                  ("config5", 2, 1, nchk5, C5_SATURATING)):
                 try:
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))

@@ -250,3 +250,37 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
     counts = np.linspace(n_nodes // 2, n_nodes, n_counts).astype(np.int32)
     scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)
     return prob, np.ascontiguousarray(scen, np.int32), orders
+
+
+def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
+                   seed: int = SEED + 6):
+    """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
+    request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
+    constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
+    ScheduleAnyway, selector = the Service's).  Nodes are zoned round robin by index (j % n_zones), which keeps nodeTree.list() =
+    index order for every cluster size (V/internal/cache/node_tree.go:119-143).  Terms: per service (selector, hostname) and
+    (selector, zone); the pods of a service match both and nothing else."""
+    from .gomath import spread_log_table
+    n_total = n_het + n_counts
+    cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
+    pcpu_all, pmem_all = gen_pods(seed, n_services)                    # one request shape per service
+    rng = SplitMix64(seed ^ 0x535643)
+    svc = np.array([rng.next() % n_services for _ in range(n_pods)], np.int32)
+    pcpu, pmem = pcpu_all[svc], pmem_all[svc]
+    shapes = list(zip(pcpu_all.tolist(), pmem_all.tolist()))
+    T = 2 * n_services
+    prob = Problem(alloc_cpu=cpu, alloc_mem=mem, alloc_pods=pods, node_class=ncls,
+                   topo_dom=np.stack([np.arange(n_total, dtype=np.int32), (np.arange(n_total) % n_zones).astype(np.int32)]),
+                   topo_n_dom=np.array([n_total, n_zones], np.int32), topo_is_hostname=np.array([1, 0], np.uint8),
+                   req_cpu=pcpu, req_mem=pmem, pod_class=svc, n_pod_classes=n_services, n_node_classes=4,
+                   simon_raw=simon_raw_table(shapes),
+                   # PodTopologySpread is no longer a constant (100 x 2 of CONST_SCORE): NodePreferAvoidPods 100 x 10000 + TaintToleration 100
+                   const_score=np.full(n_services, CONST_SCORE - 200, np.int64),
+                   term_topo_key=np.tile(np.array([0, 1], np.int32), n_services), term_node_set=np.full(T, -1, np.int32),
+                   match_off=np.arange(0, T + 1, 2, dtype=np.int32), match_idx=np.arange(T, dtype=np.int32),
+                   spread_soft_off=np.arange(0, T + 1, 2, dtype=np.int32), spread_soft_idx=np.arange(T, dtype=np.int32),
+                   spread_soft_skew=np.tile(np.array([3, 5], np.int32), n_services), spread_log=spread_log_table(n_total)).normalise()
+    orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
+    counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)
+    scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)
+    return prob, np.ascontiguousarray(scen, np.int32), orders

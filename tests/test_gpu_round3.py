@@ -123,3 +123,30 @@ def test_soft_spread_constraints_on_the_score_table_kernel(idx):
     res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_SPREAD": "1"})
     assert variant == capi.KERNEL_WIDE
     assert_same(res, ref)
+
+
+def test_service_workload_full_size_subset():
+    """config 3's pool with every pod selected by a Service (synth.config_service: 60 services, system-default soft spread constraints):
+    a subset of the 4 096 benchmarked scenarios at full size (10 000 pods x 488..1 511 nodes), every placement, on generation 7; a
+    smaller instance additionally against the all-feature kernel."""
+    prob, scen, orders = synth.config_service()
+    pick = np.unique(np.linspace(0, len(scen) - 1, 24).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        st = ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7
+        res = ctx.fetch(False)
+        assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist() and res.used_cpu[pick].tolist() == ref.used_cpu.tolist()
+        for j, s_ in enumerate(pick.tolist()):
+            row = ctx.fetch_placement(s_)
+            bad = np.flatnonzero(row != ref.placement[j])
+            assert len(bad) == 0, f"scenario {s_}: {len(bad)} placements differ, first pod {bad[0]}"
+    prob, scen, orders = synth.config_service(n_counts=24, n_orders=2, n_pods=2500, n_het=200, n_services=25)
+    ref = O.run_threaded(prob, scen, orders)
+    assert_same(run_gpu(prob, scen, orders)[0], ref)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_SPREAD": "1"})
+    assert variant == capi.KERNEL_WIDE
+    assert_same(res, ref)
