@@ -295,7 +295,8 @@ bool spread_supported(simon_ctx* c) {
     if (c->has_ipa_score || !c->sh_idx.empty() || c->has_local || !c->aff_idx.empty() || !c->anti_idx.empty() || !c->port_idx.empty()) return false;
     if (c->has_gpu || c->has_gpu_index) return false;
     if (c->topo_is_hostname.empty() || c->spread_log.size() < (size_t)c->N + 1) return false;
-    for (int32_t x : c->alloc_pods) if (x > 255) return false;            // the per-position counters are bytes
+    int64_t max_pods = 0;
+    for (int32_t x : c->alloc_pods) { if (x > 255) return false; max_pods = std::max<int64_t>(max_pods, x); }   // the per-position counters are bytes
     if (c->P > 0 && c->N > 0) { /* pre-bound pods (init_npods) carry no labels: nothing to count at the start */ }
     c->sp_kind.assign(c->Tm, 0); c->sp_row.assign(c->Tm, 0); c->sp_zslot.assign(c->Tm, 0);
     c->sp_zkeys.clear();
@@ -346,7 +347,7 @@ bool spread_supported(simon_ctx* c) {
         std::map<int, int> mult;
         for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
         if ((int)mult.size() + (c->ss_off[cp + 1] - c->ss_off[cp]) > 64) return false;
-        for (auto& kv : mult) if (kv.second > 255) return false;
+        for (auto& kv : mult) if ((int64_t)kv.second * max_pods > 255) return false;   // a byte counter: pods on a node x multiplicity
     }
     return true;
 }

@@ -98,6 +98,7 @@ constexpr int kTableMaxXres = 32;       // distinct (ephemeral-storage, extended
 constexpr int kTableMaxTerms = 120;     // node-level anti-affinity terms: two mask rows each
 constexpr int kSpreadMaxZoneDom = 16;    // domains of a zone-like key of a soft spread constraint (one u32 counter each)
 constexpr int kSpreadMaxHostTerms = 4096, kSpreadMaxZoneTerms = 1024, kSpreadMaxZoneKeys = 3;
+constexpr int kSpreadTabMax = 512;       // entries of spread_select's per-pod score table in LDS: classes x (largest counter + 1, a power of two)
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD)

@@ -41,6 +41,7 @@
 #include "simon_table.h"
 
 #include <algorithm>
+#include <type_traits>
 
 // Phase profile of the scheduling cycle (profiles/build_variant.sh ... -DSIMON_TABLE_PROFILE): s_memtime stamps at the phase
 // boundaries, accumulated per wave, written to TableCold::prof ([workgroup][12] ticks).  Not compiled into the product build.
@@ -152,7 +153,7 @@ __device__ __forceinline__ unsigned wave_or_u32_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, zdom, az, ucls, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, zdom, stash, tab, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -178,11 +179,11 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
     (void)rest;
-    // SPREAD (nzk >= 0): zone domain of a class per zone-like key, the per-class zone terms of the pod being placed (4 constraints x
-    // Cn doubles), the "ignored" flag of a class and the class of every summary unit
+    // SPREAD (nzk >= 0): zone domain of a class per zone-like key; for spread_select two bytes per position and the score table of
+    // the pod being placed
     c.zdom = o; o += nzk >= 0 ? al((nzk > 0 ? nzk : 1) * Cn) : 0;
-    c.az = o; o += nzk >= 0 ? al(4 * Cn * 8 + Cn) : 0;
-    c.ucls = o; o += nzk >= 0 ? al(c.nbp) : 0;
+    c.stash = o; o += nzk >= 0 ? al(ni_max * 2) : 0;
+    c.tab = o; o += nzk >= 0 ? kSpreadTabMax * 4 : 0;
     c.total = o;
     return c;
 }
@@ -199,7 +200,7 @@ __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coa
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
     if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2 + (((size_t)M * 4 + 127) & ~(size_t)127);
     // SPREAD: matching pods per (hostname-key term, position) u8 [TH][ni], per (zone-key term, domain) u32 [TZ][16]
-    if (TH > 0 || TZ > 0) w += (((size_t)TH * ni + 127) & ~(size_t)127) + (((size_t)TZ * 16 * 4 + 127) & ~(size_t)127);
+    if (TH > 0 || TZ > 0) w += (((size_t)TH * ni + 127) & ~(size_t)127) + (((size_t)TZ * 16 * 4 + 127) & ~(size_t)127) + (((size_t)TH + 127) & ~(size_t)127);
     return w;
 }
 
@@ -269,6 +270,17 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
     return ok;
 }
 
+#ifndef SIMON_SPREAD_BATCH1
+#define SIMON_SPREAD_BATCH1 6
+#endif
+#ifndef SIMON_SPREAD_BATCH2
+#define SIMON_SPREAD_BATCH2 6
+#endif
+#ifndef SIMON_SPREAD_BATCH4
+#define SIMON_SPREAD_BATCH4 2
+#endif
+// units of 64 positions per batch of loads in spread_select: pass 1 and pass 2 of the common shape, both passes of the general one
+constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_BATCH2, kSpreadBatch4 = SIMON_SPREAD_BATCH4;
 // NBQ counts summary ENTRIES per lane: 16 positions each, or 64 with COARSE (tcarve, above).
 // REST: some pods carry filters the (signature, node) table cannot hold -- Open-Gpu-Share device memory, required anti-affinity on
 // a node-level topology key (both directions).  Those filters live as per-block POSITION MASKS xm[block][row] (u16, bit = node
@@ -288,7 +300,11 @@ __device__ __forceinline__ bool xres_fits_t(const unsigned (&req)[5], const unsi
 // SPREAD (generation 7): pod classes with soft PodTopologySpread constraints (ScheduleAnyway: the system defaults every pod a Service /
 // ReplicaSet / StatefulSet selects gets, podtopologyspread/plugin.go:39-50) -- see spread_select.
 template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD>
-__global__ __launch_bounds__(64) void table_kernel(
+#ifndef SIMON_SPREAD_WAVES
+#define SIMON_SPREAD_WAVES 4
+#endif
+// (the SPREAD instantiations hold a batch of loads in registers: kept to 128 VGPRs = four scenario waves per SIMD, the same as the others)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIMON_SPREAD_WAVES : 1))) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
     int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
@@ -321,9 +337,8 @@ __global__ __launch_bounds__(64) void table_kernel(
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? sc.NZK : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
     signed char* s_zdom = (signed char*)(smem + cv.zdom);          // SPREAD: [NZK][Cn]
-    double* s_az = (double*)(smem + cv.az);                         // SPREAD: [4][Cn] zone terms of the pod being placed
-    unsigned char* s_ign = smem + cv.az + 4 * Cn * 8;               // SPREAD: [Cn] class lacks a key of the pod's constraints
-    unsigned char* s_ucls = smem + cv.ucls;                         // SPREAD: [units] node class of a summary unit
+    unsigned short* s_stash = (unsigned short*)(smem + cv.stash);  // SPREAD: [positions] count | table byte << 8 of the pod being placed
+    int* s_tab = (int*)(smem + cv.tab);                             // SPREAD: [class << lg | count] raw score, then class term + 2 x score
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
@@ -333,6 +348,11 @@ __global__ __launch_bounds__(64) void table_kernel(
     int* s_tmp = (int*)(smem + cv.tmp);
 
     const unsigned Krow = (unsigned)K * 16u;                          // bytes of one block's rows
+    // Byte offset of (block of 16 positions, signature k) = tile_blk(block) + k * KS.  The table is [block][K][16]: a placement
+    // refreshes one block's K rows, contiguous.  SPREAD keeps [unit of 64][K][64] instead: its select walks ONE signature's bytes of
+    // every position for each pod, and 64 contiguous bytes per unit waste a quarter of the cache lines that 4 x 16 do.
+    const unsigned KS = SPREAD ? 64u : 16u;
+    auto tile_blk = [&](unsigned blk) -> unsigned { return SPREAD ? (blk >> 2) * (Krow * 4u) + (blk & 3u) * 16u : blk * Krow; };
     const int lane = threadIdx.x;
     const int s = __builtin_amdgcn_readfirstlane(perm[blockIdx.x]);
     const int n = __builtin_amdgcn_readfirstlane(scen[s].n_nodes);
@@ -381,6 +401,7 @@ __global__ __launch_bounds__(64) void table_kernel(
     // SPREAD (never together with REST: M == 0, so the block starts where the REST rows would): placed pods a term's selector matches
     unsigned char* g_hrow = (unsigned char*)g_xm;                     // [TH][ni] per position (hostname-like key: domain = node)
     unsigned* g_zcnt = (unsigned*)(g_hrow + (((size_t)TH * ni + 127) & ~(size_t)127));   // [TZ][16] per domain of a zone-like key
+    unsigned char* g_hmax = (unsigned char*)(g_zcnt + (((size_t)TZ * 16 + 31) & ~(size_t)31));   // [TH] largest counter of a hostname-key row
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             if (!NZEQ) g_nz[p] = z;
         }
         const ShapeRow sh = s_shape[d];
-        unsigned char* tp = g_tile + ((unsigned)(p >> 4) * Krow + (unsigned)(p & 15));
+        unsigned char* tp = g_tile + (tile_blk((unsigned)(p >> 4)) + (unsigned)(p & 15));
         for (int k = 0; k < K; ++k) {
             const SigRow q = sigs[k];
             unsigned b = eval_node(q.req_c, q.req_m, q.nz_c, q.nz_m, q.flags & 1u, (double)st.rq_c, (double)st.rq_m, (double)z.x,
@@ -443,7 +464,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                 const uint64_t w = static_mask[(size_t)q.cls * sc.mask_words + (j >> 6)];
                 b = ((w >> (j & 63)) & 1ull) ? b : 0u;
             }
-            if (p < ni) tp[k * 16] = (unsigned char)b;
+            if (p < ni) tp[(unsigned)k * KS] = (unsigned char)b;
             // class term still 0: every signature starts dirty and is re-based at its first use
             const unsigned m16 = row16_max_t(b ? ((b << 4) | (unsigned)(15 - (p & 15))) : 0u);
             if constexpr (COARSE) {                                   // the 64 lanes are ONE summary entry of ONE class
@@ -518,10 +539,10 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
     }
     if constexpr (SPREAD) {
-        for (int u = lane; u < nun; u += 64) s_ucls[u] = (unsigned char)class_of_pos(u * UNIT);
         for (int i = lane; i < (NZK > 0 ? NZK : 1) * Cn; i += 64) s_zdom[i] = NZK > 0 ? cold->cls_zdom[i] : (signed char)0;
         for (size_t i = lane; i < ((size_t)TH * ni + 3) / 4; i += 64) ((unsigned*)g_hrow)[i] = 0u;     // no pod placed yet
         for (int i = lane; i < TZ * 16; i += 64) g_zcnt[i] = 0u;
+        for (int i = lane; i < TH; i += 64) g_hmax[i] = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -542,7 +563,7 @@ __global__ __launch_bounds__(64) void table_kernel(
         my_zero[q] = r.flags & 1u;
         my_add_c[q] = (unsigned)r.req_c; my_add_m[q] = (unsigned)r.req_m;
         my_addz_c[q] = (unsigned)r.nz_c; my_addz_m[q] = (unsigned)r.nz_m;
-        koff[q] = (unsigned)kk[q] * 16u;
+        koff[q] = (unsigned)kk[q] * KS;
     }
     for (int j = 0; j * 64 + lane < K; ++j) my_dirty |= 1u << j;      // bit j: signature lane + 64 j starts dirty (first use re-bases it)
     // this lane's summary entries (lane, lane + 64, ...): constant of the arg-max key (low field = PMASK - position), node class,
@@ -875,7 +896,6 @@ __global__ __launch_bounds__(64) void table_kernel(
     const int sp_N = SPREAD ? cold->N : 0;
     auto spread_select = [&](int k, int soft_n, int spv, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
-        const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
         int kind[4], rowi[4], zsl[4], skew[4];
         bool dup[4];
 #pragma unroll
@@ -885,82 +905,218 @@ __global__ __launch_bounds__(64) void table_kernel(
             kind[e] = ti & 3; rowi[e] = (ti >> 2) & 0x3FFF; zsl[e] = (ti >> 16) & 7;
             skew[e] = (ent >> 16) & 0x3FFF; dup[e] = (ent >> 30) & 1;
         }
+        int nh = 0, eh = 0;                                               // hostname-like constraints (each has its own counter row)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < soft_n && kind[e] == 1) { ++nh; eh = e; }
+        // SIMPLE: at most ONE per-node term, and it comes first -- [hostname, zone] (the system defaults, plugin.go:39-50), [hostname],
+        // or zone-like constraints alone (their sum is a per-class value): raw = int64((count * w + c) + zone_term(class)).
+        const bool simple = nh == 0 || (nh == 1 && eh == 0 && soft_n <= 2);
+        const unsigned toff = (unsigned)k * KS + (unsigned)lane;         // this lane's byte of a unit's row of signature k ([unit][K][64])
+        constexpr int SB = kSpreadBatch1, SC = kSpreadBatch2, SG = kSpreadBatch4;
+        // the first loads of the walk go out before the class bookkeeping below waits for its own (memory is served in order)
+        const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
+        unsigned czv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            czv[e] = 0u;
+            if (lane < Cn && e < soft_n && kind[e] == 2) {
+                const int zd = s_zdom[zsl[e] * Cn + dd];
+                czv[e] = zd >= 0 ? g_zcnt[rowi[e] * 16 + zd] : 0u;
+            }
+        }
+        const unsigned char* hb1 = nh == 1 ? g_hrow + (size_t)rowi[eh] * ni : (const unsigned char*)g_tile;   // (no hostname term: value unused)
+        const int hmx_v = (simple && nh == 1) ? (int)g_hmax[rowi[eh]] : 0;   // largest counter of the row (uniform address)
+        unsigned byte1[SB], h1[SB];
+        auto load1 = [&](int u0) {
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int u = min(u0 + j, nun - 1);                       // a slot beyond the last unit repeats it (changes nothing)
+                byte1[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
+                h1[j] = hb1[(unsigned)(u * 64 + lane)];
+            }
+        };
+        if (simple) load1(0);
         bool ign = false;                                                 // IgnoredNodes (:80-85): a constraint key is missing
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (e < soft_n && kind[e] == 2) ign = ign || s_zdom[zsl[e] * Cn + dd] < 0;
         const bool scored = lane < Cn && cntd > 0 && !ign;
-        const int F = wave_sum_i32_t(scored ? cntd : 0);                  // len(filteredNodes) - len(IgnoredNodes)
-        double w[4], cst[4];
+        const int F = __builtin_amdgcn_readfirstlane(wave_sum_i32_t(scored ? cntd : 0));   // len(filteredNodes) - len(IgnoredNodes)
+        int sz[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                                     // TopologyNormalizingWeight (:98-106, :279-281)
-            int size = 0;
+        for (int e = 0; e < 4; ++e) {                                     // TopologyNormalizingWeight (:98-106, :279-281): its size argument
+            sz[e] = 0;
             if (e < soft_n && !dup[e]) {
-                if (kind[e] == 1) size = F;
-                else size = __popc(wave_or_u32_t(scored ? 1u << (s_zdom[zsl[e] * Cn + dd] & 31) : 0u));
+                if (kind[e] == 1) sz[e] = F;
+                else sz[e] = __popc((unsigned)__builtin_amdgcn_readfirstlane((int)wave_or_u32_t(scored ? 1u << (s_zdom[zsl[e] * Cn + dd] & 31) : 0u)));
             }
-            w[e] = e < soft_n ? cold->spread_log[size] : 0.0;
-            cst[e] = (double)(skew[e] - 1);
         }
-        if (lane < Cn) {
-            s_ign[dd] = ign ? 1 : 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < soft_n && kind[e] == 2) {
-                    const int zd = s_zdom[zsl[e] * Cn + dd];
-                    const unsigned cz = zd >= 0 ? g_zcnt[rowi[e] * 16 + zd] : 0u;
-                    s_az[e * Cn + dd] = (double)cz * w[e] + cst[e];        // scoreForCount (:287-289) of the class's zone
-                }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned koff16 = (unsigned)k * 16u;
-        // raw score of this lane's position of unit u (class c): the constraints in list order (float addition is not associative)
-        auto raw_of = [&](int u, int c) -> int {
-            double scv = 0.0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < soft_n) {
-                    double A;
-                    if (kind[e] == 1) A = (double)g_hrow[(size_t)rowi[e] * ni + (unsigned)(u * 64 + lane)] * w[e] + cst[e];
-                    else A = s_az[e * Cn + c];
-                    scv = scv + A;
-                }
-            return (int)scv;
+        // (the doubles are built where they are used: the two branches below keep different ones alive)
+        auto w_of = [&](int e) -> double { return e < soft_n ? cold->spread_log[sz[e]] : 0.0; };
+        auto cst_of = [&](int e) -> double { return (double)(skew[e] - 1); };
+        // per class, held by lane = class: the zone term of constraint e (scoreForCount, :287-289, of the class's zone)
+        auto az_of = [&](int e) -> double { return (lane < Cn && e < soft_n && kind[e] == 2) ? (double)czv[e] * w_of(e) + cst_of(e) : 0.0; };
+        // per class as well: "ignored" and the class term of the signature's row
+        const int clsw = (int)((unsigned)s_sn[k * Cn + dd] | (ign ? 0x80000000u : 0u));
+        auto lane_f64 = [&](double v, int l) -> double {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
         };
-        auto unit_class = [&](int u) -> int { return __builtin_amdgcn_readfirstlane((int)s_ucls[u]); };
         int pmin = 0x7fffffff, pmax = 0;
-        for (int u = 0; u < nun; ++u) {                                   // pass 1: minimum / maximum over the scored feasible nodes
-            const int c = unit_class(u);
-            const unsigned byte = g_tile[(unsigned)(u * 4 + (lane >> 4)) * Krow + koff16 + (unsigned)(lane & 15)];
-            const int raw = raw_of(u, c);
-            const bool ok = byte != 0u && !s_ign[c];
-            pmin = ok && raw < pmin ? raw : pmin;
-            pmax = ok && raw > pmax ? raw : pmax;
-        }
-        pmin = wave_min_i32(pmin);
-        pmax = wave_max_i32(pmax);
-        const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
         unsigned bkey = 0;
         int bpos = 0;
-        for (int u = 0; u < nun; ++u) {                                   // pass 2: totals, first maximum in canonical order
-            const int c = unit_class(u);
-            const unsigned byte = g_tile[(unsigned)(u * 4 + (lane >> 4)) * Krow + koff16 + (unsigned)(lane & 15)];
-            const int raw = raw_of(u, c);
-            const int info = winner_info(u);                              // (offset into cls_list + 8192) | class << 16 of the unit
-            const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);   // (padding positions of the last class point past the lists)
-            const int canon = cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
-            int v = 0;                                                    // NormalizeScore (:217-256); ignored nodes score 0
-            if (!s_ign[c]) v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmax + pmin - raw)), rinv, hrinv);
-            const int total = (int)byte - 1 + (int)s_sn[k * Cn + c] + 2 * v;
-            const unsigned key = byte != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon) : 0u;
-            if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
+        // Both passes (minimum / maximum of the raw scores, then totals) walk the row a batch of units at a time: the loads of a batch
+        // are issued together, so a pass costs ceil(units / batch) memory round trips instead of one per unit (a scenario's workspace
+        // lives in HBM / MALL: ~2 000 cycles each).  A slot beyond the last unit repeats it: duplicates change neither the extremes
+        // nor the first maximum.
+        // SIMPLE and small enough: raw score and total depend on (class, count) only, so both are tabulated -- one entry per lane, all
+        // the float arithmetic of the pod in a few instructions -- and the walks look them up: integer work and LDS reads per position.
+        const int hmx = __builtin_amdgcn_readfirstlane(hmx_v);
+        const int lg = 32 - __clz(hmx);                                  // counts 0 .. (1 << lg) - 1
+        const int E = Cn << lg;
+        if (simple && E <= kSpreadTabMax) {
+            const double ws = nh == 1 ? w_of(0) : 0.0, cs = nh == 1 ? cst_of(0) : 0.0;
+            // the per-class part: the zone-like constraints in list order (float addition is not associative; x + 0.0 == x)
+            double pcl = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < soft_n && kind[e] == 2) pcl = pcl + az_of(e);
+            const unsigned long long pclb = (unsigned long long)__double_as_longlong(pcl);
+            const int hmask = (1 << lg) - 1;
+            for (int i0 = 0; i0 < E; i0 += 64) {                          // raw(class, count) = int64((count * w + c) + zone terms of the class)
+                const int i = i0 + lane, c4 = min(i >> lg, Cn - 1) * 4;
+                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)pclb), hi = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)(pclb >> 32));
+                const double pc = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                const int raw = (int)(((double)(i & hmask) * ws + cs) + pc);
+                if (i < E) s_tab[i] = raw;
+            }
+            for (int u0 = 0;;) {                                          // pass 1; leaves (count, table byte) of every position in LDS
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int u = min(u0 + j, nun - 1);
+                    const int c = winner_info(u) >> 16;
+                    const int raw = s_tab[(c << lg) + ((int)h1[j] & hmask)];   // (padding positions and the no-hostname-term case read arbitrary bytes)
+                    const bool ok = (byte1[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);   // (no short circuit: no branch)
+                    pmin = min(pmin, ok ? raw : 0x7fffffff);
+                    pmax = max(pmax, ok ? raw : 0);
+                    s_stash[u * 64 + lane] = (unsigned short)(h1[j] | (byte1[j] << 8));
+                }
+                u0 += SB;
+                if (u0 >= nun) break;
+                load1(u0);
+            }
+            pmin = wave_min_i32(pmin);
+            pmax = wave_max_i32(pmax);
+            const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
+            const int pmm = pmax + pmin;
+            for (int i0 = 0; i0 < E; i0 += 64) {                          // class term + 2 x NormalizeScore (:217-256), in place
+                const int i = i0 + lane;
+                const int raw = s_tab[min(i, E - 1)];
+                const int cw = __builtin_amdgcn_ds_bpermute(min(i >> lg, Cn - 1) * 4, clsw);
+                // (an entry no feasible scored node has may lie outside [min, max]: its value is never looked up)
+                int v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmm - raw)), rinv, hrinv);
+                v = cw >= 0 ? v : 0;                                      // ignored nodes score 0
+                if (i < E) s_tab[i] = (cw & 0x7fffffff) + 2 * v;
+            }
+            for (int u0 = 0; u0 < nun; u0 += SC) {                        // pass 2: totals, first maximum in canonical order
+                int canon[SC], cbase[SC];
+                unsigned stj[SC];
+#pragma unroll
+                for (int j = 0; j < SC; ++j) {
+                    const int u = min(u0 + j, nun - 1);
+                    const int info = winner_info(u);                      // (offset into cls_list + 8192) | class << 16 of the unit
+                    const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);   // (padding positions of the last class point past the lists)
+                    canon[j] = cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
+                    stj[j] = s_stash[u * 64 + lane];
+                    cbase[j] = (info >> 16) << lg;
+                }
+                int t2[SC];
+#pragma unroll
+                for (int j = 0; j < SC; ++j) t2[j] = s_tab[cbase[j] + ((int)stj[j] & hmask)];
+#pragma unroll
+                for (int j = 0; j < SC; ++j) {
+                    const int u = min(u0 + j, nun - 1);
+                    const unsigned byte = stj[j] >> 8;
+                    const int total = (int)byte - 1 + t2[j];
+                    const unsigned key = byte != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon[j]) : 0u;
+                    if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
+                }
+            }
+        } else {
+            // several per-node terms, or class terms before the per-node one: every constraint in list order, counters re-read in pass 2
+            const unsigned char* hb[4];
+            double w[4], cst[4], azv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                 // a slot without a hostname-like constraint reads the table (value unused)
+                hb[e] = (e < soft_n && kind[e] == 1) ? g_hrow + (size_t)rowi[e] * ni : (const unsigned char*)g_tile;
+                w[e] = w_of(e); cst[e] = cst_of(e); azv[e] = az_of(e);
+            }
+            auto raw_of = [&](const unsigned (&h)[4], int c) -> int {
+                double scv = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double az = lane_f64(azv[e], c);
+                    const double ah = (double)h[e] * w[e] + cst[e];
+                    const double A = e < soft_n ? (kind[e] == 1 ? ah : az) : 0.0;
+                    scv = scv + A;
+                }
+                return (int)scv;
+            };
+            for (int u0 = 0; u0 < nun; u0 += SG) {                        // pass 1
+                unsigned byte[SG], h[SG][4];
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    const int u = min(u0 + j, nun - 1);
+                    byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
+                }
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    const int c = winner_info(min(u0 + j, nun - 1)) >> 16;
+                    const int raw = raw_of(h[j], c);
+                    const bool ok = (byte[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);
+                    pmin = min(pmin, ok ? raw : 0x7fffffff);
+                    pmax = max(pmax, ok ? raw : 0);
+                }
+            }
+            pmin = wave_min_i32(pmin);
+            pmax = wave_max_i32(pmax);
+            const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
+            for (int u0 = 0; u0 < nun; u0 += SG) {                        // pass 2
+                unsigned byte[SG], h[SG][4];
+                int canon[SG], infoj[SG];
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    const int u = min(u0 + j, nun - 1);
+                    byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
+                    const int info = infoj[j] = winner_info(u);
+                    const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);
+                    canon[j] = cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
+                }
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    const int u = min(u0 + j, nun - 1);
+                    const int c = infoj[j] >> 16;
+                    const int raw = raw_of(h[j], c);
+                    const int cw = __builtin_amdgcn_readlane(clsw, c);
+                    int v = 0;
+                    if (cw >= 0) v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmax + pmin - raw)), rinv, hrinv);
+                    const int total = (int)byte[j] - 1 + (cw & 0x7fffffff) + 2 * v;
+                    const unsigned key = byte[j] != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon[j]) : 0u;
+                    if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
+                }
+            }
         }
         const unsigned best = wave_max_u32(bkey);
 #ifdef SIMON_SPREAD_DEBUG
         if (lane == 0) printf("SPD s=%d k=%d soft=%d kind=%d,%d row=%d,%d zsl=%d,%d skew=%d,%d F=%d w=%g,%g pmin=%d pmax=%d best=%u nun=%d Cn=%d\n", s, k, soft_n, kind[0], kind[1], rowi[0], rowi[1],
                               zsl[0], zsl[1], skew[0], skew[1], F, w[0], w[1], pmin, pmax, best, nun, Cn);
-        if (lane < Cn) printf("SPD   class %d cnt %d ign %d zdom0 %d az0 %g az1 %g sn %d\n", lane, cntd, (int)ign, (int)s_zdom[dd], s_az[dd], s_az[Cn + dd], (int)s_sn[k * Cn + dd]);
+        if (lane < Cn) printf("SPD   class %d cnt %d ign %d zdom0 %d az0 %g az1 %g sn %d\n", lane, cntd, (int)ign, (int)s_zdom[dd], azv[0], azv[1], (int)s_sn[k * Cn + dd]);
 #endif
         if (best == 0u) return -1;
         const int wl = __builtin_ctzll(__ballot(bkey == best));
@@ -988,7 +1144,9 @@ __global__ __launch_bounds__(64) void table_kernel(
         }
         if (kindt == 1) {
             unsigned char* hp = g_hrow + (size_t)rowt * ni + (unsigned)pstar;
-            *hp = (unsigned char)(*hp + mult);
+            const unsigned nv = *hp + mult;
+            *hp = (unsigned char)nv;
+            if (nv > g_hmax[rowt]) g_hmax[rowt] = (unsigned char)nv;       // (the row's largest counter bounds spread_select's score table)
         } else if (kindt == 2) {
             const int zd = s_zdom[zst * Cn + dstar];
             if (zd >= 0) g_zcnt[rowt * 16 + zd] += mult;
@@ -1053,7 +1211,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                     const int dp = __builtin_amdgcn_readfirstlane(cc->ncls[pin]);
                     const int rk = __builtin_amdgcn_readfirstlane(ranked ? cc->rk_pos[(size_t)s * (size_t)cc->N + pin] : cc->rank[pin]);
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
-                    const unsigned char byte = g_tile[(unsigned)(pp >> 4) * Krow + (unsigned)r_sig * 16u + (unsigned)(pp & 15)];
+                    const unsigned char byte = g_tile[tile_blk((unsigned)(pp >> 4)) + (unsigned)r_sig * KS + (unsigned)(pp & 15)];
                     bool clear = true;
                     if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv))) >> (pp & 15)) & 1u);
                     if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
@@ -1163,7 +1321,7 @@ __global__ __launch_bounds__(64) void table_kernel(
             unsigned oldq[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
-                rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);   // uniform table base + 32-bit byte offset
+                rowp[q] = g_tile + (tile_blk((unsigned)(pstar >> 4)) + koff[q]);   // uniform table base + 32-bit byte offset
                 T[q] = *(const uint4*)rowp[q];
                 oldq[q] = rowp[q][pstar & 15];                         // this signature's byte before the cycle (same cache line as the row)
                 if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
@@ -1182,7 +1340,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                         for (int q = 0; q < KQ; ++q) {
                             const int k = 128 * (g + 1) + 64 * q + lane;
                             kg[g][q] = k < K ? k : 0;
-                            rowg[g][q] = g_tile + ((unsigned)(pstar >> 4) * Krow + (unsigned)kg[g][q] * 16u);
+                            rowg[g][q] = g_tile + (tile_blk((unsigned)(pstar >> 4)) + (unsigned)kg[g][q] * KS);
                             Tg[g][q] = *(const uint4*)rowg[g][q];
                             oldg[g][q] = rowg[g][q][pstar & 15];
                             Fg[g][q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kg[g][q]) * 4u);
@@ -1202,7 +1360,7 @@ __global__ __launch_bounds__(64) void table_kernel(
                     st = g_state[pstar];
 #pragma unroll
                     for (int q = 0; q < KQ; ++q) {
-                        rowp[q] = g_tile + ((unsigned)(pstar >> 4) * Krow + koff[q]);
+                        rowp[q] = g_tile + (tile_blk((unsigned)(pstar >> 4)) + koff[q]);
                         T[q] = *(const uint4*)rowp[q];
                         oldq[q] = rowp[q][pstar & 15];
                         if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);

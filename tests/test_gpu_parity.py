@@ -239,6 +239,8 @@ def test_random_v2_features(idx, wg):
         env = {"SIMON_WG": wg} if wg else {}
         if set(feat) <= {"aff", "anti"}:                    # required (anti-)affinity alone fits the score-table kernel: keep the
             env["SIMON_NO_REST"] = "1"                      # all-feature kernel's coverage of it here
+        if set(feat) <= {"spread_soft"}:                    # soft spread constraints alone likewise (generation 7, tests/test_gpu_round3.py)
+            env["SIMON_NO_SPREAD"] = "1"
         res, variant = run_gpu(prob, scen, orders, env=env or None)
         assert variant == capi.KERNEL_WIDE
         assert_same(res, ref)
