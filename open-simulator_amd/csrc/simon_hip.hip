@@ -1279,7 +1279,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
         const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? (int)c->sp_zkeys.size() : -1) + c->lds_pad : 0;
-        bool use_table = c->table_ok && c->table_perm_ok && !(c->spread && c->has_ranks) && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
+        bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || !c->raw_fits_lds || c->has_ranks || c->has_static;

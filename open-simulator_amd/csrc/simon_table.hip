@@ -200,7 +200,8 @@ __host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coa
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
     if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2 + (((size_t)M * 4 + 127) & ~(size_t)127);
     // SPREAD: matching pods per (hostname-key term, position) u8 [TH][ni], per (zone-key term, domain) u32 [TZ][16]
-    if (TH > 0 || TZ > 0) w += (((size_t)TH * ni + 127) & ~(size_t)127) + (((size_t)TZ * 16 * 4 + 127) & ~(size_t)127) + (((size_t)TH + 127) & ~(size_t)127);
+    if (TH > 0 || TZ > 0) w += (((size_t)TH * ni + 127) & ~(size_t)127) + (((size_t)TZ * 16 * 4 + 127) & ~(size_t)127) + (((size_t)TH + 127) & ~(size_t)127)
+                              + (((size_t)ni * 2 + 127) & ~(size_t)127);   // + the rank of every position (per-scenario node order)
     return w;
 }
 
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     unsigned char* g_hrow = (unsigned char*)g_xm;                     // [TH][ni] per position (hostname-like key: domain = node)
     unsigned* g_zcnt = (unsigned*)(g_hrow + (((size_t)TH * ni + 127) & ~(size_t)127));   // [TZ][16] per domain of a zone-like key
     unsigned char* g_hmax = (unsigned char*)(g_zcnt + (((size_t)TZ * 16 + 31) & ~(size_t)31));   // [TH] largest counter of a hostname-key row
+    unsigned short* g_canon = (unsigned short*)(g_hmax + (((size_t)TH + 127) & ~(size_t)127));    // [ni] RANKED: rank of the position's node in the scenario's order
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
@@ -447,6 +449,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
         const bool real = p < ni && r < cnt_of_d;
         const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;   // r-th node of class d in canonical order
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
+        if constexpr (SPREAD && RANKED) {                                 // spread_select breaks its ties by rank: one coalesced read per unit
+            if (p < ni) g_canon[p] = (unsigned short)(real ? cold->rk_rank[(size_t)s * (size_t)cold->N + j] : 8191);
+        }
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
         if (p < ni) {
@@ -1028,7 +1033,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     const int u = min(u0 + j, nun - 1);
                     const int info = winner_info(u);                      // (offset into cls_list + 8192) | class << 16 of the unit
                     const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);   // (padding positions of the last class point past the lists)
-                    canon[j] = cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
+                    canon[j] = RANKED ? (int)g_canon[(unsigned)(u * 64 + lane)] : cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
                     stj[j] = s_stash[u * 64 + lane];
                     cbase[j] = (info >> 16) << lg;
                 }
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
                     const int info = infoj[j] = winner_info(u);
                     const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);
-                    canon[j] = cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
+                    canon[j] = RANKED ? (int)g_canon[(unsigned)(u * 64 + lane)] : cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
                 }
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
@@ -1547,10 +1552,15 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
             return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true, true>(a, n_blocks, lds, st)
                                           : launch_t6<M, Z, PIN, KQ, 2, true, true>(a, n_blocks, lds, st);
     }
-    if (a.spread) {                                                   // soft spread constraints: two-level layout, pool order (no per-scenario ranks)
-        if (!a.coarse || a.rest || a.sc.rk_stride != 0) return hipErrorInvalidValue;
-        return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, false, false, false, true>(a, n_blocks, lds, st)
-                                      : launch_t7<M, Z, PIN, KQ, 2, true, false, false, false, false, true>(a, n_blocks, lds, st);
+    if constexpr (PIN) {                                              // soft spread constraints likewise; two-level layout
+        if (a.spread) {
+            if (!a.coarse || a.rest) return hipErrorInvalidValue;
+            if (a.sc.rk_stride != 0)
+                return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, true, false, false, true>(a, n_blocks, lds, st)
+                                              : launch_t7<M, Z, PIN, KQ, 2, true, false, true, false, false, true>(a, n_blocks, lds, st);
+            return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, false, false, false, true>(a, n_blocks, lds, st)
+                                          : launch_t7<M, Z, PIN, KQ, 2, true, false, false, false, false, true>(a, n_blocks, lds, st);
+        }
     }
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
         return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 2, true>(a, n_blocks, lds, st);
@@ -1573,7 +1583,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 }
 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
-    has_pin = has_pin || a.rest;
+    has_pin = has_pin || a.rest || a.spread;
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }

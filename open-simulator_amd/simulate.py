@@ -28,11 +28,14 @@ class HipEngine:
         with capi.Context(self.device_id) as ctx:
             ctx.load_problem(prob)
             if node_ranks is None:
-                return ctx.run_batch(scen, orders, want_placement, want_gpu_slices)
-            ctx.load_scenarios(scen, orders)
-            ctx.set_node_ranks(node_ranks)            # per-scenario nodeTree order (clusters with several zones)
-            ctx.run_loaded(want_placement, want_gpu_slices)
-            return ctx.fetch(want_placement, want_gpu_slices)
+                res = ctx.run_batch(scen, orders, want_placement, want_gpu_slices)
+            else:
+                ctx.load_scenarios(scen, orders)
+                ctx.set_node_ranks(node_ranks)        # per-scenario nodeTree order (clusters with several zones)
+                ctx.run_loaded(want_placement, want_gpu_slices)
+                res = ctx.fetch(want_placement, want_gpu_slices)
+            self.last_stats = ctx.stats()             # which kernel ran (simon_get_stats)
+            return res
 
     def explain(self, prob: capi.Problem, n_nodes: int, order, max_failed: int):
         with capi.Context(self.device_id) as ctx:

@@ -150,3 +150,65 @@ def test_service_workload_full_size_subset():
     res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_SPREAD": "1"})
     assert variant == capi.KERNEL_WIDE
     assert_same(res, ref)
+
+
+def test_k8s_deployments_behind_services_sweep_on_generation_7():
+    """The object-level path of SURVEY.md 8(f) N1: Deployments / StatefulSets selected by Services (system-default soft spread
+    constraints, plugin.go:39-50), some with their own ScheduleAnyway constraints and node selectors, on a cluster with three zones,
+    unlabeled and tainted nodes -- `simulate.sweep` over eight cluster sizes in one batch (per-scenario nodeTree ranks) stays on the
+    score-table kernel; every placement against the oracle."""
+    import randk8s
+    from open_simulator_amd import k8s, simulate as sim
+    rng = np.random.default_rng(77)
+    nodes = []
+    for j in range(180):
+        shape = [("8", "16Gi"), ("16", "32Gi"), ("32", "64Gi")][int(rng.integers(0, 3))]
+        labels = {randk8s.HOST: f"node-{j}", "disk": ["ssd", "hdd"][j % 2]}
+        if j % 11:
+            labels[randk8s.ZONE] = f"z{j % 3}"
+        node = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"node-{j}", "labels": labels},
+                "status": {"allocatable": {"cpu": shape[0], "memory": shape[1], "pods": "60"}, "capacity": {"cpu": shape[0], "memory": shape[1]}}}
+        if j % 13 == 5:
+            node["spec"] = {"taints": [{"key": "dedicated", "value": "infra", "effect": "NoSchedule"}]}
+        nodes.append(node)
+    workloads, services = [], []
+    for w in range(40):
+        app = f"app{w}"
+        spec = {"containers": [{"name": "c", "image": "x", "resources": {"requests": {
+            "cpu": str(rng.choice(["100m", "250m", "500m", "1"])), "memory": str(rng.choice(["128Mi", "512Mi", "1Gi", "2Gi"]))}}}]}
+        r = w % 5
+        if r == 1:
+            spec["topologySpreadConstraints"] = [{"maxSkew": 2, "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "ScheduleAnyway",
+                                                  "labelSelector": {"matchLabels": {"app": app}}}]
+        elif r == 2:            # zone before hostname: the general walk of spread_select
+            spec["topologySpreadConstraints"] = [
+                {"maxSkew": 1, "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": app}}},
+                {"maxSkew": 2, "topologyKey": randk8s.HOST, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": app}}}]
+        if w % 7 == 3:
+            spec["nodeSelector"] = {"disk": "ssd"}
+        if w % 9 == 4:
+            spec["tolerations"] = [{"key": "dedicated", "operator": "Exists"}]
+        kind = "StatefulSet" if w % 4 == 0 else "Deployment"
+        workloads.append({"apiVersion": "apps/v1", "kind": kind, "metadata": {"name": app, "namespace": "default"},
+                          "spec": {"replicas": int(rng.integers(5, 60)), "selector": {"matchLabels": {"app": app}},
+                                   "template": {"metadata": {"labels": {"app": app}}, "spec": spec}}})
+        if r != 3:
+            services.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": f"svc-{w}", "namespace": "default"},
+                             "spec": {"selector": {"app": app}}})
+    cluster = k8s.group_resources(nodes + services)
+    apps = [sim.AppResource("shop", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z1"}},
+                "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "60"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
+
+    class Recording(sim.HipEngine):
+        def run(self, prob, scen, orders, want_placement=True, **kw):
+            self.args, self.kw = (prob, scen, orders), kw
+            self.out = super().run(prob, scen, orders, want_placement, **kw)
+            return self.out
+
+    eng = Recording()
+    sim.sweep(cluster, apps, template, [0, 6, 12, 18, 24, 30, 36, 42], engine=eng)
+    prob, scen, orders = eng.args
+    assert prob.n_pods > 1000 and len(scen) == 8 and eng.kw.get("node_ranks") is not None
+    assert eng.last_stats.kernel_variant == capi.KERNEL_NARROW_CACHE and eng.last_stats.kernel_generation == 7
+    assert_same(eng.out, O.run(prob, scen, orders, node_ranks=eng.kw["node_ranks"]))
