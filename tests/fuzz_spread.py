@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of generation 7 (soft PodTopologySpread constraints on the score-table kernel): random sizes, feature
-subsets and scenario batches; every placement, unscheduled count and used cpu / memory against the oracle.
+subsets, scenario batches and (every fourth case) per-scenario node ranks; every placement, unscheduled count and used cpu / memory against the oracle.
 Not collected by pytest; by hand on a GPU box:   python tests/fuzz_spread.py [n_cases] [first_seed]"""
 import os
 import sys
@@ -27,10 +27,21 @@ def one_case(case):
     prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=True, n_node_classes=int(rng.choice([1, 2, 4, 9])),
                                  n_pod_classes=int(rng.choice([1, 3, 8, 30, 60])), **feat)
     scen, orders = randprob.rand_scenarios(case, prob, S=int(rng.integers(1, 8)), min_n=1 if rng.random() < 0.4 else None)
-    ref = O.run_threaded(prob, scen, orders)
+    ranks = None
+    if case % 4 == 3:                                   # per-scenario node order (simon_set_node_ranks): ties follow the ranks
+        ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+        for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
+            ranks[s_, :n] = rng.permutation(n)
+    ref = O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run_threaded(prob, scen, orders)
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
-        res = ctx.run_batch(scen, orders)
+        if ranks is None:
+            res = ctx.run_batch(scen, orders)
+        else:
+            ctx.load_scenarios(scen, orders)
+            ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            res = ctx.fetch(True)
         st = ctx.stats()
     ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
           res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
