@@ -127,7 +127,7 @@ struct simon_ctx : simon::HostInputs {
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
     std::vector<int> sp_zkeys;                   // topology keys of the zone-like soft terms (<= kSpreadMaxZoneKeys): the class split
     int sp_TH = 0, sp_TZ = 0;
-    DevBuf<int32_t> d_sp_ent, d_sp_term;
+    DevBuf<int32_t> d_sp_ent;                    // (entry, term row) pairs: TableCold::sp_ent
     DevBuf<double> d_spread_log;
     DevBuf<uint64_t> d_node_sets;
     DevBuf<signed char> d_cls_zdom;
@@ -727,9 +727,11 @@ int stage_narrow(simon_ctx* c) {
                 for (int z = 0; z < nzk; ++z)
                     for (int d = 0; d < Ct; ++d) zdom[(size_t)z * Ct + d] = (signed char)(((sub_of_class[d] >> (5 * z)) & 31) - 1);
                 if (sp_ent.empty()) sp_ent.push_back(0);
+                std::vector<int32_t> sp_pairs(sp_ent.size() * 2);            // the term's row travels with the entry (one load in the kernel)
+                for (size_t i = 0; i < sp_ent.size(); ++i) { sp_pairs[2 * i] = sp_ent[i]; sp_pairs[2 * i + 1] = sp_term[sp_ent[i] & 0xFFFF]; }
                 std::vector<uint64_t> sets = c->node_sets;
                 if (sets.empty()) sets.push_back(0);
-                HIP_TRY(c, c->d_sp_ent.upload(sp_ent, st)); HIP_TRY(c, c->d_sp_term.upload(sp_term, st));
+                HIP_TRY(c, c->d_sp_ent.upload(sp_pairs, st));
                 HIP_TRY(c, c->d_cls_zdom.upload(zdom, st)); HIP_TRY(c, c->d_spread_log.upload(c->spread_log, st));
                 HIP_TRY(c, c->d_node_sets.upload(sets, st));
             }
@@ -1309,11 +1311,11 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
             if (c->spread) {
-                cold.sp_ent = c->d_sp_ent.p; cold.sp_term = c->d_sp_term.p; cold.spread_log = c->d_spread_log.p;
+                cold.sp_ent = (const int2*)c->d_sp_ent.p; cold.spread_log = c->d_spread_log.p;
                 cold.node_sets = c->d_node_sets.p; cold.set_words = (c->N + 63) / 64; cold.cls_zdom = c->d_cls_zdom.p;
             }
             const bool tprof = c->table_prof;
-            if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 12)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 96, c->stream)); cold.prof = c->d_table_prof.p; }
+            if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 24)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 192, c->stream)); cold.prof = c->d_table_prof.p; }
             HIP_TRY(c, c->d_table_cold.ensure(sizeof cold));
             HIP_TRY(c, hipMemcpyAsync(c->d_table_cold.p, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));             // `cold` is a stack object
@@ -1330,12 +1332,15 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
             if (tprof) {     // phase profile: mean ticks per scheduling cycle over the batch (profile builds only)
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
-                std::vector<unsigned long long> hp((size_t)S * 12);
+                std::vector<unsigned long long> hp((size_t)S * 24);
                 HIP_TRY(c, hipMemcpy(hp.data(), c->d_table_prof.p, hp.size() * 8, hipMemcpyDeviceToHost));
-                double acc[12] = {0};
-                for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 12; ++q) acc[q] += (double)hp[(size_t)s2 * 12 + q];
+                double acc[24] = {0};
+                for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 24; ++q) acc[q] += (double)hp[(size_t)s2 * 24 + q];
                 fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | state update %.0f | eval+patch+store %.0f | REST assume %.0f | REST select %.0f | canonical tie-breaks per cycle %.3f\n",
                         S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[8] / S / P, acc[9] / S / P, acc[6] / S / P, acc[10] / S / P, acc[7] / S / P);
+                if (c->spread)
+                    fprintf(stderr, "[SIMON_TABLE_PROF] spread pods, ticks/cycle: descriptor + first loads %.0f | counters, sizes %.0f | zone counters, Log, raw table %.0f | pass 1 %.0f | extremes, totals table %.0f | pass 2 %.0f | winner %.0f | counter stores %.0f\n",
+                            acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[18] / S / P, acc[19] / S / P);
             }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
             T = 64; slots = (ni_top / (c->table_coarse ? 64 : 16) + 63) / 64; lds = table_lds;

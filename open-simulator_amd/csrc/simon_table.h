@@ -64,9 +64,10 @@ struct TableCold {
     const int32_t* zdom;            // [NZ][N] domain of a node under a zone-like key (-1: no label)
     unsigned long long* gpu_slices; // [S][P] by pod id: devices Reserve booked (simon_batch_out.gpu_slices), written when TableScalars::static_tables & 8
     // SPREAD (soft PodTopologySpread constraints, generation 7): per pod class [soft constraints..., counted terms...] in sp_ent
-    // (soft: term slot | maxSkew << 16 | SIMON_SPREAD_DUP_KEY bit 30; counted: term slot), per term slot kind (1 hostname-like row, 2
-    // zone-like row) | row << 2 | zone key slot << 16 | (node set + 1) << 19; Go's math.Log table; node sets; zone domain of a class
-    const int32_t *sp_ent, *sp_term;
+    // (soft: term slot | maxSkew << 16 | SIMON_SPREAD_DUP_KEY bit 30; counted: term slot | multiplicity << 16), each with its term's
+    // row: kind (1 hostname-like row, 2 zone-like row) | row << 2 | zone key slot << 16 | (node set + 1) << 19; Go's math.Log table;
+    // node sets; zone domain of a class
+    const int2* sp_ent;             // x = the entry, y = its term's row (kind | row << 2 | zone key slot << 16 | (node set + 1) << 19)
     const double* spread_log;       // [N + 1] math.Log(float64(i + 2)) (simon_class_tables.spread_log)
     const uint64_t* node_sets;      // [R][set_words]
     int32_t set_words;
@@ -98,7 +99,10 @@ constexpr int kTableMaxXres = 32;       // distinct (ephemeral-storage, extended
 constexpr int kTableMaxTerms = 120;     // node-level anti-affinity terms: two mask rows each
 constexpr int kSpreadMaxZoneDom = 16;    // domains of a zone-like key of a soft spread constraint (one u32 counter each)
 constexpr int kSpreadMaxHostTerms = 4096, kSpreadMaxZoneTerms = 1024, kSpreadMaxZoneKeys = 3;
-constexpr int kSpreadTabMax = 512;       // entries of spread_select's per-pod score table in LDS: classes x (largest counter + 1, a power of two)
+#ifndef SIMON_SPREAD_TAB_MAX
+#define SIMON_SPREAD_TAB_MAX 512          // (tests build a library with a tiny table to drive every pod through the general walk)
+#endif
+constexpr int kSpreadTabMax = SIMON_SPREAD_TAB_MAX;       // entries of spread_select's per-pod score table in LDS: classes x (largest counter + 1, a power of two)
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD)

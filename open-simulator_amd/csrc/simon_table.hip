@@ -46,7 +46,7 @@
 // Phase profile of the scheduling cycle (profiles/build_variant.sh ... -DSIMON_TABLE_PROFILE): s_memtime stamps at the phase
 // boundaries, accumulated per wave, written to TableCold::prof ([workgroup][12] ticks).  Not compiled into the product build.
 #ifdef SIMON_TABLE_PROFILE
-#define TPROF_DECL unsigned long long tp_prev = __builtin_readcyclecounter(), tp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define TPROF_DECL unsigned long long tp_prev = __builtin_readcyclecounter(), tp_acc[24] = {0};
 #define TPROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tp_acc[i] += t_ - tp_prev; tp_prev = t_; } while (0)
 #define TPROF_WAIT_LDS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define TPROF_WAIT_MEM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -898,15 +898,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     // lists give the canonical index of a position).  Everything else about the cycle -- assume, column refresh, summaries -- is the
     // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | offset << 10 into TableCold::sp_ent; lane e
     // holds entry e (`spv`).
+    TPROF_DECL
     const int sp_N = SPREAD ? cold->N : 0;
-    auto spread_select = [&](int k, int soft_n, int spv, int& dstar, int& res) -> int {
+    auto spread_select = [&](int k, int soft_n, int spv, int spt, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         int kind[4], rowi[4], zsl[4], skew[4];
         bool dup[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ent = __builtin_amdgcn_readlane(spv, e);
-            const int ti = e < soft_n ? __builtin_amdgcn_readfirstlane(cold->sp_term[ent & 0xFFFF]) : 0;
+            const int ti = e < soft_n ? __builtin_amdgcn_readlane(spt, e) : 0;   // (the term's row travels with the entry: no dependent load)
             kind[e] = ti & 3; rowi[e] = (ti >> 2) & 0x3FFF; zsl[e] = (ti >> 16) & 7;
             skew[e] = (ent >> 16) & 0x3FFF; dup[e] = (ent >> 30) & 1;
         }
@@ -942,6 +943,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
             }
         };
         if (simple) load1(0);
+        TPROF(12);                                                         // spread: descriptor, first loads issued
         bool ign = false;                                                 // IgnoredNodes (:80-85): a constraint key is missing
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -957,6 +959,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 else sz[e] = __popc((unsigned)__builtin_amdgcn_readfirstlane((int)wave_or_u32_t(scored ? 1u << (s_zdom[zsl[e] * Cn + dd] & 31) : 0u)));
             }
         }
+        TPROF(13);                                                         // spread: feasible-node counters arrived, sizes
         // (the doubles are built where they are used: the two branches below keep different ones alive)
         auto w_of = [&](int e) -> double { return e < soft_n ? cold->spread_log[sz[e]] : 0.0; };
         auto cst_of = [&](int e) -> double { return (double)(skew[e] - 1); };
@@ -997,6 +1000,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 const int raw = (int)(((double)(i & hmask) * ws + cs) + pc);
                 if (i < E) s_tab[i] = raw;
             }
+            TPROF_WAIT_LDS; TPROF(14);                                     // spread: zone counters, Log table, raw score table
             for (int u0 = 0;;) {                                          // pass 1; leaves (count, table byte) of every position in LDS
 #pragma unroll
                 for (int j = 0; j < SB; ++j) {
@@ -1009,9 +1013,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     s_stash[u * 64 + lane] = (unsigned short)(h1[j] | (byte1[j] << 8));
                 }
                 u0 += SB;
+#ifdef SIMON_SPREAD_ABLATE_PASS1
+                break;                                                    // timing experiment only (wrong results): pass 1 over one batch
+#endif
                 if (u0 >= nun) break;
                 load1(u0);
             }
+            TPROF(15);                                                     // spread: pass 1
             pmin = wave_min_i32(pmin);
             pmax = wave_max_i32(pmax);
             const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
@@ -1025,7 +1033,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 v = cw >= 0 ? v : 0;                                      // ignored nodes score 0
                 if (i < E) s_tab[i] = (cw & 0x7fffffff) + 2 * v;
             }
-            for (int u0 = 0; u0 < nun; u0 += SC) {                        // pass 2: totals, first maximum in canonical order
+            TPROF_WAIT_LDS; TPROF(16);                                     // spread: extremes, table of totals
+#ifdef SIMON_SPREAD_ABLATE_PASS2
+            const int nun2 = nun < 2 ? nun : 2;                           // timing experiment only (wrong results): pass 2 over two units
+#else
+            const int nun2 = nun;
+#endif
+            for (int u0 = 0; u0 < nun2; u0 += SC) {                       // pass 2: totals, first maximum in canonical order
                 int canon[SC], cbase[SC];
                 unsigned stj[SC];
 #pragma unroll
@@ -1117,6 +1131,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 }
             }
         }
+        TPROF(17);                                                         // spread: pass 2
         const unsigned best = wave_max_u32(bkey);
 #ifdef SIMON_SPREAD_DEBUG
         if (lane == 0) printf("SPD s=%d k=%d soft=%d kind=%d,%d row=%d,%d zsl=%d,%d skew=%d,%d F=%d w=%g,%g pmin=%d pmax=%d best=%u nun=%d Cn=%d\n", s, k, soft_n, kind[0], kind[1], rowi[0], rowi[1],
@@ -1134,27 +1149,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     // AddPod's side of the counters (podtopologyspread/scoring.go:129-160 counts the pods ON the nodes; here they are counted as
     // they land): lane soft_n + e holds counted entry e = term slot | multiplicity << 16 (terms are distinct per class: plain
     // read-modify-writes of distinct bytes / words).  A term counts only on the nodes of its node set (scoring.go:137-141).
-    auto spread_count = [&](int pstar, int dstar, int res, int spv, int soft_n, int match_n) {
+    // The loads go out with the assume's (right after the select), the stores at the end of the cycle: nothing else touches these
+    // bytes / words in between, and the wave does not wait a memory round trip of its own for them.
+    struct SpreadLoads { unsigned old, mx; bool on; };
+    auto spread_count_load = [&](int pstar, int dstar, int res, int spv, int spt, int soft_n, int match_n) -> SpreadLoads {
+        SpreadLoads L{0u, 0u, false};
         const int e = lane - soft_n;
-        if (e < 0 || e >= match_n) return;
-        const int ti = cold->sp_term[spv & 0xFFFF];
-        const unsigned mult = ((unsigned)spv >> 16) & 0xFFu;
+        if (e < 0 || e >= match_n) return L;
+        const int ti = spt;
         const int kindt = ti & 3, rowt = (ti >> 2) & 0x3FFF, zst = (ti >> 16) & 7, set = ((ti >> 19) & 0xFFF) - 1;
 #ifdef SIMON_SPREAD_DEBUG
-        printf("SPC s=%d lane=%d e=%d spv=%x ti=%x mult=%u kind=%d row=%d set=%d pstar=%d dstar=%d res=%d\n", s, lane, e, spv, ti, mult, kindt, rowt, set, pstar, dstar, res);
+        printf("SPC s=%d lane=%d e=%d spv=%x ti=%x kind=%d row=%d set=%d pstar=%d dstar=%d res=%d\n", s, lane, e, spv, ti, kindt, rowt, set, pstar, dstar, res);
 #endif
+        L.on = true;
         if (set >= 0) {
             const int jn = cls_list[rk_off + (unsigned)res];              // the node itself (canonical pool index)
-            if (!((cold->node_sets[(size_t)set * cold->set_words + (jn >> 6)] >> (jn & 63)) & 1ull)) return;
+            L.on = (cold->node_sets[(size_t)set * cold->set_words + (jn >> 6)] >> (jn & 63)) & 1ull;
         }
         if (kindt == 1) {
-            unsigned char* hp = g_hrow + (size_t)rowt * ni + (unsigned)pstar;
-            const unsigned nv = *hp + mult;
-            *hp = (unsigned char)nv;
-            if (nv > g_hmax[rowt]) g_hmax[rowt] = (unsigned char)nv;       // (the row's largest counter bounds spread_select's score table)
+            L.old = g_hrow[(size_t)rowt * ni + (unsigned)pstar];
+            L.mx = g_hmax[rowt];
         } else if (kindt == 2) {
             const int zd = s_zdom[zst * Cn + dstar];
-            if (zd >= 0) g_zcnt[rowt * 16 + zd] += mult;
+            L.on = L.on && zd >= 0;
+            L.old = g_zcnt[rowt * 16 + (zd >= 0 ? zd : 0)];
+        } else {
+            L.on = false;
+        }
+        return L;
+    };
+    auto spread_count_store = [&](const SpreadLoads& L, int pstar, int dstar, int spv, int spt, int soft_n, int match_n) {
+        const int e = lane - soft_n;
+        if (e < 0 || e >= match_n || !L.on) return;
+        const unsigned mult = ((unsigned)spv >> 16) & 0xFFu;
+        const int kindt = spt & 3, rowt = (spt >> 2) & 0x3FFF, zst = (spt >> 16) & 7;
+        const unsigned nv = L.old + mult;
+        if (kindt == 1) {
+            g_hrow[(size_t)rowt * ni + (unsigned)pstar] = (unsigned char)nv;
+            if (nv > L.mx) g_hmax[rowt] = (unsigned char)nv;              // (the row's largest counter bounds spread_select's score table)
+        } else {
+            g_zcnt[rowt * 16 + s_zdom[zst * Cn + dstar]] = nv;
         }
     };
 
@@ -1172,7 +1206,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     };
     int4 nxt = load_chunk(0);
 
-    TPROF_DECL
     for (int i0 = 0; i0 < P; i0 += 64) {
         const int4 cur = nxt;
         nxt = load_chunk(i0 + 64);
@@ -1185,7 +1218,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
         const int rw = (REST || SPREAD) ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST / SPREAD descriptor (0: the score table alone decides the pod)
         const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0;
         int spv = 0;                                                       // SPREAD: lane e holds entry e of the pod's constraint / counted-term list
-        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match) spv = cold->sp_ent[((unsigned)rw >> 10) + lane];
+        int spt = 0;                                                       // ... and its term's row (TableCold::sp_ent holds both)
+        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match) {
+            const int2 spe = cold->sp_ent[((unsigned)rw >> 10) + lane];
+            spv = spe.x; spt = spe.y;
+        }
         const int r_gs = REST ? (rw & 63) - 1 : -1, r_xs = REST ? ((rw >> 6) & 63) - 1 : -1, r_nrows = REST ? (rw >> 12) & 63 : 0;
         int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
         if (REST && lane < r_nrows) rowv = cold->xrows[((unsigned)rw >> 18) + lane];
@@ -1234,7 +1271,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
-            pstar = spread_select(k, sp_soft, spv, dstar, res);
+            pstar = spread_select(k, sp_soft, spv, spt, dstar, res);
+            TPROF(18);                                                 // spread: winner
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
@@ -1376,6 +1414,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
             const int blk = pstar >> 4, pos = pstar & 15;
             RestLoads RL{};
             if (REST && __builtin_expect(rw != 0, 0)) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
+            SpreadLoads SPL{0u, 0u, false};
+            if (SPREAD && sp_match != 0) SPL = spread_count_load(pstar, dstar, res, spv, spt, sp_soft, sp_match);
             const ShapeRow sh = s_shape[dstar];
             unsigned snq[KQ];
 #pragma unroll
@@ -1474,7 +1514,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
             }
             TPROF(9);                                                  // evaluation, patch, block key, summary / table stores
             if (REST && __builtin_expect(rw != 0, 0)) rest_assume_store(RL, pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs, i0 + il);
-            if (SPREAD && sp_match != 0) spread_count(pstar, dstar, res, spv, sp_soft, sp_match);
+            if (SPREAD && sp_match != 0) spread_count_store(SPL, pstar, dstar, spv, spt, sp_soft, sp_match);
+            TPROF(19);                                                 // spread: counter stores
             __builtin_amdgcn_wave_barrier();
             TPROF(6);                                                  // REST: term rows, GPU commit and GPU rows
         }
@@ -1494,7 +1535,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     um = wave_sum_i64(um);
 #ifdef SIMON_TABLE_PROFILE
     if (lane == 0 && cold->prof)
-        for (int q = 0; q < 12; ++q) cold->prof[(size_t)s * 12 + q] = tp_acc[q];
+        for (int q = 0; q < 24; ++q) cold->prof[(size_t)s * 24 + q] = tp_acc[q];
 #endif
     if (lane == 0) {
         cold->unscheduled[s] = unsched;
