@@ -670,7 +670,7 @@ int stage_narrow(simon_ctx* c) {
             }
             // class-major layout: rank of a node among its class, per-class node lists in canonical order, class counts of
             // every prefix of the pool (a scenario = a prefix)
-            std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * Ct, 0), cls_off(Ct + 1, 0), cls_list(N);
+            std::vector<int32_t> rank(N), prefix((size_t)(N + 1) * Ct, 0), cls_off(Ct + 1, 0), cls_list((size_t)N + 64, 0);   // (+ 64: generation 7 reads a whole unit of the last, padded class)
             for (int j = 0; j < N; ++j) {
                 const int d = ncls_t[j];
                 rank[j] = prefix[(size_t)j * Ct + d];

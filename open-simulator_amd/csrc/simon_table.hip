@@ -899,7 +899,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | offset << 10 into TableCold::sp_ent; lane e
     // holds entry e (`spv`).
     TPROF_DECL
-    const int sp_N = SPREAD ? cold->N : 0;
     auto spread_select = [&](int k, int soft_n, int spv, int spt, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         int kind[4], rowi[4], zsl[4], skew[4];
@@ -1010,7 +1009,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     const bool ok = (byte1[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);   // (no short circuit: no branch)
                     pmin = min(pmin, ok ? raw : 0x7fffffff);
                     pmax = max(pmax, ok ? raw : 0);
-                    s_stash[u * 64 + lane] = (unsigned short)(h1[j] | (byte1[j] << 8));
+                    (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (byte1[j] << 8));   // (uniform base + lane: one address add)
                 }
                 u0 += SB;
 #ifdef SIMON_SPREAD_ABLATE_PASS1
@@ -1046,9 +1045,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 for (int j = 0; j < SC; ++j) {
                     const int u = min(u0 + j, nun - 1);
                     const int info = winner_info(u);                      // (offset into cls_list + 8192) | class << 16 of the unit
-                    const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);   // (padding positions of the last class point past the lists)
-                    canon[j] = RANKED ? (int)g_canon[(unsigned)(u * 64 + lane)] : cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
-                    stj[j] = s_stash[u * 64 + lane];
+                    // uniform base + lane (scalar address arithmetic); the padding positions of the last class read past the lists, into
+                    // the 64 entries of slack behind them (their table byte is 0)
+                    canon[j] = RANKED ? (int)(g_canon + u * 64)[lane] : (cls_list + (rk_off + (unsigned)((info & 0xFFFF) - 8192 + u * 64)))[lane];
+                    stj[j] = (s_stash + u * 64)[lane];
                     cbase[j] = (info >> 16) << lg;
                 }
                 int t2[SC];
@@ -1057,9 +1057,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
 #pragma unroll
                 for (int j = 0; j < SC; ++j) {
                     const int u = min(u0 + j, nun - 1);
-                    const unsigned byte = stj[j] >> 8;
-                    const int total = (int)byte - 1 + t2[j];
-                    const unsigned key = byte != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon[j]) : 0u;
+                    const unsigned byte = stj[j] >> 8;                   // total + 1 = (byte - 1) + (class term + 2 x score) + 1
+                    const unsigned key = byte != 0u ? ((byte + (unsigned)t2[j]) << 13) | (8191u - (unsigned)canon[j]) : 0u;
                     if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
                 }
             }
@@ -1114,8 +1113,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
                     const int info = infoj[j] = winner_info(u);
-                    const unsigned ci = (unsigned)((info & 0xFFFF) - 8192 + u * 64 + lane);
-                    canon[j] = RANKED ? (int)g_canon[(unsigned)(u * 64 + lane)] : cls_list[rk_off + (ci < (unsigned)sp_N ? ci : 0u)];
+                    canon[j] = RANKED ? (int)(g_canon + u * 64)[lane] : (cls_list + (rk_off + (unsigned)((info & 0xFFFF) - 8192 + u * 64)))[lane];
                 }
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
