@@ -868,6 +868,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
     c->wide.knobs.prof = getenv("SIMON_WIDE_PROF") != nullptr;
+    if (const char* e = getenv("SIMON_WIDE_NO_CACHE_B")) c->wide.knobs.no_cache_b = *e ? atoi(e) : 3;
     if (const char* e = getenv("SIMON_STATE_BUDGET_MB")) c->wide.knobs.state_budget = (size_t)atoll(e) << 20;
     return c;
 }

@@ -583,6 +583,10 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     // instruction per feasible node instead of a compare/select chain over the classes; -4 % on config 5), swapped out
     // against 0 once per cycle
     unsigned* const s_kc = (unsigned*)(s_rows2 + (((A.flags & kArgClassMode) != 0u) ? 2 * 4 * A.Cn : 0));
+    // caches of stage A's counter gathers for stage B, by node (written and read by the lane that owns the node)
+    int* const s_ipa = (int*)(s_kc + ((((A.flags & kArgClassMode) != 0u) && A.Cn <= 8) ? A.Cn * T : 0));
+    int* const s_pts = s_ipa + ((A.flags & kArgIpaCache) ? A.bc_words : 0);          // [slot][bc_words]
+    const bool ipa_cache = !EXPLAIN && (A.flags & kArgIpaCache), pts_cache = !EXPLAIN && (A.flags & kArgPtsCache);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int s = blockIdx.x;
@@ -787,6 +791,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         if (!m[u]) continue;
                         ipa_max = x[u] > ipa_max ? x[u] : ipa_max;
                         ipa_min = x[u] < ipa_min ? x[u] : ipa_min;
+                        if (ipa_cache) s_ipa[jn[u]] = (int)x[u];           // (|raw| < 2^31: checked on the host)
                     }
                 }
                 if (soft) {   // initPreScoreState, podtopologyspread/scoring.go:60-108
@@ -809,6 +814,17 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         if (!m[u]) continue;
                         if (ig[u]) ign |= 1u << (it0 + u); else ++scored;
                     }
+                    // the counts stage B scores (pts_raw8's gathers): issued here, in flight together with the stamps below
+                    int cq[SIMON_MAX_SPREAD][kUT];
+                    if (pts_cache) {
+#pragma unroll
+                        for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
+                            if (q >= n_soft) continue;
+                            const int off = COLD(A)->term_dom_off[COLD(A)->ss_idx[slo + q]];
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) cq[q][u] = (m[u] && !ig[u]) ? v.cnt_match()[off + dq[q][u]] : 0;
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
                         if (q >= n_soft) continue;
@@ -823,6 +839,15 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) fresh += old[u] != stamp ? 1 : 0;
                         if (q == 0) dst0 += fresh; else if (q == 1) dst1 += fresh; else if (q == 2) dst2 += fresh; else dst3 += fresh;
+                    }
+                    if (pts_cache) {
+#pragma unroll
+                        for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
+                            if (q >= n_soft) continue;
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u)
+                                if (m[u] && !ig[u]) s_pts[q * A.bc_words + jn[u]] = cq[q][u];
+                        }
                     }
                 }
             };
@@ -1171,7 +1196,12 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     }
                     if (ipa && ipa_diff > 0) {                     // interpodaffinity/scoring.go:258-271
                         long long x[kUT];
-                        ipa_raw8(A, v, p, jn, val, x);
+                        if (ipa_cache) {
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) x[u] = val[u] ? (long long)s_ipa[jn[u]] : 0;
+                        } else {
+                            ipa_raw8(A, v, p, jn, val, x);
+                        }
 #pragma unroll
                         for (int u = 0; u < kUT; ++u)
                             if (val[u]) total[u] += (long long)(100.0 * ((double)(x[u] - ipa_min) / (double)ipa_diff));
@@ -1186,7 +1216,25 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         long long x[kUT];
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) { ms[u] = val[u] && !((ign >> (it0 + u)) & 1u) && pts_max != 0; x[u] = 0; }
-                        if (pts_max != 0) pts_raw8(A, v, p, jn, ms, weight, x);
+                        if (pts_max != 0 && pts_cache) {           // pts_raw8 from the counts stage A left: the same sums in the same order
+                            double score[kUT];
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) score[u] = 0.0;
+#pragma unroll
+                            for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
+                                if (q >= n_soft) continue;
+                                const double w = sel4(weight, q), add = (double)((COLD(A)->ss_skew[slo + q] & ~SIMON_SPREAD_DUP_KEY) - 1);
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) {
+                                    const int cv = ms[u] ? s_pts[q * A.bc_words + jn[u]] : 0;
+                                    score[u] += (double)(long long)cv * w + add;     // scoreForCount (:287-289)
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) x[u] = ms[u] ? (long long)score[u] : 0;
+                        } else if (pts_max != 0) {
+                            pts_raw8(A, v, p, jn, ms, weight, x);
+                        }
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) {
                             if (!val[u]) continue;
@@ -1374,11 +1422,36 @@ int ensure_mask_lanes(WideDevice& w, const HostInputs& in, int T, hipStream_t st
     return 0;
 }
 
+// dynamic LDS of a launch: base | class, class rows, per-class keys, the stage-A caches
+static size_t wide_lds_bytes(const WideArgs& a, int T) {
+    size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 + (a.Cn <= 8 ? (size_t)a.Cn * T * 4 : 0) : 0);
+    if (a.flags & kArgIpaCache) lds += (size_t)a.bc_words * 4;
+    if (a.flags & kArgPtsCache) lds += (size_t)a.bc_words * 4 * ((a.flags >> kArgPtsSlotsShift) & 7u);
+    return lds;
+}
+
 template <bool EXPLAIN>
 hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
     dim3 grid(a.S);
-    const size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 + (a.Cn <= 8 ? (size_t)a.Cn * T * 4 : 0) : 0);
+    const size_t lds = wide_lds_bytes(a, T);
     (void)max_n;
+    if (lds > 48 * 1024) {                                                 // beyond the default dynamic-LDS limit: raise it for the instantiation that runs
+        hipError_t e = hipSuccess;
+#define WIDE_ATTR(TT)                                                                                                            \
+        if (a.flags & kArgLocal) e = hipFuncSetAttribute((const void*)wide_kernel<TT, EXPLAIN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        else if (!EXPLAIN && (a.flags & kArgLean) && !(a.flags & kArgRanked)) e = hipFuncSetAttribute((const void*)wide_kernel<TT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        else e = hipFuncSetAttribute((const void*)wide_kernel<TT, EXPLAIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        switch (T) {
+            case 64: WIDE_ATTR(64); break;
+            case 128: WIDE_ATTR(128); break;
+            case 256: WIDE_ATTR(256); break;
+            case 512: WIDE_ATTR(512); break;
+            case 1024: WIDE_ATTR(1024); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef WIDE_ATTR
+        if (e != hipSuccess) return e;
+    }
 #define WIDE_LAUNCH(TT)                                                                                   \
     if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 2>), grid, dim3(TT), lds, st, a);    \
     else if (!EXPLAIN && (a.flags & kArgLean) && !(a.flags & kArgRanked)) hipLaunchKernelGGL((wide_kernel<TT, false, 0>), grid, dim3(TT), lds, st, a); \
@@ -1690,6 +1763,33 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     if (d_node_rank && d_node_inv) a.flags |= kArgRanked;
     a.orders = d_orders;
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
+    {   // stage-A caches for stage B (kArgIpaCache / kArgPtsCache): only when they leave the workgroups-per-CU of the launch alone
+        const size_t budget = (T == 256 ? 72 : 140) * 1024;
+        if (in.has_ipa_score && !(w.knobs.no_cache_b & 1)) {
+            long long maxw = 1, len = 1;
+            for (int32_t x : in.pref_w) maxw = std::max<long long>(maxw, std::llabs((long long)x));
+            for (int32_t x : in.own_w) maxw = std::max<long long>(maxw, std::llabs((long long)x));
+            for (int cp = 0; cp < in.Cp; ++cp) {
+                long long l = 0;
+                if (!in.pref_off.empty()) l += in.pref_off[cp + 1] - in.pref_off[cp];
+                if (!in.match_off.empty()) l += in.match_off[cp + 1] - in.match_off[cp];
+                len = std::max(len, l);
+            }
+            // |raw| <= placed pods x (own scoring terms per pod x) weight x list entries: an int32 holds it
+            long long own_per_pod = 1;
+            for (int cp = 0; cp < in.Cp && !in.own_off.empty(); ++cp) own_per_pod = std::max<long long>(own_per_pod, in.own_off[cp + 1] - in.own_off[cp]);
+            if ((long double)in.P * (long double)maxw * (long double)len * (long double)own_per_pod < 2.0e9L) a.flags |= kArgIpaCache;
+            if (wide_lds_bytes(a, T) > budget) a.flags &= ~kArgIpaCache;
+        }
+        if (!in.ss_idx.empty() && !(w.knobs.no_cache_b & 2)) {
+            unsigned slots = 0;
+            for (int cp = 0; cp < in.Cp; ++cp) slots = std::max<unsigned>(slots, (unsigned)(in.ss_off[cp + 1] - in.ss_off[cp]));
+            if (slots >= 1 && slots <= 7) {
+                a.flags |= kArgPtsCache | (slots << kArgPtsSlotsShift);
+                if (wide_lds_bytes(a, T) > budget) a.flags &= ~(kArgPtsCache | (7u << kArgPtsSlotsShift));
+            }
+        }
+    }
     unsigned long long* d_prof = nullptr;
 #ifdef SIMON_WIDE_PROFILE
     const bool prof = w.knobs.prof && chunk >= S;
