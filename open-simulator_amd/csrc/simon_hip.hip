@@ -123,6 +123,7 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<uint32_t> d_gpu_devtot, d_i_gused;
     DevBuf<uint2> d_gsig;
     // SPREAD path of the score-table kernel (soft PodTopologySpread constraints, generation 7): decided by choose_variant
+    bool sig_twins = false, no_sig_twins = false; // upper-half signatures sit 64 slots above a twin (same request, other table class); env SIMON_TABLE_NO_TWINS
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
     std::vector<int> sp_zkeys;                   // topology keys of the zone-like soft terms (<= kSpreadMaxZoneKeys): the class split
@@ -494,6 +495,32 @@ int stage_narrow(simon_ctx* c) {
             }
             rowsC[p] = PodRowC{it->second | (tc << 10), (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, 0};
         }
+        // 65 .. 128 signatures: the kernel keeps two per lane (k and k + 64).  When every signature of the upper half can sit 64 slots
+        // above a TWIN -- the same request under another table class -- the kernel evaluates a lane's node byte once for both
+        // (TableScalars::static_tables & 16; config 5: 42 request shapes x 2 table classes).  A permutation of the ids, nothing else.
+        c->sig_twins = false;
+        if (c->table_ok && !c->no_sig_twins && sigs.size() > 64 && sigs.size() <= 128) {
+            const int K = (int)sigs.size(), n_hi = K - 64;
+            std::map<std::tuple<double, double, double, double, uint32_t>, std::vector<int>> by_shape;
+            for (int k = 0; k < K; ++k) by_shape[std::make_tuple(sigs[k].req_c, sigs[k].req_m, sigs[k].nz_c, sigs[k].nz_m, sigs[k].flags)].push_back(k);
+            std::vector<int> slot_of(K, -1), lo_rest;
+            int paired = 0;
+            for (auto& kv : by_shape) {
+                std::vector<int>& v = kv.second;
+                size_t i = 0;
+                for (; i + 1 < v.size() && paired < n_hi; i += 2, ++paired) { slot_of[v[i]] = paired; slot_of[v[i + 1]] = 64 + paired; }
+                for (; i < v.size(); ++i) lo_rest.push_back(v[i]);
+            }
+            if (paired == n_hi) {
+                int next = n_hi;
+                for (int k : lo_rest) slot_of[k] = next++;
+                std::vector<SigRow> moved(K);
+                for (int k = 0; k < K; ++k) moved[slot_of[k]] = sigs[k];
+                sigs.swap(moved);
+                for (int p = 0; p < P; ++p) rowsC[p].sigcls = (rowsC[p].sigcls & ~0x3FF) | slot_of[rowsC[p].sigcls & 0x3FF];
+                c->sig_twins = true;
+            }
+        }
         // REST descriptors: term class (which mask rows a pod must find clear / sets) and GPU signature of every pod
         std::vector<int32_t> xrows;           // entries of every term class: filter row | set row << 16
         std::vector<uint2> gsigs;
@@ -858,6 +885,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
+    c->no_sig_twins = getenv("SIMON_TABLE_NO_TWINS") != nullptr;      // A/B: signature ids in order of appearance
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
@@ -1325,7 +1353,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

@@ -1450,9 +1450,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
             const double rq_c = (double)st.rq_c, rq_m = (double)st.rq_m;
             TPROF(8);                                                  // state update (readlanes of the signature's request), state store
             // Signature k's byte of the touched node, its block key, summary entries and feasible-node counter (lane-local k).
-            auto refresh_sig = [&](int k, bool valid, double q_req_c, double q_req_m, double q_nz_c, double q_nz_m, bool q_zero,
+            auto refresh_sig = [&](int k, bool valid, unsigned nb_raw,
                                    unsigned char* rowk, const uint4 Tk, const uint2 Fk, unsigned old, unsigned snk, int dirty_bit) {
-                const unsigned nb_raw = eval_node(q_req_c, q_req_m, q_nz_c, q_nz_m, q_zero, rq_c, rq_m, nzc, nzm, (int)st.freep, sh);
                 const unsigned nb = old ? nb_raw : 0u;                    // static mask / monotone infeasibility
                 // One wave: its vector memory accesses are served in order, so the next cycle's loads of this row / state
                 // observe these stores; no cache maintenance, no wait.
@@ -1490,9 +1489,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     }
                 }
             };
+            // NodeResourcesFit + LeastAllocated + BalancedAllocation of the touched node per signature of this lane.  With 65 .. 128
+            // signatures the host puts a signature's twin -- same request, another table class (static mask / Simon row) -- 64 slots up
+            // whenever every upper signature has one (TableScalars::static_tables & 16): the upper byte is the lower lane's, unmasked.
+            unsigned nbq[KQ];
+            nbq[0] = eval_node(my_req_c[0], my_req_m[0], my_nz_c[0], my_nz_m[0], my_zero[0], rq_c, rq_m, nzc, nzm, (int)st.freep, sh);
+            if constexpr (KQ > 1) {
+                if (sc.static_tables & 16) nbq[KQ - 1] = nbq[0];
+                else nbq[KQ - 1] = eval_node(my_req_c[KQ - 1], my_req_m[KQ - 1], my_nz_c[KQ - 1], my_nz_m[KQ - 1], my_zero[KQ - 1], rq_c, rq_m, nzc, nzm, (int)st.freep, sh);
+            }
 #pragma unroll
             for (int q = 0; q < KQ; ++q)
-                refresh_sig(kk[q], kvalid[q], my_req_c[q], my_req_m[q], my_nz_c[q], my_nz_m[q], my_zero[q], rowp[q], T[q], COARSE ? F[q] : make_uint2(0u, 0u),
+                refresh_sig(kk[q], kvalid[q], nbq[q], rowp[q], T[q], COARSE ? F[q] : make_uint2(0u, 0u),
                             oldq[q], snq[q], q);
             // MANY: the further groups (their table rows arrived with group 0's; the signature rows of TableCold::sigs are L2-hot)
             if constexpr (MANY) {
@@ -1505,7 +1513,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                         for (int q = 0; q < KQ; ++q) { rg[q] = sigs[kg[g][q]]; sng[q] = s_sn[kg[g][q] * Cn + dstar]; }
 #pragma unroll
                         for (int q = 0; q < KQ; ++q)
-                            refresh_sig(kg[g][q], 128 * (g + 1) + 64 * q + lane < K, rg[q].req_c, rg[q].req_m, rg[q].nz_c, rg[q].nz_m, rg[q].flags & 1u,
+                            refresh_sig(kg[g][q], 128 * (g + 1) + 64 * q + lane < K,
+                                        eval_node(rg[q].req_c, rg[q].req_m, rg[q].nz_c, rg[q].nz_m, rg[q].flags & 1u, rq_c, rq_m, nzc, nzm, (int)st.freep, sh),
                                         rowg[g][q], Tg[g][q], Fg[g][q], oldg[g][q], sng[q], 2 * (g + 1) + q);
                     }
                 }
