@@ -112,6 +112,14 @@ struct simon_ctx : simon::HostInputs {
     bool no_gpu_split = false, force_table = false;
     bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
+    // fold: required anti-affinity / host ports on node-level topology keys as MONOTONE INFEASIBILITY of the score table -- a pod that
+    // lands on a node zeroes the node's byte of every signature it excludes there, for good (fold_supported); env SIMON_NO_FOLD
+    bool fold = false, no_fold = false;
+    int fold_sigs = 0;                            // upper bound of the signatures the fold needs
+    std::vector<int32_t> fold_fc;                 // [Cp] filter class of a pod class
+    std::vector<uint8_t> fold_x;                  // [FC][FC]: a pod of filter class L on a node excludes filter class S from it
+    int fold_FC = 0;
+    DevBuf<uint32_t> d_foldx;                     // [K][ceil(K / 32)]: bit S of row L = signature L landing excludes signature S
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
     std::vector<int> zone_keys;                  // topology keys of terms that are not node-level (REST: a domain = many positions)
     std::vector<int> key_zslot;                  // [Kt] index into zone_keys or -1 (node-level / unused)
@@ -293,7 +301,8 @@ bool rest_supported(simon_ctx* c) {
 // node classes are split by their domains).  Fills sp_kind / sp_row / sp_zslot / sp_zkeys.
 bool spread_supported(simon_ctx* c) {
     if (c->no_spread || c->ss_idx.empty()) return false;
-    if (c->has_ipa_score || !c->sh_idx.empty() || c->has_local || !c->aff_idx.empty() || !c->anti_idx.empty() || !c->port_idx.empty()) return false;
+    if (c->has_ipa_score || !c->sh_idx.empty() || c->has_local || !c->aff_idx.empty()) return false;
+    if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold) return false;   // required anti-affinity / ports: only folded into the table
     if (c->has_gpu || c->has_gpu_index) return false;
     if (c->topo_is_hostname.empty() || c->spread_log.size() < (size_t)c->N + 1) return false;
     int64_t max_pods = 0;
@@ -353,6 +362,77 @@ bool spread_supported(simon_ctx* c) {
     return true;
 }
 
+// Required anti-affinity (both directions, filtering.go:319-346) and NodePorts conflicts (node_ports.go:104-127) on node-level topology
+// keys never leave the node the pod lands on, and pods never leave: "signature S cannot use node j any more" is the monotone
+// infeasibility the score table already knows (byte 0 stays 0).  The fold needs: only anti / match / port lists among the
+// placement-dependent filters, every such term on a key that gives every node its own domain, counted on every node; the filter
+// class (anti list, relevant match list, port list) becomes part of the request signature.
+bool fold_supported(simon_ctx* c) {
+    c->fold_fc.clear(); c->fold_x.clear(); c->fold_FC = 0; c->fold_sigs = 0;
+    if (c->no_fold || c->Tm <= 0 || (c->anti_idx.empty() && c->port_idx.empty())) return false;
+    if (!c->aff_idx.empty() || c->has_gpu || c->has_gpu_index || c->match_off.empty()) return false;
+    const int Cp = c->Cp, N = c->N;
+    std::vector<char> relevant(c->Tm, 0);
+    auto list_of = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& idx, int cp) {
+        std::vector<int32_t> v;
+        if (!off.empty()) v.assign(idx.begin() + off[cp], idx.begin() + off[cp + 1]);
+        std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+        return v;
+    };
+    for (int cp = 0; cp < Cp; ++cp) {
+        for (int t : list_of(c->anti_off, c->anti_idx, cp)) { if (t < 0 || t >= c->Tm) return false; relevant[t] = 1; }
+        for (int t : list_of(c->port_off, c->port_idx, cp)) { if (t < 0 || t >= c->Tm) return false; relevant[t] = 1; }
+    }
+    std::vector<int> key_ok(std::max(c->Kt, 1), -1);
+    for (int t = 0; t < c->Tm; ++t) {
+        if (!relevant[t]) continue;
+        if (!c->term_set.empty() && c->term_set[t] >= 0) return false;
+        const int k = c->term_key[t];
+        if (key_ok[k] < 0) {
+            std::vector<char> seen(N, 0);
+            key_ok[k] = 1;
+            for (int j = 0; j < N && key_ok[k]; ++j) {
+                const int d = c->topo_dom[(size_t)k * N + j];
+                if (d < 0 || d >= N || seen[d]) key_ok[k] = 0; else seen[d] = 1;
+            }
+        }
+        if (!key_ok[k]) return false;
+    }
+    // filter classes by content
+    std::map<std::tuple<std::vector<int32_t>, std::vector<int32_t>, std::vector<int32_t>>, int> fc_id;
+    std::vector<std::tuple<std::vector<int32_t>, std::vector<int32_t>, std::vector<int32_t>>> fcs;
+    c->fold_fc.assign(Cp, 0);
+    for (int cp = 0; cp < Cp; ++cp) {
+        std::vector<int32_t> anti = list_of(c->anti_off, c->anti_idx, cp), port = list_of(c->port_off, c->port_idx, cp), match;
+        for (int t : list_of(c->match_off, c->match_idx, cp)) { if (t < 0 || t >= c->Tm) return false; if (relevant[t]) match.push_back(t); }
+        auto key = std::make_tuple(anti, match, port);
+        auto it = fc_id.emplace(key, (int)fcs.size());
+        if (it.second) fcs.push_back(key);
+        c->fold_fc[cp] = it.first->second;
+    }
+    const int FC = (int)fcs.size();
+    if (FC > 4096) return false;
+    auto meets = [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) {       // sorted lists share an element
+        size_t i = 0, j = 0;
+        while (i < a.size() && j < b.size()) { if (a[i] == b[j]) return true; if (a[i] < b[j]) ++i; else ++j; }
+        return false;
+    };
+    c->fold_x.assign((size_t)FC * FC, 0);
+    for (int L = 0; L < FC; ++L)
+        for (int S = 0; S < FC; ++S)       // L has landed: S meets a pod matching one of its anti terms / ports, or a pod requiring a term S matches
+            c->fold_x[(size_t)L * FC + S] = meets(std::get<0>(fcs[S]), std::get<1>(fcs[L])) || meets(std::get<1>(fcs[S]), std::get<0>(fcs[L])) ||
+                                            meets(std::get<2>(fcs[S]), std::get<1>(fcs[L]));
+    c->fold_FC = FC;
+    // signatures the table would need, at most (stage_narrow merges pod classes with equal static rows further)
+    std::set<std::tuple<int64_t, int64_t, int64_t, int64_t, int32_t>> sig;
+    for (int p = 0; p < c->P; ++p) {
+        sig.insert(std::make_tuple(c->p_req_cpu[p], c->p_req_mem[p], c->p_nz_cpu[p], c->p_nz_mem[p], c->p_cls[p]));
+        if ((int)sig.size() > kTableMaxSigs) return false;
+    }
+    c->fold_sigs = (int)sig.size();
+    return true;
+}
+
 // Decide NARROW vs WIDE and compute the gcd normalisation.
 // NARROW needs: cpu+mem+pods only; every quantity non-negative; after dividing by the gcd all
 // node totals and the worst-case accumulated NonZeroRequested stay < 2^31; simon raw scores fit
@@ -364,6 +444,7 @@ void choose_variant(simon_ctx* c) {
     c->rest = false;
     c->spread = false;
     c->has_static = c->has_na || c->has_tt || c->has_add;
+    c->fold = fold_supported(c);
     if (c->v2_features_but_ports_and_static()) {
         if (!spread_supported(c)) return;                         // only soft spread constraints: generation 7 of the score-table kernel
         c->spread = true;
@@ -385,8 +466,12 @@ void choose_variant(simon_ctx* c) {
     for (int64_t x : c->p_req_eph) if (x) c->xres = true;
     for (int64_t x : c->i_scalar_req) if (x) c->xres = true;
     for (int64_t x : c->p_scalar) if (x) c->xres = true;
-    const bool wants_rest = !c->spread && (c->has_gpu || c->Tm > 0 || c->xres);
+    if (c->fold && c->xres) c->fold = false;                        // (extra-resource rows live on the REST path)
+    // anti-affinity / ports without soft spread constraints: the fold while two signatures per lane hold them, else the position masks
+    if (c->fold && !c->spread && c->fold_sigs > 128 && rest_supported(c)) c->fold = false;
+    const bool wants_rest = !c->spread && !c->fold && (c->has_gpu || c->Tm > 0 || c->xres);
     if (c->spread && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
+    if (c->spread && !c->fold && (!c->anti_idx.empty() || !c->port_idx.empty())) { c->spread = false; return; }
     if (wants_rest && !rest_supported(c)) return;
     if (c->N >= (1 << 20) - 1) return;
     const uint64_t gc = gcd_of({&c->alloc_cpu, &c->i_req_cpu, &c->i_nz_cpu, &c->p_req_cpu, &c->p_nz_cpu});
@@ -478,13 +563,15 @@ int stage_narrow(simon_ctx* c) {
             tc_of[cp] = it.first->second;
         }
         const int Ctc = (int)tc_rep.size();
-        std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t>, int> sig_id;
+        std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t, int32_t>, int> sig_id;
         std::vector<SigRow> sigs;
+        std::vector<int32_t> sig_fc;          // fold: filter class of a signature
         std::vector<PodRowC> rowsC(P);
         for (int p = 0; p < P && c->table_ok; ++p) {
             const PodRowN& r = rows[p];
             const int32_t tc = tc_of[r.cls];
-            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, tc, r.flags);
+            const int32_t fc = c->fold ? c->fold_fc[r.cls] : 0;
+            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, tc, r.flags, fc);
             auto it = sig_id.find(key);
             if (it == sig_id.end()) {
                 if ((int)sigs.size() == kTableMaxSigs) { c->table_ok = false; break; }
@@ -492,6 +579,7 @@ int stage_narrow(simon_ctx* c) {
                 SigRow sr{};
                 sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = tc; sr.flags = r.flags;
                 sigs.push_back(sr);
+                sig_fc.push_back(fc);
             }
             rowsC[p] = PodRowC{it->second | (tc << 10), (!c->p_pin.empty() && c->p_pin[p] >= 0) ? -2 - c->p_pin[p] : r.preset, r.gate, 0};
         }
@@ -515,8 +603,9 @@ int stage_narrow(simon_ctx* c) {
                 int next = n_hi;
                 for (int k : lo_rest) slot_of[k] = next++;
                 std::vector<SigRow> moved(K);
-                for (int k = 0; k < K; ++k) moved[slot_of[k]] = sigs[k];
-                sigs.swap(moved);
+                std::vector<int32_t> moved_fc(K);
+                for (int k = 0; k < K; ++k) { moved[slot_of[k]] = sigs[k]; moved_fc[slot_of[k]] = sig_fc[k]; }
+                sigs.swap(moved); sig_fc.swap(moved_fc);
                 for (int p = 0; p < P; ++p) rowsC[p].sigcls = (rowsC[p].sigcls & ~0x3FF) | slot_of[rowsC[p].sigcls & 0x3FF];
                 c->sig_twins = true;
             }
@@ -708,6 +797,14 @@ int stage_narrow(simon_ctx* c) {
             c->h_clsprefix = prefix;
             c->h_ncls_t = ncls_t; c->h_cls_off = cls_off;
             HIP_TRY(c, c->d_sigs.upload(sigs, st));
+            if (c->fold) {                                            // which signatures a landing signature excludes from its node
+                const int K = (int)sigs.size(), KW = (K + 31) / 32;
+                std::vector<uint32_t> fx((size_t)K * KW, 0u);
+                for (int L = 0; L < K; ++L)
+                    for (int S = 0; S < K; ++S)
+                        if (c->fold_x[(size_t)sig_fc[L] * c->fold_FC + sig_fc[S]]) fx[(size_t)L * KW + (S >> 5)] |= 1u << (S & 31);
+                HIP_TRY(c, c->d_foldx.upload(fx, st));
+            }
             HIP_TRY(c, c->d_shapes.upload(shapes, st));
             HIP_TRY(c, c->d_podsC.upload(rowsC, st));
             HIP_TRY(c, c->d_t_ncls.upload(ncls_t, st));
@@ -885,6 +982,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_FORCE_WIDE")) c->force_wide = e[0] == '1';
     if (const char* e = getenv("SIMON_TABLE_COARSE")) c->force_coarse = atoi(e) != 0;
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
+    c->no_fold = getenv("SIMON_NO_FOLD") != nullptr;                  // A/B + tests: anti-affinity / ports through the position masks (or the all-feature kernel)
     c->no_sig_twins = getenv("SIMON_TABLE_NO_TWINS") != nullptr;      // A/B: signature ids in order of appearance
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
@@ -1209,6 +1307,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             if (c->rest) coarse = coarse_ok;                        // the REST path is built on the two-level layout
             if (c->n_sigs > 128) coarse = coarse_ok;                // ... and so are the signature groups beyond 128 (simon_table.hip: MANY)
             if (c->spread) coarse = coarse_ok;                      // ... and the SPREAD path (generation 7)
+            if (c->fold) coarse = coarse_ok;                        // ... and the folded exclusions (carried by the two-level instantiations)
             c->table_coarse = coarse;
             for (int s = 0; s < S; ++s) c->scen_ni[s] = coarse ? ni64[s] : ni16[s];
             const int ni_top = coarse ? top64 : top16;
@@ -1221,7 +1320,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY); else generation 2 / all-feature kernel
-            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest && !c->spread)) && (!c->spread || coarse);
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest && !c->spread)) && (!c->spread || coarse) && (!c->fold || coarse);
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1313,7 +1412,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || !c->raw_fits_lds || c->has_ranks || c->has_static;
+        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || c->fold || !c->raw_fits_lds || c->has_ranks || c->has_static;
         // Beyond 256 signatures generation 2 (register-resident state, every node re-evaluated per cycle: its time does not depend on
         // the signature count) overtakes the score table (measured, profiles/r03: 300 signatures 124 ms against 119 ms, 384: 169 ms) --
         // where it is eligible; otherwise the table (K <= 384) still beats the all-feature kernel by far.
@@ -1328,7 +1427,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             cold.ncls = c->d_t_ncls.p; cold.rank = c->d_rank.p; cold.cls_off = c->d_cls_off.p;
             cold.clsprefix = c->d_clsprefix.p; cold.a_pods = c->d_a_pods.p;
             cold.i_rq_cpu = c->d_i_rq_cpu.p; cold.i_rq_mem = c->d_i_rq_mem.p; cold.i_nz_cpu = c->d_i_nz_cpu.p; cold.i_nz_mem = c->d_i_nz_mem.p;
-            cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
+            cold.foldx = c->fold ? c->d_foldx.p : nullptr; cold.i_npods = c->d_i_npods.p; cold.sigs = c->d_sigs.p; cold.shapes = c->d_shapes.p; cold.scen = c->d_scen.p;
             cold.static_mask = c->has_mask ? c->d_t_mask.p : nullptr; cold.simon_raw = c->d_t_raw.p;
             cold.unscheduled = c->d_unsched.p; cold.used_cpu = c->d_used_cpu.p; cold.used_mem = c->d_used_mem.p;
             cold.N = c->N;
@@ -1353,7 +1452,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

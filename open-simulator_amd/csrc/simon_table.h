@@ -33,7 +33,7 @@ struct PodRowC { int32_t sigcls, preset, gate, rest; };
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
     int32_t rk_stride;   // 0: cls_list = the pool's per-class node lists; N: per-scenario lists in rank order (simon_set_node_ranks)
-    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present; bit 3: record TableCold::gpu_slices; bit 4: signature k + 64 is a twin of k (same request)
+    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present; bit 3: record TableCold::gpu_slices; bit 4: signature k + 64 is a twin of k (same request); bit 5: TableCold::foldx present
     int32_t NZ;          // REST: topology keys that are NOT node-level (a term on one marks every position of the pod's domain)
     int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
     int32_t TH, TZ, NZK; // SPREAD: hostname-key term rows, zone-key term rows, zone-like topology keys (class split)
@@ -67,6 +67,7 @@ struct TableCold {
     // (soft: term slot | maxSkew << 16 | SIMON_SPREAD_DUP_KEY bit 30; counted: term slot | multiplicity << 16), each with its term's
     // row: kind (1 hostname-like row, 2 zone-like row) | row << 2 | zone key slot << 16 | (node set + 1) << 19; Go's math.Log table;
     // node sets; zone domain of a class
+    const uint32_t* foldx;          // [K][ceil(K / 32)] (TableScalars::static_tables & 32): bit S of row L = a pod of signature L on a node excludes signature S from it
     const int2* sp_ent;             // x = the entry, y = its term's row (kind | row << 2 | zone key slot << 16 | (node set + 1) << 19)
     const double* spread_log;       // [N + 1] math.Log(float64(i + 2)) (simon_class_tables.spread_log)
     const uint64_t* node_sets;      // [R][set_words]

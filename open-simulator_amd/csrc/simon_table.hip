@@ -1367,7 +1367,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 oldq[q] = rowp[q][pstar & 15];                         // this signature's byte before the cycle (same cache line as the row)
                 if (COARSE) F[q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kk[q]) * 4u);
             }
+            // Fold (TableScalars::static_tables & 32): required anti-affinity / host ports on node-level keys.  The landing pod's signature
+            // names the signatures that may not use this node any more (TableCold::foldx, one bit per signature): their bytes go to 0 with
+            // the refresh below and stay there -- the table's monotone infeasibility; summaries and counters follow as for a full node.
+            // Only the two-level instantiations without the REST rows carry the code (the host picks them for such problems): the
+            // one-level kernel of the benchmark configurations stays as it is.
+            constexpr bool kFoldable = COARSE && !REST;
+            const bool fold = kFoldable && (sc.static_tables & 32);
+            const unsigned KW = ((unsigned)K + 31u) >> 5;
+            unsigned xfold[KQ];
+            if constexpr (kFoldable) {
+                if (__builtin_expect(fold, 0)) {                      // (a uniform branch)
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) xfold[q] = cold->foldx[(unsigned)r_sig * KW + ((unsigned)kk[q] >> 5)];
+                }
+            }
             // MANY: the rows of the signatures beyond the register-resident ones, same round trip (uniform group conditions)
+            unsigned xfg[NG ? NG : 1][KQ];
             unsigned char* rowg[NG ? NG : 1][KQ];
             uint4 Tg[NG ? NG : 1][KQ];
             uint2 Fg[NG ? NG : 1][KQ];
@@ -1385,6 +1401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                             Tg[g][q] = *(const uint4*)rowg[g][q];
                             oldg[g][q] = rowg[g][q][pstar & 15];
                             Fg[g][q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kg[g][q]) * 4u);
+                            if (__builtin_expect(fold, 0)) xfg[g][q] = cold->foldx[(unsigned)r_sig * KW + ((unsigned)kg[g][q] >> 5)];
                         }
                     }
                 }
@@ -1498,6 +1515,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 if (sc.static_tables & 16) nbq[KQ - 1] = nbq[0];
                 else nbq[KQ - 1] = eval_node(my_req_c[KQ - 1], my_req_m[KQ - 1], my_nz_c[KQ - 1], my_nz_m[KQ - 1], my_zero[KQ - 1], rq_c, rq_m, nzc, nzm, (int)st.freep, sh);
             }
+            if constexpr (kFoldable) {
+                if (__builtin_expect(fold, 0)) {                      // folded exclusions: the signatures this landing rules out get byte 0
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) nbq[q] = ((xfold[q] >> (kk[q] & 31)) & 1u) ? 0u : nbq[q];
+                }
+            }
 #pragma unroll
             for (int q = 0; q < KQ; ++q)
                 refresh_sig(kk[q], kvalid[q], nbq[q], rowp[q], T[q], COARSE ? F[q] : make_uint2(0u, 0u),
@@ -1514,6 +1537,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
 #pragma unroll
                         for (int q = 0; q < KQ; ++q)
                             refresh_sig(kg[g][q], 128 * (g + 1) + 64 * q + lane < K,
+                                        (fold && ((xfg[g][q] >> (kg[g][q] & 31)) & 1u)) ? 0u :
                                         eval_node(rg[q].req_c, rg[q].req_m, rg[q].nz_c, rg[q].nz_m, rg[q].flags & 1u, rq_c, rq_m, nzc, nzm, (int)st.freep, sh),
                                         rowg[g][q], Tg[g][q], Fg[g][q], oldg[g][q], sng[q], 2 * (g + 1) + q);
                     }

@@ -253,13 +253,14 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
 
 
 def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
-                   seed: int = SEED + 6):
+                   seed: int = SEED + 6, n_anti: int = 0):
     """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
     request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
     constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
     ScheduleAnyway, selector = the Service's).  Nodes are zoned round robin by index (j % n_zones), which keeps nodeTree.list() =
     index order for every cluster size (V/internal/cache/node_tree.go:119-143).  Terms: per service (selector, hostname) and
-    (selector, zone); the pods of a service match both and nothing else."""
+    (selector, zone); the pods of a service match both and nothing else.  `n_anti`: the first n_anti services additionally REQUIRE
+    anti-affinity to their own pods on kubernetes.io/hostname (one replica per node: the usual companion of a Service)."""
     from .gomath import spread_log_table
     n_total = n_het + n_counts
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
@@ -279,7 +280,12 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
                    term_topo_key=np.tile(np.array([0, 1], np.int32), n_services), term_node_set=np.full(T, -1, np.int32),
                    match_off=np.arange(0, T + 1, 2, dtype=np.int32), match_idx=np.arange(T, dtype=np.int32),
                    spread_soft_off=np.arange(0, T + 1, 2, dtype=np.int32), spread_soft_idx=np.arange(T, dtype=np.int32),
-                   spread_soft_skew=np.tile(np.array([3, 5], np.int32), n_services), spread_log=spread_log_table(n_total)).normalise()
+                   spread_soft_skew=np.tile(np.array([3, 5], np.int32), n_services), spread_log=spread_log_table(n_total))
+    if n_anti > 0:
+        na = min(n_anti, n_services)
+        prob.anti_off = np.concatenate([np.arange(na + 1), np.full(n_services - na, na)]).astype(np.int32)
+        prob.anti_idx = (2 * np.arange(na)).astype(np.int32)          # the service's own (selector, hostname) term
+    prob = prob.normalise()
     orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)
     scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)

@@ -147,7 +147,7 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
         prob.local_spec_of = np.where(rng.random(n_pod_classes) < 0.6, rng.integers(0, len(specs), n_pod_classes), -1).astype(np.int32)
     v2 = aff or ipa or spread_hard or spread_soft
     if anti or v2:
-        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft)
+        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft, anti_host)
     elif anti_host or ports:
         _topology_host(prob, rng, N, n_pod_classes, anti_host, ports)
     return prob.normalise()
@@ -190,7 +190,7 @@ def _topology_host(prob, rng, N, Cp, anti=True, ports=False):
         prob.port_off, prob.port_idx = _csr(portl)
 
 
-def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft):
+def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_host=False):
     """Two topology keys -- hostname (domain = node) and zone (4 zones, some nodes unlabeled) -- and 8 terms over them;
     every role list of include/simon_hip.h gets random entries for the enabled features."""
     zone = rng.integers(-1, 4, N).astype(np.int32)
@@ -222,7 +222,9 @@ def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft):
     match, antil, affl, pref, prefw, own, ownw, hard, hskew, hself, hset, soft, sskew, flags = ([] for _ in range(14))
     for c in range(Cp):
         match.append(pick(np.arange(T), 0.7, 4))
-        antil.append(pick([0, 1, 2, 3], 0.5, 2) if anti else [])
+        # anti_host (without anti): required anti-affinity on hostname-key terms only -- what the score table can fold in (term 5 is a
+        # soft-spread term as well)
+        antil.append(pick([0, 1, 2, 3], 0.5, 2) if anti else pick([0, 2, 5], 0.5, 2) if anti_host else [])
         a = pick([4, 5], 0.4, 2) if aff else []
         affl.append(a)
         flags.append(capi.CLASS_AFF_SELF if a and all(t in match[c] for t in a) else 0)

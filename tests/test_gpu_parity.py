@@ -196,10 +196,11 @@ REST_FEATURES = [
 
 
 @pytest.mark.parametrize("idx", range(len(REST_FEATURES)))
-def test_random_rest_features(idx):
+def test_random_rest_features(idx, monkeypatch):
     """Open-Gpu-Share, required anti-affinity on node-level topology keys, ephemeral storage and extended resources on the score-table
     kernel (generation 6): position masks per block, per-class best + NormalizeScore over the classes that kept a node."""
     feat = REST_FEATURES[idx]
+    monkeypatch.setenv("SIMON_NO_FOLD", "1")               # (anti-affinity / ports alone would be folded into the table: the test below)
     for seed in range(4):
         N = [37, 150, 700, 1500][seed]
         prob = randprob.rand_problem(7000 + 100 * idx + seed, N=N, P=500 + 300 * seed, n_pod_classes=6 + 5 * seed, n_node_classes=3 + 2 * seed, **feat)
@@ -213,6 +214,37 @@ def test_random_rest_features(idx):
         if feat.get("scalars", 0) <= 2:                    # more extended resources: more than 32 distinct requests may appear
             assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == (6 if set(feat) - {"static_small"} else 4)
         assert_same(res, ref)
+
+
+FOLD_FEATURES = [dict(anti_host=True), dict(ports=True), dict(anti_host=True, ports=True),
+                 dict(anti_host=True, pins=True, presets=True, tight_pods=True), dict(ports=True, anti_host=True, presets=True, gates=True, static_mask=True),
+                 dict(anti_host=True, static_small=True, nz_differs=True, init_state=True, zero_pods=True)]
+
+
+@pytest.mark.parametrize("idx", range(len(FOLD_FEATURES)))
+def test_anti_affinity_and_ports_folded_into_the_score_table(idx, monkeypatch):
+    """Required anti-affinity and host ports on node-level topology keys WITHOUT GPU share: a landing pod zeroes the node's byte of every
+    signature it excludes there (monotone infeasibility: simon_hip.hip fold_supported) -- generations 4 / 5, no position masks; the same
+    problems through the position masks (SIMON_NO_FOLD=1: generation 6)."""
+    feat = FOLD_FEATURES[idx]
+    for seed in range(4):
+        N = [37, 150, 700, 1500][seed]
+        prob = randprob.rand_problem(7900 + 100 * idx + seed, N=N, P=500 + 300 * seed, n_pod_classes=6 + 5 * seed, n_node_classes=3 + 2 * seed, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=5, min_n=1 if seed == 0 else None)
+        ref = O.run_threaded(prob, scen, orders)
+        for no_fold in (False, True):
+            if no_fold:
+                monkeypatch.setenv("SIMON_NO_FOLD", "1")
+            else:
+                monkeypatch.delenv("SIMON_NO_FOLD", raising=False)
+            with capi.Context(0) as ctx:
+                ctx.load_problem(prob)
+                ctx.load_scenarios(scen, orders)
+                ctx.run_loaded(True)
+                res, st = ctx.fetch(True), ctx.stats()
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == (6 if no_fold else st.kernel_generation)
+            assert (st.kernel_generation in (4, 5)) != no_fold, (st.kernel_generation, no_fold)
+            assert_same(res, ref)
 
 
 V2_FEATURES = [

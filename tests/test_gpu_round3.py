@@ -212,3 +212,34 @@ def test_k8s_deployments_behind_services_sweep_on_generation_7():
     assert prob.n_pods > 1000 and len(scen) == 8 and eng.kw.get("node_ranks") is not None
     assert eng.last_stats.kernel_variant == capi.KERNEL_NARROW_CACHE and eng.last_stats.kernel_generation == 7
     assert_same(eng.out, O.run(prob, scen, orders, node_ranks=eng.kw["node_ranks"]))
+
+
+@pytest.mark.parametrize("feat", [dict(anti_host=True), dict(anti_host=True, static_mask=True, presets=True, gates=True, pins=True),
+                                  dict(anti_host=True, nz_differs=True, init_state=True, tight_pods=True)])
+def test_soft_spread_constraints_with_required_hostname_anti_affinity(feat):
+    """Generation 7 + the fold: Service-style soft spread constraints together with required anti-affinity on the hostname key (a term
+    may be both) stay on the score-table kernel; every placement against the oracle, with and without per-scenario node ranks."""
+    rng = np.random.default_rng(11)
+    on7 = 0
+    for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500)]):
+        prob = randprob.rand_problem(7300 + seed, N=N, P=P, spread_soft=True, n_node_classes=4, n_pod_classes=9, **feat)
+        scen, orders = randprob.rand_scenarios(170 + seed, prob, S=5)
+        ref = O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders)
+            st = ctx.stats()
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7, (st.kernel_variant, st.kernel_generation)
+            assert_same(res, ref)
+            ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+            for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
+                ranks[s_, :n] = rng.permutation(n)
+            ctx.load_scenarios(scen, orders)
+            ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            assert ctx.stats().kernel_generation == 7
+            assert_same(ctx.fetch(True), O.run(prob, scen, orders, node_ranks=ranks))
+        on7 += 1
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_FOLD": "1"})          # without the fold: the all-feature kernel
+    assert variant == capi.KERNEL_WIDE
+    assert_same(res, ref)
