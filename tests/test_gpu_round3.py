@@ -154,7 +154,8 @@ def test_service_workload_full_size_subset():
 
 def test_k8s_deployments_behind_services_sweep_on_generation_7():
     """The object-level path of SURVEY.md 8(f) N1: Deployments / StatefulSets selected by Services (system-default soft spread
-    constraints, plugin.go:39-50), some with their own ScheduleAnyway constraints and node selectors, on a cluster with three zones,
+    constraints, plugin.go:39-50), some with their own ScheduleAnyway constraints, node selectors and required anti-affinity to their
+    own replicas on the hostname key, on a cluster with three zones,
     unlabeled and tainted nodes -- `simulate.sweep` over eight cluster sizes in one batch (per-scenario nodeTree ranks) stays on the
     score-table kernel; every placement against the oracle."""
     import randk8s
@@ -184,6 +185,9 @@ def test_k8s_deployments_behind_services_sweep_on_generation_7():
             spec["topologySpreadConstraints"] = [
                 {"maxSkew": 1, "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": app}}},
                 {"maxSkew": 2, "topologyKey": randk8s.HOST, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": app}}}]
+        if w % 6 == 5:          # one replica per node: required anti-affinity to the workload's own pods on the hostname key (folded into the table)
+            spec["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+                {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}]}}
         if w % 7 == 3:
             spec["nodeSelector"] = {"disk": "ssd"}
         if w % 9 == 4:
