@@ -1012,9 +1012,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (byte1[j] << 8));   // (uniform base + lane: one address add)
                 }
                 u0 += SB;
-#ifdef SIMON_SPREAD_ABLATE_PASS1
-                break;                                                    // timing experiment only (wrong results): pass 1 over one batch
-#endif
                 if (u0 >= nun) break;
                 load1(u0);
             }
@@ -1033,12 +1030,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 if (i < E) s_tab[i] = (cw & 0x7fffffff) + 2 * v;
             }
             TPROF_WAIT_LDS; TPROF(16);                                     // spread: extremes, table of totals
-#ifdef SIMON_SPREAD_ABLATE_PASS2
-            const int nun2 = nun < 2 ? nun : 2;                           // timing experiment only (wrong results): pass 2 over two units
-#else
-            const int nun2 = nun;
-#endif
-            for (int u0 = 0; u0 < nun2; u0 += SC) {                       // pass 2: totals, first maximum in canonical order
+            for (int u0 = 0; u0 < nun; u0 += SC) {                       // pass 2: totals, first maximum in canonical order
                 int canon[SC], cbase[SC];
                 unsigned stj[SC];
 #pragma unroll

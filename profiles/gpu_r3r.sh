@@ -1,5 +1,5 @@
 #!/bin/bash
-# generation 7: where the time of a cycle goes -- timing-only builds that cut pass 1 / pass 2 short (WRONG results, never shipped); usage: bash profiles/gpu_r3r.sh <tag>
+# generation 7: where the time of a cycle goes -- timing-only builds that cut pass 1 / pass 2 short (WRONG results, never shipped; the -DSIMON_SPREAD_ABLATE_* switches were removed from the source afterwards); usage: bash profiles/gpu_r3r.sh <tag>
 set -u
 TAG=${1:-r3r}
 export TMPDIR=/tmp
