@@ -1362,9 +1362,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
             // Fold (TableScalars::static_tables & 32): required anti-affinity / host ports on node-level keys.  The landing pod's signature
             // names the signatures that may not use this node any more (TableCold::foldx, one bit per signature): their bytes go to 0 with
             // the refresh below and stay there -- the table's monotone infeasibility; summaries and counters follow as for a full node.
-            // Only the two-level instantiations without the REST rows carry the code (the host picks them for such problems): the
-            // one-level kernel of the benchmark configurations stays as it is.
-            constexpr bool kFoldable = COARSE && !REST;
+            // Only the two-level instantiations without the REST rows that know pinned pods carry the code (the host picks them for such
+            // problems): the kernels of the benchmark configurations stay as they are.
+            constexpr bool kFoldable = COARSE && !REST && HAS_PIN;   // (launch_table sends a problem with the fold to the HAS_PIN instantiations)
             const bool fold = kFoldable && (sc.static_tables & 32);
             const unsigned KW = ((unsigned)K + 31u) >> 5;
             unsigned xfold[KQ];
@@ -1647,7 +1647,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 }
 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
-    has_pin = has_pin || a.rest || a.spread;
+    has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & 32);   // (& 32: the fold, carried by COARSE && !REST && HAS_PIN)
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }
