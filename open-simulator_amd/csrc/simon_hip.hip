@@ -132,6 +132,10 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<uint2> d_gsig;
     // SPREAD path of the score-table kernel (soft PodTopologySpread constraints, generation 7): decided by choose_variant
     bool sig_twins = false, no_sig_twins = false; // upper-half signatures sit 64 slots above a twin (same request, other table class); env SIMON_TABLE_NO_TWINS
+    // InterPodAffinity preferred terms in self-referential form, scored in spread_select's table (spread_supported); env SIMON_NO_IPA_FOLD
+    bool ipa_fold = false, no_ipa_fold = false;
+    std::vector<int32_t> ipa_h_term, ipa_h_w;     // [Cp] the hostname-like term of a class's raw score (-1: none) and its coefficient
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
     std::vector<int> sp_zkeys;                   // topology keys of the zone-like soft terms (<= kSpreadMaxZoneKeys): the class split
@@ -300,63 +304,129 @@ bool rest_supported(simon_ctx* c) {
 // topo_is_hostname, every node its own domain: one counter byte per position) or on a zone-like key (<= 16 domains; <= 3 such keys: the
 // node classes are split by their domains).  Fills sp_kind / sp_row / sp_zslot / sp_zkeys.
 bool spread_supported(simon_ctx* c) {
-    if (c->no_spread || c->ss_idx.empty()) return false;
-    if (c->has_ipa_score || !c->sh_idx.empty() || c->has_local || !c->aff_idx.empty()) return false;
+    c->ipa_fold = false;
+    c->ipa_h_term.clear(); c->ipa_h_w.clear(); c->ipa_z.clear();
+    if (c->no_spread || (c->ss_idx.empty() && !c->has_ipa_score)) return false;
+    if (c->has_ipa_score && c->no_ipa_fold) return false;
+    if (!c->sh_idx.empty() || c->has_local || !c->aff_idx.empty()) return false;
     if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold) return false;   // required anti-affinity / ports: only folded into the table
     if (c->has_gpu || c->has_gpu_index) return false;
-    if (c->topo_is_hostname.empty() || c->spread_log.size() < (size_t)c->N + 1) return false;
+    if (c->topo_is_hostname.empty()) return false;
+    if (!c->ss_idx.empty() && c->spread_log.size() < (size_t)c->N + 1) return false;
     int64_t max_pods = 0;
     for (int32_t x : c->alloc_pods) { if (x > 255) return false; max_pods = std::max<int64_t>(max_pods, x); }   // the per-position counters are bytes
-    if (c->P > 0 && c->N > 0) { /* pre-bound pods (init_npods) carry no labels: nothing to count at the start */ }
     c->sp_kind.assign(c->Tm, 0); c->sp_row.assign(c->Tm, 0); c->sp_zslot.assign(c->Tm, 0);
     c->sp_zkeys.clear();
     c->sp_TH = c->sp_TZ = 0;
     std::vector<int> key_kind(std::max(c->Kt, 1), -1);                    // 1 hostname-like, 2 zone-like, 0 unusable
-    for (int cp = 0; cp < c->Cp; ++cp) {
-        const int lo = c->ss_off[cp], hi = c->ss_off[cp + 1];
-        int n_host = 0;
-        for (int e = lo; e < hi; ++e) {
-            const int t = c->ss_idx[e];
-            if (t < 0 || t >= c->Tm) return false;
+    // a term gets a counter row: a byte per position (hostname-like key) or a word per domain (zone-like key)
+    auto classify = [&](int t) -> int {
+        if (t < 0 || t >= c->Tm) return 0;
+        const int k = c->term_key[t];
+        if (key_kind[k] < 0) {
+            key_kind[k] = 0;
+            if (c->topo_is_hostname[k]) {                                 // size = scored nodes (scoring.go:100-104): needs one domain per node
+                std::vector<char> seen(c->N, 0);
+                bool ok = true;
+                for (int j = 0; j < c->N && ok; ++j) {
+                    const int d = c->topo_dom[(size_t)k * c->N + j];
+                    ok = d >= 0 && d < c->N && !seen[d];
+                    if (ok) seen[d] = 1;
+                }
+                key_kind[k] = ok ? 1 : 0;
+            } else {
+                bool ok = c->topo_n_dom[k] <= kSpreadMaxZoneDom;
+                for (int j = 0; j < c->N && ok; ++j) { const int d = c->topo_dom[(size_t)k * c->N + j]; ok = d >= -1 && d < kSpreadMaxZoneDom; }
+                if (ok && (int)c->sp_zkeys.size() < kSpreadMaxZoneKeys) { key_kind[k] = 2; c->sp_zkeys.push_back(k); }
+            }
+        }
+        if (key_kind[k] == 0) return 0;
+        if (c->sp_kind[t] == 0) {
+            c->sp_kind[t] = key_kind[k];
+            if (key_kind[k] == 1) c->sp_row[t] = c->sp_TH++;
+            else {
+                c->sp_row[t] = c->sp_TZ++;
+                c->sp_zslot[t] = (int)(std::find(c->sp_zkeys.begin(), c->sp_zkeys.end(), k) - c->sp_zkeys.begin());
+            }
+        }
+        return key_kind[k];
+    };
+    for (int cp = 0; cp < c->Cp && !c->ss_idx.empty(); ++cp) {
+        for (int e = c->ss_off[cp]; e < c->ss_off[cp + 1]; ++e) {
             const int maxskew = c->ss_skew[e] & ~SIMON_SPREAD_DUP_KEY;
             if (maxskew < 1 || maxskew >= (1 << 14)) return false;
-            const int k = c->term_key[t];
-            if (key_kind[k] < 0) {
-                key_kind[k] = 0;
-                if (c->topo_is_hostname[k]) {                             // size = scored nodes (scoring.go:100-104): needs one domain per node
-                    std::vector<char> seen(c->N, 0);
-                    bool ok = true;
-                    for (int j = 0; j < c->N && ok; ++j) {
-                        const int d = c->topo_dom[(size_t)k * c->N + j];
-                        ok = d >= 0 && d < c->N && !seen[d];
-                        if (ok) seen[d] = 1;
-                    }
-                    key_kind[k] = ok ? 1 : 0;
-                } else {
-                    bool ok = c->topo_n_dom[k] <= kSpreadMaxZoneDom;
-                    for (int j = 0; j < c->N && ok; ++j) { const int d = c->topo_dom[(size_t)k * c->N + j]; ok = d >= -1 && d < kSpreadMaxZoneDom; }
-                    if (ok && (int)c->sp_zkeys.size() < kSpreadMaxZoneKeys) { key_kind[k] = 2; c->sp_zkeys.push_back(k); }
-                }
-            }
-            if (key_kind[k] == 0) return false;
-            if (c->sp_kind[t] == 0) {
-                c->sp_kind[t] = key_kind[k];
-                if (key_kind[k] == 1) c->sp_row[t] = c->sp_TH++;
-                else {
-                    c->sp_row[t] = c->sp_TZ++;
-                    c->sp_zslot[t] = (int)(std::find(c->sp_zkeys.begin(), c->sp_zkeys.end(), k) - c->sp_zkeys.begin());
-                }
-            }
-            n_host += key_kind[k] == 1;
+            if (!classify(c->ss_idx[e])) return false;
         }
-        (void)n_host;
+    }
+    // InterPodAffinity preferred terms (scoring.go:87-271) in their usual, SELF-REFERENTIAL form: the raw score of pod class cp on a node is
+    //   sum_e pref_w[e] * cnt_match[t_e][dom] + sum_{t in match(cp)} w_owner[t][dom],
+    // and w_owner[t] = w_t * cnt_match[t] whenever every class owns t with w_t times the multiplicity it matches t with (the pods a
+    // workload's (anti-)affinity term selects are the workload's own).  Then raw = sum_t coef(cp, t) * cnt_match[t][dom]: with at most ONE
+    // hostname-like term per class -- the one its soft spread constraint counts, if it has one -- the raw score is a function of (class,
+    // count) like the spread score and joins it in spread_select's table; zone-like terms add a per-class constant.
+    if (c->has_ipa_score) {
+        if (c->match_off.empty()) return false;
+        const int Cp = c->Cp, T = c->Tm;
+        std::vector<std::map<int, long long>> prefsum(Cp), ownsum(Cp), mult(Cp);
+        for (int cp = 0; cp < Cp; ++cp) {
+            if (!c->pref_off.empty()) for (int e = c->pref_off[cp]; e < c->pref_off[cp + 1]; ++e) prefsum[cp][c->pref_idx[e]] += c->pref_w[e];
+            if (!c->own_off.empty()) for (int e = c->own_off[cp]; e < c->own_off[cp + 1]; ++e) ownsum[cp][c->own_idx[e]] += c->own_w[e];
+            for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) mult[cp][c->match_idx[e]] += 1;
+        }
+        std::vector<long long> wt(T, 0);
+        std::vector<char> wset(T, 0), owned(T, 0);
+        for (int cp = 0; cp < Cp; ++cp) for (auto& kv : ownsum[cp]) { if (kv.first < 0 || kv.first >= T) return false; if (kv.second) owned[kv.first] = 1; }
+        for (int t = 0; t < T; ++t) {
+            if (!owned[t]) continue;
+            for (int cp = 0; cp < Cp; ++cp) {
+                const long long m = mult[cp].count(t) ? mult[cp][t] : 0, o = ownsum[cp].count(t) ? ownsum[cp][t] : 0;
+                if (m == 0) { if (o != 0) return false; continue; }      // owns the term without matching it: w_owner is not a multiple of cnt_match
+                if (o % m) return false;
+                if (!wset[t]) { wt[t] = o / m; wset[t] = 1; }
+                else if (wt[t] != o / m) return false;
+            }
+        }
+        c->ipa_h_term.assign(Cp, -1); c->ipa_h_w.assign(Cp, 0); c->ipa_z.assign(Cp, {});
+        for (int cp = 0; cp < Cp; ++cp) {
+            std::map<int, long long> coef;
+            for (auto& kv : prefsum[cp]) { if (kv.first < 0 || kv.first >= T) return false; coef[kv.first] += kv.second; }
+            for (auto& kv : mult[cp]) if (owned[kv.first]) coef[kv.first] += kv.second * wt[kv.first];
+            int spread_host = -1;                                         // the class's own hostname-like soft constraint, if any
+            for (int e = c->ss_idx.empty() ? 0 : c->ss_off[cp]; !c->ss_idx.empty() && e < c->ss_off[cp + 1]; ++e)
+                if (c->sp_kind[c->ss_idx[e]] == 1) { if (spread_host >= 0 && spread_host != c->ss_idx[e]) return false; spread_host = c->ss_idx[e]; }
+            for (auto& kv : coef) {
+                if (kv.second == 0) continue;
+                if (std::llabs(kv.second) >= (1ll << 20)) return false;
+                if (!c->term_set.empty() && c->term_set[kv.first] >= 0) return false;
+                const int kind = classify(kv.first);
+                if (kind == 0) return false;
+                if (kind == 1) {
+                    if (c->ipa_h_term[cp] >= 0) return false;             // two per-node counters: not a function of one count
+                    if (spread_host >= 0 && spread_host != kv.first) return false;
+                    c->ipa_h_term[cp] = kv.first; c->ipa_h_w[cp] = (int32_t)kv.second;
+                } else {
+                    if (c->ipa_z[cp].size() == 3) return false;
+                    c->ipa_z[cp].push_back(std::make_pair(kv.first, (int32_t)kv.second));
+                }
+            }
+            // a class whose spread constraints take the general walk of spread_select (several hostname-like constraints, or one behind a
+            // zone-like one) keeps the all-feature kernel when it also has a preferred term
+            if ((c->ipa_h_term[cp] >= 0 || !c->ipa_z[cp].empty()) && !c->ss_idx.empty()) {
+                int nh = 0, first_kind = 0, ns = c->ss_off[cp + 1] - c->ss_off[cp];
+                for (int e = c->ss_off[cp]; e < c->ss_off[cp + 1]; ++e) { nh += c->sp_kind[c->ss_idx[e]] == 1; if (e == c->ss_off[cp]) first_kind = c->sp_kind[c->ss_idx[e]]; }
+                if (!(nh == 0 || (nh == 1 && first_kind == 1 && ns <= 2))) return false;
+            }
+        }
+        c->ipa_fold = true;
     }
     if (c->sp_TH > kSpreadMaxHostTerms || c->sp_TZ > kSpreadMaxZoneTerms || c->R > 4094) return false;
-    // counted terms of a class: the soft-spread terms among its match list, with multiplicity; one lane per distinct term
+    // counted terms of a class: the terms with a counter row among its match list, with multiplicity; one lane per distinct term
     for (int cp = 0; cp < c->Cp && !c->match_off.empty(); ++cp) {
         std::map<int, int> mult;
         for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
-        if ((int)mult.size() + (c->ss_off[cp + 1] - c->ss_off[cp]) > 64) return false;
+        const int ns = c->ss_idx.empty() ? 0 : c->ss_off[cp + 1] - c->ss_off[cp];
+        const int ni = c->ipa_fold ? (c->ipa_h_term[cp] >= 0 ? 1 : 0) + (int)c->ipa_z[cp].size() : 0;
+        if ((int)mult.size() + ns + ni > 64) return false;
         for (auto& kv : mult) if ((int64_t)kv.second * max_pods > 255) return false;   // a byte counter: pods on a node x multiplicity
     }
     return true;
@@ -696,29 +766,39 @@ int stage_narrow(simon_ctx* c) {
             // run the batch (their cycle is 17 % shorter than the REST instantiation's, profiles/README.md)
             if (!any_rest && c->table_ok) { c->rest = false; c->rest_M = c->rest_G = c->rest_X = 0; }
         }
-        // SPREAD descriptors: per pod class its soft constraints (term | maxSkew << 16 | dup << 30) followed by the soft-spread terms its
-        // pods are COUNTED on (term | multiplicity << 16), interned by content; PodRowC::rest = soft | counted << 3 | offset << 10
-        std::vector<int32_t> sp_ent;
+        // SPREAD descriptors: per pod class its soft constraints (term | maxSkew << 16 | dup << 30), the terms with a counter row its pods
+        // are COUNTED on (term | multiplicity << 16) and the entries of its InterPodAffinity raw score (coefficient; the hostname-like term
+        // first), interned by content; every entry travels with its term; PodRowC::rest = soft | counted << 3 | preferred << 10 | offset << 13
+        std::vector<int32_t> sp_ent, sp_ent_term;
         if (c->spread && c->table_ok) {
             std::map<std::vector<int32_t>, int> sc_id;
             std::vector<int> desc_of(c->Cp, 0);
             for (int cp = 0; cp < c->Cp; ++cp) {
-                std::vector<int32_t> ent;
-                const int ns = c->ss_off[cp + 1] - c->ss_off[cp];
-                for (int e = c->ss_off[cp]; e < c->ss_off[cp + 1]; ++e)
+                std::vector<int32_t> ent, ent_term;
+                const int ns = c->ss_idx.empty() ? 0 : c->ss_off[cp + 1] - c->ss_off[cp];
+                for (int e = c->ss_idx.empty() ? 0 : c->ss_off[cp]; !c->ss_idx.empty() && e < c->ss_off[cp + 1]; ++e) {
                     ent.push_back(c->ss_idx[e] | ((c->ss_skew[e] & 0x3FFF) << 16) | ((c->ss_skew[e] & SIMON_SPREAD_DUP_KEY) ? 1 << 30 : 0));
+                    ent_term.push_back(c->ss_idx[e]);
+                }
                 std::map<int, int> mult;
                 if (!c->match_off.empty())
                     for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
-                for (auto& kv : mult) ent.push_back(kv.first | (kv.second << 16));
+                for (auto& kv : mult) { ent.push_back(kv.first | (kv.second << 16)); ent_term.push_back(kv.first); }
+                int n_ipa = 0;
+                if (c->ipa_fold) {
+                    if (c->ipa_h_term[cp] >= 0) { ent.push_back(c->ipa_h_w[cp]); ent_term.push_back(c->ipa_h_term[cp]); ++n_ipa; }
+                    for (auto& zt : c->ipa_z[cp]) { ent.push_back(zt.second); ent_term.push_back(zt.first); ++n_ipa; }
+                }
                 if (ent.empty()) continue;
-                std::vector<int32_t> key = ent;                            // (a soft entry and a counted entry can spell the same word)
-                key.push_back(ns);
+                std::vector<int32_t> key = ent;                            // (entries of different kinds can spell the same word)
+                key.insert(key.end(), ent_term.begin(), ent_term.end());
+                key.push_back(ns); key.push_back(n_ipa);
                 auto it = sc_id.find(key);
                 if (it == sc_id.end()) {
-                    if (sp_ent.size() + ent.size() >= (1u << 21)) { c->table_ok = false; break; }
-                    it = sc_id.emplace(key, ns | ((int)mult.size() << 3) | ((int)sp_ent.size() << 10)).first;
+                    if (sp_ent.size() + ent.size() >= (1u << 18)) { c->table_ok = false; break; }
+                    it = sc_id.emplace(key, ns | ((int)mult.size() << 3) | (n_ipa << 10) | ((int)sp_ent.size() << 13)).first;
                     sp_ent.insert(sp_ent.end(), ent.begin(), ent.end());
+                    sp_ent_term.insert(sp_ent_term.end(), ent_term.begin(), ent_term.end());
                 }
                 desc_of[cp] = it->second;
             }
@@ -850,13 +930,14 @@ int stage_narrow(simon_ctx* c) {
                 std::vector<signed char> zdom((size_t)std::max(nzk, 1) * Ct, 0);
                 for (int z = 0; z < nzk; ++z)
                     for (int d = 0; d < Ct; ++d) zdom[(size_t)z * Ct + d] = (signed char)(((sub_of_class[d] >> (5 * z)) & 31) - 1);
-                if (sp_ent.empty()) sp_ent.push_back(0);
+                if (sp_ent.empty()) { sp_ent.push_back(0); sp_ent_term.push_back(0); }
                 std::vector<int32_t> sp_pairs(sp_ent.size() * 2);            // the term's row travels with the entry (one load in the kernel)
-                for (size_t i = 0; i < sp_ent.size(); ++i) { sp_pairs[2 * i] = sp_ent[i]; sp_pairs[2 * i + 1] = sp_term[sp_ent[i] & 0xFFFF]; }
+                for (size_t i = 0; i < sp_ent.size(); ++i) { sp_pairs[2 * i] = sp_ent[i]; sp_pairs[2 * i + 1] = sp_term[sp_ent_term[i]]; }
                 std::vector<uint64_t> sets = c->node_sets;
                 if (sets.empty()) sets.push_back(0);
                 HIP_TRY(c, c->d_sp_ent.upload(sp_pairs, st));
-                HIP_TRY(c, c->d_cls_zdom.upload(zdom, st)); HIP_TRY(c, c->d_spread_log.upload(c->spread_log, st));
+                HIP_TRY(c, c->d_cls_zdom.upload(zdom, st));
+                { std::vector<double> lg = c->spread_log; if (lg.empty()) lg.push_back(0.0); HIP_TRY(c, c->d_spread_log.upload(lg, st)); }
                 HIP_TRY(c, c->d_node_sets.upload(sets, st));
             }
             HIP_TRY(c, hipStreamSynchronize(st));
@@ -984,6 +1065,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
     c->no_fold = getenv("SIMON_NO_FOLD") != nullptr;                  // A/B + tests: anti-affinity / ports through the position masks (or the all-feature kernel)
     c->no_sig_twins = getenv("SIMON_TABLE_NO_TWINS") != nullptr;      // A/B: signature ids in order of appearance
+    c->no_ipa_fold = getenv("SIMON_NO_IPA_FOLD") != nullptr;          // A/B + tests: preferred pod (anti-)affinity always on the all-feature kernel
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
@@ -1292,7 +1374,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             // 256 scenarios 7.7 ms, 4 096 14.0 ms, 8 192 27.5 ms one-level / 32.3 ms two-level; 100 signatures 39.5 / 32.1 ms):
             // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
-            const int nzk = c->spread ? (int)c->sp_zkeys.size() : -1;
+            const int nzk = c->spread ? ((int)c->sp_zkeys.size() | (c->ipa_fold ? 0x100 : 0)) : -1;   // (| 0x100: the second score table of spread_select)
             const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest, nzk) + c->lds_pad;
             const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
@@ -1408,7 +1490,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? (int)c->sp_zkeys.size() : -1) + c->lds_pad : 0;
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | (c->ipa_fold ? 0x100 : 0)) : -1) + c->lds_pad : 0;
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
@@ -1452,7 +1534,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && c->ipa_fold) ? 64 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

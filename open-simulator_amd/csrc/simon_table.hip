@@ -153,7 +153,7 @@ __device__ __forceinline__ unsigned wave_or_u32_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, zdom, stash, tab, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, zdom, stash, tab, tabi, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -181,9 +181,12 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     (void)rest;
     // SPREAD (nzk >= 0): zone domain of a class per zone-like key; for spread_select two bytes per position and the score table of
     // the pod being placed
+    const bool ipa = nzk >= 0 && (nzk & 0x100);                       // the problem has preferred pod (anti-)affinity terms: a second table
+    if (nzk >= 0) nzk &= 0xFF;
     c.zdom = o; o += nzk >= 0 ? al((nzk > 0 ? nzk : 1) * Cn) : 0;
     c.stash = o; o += nzk >= 0 ? al(ni_max * 2) : 0;
     c.tab = o; o += nzk >= 0 ? kSpreadTabMax * 4 : 0;
+    c.tabi = o; o += ipa ? kSpreadTabMax * 4 : 0;
     c.total = o;
     return c;
 }
@@ -335,10 +338,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
     static_assert(!SPREAD || (COARSE && !REST && !MANY), "SPREAD is built on the two-level layout, without the REST rows");
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? sc.NZK : -1);
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
     signed char* s_zdom = (signed char*)(smem + cv.zdom);          // SPREAD: [NZK][Cn]
     unsigned short* s_stash = (unsigned short*)(smem + cv.stash);  // SPREAD: [positions] count | table byte << 8 of the pod being placed
+    int* s_tabi = (int*)(smem + cv.tabi);                           // SPREAD (problems with preferred pod (anti-)affinity): [class << lg | count] InterPodAffinity raw score
     int* s_tab = (int*)(smem + cv.tab);                             // SPREAD: [class << lg | count] raw score, then class term + 2 x score
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
@@ -896,10 +900,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
     // the summaries cannot carry it: a spread pod scans its signature's row, one position per lane, 64 positions per step, twice
     // (minimum / maximum of the raw scores, then totals), and takes the first maximum in canonical order (the static per-class node
     // lists give the canonical index of a position).  Everything else about the cycle -- assume, column refresh, summaries -- is the
-    // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | offset << 10 into TableCold::sp_ent; lane e
+    // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | preferred-term entries << 10 | offset << 13 into TableCold::sp_ent; lane e
     // holds entry e (`spv`).
     TPROF_DECL
-    auto spread_select = [&](int k, int soft_n, int spv, int spt, int& dstar, int& res) -> int {
+    auto spread_select = [&](int k, int soft_n, int match_n, int ipa_n, int spv, int spt, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         int kind[4], rowi[4], zsl[4], skew[4];
         bool dup[4];
@@ -914,6 +918,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (e < soft_n && kind[e] == 1) { ++nh; eh = e; }
+        // InterPodAffinity preferred terms in self-referential form (simon_hip.hip: spread_supported): raw = Wh x count of the class's
+        // hostname-like term (the row its spread constraint counts, if it has one) + sum of Wz x count of a zone-like term.  Entry i sits
+        // in lane soft_n + match_n + i: the hostname-like term first.
+        // The code lives in its own instantiations (kIpa = SPREAD && AFF: launched for problems with such terms), so that the others
+        // keep their registers.
+        constexpr bool kIpa = SPREAD && AFF;
+        int wI[4] = {0, 0, 0, 0}, kI[4] = {0, 0, 0, 0}, rI[4] = {0, 0, 0, 0}, zI[4] = {0, 0, 0, 0};
+        if constexpr (kIpa) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = (soft_n + match_n + i) & 63;
+                const int w_ = __builtin_amdgcn_readlane(spv, l), t_ = __builtin_amdgcn_readlane(spt, l);
+                wI[i] = i < ipa_n ? w_ : 0; kI[i] = i < ipa_n ? (t_ & 3) : 0; rI[i] = (t_ >> 2) & 0x3FFF; zI[i] = (t_ >> 16) & 7;
+            }
+        }
+        const bool ipa_h = kIpa && ipa_n > 0 && kI[0] == 1;
+        const int Wh = ipa_h ? wI[0] : 0;
+        const bool has_hrow = nh == 1 || (nh == 0 && ipa_h);             // ONE per-node counter (host: the same term when both exist)
+        const int hrow_i = nh == 1 ? rowi[eh] : rI[0];
         // SIMPLE: at most ONE per-node term, and it comes first -- [hostname, zone] (the system defaults, plugin.go:39-50), [hostname],
         // or zone-like constraints alone (their sum is a per-class value): raw = int64((count * w + c) + zone_term(class)).
         const bool simple = nh == 0 || (nh == 1 && eh == 0 && soft_n <= 2);
@@ -930,8 +953,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 czv[e] = zd >= 0 ? g_zcnt[rowi[e] * 16 + zd] : 0u;
             }
         }
-        const unsigned char* hb1 = nh == 1 ? g_hrow + (size_t)rowi[eh] * ni : (const unsigned char*)g_tile;   // (no hostname term: value unused)
-        const int hmx_v = (simple && nh == 1) ? (int)g_hmax[rowi[eh]] : 0;   // largest counter of the row (uniform address)
+        int zipa = 0;                                                     // per class: the zone-like part of the InterPodAffinity raw score
+        if constexpr (kIpa) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lane < Cn && kI[i] == 2) {
+                    const int zd = s_zdom[zI[i] * Cn + dd];
+                    zipa += zd >= 0 ? wI[i] * (int)g_zcnt[rI[i] * 16 + zd] : 0;
+                }
+        }
+        const unsigned char* hb1 = has_hrow ? g_hrow + (size_t)hrow_i * ni : (const unsigned char*)g_tile;   // (no hostname term: value unused)
+        const int hmx_v = (simple && has_hrow) ? (int)g_hmax[hrow_i] : 0;   // largest counter of the row (uniform address)
         unsigned byte1[SB], h1[SB];
         auto load1 = [&](int u0) {
 #pragma unroll
@@ -985,6 +1017,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
         const int E = Cn << lg;
         if (simple && E <= kSpreadTabMax) {
             const double ws = nh == 1 ? w_of(0) : 0.0, cs = nh == 1 ? cst_of(0) : 0.0;
+            const bool ipa_pod = kIpa && ipa_n > 0;
             // the per-class part: the zone-like constraints in list order (float addition is not associative; x + 0.0 == x)
             double pcl = 0.0;
 #pragma unroll
@@ -998,26 +1031,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 const double pc = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
                 const int raw = (int)(((double)(i & hmask) * ws + cs) + pc);
                 if (i < E) s_tab[i] = raw;
+                if constexpr (kIpa) {                                     // InterPodAffinity raw score of (class, count): integer (scoring.go:211-236)
+                    const int zc = __builtin_amdgcn_ds_bpermute(c4, zipa);    // (every lane: the source lane of a permute must be active)
+                    if (ipa_pod && i < E) s_tabi[i] = Wh * (i & hmask) + zc;
+                }
             }
             TPROF_WAIT_LDS; TPROF(14);                                     // spread: zone counters, Log table, raw score table
-            for (int u0 = 0;;) {                                          // pass 1; leaves (count, table byte) of every position in LDS
+            int imin = 0, imax = 0;                                       // InterPodAffinity: extremes over ALL feasible nodes, from 0 (:247-256)
+            auto pass1 = [&](auto ipa_tag) {                              // pass 1; leaves (count, table byte) of every position in LDS
+                constexpr bool IPA = decltype(ipa_tag)::value;
+                for (int u0 = 0;;) {
 #pragma unroll
-                for (int j = 0; j < SB; ++j) {
-                    const int u = min(u0 + j, nun - 1);
-                    const int c = winner_info(u) >> 16;
-                    const int raw = s_tab[(c << lg) + ((int)h1[j] & hmask)];   // (padding positions and the no-hostname-term case read arbitrary bytes)
-                    const bool ok = (byte1[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);   // (no short circuit: no branch)
-                    pmin = min(pmin, ok ? raw : 0x7fffffff);
-                    pmax = max(pmax, ok ? raw : 0);
-                    (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (byte1[j] << 8));   // (uniform base + lane: one address add)
+                    for (int j = 0; j < SB; ++j) {
+                        const int u = min(u0 + j, nun - 1);
+                        const int c = winner_info(u) >> 16;
+                        const int idx = (c << lg) + ((int)h1[j] & hmask);     // (padding positions and the no-hostname-term case read arbitrary bytes)
+                        const int raw = s_tab[idx];
+                        const bool ok = (byte1[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);   // (no short circuit: no branch)
+                        pmin = min(pmin, ok ? raw : 0x7fffffff);
+                        pmax = max(pmax, ok ? raw : 0);
+                        if constexpr (IPA) {
+                            const int ir = s_tabi[idx];
+                            imin = min(imin, byte1[j] != 0u ? ir : 0);
+                            imax = max(imax, byte1[j] != 0u ? ir : 0);
+                        }
+                        (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (byte1[j] << 8));   // (uniform base + lane: one address add)
+                    }
+                    u0 += SB;
+                    if (u0 >= nun) break;
+                    load1(u0);
                 }
-                u0 += SB;
-                if (u0 >= nun) break;
-                load1(u0);
-            }
+            };
+            if constexpr (kIpa) { if (ipa_pod) pass1(std::true_type{}); else pass1(std::false_type{}); }
+            else pass1(std::false_type{});
             TPROF(15);                                                     // spread: pass 1
             pmin = wave_min_i32(pmin);
             pmax = wave_max_i32(pmax);
+            if constexpr (kIpa) {
+                if (ipa_pod) { imin = wave_min_i32(imin); imax = wave_max_i32(imax); }
+            }
+            const int idiff = imax - imin;
             const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
             const int pmm = pmax + pmin;
             for (int i0 = 0; i0 < E; i0 += 64) {                          // class term + 2 x NormalizeScore (:217-256), in place
@@ -1027,7 +1080,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 // (an entry no feasible scored node has may lie outside [min, max]: its value is never looked up)
                 int v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmm - raw)), rinv, hrinv);
                 v = cw >= 0 ? v : 0;                                      // ignored nodes score 0
-                if (i < E) s_tab[i] = (cw & 0x7fffffff) + 2 * v;
+                int iv = 0;                                               // InterPodAffinity NormalizeScore (:258-271): float64, weight 1
+                if constexpr (kIpa) {
+                    if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)(s_tabi[min(i, E - 1)] - imin) / (double)idiff));
+                }
+                if (i < E) s_tab[i] = (cw & 0x7fffffff) + 2 * v + iv;
             }
             TPROF_WAIT_LDS; TPROF(16);                                     // spread: extremes, table of totals
             for (int u0 = 0; u0 < nun; u0 += SC) {                       // pass 2: totals, first maximum in canonical order
@@ -1063,6 +1120,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 hb[e] = (e < soft_n && kind[e] == 1) ? g_hrow + (size_t)rowi[e] * ni : (const unsigned char*)g_tile;
                 w[e] = w_of(e); cst[e] = cst_of(e); azv[e] = az_of(e);
             }
+            // (InterPodAffinity raw score per position here: the count of its hostname-like term + the class's zone part)
+            const unsigned char* hbI = ipa_h ? g_hrow + (size_t)rI[0] * ni : (const unsigned char*)g_tile;
+            const bool ipa_pod = kIpa && ipa_n > 0;
+            int imin = 0, imax = 0;
             auto raw_of = [&](const unsigned (&h)[4], int c) -> int {
                 double scv = 0.0;
 #pragma unroll
@@ -1075,13 +1136,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                 return (int)scv;
             };
             for (int u0 = 0; u0 < nun; u0 += SG) {                        // pass 1
-                unsigned byte[SG], h[SG][4];
+                unsigned byte[SG], h[SG][4], hI[SG];
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
                     const int u = min(u0 + j, nun - 1);
                     byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
+                    hI[j] = kIpa ? hbI[(unsigned)(u * 64 + lane)] : 0u;
                 }
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
@@ -1090,13 +1152,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     const bool ok = (byte[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);
                     pmin = min(pmin, ok ? raw : 0x7fffffff);
                     pmax = max(pmax, ok ? raw : 0);
+                    if constexpr (kIpa) {
+                        const int ir = (ipa_h ? Wh * (int)hI[j] : 0) + __builtin_amdgcn_readlane(zipa, c);
+                        imin = min(imin, (ipa_pod && byte[j] != 0u) ? ir : 0);
+                        imax = max(imax, (ipa_pod && byte[j] != 0u) ? ir : 0);
+                    }
                 }
             }
             pmin = wave_min_i32(pmin);
             pmax = wave_max_i32(pmax);
+            if constexpr (kIpa) { imin = wave_min_i32(imin); imax = wave_max_i32(imax); }
+            const int idiff = imax - imin;
             const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
             for (int u0 = 0; u0 < nun; u0 += SG) {                        // pass 2
-                unsigned byte[SG], h[SG][4];
+                unsigned byte[SG], h[SG][4], hI[SG];
                 int canon[SG], infoj[SG];
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
@@ -1104,6 +1173,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
+                    hI[j] = kIpa ? hbI[(unsigned)(u * 64 + lane)] : 0u;
                     const int info = infoj[j] = winner_info(u);
                     canon[j] = RANKED ? (int)(g_canon + u * 64)[lane] : (cls_list + (rk_off + (unsigned)((info & 0xFFFF) - 8192 + u * 64)))[lane];
                 }
@@ -1115,7 +1185,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
                     const int cw = __builtin_amdgcn_readlane(clsw, c);
                     int v = 0;
                     if (cw >= 0) v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmax + pmin - raw)), rinv, hrinv);
-                    const int total = (int)byte[j] - 1 + (cw & 0x7fffffff) + 2 * v;
+                    int iv = 0;                                           // InterPodAffinity NormalizeScore (:258-271)
+                    if constexpr (kIpa) {
+                        if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)((ipa_h ? Wh * (int)hI[j] : 0) + __builtin_amdgcn_readlane(zipa, c) - imin) / (double)idiff));
+                    }
+                    const int total = (int)byte[j] - 1 + (cw & 0x7fffffff) + 2 * v + iv;
                     const unsigned key = byte[j] != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon[j]) : 0u;
                     if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
                 }
@@ -1123,11 +1197,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
         }
         TPROF(17);                                                         // spread: pass 2
         const unsigned best = wave_max_u32(bkey);
-#ifdef SIMON_SPREAD_DEBUG
-        if (lane == 0) printf("SPD s=%d k=%d soft=%d kind=%d,%d row=%d,%d zsl=%d,%d skew=%d,%d F=%d w=%g,%g pmin=%d pmax=%d best=%u nun=%d Cn=%d\n", s, k, soft_n, kind[0], kind[1], rowi[0], rowi[1],
-                              zsl[0], zsl[1], skew[0], skew[1], F, w[0], w[1], pmin, pmax, best, nun, Cn);
-        if (lane < Cn) printf("SPD   class %d cnt %d ign %d zdom0 %d az0 %g az1 %g sn %d\n", lane, cntd, (int)ign, (int)s_zdom[dd], azv[0], azv[1], (int)s_sn[k * Cn + dd]);
-#endif
         if (best == 0u) return -1;
         const int wl = __builtin_ctzll(__ballot(bkey == best));
         const int pstar = __builtin_amdgcn_readlane(bpos, wl);
@@ -1206,11 +1275,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0x3FF, r_cls = (pk >> 10) & 0x1FFFFF;
         const int rw = (REST || SPREAD) ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST / SPREAD descriptor (0: the score table alone decides the pod)
-        const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0;
+        const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0, sp_ipa = SPREAD ? ((rw >> 10) & 7) : 0;
         int spv = 0;                                                       // SPREAD: lane e holds entry e of the pod's constraint / counted-term list
         int spt = 0;                                                       // ... and its term's row (TableCold::sp_ent holds both)
-        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match) {
-            const int2 spe = cold->sp_ent[((unsigned)rw >> 10) + lane];
+        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match + sp_ipa) {
+            const int2 spe = cold->sp_ent[((unsigned)rw >> 13) + lane];
             spv = spe.x; spt = spe.y;
         }
         const int r_gs = REST ? (rw & 63) - 1 : -1, r_xs = REST ? ((rw >> 6) & 63) - 1 : -1, r_nrows = REST ? (rw >> 12) & 63 : 0;
@@ -1254,14 +1323,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIM
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv), dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
-        } else if (SPREAD && sp_soft != 0) {                               // a pod with soft spread constraints: every node's score moves
+        } else if (SPREAD && (sp_soft | sp_ipa) != 0) {                    // a pod with soft spread constraints / preferred pod (anti-)affinity: every node's score moves
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
             if ((dq >> (k >> 6)) & 1u) {                               // the class terms of row k (s_sn) must be current
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
-            pstar = spread_select(k, sp_soft, spv, spt, dstar, res);
+            pstar = spread_select(k, sp_soft, sp_match, sp_ipa, spv, spt, dstar, res);
             TPROF(18);                                                 // spread: winner
             if (pstar < 0) { ++unsched; res = -1; }
         } else {
@@ -1619,6 +1688,13 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
     if constexpr (PIN) {                                              // soft spread constraints likewise; two-level layout
         if (a.spread) {
             if (!a.coarse || a.rest) return hipErrorInvalidValue;
+            if (a.sc.static_tables & 64) {                            // preferred pod (anti-)affinity in spread_select: SPREAD && AFF
+                if (a.sc.rk_stride != 0)
+                    return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, true, true, false, true>(a, n_blocks, lds, st)
+                                                  : launch_t7<M, Z, PIN, KQ, 2, true, false, true, true, false, true>(a, n_blocks, lds, st);
+                return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, false, true, false, true>(a, n_blocks, lds, st)
+                                              : launch_t7<M, Z, PIN, KQ, 2, true, false, false, true, false, true>(a, n_blocks, lds, st);
+            }
             if (a.sc.rk_stride != 0)
                 return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, true, false, false, true>(a, n_blocks, lds, st)
                                               : launch_t7<M, Z, PIN, KQ, 2, true, false, true, false, false, true>(a, n_blocks, lds, st);

@@ -253,14 +253,15 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
 
 
 def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
-                   seed: int = SEED + 6, n_anti: int = 0):
+                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0):
     """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
     request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
     constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
     ScheduleAnyway, selector = the Service's).  Nodes are zoned round robin by index (j % n_zones), which keeps nodeTree.list() =
     index order for every cluster size (V/internal/cache/node_tree.go:119-143).  Terms: per service (selector, hostname) and
     (selector, zone); the pods of a service match both and nothing else.  `n_anti`: the first n_anti services additionally REQUIRE
-    anti-affinity to their own pods on kubernetes.io/hostname (one replica per node: the usual companion of a Service)."""
+    anti-affinity to their own pods on kubernetes.io/hostname (one replica per node: the usual companion of a Service); `n_pref`: the
+    LAST n_pref services PREFER not to sit next to their own pods (weight 100 on the hostname key, 50 on the zone key: the chart default)."""
     from .gomath import spread_log_table
     n_total = n_het + n_counts
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
@@ -285,6 +286,14 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
         na = min(n_anti, n_services)
         prob.anti_off = np.concatenate([np.arange(na + 1), np.full(n_services - na, na)]).astype(np.int32)
         prob.anti_idx = (2 * np.arange(na)).astype(np.int32)          # the service's own (selector, hostname) term
+    if n_pref > 0:
+        npf = min(n_pref, n_services)
+        first = n_services - npf
+        off = np.concatenate([np.zeros(first + 1, np.int64), 2 * np.arange(1, npf + 1)]).astype(np.int32)
+        idx = np.arange(2 * first, 2 * n_services, dtype=np.int32)                       # the service's own (selector, hostname) and (selector, zone) terms
+        w = np.tile(np.array([-100, -50], np.int32), npf)
+        prob.pref_off, prob.pref_idx, prob.pref_w = off, idx, w                          # preferred anti-affinity: negative weights (scoring.go:120-131)
+        prob.own_off, prob.own_idx, prob.own_w = off.copy(), idx.copy(), w.copy()        # ... which the placed pods hold against newcomers alike
     prob = prob.normalise()
     orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)

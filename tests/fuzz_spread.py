@@ -13,7 +13,7 @@ import oracle_lib as O  # noqa: E402
 import randprob  # noqa: E402
 from open_simulator_amd import capi  # noqa: E402
 
-FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small", "anti_host"]
+FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small", "anti_host", "ipa_self"]
 
 
 def one_case(case):
@@ -24,7 +24,7 @@ def one_case(case):
     feat = {f: True for f in FEATURES if rng.random() < 0.3}
     if size == 2:
         feat.pop("static_mask", None)
-    prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=True, n_node_classes=int(rng.choice([1, 2, 4, 9])),
+    prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=(case % 7 != 6 or "ipa_self" not in feat), n_node_classes=int(rng.choice([1, 2, 4, 9])),
                                  n_pod_classes=int(rng.choice([1, 3, 8, 30, 60])), **feat)
     scen, orders = randprob.rand_scenarios(case, prob, S=int(rng.integers(1, 8)), min_n=1 if rng.random() < 0.4 else None)
     ranks = None

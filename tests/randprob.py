@@ -10,7 +10,7 @@ GiB = 1 << 30
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
                  odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
-                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False, static_small=False):
+                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False, static_small=False, ipa_self=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -145,9 +145,9 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
             sp["hdd_size"][:] = np.sort(rng.choice([5, 10, 40, 80], capi.MAX_LVOL)) * GiB_
         prob.local_specs = specs
         prob.local_spec_of = np.where(rng.random(n_pod_classes) < 0.6, rng.integers(0, len(specs), n_pod_classes), -1).astype(np.int32)
-    v2 = aff or ipa or spread_hard or spread_soft
+    v2 = aff or ipa or spread_hard or spread_soft or ipa_self
     if anti or v2:
-        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft, anti_host)
+        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft, anti_host, ipa_self)
     elif anti_host or ports:
         _topology_host(prob, rng, N, n_pod_classes, anti_host, ports)
     return prob.normalise()
@@ -190,7 +190,7 @@ def _topology_host(prob, rng, N, Cp, anti=True, ports=False):
         prob.port_off, prob.port_idx = _csr(portl)
 
 
-def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_host=False):
+def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_host=False, ipa_self=False):
     """Two topology keys -- hostname (domain = node) and zone (4 zones, some nodes unlabeled) -- and 8 terms over them;
     every role list of include/simon_hip.h gets random entries for the enabled features."""
     zone = rng.integers(-1, 4, N).astype(np.int32)
@@ -234,6 +234,18 @@ def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_h
         ow = pick([0, 1, 2, 3, 4], 0.6, 3) if ipa else []
         own.append(ow)
         ownw.append([int(rng.integers(1, 101)) * (1 if rng.random() < 0.7 else -1) for _ in ow])
+        if ipa_self and not ipa:
+            # preferred pod (anti-)affinity in its usual, self-referential form: whoever matches one of the terms 1, 3 (zone key) or 5
+            # (hostname key; also a soft-spread term) owns it with the term's weight; preferences of the class itself on the same terms
+            if c == 0:
+                self_w = {t: (int(rng.integers(1, 101)) * (1 if rng.random() < 0.3 else -1) if rng.random() < 0.8 else 0) for t in (1, 3, 5)}
+                prob._self_w = self_w
+            self_w = prob._self_w
+            own[-1] = [t for t in match[c] if t in self_w and self_w[t] != 0]
+            ownw[-1] = [self_w[t] for t in own[-1]]
+            pr = pick([1, 3, 5], 0.6, 3)
+            pref[-1] = pr
+            prefw[-1] = [int(rng.integers(1, 101)) * (1 if rng.random() < 0.4 else -1) for _ in pr]
         h = pick([1, 3], 0.5, 2) if spread_hard else []
         hard.append(h)
         hskew.append([int(rng.integers(1, 4)) for _ in h])
@@ -248,7 +260,7 @@ def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_h
     if aff:
         prob.aff_off, prob.aff_idx = _csr(affl)
         prob.class_flags = np.array(flags, np.uint8)
-    if ipa:
+    if ipa or ipa_self:
         prob.pref_off, prob.pref_idx = _csr(pref)
         prob.pref_w = _csr(prefw)[1]
         prob.own_off, prob.own_idx = _csr(own)

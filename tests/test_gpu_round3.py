@@ -247,3 +247,27 @@ def test_soft_spread_constraints_with_required_hostname_anti_affinity(feat):
     res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_FOLD": "1"})          # without the fold: the all-feature kernel
     assert variant == capi.KERNEL_WIDE
     assert_same(res, ref)
+
+
+@pytest.mark.parametrize("feat", [dict(ipa_self=True), dict(ipa_self=True, spread_soft=True), dict(ipa_self=True, spread_soft=True, anti_host=True),
+                                  dict(ipa_self=True, spread_soft=True, static_mask=True, presets=True, gates=True, pins=True, nz_differs=True)])
+def test_preferred_pod_affinity_in_self_referential_form_on_generation_7(feat):
+    """InterPodAffinity preferred terms whose owners are the pods they select (the usual chart default: prefer not to sit next to your own
+    replicas): the raw score is a function of (class, count) and joins the spread score in spread_select's table (simon_hip.hip:
+    spread_supported).  Random problems -- not every draw has the shape (a class with two per-node counters keeps the all-feature
+    kernel) -- every placement against the oracle on whichever kernel runs, and the same problems with SIMON_NO_IPA_FOLD=1."""
+    on7 = 0
+    for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500), (90, 600), (400, 1200)]):
+        prob = randprob.rand_problem(7600 + seed, N=N, P=P, n_node_classes=4, n_pod_classes=5 + seed, **feat)
+        scen, orders = randprob.rand_scenarios(270 + seed, prob, S=5)
+        ref = O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders)
+            st = ctx.stats()
+        on7 += st.kernel_generation == 7
+        assert_same(res, ref)
+        res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_IPA_FOLD": "1"})
+        assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+    assert on7 >= 2, on7
