@@ -50,6 +50,7 @@ DTYPE = {1: "u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)",
          4: "u8 score table + u32 (gcd-normalised int64 quantities) + f64 (BalancedAllocation)"}
 KERNEL_NAME = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fast_kernel", 4: "simon::table_kernel"}
 KERNEL_SHORT = {1: "narrow_v1", 2: "wide (all-feature kernel)", 3: "narrow_fast", 4: "score_table"}
+SERVICE_PREF = 60                 # services of the `config3_service_pref` sub-record whose pods carry preferred self anti-affinity
 SERVICE_ANTI = 20                 # services of the `config3_service_anti` sub-record that also require anti-affinity to their own pods (hostname key)
 SIG_RECORD = 200                  # request signatures of the `config3_sigs` sub-record (beyond the 128 two registers per lane hold; the table takes 384)
 C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
@@ -372,6 +373,10 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config_service(n_anti=SERVICE_ANTI)
         child = ["--workload", "service", "--anti", str(SERVICE_ANTI)]
         wl, label = "config3", f"config 3 with Service-selected pods, {SERVICE_ANTI} services with required self anti-affinity (hostname)"
+    elif name == "service_pref":                    # ... every service also PREFERS not to sit next to its own pods (hostname 100, zone 50)
+        prob, scen, orders = synth.config_service(n_pref=SERVICE_PREF)
+        child = ["--workload", "service", "--pref", str(SERVICE_PREF)]
+        wl, label = "config3", f"config 3 with Service-selected pods that prefer not to sit next to their own kind ({SERVICE_PREF} services, hostname 100 + zone 50)"
     elif name == "config3sig":                      # config 3 with SIG_RECORD request signatures: the > 128-signature regime as a number
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_RECORD)
         child = ["--workload", "config3sig", "--sigs", str(SIG_RECORD)]
@@ -381,7 +386,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_anti": f"config3_service_anti{SERVICE_ANTI}",
+    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
                         "config3sig": f"config3_sigs{SIG_RECORD}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
         ctx.load_problem(prob)
@@ -668,7 +673,7 @@ def main():
             out["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, local_rank)
             subs = []
             nchk5 = int(os.environ.get("SIMON_BENCH_C5_CHECK", "32"))
-            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", 3, 1, 64, 0), ("service", 2, 1, 64, 0), ("service_anti", 2, 1, 48, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
+            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", 3, 1, 64, 0), ("service", 2, 1, 64, 0), ("service_anti", 2, 1, 48, 0), ("service_pref", 2, 1, 48, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
                                                  ("config5", 2, 1, nchk5, C5_SATURATING)):
                 try:
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))

@@ -138,6 +138,7 @@ struct simon_ctx : simon::HostInputs {
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
+    std::vector<int> sp_rep;                      // per term: the first term with the same key, node set and matching classes (they share a counter row)
     std::vector<int> sp_zkeys;                   // topology keys of the zone-like soft terms (<= kSpreadMaxZoneKeys): the class split
     int sp_TH = 0, sp_TZ = 0;
     DevBuf<int32_t> d_sp_ent;                    // (entry, term row) pairs: TableCold::sp_ent
@@ -319,10 +320,36 @@ bool spread_supported(simon_ctx* c) {
     c->sp_zkeys.clear();
     c->sp_TH = c->sp_TZ = 0;
     std::vector<int> key_kind(std::max(c->Kt, 1), -1);                    // 1 hostname-like, 2 zone-like, 0 unusable
+    // Terms on one key, counted on the same nodes, that the same pod classes match with the same multiplicities have the same
+    // counters at all times (a Service's default constraint and the chart's anti-affinity term with the same selector): they share
+    // ONE row, kept under the first of them (sp_rep).
+    c->sp_rep.assign(c->Tm, 0);
+    {
+        std::vector<std::vector<std::pair<int, int>>> who(c->Tm);
+        for (int cp = 0; cp < c->Cp && !c->match_off.empty(); ++cp) {
+            std::map<int, int> mult;
+            for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) { const int t = c->match_idx[e]; if (t < 0 || t >= c->Tm) return false; ++mult[t]; }
+            for (auto& kv : mult) who[kv.first].push_back(std::make_pair(cp, kv.second));
+        }
+        const int words = (c->N + 63) / 64;                               // a node set that holds every node counts like no node set
+        std::vector<char> full(std::max(c->R, 1), 0);
+        for (int r = 0; r < c->R && (size_t)(r + 1) * words <= c->node_sets.size(); ++r) {
+            long long n_in = 0;
+            for (int wd = 0; wd < words; ++wd) n_in += __builtin_popcountll(c->node_sets[(size_t)r * words + wd] & (wd == words - 1 && (c->N & 63) ? (1ull << (c->N & 63)) - 1 : ~0ull));
+            full[r] = n_in == c->N;
+        }
+        std::map<std::tuple<int, int, std::vector<std::pair<int, int>>>, int> first;
+        for (int t = 0; t < c->Tm; ++t) {
+            int set = c->term_set.empty() ? -1 : c->term_set[t];
+            if (set >= 0 && set < c->R && full[set]) set = -1;
+            c->sp_rep[t] = first.emplace(std::make_tuple(c->term_key[t], set, who[t]), t).first->second;
+        }
+    }
     // a term gets a counter row: a byte per position (hostname-like key) or a word per domain (zone-like key)
     auto classify = [&](int t) -> int {
         if (t < 0 || t >= c->Tm) return 0;
-        const int k = c->term_key[t];
+        const int r = c->sp_rep[t];
+        const int k = c->term_key[r];
         if (key_kind[k] < 0) {
             key_kind[k] = 0;
             if (c->topo_is_hostname[k]) {                                 // size = scored nodes (scoring.go:100-104): needs one domain per node
@@ -341,14 +368,15 @@ bool spread_supported(simon_ctx* c) {
             }
         }
         if (key_kind[k] == 0) return 0;
-        if (c->sp_kind[t] == 0) {
-            c->sp_kind[t] = key_kind[k];
-            if (key_kind[k] == 1) c->sp_row[t] = c->sp_TH++;
+        if (c->sp_kind[r] == 0) {
+            c->sp_kind[r] = key_kind[k];
+            if (key_kind[k] == 1) c->sp_row[r] = c->sp_TH++;
             else {
-                c->sp_row[t] = c->sp_TZ++;
-                c->sp_zslot[t] = (int)(std::find(c->sp_zkeys.begin(), c->sp_zkeys.end(), k) - c->sp_zkeys.begin());
+                c->sp_row[r] = c->sp_TZ++;
+                c->sp_zslot[r] = (int)(std::find(c->sp_zkeys.begin(), c->sp_zkeys.end(), k) - c->sp_zkeys.begin());
             }
         }
+        if (t != r) { c->sp_kind[t] = c->sp_kind[r]; c->sp_row[t] = c->sp_row[r]; c->sp_zslot[t] = c->sp_zslot[r]; }
         return key_kind[k];
     };
     for (int cp = 0; cp < c->Cp && !c->ss_idx.empty(); ++cp) {
@@ -389,11 +417,11 @@ bool spread_supported(simon_ctx* c) {
         c->ipa_h_term.assign(Cp, -1); c->ipa_h_w.assign(Cp, 0); c->ipa_z.assign(Cp, {});
         for (int cp = 0; cp < Cp; ++cp) {
             std::map<int, long long> coef;
-            for (auto& kv : prefsum[cp]) { if (kv.first < 0 || kv.first >= T) return false; coef[kv.first] += kv.second; }
-            for (auto& kv : mult[cp]) if (owned[kv.first]) coef[kv.first] += kv.second * wt[kv.first];
+            for (auto& kv : prefsum[cp]) { if (kv.first < 0 || kv.first >= T) return false; coef[c->sp_rep[kv.first]] += kv.second; }   // (per counter row)
+            for (auto& kv : mult[cp]) if (owned[kv.first]) coef[c->sp_rep[kv.first]] += kv.second * wt[kv.first];
             int spread_host = -1;                                         // the class's own hostname-like soft constraint, if any
             for (int e = c->ss_idx.empty() ? 0 : c->ss_off[cp]; !c->ss_idx.empty() && e < c->ss_off[cp + 1]; ++e)
-                if (c->sp_kind[c->ss_idx[e]] == 1) { if (spread_host >= 0 && spread_host != c->ss_idx[e]) return false; spread_host = c->ss_idx[e]; }
+                if (c->sp_kind[c->ss_idx[e]] == 1) { const int r = c->sp_rep[c->ss_idx[e]]; if (spread_host >= 0 && spread_host != r) return false; spread_host = r; }
             for (auto& kv : coef) {
                 if (kv.second == 0) continue;
                 if (std::llabs(kv.second) >= (1ll << 20)) return false;
@@ -422,8 +450,12 @@ bool spread_supported(simon_ctx* c) {
     if (c->sp_TH > kSpreadMaxHostTerms || c->sp_TZ > kSpreadMaxZoneTerms || c->R > 4094) return false;
     // counted terms of a class: the terms with a counter row among its match list, with multiplicity; one lane per distinct term
     for (int cp = 0; cp < c->Cp && !c->match_off.empty(); ++cp) {
-        std::map<int, int> mult;
-        for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
+        std::map<int, int> mult;                                           // per counter ROW (terms that share one count once)
+        {
+            std::map<int, int> per_term;
+            for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++per_term[c->match_idx[e]];
+            for (auto& kv : per_term) mult[c->sp_rep[kv.first]] = kv.second;
+        }
         const int ns = c->ss_idx.empty() ? 0 : c->ss_off[cp + 1] - c->ss_off[cp];
         const int ni = c->ipa_fold ? (c->ipa_h_term[cp] >= 0 ? 1 : 0) + (int)c->ipa_z[cp].size() : 0;
         if ((int)mult.size() + ns + ni > 64) return false;
@@ -780,9 +812,12 @@ int stage_narrow(simon_ctx* c) {
                     ent.push_back(c->ss_idx[e] | ((c->ss_skew[e] & 0x3FFF) << 16) | ((c->ss_skew[e] & SIMON_SPREAD_DUP_KEY) ? 1 << 30 : 0));
                     ent_term.push_back(c->ss_idx[e]);
                 }
-                std::map<int, int> mult;
-                if (!c->match_off.empty())
-                    for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++mult[c->match_idx[e]];
+                std::map<int, int> mult;                                   // per counter ROW (terms that share one count once)
+                if (!c->match_off.empty()) {
+                    std::map<int, int> per_term;
+                    for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++per_term[c->match_idx[e]];
+                    for (auto& kv : per_term) mult[c->sp_rep[kv.first]] = kv.second;
+                }
                 for (auto& kv : mult) { ent.push_back(kv.first | (kv.second << 16)); ent_term.push_back(kv.first); }
                 int n_ipa = 0;
                 if (c->ipa_fold) {

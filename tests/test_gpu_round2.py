@@ -285,7 +285,7 @@ def test_bench_line_is_self_verifying():
     e2e = d["end_to_end"]
     assert e2e["batch_ms"] > e2e["kernel_ms"] > 0 and e2e["load_problem_ms"] > 0 and e2e["scenarios"] == d["config"]["scenarios_per_gpu"]
     names = [w["workload"] for w in d["other_workloads"]]
-    assert names == ["config2", "config3_sigs200", "config3_service", "config3_service_anti20", "config5_S16", "config5_S2048"]
+    assert names == ["config2", "config3_sigs200", "config3_service", "config3_service_anti20", "config3_service_pref60", "config5_S16", "config5_S2048"]
     for w in d["other_workloads"]:
         assert "error" not in w, w
         assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
@@ -295,7 +295,8 @@ def test_bench_line_is_self_verifying():
     assert d["other_workloads"][1]["kernel_generation"] == 5 and d["other_workloads"][1]["scenarios"] == 4096
     assert d["other_workloads"][2]["kernel_generation"] == 7 and d["other_workloads"][2]["scenarios"] == 4096
     assert d["other_workloads"][3]["kernel_generation"] == 7 and d["other_workloads"][3]["scenarios"] == 4096
-    assert d["other_workloads"][4]["kernel_generation"] == 6 and d["other_workloads"][5]["scenarios"] == 2048
+    assert d["other_workloads"][4]["kernel_generation"] == 7 and d["other_workloads"][4]["scenarios"] == 4096
+    assert d["other_workloads"][5]["kernel_generation"] == 6 and d["other_workloads"][6]["scenarios"] == 2048
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
 
 

@@ -154,8 +154,8 @@ def test_service_workload_full_size_subset():
 
 def test_k8s_deployments_behind_services_sweep_on_generation_7():
     """The object-level path of SURVEY.md 8(f) N1: Deployments / StatefulSets selected by Services (system-default soft spread
-    constraints, plugin.go:39-50), some with their own ScheduleAnyway constraints, node selectors and required anti-affinity to their
-    own replicas on the hostname key, on a cluster with three zones,
+    constraints, plugin.go:39-50), some with their own ScheduleAnyway constraints, node selectors, required anti-affinity to their own
+    replicas on the hostname key or the preferred kind (hostname + zone), on a cluster with three zones,
     unlabeled and tainted nodes -- `simulate.sweep` over eight cluster sizes in one batch (per-scenario nodeTree ranks) stays on the
     score-table kernel; every placement against the oracle."""
     import randk8s
@@ -185,9 +185,15 @@ def test_k8s_deployments_behind_services_sweep_on_generation_7():
             spec["topologySpreadConstraints"] = [
                 {"maxSkew": 1, "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": app}}},
                 {"maxSkew": 2, "topologyKey": randk8s.HOST, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": app}}}]
+        paa = {}
         if w % 6 == 5:          # one replica per node: required anti-affinity to the workload's own pods on the hostname key (folded into the table)
-            spec["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
-                {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}]}}
+            paa["requiredDuringSchedulingIgnoredDuringExecution"] = [{"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}]
+        if w in (13, 33):       # the chart default: prefer not to sit next to your own replicas (hostname 100, zone 50); these two have no Service
+            paa["preferredDuringSchedulingIgnoredDuringExecution"] = [      # (a Service's constraints count on the zoned nodes only: another counter, below)
+                {"weight": 100, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}},
+                {"weight": 50, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.ZONE}}]
+        if paa:
+            spec["affinity"] = {"podAntiAffinity": paa}
         if w % 7 == 3:
             spec["nodeSelector"] = {"disk": "ssd"}
         if w % 9 == 4:
@@ -271,3 +277,50 @@ def test_preferred_pod_affinity_in_self_referential_form_on_generation_7(feat):
         assert variant == capi.KERNEL_WIDE
         assert_same(res, ref)
     assert on7 >= 2, on7
+
+
+def test_k8s_service_and_preferred_self_anti_affinity_share_their_counter_rows():
+    """A Deployment behind a Service whose pods also PREFER not to sit next to their own replicas (hostname 100, zone 50): the Service's
+    default spread constraints and the anti-affinity terms select the same pods on the same keys -- on a fully zoned cluster their
+    counters are the same, the terms share one row each (simon_hip.hip: sp_rep) and the preferred score joins spread_select's table.
+    Object level, `simulate.sweep`, every placement against the oracle."""
+    import randk8s
+    from open_simulator_amd import k8s, simulate as sim
+    rng = np.random.default_rng(5)
+    nodes = []
+    for j in range(90):
+        shape = [("8", "16Gi"), ("16", "32Gi")][j % 2]
+        nodes.append({"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"node-{j}", "labels": {randk8s.HOST: f"node-{j}", randk8s.ZONE: f"z{j % 3}"}},
+                      "status": {"allocatable": {"cpu": shape[0], "memory": shape[1], "pods": "40"}, "capacity": {"cpu": shape[0], "memory": shape[1]}}})
+    workloads, services = [], []
+    for w in range(14):
+        app = f"app{w}"
+        spec = {"containers": [{"name": "c", "image": "x", "resources": {"requests": {
+            "cpu": str(rng.choice(["100m", "250m", "500m"])), "memory": str(rng.choice(["128Mi", "512Mi", "1Gi"]))}}}]}
+        if w % 3 != 2:
+            spec["affinity"] = {"podAntiAffinity": {"preferredDuringSchedulingIgnoredDuringExecution": [
+                {"weight": 100, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}},
+                {"weight": int(rng.choice([20, 50])), "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.ZONE}}]}}
+        workloads.append({"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": app, "namespace": "default"},
+                          "spec": {"replicas": int(rng.integers(10, 50)), "selector": {"matchLabels": {"app": app}},
+                                   "template": {"metadata": {"labels": {"app": app}}, "spec": spec}}})
+        if w % 4 != 3:
+            services.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": f"svc-{w}", "namespace": "default"}, "spec": {"selector": {"app": app}}})
+    cluster = k8s.group_resources(nodes + services)
+    apps = [sim.AppResource("shop", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {randk8s.ZONE: "z1"}},
+                "status": {"allocatable": {"cpu": "16", "memory": "32Gi", "pods": "40"}, "capacity": {"cpu": "16", "memory": "32Gi"}}}
+
+    class Recording(sim.HipEngine):
+        def run(self, prob, scen, orders, want_placement=True, **kw):
+            self.args, self.kw = (prob, scen, orders), kw
+            self.out = super().run(prob, scen, orders, want_placement, **kw)
+            return self.out
+
+    eng = Recording()
+    sim.sweep(cluster, apps, template, [0, 4, 8, 12, 16, 20], engine=eng)
+    prob, scen, orders = eng.args
+    assert prob.pref_off is not None and len(scen) == 6
+    assert eng.last_stats.kernel_variant == capi.KERNEL_NARROW_CACHE and eng.last_stats.kernel_generation == 7
+    ranks = eng.kw.get("node_ranks")
+    assert_same(eng.out, O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run(prob, scen, orders))
