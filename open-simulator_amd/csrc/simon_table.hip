@@ -307,8 +307,11 @@ template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, 
 #ifndef SIMON_SPREAD_WAVES
 #define SIMON_SPREAD_WAVES 4
 #endif
+#ifndef SIMON_SPREAD_IPA_WAVES
+#define SIMON_SPREAD_IPA_WAVES 3
+#endif
 // (the SPREAD instantiations hold a batch of loads in registers: kept to 128 VGPRs = four scenario waves per SIMD, the same as the others)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? SIMON_SPREAD_WAVES : 1))) void table_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AFF ? SIMON_SPREAD_IPA_WAVES : SIMON_SPREAD_WAVES) : 1))) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
     int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
