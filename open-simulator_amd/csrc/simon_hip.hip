@@ -316,16 +316,29 @@ bool spread_supported(simon_ctx* c) {
     if (!c->ss_idx.empty() && c->spread_log.size() < (size_t)c->N + 1) return false;
     int64_t max_pods = 0;
     for (int32_t x : c->alloc_pods) { if (x > 255) return false; max_pods = std::max<int64_t>(max_pods, x); }   // the per-position counters are bytes
-    c->sp_kind.assign(c->Tm, 0); c->sp_row.assign(c->Tm, 0); c->sp_zslot.assign(c->Tm, 0);
+    // ids: t < Tm = the pods MATCHING term t; Tm + t = the pods OWNING a scoring term t (one weight per pod: InterPodAffinity below)
+    c->sp_kind.assign(2 * (size_t)c->Tm, 0); c->sp_row.assign(2 * (size_t)c->Tm, 0); c->sp_zslot.assign(2 * (size_t)c->Tm, 0);
     c->sp_zkeys.clear();
     c->sp_TH = c->sp_TZ = 0;
     std::vector<int> key_kind(std::max(c->Kt, 1), -1);                    // 1 hostname-like, 2 zone-like, 0 unusable
     // Terms on one key, counted on the same nodes, that the same pod classes match with the same multiplicities have the same
     // counters at all times (a Service's default constraint and the chart's anti-affinity term with the same selector): they share
     // ONE row, kept under the first of them (sp_rep).
-    c->sp_rep.assign(c->Tm, 0);
+    c->sp_rep.assign(2 * (size_t)c->Tm, 0);
+    std::vector<long long> own_w_of(c->Tm, 0);                            // per-pod weight of the owners of term t (0: nobody owns it)
+    bool own_uniform = true;
     {
-        std::vector<std::vector<std::pair<int, int>>> who(c->Tm);
+        std::vector<std::vector<std::pair<int, int>>> who(2 * (size_t)c->Tm);
+        for (int cp = 0; cp < c->Cp && !c->own_off.empty(); ++cp) {     // the owner classes of a scoring term, when they all hold one weight per pod
+            std::map<int, long long> os;
+            for (int e = c->own_off[cp]; e < c->own_off[cp + 1]; ++e) { const int t = c->own_idx[e]; if (t < 0 || t >= c->Tm) return false; os[t] += c->own_w[e]; }
+            for (auto& kv : os) {
+                if (kv.second == 0) continue;
+                if (own_w_of[kv.first] == 0) own_w_of[kv.first] = kv.second;
+                else if (own_w_of[kv.first] != kv.second) own_uniform = false;
+                who[(size_t)c->Tm + kv.first].push_back(std::make_pair(cp, 1));
+            }
+        }
         for (int cp = 0; cp < c->Cp && !c->match_off.empty(); ++cp) {
             std::map<int, int> mult;
             for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) { const int t = c->match_idx[e]; if (t < 0 || t >= c->Tm) return false; ++mult[t]; }
@@ -339,17 +352,18 @@ bool spread_supported(simon_ctx* c) {
             full[r] = n_in == c->N;
         }
         std::map<std::tuple<int, int, std::vector<std::pair<int, int>>>, int> first;
-        for (int t = 0; t < c->Tm; ++t) {
-            int set = c->term_set.empty() ? -1 : c->term_set[t];
+        for (int id = 0; id < 2 * c->Tm; ++id) {
+            const int t = id < c->Tm ? id : id - c->Tm;
+            int set = (id >= c->Tm || c->term_set.empty()) ? -1 : c->term_set[t];      // (owners are counted wherever they land)
             if (set >= 0 && set < c->R && full[set]) set = -1;
-            c->sp_rep[t] = first.emplace(std::make_tuple(c->term_key[t], set, who[t]), t).first->second;
+            c->sp_rep[id] = first.emplace(std::make_tuple(c->term_key[t], set, who[id]), id).first->second;
         }
     }
     // a term gets a counter row: a byte per position (hostname-like key) or a word per domain (zone-like key)
     auto classify = [&](int t) -> int {
-        if (t < 0 || t >= c->Tm) return 0;
+        if (t < 0 || t >= 2 * c->Tm) return 0;
         const int r = c->sp_rep[t];
-        const int k = c->term_key[r];
+        const int k = c->term_key[r < c->Tm ? r : r - c->Tm];
         if (key_kind[k] < 0) {
             key_kind[k] = 0;
             if (c->topo_is_hostname[k]) {                                 // size = scored nodes (scoring.go:100-104): needs one domain per node
@@ -401,31 +415,21 @@ bool spread_supported(simon_ctx* c) {
             if (!c->own_off.empty()) for (int e = c->own_off[cp]; e < c->own_off[cp + 1]; ++e) ownsum[cp][c->own_idx[e]] += c->own_w[e];
             for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) mult[cp][c->match_idx[e]] += 1;
         }
-        std::vector<long long> wt(T, 0);
-        std::vector<char> wset(T, 0), owned(T, 0);
-        for (int cp = 0; cp < Cp; ++cp) for (auto& kv : ownsum[cp]) { if (kv.first < 0 || kv.first >= T) return false; if (kv.second) owned[kv.first] = 1; }
-        for (int t = 0; t < T; ++t) {
-            if (!owned[t]) continue;
-            for (int cp = 0; cp < Cp; ++cp) {
-                const long long m = mult[cp].count(t) ? mult[cp][t] : 0, o = ownsum[cp].count(t) ? ownsum[cp][t] : 0;
-                if (m == 0) { if (o != 0) return false; continue; }      // owns the term without matching it: w_owner is not a multiple of cnt_match
-                if (o % m) return false;
-                if (!wset[t]) { wt[t] = o / m; wset[t] = 1; }
-                else if (wt[t] != o / m) return false;
-            }
-        }
+        // w_owner[t] = (the owners' weight per pod) x (owner pods in the domain): a counter row of its own (id Tm + t) -- the SAME row as
+        // cnt_match[t]'s when the owners are the matchers (sp_rep), the self-referential case
+        if (!own_uniform) return false;
         c->ipa_h_term.assign(Cp, -1); c->ipa_h_w.assign(Cp, 0); c->ipa_z.assign(Cp, {});
         for (int cp = 0; cp < Cp; ++cp) {
             std::map<int, long long> coef;
             for (auto& kv : prefsum[cp]) { if (kv.first < 0 || kv.first >= T) return false; coef[c->sp_rep[kv.first]] += kv.second; }   // (per counter row)
-            for (auto& kv : mult[cp]) if (owned[kv.first]) coef[c->sp_rep[kv.first]] += kv.second * wt[kv.first];
+            for (auto& kv : mult[cp]) if (own_w_of[kv.first] != 0) coef[c->sp_rep[(size_t)T + kv.first]] += kv.second * own_w_of[kv.first];
             int spread_host = -1;                                         // the class's own hostname-like soft constraint, if any
             for (int e = c->ss_idx.empty() ? 0 : c->ss_off[cp]; !c->ss_idx.empty() && e < c->ss_off[cp + 1]; ++e)
                 if (c->sp_kind[c->ss_idx[e]] == 1) { const int r = c->sp_rep[c->ss_idx[e]]; if (spread_host >= 0 && spread_host != r) return false; spread_host = r; }
             for (auto& kv : coef) {
                 if (kv.second == 0) continue;
                 if (std::llabs(kv.second) >= (1ll << 20)) return false;
-                if (!c->term_set.empty() && c->term_set[kv.first] >= 0) return false;
+                if (kv.first < T && !c->term_set.empty() && c->term_set[kv.first] >= 0) return false;
                 const int kind = classify(kv.first);
                 if (kind == 0) return false;
                 if (kind == 1) {
@@ -455,6 +459,8 @@ bool spread_supported(simon_ctx* c) {
             std::map<int, int> per_term;
             for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++per_term[c->match_idx[e]];
             for (auto& kv : per_term) mult[c->sp_rep[kv.first]] = kv.second;
+            for (int e = c->own_off.empty() ? 0 : c->own_off[cp]; !c->own_off.empty() && e < c->own_off[cp + 1]; ++e)      // rows that count this class as an owner
+                if (c->sp_kind[(size_t)c->Tm + c->own_idx[e]] && own_w_of[c->own_idx[e]] != 0) mult[c->sp_rep[(size_t)c->Tm + c->own_idx[e]]] = 1;
         }
         const int ns = c->ss_idx.empty() ? 0 : c->ss_off[cp + 1] - c->ss_off[cp];
         const int ni = c->ipa_fold ? (c->ipa_h_term[cp] >= 0 ? 1 : 0) + (int)c->ipa_z[cp].size() : 0;
@@ -818,7 +824,12 @@ int stage_narrow(simon_ctx* c) {
                     for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) if (c->sp_kind[c->match_idx[e]]) ++per_term[c->match_idx[e]];
                     for (auto& kv : per_term) mult[c->sp_rep[kv.first]] = kv.second;
                 }
-                for (auto& kv : mult) { ent.push_back(kv.first | (kv.second << 16)); ent_term.push_back(kv.first); }
+                if (c->ipa_fold && !c->own_off.empty()) {                 // rows that count the class's pods as OWNERS of a scoring term (one per pod)
+                    std::map<int, long long> os;
+                    for (int e = c->own_off[cp]; e < c->own_off[cp + 1]; ++e) os[c->own_idx[e]] += c->own_w[e];
+                    for (auto& kv : os) if (kv.second != 0 && c->sp_kind[(size_t)c->Tm + kv.first]) mult[c->sp_rep[(size_t)c->Tm + kv.first]] = 1;
+                }
+                for (auto& kv : mult) { ent.push_back((kv.first & 0xFFFF) | (kv.second << 16)); ent_term.push_back(kv.first); }
                 int n_ipa = 0;
                 if (c->ipa_fold) {
                     if (c->ipa_h_term[cp] >= 0) { ent.push_back(c->ipa_h_w[cp]); ent_term.push_back(c->ipa_h_term[cp]); ++n_ipa; }
@@ -958,9 +969,9 @@ int stage_narrow(simon_ctx* c) {
                 HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
             }
             if (c->spread) {
-                std::vector<int32_t> sp_term(std::max(c->Tm, 1), 0);
-                for (int t = 0; t < c->Tm; ++t)
-                    sp_term[t] = c->sp_kind[t] | (c->sp_row[t] << 2) | (c->sp_zslot[t] << 16) | ((c->term_set[t] + 1) << 19);
+                std::vector<int32_t> sp_term(std::max(2 * c->Tm, 1), 0);      // ids Tm + t: rows that count the OWNERS of scoring term t (no node set)
+                for (int id = 0; id < 2 * c->Tm; ++id)
+                    sp_term[id] = c->sp_kind[id] | (c->sp_row[id] << 2) | (c->sp_zslot[id] << 16) | (((id < c->Tm && !c->term_set.empty() ? c->term_set[id] : -1) + 1) << 19);
                 const int nzk = (int)c->sp_zkeys.size();
                 std::vector<signed char> zdom((size_t)std::max(nzk, 1) * Ct, 0);
                 for (int z = 0; z < nzk; ++z)

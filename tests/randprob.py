@@ -241,7 +241,12 @@ def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_h
                 self_w = {t: (int(rng.integers(1, 101)) * (1 if rng.random() < 0.3 else -1) if rng.random() < 0.8 else 0) for t in (1, 3, 5)}
                 prob._self_w = self_w
             self_w = prob._self_w
-            own[-1] = [t for t in match[c] if t in self_w and self_w[t] != 0]
+            if c == 0:
+                prob._own_any = rng.random() < 0.4     # owners need not be matchers (affinity TO another workload): rows that count owners
+            if prob._own_any:
+                own[-1] = [t for t in (1, 3, 5) if self_w[t] != 0 and rng.random() < 0.4]
+            else:
+                own[-1] = [t for t in match[c] if t in self_w and self_w[t] != 0]
             ownw[-1] = [self_w[t] for t in own[-1]]
             pr = pick([1, 3, 5], 0.6, 3)
             pref[-1] = pr
