@@ -138,6 +138,7 @@ struct simon_ctx : simon::HostInputs {
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
+    std::vector<int> sp_set_eff;                  // per id: the node set its row is counted on (-1: every node)
     std::vector<int> sp_rep;                      // per term: the first term with the same key, node set and matching classes (they share a counter row)
     std::vector<int> sp_zkeys;                   // topology keys of the zone-like soft terms (<= kSpreadMaxZoneKeys): the class split
     int sp_TH = 0, sp_TZ = 0;
@@ -351,13 +352,37 @@ bool spread_supported(simon_ctx* c) {
             for (int wd = 0; wd < words; ++wd) n_in += __builtin_popcountll(c->node_sets[(size_t)r * words + wd] & (wd == words - 1 && (c->N & 63) ? (1ull << (c->N & 63)) - 1 : ~0ull));
             full[r] = n_in == c->N;
         }
+        // A node set that leaves out only nodes WITHOUT the term's own label changes no counter (a zone-like key: such a node has no
+        // domain); on a hostname-like key the set never matters to a reader at all -- a node outside it either fails the class's node
+        // affinity (never feasible) or lacks a constraint key (IgnoredNodes: never scored).  Such terms join the unrestricted ones; a
+        // group is kept under an unrestricted member when it has one (a reader of the preferred score wants the count everywhere).
+        std::map<std::pair<int, int>, char> harmless;
+        auto set_of = [&](int id) -> int {
+            if (id >= c->Tm || c->term_set.empty()) return -1;            // (owners are counted wherever they land)
+            const int set = c->term_set[id], k = c->term_key[id];
+            if (set < 0 || set >= c->R || full[set]) return -1;
+            if (c->topo_is_hostname[k]) return -1;
+            auto it = harmless.find(std::make_pair(k, set));
+            if (it == harmless.end()) {
+                bool ok = true;
+                for (int j = 0; j < c->N && ok; ++j)
+                    if (!((c->node_sets[(size_t)set * words + (j >> 6)] >> (j & 63)) & 1ull)) ok = c->topo_dom[(size_t)k * c->N + j] < 0;
+                it = harmless.emplace(std::make_pair(k, set), (char)ok).first;
+            }
+            return it->second ? -1 : set;
+        };
         std::map<std::tuple<int, int, std::vector<std::pair<int, int>>>, int> first;
-        for (int id = 0; id < 2 * c->Tm; ++id) {
-            const int t = id < c->Tm ? id : id - c->Tm;
-            int set = (id >= c->Tm || c->term_set.empty()) ? -1 : c->term_set[t];      // (owners are counted wherever they land)
-            if (set >= 0 && set < c->R && full[set]) set = -1;
-            c->sp_rep[id] = first.emplace(std::make_tuple(c->term_key[t], set, who[id]), id).first->second;
-        }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int id = 0; id < 2 * c->Tm; ++id) {
+                const int t = id < c->Tm ? id : id - c->Tm;
+                const bool unrestricted = id >= c->Tm || c->term_set.empty() || c->term_set[id] < 0;
+                if (unrestricted != (pass == 0)) continue;
+                c->sp_rep[id] = first.emplace(std::make_tuple(c->term_key[t], set_of(id), who[id]), id).first->second;
+            }
+        // the set a row is COUNTED on: none where it does not matter -- members of one group may carry different (harmless) sets, and each
+        // reads inside its own only, where counting everywhere and counting on the set agree
+        c->sp_set_eff.assign(2 * (size_t)c->Tm, -1);
+        for (int id = 0; id < c->Tm; ++id) c->sp_set_eff[id] = set_of(id);
     }
     // a term gets a counter row: a byte per position (hostname-like key) or a word per domain (zone-like key)
     auto classify = [&](int t) -> int {
@@ -971,7 +996,7 @@ int stage_narrow(simon_ctx* c) {
             if (c->spread) {
                 std::vector<int32_t> sp_term(std::max(2 * c->Tm, 1), 0);      // ids Tm + t: rows that count the OWNERS of scoring term t (no node set)
                 for (int id = 0; id < 2 * c->Tm; ++id)
-                    sp_term[id] = c->sp_kind[id] | (c->sp_row[id] << 2) | (c->sp_zslot[id] << 16) | (((id < c->Tm && !c->term_set.empty() ? c->term_set[id] : -1) + 1) << 19);
+                    sp_term[id] = c->sp_kind[id] | (c->sp_row[id] << 2) | (c->sp_zslot[id] << 16) | ((c->sp_set_eff[id] + 1) << 19);
                 const int nzk = (int)c->sp_zkeys.size();
                 std::vector<signed char> zdom((size_t)std::max(nzk, 1) * Ct, 0);
                 for (int z = 0; z < nzk; ++z)

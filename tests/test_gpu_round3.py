@@ -188,8 +188,8 @@ def test_k8s_deployments_behind_services_sweep_on_generation_7():
         paa = {}
         if w % 6 == 5:          # one replica per node: required anti-affinity to the workload's own pods on the hostname key (folded into the table)
             paa["requiredDuringSchedulingIgnoredDuringExecution"] = [{"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}]
-        if w in (13, 33):       # the chart default: prefer not to sit next to your own replicas (hostname 100, zone 50); these two have no Service
-            paa["preferredDuringSchedulingIgnoredDuringExecution"] = [      # (a Service's constraints count on the zoned nodes only: another counter, below)
+        if w % 10 == 9 or w in (13, 33):   # the chart default: prefer not to sit next to your own replicas (hostname 100, zone 50), with a Service
+            paa["preferredDuringSchedulingIgnoredDuringExecution"] = [      # (9, 19, 29, 39: its constraints count on the zoned nodes only -- a harmless node set) or without
                 {"weight": 100, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}},
                 {"weight": 50, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.ZONE}}]
         if paa:
@@ -290,9 +290,19 @@ def test_k8s_service_and_preferred_self_anti_affinity_share_their_counter_rows()
     nodes = []
     for j in range(90):
         shape = [("8", "16Gi"), ("16", "32Gi")][j % 2]
-        nodes.append({"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"node-{j}", "labels": {randk8s.HOST: f"node-{j}", randk8s.ZONE: f"z{j % 3}"}},
+        nodes.append({"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"node-{j}", "labels": {randk8s.HOST: f"node-{j}", randk8s.ZONE: f"z{j % 3}",
+                                                                                                         "disk": ["ssd", "hdd"][(j // 3) % 2]}},
                       "status": {"allocatable": {"cpu": shape[0], "memory": shape[1], "pods": "40"}, "capacity": {"cpu": shape[0], "memory": shape[1]}}})
     workloads, services = [], []
+    # three Deployments with the SAME labels behind one Service, one anywhere, one on the ssd, one on the hdd nodes: their default constraints are terms with
+    # different node sets whose hostname-key counters are one row -- counted on every node (each class reads inside its own set only)
+    for name, sel in (("twin-any", None), ("twin-ssd", {"disk": "ssd"}), ("twin-hdd", {"disk": "hdd"})):
+        spec = {"containers": [{"name": "c", "image": "x", "resources": {"requests": {"cpu": "250m", "memory": "256Mi"}}}]}
+        if sel:
+            spec["nodeSelector"] = sel
+        workloads.append({"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": name, "namespace": "default"},
+                          "spec": {"replicas": 30, "selector": {"matchLabels": {"app": "twin"}}, "template": {"metadata": {"labels": {"app": "twin"}}, "spec": spec}}})
+    services.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": "svc-twin", "namespace": "default"}, "spec": {"selector": {"app": "twin"}}})
     for w in range(14):
         app = f"app{w}"
         spec = {"containers": [{"name": "c", "image": "x", "resources": {"requests": {
