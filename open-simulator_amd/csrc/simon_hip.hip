@@ -133,6 +133,7 @@ struct simon_ctx : simon::HostInputs {
     // SPREAD path of the score-table kernel (soft PodTopologySpread constraints, generation 7): decided by choose_variant
     bool sig_twins = false, no_sig_twins = false; // upper-half signatures sit 64 slots above a twin (same request, other table class); env SIMON_TABLE_NO_TWINS
     // InterPodAffinity preferred terms in self-referential form, scored in spread_select's table (spread_supported); env SIMON_NO_IPA_FOLD
+    bool hard_fold = false, no_hard_fold = false; // hard spread constraints on zone-like keys as per-class verdicts of spread_select; env SIMON_NO_HARD_FOLD
     bool ipa_fold = false, no_ipa_fold = false;
     std::vector<int32_t> ipa_h_term, ipa_h_w;     // [Cp] the hostname-like term of a class's raw score (-1: none) and its coefficient
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
@@ -308,9 +309,11 @@ bool rest_supported(simon_ctx* c) {
 bool spread_supported(simon_ctx* c) {
     c->ipa_fold = false;
     c->ipa_h_term.clear(); c->ipa_h_w.clear(); c->ipa_z.clear();
-    if (c->no_spread || (c->ss_idx.empty() && !c->has_ipa_score)) return false;
+    c->hard_fold = false;
+    if (c->no_spread || (c->ss_idx.empty() && !c->has_ipa_score && c->sh_idx.empty())) return false;
+    if (!c->sh_idx.empty() && c->no_hard_fold) return false;
     if (c->has_ipa_score && c->no_ipa_fold) return false;
-    if (!c->sh_idx.empty() || c->has_local || !c->aff_idx.empty()) return false;
+    if (c->has_local || !c->aff_idx.empty()) return false;
     if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold) return false;   // required anti-affinity / ports: only folded into the table
     if (c->has_gpu || c->has_gpu_index) return false;
     if (c->topo_is_hostname.empty()) return false;
@@ -425,6 +428,29 @@ bool spread_supported(simon_ctx* c) {
             if (!classify(c->ss_idx[e])) return false;
         }
     }
+    // Hard (DoNotSchedule) constraints on ZONE-like keys: a per-class verdict in spread_select (the classes are split by zone).  The
+    // eligibility set of an entry (filtering.go:236-251: which nodes register a zone) may leave out unlabelled nodes only.
+    if (!c->sh_idx.empty()) {
+        const int words = (c->N + 63) / 64;
+        for (int cp = 0; cp < c->Cp; ++cp) {
+            if (c->sh_off[cp + 1] - c->sh_off[cp] > 3) return false;
+            for (int e = c->sh_off[cp]; e < c->sh_off[cp + 1]; ++e) {
+                const int t = c->sh_idx[e];
+                if (t < 0 || t >= c->Tm || c->sh_skew[e] < 1 || c->sh_skew[e] >= (1 << 14)) return false;
+                if (classify(t) != 2) return false;                       // hostname-like hard constraints: the all-feature kernel
+                const int set = c->sh_set.empty() ? -1 : c->sh_set[e], k = c->term_key[t];
+                if (set >= 0) {
+                    if (set >= c->R) return false;
+                    for (int j = 0; j < c->N; ++j)
+                        if (!((c->node_sets[(size_t)set * words + (j >> 6)] >> (j & 63)) & 1ull) && c->topo_dom[(size_t)k * c->N + j] >= 0) return false;
+                }
+            }
+        }
+        // a pinned pod (one admissible node) is decided from the table byte of that node alone: it must not carry a hard constraint
+        for (int p = 0; p < c->P && !c->p_pin.empty(); ++p)
+            if (c->p_pin[p] >= 0 && c->sh_off[c->p_cls[p] + 1] > c->sh_off[c->p_cls[p]]) return false;
+        c->hard_fold = true;
+    }
     // InterPodAffinity preferred terms (scoring.go:87-271) in their usual, SELF-REFERENTIAL form: the raw score of pod class cp on a node is
     //   sum_e pref_w[e] * cnt_match[t_e][dom] + sum_{t in match(cp)} w_owner[t][dom],
     // and w_owner[t] = w_t * cnt_match[t] whenever every class owns t with w_t times the multiplicity it matches t with (the pods a
@@ -488,7 +514,7 @@ bool spread_supported(simon_ctx* c) {
                 if (c->sp_kind[(size_t)c->Tm + c->own_idx[e]] && own_w_of[c->own_idx[e]] != 0) mult[c->sp_rep[(size_t)c->Tm + c->own_idx[e]]] = 1;
         }
         const int ns = c->ss_idx.empty() ? 0 : c->ss_off[cp + 1] - c->ss_off[cp];
-        const int ni = c->ipa_fold ? (c->ipa_h_term[cp] >= 0 ? 1 : 0) + (int)c->ipa_z[cp].size() : 0;
+        const int ni = (c->ipa_fold ? (c->ipa_h_term[cp] >= 0 ? 1 : 0) + (int)c->ipa_z[cp].size() : 0) + (c->hard_fold ? c->sh_off[cp + 1] - c->sh_off[cp] : 0);
         if ((int)mult.size() + ns + ni > 64) return false;
         for (auto& kv : mult) if ((int64_t)kv.second * max_pods > 255) return false;   // a byte counter: pods on a node x multiplicity
     }
@@ -860,14 +886,20 @@ int stage_narrow(simon_ctx* c) {
                     if (c->ipa_h_term[cp] >= 0) { ent.push_back(c->ipa_h_w[cp]); ent_term.push_back(c->ipa_h_term[cp]); ++n_ipa; }
                     for (auto& zt : c->ipa_z[cp]) { ent.push_back(zt.second); ent_term.push_back(zt.first); ++n_ipa; }
                 }
+                int n_hard = 0;
+                if (c->hard_fold)
+                    for (int e = c->sh_off[cp]; e < c->sh_off[cp + 1]; ++e, ++n_hard) {
+                        ent.push_back((c->sh_skew[e] & 0x3FFF) | ((!c->sh_self.empty() && c->sh_self[e]) ? 1 << 14 : 0));
+                        ent_term.push_back(c->sh_idx[e]);
+                    }
                 if (ent.empty()) continue;
                 std::vector<int32_t> key = ent;                            // (entries of different kinds can spell the same word)
                 key.insert(key.end(), ent_term.begin(), ent_term.end());
-                key.push_back(ns); key.push_back(n_ipa);
+                key.push_back(ns); key.push_back(n_ipa); key.push_back(n_hard);
                 auto it = sc_id.find(key);
                 if (it == sc_id.end()) {
-                    if (sp_ent.size() + ent.size() >= (1u << 18)) { c->table_ok = false; break; }
-                    it = sc_id.emplace(key, ns | ((int)mult.size() << 3) | (n_ipa << 10) | ((int)sp_ent.size() << 13)).first;
+                    if (sp_ent.size() + ent.size() >= (1u << 16)) { c->table_ok = false; break; }
+                    it = sc_id.emplace(key, ns | ((int)mult.size() << 3) | (n_ipa << 10) | (n_hard << 13) | ((int)sp_ent.size() << 15)).first;
                     sp_ent.insert(sp_ent.end(), ent.begin(), ent.end());
                     sp_ent_term.insert(sp_ent_term.end(), ent_term.begin(), ent_term.end());
                 }
@@ -1136,6 +1168,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_rest = getenv("SIMON_NO_REST") != nullptr;
     c->no_fold = getenv("SIMON_NO_FOLD") != nullptr;                  // A/B + tests: anti-affinity / ports through the position masks (or the all-feature kernel)
     c->no_sig_twins = getenv("SIMON_TABLE_NO_TWINS") != nullptr;      // A/B: signature ids in order of appearance
+    c->no_hard_fold = getenv("SIMON_NO_HARD_FOLD") != nullptr;        // A/B + tests: hard spread constraints always on the all-feature kernel
     c->no_ipa_fold = getenv("SIMON_NO_IPA_FOLD") != nullptr;          // A/B + tests: preferred pod (anti-)affinity always on the all-feature kernel
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
@@ -1445,7 +1478,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             // 256 scenarios 7.7 ms, 4 096 14.0 ms, 8 192 27.5 ms one-level / 32.3 ms two-level; 100 signatures 39.5 / 32.1 ms):
             // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
-            const int nzk = c->spread ? ((int)c->sp_zkeys.size() | (c->ipa_fold ? 0x100 : 0)) : -1;   // (| 0x100: the second score table of spread_select)
+            const int nzk = c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0)) : -1;   // (| 0x100: the second score table of spread_select)
             const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest, nzk) + c->lds_pad;
             const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
@@ -1561,7 +1594,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | (c->ipa_fold ? 0x100 : 0)) : -1) + c->lds_pad : 0;
+        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0)) : -1) + c->lds_pad : 0;
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
@@ -1605,7 +1638,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty();
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && c->ipa_fold) ? 64 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && (c->ipa_fold || c->hard_fold)) ? 64 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

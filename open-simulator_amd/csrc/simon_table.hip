@@ -903,10 +903,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
     // the summaries cannot carry it: a spread pod scans its signature's row, one position per lane, 64 positions per step, twice
     // (minimum / maximum of the raw scores, then totals), and takes the first maximum in canonical order (the static per-class node
     // lists give the canonical index of a position).  Everything else about the cycle -- assume, column refresh, summaries -- is the
-    // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | preferred-term entries << 10 | offset << 13 into TableCold::sp_ent; lane e
+    // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | preferred-term entries << 10 | hard constraints << 13 | offset << 15 into TableCold::sp_ent; lane e
     // holds entry e (`spv`).
     TPROF_DECL
-    auto spread_select = [&](int k, int soft_n, int match_n, int ipa_n, int spv, int spt, int& dstar, int& res) -> int {
+    auto spread_select = [&](int k, int tc, int soft_n, int match_n, int ipa_n, int hard_n, int spv, int spt, int& dstar, int& res) -> int {
         const int dd = lane < Cn ? lane : 0;
         int kind[4], rowi[4], zsl[4], skew[4];
         bool dup[4];
@@ -934,6 +934,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
                 const int l = (soft_n + match_n + i) & 63;
                 const int w_ = __builtin_amdgcn_readlane(spv, l), t_ = __builtin_amdgcn_readlane(spt, l);
                 wI[i] = i < ipa_n ? w_ : 0; kI[i] = i < ipa_n ? (t_ & 3) : 0; rI[i] = (t_ >> 2) & 0x3FFF; zI[i] = (t_ >> 16) & 7;
+            }
+        }
+        // Hard (DoNotSchedule) constraints on zone-like keys (podtopologyspread/filtering.go:198-333): the node classes are split by zone, so
+        // the filter is a per-CLASS verdict -- the class's zone must carry the label and count + self - min over the registered zones
+        // must not exceed maxSkew -- and an excluded class simply has no feasible node for this pod.  Entry i sits behind the preferred
+        // entries: skew | self << 14, the term's row.
+        int hS[3] = {0, 0, 0}, hR[3] = {0, 0, 0}, hZ[3] = {0, 0, 0};
+        if constexpr (kIpa) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int l = (soft_n + match_n + ipa_n + i) & 63;
+                const int x_ = __builtin_amdgcn_readlane(spv, l), t_ = __builtin_amdgcn_readlane(spt, l);
+                hS[i] = i < hard_n ? x_ : 0; hR[i] = (t_ >> 2) & 0x3FFF; hZ[i] = (t_ >> 16) & 7;
             }
         }
         const bool ipa_h = kIpa && ipa_n > 0 && kI[0] == 1;
@@ -965,6 +978,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
                     zipa += zd >= 0 ? wI[i] * (int)g_zcnt[rI[i] * 16 + zd] : 0;
                 }
         }
+        unsigned hcz[3] = {0u, 0u, 0u};                                   // per class: matching pods in the class's zone, per hard constraint
+        int hzd[3] = {0, 0, 0};
+        if constexpr (kIpa) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < hard_n) {
+                    hzd[i] = lane < Cn ? (int)s_zdom[hZ[i] * Cn + dd] : -1;
+                    hcz[i] = hzd[i] >= 0 ? g_zcnt[hR[i] * 16 + hzd[i]] : 0u;
+                }
+        }
         const unsigned char* hb1 = has_hrow ? g_hrow + (size_t)hrow_i * ni : (const unsigned char*)g_tile;   // (no hostname term: value unused)
         const int hmx_v = (simple && has_hrow) ? (int)g_hmax[hrow_i] : 0;   // largest counter of the row (uniform address)
         unsigned byte1[SB], h1[SB];
@@ -982,7 +1005,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (e < soft_n && kind[e] == 2) ign = ign || s_zdom[zsl[e] * Cn + dd] < 0;
-        const bool scored = lane < Cn && cntd > 0 && !ign;
+        bool excl = false;                                                // this class fails a hard constraint of the pod
+        if constexpr (kIpa) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < hard_n) {
+                    // registered zones (:236-251): those of the scenario's labelled nodes (the host admits eligibility sets that leave out
+                    // unlabelled nodes only); criticalPaths minimum over them (:272-278), math.MaxInt32 when there is none
+                    const bool reg = lane < Cn && cnt_d > 0 && hzd[i] >= 0;
+                    const int mn = wave_min_i32(reg ? (int)hcz[i] : 0x7fffffff);
+                    const long long skew = (long long)hcz[i] + ((hS[i] >> 14) & 1) - (long long)mn;
+                    excl = excl || hzd[i] < 0 || skew > (long long)(hS[i] & 0x3FFF);
+                }
+        }
+        const bool scored = lane < Cn && cntd > 0 && !ign && !excl;
         const int F = __builtin_amdgcn_readfirstlane(wave_sum_i32_t(scored ? cntd : 0));   // len(filteredNodes) - len(IgnoredNodes)
         int sz[4];
 #pragma unroll
@@ -1000,7 +1036,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
         // per class, held by lane = class: the zone term of constraint e (scoreForCount, :287-289, of the class's zone)
         auto az_of = [&](int e) -> double { return (lane < Cn && e < soft_n && kind[e] == 2) ? (double)czv[e] * w_of(e) + cst_of(e) : 0.0; };
         // per class as well: "ignored" and the class term of the signature's row
-        const int clsw = (int)((unsigned)s_sn[k * Cn + dd] | (ign ? 0x80000000u : 0u));
+        // (bit 30: excluded -- its nodes count as infeasible; the Simon normalisation then runs over the classes that are left, simon.go:76-101)
+        int ctermv = (int)s_sn[k * Cn + dd];
+        if constexpr (kIpa) {
+            if (hard_n > 0 && __ballot(lane < Cn && cntd > 0 && excl) != 0ull)
+                ctermv = class_term(lane < Cn && cntd > 0 && !excl, simon_raw[tc * Cn + dd], tc, dd);
+        }
+        const int clsw = (int)((unsigned)ctermv | (ign ? 0x80000000u : 0u) | (excl ? 0x40000000u : 0u));
         auto lane_f64 = [&](double v, int l) -> double {
             const unsigned long long b = (unsigned long long)__double_as_longlong(v);
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
@@ -1050,15 +1092,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
                         const int c = winner_info(u) >> 16;
                         const int idx = (c << lg) + ((int)h1[j] & hmask);     // (padding positions and the no-hostname-term case read arbitrary bytes)
                         const int raw = s_tab[idx];
-                        const bool ok = (byte1[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);   // (no short circuit: no branch)
+                        const int cwv = __builtin_amdgcn_readlane(clsw, c);
+                        unsigned beff = byte1[j];
+                        if constexpr (kIpa) beff = (cwv & 0x40000000) ? 0u : beff;   // a class a hard constraint excludes: no feasible node
+                        const bool ok = (beff != 0u) & (cwv >= 0);            // (no short circuit: no branch)
                         pmin = min(pmin, ok ? raw : 0x7fffffff);
                         pmax = max(pmax, ok ? raw : 0);
                         if constexpr (IPA) {
                             const int ir = s_tabi[idx];
-                            imin = min(imin, byte1[j] != 0u ? ir : 0);
-                            imax = max(imax, byte1[j] != 0u ? ir : 0);
+                            imin = min(imin, beff != 0u ? ir : 0);
+                            imax = max(imax, beff != 0u ? ir : 0);
                         }
-                        (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (byte1[j] << 8));   // (uniform base + lane: one address add)
+                        (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (beff << 8));   // (uniform base + lane: one address add)
                     }
                     u0 += SB;
                     if (u0 >= nun) break;
@@ -1087,7 +1132,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
                 if constexpr (kIpa) {
                     if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)(s_tabi[min(i, E - 1)] - imin) / (double)idiff));
                 }
-                if (i < E) s_tab[i] = (cw & 0x7fffffff) + 2 * v + iv;
+                if (i < E) s_tab[i] = (cw & 0x3fffffff) + 2 * v + iv;
             }
             TPROF_WAIT_LDS; TPROF(16);                                     // spread: extremes, table of totals
             for (int u0 = 0; u0 < nun; u0 += SC) {                       // pass 2: totals, first maximum in canonical order
@@ -1152,13 +1197,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
                 for (int j = 0; j < SG; ++j) {
                     const int c = winner_info(min(u0 + j, nun - 1)) >> 16;
                     const int raw = raw_of(h[j], c);
-                    const bool ok = (byte[j] != 0u) & (__builtin_amdgcn_readlane(clsw, c) >= 0);
+                    const int cwv = __builtin_amdgcn_readlane(clsw, c);
+                    unsigned beff = byte[j];
+                    if constexpr (kIpa) beff = (cwv & 0x40000000) ? 0u : beff;
+                    const bool ok = (beff != 0u) & (cwv >= 0);
                     pmin = min(pmin, ok ? raw : 0x7fffffff);
                     pmax = max(pmax, ok ? raw : 0);
                     if constexpr (kIpa) {
                         const int ir = (ipa_h ? Wh * (int)hI[j] : 0) + __builtin_amdgcn_readlane(zipa, c);
-                        imin = min(imin, (ipa_pod && byte[j] != 0u) ? ir : 0);
-                        imax = max(imax, (ipa_pod && byte[j] != 0u) ? ir : 0);
+                        imin = min(imin, (ipa_pod && beff != 0u) ? ir : 0);
+                        imax = max(imax, (ipa_pod && beff != 0u) ? ir : 0);
                     }
                 }
             }
@@ -1192,8 +1240,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
                     if constexpr (kIpa) {
                         if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)((ipa_h ? Wh * (int)hI[j] : 0) + __builtin_amdgcn_readlane(zipa, c) - imin) / (double)idiff));
                     }
-                    const int total = (int)byte[j] - 1 + (cw & 0x7fffffff) + 2 * v + iv;
-                    const unsigned key = byte[j] != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon[j]) : 0u;
+                    unsigned beff = byte[j];
+                    if constexpr (kIpa) beff = (cw & 0x40000000) ? 0u : beff;
+                    const int total = (int)beff - 1 + (cw & 0x3fffffff) + 2 * v + iv;
+                    const unsigned key = beff != 0u ? ((unsigned)(total + 1) << 13) | (8191u - (unsigned)canon[j]) : 0u;
                     if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
                 }
             }
@@ -1278,11 +1328,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0x3FF, r_cls = (pk >> 10) & 0x1FFFFF;
         const int rw = (REST || SPREAD) ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST / SPREAD descriptor (0: the score table alone decides the pod)
-        const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0, sp_ipa = SPREAD ? ((rw >> 10) & 7) : 0;
+        const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0, sp_ipa = SPREAD ? ((rw >> 10) & 7) : 0, sp_hard = SPREAD ? ((rw >> 13) & 3) : 0;
         int spv = 0;                                                       // SPREAD: lane e holds entry e of the pod's constraint / counted-term list
         int spt = 0;                                                       // ... and its term's row (TableCold::sp_ent holds both)
-        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match + sp_ipa) {
-            const int2 spe = cold->sp_ent[((unsigned)rw >> 13) + lane];
+        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match + sp_ipa + sp_hard) {
+            const int2 spe = cold->sp_ent[((unsigned)rw >> 15) + lane];
             spv = spe.x; spt = spe.y;
         }
         const int r_gs = REST ? (rw & 63) - 1 : -1, r_xs = REST ? ((rw >> 6) & 63) - 1 : -1, r_nrows = REST ? (rw >> 12) & 63 : 0;
@@ -1326,14 +1376,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AF
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv), dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
-        } else if (SPREAD && (sp_soft | sp_ipa) != 0) {                    // a pod with soft spread constraints / preferred pod (anti-)affinity: every node's score moves
+        } else if (SPREAD && (sp_soft | sp_ipa | sp_hard) != 0) {                    // a pod with soft spread constraints / preferred pod (anti-)affinity: every node's score moves
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
             if ((dq >> (k >> 6)) & 1u) {                               // the class terms of row k (s_sn) must be current
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
-            pstar = spread_select(k, sp_soft, sp_match, sp_ipa, spv, spt, dstar, res);
+            pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
             TPROF(18);                                                 // spread: winner
             if (pstar < 0) { ++unsched; res = -1; }
         } else {

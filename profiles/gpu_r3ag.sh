@@ -5,8 +5,8 @@ TAG=${1:-r3ag}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
 t0=$(date +%s)
-( timeout 1500 python -m pytest tests -m gpu -q -x -k "preferred or spread or generation_7 or fold or anti_affinity or service" 2>&1 | tail -12 ) > "$OUT/pytest.log"; tail -5 "$OUT/pytest.log"
-( timeout 900 python tests/fuzz_spread.py 600 130000 2>&1 | tail -5 ) > "$OUT/fuzz_spread.log"; tail -3 "$OUT/fuzz_spread.log"
+( timeout 1500 python -m pytest tests -m gpu -q -x -k "hard or preferred or spread or generation_7 or fold or anti_affinity or service" 2>&1 | tail -12 ) > "$OUT/pytest.log"; tail -5 "$OUT/pytest.log"
+( timeout 900 python tests/fuzz_spread.py 500 140000 2>&1 | tail -5 ) > "$OUT/fuzz_spread.log"; tail -3 "$OUT/fuzz_spread.log"
 echo "tests $(( $(date +%s) - t0 )) s"
 {
 for LIB in $PWD/profiles/ab/libsimon_r3ab0.so $PWD/open-simulator_amd/csrc/libsimon_hip.so; do

@@ -13,7 +13,7 @@ import oracle_lib as O  # noqa: E402
 import randprob  # noqa: E402
 from open_simulator_amd import capi  # noqa: E402
 
-FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small", "anti_host", "ipa_self", "ipa"]
+FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small", "anti_host", "ipa_self", "ipa", "hard_simple"]
 
 
 def one_case(case):

@@ -10,7 +10,7 @@ GiB = 1 << 30
 def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, static_mask=False, presets=False,
                  gates=False, eph=False, scalars=0, gpu=False, anti=False, zero_pods=False, tight_pods=False,
                  odd_units=False, n_node_classes=5, n_pod_classes=6, aff=False, ipa=False, spread_hard=False,
-                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False, static_small=False, ipa_self=False):
+                 spread_soft=False, static_scores=False, local=False, pins=False, anti_host=False, ports=False, static_small=False, ipa_self=False, hard_simple=False):
     rng = np.random.default_rng(seed)
     ncls = rng.integers(0, n_node_classes, N).astype(np.int32)
     cls_cpu = rng.choice([2000, 4000, 8000, 16000, 32000, 64000], n_node_classes)
@@ -145,9 +145,10 @@ def rand_problem(seed, N=40, P=200, *, nz_differs=False, init_state=False, stati
             sp["hdd_size"][:] = np.sort(rng.choice([5, 10, 40, 80], capi.MAX_LVOL)) * GiB_
         prob.local_specs = specs
         prob.local_spec_of = np.where(rng.random(n_pod_classes) < 0.6, rng.integers(0, len(specs), n_pod_classes), -1).astype(np.int32)
+    spread_hard = spread_hard or hard_simple
     v2 = aff or ipa or spread_hard or spread_soft or ipa_self
     if anti or v2:
-        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft, anti_host, ipa_self)
+        _topology(prob, rng, N, n_pod_classes, anti, aff, ipa, spread_hard, spread_soft, anti_host, ipa_self, hard_simple)
     elif anti_host or ports:
         _topology_host(prob, rng, N, n_pod_classes, anti_host, ports)
     return prob.normalise()
@@ -190,7 +191,7 @@ def _topology_host(prob, rng, N, Cp, anti=True, ports=False):
         prob.port_off, prob.port_idx = _csr(portl)
 
 
-def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_host=False, ipa_self=False):
+def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_host=False, ipa_self=False, hard_simple=False):
     """Two topology keys -- hostname (domain = node) and zone (4 zones, some nodes unlabeled) -- and 8 terms over them;
     every role list of include/simon_hip.h gets random entries for the enabled features."""
     zone = rng.integers(-1, 4, N).astype(np.int32)
@@ -255,7 +256,7 @@ def _topology(prob, rng, N, Cp, anti, aff, ipa, spread_hard, spread_soft, anti_h
         hard.append(h)
         hskew.append([int(rng.integers(1, 4)) for _ in h])
         hself.append([int(t in match[c]) for t in h])
-        hset.append([int(rng.integers(-1, 2)) for _ in h])
+        hset.append([-1 if hard_simple else int(rng.integers(-1, 2)) for _ in h])   # hard_simple: every labelled node is eligible
         so = pick([6, 7, 5], 0.7, 3) if spread_soft else []
         soft.append(so)
         sskew.append([int(rng.integers(1, 6)) for _ in so])

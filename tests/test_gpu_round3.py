@@ -334,3 +334,27 @@ def test_k8s_service_and_preferred_self_anti_affinity_share_their_counter_rows()
     assert eng.last_stats.kernel_variant == capi.KERNEL_NARROW_CACHE and eng.last_stats.kernel_generation == 7
     ranks = eng.kw.get("node_ranks")
     assert_same(eng.out, O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run(prob, scen, orders))
+
+
+@pytest.mark.parametrize("feat", [dict(hard_simple=True), dict(hard_simple=True, spread_soft=True), dict(hard_simple=True, spread_soft=True, ipa_self=True, anti_host=True),
+                                  dict(hard_simple=True, static_mask=True, presets=True, gates=True, tight_pods=True)])   # (pinned pods with a hard constraint: all-feature kernel)
+def test_hard_zone_spread_constraints_as_class_verdicts_on_generation_7(feat):
+    """DoNotSchedule constraints on a zone-like key whose eligible nodes are all the labelled ones: the node classes are split by zone, so
+    the filter is a per-class verdict inside spread_select (count + self - minimum over the registered zones <= maxSkew; classes without
+    the label are out) and the Simon normalisation runs over the classes that are left.  Every placement against the oracle, and the same
+    problems with SIMON_NO_HARD_FOLD=1 (all-feature kernel)."""
+    on7 = 0
+    for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500), (90, 600), (400, 1200)]):
+        prob = randprob.rand_problem(7800 + seed, N=N, P=P, n_node_classes=4, n_pod_classes=5 + seed, **feat)
+        scen, orders = randprob.rand_scenarios(370 + seed, prob, S=5)
+        ref = O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders)
+            st = ctx.stats()
+        on7 += st.kernel_generation == 7
+        assert_same(res, ref)
+        res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_HARD_FOLD": "1"})
+        assert variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+    assert on7 >= 3, on7
