@@ -288,7 +288,7 @@ def build_workload(args, synth, world):
     if args.workload == "config2":
         return synth.config2(), 1
     if args.workload == "service":             # config 3's pool and sweep, every pod selected by a Service (system-default soft spread)
-        return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, n_anti=args.anti, n_pref=args.pref), n_orders
+        return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, n_anti=args.anti, n_pref=args.pref, n_hard=args.hard), n_orders
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
         return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
     seed = synth.SEED + (3 if world == 1 else 4)
@@ -532,6 +532,7 @@ def main():
                     help="PMC counters for the roofline records: live = rocprofv3 passes over child runs (auto: live at N = 1 when "
                          "rocprofv3 exists, else the committed profile)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--hard", type=int, default=0, help="--workload service: services (every third) with a hard zone constraint on their own pods (maxSkew 2)")
     ap.add_argument("--pref", type=int, default=0, help="--workload service: services whose pods prefer not to sit next to their own kind (hostname 100, zone 50)")
     ap.add_argument("--anti", type=int, default=0, help="--workload service: services whose pods also require anti-affinity to their own kind on the hostname key")
     ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig", "service"], default="config3",

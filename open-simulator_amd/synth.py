@@ -253,7 +253,7 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
 
 
 def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
-                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0):
+                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0):
     """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
     request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
     constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
@@ -261,7 +261,8 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
     index order for every cluster size (V/internal/cache/node_tree.go:119-143).  Terms: per service (selector, hostname) and
     (selector, zone); the pods of a service match both and nothing else.  `n_anti`: the first n_anti services additionally REQUIRE
     anti-affinity to their own pods on kubernetes.io/hostname (one replica per node: the usual companion of a Service); `n_pref`: the
-    LAST n_pref services PREFER not to sit next to their own pods (weight 100 on the hostname key, 50 on the zone key: the chart default)."""
+    LAST n_pref services PREFER not to sit next to their own pods (weight 100 on the hostname key, 50 on the zone key: the chart default);
+    `n_hard`: every third service up to n_hard of them carries a HARD zone constraint on its own pods (maxSkew 2, DoNotSchedule)."""
     from .gomath import spread_log_table
     n_total = n_het + n_counts
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
@@ -286,6 +287,14 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
         na = min(n_anti, n_services)
         prob.anti_off = np.concatenate([np.arange(na + 1), np.full(n_services - na, na)]).astype(np.int32)
         prob.anti_idx = (2 * np.arange(na)).astype(np.int32)          # the service's own (selector, hostname) term
+    if n_hard > 0:
+        hard = [[2 * i + 1] if (i % 3 == 0 and i // 3 < n_hard) else [] for i in range(n_services)]      # the service's own (selector, zone) term
+        prob.spread_hard_off = np.cumsum([0] + [len(x) for x in hard]).astype(np.int32)
+        flat_h = [t for x in hard for t in x]
+        prob.spread_hard_idx = np.array(flat_h, np.int32)
+        prob.spread_hard_skew = np.full(len(flat_h), 2, np.int32)
+        prob.spread_hard_self = np.ones(len(flat_h), np.int32)
+        prob.spread_hard_set = np.full(len(flat_h), -1, np.int32)
     if n_pref > 0:
         npf = min(n_pref, n_services)
         first = n_services - npf

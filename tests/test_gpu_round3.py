@@ -311,6 +311,9 @@ def test_k8s_service_and_preferred_self_anti_affinity_share_their_counter_rows()
             spec["affinity"] = {"podAntiAffinity": {"preferredDuringSchedulingIgnoredDuringExecution": [
                 {"weight": 100, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}},
                 {"weight": int(rng.choice([20, 50])), "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.ZONE}}]}}
+        if w % 5 == 4:          # a hard zone constraint: a per-class verdict of spread_select
+            spec["topologySpreadConstraints"] = [{"maxSkew": int(1 + w % 2), "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "DoNotSchedule",
+                                                  "labelSelector": {"matchLabels": {"app": app}}}]
         workloads.append({"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": app, "namespace": "default"},
                           "spec": {"replicas": int(rng.integers(10, 50)), "selector": {"matchLabels": {"app": app}},
                                    "template": {"metadata": {"labels": {"app": app}}, "spec": spec}}})
