@@ -301,11 +301,14 @@ bool rest_supported(simon_ctx* c) {
     return true;
 }
 
-// Can the score-table kernel's SPREAD path (generation 7) take this problem?  Of the ABI v2 features only SOFT PodTopologySpread
-// constraints (+ the static score tables the class term folds in): no hard constraints, no InterPodAffinity terms of any kind, no host
-// ports, no Open-Gpu-Share / extra-resource rows (the REST path), no Open-Local.  Every soft term sits on a hostname-like key (flagged
-// topo_is_hostname, every node its own domain: one counter byte per position) or on a zone-like key (<= 16 domains; <= 3 such keys: the
-// node classes are split by their domains).  Fills sp_kind / sp_row / sp_zslot / sp_zkeys.
+// Can the score-table kernel's SPREAD path (generation 7) take this problem?  Of the ABI v2 features: SOFT PodTopologySpread constraints
+// (+ the static score tables the class term folds in), InterPodAffinity PREFERRED terms whose owners hold one weight per pod with at
+// most one hostname-like counter per class, HARD spread constraints on zone-like keys whose eligible nodes are all the
+// labelled ones (5.3f), required anti-affinity / host ports where they fold into the table (fold_supported, 5.3d).  Not: required
+// affinity, Open-Gpu-Share / extra-resource rows (the REST path), Open-Local.  Every term with a counter sits on a hostname-like key
+// (flagged topo_is_hostname, every node its own domain: one counter byte per position) or on a zone-like key (<= 16 domains; <= 3 such
+// keys: the node classes are split by their domains).  Fills sp_kind / sp_row / sp_zslot / sp_zkeys / sp_rep / sp_set_eff and the
+// per-class entries of the preferred score.
 bool spread_supported(simon_ctx* c) {
     c->ipa_fold = false;
     c->ipa_h_term.clear(); c->ipa_h_w.clear(); c->ipa_z.clear();
@@ -460,10 +463,9 @@ bool spread_supported(simon_ctx* c) {
     if (c->has_ipa_score) {
         if (c->match_off.empty()) return false;
         const int Cp = c->Cp, T = c->Tm;
-        std::vector<std::map<int, long long>> prefsum(Cp), ownsum(Cp), mult(Cp);
+        std::vector<std::map<int, long long>> prefsum(Cp), mult(Cp);
         for (int cp = 0; cp < Cp; ++cp) {
             if (!c->pref_off.empty()) for (int e = c->pref_off[cp]; e < c->pref_off[cp + 1]; ++e) prefsum[cp][c->pref_idx[e]] += c->pref_w[e];
-            if (!c->own_off.empty()) for (int e = c->own_off[cp]; e < c->own_off[cp + 1]; ++e) ownsum[cp][c->own_idx[e]] += c->own_w[e];
             for (int e = c->match_off[cp]; e < c->match_off[cp + 1]; ++e) mult[cp][c->match_idx[e]] += 1;
         }
         // w_owner[t] = (the owners' weight per pod) x (owner pods in the domain): a counter row of its own (id Tm + t) -- the SAME row as
