@@ -584,10 +584,23 @@ bool fold_supported(simon_ctx* c) {
             c->fold_x[(size_t)L * FC + S] = meets(std::get<0>(fcs[S]), std::get<1>(fcs[L])) || meets(std::get<1>(fcs[S]), std::get<0>(fcs[L])) ||
                                             meets(std::get<2>(fcs[S]), std::get<1>(fcs[L]));
     c->fold_FC = FC;
-    // signatures the table would need, at most (stage_narrow merges pod classes with equal static rows further)
-    std::set<std::tuple<int64_t, int64_t, int64_t, int64_t, int32_t>> sig;
+    // signatures the table would need: (request, content of the class's static rows as stage_narrow interns them, filter class)
+    std::vector<int32_t> content_of(Cp);
+    {
+        const size_t words = (size_t)(N + 63) / 64;
+        std::map<std::pair<std::vector<uint64_t>, std::vector<int64_t>>, int> ids;
+        for (int cp = 0; cp < Cp; ++cp) {
+            std::vector<uint64_t> mrow;
+            if (c->has_mask) mrow.assign(c->static_mask.begin() + (size_t)cp * words, c->static_mask.begin() + (size_t)(cp + 1) * words);
+            std::vector<int64_t> rrow;
+            for (const std::vector<int64_t>* tab : {&c->simon_raw, &c->na_raw, &c->tt_raw, &c->static_add})
+                if (!tab->empty()) rrow.insert(rrow.end(), tab->begin() + (size_t)cp * c->Cn, tab->begin() + (size_t)(cp + 1) * c->Cn);
+            content_of[cp] = ids.emplace(std::make_pair(std::move(mrow), std::move(rrow)), (int)ids.size()).first->second;
+        }
+    }
+    std::set<std::tuple<int64_t, int64_t, int64_t, int64_t, int32_t, int32_t>> sig;
     for (int p = 0; p < c->P; ++p) {
-        sig.insert(std::make_tuple(c->p_req_cpu[p], c->p_req_mem[p], c->p_nz_cpu[p], c->p_nz_mem[p], c->p_cls[p]));
+        sig.insert(std::make_tuple(c->p_req_cpu[p], c->p_req_mem[p], c->p_nz_cpu[p], c->p_nz_mem[p], content_of[c->p_cls[p]], c->fold_fc[c->p_cls[p]]));
         if ((int)sig.size() > kTableMaxSigs) return false;
     }
     c->fold_sigs = (int)sig.size();

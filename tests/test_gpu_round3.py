@@ -361,3 +361,36 @@ def test_hard_zone_spread_constraints_as_class_verdicts_on_generation_7(feat):
         assert variant == capi.KERNEL_WIDE
         assert_same(res, ref)
     assert on7 >= 3, on7
+
+
+def test_k8s_typical_cluster_sweep_on_generation_7():
+    """profiles/e2e_sweep.py --typical at a size the oracle checks in seconds: Deployments / StatefulSets behind Services, preferred and
+    required anti-affinity to their own replicas, hard zone constraints, tolerations, node selectors -- the whole sweep on the score-table
+    kernel, every placement against the oracle."""
+    import importlib.util
+    import randk8s
+    from open_simulator_amd import k8s, simulate as sim
+    spec = importlib.util.spec_from_file_location("e2e_sweep", os.path.join(ROOT, "profiles", "e2e_sweep.py"))
+    e2e = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(e2e)
+    nodes, workloads, services = e2e.typical_cluster(3, 360, 70, 40)
+    for j, n in enumerate(nodes):
+        n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"
+    cluster = k8s.group_resources(nodes + services)
+    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z0"}},
+                "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "110"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
+
+    class Recording(sim.HipEngine):
+        def run(self, prob, scen, orders, want_placement=True, **kw):
+            self.args, self.kw = (prob, scen, orders), kw
+            self.out = super().run(prob, scen, orders, want_placement, **kw)
+            return self.out
+
+    eng = Recording()
+    sim.sweep(cluster, apps, template, [0, 20, 40, 60, 80, 100, 120], engine=eng)
+    prob, scen, orders = eng.args
+    assert prob.n_pods > 1000 and len(scen) == 7
+    assert eng.last_stats.kernel_variant == capi.KERNEL_NARROW_CACHE and eng.last_stats.kernel_generation == 7
+    ranks = eng.kw.get("node_ranks")
+    assert_same(eng.out, O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run(prob, scen, orders))
