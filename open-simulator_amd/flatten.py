@@ -13,6 +13,7 @@ Each step names the reference code it restates (V/ = vendor/k8s.io/kubernetes/pk
 """
 from __future__ import annotations
 
+import functools
 import json
 import os
 from dataclasses import dataclass, field
@@ -126,9 +127,16 @@ def _affinity_terms(pod: dict):
     return out
 
 
+@functools.lru_cache(maxsize=None)
+def _parsed(text: str):
+    """json.loads of a selector that travels as text inside the interned term tuples: parsed ONCE (the class x term matching below asked
+    for it classes x terms times -- 670 000 json.loads on a 400-workload cluster; the parsed objects are only ever read)."""
+    return json.loads(text)
+
+
 def _matches_term(pod_ns: str, pod_labels: dict, namespaces, sel_json: str) -> bool:
     """schedutil.PodMatchesTermsNamespaceAndSelector, V/util/topologies.go:40-49."""
-    return pod_ns in namespaces and k8s.label_selector_matches(json.loads(sel_json), pod_labels)
+    return pod_ns in namespaces and k8s.label_selector_matches(_parsed(sel_json), pod_labels)
 
 
 def _default_spread_selector(pod: dict, services, replicasets, statefulsets):
@@ -179,7 +187,7 @@ def _spread_constraints(pod: dict, services, replicasets, statefulsets):
 
 
 def _selectors_match(sel_list_json: str, labels: dict) -> bool:
-    return all(k8s.label_selector_matches(sel, labels) for sel in json.loads(sel_list_json))
+    return all(k8s.label_selector_matches(sel, labels) for sel in _parsed(sel_list_json))
 
 
 def _prefer_avoid(node: dict, pod: dict) -> int:
@@ -739,10 +747,10 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         if kind == "sel":
             return _matches_term(ns, labels, nss, sel)
         if kind == "all":
-            return all(_matches_term(ns, labels, tuple(x[:-1]), x[-1]) for x in json.loads(sel))
+            return all(_matches_term(ns, labels, tuple(x[:-1]), x[-1]) for x in _parsed(sel))
         if ns not in nss:                                           # countPodsMatchSelector: same namespace (common.go:93-105)
             return 0
-        return sum(1 for s_ in json.loads(sel) if _selectors_match(s_, labels))   # multiplicity, see `grouped` above
+        return sum(1 for s_ in _parsed(sel) if _selectors_match(s_, labels))   # multiplicity, see `grouped` above
     match_memo: Dict[str, list] = {}                # a class matches terms through its namespace, labels and host ports only
     match = []
     for c, p in enumerate(class_rep):
