@@ -751,12 +751,52 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         if ns not in nss:                                           # countPodsMatchSelector: same namespace (common.go:93-105)
             return 0
         return sum(1 for s_ in _parsed(sel) if _selectors_match(s_, labels))   # multiplicity, see `grouped` above
+    # Which terms can a class match at all?  A selector with matchLabels needs one of its pairs among the pod's labels: terms are indexed
+    # by such a pair, the rest (match-everything selectors, expressions only) are always tried -- classes x terms tests become
+    # classes x (a handful) on clusters of many workloads.
+    def required_pair(sel):
+        for kv in ((sel or {}).get("matchLabels") or {}).items():
+            return kv
+        return None
+    by_pair: Dict[tuple, List[int]] = {}
+    always: List[int] = []
+    port_terms: List[int] = []
+    for ti, t in enumerate(terms):
+        kind, sel = t[0], t[2]
+        if kind == "port":
+            port_terms.append(ti)
+            continue
+        if kind == "sel":
+            pairs = [required_pair(_parsed(sel))]
+        elif kind == "all":
+            xs = _parsed(sel)
+            pairs = [required_pair(_parsed(xs[0][-1]))] if xs else [None]
+        else:                                           # spread terms: a list of selector lists, each of which may match (multiplicity)
+            pairs = []
+            for s_ in _parsed(sel):
+                sels = _parsed(s_)
+                pairs.append(required_pair(sels[0]) if sels else None)
+            if not pairs:
+                continue                                # nothing to match: count 0
+        if any(pr is None for pr in pairs):
+            always.append(ti)
+        else:
+            for pr in set(pairs):
+                by_pair.setdefault(pr, []).append(ti)
     match_memo: Dict[str, list] = {}                # a class matches terms through its namespace, labels and host ports only
     match = []
     for c, p in enumerate(class_rep):
-        mk = json.dumps([p["metadata"]["namespace"], p["metadata"].get("labels") or {}, host_ports(p)], sort_keys=True)
+        labels = p["metadata"].get("labels") or {}
+        mk = json.dumps([p["metadata"]["namespace"], labels, host_ports(p)], sort_keys=True)
         if mk not in match_memo:
-            match_memo[mk] = [t for t in range(len(terms)) for _ in range(int(class_matches(c, terms[t])))]
+            cand = set(always)
+            for kv in labels.items():
+                cand.update(by_pair.get(kv, ()))
+            if host_ports(p):
+                cand.update(port_terms)
+            match_memo[mk] = [t for t in sorted(cand) for _ in range(int(class_matches(c, terms[t])))]
+            if os.environ.get("SIMON_CHECK_MATCH_INDEX"):      # tests: the index must not lose a match
+                assert match_memo[mk] == [t for t in range(len(terms)) for _ in range(int(class_matches(c, terms[t])))], (c, mk)
         match.append(match_memo[mk])
 
     T = len(terms)

@@ -464,3 +464,21 @@ def test_named_zero_extended_resource_with_no_other_request_is_refused():
         fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
     pod["spec"]["containers"][0]["resources"]["requests"]["cpu"] = "100m"      # with a real request the shortcut never applies
     fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
+
+
+def test_term_index_finds_every_match(monkeypatch):
+    """flatten tries only the terms a class can match (indexed by a matchLabels pair of their selector); SIMON_CHECK_MATCH_INDEX makes it
+    compare with the classes x terms evaluation: random clusters with every selector shape randk8s draws."""
+    import randk8s
+    from open_simulator_amd import flatten as fl, simulate as sim
+    monkeypatch.setenv("SIMON_CHECK_MATCH_INDEX", "1")
+    for seed in range(6):
+        nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=14, n_workloads=30, max_replicas=4, gpu=seed % 2 == 0, local=seed % 3 == 0)
+        nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
+        cluster = {k: [] for k in k8s.KINDS}
+        cluster["Node"], cluster["Service"] = nodes, services
+        pods, _ = sim.build_stream(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], nodes, len(nodes))
+        try:
+            fl.flatten(nodes, pods, services, [], [], storage_classes=randk8s.STORAGE_CLASSES)
+        except fl.Unsupported:
+            pass
