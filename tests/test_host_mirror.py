@@ -482,3 +482,27 @@ def test_term_index_finds_every_match(monkeypatch):
             fl.flatten(nodes, pods, services, [], [], storage_classes=randk8s.STORAGE_CLASSES)
         except fl.Unsupported:
             pass
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_typical_cluster_against_the_object_level_scheduler(seed):
+    """profiles/e2e_sweep.py --typical (Deployments / StatefulSets behind Services, preferred and required anti-affinity to their own
+    replicas, hard zone constraints, tolerations, node selectors -- the shapes the score-table kernel keeps since round 3) at a small
+    size: flatten + oracle against tests/pyref_sched.py, the restatement that works on the objects the way the Go code does."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("e2e_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "e2e_sweep.py"))
+    e2e = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(e2e)
+    nodes, workloads, services = e2e.typical_cluster(100 + seed, 45, 16, 12)
+    for j, n in enumerate(nodes):
+        n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"
+        n["status"]["allocatable"]["pods"] = "20"
+    nodes = [nodes[j] for j in k8s.canonical_node_order(nodes)]
+    cluster = {k: [] for k in k8s.KINDS}
+    cluster["Node"], cluster["Service"] = nodes, services
+    pods, _ = sim.build_stream(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], nodes, len(nodes))
+    flat = fl.flatten(nodes, pods, services, [], [])
+    assert flat.problem.pref_off is not None and flat.problem.spread_soft_off is not None
+    res = O.run(flat.problem, [[len(nodes), 0]], np.arange(len(pods), dtype=np.int32)[None])
+    ref = pyref_sched.Scheduler(nodes, services, [], []).run(pods)
+    assert [None if j < 0 else flat.node_names[j] for j in res.placement[0].tolist()] == ref
