@@ -15,11 +15,15 @@ read RANK / LOCAL_RANK / WORLD_SIZE from the environment as usual.
 
 `python bench.py --group N` is the one-process variant: N devices behind simon_group_* (what a Go host does).
 
-Prints ONE JSON line on rank 0: the headline record (config 3) with `roofline` + `cpu_baseline` + `parity_sample`, an `end_to_end`
-leg from host buffers, and `other_workloads` -- config 2 and config 5 (at 256 scenarios and at the saturating batch size), each with
-its OWN live-PMC roofline, CPU baseline and parity sample.  The oracle (oracle/) is only the checker: `cpu_baseline` times it and
-`parity_sample` compares what it computed with the GPU's results of the timed batch (exit code 3 on a
-mismatch).  Nothing under oracle/ is on the timed path.
+Output on rank 0: the LAST stdout line is ONE compact JSON record (<= 3 KB: the driver keeps the last ~8 KB of stdout and parses
+the last line; round 3's 24.8 KB line lost its head) -- the headline record (config 3) with `roofline` + `cpu_baseline` +
+`parity_sample` and a `digest` with one short row per other workload.  Everything else -- notes, peaks, instruction mixes, the
+`end_to_end` leg from host buffers, `other_workloads` in full (config 2, 200 signatures, the Service workloads, config 5 at 256
+scenarios and at the saturating batch size, the all-feature kernel's random mix; each with its OWN live-PMC roofline, CPU
+baseline and parity sample) -- goes to the sidecar `bench_detail.json` (path in the line's `detail`; SIMON_BENCH_DETAIL overrides)
+and to EARLIER stdout lines prefixed `#detail `.  The oracle (oracle/) is only the checker: `cpu_baseline` times it and
+`parity_sample` compares what it computed with the GPU's results of the timed batch (exit code 3 on a mismatch).  Nothing under
+oracle/ is on the timed path.
 """
 import argparse
 import glob
@@ -418,6 +422,109 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
     return rec
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Output: full record -> sidecar + `#detail` lines; compact record (<= LINE_BUDGET bytes) -> the LAST stdout line
+# ---------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 3000                # bytes of the final JSON line (the driver keeps ~8 KB of the stdout tail)
+
+
+def _short_roofline(r):
+    if not r:
+        return None
+    src = r.get("counters_source") or ""
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "launches_per_step", "measured_hbm_gbs",
+            "measured_hbm_frac", "algorithmic_ratio", "lds_frac", "valu_pipe_busy_frac")
+    out = {k: r.get(k) for k in keep if k in r}
+    out["counters"] = "live" if src.startswith("measured live") else ("replayed" if src.startswith("replayed") else None)
+    return out
+
+
+DIGEST_COLS = ["name", "scenarios_per_s", "kernel_ms", "generation", "roofline_frac", "hbm_frac", "cpu_scenarios_per_s", "checked", "mismatches"]
+
+
+def _digest_row(w):
+    """One row per other workload, in DIGEST_COLS order (a list, not a dict: the line has a byte budget)."""
+    r = w.get("roofline") or {}
+    if "error" in w:
+        return [w.get("workload"), None, None, None, None, None, None, None, "error: " + str(w["error"])[:60]]
+    return [w.get("workload"), w.get("value"), w.get("kernel_ms"), w.get("kernel_generation"), r.get("frac"), r.get("measured_hbm_frac"),
+            (w.get("cpu_baseline") or {}).get("value"), (w.get("parity_sample") or {}).get("scenarios"), (w.get("parity_sample") or {}).get("mismatches")]
+
+
+def compact_line(out, detail_name):
+    """The record the driver parses: the contract's keys, the headline `roofline` / `cpu_baseline` / `parity_sample` without their
+    prose, one digest row per other workload.  Trimmed further (never the contract's keys) if it would exceed LINE_BUDGET."""
+    cfg = out.get("config", {})
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data", "pods_placed_per_sec")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "scenarios_per_gpu", "pods", "node_pool", "kernel", "kernel_generation", "plan") if k in cfg}
+    if out.get("roofline"):
+        line["roofline"] = _short_roofline(out["roofline"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
+    ps = out.get("parity_sample")
+    if ps:
+        line["parity_sample"] = {k: ps.get(k) for k in ("scenarios", "placement_rows", "mismatches")}
+    rk = out.get("ranks") or {}
+    if rk.get("world_size", 1) > 1 or "devices" in rk:
+        sc = rk.get("selfcheck") or {}
+        line["ranks"] = {k: v for k, v in {"world_size": rk.get("world_size"), "backend": rk.get("backend"), "mode": (rk.get("mode") or "")[:40] or None,
+                                           "all_gather_ms_per_step": rk.get("all_gather_ms_per_step"), "collective": rk.get("plan_collective"),
+                                           "distinct_devices": sc.get("distinct_devices_over_ranks"),
+                                           "one_device_test_hook": sc.get("one_device_test_hook", rk.get("one_device_test_hook"))}.items() if v is not None}
+    e2e = out.get("end_to_end")
+    if e2e:
+        line["end_to_end"] = {k: e2e.get(k) for k in ("load_problem_ms", "batch_ms", "kernel_ms", "scenarios_per_s")}
+    if out.get("other_workloads"):
+        line["digest"] = {"cols": DIGEST_COLS, "rows": [_digest_row(w) for w in out["other_workloads"]]}
+    line["detail"] = detail_name
+    def drop_col(name):
+        def f():
+            dg = line.get("digest")
+            if dg and name in dg["cols"]:
+                i = dg["cols"].index(name)
+                dg["cols"] = dg["cols"][:i] + dg["cols"][i + 1:]
+                dg["rows"] = [r[:i] + r[i + 1:] for r in dg["rows"]]
+        return f
+
+    def sig4():                                                      # digest numbers to 4 significant digits
+        dg = line.get("digest")
+        if dg:
+            dg["rows"] = [[float(f"{v:.4g}") if isinstance(v, float) else v for v in r] for r in dg["rows"]]
+
+    trims = [lambda: line.pop("end_to_end", None), sig4, lambda: line["roofline"].pop("lds_frac", None) if line.get("roofline") else None,
+             lambda: line["roofline"].pop("valu_pipe_busy_frac", None) if line.get("roofline") else None,
+             drop_col("cpu_scenarios_per_s"), drop_col("checked"), drop_col("generation"), drop_col("hbm_frac"),
+             lambda: line["cpu_baseline"].update(sample=line["cpu_baseline"]["sample"][:40]) if line.get("cpu_baseline") else None,
+             drop_col("roofline_frac"), lambda: line.pop("digest", None)]
+    for trim in trims:                                               # never the contract's keys, roofline, cpu_baseline, parity_sample
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        trim()
+    return line
+
+
+def emit(out):
+    """Sidecar + `#detail` lines first, the compact record LAST (flushed): whatever tail of stdout survives holds it whole."""
+    path = os.environ.get("SIMON_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+    name = os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+        name = None
+    head = {k: v for k, v in out.items() if k != "other_workloads"}
+    print("#detail " + json.dumps(head), flush=True)
+    for w in out.get("other_workloads", []):
+        print("#detail " + json.dumps(w), flush=True)
+    line = compact_line(out, name)
+    text = json.dumps(line)
+    assert len(text) <= 4096, f"final bench line is {len(text)} bytes"
+    print(text, flush=True)
+
+
 def multi_rank_selfcheck(torch, dist, world, rank, local_rank, backend):
     """What must hold when N ranks claim N GPUs (the nccl branch has never met hardware: the line states what it saw).  Unless the
     one-device test hook is set: enough visible devices, and every rank on its own device (all-gather of the device identity)."""
@@ -492,7 +599,7 @@ def run_group(args, capi, synth, torch):
                      "member_kernel_ms": [round(s.kernel_ms, 3) for s in sts]}}
     if par is not None:
         out["parity_sample"] = par
-    print(json.dumps(out), flush=True)
+    emit(out)
     if par and par["mismatches"]:
         raise SystemExit(3)
 
@@ -674,8 +781,10 @@ def main():
             out["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, local_rank)
             subs = []
             nchk5 = int(os.environ.get("SIMON_BENCH_C5_CHECK", "32"))
-            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", 3, 1, 64, 0), ("service", 2, 1, 64, 0), ("service_anti", 2, 1, 48, 0), ("service_pref", 2, 1, 48, 0), ("config5", 2, 1, nchk5, c5_scenarios(args)),
-                                                 ("config5", 2, 1, nchk5, C5_SATURATING)):
+            sub_steps = int(os.environ.get("SIMON_BENCH_SUB_STEPS", "5"))       # every sub-record times >= 5 steps after a warm-up
+            for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", sub_steps, 1, 64, 0), ("service", sub_steps, 1, 64, 0),
+                                                 ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
+                                                 ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING)):
                 try:
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))
                     if subs[-1].get("parity_sample", {}).get("mismatches"):
@@ -684,7 +793,7 @@ def main():
                     subs.append({"workload": name, "error": repr(e)})
                     rc = rc or 4
             out["other_workloads"] = subs
-        print(json.dumps(out), flush=True)
+        emit(out)
     else:
         ctx.close()
     if world > 1:

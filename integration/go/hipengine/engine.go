@@ -487,8 +487,9 @@ func withAnyNodeName(p *corev1.Pod) *corev1.Pod {
 }
 
 // gpuNodeStatus is what GpuSharePlugin.Reserve leaves on a node it booked GPU pods on (pkg/simulator/plugin/open-gpu-share.go:160-186):
-// annotation simon/node-gpu-share = NodeGpuInfo as JSON (ExportGpuNodeInfoAsNodeGpuInfo, gpunodeinfo.go:345-368) and allocatable
-// gpu-count = devices that are not full.  pods: the GPU pods bound to the node, already carrying their gpu-index annotation.
+// annotation simon/node-gpu-share = NodeGpuInfo as JSON (ExportGpuNodeInfoAsNodeGpuInfo, gpunodeinfo.go:345-368).  Allocatable
+// gpu-count is left alone: Reserve calls Set on a COPY of the map's Quantity (:177-182) and never stores it back, so the reference's
+// NodeStatus keeps the node's original value.  pods: the GPU pods bound to the node, already carrying their gpu-index annotation.
 func gpuNodeStatus(node *corev1.Node, pods []*corev1.Pod) *corev1.Node {
 	n := node.DeepCopy()
 	cnt := gpushareutils.GetGpuCountInNode(n)
@@ -527,10 +528,6 @@ func gpuNodeStatus(node *corev1.Node, pods []*corev1.Pod) *corev1.Node {
 	}
 	if data, err := ffjson.Marshal(info); err == nil {
 		metav1.SetMetaDataAnnotation(&n.ObjectMeta, simontype.AnnoNodeGpuShare, string(data))
-	}
-	if q, ok := n.Status.Allocatable[gpushareutils.CountName]; ok && q.Value() != int64(info.GpuAllocatable) {
-		q.Set(int64(info.GpuAllocatable))
-		n.Status.Allocatable[gpushareutils.CountName] = q
 	}
 	return n
 }

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import functools
 import json
+import re
 import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -89,6 +90,9 @@ def _gpu_annotations(pod: dict) -> Tuple[int, int]:
     return mem, cnt if cnt >= 0 else 0
 
 
+_ATOI = re.compile(r"^[+-]?[0-9]+$")
+
+
 def gpu_index_annotation(pod: dict):
     """GetGpuIdFromAnnotation + GpuIdStrToIntList (pkg/type/open-gpu-share/utils/pod.go:35-53,100-115): the device ids of an
     alibabacloud.com/gpu-index annotation the pod ARRIVES with ("2", "0-0-1"), or None when it has none or an invalid one (the
@@ -99,10 +103,14 @@ def gpu_index_annotation(pod: dict):
         return None
     ids = []
     for part in str(text).split("-"):
-        try:
-            ids.append(int(part))                     # strconv.Atoi: optional sign, decimal digits
-        except ValueError:
+        # strconv.Atoi: one optional sign, then ASCII decimal digits only -- Python's int() also takes " 1", "1_0" and Unicode
+        # digits, which the reference rejects (it then allocates normally)
+        if not _ATOI.match(part):
             return None
+        v = int(part)
+        if not -(1 << 63) <= v < (1 << 63):           # Atoi reports ErrRange beyond int (64 bits on amd64)
+            return None
+        ids.append(v)
     return ids or None
 
 

@@ -138,7 +138,8 @@ def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict
         if gpu_slices is not None and gmem is not None and gmem[pid] > 0 and not pod["spec"].get("nodeName"):
             ids = capi.gpu_ids_of(int(gpu_slices[pid]))
             preset = fl.gpu_index_annotation(pod)
-            text = "-".join(str(i) for i in (preset if preset else ids))   # a pod that arrived with ids keeps its own string
+            # a pod that arrived with valid ids keeps its OWN annotation text ("00-1" stays "00-1": the reference never rewrites it)
+            text = str(pod["metadata"]["annotations"][k8s.GPU_INDEX]) if preset else "-".join(str(i) for i in ids)
             bound["metadata"]["annotations"] = dict(bound["metadata"].get("annotations") or {},
                                                     **{k8s.GPU_INDEX: text, k8s.GPU_ASSUME_TIME: str(time.time_ns())})
             for d in sorted(set(ids)):
@@ -162,7 +163,9 @@ def _mi(n_bytes: int) -> str:
 def _gpu_node_status(node: dict, per_dev: Dict[int, List[tuple]]) -> dict:
     """What GpuSharePlugin.Reserve leaves on a node it booked a GPU pod on (pkg/simulator/plugin/open-gpu-share.go:160-186):
     annotation simon/node-gpu-share = NodeGpuInfo as JSON (ExportGpuNodeInfoAsNodeGpuInfo, gpunodeinfo.go:345-368; the reference
-    lists a device's pods in Go map order, here in scheduling order) and allocatable gpu-count = devices not yet full."""
+    lists a device's pods in Go map order, here in scheduling order).  status.allocatable[gpu-count] stays what it was: Reserve
+    copies the Quantity out of the map (`allocValue := node.Status.Allocatable[CountName]`, :177-182), calls Set on the COPY and never
+    writes it back before Nodes().Update -- the number of non-full devices only appears as GpuAllocatable inside the annotation."""
     node = copy.deepcopy(node)
     cap = node.get("status", {}).get("capacity") or {}
     cnt = int(fl.parse_quantity(str(cap[k8s.GPU_COUNT])).int_value()) if k8s.GPU_COUNT in cap else 0
@@ -181,8 +184,6 @@ def _gpu_node_status(node: dict, per_dev: Dict[int, List[tuple]]) -> dict:
     import json
     md = node["metadata"]
     md["annotations"] = dict(md.get("annotations") or {}, **{k8s.ANNO_NODE_GPU_SHARE: json.dumps(info, separators=(",", ":"))})
-    alloc = node["status"].setdefault("allocatable", {})
-    alloc[k8s.GPU_COUNT] = str(allocatable)
     return node
 
 

@@ -108,8 +108,8 @@ def test_object_level_scheduler_and_oracle_agree_on_ids():
 
 
 def test_simulate_result_carries_the_annotations():
-    """NodeStatus.Pods of GPU pods carry alibabacloud.com/gpu-index / assume-time, their nodes simon/node-gpu-share and an
-    allocatable gpu-count of the devices that are not full."""
+    """NodeStatus.Pods of GPU pods carry alibabacloud.com/gpu-index / assume-time, their nodes simon/node-gpu-share; the
+    node's allocatable gpu-count is NOT touched (open-gpu-share.go:177-182 sets a copy of the Quantity and drops it)."""
     nodes, pods = _gpu_cluster()
     cluster = k8s.group_resources(nodes + pods)
     res = sim.simulate(cluster, [], engine=OracleEngine())
@@ -135,7 +135,8 @@ def test_simulate_result_carries_the_annotations():
                      for p in s["pods"])
         assert used == booked
         full = sum(1 for b in info["DevsBrief"].values() if fl.parse_quantity(b["GpuUsedMemory"]).int_value() >= 16 * GiB)
-        assert info["GpuAllocatable"] == cnt - full == int(n["status"]["allocatable"][k8s.GPU_COUNT])
+        assert info["GpuAllocatable"] == cnt - full
+        assert n["status"]["allocatable"][k8s.GPU_COUNT] == n["status"]["capacity"][k8s.GPU_COUNT]    # as the input node had it
         assert info["NumPods"] == sum(len(b["PodList"] or []) for b in info["DevsBrief"].values())
 
 
@@ -235,3 +236,12 @@ def test_config5_subset_ids_and_group_fetch():
         g.run_loaded(True, want_gpu_slices=True)
         for s in (0, 3, 5):
             assert (g.fetch_gpu_slices(s) == ref.gpu_slices[s]).all()
+
+
+@pytest.mark.parametrize("text,ids", [("1", [1]), ("0-0-1", [0, 0, 1]), ("+2", [2]), ("00-1", [0, 1]), (" 1", None), ("1_0", None),
+                                      ("١", None), ("1-", None), ("", None), ("99999999999999999999", None)])
+def test_gpu_index_annotation_parses_like_strconv_atoi(text, ids):
+    """GpuIdStrToIntList (pkg/type/open-gpu-share/utils/pod.go:100-115) splits on '-' and runs strconv.Atoi on each part: one optional
+    sign + ASCII digits, int64 range.  Forms Python's int() would take (' 1', '1_0', Unicode digits) are INVALID in the reference --
+    it logs a warning and allocates normally (gpunodeinfo.go:247-253)."""
+    assert fl.gpu_index_annotation({"metadata": {"annotations": {k8s.GPU_INDEX: text}}}) == ids

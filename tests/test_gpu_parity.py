@@ -666,13 +666,14 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
-    env = dict(os.environ, SIMON_BENCH_BACKEND="gloo", SIMON_BENCH_SHARE_DEVICE="1")
+    env = dict(os.environ, SIMON_BENCH_BACKEND="gloo", SIMON_BENCH_SHARE_DEVICE="1", SIMON_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--counts", "32", "--pods", "2000", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    line = out.stdout.strip().splitlines()[-1]                    # the LAST line is the record the driver parses
+    assert len(line) <= 4096
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
     assert d["config"]["scenarios_per_gpu"] == 32 * 4 and d["value"] > 0

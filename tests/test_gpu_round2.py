@@ -3,6 +3,7 @@ scenarios, config 4's shuffled orders), the multi-device / multi-rank entry poin
 import json
 import os
 import subprocess
+import tempfile
 import sys
 import threading
 
@@ -235,11 +236,26 @@ def test_explain_loaded_uses_the_scenarios_own_ranks():
 
 
 # ---- bench.py ---------------------------------------------------------------------------------------------------
-def _bench(args, env=None, timeout=900):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=dict(os.environ, **(env or {})),
+def _bench(args, env=None, timeout=900, detail=None):
+    """Runs bench.py; returns (process, FULL record).  The full record lives in the sidecar the compact last line names; the last
+    line itself -- what the driver parses -- must be one JSON object of at most 4 KB that carries the contract's keys."""
+    detail = detail or os.path.join(tempfile.mkdtemp(prefix="simon_bench_"), "bench_detail.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=dict(os.environ, SIMON_BENCH_DETAIL=detail, **(env or {})),
                          capture_output=True, text=True, timeout=timeout)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    return out, (json.loads(lines[-1]) if lines else None)
+    lines = out.stdout.strip().splitlines()
+    if out.returncode != 0 or not lines or not lines[-1].startswith("{"):
+        return out, None
+    assert len(lines[-1]) <= 4096, f"final bench line: {len(lines[-1])} bytes"
+    line = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "parity_sample", "detail"):
+        assert k in line, k
+    assert "workload" in line["config"] and line["detail"] == detail
+    with open(detail) as f:
+        full = json.load(f)
+    assert full["value"] == line["value"] and full["config"]["workload"] == line["config"]["workload"]
+    full["_line"] = line
+    return out, full
 
 
 def test_bench_gpus_flag_spawns_the_ranks_itself():
@@ -247,10 +263,13 @@ def test_bench_gpus_flag_spawns_the_ranks_itself():
     one).  On a single-GPU box the ranks share device 0 over gloo (SIMON_BENCH_SHARE_DEVICE=1, test hook)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["SIMON_BENCH_SHARE_DEVICE"] = "1"
+    env["SIMON_BENCH_DETAIL"] = os.path.join(tempfile.mkdtemp(prefix="simon_bench_"), "bench_detail.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--counts", "32",
                           "--pods", "2000"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["backend"] == "gloo" and line["ranks"]["one_device_test_hook"] is True
+    d = json.load(open(env["SIMON_BENCH_DETAIL"]))
     assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
     assert "self-spawned" in d["ranks"]["launched_by"]
     # the multi-rank self-check: what the ranks saw (the hook is stated, so a one-device run cannot pass for a multi-GPU one)
@@ -298,6 +317,14 @@ def test_bench_line_is_self_verifying():
     assert d["other_workloads"][4]["kernel_generation"] == 7 and d["other_workloads"][4]["scenarios"] == 4096
     assert d["other_workloads"][5]["kernel_generation"] == 6 and d["other_workloads"][6]["scenarios"] == 2048
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    for w in d["other_workloads"]:
+        assert w["steps"] >= 5, w["workload"]                     # every sub-record times at least five steps
+    # what the DRIVER reads: the compact last line (size asserted in _bench) with the headline roofline, the CPU baseline and a digest
+    line = d["_line"]
+    assert line["roofline"]["kernel"] == "simon::table_kernel" and line["roofline"]["kernel_ms"] > 0 and "frac" in line["roofline"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    assert line["parity_sample"]["mismatches"] == 0
+    assert [r[0] for r in line["digest"]["rows"]] == names and all(r[-1] == 0 for r in line["digest"]["rows"])
 
 
 def test_bench_group_mode_one_process_two_members():

@@ -127,3 +127,32 @@ def test_cabi_fixtures_are_regenerated_byte_for_byte(tmp_path, monkeypatch):
     for name in ("cabi_kav.bin", "cabi_config2_sweep.bin", "cabi_features.bin"):
         assert open(tmp_path / name, "rb").read() == open(os.path.join(root, "tests", "golden", name), "rb").read(), name
     assert open(tmp_path / "cabi_features.bin", "rb").read()[:8] == b"SIMONFX2"
+
+
+def test_bench_final_line_fits_the_driver(capsys, tmp_path, monkeypatch):
+    """The driver keeps the last ~8 KB of bench.py's stdout and parses the LAST line.  Round 3's record (24.8 KB on one line, committed
+    as profiles/r03/r03f_bench_default.json) lost its head that way: `parsed` was null.  bench.emit() must put the full record into the
+    sidecar + `#detail` lines and end with ONE compact JSON line that still carries the contract's keys, `roofline`, `cpu_baseline`,
+    `parity_sample` and one digest row per other workload -- also when many more sub-records are added."""
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r03", "r03f_bench_default.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    full["other_workloads"] = full["other_workloads"] * 3                      # 21 sub-records: the line must still fit
+    side = tmp_path / "bench_detail.json"
+    monkeypatch.setenv("SIMON_BENCH_DETAIL", str(side))
+    bench.emit(full)
+    lines = capsys.readouterr().out.strip().splitlines()
+    last = lines[-1]
+    assert len(last) <= bench.LINE_BUDGET <= 3072 and all(l.startswith("#detail ") for l in lines[:-1])
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert d[k] == full[k], k
+    assert d["config"]["workload"] == full["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] == "valu_issue" and r["frac"] == full["roofline"]["frac"] and r["kernel_ms"] == full["roofline"]["kernel_ms"]
+    assert r["traffic"] == full["roofline"]["traffic"] and r["achieved"] and r["peak"] and r["unit"] and r["counters"] == "live"
+    assert d["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 16
+    assert d["parity_sample"] == {"scenarios": 2376, "placement_rows": 2376, "mismatches": 0}
+    assert len(d["digest"]["rows"]) == 21 and d["digest"]["rows"][0][0] == "config2" and len(d["digest"]["cols"]) == len(d["digest"]["rows"][0])
+    assert json.load(open(side)) == full                                         # nothing is lost: the sidecar holds the whole record
