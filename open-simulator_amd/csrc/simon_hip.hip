@@ -138,6 +138,9 @@ struct simon_ctx : simon::HostInputs {
     std::vector<int32_t> ipa_h_term, ipa_h_w;     // [Cp] the hostname-like term of a class's raw score (-1: none) and its coefficient
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
+    // team mode of generation 7 (simon_table.hip: NW waves per scenario): env SIMON_TEAM = 0 never / 1 always / unset: batches of at
+    // most team_max_s scenarios (default 2 per CU: beyond that one wave per scenario fills the SIMDs by itself; env SIMON_TEAM_MAX_S)
+    int team_mode = -1, team_max_s = -1;
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
     std::vector<int> sp_set_eff;                  // per id: the node set its row is counted on (-1: every node)
     std::vector<int> sp_rep;                      // per term: the first term with the same key, node set and matching classes (they share a counter row)
@@ -1186,6 +1189,8 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_hard_fold = getenv("SIMON_NO_HARD_FOLD") != nullptr;        // A/B + tests: hard spread constraints always on the all-feature kernel
     c->no_ipa_fold = getenv("SIMON_NO_IPA_FOLD") != nullptr;          // A/B + tests: preferred pod (anti-)affinity always on the all-feature kernel
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
+    if (const char* e = getenv("SIMON_TEAM")) c->team_mode = atoi(e) != 0;
+    if (const char* e = getenv("SIMON_TEAM_MAX_S")) c->team_max_s = atoi(e);
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
@@ -1609,7 +1614,15 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        const size_t table_lds = c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0)) : -1) + c->lds_pad : 0;
+        // team mode: a small batch of a problem with soft spread constraints gets kTeamWaves waves per scenario (the walks of
+        // spread_select and the prologue are split; LDS: + one score table + the exchange slots)
+        const int team_max = c->team_max_s >= 0 ? c->team_max_s : 2 * c->n_cus;
+        int team = (c->spread && c->table_coarse && !c->rest && c->n_sigs <= 128 && (c->team_mode == 1 || (c->team_mode < 0 && S <= team_max))) ? kTeamWaves : 1;
+        auto lds_for = [&](int tm) -> size_t {
+            return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0)) : -1) + c->lds_pad : 0;
+        };
+        if (team > 1 && lds_for(team) > 64 * 1024) team = 1;           // (its extra table does not fit: the single-wave shape still may)
+        const size_t table_lds = lds_for(team);
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
@@ -1651,7 +1664,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty();
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty(); f.team = team;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && (c->ipa_fold || c->hard_fold)) ? 64 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -1672,7 +1685,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                             acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[18] / S / P, acc[19] / S / P);
             }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
-            T = 64; slots = (ni_top / (c->table_coarse ? 64 : 16) + 63) / 64; lds = table_lds;
+            T = 64 * team; slots = (ni_top / (c->table_coarse ? 64 : 16) + 63) / 64; lds = table_lds;
             c->stats.n_launches = 1;
             table_used = true;
         } else if (c->fast_ok && !c->force_v1 && T >= 128) {

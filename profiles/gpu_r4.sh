@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-4 GPU stages (ONE launcher; a stage per argument).  usage: bash profiles/gpu_r4.sh <tag> <stage> [<stage> ...]
+#   team_tests  tests/test_gpu_round4.py + the generation-7 tests of round 3
+#   fuzz_spread tests/fuzz_spread.py (both shapes per case), N cases (env FUZZ_N, default 300)
+#   team_ab     profiles/team_ab.py (one wave against a team of waves over the batch size) + the typical cluster x 64 sizes on both shapes
+#   all_tests   every GPU test + smoke
+#   bench       the default bench line (what the driver runs) + its sidecar
+#   rocprof     rocprofv3 --kernel-trace --stats of the default bench command (no PMC in the same run)
+set -u
+TAG=$1; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
+for STAGE in "$@"; do
+  t0=$(date +%s)
+  case $STAGE in
+    team_tests)
+      ( timeout 1500 python -m pytest tests/test_gpu_round4.py tests/test_gpu_round3.py -m gpu -q -x -k "team or shape or spread or service or generation_7 or fuzz" 2>&1 | tail -15 ) > "$OUT/pytest_team.log"; tail -3 "$OUT/pytest_team.log" ;;
+    fuzz_spread)
+      ( timeout 1500 python tests/fuzz_spread.py ${FUZZ_N:-300} ${FUZZ_FIRST:-20000} 2>&1 | tail -20 ) > "$OUT/fuzz_spread.log"; tail -2 "$OUT/fuzz_spread.log" ;;
+    team_ab)
+      ( timeout 900 python profiles/team_ab.py 2>&1 | tail -12 ) > "$OUT/team_ab_service.txt"; cat "$OUT/team_ab_service.txt"
+      ( timeout 600 python profiles/team_ab.py --pref 60 --sizes 16,64,256 2>&1 | tail -6 ) > "$OUT/team_ab_service_pref.txt"; cat "$OUT/team_ab_service_pref.txt"
+      for T in 0 1; do ( SIMON_TEAM=$T timeout 600 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | tail -1 ) > "$OUT/typical_x64_team$T.txt"; cat "$OUT/typical_x64_team$T.txt"; done ;;
+    all_tests)
+      ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > "$OUT/pytest_gpu.log"; tail -2 "$OUT/pytest_gpu.log"
+      ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ) > "$OUT/smoke.log"; tail -1 "$OUT/smoke.log" ;;
+    bench)
+      SIMON_BENCH_DETAIL=$OUT/bench_detail.json timeout 1500 python bench.py > "$OUT/bench_default.out" 2> "$OUT/bench_default.err"; echo "bench rc=$?"
+      tail -1 "$OUT/bench_default.out" > "$OUT/bench_default.json"; wc -c "$OUT/bench_default.json"; cat "$OUT/bench_default.json" ;;
+    rocprof)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/rocprof" -o bench -- python $OLDPWD/bench.py --no-sub --pmc off --no-cpu-baseline --steps 5 > "$OUT/rocprof_bench.out" 2>&1 ); ls "$OUT/rocprof" | head ;;
+    *) echo "unknown stage $STAGE" ;;
+  esac
+  echo "[$STAGE] $(( $(date +%s) - t0 )) s"
+done

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Same-box A/B of the two shapes of generation 7 (simon_table.hip): one wave per scenario (SIMON_TEAM=0) against a team of
+kTeamWaves waves (SIMON_TEAM=1), over the batch size -- kernel milliseconds (HIP events, best of 3 after a warm-up).  Workloads:
+config 3's pool with every pod behind a Service (synth.config_service; optionally with preferred self anti-affinity), at
+S = 4 x counts scenarios.  Needs a GPU:  python profiles/team_ab.py [--pref 60] [--sizes 4,16,64,128,256,512]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from open_simulator_amd import capi, synth  # noqa: E402
+
+
+def kernel_ms(prob, scen, orders, team):
+    os.environ["SIMON_TEAM"] = team
+    try:
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ms = []
+            for _ in range(4):
+                ctx.run_loaded(True)
+                ms.append(ctx.stats().kernel_ms)
+            st = ctx.stats()
+            res = ctx.fetch(False)
+        return min(ms[1:]), st.workgroup_size, st.kernel_generation, res
+    finally:
+        os.environ.pop("SIMON_TEAM", None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pref", type=int, default=0)
+    ap.add_argument("--sizes", default="4,16,64,128,256,512,1024")
+    a = ap.parse_args()
+    for counts in [int(x) for x in a.sizes.split(",")]:
+        prob, scen, orders = synth.config_service(n_counts=counts, n_orders=4, n_pref=a.pref)
+        if counts < 4:
+            scen = scen[:counts]
+        one, wg1, g1, r1 = kernel_ms(prob, scen, orders, "0")
+        team, wg4, g4, r4 = kernel_ms(prob, scen, orders, "1")
+        same = bool((r1.unscheduled == r4.unscheduled).all() and (r1.used_cpu == r4.used_cpu).all())
+        print(json.dumps({"workload": f"config3_service{'_pref%d' % a.pref if a.pref else ''}", "scenarios": len(scen), "pods": int(prob.n_pods),
+                          "one_wave_ms": round(one, 3), "team_ms": round(team, 3), "speedup": round(one / team, 3),
+                          "workgroup": [wg1, wg4], "generation": [g1, g4], "same_counts": same}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of generation 7 (soft PodTopologySpread constraints on the score-table kernel): random sizes, feature
-subsets, scenario batches and (every fourth case) per-scenario node ranks; every placement, unscheduled count and used cpu / memory against the oracle.
+subsets, scenario batches and (every fourth case) per-scenario node ranks, each case on the single-wave AND the team shape; every placement, unscheduled count and used cpu / memory against the oracle.
 Not collected by pytest; by hand on a GPU box:   python tests/fuzz_spread.py [n_cases] [first_seed]"""
 import os
 import sys
@@ -33,32 +33,40 @@ def one_case(case):
         for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
             ranks[s_, :n] = rng.permutation(n)
     ref = O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run_threaded(prob, scen, orders)
-    with capi.Context(0) as ctx:
-        ctx.load_problem(prob)
-        if ranks is None:
-            res = ctx.run_batch(scen, orders)
-        else:
-            ctx.load_scenarios(scen, orders)
-            ctx.set_node_ranks(ranks)
-            ctx.run_loaded(True)
-            res = ctx.fetch(True)
-        st = ctx.stats()
-    ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
-          res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
-    return ok, dict(case=case, N=N, P=P, S=len(scen), feat=sorted(feat), generation=st.kernel_generation, variant=st.kernel_variant)
+    ok, teams = True, 0
+    for team in ("0", "1"):                             # one wave per scenario, then the team shape (simon_table.hip: NW waves per scenario)
+        os.environ["SIMON_TEAM"] = team
+        try:
+            with capi.Context(0) as ctx:
+                ctx.load_problem(prob)
+                if ranks is None:
+                    res = ctx.run_batch(scen, orders)
+                else:
+                    ctx.load_scenarios(scen, orders)
+                    ctx.set_node_ranks(ranks)
+                    ctx.run_loaded(True)
+                    res = ctx.fetch(True)
+                st = ctx.stats()
+        finally:
+            os.environ.pop("SIMON_TEAM", None)
+        teams += st.workgroup_size > 64 and st.kernel_generation == 7
+        ok = ok and (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
+                     res.used_mem.tolist() == ref.used_mem.tolist() and bool((res.placement == ref.placement).all()))
+    return ok, dict(case=case, N=N, P=P, S=len(scen), feat=sorted(feat), generation=st.kernel_generation, variant=st.kernel_variant, team=teams)
 
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad = on7 = 0
+    bad = on7 = teams = 0
     for case in range(first, first + n_cases):
         ok, info = one_case(case)
         on7 += info["generation"] == 7
+        teams += info["team"]
         if not ok:
             bad += 1
             print("MISMATCH", info, flush=True)
-    print(f"fuzz_spread: {n_cases} cases from {first}, {on7} on generation 7, mismatches {bad}")
+    print(f"fuzz_spread: {n_cases} cases from {first} (each with one wave and with a team of waves per scenario), {on7} on generation 7, {teams} of them also in team mode, mismatches {bad}")
     return 1 if bad else 0
 
 

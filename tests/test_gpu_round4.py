@@ -1,0 +1,127 @@
+"""GPU parity tests, round 4: team mode of generation 7 (simon_table.hip: NW waves per scenario for batches too small to fill the
+chip with one wave each) -- every placement against the oracle on BOTH shapes of the same problem, the shapes' own edge cases
+(fewer units than waves, one unit, per-scenario node ranks), the automatic choice by batch size, and the randomised sweep."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import randprob
+from open_simulator_amd import capi, synth
+from test_gpu_parity import assert_same
+from test_gpu_round3 import SPREAD_FEATURES
+
+pytestmark = pytest.mark.gpu
+TEAM_THREADS = 256                       # 64 x kTeamWaves (csrc/simon_table.h)
+
+
+def run_shape(prob, scen, orders, team, ranks=None, monkeypatch=None):
+    """One context under SIMON_TEAM = team ("0": one wave per scenario, "1": the team shape, None: the library chooses)."""
+    if team is None:
+        monkeypatch.delenv("SIMON_TEAM", raising=False)
+    else:
+        monkeypatch.setenv("SIMON_TEAM", team)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        if ranks is not None:
+            ctx.set_node_ranks(ranks)
+        ctx.run_loaded(True)
+        return ctx.fetch(True), ctx.stats()
+
+
+@pytest.mark.parametrize("idx", range(len(SPREAD_FEATURES)))
+def test_team_mode_matches_the_oracle_on_soft_spread_problems(idx, monkeypatch):
+    """The problems of round 3's generation-7 test on both shapes: workgroup 64 (one wave per scenario) and 256 (a team of four);
+    the oracle decides, not the other shape."""
+    feat = SPREAD_FEATURES[idx]
+    for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500)]):
+        prob = randprob.rand_problem(7000 + 10 * idx + seed, N=N, P=P, spread_soft=True, n_node_classes=4, n_pod_classes=9, **feat)
+        scen, orders = randprob.rand_scenarios(70 + seed, prob, S=5)
+        ref = O.run_threaded(prob, scen, orders)
+        for team, threads in (("0", 64), ("1", TEAM_THREADS)):
+            res, st = run_shape(prob, scen, orders, team, monkeypatch=monkeypatch)
+            if "odd_units" not in feat:
+                assert st.kernel_generation == 7 and st.workgroup_size == threads, (team, st.kernel_generation, st.workgroup_size)
+            assert_same(res, ref)
+
+
+@pytest.mark.parametrize("feat", [dict(anti_host=True), dict(ipa_self=True), dict(ipa=True, ipa_self=True), dict(hard_simple=True),
+                                  dict(hard_simple=True, ipa_self=True, anti_host=True, pins=True)])
+def test_team_mode_with_the_folds_and_the_second_score_table(feat, monkeypatch):
+    """Required hostname anti-affinity (the fold), preferred pod (anti-)affinity (SPREAD && AFF instantiations: the InterPodAffinity
+    extremes travel through the team's exchange slots too) and hard zone constraints (a class verdict every wave derives alike)."""
+    for seed, (N, P) in enumerate([(60, 400), (500, 1200), (1500, 2200)]):
+        prob = randprob.rand_problem(8100 + seed, N=N, P=P, spread_soft=True, n_node_classes=3, n_pod_classes=7, **feat)
+        scen, orders = randprob.rand_scenarios(81 + seed, prob, S=4)
+        ref = O.run_threaded(prob, scen, orders)
+        for team in ("0", "1"):
+            res, st = run_shape(prob, scen, orders, team, monkeypatch=monkeypatch)
+            if st.kernel_generation == 7:
+                assert st.workgroup_size == (TEAM_THREADS if team == "1" else 64)
+            assert_same(res, ref)
+
+
+@pytest.mark.parametrize("n_classes,N", [(1, 30), (1, 64), (1, 100), (2, 90), (3, 200)])
+def test_team_mode_with_fewer_units_than_waves(n_classes, N, monkeypatch):
+    """A scenario of u < 4 units of 64 positions leaves waves without a share (their extremes and best key must be neutral); scenario
+    sizes from 1 node on, so that the same batch mixes 1-, 2- and 3-unit scenarios."""
+    prob = randprob.rand_problem(8200 + N, N=N, P=400, spread_soft=True, n_node_classes=n_classes, n_pod_classes=5)
+    scen, orders = randprob.rand_scenarios(82, prob, S=6, min_n=1)
+    ref = O.run_threaded(prob, scen, orders)
+    res, st = run_shape(prob, scen, orders, "1", monkeypatch=monkeypatch)
+    assert st.kernel_generation == 7 and st.workgroup_size == TEAM_THREADS
+    assert_same(res, ref)
+
+
+def test_team_mode_with_per_scenario_node_ranks(monkeypatch):
+    """simon_set_node_ranks: ties follow the scenario's own order (g_canon is filled by whichever wave owns the chunk in the prologue)."""
+    rng = np.random.default_rng(83)
+    prob = randprob.rand_problem(8300, N=600, P=1500, spread_soft=True, n_node_classes=4, n_pod_classes=6)
+    scen, orders = randprob.rand_scenarios(83, prob, S=4)
+    ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+    for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
+        ranks[s_, :n] = rng.permutation(n)
+    ref = O.run(prob, scen, orders, node_ranks=ranks)
+    for team in ("0", "1"):
+        res, st = run_shape(prob, scen, orders, team, ranks=ranks, monkeypatch=monkeypatch)
+        assert st.kernel_generation == 7 and st.workgroup_size == (TEAM_THREADS if team == "1" else 64)
+        assert_same(res, ref)
+
+
+def test_the_library_picks_the_shape_by_batch_size(monkeypatch):
+    """Unset SIMON_TEAM: a batch of at most two scenarios per CU runs as teams, a larger one as single waves (the throughput shape the
+    bench times at 4 096 scenarios must not change); both against the oracle on a sample."""
+    prob, scen, orders = synth.config_service(n_counts=256, n_orders=4, n_pods=1200, n_het=200, n_services=12)
+    assert len(scen) == 1024
+    pick = np.unique(np.linspace(0, len(scen) - 1, 24).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    res, st = run_shape(prob, scen, orders, None, monkeypatch=monkeypatch)
+    assert st.kernel_generation == 7 and st.workgroup_size == 64
+    assert (res.placement[pick] == ref.placement).all() and res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
+    res2, st2 = run_shape(prob, scen[pick], orders, None, monkeypatch=monkeypatch)
+    assert st2.kernel_generation == 7 and st2.workgroup_size == TEAM_THREADS
+    assert_same(res2, ref)
+    monkeypatch.setenv("SIMON_TEAM_MAX_S", "8")                       # the threshold is a knob
+    res3, st3 = run_shape(prob, scen[pick], orders, None, monkeypatch=monkeypatch)
+    assert st3.workgroup_size == 64
+    assert_same(res3, ref)
+
+
+def test_service_workload_full_size_in_team_mode(monkeypatch):
+    """config 3's pool with every pod behind a Service at FULL size (10 000 pods x 488..1 511 nodes), 24 scenarios = the shape a real
+    `simon apply` offers: the team shape, every placement against the oracle."""
+    prob, scen, orders = synth.config_service()
+    pick = np.unique(np.linspace(0, len(scen) - 1, 24).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    res, st = run_shape(prob, scen[pick], orders, None, monkeypatch=monkeypatch)
+    assert st.kernel_generation == 7 and st.workgroup_size == TEAM_THREADS
+    assert_same(res, ref)
+
+
+def test_fuzz_spread_slice_on_both_shapes():
+    """A slice of tests/fuzz_spread.py (each case runs on both shapes); the sweep itself runs by hand at scale (profiles/r04)."""
+    import fuzz_spread
+    bad = [info for ok, info in (fuzz_spread.one_case(c) for c in range(5000, 5024)) if not ok]
+    assert not bad, bad
