@@ -189,7 +189,7 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.tab = o; o += nzk >= 0 ? kSpreadTabMax * 4 : 0;
     c.tabi = o; o += ipa ? kSpreadTabMax * 4 : 0;
     c.tab2 = o; o += team ? kSpreadTabMax * 4 : 0;
-    c.xch = o; o += team ? 256 : 0;
+    c.xch = o; o += team ? kTeamWavesMax * 6 * 4 : 0;
     c.total = o;
     return c;
 }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     int* s_tabi = (int*)(smem + cv.tabi);                           // SPREAD (problems with preferred pod (anti-)affinity): [class << lg | count] InterPodAffinity raw score
     int* s_tab = (int*)(smem + cv.tab);                             // SPREAD: [class << lg | count] raw score, then class term + 2 x score
     int* s_tot = NW > 1 ? (int*)(smem + cv.tab2) : s_tab;          // ... team mode: the totals get a table of their own (every wave writes all of it)
-    int* s_xch = (int*)(smem + cv.xch);                             // team mode: [NW][4] extremes of pass 1, [16 + 2 w] best key / position of pass 2
+    int* s_xch = (int*)(smem + cv.xch);                             // team mode: [NW][4] extremes of pass 1, then [NW][2] best key / position of pass 2
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         // or zone-like constraints alone (their sum is a per-class value): raw = int64((count * w + c) + zone_term(class)).
         const bool simple = nh == 0 || (nh == 1 && eh == 0 && soft_n <= 2);
         const unsigned toff = (unsigned)k * KS + (unsigned)lane;         // this lane's byte of a unit's row of signature k ([unit][K][64])
-        constexpr int SB = kSpreadBatch1, SC = kSpreadBatch2, SG = kSpreadBatch4;
+        // (team mode: no register budget to keep -- a wave's share of the units in as few batches of loads as its size suggests)
+        constexpr int SB = NW == 1 ? kSpreadBatch1 : NW == 4 ? 10 : NW == 8 ? 8 : 6, SC = NW == 1 ? kSpreadBatch2 : SB, SG = NW == 1 ? kSpreadBatch4 : 4;
         // the first loads of the walk go out before the class bookkeeping below waits for its own (memory is served in order)
         const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
         unsigned czv[4];
@@ -1312,13 +1313,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         } else {                                                          // the team's best: keys carry the canonical index, so the maximum is one node
             const int wl = best != 0u ? __builtin_ctzll(__ballot(bkey == best)) : 0;
             const int pw = __builtin_amdgcn_readlane(bpos, wl);
-            if (lane == 0) { s_xch[16 + 2 * wv] = (int)best; s_xch[17 + 2 * wv] = pw; }
+            if (lane == 0) { s_xch[4 * NW + 2 * wv] = (int)best; s_xch[4 * NW + 2 * wv + 1] = pw; }
             __syncthreads();
             best = 0u; pstar = -1;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                const unsigned kw = (unsigned)s_xch[16 + 2 * w];
-                const int pq = s_xch[17 + 2 * w];
+                const unsigned kw = (unsigned)s_xch[4 * NW + 2 * w];
+                const int pq = s_xch[4 * NW + 2 * w + 1];
                 if (kw > best) { best = kw; pstar = pq; }
             }
             pstar = __builtin_amdgcn_readfirstlane(pstar);
@@ -1769,14 +1770,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 }
 
 #ifdef SIMON_TABLE_TEAM_TU
-// ---- this translation unit (simon_table_team.hip) holds the team-mode instantiations only: NW = kTeamWaves waves per scenario ----
+// ---- this translation unit (simon_table_team<N>.hip) holds the team-mode instantiations only: NW = SIMON_TABLE_TEAM_TU waves per scenario ----
+constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
+#define SIMON_TEAM_CAT2(a, b) a##b
+#define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
 template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTeamWaves>;
+    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTuWaves>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * kTeamWaves), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * kTuWaves), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
     return hipGetLastError();
 }
 template <bool M, bool Z, int KQ, int NBQ>
@@ -1791,8 +1795,8 @@ static hipError_t launch_team2(const TableLaunch& a, int n_blocks, size_t lds, h
     if (a.sc.K > 64) return one ? launch_team4<M, Z, 2, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 2, 2>(a, n_blocks, lds, st);
     return one ? launch_team4<M, Z, 1, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 1, 2>(a, n_blocks, lds, st);
 }
-hipError_t launch_table_team(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.coarse || a.rest || a.team != kTeamWaves) return hipErrorInvalidValue;
+hipError_t SIMON_TEAM_CAT(launch_table_team, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.spread || !a.coarse || a.rest || a.team != kTuWaves) return hipErrorInvalidValue;
     if (has_mask) return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_team2<false, true>(a, n_blocks, lds_bytes, st) : launch_team2<false, false>(a, n_blocks, lds_bytes, st);
 }
@@ -1884,7 +1888,10 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 }
 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
-    if (a.team > 1) return launch_table_team(a, n_blocks, has_mask, nzeq, lds_bytes, st);   // several waves per scenario: simon_table_team.hip
+    if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
+        return a.team == 4 ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st)
+             : a.team == 8 ? launch_table_team8(a, n_blocks, has_mask, nzeq, lds_bytes, st)
+             : a.team == 16 ? launch_table_team16(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
     has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & 32);   // (& 32: the fold, carried by COARSE && !REST && HAS_PIN)
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);

@@ -20,7 +20,8 @@ for STAGE in "$@"; do
     team_ab)
       ( timeout 900 python profiles/team_ab.py 2>&1 | tail -12 ) > "$OUT/team_ab_service.txt"; cat "$OUT/team_ab_service.txt"
       ( timeout 600 python profiles/team_ab.py --pref 60 --sizes 16,64,256 2>&1 | tail -6 ) > "$OUT/team_ab_service_pref.txt"; cat "$OUT/team_ab_service_pref.txt"
-      for T in 0 1; do ( SIMON_TEAM=$T timeout 600 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | tail -1 ) > "$OUT/typical_x64_team$T.txt"; cat "$OUT/typical_x64_team$T.txt"; done ;;
+      for T in 0 4 8 16; do ( SIMON_TEAM=$T timeout 600 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | tail -1 ) > "$OUT/typical_x64_team$T.txt"; cat "$OUT/typical_x64_team$T.txt"; done
+      for C in 8 256; do ( timeout 600 python profiles/e2e_sweep.py --typical --counts $C 2>&1 | tail -1 ) > "$OUT/typical_x${C}_auto.txt"; cat "$OUT/typical_x${C}_auto.txt"; done ;;
     all_tests)
       ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > "$OUT/pytest_gpu.log"; tail -2 "$OUT/pytest_gpu.log"
       ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ) > "$OUT/smoke.log"; tail -1 "$OUT/smoke.log" ;;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of the two shapes of generation 7 (simon_table.hip): one wave per scenario (SIMON_TEAM=0) against a team of
-kTeamWaves waves (SIMON_TEAM=1), over the batch size -- kernel milliseconds (HIP events, best of 3 after a warm-up).  Workloads:
+4 / 8 / 16 waves (SIMON_TEAM=4|8|16), and the width the library picks (unset), over the batch size -- kernel milliseconds (HIP events, best of 3 after a warm-up).  Workloads:
 config 3's pool with every pod behind a Service (synth.config_service; optionally with preferred self anti-affinity), at
 S = 4 x counts scenarios.  Needs a GPU:  python profiles/team_ab.py [--pref 60] [--sizes 4,16,64,128,256,512]"""
 import argparse
@@ -14,7 +14,8 @@ from open_simulator_amd import capi, synth  # noqa: E402
 
 
 def kernel_ms(prob, scen, orders, team):
-    os.environ["SIMON_TEAM"] = team
+    if team is not None:
+        os.environ["SIMON_TEAM"] = team
     try:
         with capi.Context(0) as ctx:
             ctx.load_problem(prob)
@@ -40,11 +41,17 @@ def main():
         if counts < 4:
             scen = scen[:counts]
         one, wg1, g1, r1 = kernel_ms(prob, scen, orders, "0")
-        team, wg4, g4, r4 = kernel_ms(prob, scen, orders, "1")
-        same = bool((r1.unscheduled == r4.unscheduled).all() and (r1.used_cpu == r4.used_cpu).all())
-        print(json.dumps({"workload": f"config3_service{'_pref%d' % a.pref if a.pref else ''}", "scenarios": len(scen), "pods": int(prob.n_pods),
-                          "one_wave_ms": round(one, 3), "team_ms": round(team, 3), "speedup": round(one / team, 3),
-                          "workgroup": [wg1, wg4], "generation": [g1, g4], "same_counts": same}), flush=True)
+        row = {"workload": f"config3_service{'_pref%d' % a.pref if a.pref else ''}", "scenarios": len(scen), "pods": int(prob.n_pods), "one_wave_ms": round(one, 3)}
+        same = True
+        for w in ("4", "8", "16"):
+            if len(scen) * int(w) > 16384:              # (more waves than the chip holds at once: not a shape anyone would pick)
+                continue
+            ms, wg, g, r = kernel_ms(prob, scen, orders, w)
+            row[f"team{w}_ms"] = round(ms, 3)
+            same = same and wg == 64 * int(w) and g == g1 and bool((r1.unscheduled == r.unscheduled).all() and (r1.used_cpu == r.used_cpu).all())
+        ms, wg, g, r = kernel_ms(prob, scen, orders, None)
+        row.update({"auto_ms": round(ms, 3), "auto_workgroup": wg, "speedup_auto": round(one / ms, 3), "same_counts": same})
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":

@@ -13,11 +13,13 @@ from test_gpu_parity import assert_same
 from test_gpu_round3 import SPREAD_FEATURES
 
 pytestmark = pytest.mark.gpu
-TEAM_THREADS = 256                       # 64 x kTeamWaves (csrc/simon_table.h)
+TEAM_THREADS = (256, 512, 1024)          # 64 x {4, 8, 16} waves per scenario (csrc/simon_table.h); SIMON_TEAM=1 lets the library pick the width
+SHAPES = (("0", (64,)), ("4", (256,)), ("8", (512,)), ("16", (1024,)))
 
 
 def run_shape(prob, scen, orders, team, ranks=None, monkeypatch=None):
-    """One context under SIMON_TEAM = team ("0": one wave per scenario, "1": the team shape, None: the library chooses)."""
+    """One context under SIMON_TEAM = team ("0": one wave per scenario, "1": a team, width by batch size, "4" / "8" / "16": that width,
+    None: the library chooses)."""
     if team is None:
         monkeypatch.delenv("SIMON_TEAM", raising=False)
     else:
@@ -33,17 +35,17 @@ def run_shape(prob, scen, orders, team, ranks=None, monkeypatch=None):
 
 @pytest.mark.parametrize("idx", range(len(SPREAD_FEATURES)))
 def test_team_mode_matches_the_oracle_on_soft_spread_problems(idx, monkeypatch):
-    """The problems of round 3's generation-7 test on both shapes: workgroup 64 (one wave per scenario) and 256 (a team of four);
-    the oracle decides, not the other shape."""
+    """The problems of round 3's generation-7 test on every shape: workgroup 64 (one wave per scenario), 256 / 512 / 1 024 (teams of
+    4 / 8 / 16 waves) and the width the library picks; the oracle decides, not another shape."""
     feat = SPREAD_FEATURES[idx]
     for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500)]):
         prob = randprob.rand_problem(7000 + 10 * idx + seed, N=N, P=P, spread_soft=True, n_node_classes=4, n_pod_classes=9, **feat)
         scen, orders = randprob.rand_scenarios(70 + seed, prob, S=5)
         ref = O.run_threaded(prob, scen, orders)
-        for team, threads in (("0", 64), ("1", TEAM_THREADS)):
+        for team, threads in SHAPES + (("1", TEAM_THREADS),):
             res, st = run_shape(prob, scen, orders, team, monkeypatch=monkeypatch)
             if "odd_units" not in feat:
-                assert st.kernel_generation == 7 and st.workgroup_size == threads, (team, st.kernel_generation, st.workgroup_size)
+                assert st.kernel_generation == 7 and st.workgroup_size in threads, (team, st.kernel_generation, st.workgroup_size)
             assert_same(res, ref)
 
 
@@ -56,23 +58,24 @@ def test_team_mode_with_the_folds_and_the_second_score_table(feat, monkeypatch):
         prob = randprob.rand_problem(8100 + seed, N=N, P=P, spread_soft=True, n_node_classes=3, n_pod_classes=7, **feat)
         scen, orders = randprob.rand_scenarios(81 + seed, prob, S=4)
         ref = O.run_threaded(prob, scen, orders)
-        for team in ("0", "1"):
+        for team, threads in SHAPES:
             res, st = run_shape(prob, scen, orders, team, monkeypatch=monkeypatch)
             if st.kernel_generation == 7:
-                assert st.workgroup_size == (TEAM_THREADS if team == "1" else 64)
+                assert st.workgroup_size in threads
             assert_same(res, ref)
 
 
 @pytest.mark.parametrize("n_classes,N", [(1, 30), (1, 64), (1, 100), (2, 90), (3, 200)])
 def test_team_mode_with_fewer_units_than_waves(n_classes, N, monkeypatch):
-    """A scenario of u < 4 units of 64 positions leaves waves without a share (their extremes and best key must be neutral); scenario
+    """A scenario of fewer units of 64 positions than the team has waves leaves waves without a share (their extremes and best key must be neutral); scenario
     sizes from 1 node on, so that the same batch mixes 1-, 2- and 3-unit scenarios."""
     prob = randprob.rand_problem(8200 + N, N=N, P=400, spread_soft=True, n_node_classes=n_classes, n_pod_classes=5)
     scen, orders = randprob.rand_scenarios(82, prob, S=6, min_n=1)
     ref = O.run_threaded(prob, scen, orders)
-    res, st = run_shape(prob, scen, orders, "1", monkeypatch=monkeypatch)
-    assert st.kernel_generation == 7 and st.workgroup_size == TEAM_THREADS
-    assert_same(res, ref)
+    for team, threads in SHAPES[1:]:
+        res, st = run_shape(prob, scen, orders, team, monkeypatch=monkeypatch)
+        assert st.kernel_generation == 7 and st.workgroup_size in threads
+        assert_same(res, ref)
 
 
 def test_team_mode_with_per_scenario_node_ranks(monkeypatch):
@@ -84,9 +87,9 @@ def test_team_mode_with_per_scenario_node_ranks(monkeypatch):
     for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
         ranks[s_, :n] = rng.permutation(n)
     ref = O.run(prob, scen, orders, node_ranks=ranks)
-    for team in ("0", "1"):
+    for team, threads in SHAPES:
         res, st = run_shape(prob, scen, orders, team, ranks=ranks, monkeypatch=monkeypatch)
-        assert st.kernel_generation == 7 and st.workgroup_size == (TEAM_THREADS if team == "1" else 64)
+        assert st.kernel_generation == 7 and st.workgroup_size in threads
         assert_same(res, ref)
 
 
@@ -101,7 +104,7 @@ def test_the_library_picks_the_shape_by_batch_size(monkeypatch):
     assert st.kernel_generation == 7 and st.workgroup_size == 64
     assert (res.placement[pick] == ref.placement).all() and res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
     res2, st2 = run_shape(prob, scen[pick], orders, None, monkeypatch=monkeypatch)
-    assert st2.kernel_generation == 7 and st2.workgroup_size == TEAM_THREADS
+    assert st2.kernel_generation == 7 and st2.workgroup_size in TEAM_THREADS
     assert_same(res2, ref)
     monkeypatch.setenv("SIMON_TEAM_MAX_S", "8")                       # the threshold is a knob
     res3, st3 = run_shape(prob, scen[pick], orders, None, monkeypatch=monkeypatch)
@@ -116,7 +119,7 @@ def test_service_workload_full_size_in_team_mode(monkeypatch):
     pick = np.unique(np.linspace(0, len(scen) - 1, 24).astype(int))
     ref = O.run_threaded(prob, scen[pick], orders)
     res, st = run_shape(prob, scen[pick], orders, None, monkeypatch=monkeypatch)
-    assert st.kernel_generation == 7 and st.workgroup_size == TEAM_THREADS
+    assert st.kernel_generation == 7 and st.workgroup_size in TEAM_THREADS
     assert_same(res, ref)
 
 
