@@ -56,6 +56,7 @@ KERNEL_NAME = {1: "simon::narrow_kernel", 2: "simon::wide_kernel", 3: "simon::fa
 KERNEL_SHORT = {1: "narrow_v1", 2: "wide (all-feature kernel)", 3: "narrow_fast", 4: "score_table"}
 SERVICE_PREF = 60                 # services of the `config3_service_pref` sub-record whose pods carry preferred self anti-affinity
 SERVICE_ANTI = 20                 # services of the `config3_service_anti` sub-record that also require anti-affinity to their own pods (hostname key)
+SMALL_COUNTS = 16                 # node counts of the `service_small` sub-record (x 4 pod orders = 64 scenarios: what a sweep of candidate sizes looks like)
 SIG_RECORD = 200                  # request signatures of the `config3_sigs` sub-record (beyond the 128 two registers per lane hold; the table takes 384)
 C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
 
@@ -293,15 +294,45 @@ def build_workload(args, synth, world):
         return synth.config2(), 1
     if args.workload == "service":             # config 3's pool and sweep, every pod selected by a Service (system-default soft spread)
         return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, n_anti=args.anti, n_pref=args.pref, n_hard=args.hard), n_orders
+    if args.workload == "typical":             # Kubernetes objects of a typical cluster, 64 candidate sizes (the `simon apply` shape; team mode of generation 7)
+        return synth.typical_cluster_sweep(), 1
+    if args.workload == "widemix":             # the adversarial random object mix: every plugin, 464 node classes -> the all-feature kernel
+        return wide_mix_sweep(), 1
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
         return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
     seed = synth.SEED + (3 if world == 1 else 4)
     return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=seed), n_orders
 
 
+def wide_mix_sweep(n_nodes=2500, new_nodes=2500, n_workloads=400, max_replicas=250, n_counts=64, seed=1):
+    """profiles/e2e_sweep.py's random mix as arrays: tests/randk8s.py objects (required / preferred (anti-)affinity on several keys, hard
+    and soft spread constraints, taints, host ports, node selectors, random pod capacities: 464 node classes) -> workloads.expand ->
+    flatten -> one scenario per candidate number of new nodes.  What lands on the all-feature kernel (simon::wide_kernel)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import randk8s
+    from open_simulator_amd import k8s, simulate as sim
+    nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=n_nodes, n_workloads=n_workloads, max_replicas=max_replicas)
+    for j, n in enumerate(nodes):
+        n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"       # zones round robin by index: every size is a prefix of the pool's nodeTree order
+    ds = [{"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "agent0", "namespace": "kube-system"},
+           "spec": {"selector": {"matchLabels": {"app": "agent0"}},
+                    "template": {"metadata": {"labels": {"app": "agent0"}},
+                                 "spec": {"containers": [{"name": "a", "image": "x", "resources": {"requests": {"cpu": "100m", "memory": "128Mi"}}}],
+                                          "tolerations": [{"operator": "Exists"}]}}}}]
+    cluster = k8s.group_resources(nodes + services + ds)
+    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", randk8s.ZONE: "z0"}},
+                "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "40"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
+    counts = np.unique(np.linspace(0, new_nodes, n_counts).astype(int)).tolist()
+    batch = sim.sweep_batch(cluster, apps, template, counts)
+    return batch.flat.problem, batch.scen, batch.orders
+
+
 def workload_name(args, prob, scen_all, n_orders, S_local, world):
     head = {"config5": "BASELINE config 5-style (gpushare): ", "config2": "BASELINE config 2: ",
             "service": "config 3 with every pod selected by a Service (system-default soft PodTopologySpread constraints): ",
+            "typical": "typical cluster (Kubernetes objects: Deployments behind Services, preferred / required self anti-affinity, hard zone constraints): ",
+            "widemix": "random Kubernetes-object mix with every plugin (all-feature kernel): ",
             "config3sig": f"config 3 variant with {args.sigs} request signatures: "}.get(
                 args.workload, f"BASELINE config {'3' if world == 1 else '4-style'}: ")
     return (head + f"{prob.n_pods} pods x {int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, "
@@ -381,6 +412,18 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config_service(n_pref=SERVICE_PREF)
         child = ["--workload", "service", "--pref", str(SERVICE_PREF)]
         wl, label = "config3", f"config 3 with Service-selected pods that prefer not to sit next to their own kind ({SERVICE_PREF} services, hostname 100 + zone 50)"
+    elif name == "service_small":                   # the `simon apply` shape: 64 candidate scenarios -- generation 7 in team mode (four waves per scenario)
+        prob, scen, orders = synth.config_service(n_counts=SMALL_COUNTS)
+        child = ["--workload", "service", "--counts", str(SMALL_COUNTS)]
+        wl, label = "config3", f"config 3 with Service-selected pods, {4 * SMALL_COUNTS} scenarios"
+    elif name == "typical":                         # Kubernetes objects through the host mirror: 50 707 pods x 2 500..5 000 nodes, 64 candidate sizes
+        prob, scen, orders = synth.typical_cluster_sweep()
+        child = ["--workload", "typical"]
+        wl, label = "config3", "typical cluster, 64 candidate sizes"
+    elif name == "widemix":                         # what the all-feature kernel gets: the adversarial random mix, 64 candidate sizes
+        prob, scen, orders = wide_mix_sweep()
+        child = ["--workload", "widemix"]
+        wl, label = "config5", "random object mix, 64 candidate sizes"
     elif name == "config3sig":                      # config 3 with SIG_RECORD request signatures: the > 128-signature regime as a number
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_RECORD)
         child = ["--workload", "config3sig", "--sigs", str(SIG_RECORD)]
@@ -390,7 +433,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
+    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
                         "config3sig": f"config3_sigs{SIG_RECORD}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
         ctx.load_problem(prob)
@@ -403,6 +446,16 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                     "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                     "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_generation": st.kernel_generation,
                     "kernel_ms": round(k_ms, 3), "workgroup": st.workgroup_size})
+        if st.kernel_generation == 7 and st.workgroup_size > 64:   # team mode: the same batch with ONE wave per scenario, same process (SIMON_TEAM=0)
+            os.environ["SIMON_TEAM"] = "0"
+            try:
+                with capi.Context(device) as ctx1:
+                    ctx1.load_problem(prob)
+                    ctx1.load_scenarios(scen, orders)
+                    _, k1 = time_steps(ctx1, max(2, steps // 2), 1, True, torch.cuda.synchronize)
+            finally:
+                os.environ.pop("SIMON_TEAM", None)
+            rec["team"] = {"waves_per_scenario": st.workgroup_size // 64, "one_wave_kernel_ms": round(k1, 3), "speedup": round(k1 / k_ms, 3)}
         if oracle_k > 0:
             pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=cpu_budget_s, min_k=min(oracle_k, len(scen)), max_k=max(oracle_k, 1))
             rec["cpu_baseline"] = cpu_baseline_record(tm, len(scen), label)
@@ -416,7 +469,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
             source = (f"measured live in this run: rocprofv3 --kernel-trace --pmc, {len(PMC_GROUPS)} separate passes over a 1-step child run of "
                       f"this workload ({time.perf_counter() - t0:.0f} s)")
     rec["roofline"] = roofline_record(kernel_of(st), st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl,
-                                      lds_bytes=st.lds_bytes if st.workgroup_size == 64 else None, scenarios=len(scen))
+                                      lds_bytes=st.lds_bytes if st.kernel_variant == 4 else None, scenarios=len(scen))
     if name == "config5" and c5_scen <= 256:          # what a host that starts from HOST buffers waits for at this size (staging included)
         rec["end_to_end"] = end_to_end(capi, torch, prob, scen, orders, device)
     return rec
@@ -439,16 +492,17 @@ def _short_roofline(r):
     return out
 
 
-DIGEST_COLS = ["name", "scenarios_per_s", "kernel_ms", "generation", "roofline_frac", "hbm_frac", "cpu_scenarios_per_s", "checked", "mismatches"]
+DIGEST_COLS = ["name", "scenarios_per_s", "kernel_ms", "generation", "roofline_frac", "hbm_frac", "cpu_scenarios_per_s", "team_speedup", "checked", "mismatches"]
 
 
 def _digest_row(w):
     """One row per other workload, in DIGEST_COLS order (a list, not a dict: the line has a byte budget)."""
     r = w.get("roofline") or {}
     if "error" in w:
-        return [w.get("workload"), None, None, None, None, None, None, None, "error: " + str(w["error"])[:60]]
+        return [w.get("workload"), None, None, None, None, None, None, None, None, "error: " + str(w["error"])[:60]]
     return [w.get("workload"), w.get("value"), w.get("kernel_ms"), w.get("kernel_generation"), r.get("frac"), r.get("measured_hbm_frac"),
-            (w.get("cpu_baseline") or {}).get("value"), (w.get("parity_sample") or {}).get("scenarios"), (w.get("parity_sample") or {}).get("mismatches")]
+            (w.get("cpu_baseline") or {}).get("value"), (w.get("team") or {}).get("speedup"), (w.get("parity_sample") or {}).get("scenarios"),
+            (w.get("parity_sample") or {}).get("mismatches")]
 
 
 def compact_line(out, detail_name):
@@ -495,7 +549,7 @@ def compact_line(out, detail_name):
 
     trims = [lambda: line.pop("end_to_end", None), sig4, lambda: line["roofline"].pop("lds_frac", None) if line.get("roofline") else None,
              lambda: line["roofline"].pop("valu_pipe_busy_frac", None) if line.get("roofline") else None,
-             drop_col("cpu_scenarios_per_s"), drop_col("checked"), drop_col("generation"), drop_col("hbm_frac"),
+             drop_col("cpu_scenarios_per_s"), drop_col("checked"), drop_col("generation"), drop_col("team_speedup"), drop_col("hbm_frac"),
              lambda: line["cpu_baseline"].update(sample=line["cpu_baseline"]["sample"][:40]) if line.get("cpu_baseline") else None,
              drop_col("roofline_frac"), lambda: line.pop("digest", None)]
     for trim in trims:                                               # never the contract's keys, roofline, cpu_baseline, parity_sample
@@ -642,7 +696,7 @@ def main():
     ap.add_argument("--hard", type=int, default=0, help="--workload service: services (every third) with a hard zone constraint on their own pods (maxSkew 2)")
     ap.add_argument("--pref", type=int, default=0, help="--workload service: services whose pods prefer not to sit next to their own kind (hostname 100, zone 50)")
     ap.add_argument("--anti", type=int, default=0, help="--workload service: services whose pods also require anti-affinity to their own kind on the hostname key")
-    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig", "service"], default="config3",
+    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig", "service", "typical", "widemix"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
                          "(GPU share + anti-affinity + taints) on generation 6 of the score-table kernel, --c5-scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
@@ -764,7 +818,7 @@ def main():
             if pmc:
                 source = f"replayed from the committed profile ({src}), not measured in this run"
         out["roofline"] = roofline_record(kname, st.kernel_variant, k_ms, st.n_launches, alg, pmc, source, wl,
-                                          lds_bytes=st.lds_bytes if st.workgroup_size == 64 else None, scenarios=S_local)
+                                          lds_bytes=st.lds_bytes if st.kernel_variant == 4 else None, scenarios=S_local)
         # ---- the oracle: CPU baseline (N = 1) and parity of the timed batch ---------------------------------------
         if not args.no_cpu_baseline:
             if world == 1:
@@ -784,7 +838,8 @@ def main():
             sub_steps = int(os.environ.get("SIMON_BENCH_SUB_STEPS", "5"))       # every sub-record times >= 5 steps after a warm-up
             for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", sub_steps, 1, 64, 0), ("service", sub_steps, 1, 64, 0),
                                                  ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
-                                                 ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING)):
+                                                 ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING),
+                                                 ("service_small", sub_steps, 1, 16, 0), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0)):
                 try:
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))
                     if subs[-1].get("parity_sample", {}).get("mismatches"):

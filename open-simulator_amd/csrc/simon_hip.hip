@@ -138,9 +138,9 @@ struct simon_ctx : simon::HostInputs {
     std::vector<int32_t> ipa_h_term, ipa_h_w;     // [Cp] the hostname-like term of a class's raw score (-1: none) and its coefficient
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
-    // team mode of generation 7 (simon_table.hip: NW waves per scenario): env SIMON_TEAM = 0 never / 1 always, width by batch size /
-    // 4, 8, 16 always, that width / unset: batches of at most team_max_s scenarios (default 2 per CU: beyond that one wave per
-    // scenario fills the SIMDs by itself; env SIMON_TEAM_MAX_S)
+    // team mode of generation 7 (simon_table.hip: NW = kTeamWaves waves per scenario): env SIMON_TEAM = 0 never / 1 (or 4) always /
+    // unset: batches of at most team_max_s scenarios (default 2 per CU: beyond that one wave per scenario fills the SIMDs by
+    // itself -- measured crossover between 512 and 1 024 scenarios, profiles/r04; env SIMON_TEAM_MAX_S)
     int team_mode = -1, team_max_s = -1;
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
     std::vector<int> sp_set_eff;                  // per id: the node set its row is counted on (-1: every node)
@@ -1190,7 +1190,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_hard_fold = getenv("SIMON_NO_HARD_FOLD") != nullptr;        // A/B + tests: hard spread constraints always on the all-feature kernel
     c->no_ipa_fold = getenv("SIMON_NO_IPA_FOLD") != nullptr;          // A/B + tests: preferred pod (anti-)affinity always on the all-feature kernel
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
-    if (const char* e = getenv("SIMON_TEAM")) { const int v = atoi(e); c->team_mode = (v == 0 || v == 1 || v == 4 || v == 8 || v == 16) ? v : -1; }
+    if (const char* e = getenv("SIMON_TEAM")) { const int v = atoi(e); c->team_mode = v == 0 ? 0 : (v == 1 || v == kTeamWaves) ? 1 : -1; }
     if (const char* e = getenv("SIMON_TEAM_MAX_S")) c->team_max_s = atoi(e);
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
@@ -1615,18 +1615,10 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (slots == 7) slots = 8;
         // the score-table kernel: one workgroup (one wave) per scenario, ONE launch, scenarios in LPT order
         const int ni_top = c->table_ni_top;
-        // team mode: a small batch of a problem with soft spread constraints gets 4, 8 or 16 waves per scenario (the walks of
-        // spread_select and the prologue are split; LDS: + one score table + the exchange slots).  Width: about eight waves per CU
-        // over the batch (two per SIMD: the walks wait on memory), never so many that a wave's share falls below two units of 64 positions.
+        // team mode: a small batch of a problem with soft spread constraints gets kTeamWaves waves per scenario (the walks of
+        // spread_select and the prologue are split; LDS: + one score table, the canonical indices and the exchange slots)
         const int team_max = c->team_max_s >= 0 ? c->team_max_s : 2 * c->n_cus;
-        int team = 1;
-        if (c->spread && c->table_coarse && !c->rest && c->n_sigs <= 128 && c->team_mode != 0 && (c->team_mode > 0 || S <= team_max)) {
-            if (c->team_mode > 1) team = c->team_mode;
-            else {
-                team = 2 * S <= c->n_cus ? 16 : S <= c->n_cus ? 8 : 4;
-                while (team > 4 && ni_top / 64 < 2 * team) team /= 2;
-            }
-        }
+        int team = (c->spread && c->table_coarse && !c->rest && c->n_sigs <= 128 && c->team_mode != 0 && (c->team_mode > 0 || S <= team_max)) ? kTeamWaves : 1;
         auto lds_for = [&](int tm) -> size_t {
             return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0)) : -1) + c->lds_pad : 0;
         };

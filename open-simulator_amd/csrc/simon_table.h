@@ -82,7 +82,7 @@ struct TableLaunch {
     const int32_t* cls_list; const PodRowC* pods; const int32_t* orders; const int32_t* perm; int32_t* place_step;
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
     unsigned char* ws;   // HBM workspace: byte table + node state (+ per-16 summary entries and counters when coarse) of every scenario
-    int team;            // waves per scenario: 0 / 1 = one (the throughput shape); 4, 8 or 16 = team mode (SPREAD only; small batches)
+    int team;            // waves per scenario: 0 / 1 = one (the throughput shape); kTeamWaves = team mode (SPREAD only; small batches)
     bool spread;         // some pod class carries soft spread constraints (generation 7; implies coarse, excludes rest)
     bool aff;            // some pod class carries required-affinity entries (REST)
     bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
@@ -105,17 +105,17 @@ constexpr int kSpreadMaxHostTerms = 4096, kSpreadMaxZoneTerms = 1024, kSpreadMax
 #define SIMON_SPREAD_TAB_MAX 512          // (tests build a library with a tiny table to drive every pod through the general walk)
 #endif
 constexpr int kSpreadTabMax = SIMON_SPREAD_TAB_MAX;       // entries of spread_select's per-pod score table in LDS: classes x (largest counter + 1, a power of two)
-constexpr int kTeamWavesMax = 16;       // team mode (table_kernel: NW = 4, 8 or 16 waves per scenario: one, two or four per SIMD of the CU)
+constexpr int kTeamWaves = 4;           // team mode (table_kernel: NW): waves per scenario, one per SIMD of the CU.  8 and 16 were built and measured
+                                        // SLOWER on every batch (profiles/r04/r04b_*: once the walks are a quarter, the leader's chain and the barriers decide)
+constexpr int kTeamWavesMax = 16;       // (the exchange slots are sized for it: a wider team is one more translation unit, simon_table_team<N>.hip)
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD; | 0x100: second score table; | 0x200: team mode)
 size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0);  // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
-// the same for a.team == 4 / 8 / 16 (64 * team threads per scenario; SPREAD problems only): simon_table_team<N>.hip
+// the same for a.team == kTeamWaves (64 * team threads per scenario; SPREAD problems only): simon_table_team4.hip
 hipError_t launch_table_team4(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
-hipError_t launch_table_team8(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
-hipError_t launch_table_team16(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
                             int32_t* placement, hipStream_t st);

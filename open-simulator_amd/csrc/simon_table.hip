@@ -321,7 +321,10 @@ template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, 
 #define SIMON_SPREAD_IPA_WAVES 3
 #endif
 // (the SPREAD instantiations hold a batch of loads in registers: kept to 128 VGPRs = four scenario waves per SIMD, the same as the others)
-// (team mode runs at one or two workgroups per CU = one or two waves per SIMD: no register budget to keep)
+// (team mode runs at one or two workgroups per CU = one or two waves per SIMD: no register budget to keep.  Tried on top and dropped,
+// same-box A/B profiles/r04/r04e_*, r04f_*: the canonical indices fetched with pass 1's loads and stashed in LDS for pass 2 (+4 %),
+// the spread entries fetched one pod ahead (+-1 %), 1 / 3 / 4 waves per SIMD as the register budget (within 2 %), 8 and 16 waves
+// per scenario (slower on every batch size, r04b_*))
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD ? (NW > 1 ? 2 : AFF ? SIMON_SPREAD_IPA_WAVES : SIMON_SPREAD_WAVES) : 1))) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
@@ -1009,7 +1012,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const bool simple = nh == 0 || (nh == 1 && eh == 0 && soft_n <= 2);
         const unsigned toff = (unsigned)k * KS + (unsigned)lane;         // this lane's byte of a unit's row of signature k ([unit][K][64])
         // (team mode: no register budget to keep -- a wave's share of the units in as few batches of loads as its size suggests)
-        constexpr int SB = NW == 1 ? kSpreadBatch1 : NW == 4 ? 10 : NW == 8 ? 8 : 6, SC = NW == 1 ? kSpreadBatch2 : SB, SG = NW == 1 ? kSpreadBatch4 : 4;
+        // (team mode keeps the batch sizes: 10 / 8 units per batch measured SLOWER than 6 -- a wave's share is 6 .. 20 units and the
+        // slots beyond it repeat the last unit; profiles/r04/r04b_team_ab_*.txt)
+        constexpr int SB = kSpreadBatch1, SC = kSpreadBatch2, SG = kSpreadBatch4;
         // the first loads of the walk go out before the class bookkeeping below waits for its own (memory is served in order)
         const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
         unsigned czv[4];
@@ -1889,9 +1894,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
     if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
-        return a.team == 4 ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st)
-             : a.team == 8 ? launch_table_team8(a, n_blocks, has_mask, nzeq, lds_bytes, st)
-             : a.team == 16 ? launch_table_team16(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
+        return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
     has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & 32);   // (& 32: the fold, carried by COARSE && !REST && HAS_PIN)
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);

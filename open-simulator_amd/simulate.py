@@ -241,17 +241,22 @@ def occupancy_pct(used: int, alloc: int) -> int:
     return int(float(used) / float(alloc) * 100) if alloc else 0
 
 
-def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node: Optional[dict], counts: Sequence[int],
-          engine=None, max_cpu: int = 100, max_mem: int = 100, max_vg: int = 100) -> SweepResult:
-    """The add-nodes loop of Applier.Run (pkg/apply/apply.go:203-259) as ONE scenario batch: scenario k = the cluster plus
-    counts[k] clones of new_node (utils.NewFakeNodes); the answer is the smallest count with no unscheduled pod whose
-    occupancy satisfies MaxCPU / MaxMemory (satisfyResourceSetting, :689-775)."""
-    engine = engine or HipEngine()
+@dataclass
+class SweepBatch:
+    """The host side of `sweep` before the engine runs: the flattened problem of the whole node pool and one scenario per count."""
+    flat: "fl.Flat"
+    scen: np.ndarray                     # [S][2] (nodes of the scenario, order 0)
+    orders: np.ndarray                   # [1][P] identity
+    node_ranks: Optional[np.ndarray]     # [S][N] per-scenario nodeTree ranks, or None when every size is a prefix of the pool's order
+    pool: List[dict]
+    base: List[dict]
+
+
+def sweep_batch(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node: Optional[dict], counts: Sequence[int],
+                ranks_ok: bool = True) -> SweepBatch:
+    """cluster + up to max(counts) clones of new_node -> ONE problem and len(counts) scenarios (what `sweep` hands to the engine; also
+    used by bench.py and profiles/e2e_sweep.py to time the engine on Kubernetes-object workloads)."""
     counts = list(counts)
-    if max_cpu > 100 or max_cpu < 0:
-        max_cpu = 100
-    if max_mem > 100 or max_mem < 0:
-        max_mem = 100
     base = list(cluster.get("Node", []))
     if max(counts) > 0 and new_node is None:
         raise ValueError("new node is nil when adding node to cluster")          # utils.NewFakeNodes (utils.go:886-888)
@@ -263,24 +268,40 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
         # nodes in several zones: the nodeTree order of one cluster size is not a prefix of the next one's.  The pool keeps
         # its layout (cluster nodes, then clones: every scenario is a prefix SET) and each scenario brings its own
         # canonical ranks for selectHost's tie-break (simon_set_node_ranks); engines without that run size by size.
-        if not getattr(engine, "supports_node_ranks", True):
-            return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
+        if not ranks_ok:
+            raise fl.Unsupported("the engine has no per-scenario node ranks")
         node_ranks = np.zeros((len(counts), len(pool)), np.int32)
         for s, k in enumerate(counts):
             order = k8s.canonical_node_order(pool[:len(base) + k])
             node_ranks[s, order] = np.arange(len(order), dtype=np.int32)
     pods, gates = build_stream(cluster, apps, pool, len(base))
-    try:
-        flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates,
-                          storage_classes=_storage_classes(cluster, apps))
-    except fl.Unsupported as e:
-        if "ImageLocality" not in str(e):
-            raise
-        # ImageLocality scores depend on the cluster size: every size is its own problem with its own static scores
-        return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
-    P = len(pods)
+    flat = fl.flatten(pool, pods, cluster.get("Service", []), cluster.get("ReplicaSet", []), cluster.get("StatefulSet", []), gates,
+                      storage_classes=_storage_classes(cluster, apps))
     scen = np.array([[len(base) + k, 0] for k in counts], np.int32)
-    orders = np.arange(P, dtype=np.int32)[None, :]
+    orders = np.arange(len(pods), dtype=np.int32)[None, :]
+    return SweepBatch(flat, scen, orders, node_ranks, pool, base)
+
+
+def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node: Optional[dict], counts: Sequence[int],
+          engine=None, max_cpu: int = 100, max_mem: int = 100, max_vg: int = 100) -> SweepResult:
+    """The add-nodes loop of Applier.Run (pkg/apply/apply.go:203-259) as ONE scenario batch: scenario k = the cluster plus
+    counts[k] clones of new_node (utils.NewFakeNodes); the answer is the smallest count with no unscheduled pod whose
+    occupancy satisfies MaxCPU / MaxMemory (satisfyResourceSetting, :689-775)."""
+    engine = engine or HipEngine()
+    counts = list(counts)
+    if max_cpu > 100 or max_cpu < 0:
+        max_cpu = 100
+    if max_mem > 100 or max_mem < 0:
+        max_mem = 100
+    try:
+        batch = sweep_batch(cluster, apps, new_node, counts, ranks_ok=getattr(engine, "supports_node_ranks", True))
+    except fl.Unsupported as e:
+        if "ImageLocality" not in str(e) and "node ranks" not in str(e):
+            raise
+        # ImageLocality scores depend on the cluster size: every size is its own problem with its own static scores (and an engine
+        # without per-scenario node ranks runs a pool of several zones size by size)
+        return _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg)
+    flat, scen, orders, node_ranks, pool, base = batch.flat, batch.scen, batch.orders, batch.node_ranks, batch.pool, batch.base
     want_gpu = flat.problem.gpu_mem is not None
     kw = {"want_gpu_slices": True} if want_gpu else {}
     if node_ranks is not None:

@@ -308,3 +308,77 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)
     scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)
     return prob, np.ascontiguousarray(scen, np.int32), orders
+
+
+def typical_cluster_objects(seed: int, n_nodes: int, n_workloads: int, max_replicas: int):
+    """What a production namespace usually looks like: every workload a Deployment (some StatefulSets) with its own `app` label, most behind
+    a Service (system-default soft spread constraints), half of them preferring not to sit next to their own replicas (hostname 100, zone
+    50), a few REQUIRING it (hostname), a few with a DoNotSchedule zone constraint, some tolerating the dedicated pool, some pinned to
+    ssd nodes.  Nodes: three shapes, three zones, a tainted dedicated pool.  Kubernetes OBJECTS (dicts): they go through the host
+    mirror (workloads -> flatten) like a `simon apply` input; returns (nodes, workloads, services)."""
+    from . import k8s
+    rng = np.random.default_rng(seed)
+    nodes = []
+    for j in range(n_nodes):
+        shape = [("8", "16Gi"), ("16", "32Gi"), ("32", "64Gi")][int(rng.integers(0, 3))]
+        node = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"node-{j}", "labels": {k8s.LABEL_HOSTNAME: f"node-{j}", "disk": ["ssd", "hdd"][j % 2]}},
+                "status": {"allocatable": {"cpu": shape[0], "memory": shape[1], "pods": "110"}, "capacity": {"cpu": shape[0], "memory": shape[1]}}}
+        if j % 10 == 7:
+            node["spec"] = {"taints": [{"key": "dedicated", "value": "infra", "effect": "NoSchedule"}]}
+        nodes.append(node)
+    workloads, services = [], []
+    for w in range(n_workloads):
+        app = f"app{w}"
+        spec = {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {
+            "cpu": str(rng.choice(["100m", "250m", "500m", "1", "2"])), "memory": str(rng.choice(["128Mi", "256Mi", "1Gi", "2Gi"]))}}}]}
+        replicas = int(rng.integers(1, max_replicas + 1))
+        paa = {}
+        r = rng.random()
+        if r < 0.5:
+            paa["preferredDuringSchedulingIgnoredDuringExecution"] = [
+                {"weight": 100, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": k8s.LABEL_HOSTNAME}},
+                {"weight": 50, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": k8s.LABEL_ZONE}}]
+        elif r < 0.6:
+            paa["requiredDuringSchedulingIgnoredDuringExecution"] = [{"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": k8s.LABEL_HOSTNAME}]
+            replicas = min(replicas, 40)
+        if paa:
+            spec["affinity"] = {"podAntiAffinity": paa}
+        r2 = rng.random()
+        if r2 < 0.1:
+            spec["topologySpreadConstraints"] = [{"maxSkew": int(rng.integers(1, 4)), "topologyKey": k8s.LABEL_ZONE, "whenUnsatisfiable": "DoNotSchedule",
+                                                  "labelSelector": {"matchLabels": {"app": app}}}]
+        elif r2 < 0.2:
+            spec["nodeSelector"] = {"disk": "ssd"}
+        if rng.random() < 0.15:
+            spec["tolerations"] = [{"key": "dedicated", "operator": "Exists"}]
+        kind = "StatefulSet" if rng.random() < 0.1 else "Deployment"
+        workloads.append({"apiVersion": "apps/v1", "kind": kind, "metadata": {"name": app, "namespace": "default"},
+                          "spec": {"replicas": replicas, "selector": {"matchLabels": {"app": app}}, "template": {"metadata": {"labels": {"app": app}}, "spec": spec}}})
+        if rng.random() < 0.8:
+            services.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": f"svc-{w}", "namespace": "default"}, "spec": {"selector": {"app": app}}})
+    return nodes, workloads, services
+
+
+def typical_cluster_sweep(n_nodes: int = 2500, new_nodes: int = 2500, n_workloads: int = 400, max_replicas: int = 250, n_counts: int = 64,
+                          seed: int = 1):
+    """The typical cluster as ONE scenario batch the way `simon apply` would sweep it: `n_counts` candidate numbers of new nodes
+    (clones of a 32-cpu template) between 0 and `new_nodes`, one DaemonSet, zones round robin by node index (so every size is a prefix
+    of the pool's nodeTree order).  Returns (Problem, scen, orders) -- through workloads.expand + flatten.flatten, no engine involved."""
+    from . import k8s, simulate as sim
+    nodes, workloads, services = typical_cluster_objects(seed, n_nodes, n_workloads, max_replicas)
+    for j, n in enumerate(nodes):
+        n["metadata"]["labels"][k8s.LABEL_ZONE] = f"z{j % 3}"
+        n["status"]["allocatable"]["pods"] = "110"
+    ds = [{"apiVersion": "apps/v1", "kind": "DaemonSet", "metadata": {"name": "agent0", "namespace": "kube-system"},
+           "spec": {"selector": {"matchLabels": {"app": "agent0"}},
+                    "template": {"metadata": {"labels": {"app": "agent0"}},
+                                 "spec": {"containers": [{"name": "a", "image": "x", "resources": {"requests": {"cpu": "100m", "memory": "128Mi"}}}],
+                                          "tolerations": [{"operator": "Exists"}]}}}}]
+    cluster = k8s.group_resources(nodes + services + ds)
+    apps = [sim.AppResource("app", k8s.group_resources(workloads))]
+    template = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": "tmpl", "labels": {"disk": "ssd", k8s.LABEL_ZONE: "z0"}},
+                "status": {"allocatable": {"cpu": "32", "memory": "64Gi", "pods": "40"}, "capacity": {"cpu": "32", "memory": "64Gi"}}}
+    counts = np.unique(np.linspace(0, new_nodes, n_counts).astype(int)).tolist()
+    batch = sim.sweep_batch(cluster, apps, template, counts)
+    assert batch.node_ranks is None
+    return batch.flat.problem, batch.scen, batch.orders

@@ -18,54 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conftest  # noqa: E402,F401
 import randk8s  # noqa: E402
-from open_simulator_amd import capi, flatten as fl, k8s, simulate as sim, workloads as wl  # noqa: E402
-
-
-def typical_cluster(seed, n_nodes, n_workloads, max_replicas):
-    """What a production namespace usually looks like: every workload a Deployment (some StatefulSets) with its own `app` label, most behind
-    a Service (system-default soft spread constraints), half of them preferring not to sit next to their own replicas (hostname 100, zone
-    50), a few REQUIRING it (hostname), a few with a DoNotSchedule zone constraint, some tolerating the dedicated pool, some pinned to
-    ssd nodes.  Nodes: three shapes, three zones, a tainted dedicated pool."""
-    rng = np.random.default_rng(seed)
-    nodes = []
-    for j in range(n_nodes):
-        shape = [("8", "16Gi"), ("16", "32Gi"), ("32", "64Gi")][int(rng.integers(0, 3))]
-        node = {"apiVersion": "v1", "kind": "Node", "metadata": {"name": f"node-{j}", "labels": {randk8s.HOST: f"node-{j}", "disk": ["ssd", "hdd"][j % 2]}},
-                "status": {"allocatable": {"cpu": shape[0], "memory": shape[1], "pods": "110"}, "capacity": {"cpu": shape[0], "memory": shape[1]}}}
-        if j % 10 == 7:
-            node["spec"] = {"taints": [{"key": "dedicated", "value": "infra", "effect": "NoSchedule"}]}
-        nodes.append(node)
-    workloads, services = [], []
-    for w in range(n_workloads):
-        app = f"app{w}"
-        spec = {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {
-            "cpu": str(rng.choice(["100m", "250m", "500m", "1", "2"])), "memory": str(rng.choice(["128Mi", "256Mi", "1Gi", "2Gi"]))}}}]}
-        replicas = int(rng.integers(1, max_replicas + 1))
-        paa = {}
-        r = rng.random()
-        if r < 0.5:
-            paa["preferredDuringSchedulingIgnoredDuringExecution"] = [
-                {"weight": 100, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}},
-                {"weight": 50, "podAffinityTerm": {"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.ZONE}}]
-        elif r < 0.6:
-            paa["requiredDuringSchedulingIgnoredDuringExecution"] = [{"labelSelector": {"matchLabels": {"app": app}}, "topologyKey": randk8s.HOST}]
-            replicas = min(replicas, 40)
-        if paa:
-            spec["affinity"] = {"podAntiAffinity": paa}
-        r2 = rng.random()
-        if r2 < 0.1:
-            spec["topologySpreadConstraints"] = [{"maxSkew": int(rng.integers(1, 4)), "topologyKey": randk8s.ZONE, "whenUnsatisfiable": "DoNotSchedule",
-                                                  "labelSelector": {"matchLabels": {"app": app}}}]
-        elif r2 < 0.2:
-            spec["nodeSelector"] = {"disk": "ssd"}
-        if rng.random() < 0.15:
-            spec["tolerations"] = [{"key": "dedicated", "operator": "Exists"}]
-        kind = "StatefulSet" if rng.random() < 0.1 else "Deployment"
-        workloads.append({"apiVersion": "apps/v1", "kind": kind, "metadata": {"name": app, "namespace": "default"},
-                          "spec": {"replicas": replicas, "selector": {"matchLabels": {"app": app}}, "template": {"metadata": {"labels": {"app": app}}, "spec": spec}}})
-        if rng.random() < 0.8:
-            services.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": f"svc-{w}", "namespace": "default"}, "spec": {"selector": {"app": app}}})
-    return nodes, workloads, services
+from open_simulator_amd import capi, flatten as fl, k8s, simulate as sim, synth, workloads as wl  # noqa: E402
 
 
 def main():
@@ -83,7 +36,7 @@ def main():
                     "Services, preferred (some required) anti-affinity to their own replicas, some hard zone constraints, tolerations, node selectors")
     a = ap.parse_args()
     if a.typical:
-        nodes, workloads, services = typical_cluster(1, a.nodes, a.workloads, a.max_replicas)
+        nodes, workloads, services = synth.typical_cluster_objects(1, a.nodes, a.workloads, a.max_replicas)
     else:
         nodes, workloads, services = randk8s.rand_cluster(1, n_nodes=a.nodes, n_workloads=a.workloads, max_replicas=a.max_replicas)
     # prefix pools need ONE zone round-robin order: keep zone labels only on a prefix-stable pattern (all nodes zoned, by index)

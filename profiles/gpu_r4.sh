@@ -20,7 +20,7 @@ for STAGE in "$@"; do
     team_ab)
       ( timeout 900 python profiles/team_ab.py 2>&1 | tail -12 ) > "$OUT/team_ab_service.txt"; cat "$OUT/team_ab_service.txt"
       ( timeout 600 python profiles/team_ab.py --pref 60 --sizes 16,64,256 2>&1 | tail -6 ) > "$OUT/team_ab_service_pref.txt"; cat "$OUT/team_ab_service_pref.txt"
-      for T in 0 4 8 16; do ( SIMON_TEAM=$T timeout 600 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | tail -1 ) > "$OUT/typical_x64_team$T.txt"; cat "$OUT/typical_x64_team$T.txt"; done
+      for T in 0 4; do ( SIMON_TEAM=$T timeout 600 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | tail -1 ) > "$OUT/typical_x64_team$T.txt"; cat "$OUT/typical_x64_team$T.txt"; done
       for C in 8 256; do ( timeout 600 python profiles/e2e_sweep.py --typical --counts $C 2>&1 | tail -1 ) > "$OUT/typical_x${C}_auto.txt"; cat "$OUT/typical_x${C}_auto.txt"; done ;;
     all_tests)
       ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > "$OUT/pytest_gpu.log"; tail -2 "$OUT/pytest_gpu.log"
@@ -30,6 +30,19 @@ for STAGE in "$@"; do
       tail -1 "$OUT/bench_default.out" > "$OUT/bench_default.json"; wc -c "$OUT/bench_default.json"; cat "$OUT/bench_default.json" ;;
     rocprof)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/rocprof" -o bench -- python $OLDPWD/bench.py --no-sub --pmc off --no-cpu-baseline --steps 5 > "$OUT/rocprof_bench.out" 2>&1 ); ls "$OUT/rocprof" | head ;;
+    tprof)   # phase profile (bash profiles/build_variant.sh tprof -DSIMON_TABLE_PROFILE first): the leader's ticks per scheduling cycle, both shapes
+      for T in 0 4; do
+        ( SIMON_TEAM=$T SIMON_TABLE_PROF=1 SIMON_HIP_LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_tprof.so timeout 600 python profiles/team_ab.py --sizes 16 --only $T 2>&1 | grep -v amdgpu.ids | tail -8 ) > "$OUT/tprof_service_S64_team$T.txt"; cat "$OUT/tprof_service_S64_team$T.txt"
+        ( SIMON_TEAM=$T SIMON_TABLE_PROF=1 SIMON_HIP_LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_tprof.so timeout 600 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | grep -v amdgpu.ids | tail -4 ) > "$OUT/tprof_typical_x64_team$T.txt"; cat "$OUT/tprof_typical_x64_team$T.txt"
+      done ;;
+    libab)   # same-box A/B of library variants (env LIBS="name name ..": open-simulator_amd/csrc/libsimon_hip_<name>.so; "main" = the product build)
+      for L in ${LIBS:-main}; do
+        LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_$L.so; [ $L = main ] && LIB=$PWD/open-simulator_amd/csrc/libsimon_hip.so
+        for REP in 1 2; do
+          echo "$L service_S64 $( SIMON_HIP_LIB=$LIB timeout 300 python profiles/team_ab.py --sizes 16 --only 4 2>&1 | tail -1 )" | tee -a "$OUT/libab.txt"
+          echo "$L typical_x64 $( SIMON_TEAM=4 SIMON_HIP_LIB=$LIB timeout 300 python profiles/e2e_sweep.py --typical --counts 64 2>&1 | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["kernel_ms"], d["workgroup"])' )" | tee -a "$OUT/libab.txt"
+        done
+      done ;;
     *) echo "unknown stage $STAGE" ;;
   esac
   echo "[$STAGE] $(( $(date +%s) - t0 )) s"

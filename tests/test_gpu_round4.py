@@ -13,13 +13,12 @@ from test_gpu_parity import assert_same
 from test_gpu_round3 import SPREAD_FEATURES
 
 pytestmark = pytest.mark.gpu
-TEAM_THREADS = (256, 512, 1024)          # 64 x {4, 8, 16} waves per scenario (csrc/simon_table.h); SIMON_TEAM=1 lets the library pick the width
-SHAPES = (("0", (64,)), ("4", (256,)), ("8", (512,)), ("16", (1024,)))
+TEAM_THREADS = (256,)                    # 64 x kTeamWaves (csrc/simon_table.h)
+SHAPES = (("0", (64,)), ("4", TEAM_THREADS))
 
 
 def run_shape(prob, scen, orders, team, ranks=None, monkeypatch=None):
-    """One context under SIMON_TEAM = team ("0": one wave per scenario, "1": a team, width by batch size, "4" / "8" / "16": that width,
-    None: the library chooses)."""
+    """One context under SIMON_TEAM = team ("0": one wave per scenario, "1" / "4": a team of four, None: the library chooses)."""
     if team is None:
         monkeypatch.delenv("SIMON_TEAM", raising=False)
     else:
@@ -35,8 +34,8 @@ def run_shape(prob, scen, orders, team, ranks=None, monkeypatch=None):
 
 @pytest.mark.parametrize("idx", range(len(SPREAD_FEATURES)))
 def test_team_mode_matches_the_oracle_on_soft_spread_problems(idx, monkeypatch):
-    """The problems of round 3's generation-7 test on every shape: workgroup 64 (one wave per scenario), 256 / 512 / 1 024 (teams of
-    4 / 8 / 16 waves) and the width the library picks; the oracle decides, not another shape."""
+    """The problems of round 3's generation-7 test on both shapes: workgroup 64 (one wave per scenario) and 256 (a team of four waves);
+    the oracle decides, not the other shape."""
     feat = SPREAD_FEATURES[idx]
     for seed, (N, P) in enumerate([(40, 300), (200, 900), (700, 1500), (1300, 2500)]):
         prob = randprob.rand_problem(7000 + 10 * idx + seed, N=N, P=P, spread_soft=True, n_node_classes=4, n_pod_classes=9, **feat)
