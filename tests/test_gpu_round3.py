@@ -367,13 +367,10 @@ def test_k8s_typical_cluster_sweep_on_generation_7():
     """profiles/e2e_sweep.py --typical at a size the oracle checks in seconds: Deployments / StatefulSets behind Services, preferred and
     required anti-affinity to their own replicas, hard zone constraints, tolerations, node selectors -- the whole sweep on the score-table
     kernel, every placement against the oracle."""
-    import importlib.util
     import randk8s
     from open_simulator_amd import k8s, simulate as sim
-    spec = importlib.util.spec_from_file_location("e2e_sweep", os.path.join(ROOT, "profiles", "e2e_sweep.py"))
-    e2e = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(e2e)
-    nodes, workloads, services = e2e.typical_cluster(3, 360, 70, 40)
+    from open_simulator_amd import synth as _synth
+    nodes, workloads, services = _synth.typical_cluster_objects(3, 360, 70, 40)
     for j, n in enumerate(nodes):
         n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"
     cluster = k8s.group_resources(nodes + services)

@@ -489,11 +489,8 @@ def test_typical_cluster_against_the_object_level_scheduler(seed):
     """profiles/e2e_sweep.py --typical (Deployments / StatefulSets behind Services, preferred and required anti-affinity to their own
     replicas, hard zone constraints, tolerations, node selectors -- the shapes the score-table kernel keeps since round 3) at a small
     size: flatten + oracle against tests/pyref_sched.py, the restatement that works on the objects the way the Go code does."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("e2e_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "e2e_sweep.py"))
-    e2e = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(e2e)
-    nodes, workloads, services = e2e.typical_cluster(100 + seed, 45, 16, 12)
+    from open_simulator_amd import synth as _synth
+    nodes, workloads, services = _synth.typical_cluster_objects(100 + seed, 45, 16, 12)
     for j, n in enumerate(nodes):
         n["metadata"]["labels"][randk8s.ZONE] = f"z{j % 3}"
         n["status"]["allocatable"]["pods"] = "20"
