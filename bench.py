@@ -626,6 +626,7 @@ def run_group(args, capi, synth, torch):
         for _ in range(args.steps):
             g.run_loaded(True)
             plan, _ = g.min_plan()
+        collective = g.collective()
         for d in sorted(set(devices)):
             torch.cuda.synchronize(d)
         dt = time.perf_counter() - t0
@@ -648,7 +649,9 @@ def run_group(args, capi, synth, torch):
            "config": {"workload": workload_name(args, prob, scen, n_orders, len(scen) // n, n), "scenarios_per_gpu": len(scen) // n,
                       "pods": prob.n_pods, "node_pool": prob.n_nodes, "kernel": KERNEL_SHORT.get(st0.kernel_variant, "?"),
                       "kernel_generation": st0.kernel_generation, "plan": plan.as_dict()},
-           "ranks": {"mode": "one process, simon_group over the device list (no collective: the per-device plans are reduced on the host)",
+           "ranks": {"mode": "one process, simon_group over the device list", "plan_collective": collective,
+                     "plan_collective_note": "rccl_all_gather = ONE ncclAllGather of the 8-byte plan keys over the members' own devices (distinct devices only); "
+                                             "host = the members' plans reduced on the host (one member, shared devices under the test hook, no librccl)",
                      "devices": devices, "one_device_test_hook": shared and ndev < n,
                      "member_kernel_ms": [round(s.kernel_ms, 3) for s in sts]}}
     if par is not None:

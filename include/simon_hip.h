@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIMON_HIP_ABI_VERSION 4
+#define SIMON_HIP_ABI_VERSION 5   /* v5 (round 4): + simon_min_plan_device, simon_group_collective -- additive, every v4 struct unchanged */
 
 #define SIMON_MAX_GPU_DEV 8 /* devices per GPU-share node (pkg/type/open-gpu-share/cache/gpunodeinfo.go:34-56) */
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
@@ -392,6 +392,13 @@ int simon_min_plan(simon_ctx* ctx, int32_t max_cpu_pct, int32_t max_mem_pct, sim
 int simon_min_plan_vg(simon_ctx* ctx, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
                       int32_t* vg_pct);
 
+/* The device half of the same search, for a collective (ABI v5): runs the reduction and returns the DEVICE address of its
+ * 8-byte key -- n_nodes << 32 | scenario index of the minimum plan, ~0 when no scenario qualifies -- and the HIP stream
+ * (hipStream_t as void*, may be NULL) the reduction was enqueued on, so that an ncclAllGather of the key enqueued on that
+ * stream is ordered behind it without a host synchronisation (simon_group_min_plan does exactly this over RCCL; a
+ * one-process-per-GPU launcher can hand the pointer to its own communicator).  Valid until the next call on ctx. */
+int simon_min_plan_device(simon_ctx* ctx, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, void** d_key, void** stream);
+
 /* Re-run ONE scenario and dump, for every pod that ends unscheduled, the per-node failure code
  * (SIMON_FAIL_*), from which the host rebuilds FitError.Error()'s reason histogram
  * (V/core/generic_scheduler.go:72-90).  fail_codes is [max_failed][n_nodes of that scenario];
@@ -448,9 +455,15 @@ int simon_group_fetch_gpu_slices(simon_group* g, int32_t scenario, uint64_t* sli
 
 /* The add-nodes search over every device: minimum n_nodes among the scenarios of the last run that schedule every pod
  * within the caps (satisfyResourceSetting, pkg/apply/apply.go:689-775); ties go to the lowest scenario index, exactly
- * as simon_min_plan_vg on one device running the whole batch.  vg_pct may be NULL. */
+ * as simon_min_plan_vg on one device running the whole batch.  vg_pct may be NULL.
+ * Members on DISTINCT devices exchange their plans through ONE ncclAllGather (RCCL over xGMI) of the 8-byte plan key, device to
+ * device, on communicators made by ncclCommInitAll when the group was created (librccl is bound at run time); one member,
+ * members that share a device, a missing librccl or SIMON_GROUP_RCCL=0 reduce the members' host-side plans instead.  Same
+ * result either way. */
 int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
                          int32_t* vg_pct);
+/* What the last simon_group_min_plan did: 0 = host reduction (no collective), 1 = RCCL all-gather of the plan keys; -1 = NULL group.  (ABI v5) */
+int32_t simon_group_collective(simon_group* g);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_GPU_DEV = 8
 MAX_SCALAR = 4
 
@@ -474,12 +474,12 @@ _LIB = None
 EXPORTS = [
     "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
-    "simon_fetch_results", "simon_fetch_placement", "simon_fetch_gpu_slices", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_explain", "simon_set_node_ranks",
+    "simon_fetch_results", "simon_fetch_placement", "simon_fetch_gpu_slices", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_min_plan_device", "simon_explain", "simon_set_node_ranks",
     "simon_get_stats", "simon_device_results", "simon_explain_loaded",
     "simon_group_create", "simon_group_destroy", "simon_group_last_error", "simon_group_size", "simon_group_member",
     "simon_group_load_nodes", "simon_group_load_pods", "simon_group_load_class_tables", "simon_group_load_scenarios",
     "simon_group_run_loaded", "simon_group_fetch_results", "simon_group_run_batch", "simon_group_fetch_placement", "simon_group_fetch_gpu_slices",
-    "simon_group_min_plan",
+    "simon_group_min_plan", "simon_group_collective",
 ]
 
 
@@ -537,6 +537,9 @@ def load_library(path: Optional[str] = None):
     lib.simon_group_fetch_placement.argtypes = [vp, C.c_int32, _p32]
     lib.simon_group_fetch_gpu_slices.argtypes = [vp, C.c_int32, _pu64]
     lib.simon_group_min_plan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
+    lib.simon_group_collective.argtypes = [vp]
+    lib.simon_group_collective.restype = C.c_int32
+    lib.simon_min_plan_device.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp)]
     lib.simon_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.simon_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     for name in EXPORTS:
@@ -787,3 +790,8 @@ class Group:
         self._check(self.lib.simon_group_min_plan(self.h, int(max_cpu_pct), int(max_mem_pct), int(max_vg_pct), C.byref(plan),
                                                   C.byref(vg)), "simon_group_min_plan")
         return plan, int(vg.value)
+
+    def collective(self) -> str:
+        """How the last min_plan combined the members' plans: "rccl_all_gather" (members on distinct devices: one ncclAllGather of the
+        8-byte plan keys, device to device) or "host" (one member / shared devices / librccl unavailable)."""
+        return {0: "host", 1: "rccl_all_gather"}.get(int(self.lib.simon_group_collective(self.h)), "?")

@@ -5,12 +5,24 @@
 // to member s % n_dev (with the batch ordered count-major every member sees every node count:
 // balanced, cost grows with the count), replicates the immutable inputs, runs the members
 // concurrently -- one host thread per member for the duration of a call, every member on its own
-// HIP device and stream -- and reduces the members' minimum plans on the host: in ONE process the
-// "all-gather of the per-device plan" of north_star is a loop over n_dev 40-byte records.  (With
-// one process per GPU the same record travels through RCCL: bench.py / open-simulator_amd/sweep.py.)
+// HIP device and stream.  The one cross-device exchange of the path is the minimum-node plan
+// (north_star: "RCCL all-gather over xGMI only to collect the global minimum-node plan"):
+//   * members on DISTINCT devices: one ncclAllGather of the 8-byte plan key (n_nodes << 32 | scenario, written by plan_kernel)
+//     straight from device memory, on every member's own stream, through communicators made once by ncclCommInitAll at
+//     group creation; every member then holds all keys, member 0's copy is read back and the lexicographic minimum
+//     (n_nodes, global scenario) picks the winner, whose own context fills in the occupancy figures;
+//   * one member, members sharing a device (tests), RCCL not loadable / failing, or SIMON_GROUP_RCCL=0: the same
+//     minimum over the members' host-side plans, no collective.
+// simon_group_collective() says which one the last simon_group_min_plan took.  librccl is bound at run time (dlopen):
+// a single-GPU host needs neither the library nor a communicator.  (With one PROCESS per GPU the same record travels
+// through torch.distributed's RCCL: bench.py / open-simulator_amd/sweep.py.)
 //
-// Built on the public single-device entry points only; holds no HIP state of its own.
+// Scenario work is built on the public single-device entry points only; the group's own HIP state is the gather buffers.
 #include "../../include/simon_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -27,6 +39,16 @@ struct simon_group {
     int32_t S = 0, P = 0;                       // last loaded batch: global scenario count; pods
     std::vector<std::vector<simon_scenario>> part;   // per member: its scenarios, in global order
     bool have_results = false, have_placement = false, have_slices = false;
+    // RCCL (bound at run time): communicators of the members, gather buffers [n_dev] keys on every member's device
+    void* rccl = nullptr;
+    ncclResult_t (*p_init_all)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*p_all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
+    const char* (*p_errstr)(ncclResult_t) = nullptr;
+    std::vector<ncclComm_t> comm;
+    std::vector<void*> d_gather;
+    bool comm_ok = false;
+    int32_t collective = 0;                     // what the last min_plan did: 0 host reduction, 1 RCCL all-gather
 };
 
 namespace {
@@ -73,6 +95,40 @@ int on_all(simon_group* g, const char* what, F fn) {
     return SIMON_OK;
 }
 
+// Communicators for members on distinct devices (SIMON_GROUP_RCCL=1: also for a single member -- the test hook that runs the
+// collective path on a one-GPU box; =0: never).  Any failure leaves comm_ok false: the host reduction is always available.
+void rccl_setup(simon_group* g) {
+    const int n = (int)g->ctx.size();
+    const char* knob = getenv("SIMON_GROUP_RCCL");
+    if (knob && knob[0] == '0') return;
+    if (n < 2 && !(knob && knob[0] == '1')) return;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (g->device[i] == g->device[j]) return;           // one communicator rank per device
+    g->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!g->rccl) g->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!g->rccl) return;
+    g->p_init_all = reinterpret_cast<decltype(g->p_init_all)>(dlsym(g->rccl, "ncclCommInitAll"));
+    g->p_all_gather = reinterpret_cast<decltype(g->p_all_gather)>(dlsym(g->rccl, "ncclAllGather"));
+    g->p_destroy = reinterpret_cast<decltype(g->p_destroy)>(dlsym(g->rccl, "ncclCommDestroy"));
+    g->p_errstr = reinterpret_cast<decltype(g->p_errstr)>(dlsym(g->rccl, "ncclGetErrorString"));
+    if (!g->p_init_all || !g->p_all_gather || !g->p_destroy) return;
+    try { g->comm.assign(n, nullptr); g->d_gather.assign(n, nullptr); } catch (...) { return; }
+    std::vector<int> devs(g->device.begin(), g->device.end());
+    if (g->p_init_all(g->comm.data(), n, devs.data()) != ncclSuccess) { g->comm.clear(); return; }
+    for (int i = 0; i < n; ++i) {
+        if (hipSetDevice(g->device[i]) != hipSuccess || hipMalloc(&g->d_gather[i], (size_t)n * sizeof(unsigned long long)) != hipSuccess) return;
+    }
+    g->comm_ok = true;
+}
+
+void rccl_teardown(simon_group* g) {
+    for (size_t i = 0; i < g->d_gather.size(); ++i)
+        if (g->d_gather[i]) { (void)hipSetDevice(g->device[i]); (void)hipFree(g->d_gather[i]); }
+    if (g->p_destroy) for (ncclComm_t c : g->comm) if (c) (void)g->p_destroy(c);
+    if (g->rccl) dlclose(g->rccl);
+}
+
 }  // namespace
 
 extern "C" {
@@ -92,14 +148,18 @@ simon_group* simon_group_create(const int32_t* device_ids, int32_t n_dev) {
         g->ctx.push_back(c);                                // capacity reserved above: cannot throw
         g->device.push_back(device_ids[i]);
     }
+    rccl_setup(g);
     return g;
 }
 
 void simon_group_destroy(simon_group* g) {
     if (!g) return;
+    rccl_teardown(g);
     for (simon_ctx* c : g->ctx) simon_ctx_destroy(c);
     delete g;
 }
+
+int32_t simon_group_collective(simon_group* g) { return g ? g->collective : -1; }
 
 const char* simon_group_last_error(simon_group* g) { return g ? g->err.c_str() : "null group"; }
 int32_t simon_group_size(simon_group* g) { return g ? (int32_t)g->ctx.size() : 0; }
@@ -223,6 +283,49 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
     if (!g || !best) return SIMON_EINVAL;
     if (!g->have_results) return gfail(g, SIMON_ESTATE, "group min_plan: nothing has run");
     const int n = (int)g->ctx.size();
+    g->collective = 0;
+    if (g->comm_ok) {
+        // every member: plan_kernel leaves its 8-byte key in device memory; then ONE all-gather of the keys, device to device
+        void* d_key[64] = {nullptr};
+        void* stream[64] = {nullptr};
+        int rc = on_all(g, "min_plan (plan kernel)", [&](int i) { return simon_min_plan_device(g->ctx[i], max_cpu_pct, max_mem_pct, max_vg_pct, &d_key[i], &stream[i]); });
+        if (rc) return rc;
+        ncclResult_t nr[64];
+        for (int i = 0; i < n; ++i) nr[i] = ncclSuccess;
+        hipError_t he[64];
+        for (int i = 0; i < n; ++i) he[i] = hipSuccess;
+        (void)on_all(g, "min_plan (all-gather)", [&](int i) {
+            if ((he[i] = hipSetDevice(g->device[i])) != hipSuccess) return (int)SIMON_OK;   // (still join the collective: the others wait for this rank)
+            nr[i] = g->p_all_gather(d_key[i], g->d_gather[i], 1, ncclUint64, g->comm[i], (hipStream_t)stream[i]);
+            he[i] = hipStreamSynchronize((hipStream_t)stream[i]);
+            return (int)SIMON_OK;
+        });
+        for (int i = 0; i < n; ++i) {
+            if (nr[i] != ncclSuccess) return gfail(g, SIMON_ENODEV, "min_plan: ncclAllGather on member %d: %s", i, g->p_errstr ? g->p_errstr(nr[i]) : "error");
+            if (he[i] != hipSuccess) return gfail(g, SIMON_ENODEV, "min_plan: member %d: %s", i, hipGetErrorString(he[i]));
+        }
+        unsigned long long keys[64];
+        if (hipSetDevice(g->device[0]) != hipSuccess || hipMemcpy(keys, g->d_gather[0], (size_t)n * sizeof keys[0], hipMemcpyDeviceToHost) != hipSuccess)
+            return gfail(g, SIMON_ENODEV, "min_plan: reading the gathered keys back failed");
+        g->collective = 1;
+        memset(best, 0, sizeof *best);
+        best->scenario = -1;
+        if (vg_pct) *vg_pct = 0;
+        int w = -1;
+        unsigned long long wn = 0, ws = 0;
+        for (int i = 0; i < n; ++i) {                          // key = n_nodes << 32 | member-local scenario; ~0 = no qualifying scenario
+            if (keys[i] == ~0ull) continue;
+            const unsigned long long nn = keys[i] >> 32, gs = (keys[i] & 0xFFFFFFFFull) * (unsigned long long)n + (unsigned long long)i;
+            if (w < 0 || nn < wn || (nn == wn && gs < ws)) { w = i; wn = nn; ws = gs; }
+        }
+        if (w < 0) return SIMON_OK;
+        int32_t vgw = 0;
+        rc = simon_min_plan_vg(g->ctx[w], max_cpu_pct, max_mem_pct, max_vg_pct, best, &vgw);   // the winner's own record (occupancy figures)
+        if (rc) return gfail(g, rc, "min_plan: member %d: %s", w, simon_last_error(g->ctx[w]));
+        best->scenario = (int32_t)ws;
+        if (vg_pct) *vg_pct = vgw;
+        return SIMON_OK;
+    }
     simon_plan plans[64];                                   // at most 64 members (simon_group_create)
     int32_t vg[64] = {0};
     memset(plans, 0, sizeof plans);

@@ -1829,10 +1829,8 @@ int simon_min_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, simon
     return simon_min_plan_vg(c, max_cpu_pct, max_mem_pct, 100, best, nullptr);
 }
 
-int simon_min_plan_vg(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
-                      int32_t* vg_pct) {
-    if (!c || !best) return SIMON_EINVAL;
-    if (vg_pct) *vg_pct = 0;
+// satisfyResourceSetting + minimum over the batch on the device: leaves the key (n_nodes << 32 | scenario, ~0 = none) in c->d_plan
+static int launch_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct) {
     if (max_vg_pct > 100 || max_vg_pct < 0) max_vg_pct = 100;
     if (!c->have_results) return fail(c, SIMON_ESTATE, "min_plan: nothing has run");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1844,6 +1842,24 @@ int simon_min_plan_vg(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, in
                        c->d_used_cpu.p, c->d_used_mem.p, c->d_prefix_cpu.p, c->d_prefix_mem.p, max_cpu_pct, max_mem_pct,
                        c->has_local ? c->d_used_vg.p : nullptr, c->d_prefix_vg.p, max_vg_pct, c->d_plan.p);
     HIP_TRY(c, hipGetLastError());
+    return SIMON_OK;
+}
+
+int simon_min_plan_device(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, void** d_key, void** stream) {
+    if (!c || !d_key) return SIMON_EINVAL;
+    const int rc = launch_plan(c, max_cpu_pct, max_mem_pct, max_vg_pct);
+    if (rc) return rc;
+    *d_key = c->d_plan.p;                                          // ordered behind plan_kernel on `stream`: a collective enqueued there needs no host sync
+    if (stream) *stream = (void*)c->stream;
+    return SIMON_OK;
+}
+
+int simon_min_plan_vg(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, int32_t max_vg_pct, simon_plan* best,
+                      int32_t* vg_pct) {
+    if (!c || !best) return SIMON_EINVAL;
+    if (vg_pct) *vg_pct = 0;
+    const int rcl = launch_plan(c, max_cpu_pct, max_mem_pct, max_vg_pct);
+    if (rcl) return rcl;
     unsigned long long key = 0;
     HIP_TRY(c, hipMemcpyAsync(&key, c->d_plan.p, sizeof key, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

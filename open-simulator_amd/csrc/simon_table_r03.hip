@@ -102,7 +102,7 @@ constexpr SelTab make_sel_tab() {
             }
     return t;
 }
-static __device__ __constant__ SelTab kSelTab = make_sel_tab();   // (static: simon_table_team.hip compiles this file a second time)
+__device__ __constant__ SelTab kSelTab = make_sel_tab();
 #define kSel (kSelTab.v)
 
 __device__ __forceinline__ unsigned pk_key(unsigned pair, unsigned c) {   // (x << 4) + c on both halves in ONE instruction
@@ -153,7 +153,7 @@ __device__ __forceinline__ unsigned wave_or_u32_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, zdom, stash, tab, tabi, tab2, xch, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, zdom, stash, tab, tabi, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -182,14 +182,11 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     // SPREAD (nzk >= 0): zone domain of a class per zone-like key; for spread_select two bytes per position and the score table of
     // the pod being placed
     const bool ipa = nzk >= 0 && (nzk & 0x100);                       // the problem has preferred pod (anti-)affinity terms: a second table
-    const bool team = nzk >= 0 && (nzk & 0x200);                      // several waves per scenario (table_kernel: NW > 1): totals table of its own + exchange slots
     if (nzk >= 0) nzk &= 0xFF;
     c.zdom = o; o += nzk >= 0 ? al((nzk > 0 ? nzk : 1) * Cn) : 0;
     c.stash = o; o += nzk >= 0 ? al(ni_max * 2) : 0;
     c.tab = o; o += nzk >= 0 ? kSpreadTabMax * 4 : 0;
     c.tabi = o; o += ipa ? kSpreadTabMax * 4 : 0;
-    c.tab2 = o; o += team ? kSpreadTabMax * 4 : 0;
-    c.xch = o; o += team ? kTeamWavesMax * 6 * 4 : 0;
     c.total = o;
     return c;
 }
@@ -306,14 +303,7 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // trip per cycle; own instantiation: the extra rows cost ~40 VGPRs the K <= 128 kernels must not pay).
 // SPREAD (generation 7): pod classes with soft PodTopologySpread constraints (ScheduleAnyway: the system defaults every pod a Service /
 // ReplicaSet / StatefulSet selects gets, podtopologyspread/plugin.go:39-50) -- see spread_select.
-// NW (team mode, SPREAD only): waves per scenario.  A batch with fewer scenarios than the chip has wave slots -- what a real
-// Applier.Run offers: a handful of candidate sizes (pkg/apply/apply.go:203-259) -- leaves most SIMDs idle when one wave owns a
-// scenario, and a pod with soft spread constraints walks EVERY position twice (spread_select).  With NW > 1 the workgroup is NW waves:
-// wave 0 (the leader) runs the scheduling cycle exactly as the single-wave kernel does; for a spread pod all NW waves walk a
-// contiguous share of the units each, and the extremes of pass 1 and the best key of pass 2 are combined through LDS (three
-// s_barriers per spread pod).  The waves of one workgroup share the CU's vector L1 (no tgsplit), so the leader's stores are
-// visible to the helpers after the barrier's s_waitcnt without cache maintenance.  The prologue (K x n table) is split the same way.
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1>
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD>
 #ifndef SIMON_SPREAD_WAVES
 #define SIMON_SPREAD_WAVES 4
 #endif
@@ -321,11 +311,7 @@ template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, 
 #define SIMON_SPREAD_IPA_WAVES 3
 #endif
 // (the SPREAD instantiations hold a batch of loads in registers: kept to 128 VGPRs = four scenario waves per SIMD, the same as the others)
-// (team mode runs at one or two workgroups per CU = one or two waves per SIMD: no register budget to keep.  Tried on top and dropped,
-// same-box A/B profiles/r04/r04e_*, r04f_*: the canonical indices fetched with pass 1's loads and stashed in LDS for pass 2 (+4 %),
-// the spread entries fetched one pod ahead (+-1 %), 1 / 3 / 4 waves per SIMD as the register budget (within 2 %), 8 and 16 waves
-// per scenario (slower on every batch size, r04b_*))
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD ? (NW > 1 ? 2 : AFF ? SIMON_SPREAD_IPA_WAVES : SIMON_SPREAD_WAVES) : 1))) void table_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPREAD ? (AFF ? SIMON_SPREAD_IPA_WAVES : SIMON_SPREAD_WAVES) : 1))) void table_kernel(
     const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
     int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
@@ -355,15 +341,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
     static_assert(!SPREAD || (COARSE && !REST && !MANY), "SPREAD is built on the two-level layout, without the REST rows");
-    static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0)) : -1);
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
     signed char* s_zdom = (signed char*)(smem + cv.zdom);          // SPREAD: [NZK][Cn]
     unsigned short* s_stash = (unsigned short*)(smem + cv.stash);  // SPREAD: [positions] count | table byte << 8 of the pod being placed
     int* s_tabi = (int*)(smem + cv.tabi);                           // SPREAD (problems with preferred pod (anti-)affinity): [class << lg | count] InterPodAffinity raw score
     int* s_tab = (int*)(smem + cv.tab);                             // SPREAD: [class << lg | count] raw score, then class term + 2 x score
-    int* s_tot = NW > 1 ? (int*)(smem + cv.tab2) : s_tab;          // ... team mode: the totals get a table of their own (every wave writes all of it)
-    int* s_xch = (int*)(smem + cv.xch);                             // team mode: [NW][4] extremes of pass 1, then [NW][2] best key / position of pass 2
     const int M = REST ? sc.M : 0, G = REST ? sc.G : 0, X = REST ? sc.X : 0, NZ = REST ? sc.NZ : 0;
     const int nbp = cv.nbp;
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
@@ -378,16 +361,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // every position for each pod, and 64 contiguous bytes per unit waste a quarter of the cache lines that 4 x 16 do.
     const unsigned KS = SPREAD ? 64u : 16u;
     auto tile_blk = [&](unsigned blk) -> unsigned { return SPREAD ? (blk >> 2) * (Krow * 4u) + (blk & 3u) * 16u : blk * Krow; };
-    const int tid = threadIdx.x;
-    const int lane = NW == 1 ? tid : (tid & 63);
-    const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);   // wave of the team
-    const bool lead = NW == 1 || wv == 0;                                     // the wave that runs the scheduling cycle
-    constexpr int TT = 64 * NW;                                                 // threads of the workgroup
-    // the leader alone works on LDS it shares with nobody at that moment: LDS operations of ONE wave execute in order
-    auto lead_sync = [&]() {
-        if constexpr (NW == 1) __syncthreads();
-        else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    };
+    const int lane = threadIdx.x;
     const int s = __builtin_amdgcn_readfirstlane(perm[blockIdx.x]);
     const int n = __builtin_amdgcn_readfirstlane(scen[s].n_nodes);
     // Per-scenario node order (simon_set_node_ranks: the scenario's own nodeTree order): the per-class node lists, a node's index
@@ -402,8 +376,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
-    for (int i = tid; i < K * Cn; i += TT) { if (!COARSE) s_cnt[i] = 0; s_sn[i] = 0; }
-    for (int i = tid; i < Cn * 12; i += TT) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
+    for (int i = lane; i < K * Cn; i += 64) { if (!COARSE) s_cnt[i] = 0; s_sn[i] = 0; }
+    for (int i = lane; i < Cn * 12; i += 64) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
     // count of class-d nodes among the first n canonical nodes, padded to 16 (COARSE: to 64, one class per summary entry)
     const int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
     const int pad_d = (cnt_d + (UNIT - 1)) & ~(UNIT - 1);
@@ -414,8 +388,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         if (lane >= off) incl += o;
     }
     const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size (classes beyond Cn add nothing)
-    if (lead && lane < Cn) s_seg[lane] = incl - pad_d;
-    if (lead && lane == 0) s_seg[Cn] = ni;                            // the sentinel: with Cn == 64 no lane Cn exists to write it
+    if (lane < Cn) s_seg[lane] = incl - pad_d;
+    if (lane == 0) s_seg[Cn] = ni;                                    // the sentinel: with Cn == 64 no lane Cn exists to write it
     const int nblk = ni >> 4, nun = ni >> UB;                         // table blocks (16 positions); summary entries
     unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
     NodeState* g_state = (NodeState*)(wsb + (((size_t)nblk * Krow + 127) & ~(size_t)127));
@@ -439,10 +413,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     unsigned short* g_canon = (unsigned short*)(g_hmax + (((size_t)TH + 127) & ~(size_t)127));    // [ni] RANKED: rank of the position's node in the scenario's order
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
-    for (int i = tid; i < K * nbp / 2; i += TT) ((unsigned*)s_sum)[i] = 0u;
-    if (tid == 0 && ((K * nbp) & 1)) s_sum[K * nbp - 1] = 0;
-    if (COARSE) for (int i = tid; i < K * Cn; i += TT) g_cnt[i] = 0;
-    if constexpr (NW > 1) __threadfence();                            // (the zeroes are in L2 before another wave's atomics add to them)
+    for (int i = lane; i < K * nbp / 2; i += 64) ((unsigned*)s_sum)[i] = 0u;
+    if (lane == 0 && ((K * nbp) & 1)) s_sum[K * nbp - 1] = 0;
+    if (COARSE) for (int i = lane; i < K * Cn; i += 64) g_cnt[i] = 0;
     __syncthreads();
 
     // class of a position (segments are contiguous): number of segment ENDS at or below it
@@ -473,7 +446,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     };
 
     // ---- prologue 2: node rows, table and summary; lanes = 64 consecutive positions (4 blocks) ----
-    for (int p0 = wv * 64; p0 < ni; p0 += TT) {                          // (team mode: chunk i belongs to wave i % NW)
+    for (int p0 = 0; p0 < ni; p0 += 64) {
         const int p = p0 + lane;
         const int d = class_of_pos(p < ni ? p : 0);
         const int r = p - s_seg[d];
@@ -513,10 +486,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 const int nfe = __popcll(__ballot(b != 0));
                 if (lane == 0) {
                     s_sum[k * nbp + (p0 >> 6)] = (unsigned short)c64;
-                    if (nfe) {
-                        if constexpr (NW == 1) g_cnt[k * Cn + d] += nfe;   // lane 0 alone, chunk after chunk: plain (see the refresh)
-                        else atomicAdd(&g_cnt[k * Cn + d], nfe);           // chunks of one class on several waves (L1 is invalidated below)
-                    }
+                    if (nfe) g_cnt[k * Cn + d] += nfe;                     // lane 0 alone, chunk after chunk: plain (see the refresh)
                 }
             } else {
                 if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
@@ -581,15 +551,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
     }
     if constexpr (SPREAD) {
-        for (int i = tid; i < (NZK > 0 ? NZK : 1) * Cn; i += TT) s_zdom[i] = NZK > 0 ? cold->cls_zdom[i] : (signed char)0;
-        for (size_t i = tid; i < ((size_t)TH * ni + 3) / 4; i += TT) ((unsigned*)g_hrow)[i] = 0u;     // no pod placed yet
-        for (int i = tid; i < TZ * 16; i += TT) g_zcnt[i] = 0u;
-        for (int i = tid; i < TH; i += TT) g_hmax[i] = 0;
+        for (int i = lane; i < (NZK > 0 ? NZK : 1) * Cn; i += 64) s_zdom[i] = NZK > 0 ? cold->cls_zdom[i] : (signed char)0;
+        for (size_t i = lane; i < ((size_t)TH * ni + 3) / 4; i += 64) ((unsigned*)g_hrow)[i] = 0u;     // no pod placed yet
+        for (int i = lane; i < TZ * 16; i += 64) g_zcnt[i] = 0u;
+        for (int i = lane; i < TH; i += 64) g_hmax[i] = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (NW > 1) __threadfence();                            // the counters were added to in L2 (atomics): no stale L1 line may serve the plain loads of the loop
     __syncthreads();
-    if constexpr (NW > 1) __threadfence();
 
     // this lane's signatures: lane l re-evaluates signatures l (and l + 64) on a touched node
     int kk[KQ];
@@ -675,7 +643,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             s_tmp[dd] = sn - (int)s_sn[k * Cn + dd];
             s_sn[k * Cn + dd] = (unsigned short)sn;
         }
-        lead_sync();
+        __syncthreads();
         unsigned short* srow = s_sum + k * nbp;
 #pragma unroll
         for (int q = 0; q < NBQ; ++q) {
@@ -696,7 +664,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
             }
         }
-        lead_sync();
+        __syncthreads();
     };
 
     // ---- REST path -------------------------------------------------------------------------------------------------------
@@ -939,28 +907,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // holds entry e (`spv`).
     TPROF_DECL
     auto spread_select = [&](int k, int tc, int soft_n, int match_n, int ipa_n, int hard_n, int spv, int spt, int& dstar, int& res) -> int {
-        // team mode: everything the leader stored in the cycles since the last spread pod -- table bytes, counters, class terms -- is
-        // complete (the barrier's release waits for vmcnt / lgkmcnt) before a helper reads it; wave w walks units [ulo, uhi)
-        if constexpr (NW > 1) __syncthreads();
-        int ulo = 0, uhi = nun;
-        if constexpr (NW > 1) {
-            const int per = (nun + NW - 1) / NW;
-            ulo = min(wv * per, nun); uhi = min(ulo + per, nun);
-        }
-        const bool have = ulo < uhi;                                      // (a scenario with fewer units than waves leaves some without a share)
-        auto team_extremes = [&](int& pmin, int& pmax, int& imin, int& imax) {   // wave-reduced extremes of pass 1, combined over the team
-            if constexpr (NW > 1) {
-                if (lane == 0) { s_xch[wv * 4 + 0] = pmin; s_xch[wv * 4 + 1] = pmax; s_xch[wv * 4 + 2] = imin; s_xch[wv * 4 + 3] = imax; }
-                __syncthreads();
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    pmin = min(pmin, s_xch[w * 4 + 0]); pmax = max(pmax, s_xch[w * 4 + 1]);
-                    imin = min(imin, s_xch[w * 4 + 2]); imax = max(imax, s_xch[w * 4 + 3]);
-                }
-                pmin = __builtin_amdgcn_readfirstlane(pmin); pmax = __builtin_amdgcn_readfirstlane(pmax);
-                imin = __builtin_amdgcn_readfirstlane(imin); imax = __builtin_amdgcn_readfirstlane(imax);
-            }
-        };
         const int dd = lane < Cn ? lane : 0;
         int kind[4], rowi[4], zsl[4], skew[4];
         bool dup[4];
@@ -1011,9 +957,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         // or zone-like constraints alone (their sum is a per-class value): raw = int64((count * w + c) + zone_term(class)).
         const bool simple = nh == 0 || (nh == 1 && eh == 0 && soft_n <= 2);
         const unsigned toff = (unsigned)k * KS + (unsigned)lane;         // this lane's byte of a unit's row of signature k ([unit][K][64])
-        // (team mode: no register budget to keep -- a wave's share of the units in as few batches of loads as its size suggests)
-        // (team mode keeps the batch sizes: 10 / 8 units per batch measured SLOWER than 6 -- a wave's share is 6 .. 20 units and the
-        // slots beyond it repeat the last unit; profiles/r04/r04b_team_ab_*.txt)
         constexpr int SB = kSpreadBatch1, SC = kSpreadBatch2, SG = kSpreadBatch4;
         // the first loads of the walk go out before the class bookkeeping below waits for its own (memory is served in order)
         const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
@@ -1051,12 +994,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         auto load1 = [&](int u0) {
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
-                const int u = min(u0 + j, uhi - 1);                       // a slot beyond the last unit repeats it (changes nothing)
+                const int u = min(u0 + j, nun - 1);                       // a slot beyond the last unit repeats it (changes nothing)
                 byte1[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
                 h1[j] = hb1[(unsigned)(u * 64 + lane)];
             }
         };
-        if (simple && have) load1(ulo);
+        if (simple) load1(0);
         TPROF(12);                                                         // spread: descriptor, first loads issued
         bool ign = false;                                                 // IgnoredNodes (:80-85): a constraint key is missing
 #pragma unroll
@@ -1142,11 +1085,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             int imin = 0, imax = 0;                                       // InterPodAffinity: extremes over ALL feasible nodes, from 0 (:247-256)
             auto pass1 = [&](auto ipa_tag) {                              // pass 1; leaves (count, table byte) of every position in LDS
                 constexpr bool IPA = decltype(ipa_tag)::value;
-                if (!have) return;
-                for (int u0 = ulo;;) {
+                for (int u0 = 0;;) {
 #pragma unroll
                     for (int j = 0; j < SB; ++j) {
-                        const int u = min(u0 + j, uhi - 1);
+                        const int u = min(u0 + j, nun - 1);
                         const int c = winner_info(u) >> 16;
                         const int idx = (c << lg) + ((int)h1[j] & hmask);     // (padding positions and the no-hostname-term case read arbitrary bytes)
                         const int raw = s_tab[idx];
@@ -1164,7 +1106,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         (s_stash + u * 64)[lane] = (unsigned short)(h1[j] | (beff << 8));   // (uniform base + lane: one address add)
                     }
                     u0 += SB;
-                    if (u0 >= uhi) break;
+                    if (u0 >= nun) break;
                     load1(u0);
                 }
             };
@@ -1176,7 +1118,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             if constexpr (kIpa) {
                 if (ipa_pod) { imin = wave_min_i32(imin); imax = wave_max_i32(imax); }
             }
-            team_extremes(pmin, pmax, imin, imax);
             const int idiff = imax - imin;
             const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
             const int pmm = pmax + pmin;
@@ -1191,15 +1132,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if constexpr (kIpa) {
                     if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)(s_tabi[min(i, E - 1)] - imin) / (double)idiff));
                 }
-                if (i < E) s_tot[i] = (cw & 0x3fffffff) + 2 * v + iv;       // (team mode: every wave writes the whole table -- identical values)
+                if (i < E) s_tab[i] = (cw & 0x3fffffff) + 2 * v + iv;
             }
             TPROF_WAIT_LDS; TPROF(16);                                     // spread: extremes, table of totals
-            for (int u0 = ulo; u0 < uhi; u0 += SC) {                     // pass 2: totals, first maximum in canonical order
+            for (int u0 = 0; u0 < nun; u0 += SC) {                       // pass 2: totals, first maximum in canonical order
                 int canon[SC], cbase[SC];
                 unsigned stj[SC];
 #pragma unroll
                 for (int j = 0; j < SC; ++j) {
-                    const int u = min(u0 + j, uhi - 1);
+                    const int u = min(u0 + j, nun - 1);
                     const int info = winner_info(u);                      // (offset into cls_list + 8192) | class << 16 of the unit
                     // uniform base + lane (scalar address arithmetic); the padding positions of the last class read past the lists, into
                     // the 64 entries of slack behind them (their table byte is 0)
@@ -1209,10 +1150,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
                 int t2[SC];
 #pragma unroll
-                for (int j = 0; j < SC; ++j) t2[j] = s_tot[cbase[j] + ((int)stj[j] & hmask)];
+                for (int j = 0; j < SC; ++j) t2[j] = s_tab[cbase[j] + ((int)stj[j] & hmask)];
 #pragma unroll
                 for (int j = 0; j < SC; ++j) {
-                    const int u = min(u0 + j, uhi - 1);
+                    const int u = min(u0 + j, nun - 1);
                     const unsigned byte = stj[j] >> 8;                   // total + 1 = (byte - 1) + (class term + 2 x score) + 1
                     const unsigned key = byte != 0u ? ((byte + (unsigned)t2[j]) << 13) | (8191u - (unsigned)canon[j]) : 0u;
                     if (key > bkey) { bkey = key; bpos = u * 64 + lane; }
@@ -1242,11 +1183,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
                 return (int)scv;
             };
-            for (int u0 = ulo; u0 < uhi; u0 += SG) {                      // pass 1
+            for (int u0 = 0; u0 < nun; u0 += SG) {                        // pass 1
                 unsigned byte[SG], h[SG][4], hI[SG];
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
-                    const int u = min(u0 + j, uhi - 1);
+                    const int u = min(u0 + j, nun - 1);
                     byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
@@ -1254,7 +1195,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
-                    const int c = winner_info(min(u0 + j, uhi - 1)) >> 16;
+                    const int c = winner_info(min(u0 + j, nun - 1)) >> 16;
                     const int raw = raw_of(h[j], c);
                     const int cwv = __builtin_amdgcn_readlane(clsw, c);
                     unsigned beff = byte[j];
@@ -1272,15 +1213,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             pmin = wave_min_i32(pmin);
             pmax = wave_max_i32(pmax);
             if constexpr (kIpa) { imin = wave_min_i32(imin); imax = wave_max_i32(imax); }
-            team_extremes(pmin, pmax, imin, imax);
             const int idiff = imax - imin;
             const double rinv = pmax > 0 ? 1.0 / (double)pmax : 0.0, hrinv = 0.5 * rinv;
-            for (int u0 = ulo; u0 < uhi; u0 += SG) {                      // pass 2
+            for (int u0 = 0; u0 < nun; u0 += SG) {                        // pass 2
                 unsigned byte[SG], h[SG][4], hI[SG];
                 int canon[SG], infoj[SG];
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
-                    const int u = min(u0 + j, uhi - 1);
+                    const int u = min(u0 + j, nun - 1);
                     byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
@@ -1290,7 +1230,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
 #pragma unroll
                 for (int j = 0; j < SG; ++j) {
-                    const int u = min(u0 + j, uhi - 1);
+                    const int u = min(u0 + j, nun - 1);
                     const int c = infoj[j] >> 16;
                     const int raw = raw_of(h[j], c);
                     const int cw = __builtin_amdgcn_readlane(clsw, c);
@@ -1309,27 +1249,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             }
         }
         TPROF(17);                                                         // spread: pass 2
-        unsigned best = wave_max_u32(bkey);
-        int pstar;
-        if constexpr (NW == 1) {
-            if (best == 0u) return -1;
-            const int wl = __builtin_ctzll(__ballot(bkey == best));
-            pstar = __builtin_amdgcn_readlane(bpos, wl);
-        } else {                                                          // the team's best: keys carry the canonical index, so the maximum is one node
-            const int wl = best != 0u ? __builtin_ctzll(__ballot(bkey == best)) : 0;
-            const int pw = __builtin_amdgcn_readlane(bpos, wl);
-            if (lane == 0) { s_xch[4 * NW + 2 * wv] = (int)best; s_xch[4 * NW + 2 * wv + 1] = pw; }
-            __syncthreads();
-            best = 0u; pstar = -1;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const unsigned kw = (unsigned)s_xch[4 * NW + 2 * w];
-                const int pq = s_xch[4 * NW + 2 * w + 1];
-                if (kw > best) { best = kw; pstar = pq; }
-            }
-            pstar = __builtin_amdgcn_readfirstlane(pstar);
-            if (best == 0u) return -1;
-        }
+        const unsigned best = wave_max_u32(bkey);
+        if (best == 0u) return -1;
+        const int wl = __builtin_ctzll(__ballot(bkey == best));
+        const int pstar = __builtin_amdgcn_readlane(bpos, wl);
         const int info = winner_info(pstar >> 6);
         dstar = info >> 16;
         res = (info & 0xFFFF) - 8192 + pstar;
@@ -1423,12 +1346,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         int res, pstar = -1, dstar = 0;
         unsigned top = 0, m16q[NBQ];
         bool scanned = false, bound = false;                           // bound: a preset pod (no Reserve: the scheduler never saw it)
-        // a pod with soft spread constraints / preferred pod (anti-)affinity / hard zone constraints: every node's score moves -- the one
-        // select the whole team takes part in (a single call site below: helpers skip everything else of the cycle)
-        const bool spread_pod = SPREAD && pk >= 0 && (sp_soft | sp_ipa | sp_hard) != 0;
-        if (!lead) {
-            res = -2;
-        } else if (__builtin_expect(pk < 0, 0)) {
+        if (__builtin_expect(pk < 0, 0)) {
             const int r_preset = __builtin_amdgcn_readlane(cur.y, il), r_gate = __builtin_amdgcn_readlane(cur.z, il);
             const TableCold* cc = cold;
             asm volatile("" : "+s"(cc));                               // rare paths: fetch their pointers here, not in loop-long SGPRs
@@ -1458,18 +1376,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv), dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
-        } else if (spread_pod) {
+        } else if (SPREAD && (sp_soft | sp_ipa | sp_hard) != 0) {                    // a pod with soft spread constraints / preferred pod (anti-)affinity: every node's score moves
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
             if ((dq >> (k >> 6)) & 1u) {                               // the class terms of row k (s_sn) must be current
                 renormalise(k, r_cls);
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
-            if constexpr (NW == 1) {                                   // (one wave: the select sits where it always sat -- the team's call site is below)
-                pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
-                TPROF(18);                                             // spread: winner
-                if (pstar < 0) { ++unsched; res = -1; }
-            }
+            pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
+            TPROF(18);                                                 // spread: winner
+            if (pstar < 0) { ++unsched; res = -1; }
         } else {
             const int k = r_sig;
             const unsigned dq = (unsigned)__builtin_amdgcn_readlane((int)my_dirty, k & 63);
@@ -1508,15 +1424,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 scanned = true;
             }
         }
-        if constexpr (NW > 1) {
-            if (spread_pod) {                                          // every wave of the team
-                pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
-                TPROF(18);                                             // spread: winner
-                if (pstar < 0) { ++unsched; res = -1; }
-            }
-        }
         // -------- assume: NodeInfo.AddPod (V/framework/types.go:482-508) + table column + summary ----
-        if (lead && pstar >= 0) {
+        if (pstar >= 0) {
             TPROF(3);                                                  // winner info
             // Position order is canonical order inside a class only: do entries of ANOTHER class reach the same total?  Then the
             // first maximum in CANONICAL order decides (static per-class node lists, L2-hot).
@@ -1761,11 +1670,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         // -------- placement, recorded by STEP (coalesced); simon_hip.hip permutes to pod ids ---
         plreg = (il == lane) ? res : plreg;
         }
-        if (lead && place && lane < steps) place[i0 + lane] = plreg >= 0 ? cls_list[rk_off + (unsigned)plreg] : plreg;   // 64 canonical indices per gather
+        if (place && lane < steps) place[i0 + lane] = plreg >= 0 ? cls_list[rk_off + (unsigned)plreg] : plreg;   // 64 canonical indices per gather
     }
 
     // ---- epilogue: sum of Requested over the scenario's nodes (padding rows hold 0) -----------
-    if (!lead) return;
     long long uc = 0, um = 0;
     for (int p = lane; p < ni; p += 64) { const NodeState st = g_state[p]; uc += st.rq_c; um += st.rq_m; }
     uc = wave_sum_i64(uc);
@@ -1781,38 +1689,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     }
 }
 
-#ifdef SIMON_TABLE_TEAM_TU
-// ---- this translation unit (simon_table_team<N>.hip) holds the team-mode instantiations only: NW = SIMON_TABLE_TEAM_TU waves per scenario ----
-constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
-#define SIMON_TEAM_CAT2(a, b) a##b
-#define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
-template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF>
-static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTuWaves>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * kTuWaves), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
-    return hipGetLastError();
-}
-template <bool M, bool Z, int KQ, int NBQ>
-static hipError_t launch_team4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    const bool ranked = a.sc.rk_stride != 0, ipa = (a.sc.static_tables & 64) != 0;     // (& 64: preferred pod (anti-)affinity / hard zone constraints: SPREAD && AFF)
-    if (ranked) return ipa ? launch_team6<M, Z, KQ, NBQ, true, true>(a, n_blocks, lds, st) : launch_team6<M, Z, KQ, NBQ, true, false>(a, n_blocks, lds, st);
-    return ipa ? launch_team6<M, Z, KQ, NBQ, false, true>(a, n_blocks, lds, st) : launch_team6<M, Z, KQ, NBQ, false, false>(a, n_blocks, lds, st);
-}
-template <bool M, bool Z>
-static hipError_t launch_team2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    const bool one = a.sc.ni_max / 64 <= 64;
-    if (a.sc.K > 64) return one ? launch_team4<M, Z, 2, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 2, 2>(a, n_blocks, lds, st);
-    return one ? launch_team4<M, Z, 1, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 1, 2>(a, n_blocks, lds, st);
-}
-hipError_t SIMON_TEAM_CAT(launch_table_team, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.coarse || a.rest || a.team != kTuWaves) return hipErrorInvalidValue;
-    if (has_mask) return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
-    return nzeq ? launch_team2<false, true>(a, n_blocks, lds_bytes, st) : launch_team2<false, false>(a, n_blocks, lds_bytes, st);
-}
-#else
 // placement[s][pod] = place_step[s][inv_order[order_id(s)][pod]]: gather (scattered reads hit L2, stores coalesced)
 __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restrict__ place_step, const int32_t* __restrict__ inv_orders,
                                                         const ScenarioDesc* __restrict__ scen, int P, int32_t* __restrict__ placement) {
@@ -1900,12 +1776,9 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 }
 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
-    if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
-        return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
     has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & 32);   // (& 32: the fold, carried by COARSE && !REST && HAS_PIN)
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }
-#endif  // SIMON_TABLE_TEAM_TU
 
 }  // namespace simon

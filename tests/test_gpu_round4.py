@@ -127,3 +127,61 @@ def test_fuzz_spread_slice_on_both_shapes():
     import fuzz_spread
     bad = [info for ok, info in (fuzz_spread.one_case(c) for c in range(5000, 5024)) if not ok]
     assert not bad, bad
+
+
+# ---- the device group's plan exchange (ABI v5) -------------------------------------------------------------------------------------
+def test_group_min_plan_through_the_rccl_all_gather(monkeypatch):
+    """simon_group_min_plan with a communicator: ONE ncclAllGather of the 8-byte plan keys from device memory (librccl bound at run
+    time, ncclCommInitAll at group creation).  A one-GPU box cannot hold two ranks on two devices, so the collective path runs with a
+    single member under SIMON_GROUP_RCCL=1 (the hook: a communicator of one rank) -- dlopen, communicator, all-gather on the member's
+    stream, read-back, winner -- and must agree with the host reduction, with a plain context and with the oracle's plan."""
+    prob, scen, orders = synth.config3(n_counts=24, n_orders=2, n_pods=900, n_het=60)
+    ref = O.run_threaded(prob, scen, orders)
+    want = O.min_plan(prob, scen, ref).as_dict()
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.run_batch(scen, orders)
+        assert ctx.min_plan().as_dict() == want
+    monkeypatch.setenv("SIMON_GROUP_RCCL", "1")
+    with capi.Group([0]) as g:
+        g.load_problem(prob)
+        g.load_scenarios(scen, orders)
+        g.run_loaded(True)
+        plan, _ = g.min_plan()
+        assert g.collective() == "rccl_all_gather"
+        assert plan.as_dict() == want
+        tight, _ = g.min_plan(max_cpu_pct=1)                          # nothing qualifies: the all-ones key travels, found = 0
+        assert not tight.found and g.collective() == "rccl_all_gather"
+    monkeypatch.setenv("SIMON_GROUP_RCCL", "0")
+    with capi.Group([0]) as g:
+        g.load_problem(prob)
+        g.load_scenarios(scen, orders)
+        g.run_loaded(True)
+        plan, _ = g.min_plan()
+        assert g.collective() == "host" and plan.as_dict() == want
+    monkeypatch.delenv("SIMON_GROUP_RCCL")
+    with capi.Group([0, 0]) as g:                                      # two members on ONE device: no communicator (a rank per device) -> host
+        g.load_problem(prob)
+        g.load_scenarios(scen, orders)
+        g.run_loaded(True)
+        plan, _ = g.min_plan()
+        assert g.collective() == "host" and plan.as_dict() == want
+
+
+def test_min_plan_device_hands_out_the_key(monkeypatch):
+    """simon_min_plan_device (what a one-process-per-GPU launcher would all-gather itself): the device address of the key n_nodes << 32 |
+    scenario and the stream it was produced on."""
+    import ctypes as C
+    prob, scen, orders = synth.config3(n_counts=8, n_orders=2, n_pods=600, n_het=40)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.run_batch(scen, orders)
+        plan = ctx.min_plan()
+        d_key, stream = C.c_void_p(), C.c_void_p()
+        assert ctx.lib.simon_min_plan_device(ctx.h, 100, 100, 100, C.byref(d_key), C.byref(stream)) == 0 and d_key.value
+        import torch
+        torch.cuda.synchronize()
+        key = torch.empty(1, dtype=torch.int64)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(key.data_ptr()), d_key, C.c_size_t(8), C.c_int(2)) == 0        # hipMemcpyDeviceToHost
+        assert int(key.item()) == (plan.n_nodes << 32 | plan.scenario)
