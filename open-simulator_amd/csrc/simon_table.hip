@@ -947,7 +947,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             const int per = (nun + NW - 1) / NW;
             ulo = min(wv * per, nun); uhi = min(ulo + per, nun);
         }
-        const bool have = ulo < uhi;                                      // (a scenario with fewer units than waves leaves some without a share)
+        const bool have = NW == 1 || ulo < uhi;                           // (a scenario with fewer units than waves leaves some without a share)
         auto team_extremes = [&](int& pmin, int& pmax, int& imin, int& imax) {   // wave-reduced extremes of pass 1, combined over the team
             if constexpr (NW > 1) {
                 if (lane == 0) { s_xch[wv * 4 + 0] = pmin; s_xch[wv * 4 + 1] = pmax; s_xch[wv * 4 + 2] = imin; s_xch[wv * 4 + 3] = imax; }

@@ -46,7 +46,8 @@ for STAGE in "$@"; do
     regress)   # the single-wave kernels against another build of simon_table.hip, same box (env LIBS, as libab): kernel ms of the benchmarked workloads
       for L in ${LIBS:-main}; do
         LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_$L.so; [ $L = main ] && LIB=$PWD/open-simulator_amd/csrc/libsimon_hip.so
-        for W in "config3" "service" "service --pref 60" "config3sig --sigs 200" "config5 --c5-scenarios 256" "config5 --c5-scenarios 2048"; do
+        IFS=';' read -ra WL <<< "${WORKLOADS:-config3;service;service --pref 60;config3sig --sigs 200;config5 --c5-scenarios 256;config5 --c5-scenarios 2048}"
+        for W in "${WL[@]}"; do
           for REP in 1 2; do
             echo "$L [$W] $( SIMON_HIP_LIB=$LIB SIMON_BENCH_DETAIL=/tmp/d.json timeout 600 python bench.py --workload $W --pmc off --no-cpu-baseline --no-sub --steps 5 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["roofline"]["kernel_ms"], d["config"]["kernel_generation"])' )" | tee -a "$OUT/regress.txt"
           done
