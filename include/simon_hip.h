@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIMON_HIP_ABI_VERSION 5   /* v5 (round 4): + simon_min_plan_device, simon_group_collective -- additive, every v4 struct unchanged */
+#define SIMON_HIP_ABI_VERSION 5   /* v5 (round 4): + simon_min_plan_device, simon_group_collective, simon_explain_local_detail -- additive, every v4 struct unchanged */
 
 #define SIMON_MAX_GPU_DEV 8 /* devices per GPU-share node (pkg/type/open-gpu-share/cache/gpunodeinfo.go:34-56) */
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
@@ -82,6 +82,13 @@ extern "C" {
 #define SIMON_FAIL_LOCAL 0x0400u           /* Open-Local: node has no local storage (Unschedulable without reason text, open-local.go:64-69) */
 #define SIMON_FAIL_LOCAL_LVM 0x0401u       /* ... no volume group holds an LVM volume (ProcessLVMPVCPredicate's error text carries sizes) */
 #define SIMON_FAIL_LOCAL_DEV 0x0402u       /* ... not enough free exclusive devices of the requested media type / size */
+/* What simon_explain_local_detail reports for a SIMON_FAIL_LOCAL_LVM / _DEV node: the error of open-local's predicate whose
+ * Error() text is the plugin's reason (pkg/simulator/plugin/open-local.go:78-88; vendor/github.com/alibaba/open-local/pkg/scheduler/errors/errors.go) */
+#define SIMON_LOCAL_ERR_NONE 0
+#define SIMON_LOCAL_ERR_NO_SUCH_VG 1       /* NotSuchVGError: "not LVM named <a = interned VG name>" (algo/common.go:72-74) */
+#define SIMON_LOCAL_ERR_NO_VG 2            /* NoAvailableVGError: "not LVM on node <node name>" (:104-106) */
+#define SIMON_LOCAL_ERR_LVM 3              /* InsufficientLVMError: requested a, used b, capacity c bytes (:79-81, :120-123) */
+#define SIMON_LOCAL_ERR_DEVICE 4           /* InsufficientExclusiveResourceError(Device): requested a, available b, capacity c devices (:317-326, :412-435) */
 #define SIMON_FAIL_PORTS 0x0800u           /* "node(s) didn't have free ports for the requested pod ports" (nodeports/node_ports.go:37) */
 #define SIMON_FAIL_GPUSHARE 0x1000u        /* reason "Node:<name>" (pkg/simulator/plugin/open-gpu-share.go:64-78) */
 
@@ -411,6 +418,12 @@ int simon_explain(simon_ctx* ctx, simon_scenario scen, const int32_t* order, int
  * [max_failed][n_nodes of that scenario].  With ranks loaded simon_explain refuses (SIMON_ESTATE): an ad-hoc scenario has
  * no rank row.  (ABI v3) */
 int simon_explain_loaded(simon_ctx* ctx, int32_t scenario, int32_t* failed_pods, uint16_t* fail_codes, int32_t max_failed);
+/* Open-Local's reasons embed sizes (`err.Error()`, pkg/simulator/plugin/open-local.go:78-88), which a 16-bit code cannot carry.
+ * After simon_explain / simon_explain_loaded on a problem with local storage: detail[i][j][4] = {SIMON_LOCAL_ERR_*, a, b, c} for
+ * failed pod i (the same rows as fail_codes, at most max_failed of them) and node j of that scenario; all zero where the code
+ * is not SIMON_FAIL_LOCAL_LVM / _DEV.  Returns the number of rows written (0 when the problem has no local storage), or a
+ * negative error (SIMON_ESTATE before any explain call).  (ABI v5) */
+int simon_explain_local_detail(simon_ctx* ctx, int64_t* detail, int32_t max_failed);
 
 int simon_get_stats(simon_ctx* ctx, simon_stats* stats);
 

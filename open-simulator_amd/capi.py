@@ -38,6 +38,7 @@ CLASS_AFF_SELF = 0x1
 MAX_SPREAD = 4
 MAX_VG, MAX_LDEV, MAX_LVOL = 4, 8, 4
 FAIL_LOCAL, FAIL_LOCAL_LVM, FAIL_LOCAL_DEV = 0x0400, 0x0401, 0x0402
+LOCAL_ERR_NONE, LOCAL_ERR_NO_SUCH_VG, LOCAL_ERR_NO_VG, LOCAL_ERR_LVM, LOCAL_ERR_DEVICE = 0, 1, 2, 3, 4   # simon_explain_local_detail
 SPREAD_DUP_KEY = 0x40000000
 
 KERNEL_NARROW = 1
@@ -475,7 +476,7 @@ EXPORTS = [
     "simon_hip_version", "simon_hip_device_count", "simon_ctx_create", "simon_ctx_destroy", "simon_last_error",
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
     "simon_fetch_results", "simon_fetch_placement", "simon_fetch_gpu_slices", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_min_plan_device", "simon_explain", "simon_set_node_ranks",
-    "simon_get_stats", "simon_device_results", "simon_explain_loaded",
+    "simon_get_stats", "simon_device_results", "simon_explain_loaded", "simon_explain_local_detail",
     "simon_group_create", "simon_group_destroy", "simon_group_last_error", "simon_group_size", "simon_group_member",
     "simon_group_load_nodes", "simon_group_load_pods", "simon_group_load_class_tables", "simon_group_load_scenarios",
     "simon_group_run_loaded", "simon_group_fetch_results", "simon_group_run_batch", "simon_group_fetch_placement", "simon_group_fetch_gpu_slices",
@@ -517,6 +518,7 @@ def load_library(path: Optional[str] = None):
     lib.simon_min_plan_vg.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Plan), C.POINTER(C.c_int32)]
     lib.simon_explain.argtypes = [vp, Scenario, _p32, _p32, _pu16, C.c_int32]
     lib.simon_explain_loaded.argtypes = [vp, C.c_int32, _p32, _pu16, C.c_int32]
+    lib.simon_explain_local_detail.argtypes = [vp, _p64, C.c_int32]
     lib.simon_group_create.restype = vp
     lib.simon_group_create.argtypes = [_p32, C.c_int32]
     lib.simon_group_destroy.argtypes = [vp]
@@ -685,6 +687,15 @@ class Context:
                                                       int(max_failed)), "simon_explain_loaded")
         k = min(n, max_failed)
         return n, failed[:k], codes[:k]
+
+    def explain_local_detail(self, n_failed: int, n_nodes: int) -> Optional[np.ndarray]:
+        """simon_explain_local_detail after explain / explain_loaded: [n_failed][n_nodes][4] int64 {LOCAL_ERR_*, a, b, c} -- what
+        Open-Local's error texts carry -- or None when the problem has no local storage."""
+        if n_failed <= 0:
+            return None
+        detail = np.zeros((int(n_failed), int(n_nodes), 4), np.int64)
+        k = self._check(self.lib.simon_explain_local_detail(self.h, _ptr(detail, C.c_int64), int(n_failed)), "simon_explain_local_detail")
+        return detail[:k] if k > 0 else None
 
     def stats(self) -> Stats:
         st = Stats()

@@ -154,6 +154,9 @@ struct simon_ctx : simon::HostInputs {
     bool table_coarse = false;                   // two-level summary (simon_table.hip: COARSE), decided per loaded batch
     int force_coarse = -1, table_ni_top = 16;    // env SIMON_TABLE_COARSE = 0 / 1 (A/B)
     std::vector<int32_t> h_perm;
+    std::vector<int64_t> explain_detail;   // [failed][n][4] of the last explain (Open-Local error sizes), simon_explain_local_detail
+    int explain_nodes = 0;
+    bool explain_ran = false;
     std::vector<int32_t> h_orders;   // host copy of the loaded orders (simon_explain_loaded replays one of them)
     DevBuf<uint64_t> d_mask, d_t_mask;           // static masks by pod class; by table class (simon_table.hip)
     DevBuf<int64_t> d_prefix_cpu, d_prefix_mem, d_prefix_vg;
@@ -1904,7 +1907,9 @@ static int explain_impl(simon_ctx* c, int n_nodes, const int32_t* order, int ran
         rk = c->d_node_rank.p + (size_t)ranked_scenario * c->N;
         iv = c->d_node_inv.p + (size_t)ranked_scenario * c->N;
     }
-    return wide_explain(c->wide, *c, n_nodes, order, failed_pods, fail_codes, max_failed, T, rk, iv, c->stream, c->err);
+    c->explain_nodes = n_nodes;
+    c->explain_ran = true;
+    return wide_explain(c->wide, *c, n_nodes, order, failed_pods, fail_codes, max_failed, T, rk, iv, c->stream, c->err, &c->explain_detail);
 }
 
 int simon_explain(simon_ctx* c, simon_scenario scen, const int32_t* order, int32_t* failed_pods, uint16_t* fail_codes,
@@ -1928,6 +1933,15 @@ int simon_get_stats(simon_ctx* c, simon_stats* st) {
     if (!c || !st) return SIMON_EINVAL;
     *st = c->stats;
     return SIMON_OK;
+}
+
+int simon_explain_local_detail(simon_ctx* c, int64_t* detail, int32_t max_failed) {
+    if (!c || !detail || max_failed <= 0) return c ? fail(c, SIMON_EINVAL, "explain_local_detail: bad arguments") : SIMON_EINVAL;
+    if (!c->explain_ran) return fail(c, SIMON_ESTATE, "explain_local_detail: no simon_explain call yet");
+    const size_t row = (size_t)std::max(c->explain_nodes, 0) * 4;
+    const size_t rows = row ? std::min<size_t>(c->explain_detail.size() / row, (size_t)max_failed) : 0;
+    if (rows) std::memcpy(detail, c->explain_detail.data(), rows * row * sizeof(int64_t));
+    return (int)rows;
 }
 
 int simon_device_results(simon_ctx* c, void** d_unscheduled, void** d_used_cpu, void** d_used_mem) {

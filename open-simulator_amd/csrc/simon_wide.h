@@ -147,6 +147,7 @@ struct WideCold {
     int32_t* st_seen /*[S][seen_stride]: distinct-domain stamps of the soft spread constraints*/;
     // explain outputs (single scenario)
     int32_t* failed_pods; uint16_t* fail_codes; int32_t* n_failed;
+    long long* fail_detail /*[max_failed][n][4]: what Open-Local's error text carries (local_eval DETAIL), or null*/;
     // diagnostics (env SIMON_WIDE_PROF): per (scenario, wave) cycle sums of the phases of a cycle, or null
     unsigned long long* prof;
     // per-scenario nodeTree order (simon_set_node_ranks), rows of the WHOLE batch [S_total][N]: rank of a pool node / node of a
@@ -242,6 +243,6 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
              hipStream_t st, std::string& err);
 int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
                  uint16_t* fail_codes, int32_t max_failed, int T, const int32_t* d_rank_row, const int32_t* d_inv_row, hipStream_t st,
-                 std::string& err);
+                 std::string& err, std::vector<int64_t>* local_detail = nullptr);
 
 }  // namespace simon

@@ -318,15 +318,21 @@ __device__ __forceinline__ unsigned base_score(const Q& q, const NodeLoads& L) {
 //   filter  ProcessLVMPVCPredicate (:59-144) + ProcessDevicePVC (:394-449, CheckExclusiveResourceMeetsPVCSize :290-350)
 //   score   ScoreLVM (Binpack, :660-692) + ScoreDevice (:753-762), MaxScore 10
 //   COMMIT  LocalPlugin.Bind: Requested of the chosen volume groups, IsAllocated of the chosen devices
+//   DETAIL  (simon_explain only) the numbers open-local's error text carries (errors/errors.go), dt[4] = kind, a, b, c:
+//           SIMON_LOCAL_ERR_NO_SUCH_VG (a = interned VG name) | _NO_VG | _LVM (requested, used, capacity of the volume group the
+//           predicate gave up on) | _DEVICE (requested, available, capacity: counts as ProcessDevicePVC passes them)
 struct LocalEval { unsigned code; int score; };
-template <bool COMMIT>
-__device__ LocalEval local_eval(const WideArgs& A, const NodeView& v, const WidePod& p, int j) {
+template <bool COMMIT, bool DETAIL = false>
+__device__ LocalEval local_eval(const WideArgs& A, const NodeView& v, const WidePod& p, int j, long long* dt = nullptr) {
     const simon_local_spec sp = COLD(A)->l_specs[COLD(A)->l_spec_of[p.cls]];
     LocalEval out{0u, 0};
     if (!(COLD(A)->l_flags[j] & 1)) { out.code = SIMON_FAIL_LOCAL; return out; }
     if (sp.n_lvm > 0) {
         const int nvg = COLD(A)->l_vg_cnt[j];
-        if (nvg <= 0) { out.code = SIMON_FAIL_LOCAL_LVM; return out; }            // NewNoAvailableVGError (:109-111)
+        if (nvg <= 0) {                                                            // NewNoAvailableVGError (:109-111)
+            if (DETAIL) { dt[0] = SIMON_LOCAL_ERR_NO_VG; dt[1] = dt[2] = dt[3] = 0; }
+            out.code = SIMON_FAIL_LOCAL_LVM; return out;
+        }
         int64_t* vg = v.st_vg() + (size_t)j * SIMON_MAX_VG;
         long long cap[SIMON_MAX_VG], req[SIMON_MAX_VG], used[SIMON_MAX_VG];
         int name[SIMON_MAX_VG];
@@ -352,7 +358,26 @@ __device__ LocalEval local_eval(const WideArgs& A, const NodeView& v, const Wide
                     pick = q; pick_free = fr;
                 }
             }
-            if (pick < 0 || pick_free < size) { out.code = SIMON_FAIL_LOCAL_LVM; return out; }
+            if (pick < 0 || pick_free < size) {
+                if (DETAIL) {
+                    if (want >= 0 && pick < 0) { dt[0] = SIMON_LOCAL_ERR_NO_SUCH_VG; dt[1] = want; dt[2] = dt[3] = 0; }   // NewNotSuchVGError (:72-74)
+                    else {
+                        // the named group (:79-81), or the LAST group in ascending order of free size (:113-124; equal free sizes: the
+                        // later one in annotation order, as a stable sort leaves them)
+                        int q_err = pick;
+                        if (want < 0) {
+                            long long best = 0;
+#pragma unroll
+                            for (int q = 0; q < SIMON_MAX_VG; ++q)
+                                if (q < nvg && (q_err < 0 || cap[q] - req[q] >= best)) { q_err = q; best = cap[q] - req[q]; }
+                        }
+                        dt[0] = SIMON_LOCAL_ERR_LVM; dt[1] = size;
+#pragma unroll
+                        for (int q = 0; q < SIMON_MAX_VG; ++q) if (q == q_err) { dt[2] = req[q]; dt[3] = cap[q]; }
+                    }
+                }
+                out.code = SIMON_FAIL_LOCAL_LVM; return out;
+            }
 #pragma unroll
             for (int q = 0; q < SIMON_MAX_VG; ++q)
                 if (q == pick) { req[q] += size; used[q] = (used[q] < 0 ? 0 : used[q]) + size; }
@@ -385,7 +410,17 @@ __device__ LocalEval local_eval(const WideArgs& A, const NodeView& v, const Wide
             for (int d = 0; d < SIMON_MAX_LDEV; ++d)
                 if (d < cnt && ((media >> (2 * d)) & 3) == m && !((alloc >> d) & 1)) free_mask |= 1u << d;   // GetFreeDevice (:367-383)
             const int nfree = __popc(free_mask);
-            if (nfree < n_pvc) { out.code = SIMON_FAIL_LOCAL_DEV; return out; }
+            if (nfree < n_pvc) {
+                // both branches of ProcessDevicePVC report the SSD counts (:412-418, :429-435)
+                if (DETAIL) {
+                    unsigned ssd_free = 0;
+#pragma unroll
+                    for (int d = 0; d < SIMON_MAX_LDEV; ++d)
+                        if (d < cnt && ((media >> (2 * d)) & 3) == 1 && !((alloc >> d) & 1)) ssd_free |= 1u << d;
+                    dt[0] = SIMON_LOCAL_ERR_DEVICE; dt[1] = sp.n_ssd; dt[2] = __popc(ssd_free); dt[3] = cnt;
+                }
+                out.code = SIMON_FAIL_LOCAL_DEV; return out;
+            }
             int i = 0;
             for (int step = 0; step < nfree && n_pvc > 0; ++step) {                // devices ascending by (capacity, index)
                 int d = -1;
@@ -397,7 +432,10 @@ __device__ LocalEval local_eval(const WideArgs& A, const NodeView& v, const Wide
                 const long long size = m == 1 ? (i == 0 ? sp.ssd_size[0] : i == 1 ? sp.ssd_size[1] : i == 2 ? sp.ssd_size[2] : sp.ssd_size[3])
                                               : (i == 0 ? sp.hdd_size[0] : i == 1 ? sp.hdd_size[1] : i == 2 ? sp.hdd_size[2] : sp.hdd_size[3]);
                 if (c < size) {
-                    if (step == nfree - 1) { out.code = SIMON_FAIL_LOCAL_DEV; return out; }   // only the last device can fail the match
+                    if (step == nfree - 1) {                                            // only the last device can fail the match (:317-326)
+                        if (DETAIL) { dt[0] = SIMON_LOCAL_ERR_DEVICE; dt[1] = n_pvc; dt[2] = nfree; dt[3] = cnt; }
+                        out.code = SIMON_FAIL_LOCAL_DEV; return out;
+                    }
                     continue;
                 }
                 f += (double)size / (double)c;
@@ -1113,9 +1151,17 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                 if (EXPLAIN) {
                     if (unsched < COLD(A)->max_failed) {
                         if (tid == 0) COLD(A)->failed_pods[unsched] = pid;
-                        for (int j = tid; j < n; j += T)
-                            COLD(A)->fail_codes[(size_t)unsched * n + j] =
-                                (uint16_t)filter_code(A, v, p, j, n, load_state(A, v, j), mask_bit(A, p.cls, j), hard_min);
+                        for (int j = tid; j < n; j += T) {
+                            const unsigned code = filter_code(A, v, p, j, n, load_state(A, v, j), mask_bit(A, p.cls, j), hard_min);
+                            COLD(A)->fail_codes[(size_t)unsched * n + j] = (uint16_t)code;
+                            if constexpr (VAR == 2) {                           // Open-Local: the sizes its error text carries
+                                if ((code == SIMON_FAIL_LOCAL_LVM || code == SIMON_FAIL_LOCAL_DEV) && COLD(A)->fail_detail) {
+                                    long long dt[4] = {0, 0, 0, 0};
+                                    (void)local_eval<false, true>(A, v, p, j, dt);
+                                    for (int q = 0; q < 4; ++q) COLD(A)->fail_detail[((size_t)unsched * n + j) * 4 + q] = dt[q];
+                                }
+                            }
+                        }
                     }
                 }
                 ++unsched;
@@ -1839,16 +1885,19 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
 
 int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t* order, int32_t* failed_pods,
                  uint16_t* fail_codes, int32_t max_failed, int T, const int32_t* d_rank_row, const int32_t* d_inv_row, hipStream_t st,
-                 std::string& err) {
+                 std::string& err, std::vector<int64_t>* local_detail) {
     if ((long long)n_nodes > (long long)kMaxIter * T) { err = "wide kernel: more than 32 nodes per lane"; return SIMON_ERANGE; }
     int rc = ensure_state(w, in, 1, err);
     if (rc) return rc;
     const size_t P = in.P;
     WideScenario hs{n_nodes, 0};
-    void *d_scen = nullptr, *d_order = nullptr, *d_failed = nullptr, *d_codes = nullptr, *d_nf = nullptr, *d_out = nullptr;
+    void *d_scen = nullptr, *d_order = nullptr, *d_failed = nullptr, *d_codes = nullptr, *d_nf = nullptr, *d_out = nullptr, *d_detail = nullptr;
     const size_t code_bytes = (size_t)max_failed * std::max(n_nodes, 1) * 2;
+    const bool want_detail = local_detail && in.has_local;             // Open-Local in the problem: [max_failed][n][4] int64
+    const size_t detail_bytes = want_detail ? code_bytes / 2 * 4 * 8 : 0;
+    if (local_detail) local_detail->clear();
     hipError_t e = hipSuccess;
-    auto cleanup = [&]() { for (void* p : {d_scen, d_order, d_failed, d_codes, d_nf, d_out}) if (p) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void* p : {d_scen, d_order, d_failed, d_codes, d_nf, d_out, d_detail}) if (p) (void)hipFree(p); };
 #define TRY(x) if ((e = (x)) != hipSuccess) { err = std::string(#x ": ") + hipGetErrorString(e); cleanup(); return SIMON_ENODEV; }
     TRY(hipMalloc(&d_scen, sizeof hs)); TRY(hipMalloc(&d_order, std::max<size_t>(P, 1) * 4));
     TRY(hipMalloc(&d_failed, (size_t)max_failed * 4)); TRY(hipMalloc(&d_codes, code_bytes));
@@ -1857,6 +1906,7 @@ int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t
     TRY(hipMemcpyAsync(d_order, order, P * 4, hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_codes, 0, code_bytes, st));
     TRY(hipMemsetAsync(d_nf, 0, 4, st));
+    if (want_detail) { TRY(hipMalloc(&d_detail, detail_bytes)); TRY(hipMemsetAsync(d_detail, 0, detail_bytes, st)); }
     WideArgs a;
     WideCold c;
     rc = ensure_mask_lanes(w, in, T, st, err);
@@ -1871,6 +1921,7 @@ int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t
     a.unscheduled = (int32_t*)d_out; a.used_cpu = (int64_t*)((char*)d_out + 8); a.used_mem = (int64_t*)((char*)d_out + 16);
     a.placement = nullptr;
     c.failed_pods = (int32_t*)d_failed; c.fail_codes = (uint16_t*)d_codes; c.max_failed = max_failed; c.n_failed = (int32_t*)d_nf;
+    c.fail_detail = (long long*)d_detail;
     a.cold = w.d_cold + 1;
     TRY(hipMemcpyAsync(w.d_cold + 1, &c, sizeof c, hipMemcpyHostToDevice, st));
     TRY(hipStreamSynchronize(st));
@@ -1882,6 +1933,10 @@ int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t
     if (k > 0) {
         TRY(hipMemcpy(failed_pods, d_failed, (size_t)k * 4, hipMemcpyDeviceToHost));
         TRY(hipMemcpy(fail_codes, d_codes, (size_t)k * n_nodes * 2, hipMemcpyDeviceToHost));
+        if (want_detail) {
+            local_detail->resize((size_t)k * n_nodes * 4);
+            TRY(hipMemcpy(local_detail->data(), d_detail, (size_t)k * n_nodes * 4 * 8, hipMemcpyDeviceToHost));
+        }
     }
 #undef TRY
     cleanup();

@@ -37,8 +37,52 @@ def taint_reason(key: str, value: str = "") -> str:
     return f"node(s) had taint {{{key}: {value}}}, that the pod didn't tolerate"
 
 
-def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scalar_names: Sequence[str]) -> list:
-    """Status.Reasons() of ONE node for one pod, from its SIMON_FAIL_* code."""
+_BIN_SUFFIX = ["", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei"]
+_DEC_SUFFIX = {0: "", 3: "k", 6: "M", 9: "G", 12: "T", 15: "P", 18: "E"}
+
+
+def quantity_binary_si(value: int) -> str:
+    """resource.NewQuantity(value, resource.BinarySI).String() for an int64 (vendor/k8s.io/apimachinery/pkg/api/resource/
+    quantity.go:407-444 CanonicalizeBytes, amount.go:219-255): below 1024 in magnitude the DecimalSI form (factors of ten moved to an
+    exponent that is a multiple of three: 1000 -> "1k"), else the factors of 1024 become the suffix (2048 -> "2Ki", 1536 -> "1536")."""
+    v = int(value)
+    if v == 0:
+        return "0"
+    sign, amount, exp = ("-" if v < 0 else ""), abs(v), 0
+    if amount < 1024:
+        while amount % 10 == 0:
+            amount //= 10
+            exp += 1
+        while exp % 3:
+            amount *= 10
+            exp -= 1
+        return f"{sign}{amount}{_DEC_SUFFIX[exp]}"
+    while amount % 1024 == 0:
+        amount //= 1024
+        exp += 1
+    return f"{sign}{amount}{_BIN_SUFFIX[exp]}"
+
+
+def local_reason(detail, node_name: str, vg_names: Sequence[str] = ()) -> str:
+    """err.Error() of open-local's predicate (pkg/simulator/plugin/open-local.go:78-88) from a simon_explain_local_detail row
+    {LOCAL_ERR_*, a, b, c}: vendor/github.com/alibaba/open-local/pkg/scheduler/errors/errors.go."""
+    kind, a, b, c = (int(x) for x in detail)
+    if kind == capi.LOCAL_ERR_NO_SUCH_VG:                              # NotSuchVGError.Error(), errors.go:49-51
+        return f"not LVM named {vg_names[a] if 0 <= a < len(vg_names) else a}"
+    if kind == capi.LOCAL_ERR_NO_VG:                                   # NoAvailableVGError.Error(), :70-72
+        return f"not LVM on node {node_name}"
+    if kind == capi.LOCAL_ERR_LVM:                                     # InsufficientLVMError.Error(), :96-102
+        return f"Insufficient LVM storage, requested {quantity_binary_si(a)}, used {quantity_binary_si(b)}, capacity {quantity_binary_si(c)}"
+    if kind == capi.LOCAL_ERR_DEVICE:                                  # InsufficientExclusiveResourceError.Error(), :187-193
+        return (f"Insufficient Device storage, requested {quantity_binary_si(a)}, available {quantity_binary_si(b)}, "
+                f"capacity {quantity_binary_si(c)}")
+    raise ValueError(f"unknown Open-Local error kind {kind}")
+
+
+def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scalar_names: Sequence[str],
+                 local_detail=None, vg_names: Sequence[str] = ()) -> list:
+    """Status.Reasons() of ONE node for one pod, from its SIMON_FAIL_* code (and, for Open-Local's two size-carrying errors, its
+    simon_explain_local_detail row)."""
     if code == 0:
         return []
     if code & capi.FAIL_STATIC:
@@ -57,8 +101,9 @@ def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scal
     if code == capi.FAIL_LOCAL:
         return []                                  # Unschedulable without a reason (plugin/open-local.go:64-69)
     if code in (capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL_DEV):
-        # the reference's reason is open-local's error text, which embeds sizes the per-node code does not carry
-        return ["insufficient local storage (LVM)" if code == capi.FAIL_LOCAL_LVM else "insufficient local storage (device)"]
+        if local_detail is None:
+            raise ValueError("Open-Local's reason embeds sizes: pass the node's simon_explain_local_detail row")
+        return [local_reason(local_detail, node_name, vg_names)]
     if code == capi.FAIL_PORTS:
         return ["node(s) didn't have free ports for the requested pod ports"]     # nodeports/node_ports.go:37
     if code == capi.FAIL_AFFINITY:
@@ -73,13 +118,16 @@ def node_reasons(code: int, node_name: str, static_reasons: Dict[int, str], scal
 
 
 def fit_error(codes: Sequence[int], node_names: Optional[Sequence[str]] = None,
-              static_reasons: Optional[Dict[int, str]] = None, scalar_names: Sequence[str] = ()) -> str:
-    """FitError.Error(): "0/<N> nodes are available: <count> <reason>, ... ." """
+              static_reasons: Optional[Dict[int, str]] = None, scalar_names: Sequence[str] = (),
+              local_detail=None, vg_names: Sequence[str] = ()) -> str:
+    """FitError.Error(): "0/<N> nodes are available: <count> <reason>, ... ."  local_detail: the pod's [n][4] rows of
+    simon_explain_local_detail (needed only when a node fails with FAIL_LOCAL_LVM / FAIL_LOCAL_DEV)."""
     n = len(codes)
     names = node_names if node_names is not None else [f"node-{j}" for j in range(n)]
     hist: Counter = Counter()
     for j, code in enumerate(codes):
-        for r in node_reasons(int(code), names[j], static_reasons or {}, scalar_names):
+        for r in node_reasons(int(code), names[j], static_reasons or {}, scalar_names,
+                              None if local_detail is None else local_detail[j], vg_names):
             hist[r] += 1
     parts = sorted(f"{v} {k}" for k, v in hist.items())               # sort.Strings on the formatted strings
     return f"0/{n} nodes are available: {', '.join(parts)}."

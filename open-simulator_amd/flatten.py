@@ -857,6 +857,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
 
     # ---- Open-Local: node storage and per-class volume specs -------------------------------------------------
     vols = [pod_local_volumes(p, storage_classes) for p in class_rep]
+    vg_name_list: List[str] = []                    # interned volume-group names (local_vg_name / lvm_vg ids -> text, for the reasons)
     if any(v is not None for v in vols):
         storage = [node_local_storage(n) for n in nodes]
         vg_names: Dict[str, int] = {}
@@ -899,6 +900,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 row["hdd_size"][:len(hdd)] = hdd
                 specs.append(row)
             spec_of[c] = spec_ids[key]
+        vg_name_list = sorted(vg_names, key=vg_names.get)
         prob_kw.update(local_flags=lf, local_vg_cnt=vcnt, local_vg_cap=vcap, init_vg_req=vreq, local_vg_name=vname,
                        local_dev_cnt=dcnt, local_dev_cap=dcap, local_dev_media=dmedia, init_dev_alloc=dalloc,
                        local_spec_of=spec_of, local_specs=np.array(specs, capi.LOCAL_SPEC_DTYPE))
@@ -921,4 +923,5 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 pod_refs=[(p["metadata"]["namespace"], p["metadata"]["name"]) for p in pods], pods=pods,
                 static_reasons={v: k for k, v in reason_ids.items()}, scalar_names=scalar_names,
                 pod_class_of=pod_class, const_score=const,
-                info={"n_pod_classes": Cp, "n_node_classes": Cn, "n_terms": T, "n_topology_keys": Kt})
+                info={"n_pod_classes": Cp, "n_node_classes": Cn, "n_terms": T, "n_topology_keys": Kt,
+                      "vg_names": vg_name_list})

@@ -38,9 +38,11 @@ class HipEngine:
             return res
 
     def explain(self, prob: capi.Problem, n_nodes: int, order, max_failed: int):
+        """(n_failed, failed pod ids, [k][n_nodes] failure codes, [k][n_nodes][4] Open-Local error sizes or None)."""
         with capi.Context(self.device_id) as ctx:
             ctx.load_problem(prob)
-            return ctx.explain(n_nodes, order, max_failed)
+            nf, failed, codes = ctx.explain(n_nodes, order, max_failed)
+            return nf, failed, codes, ctx.explain_local_detail(len(failed), n_nodes)
 
 
 @dataclass
@@ -215,11 +217,13 @@ def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine
     out = engine.run(flat.problem, scen, orders, want_gpu_slices=True) if want_gpu else engine.run(flat.problem, scen, orders)
     reasons = {}
     if out.unscheduled[0] > 0:
-        nf, failed, codes = engine.explain(flat.problem, len(nodes), orders[0], int(out.unscheduled[0]))
-        for pid, row in zip(failed.tolist(), codes):
+        nf, failed, codes, detail = engine.explain(flat.problem, len(nodes), orders[0], int(out.unscheduled[0]))
+        for i, (pid, row) in enumerate(zip(failed.tolist(), codes)):
             ns, name = flat.pod_refs[pid]
             reasons[pid] = fiterror.unscheduled_reason(ns, name, row, node_names=flat.node_names,
-                                                       static_reasons=flat.static_reasons, scalar_names=flat.scalar_names)
+                                                       static_reasons=flat.static_reasons, scalar_names=flat.scalar_names,
+                                                       local_detail=None if detail is None else detail[i],
+                                                       vg_names=flat.info.get("vg_names", ()))
     res, per_node, per_dev = _unflatten(flat, out.placement[0], len(nodes), reasons, out.gpu_slices[0] if want_gpu and out.gpu_slices is not None else None)
     res.node_status = [{"node": _gpu_node_status(n, per_dev[j]) if j in per_dev else copy.deepcopy(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
     return res

@@ -14,7 +14,8 @@ Two halves, driven by oracle/run_ref.sh:
       SUBMITTED THEM (the trace; the reference's sort.Sort result and its goroutine-ordered expansion are data, not re-derived),
       the C oracle run on the flattened problem, and a pod-by-pod diff of bound node / FitError text.  Also reports whether
       gosort.py (the go1.18 sort.Sort restatement) reproduces the reference's app-pod order.
-      Exit code 0 = every case identical, 1 = differences, 2 = could not run.
+      Exit code 0 = every case identical, 1 = differences, 2 = could not run.  --engine hip|both puts the HIP library (GPU box) in the
+      oracle's place / next to it (env SIMON_PARITY_ENGINE in run_ref.sh).
 
   python oracle/compare_ref.py selftest --work <dir>
       no Go needed: manufactures a `ref_out.json` from tests/pyref_sched.py (the object-level restatement, which shares nothing
@@ -44,8 +45,16 @@ EXAMPLE_CASES = [    # (name, cluster dir, [(app name, app dir)], new-node dir, 
                                             ("more_pods", "application/more_pods")], "newnode/demo_1", 6),
     ("example_gpushare", "cluster/gpushare", [("gpushare", "application/gpushare")], "", 0),
     ("example_gpushare_1new", "cluster/gpushare", [("gpushare", "application/gpushare")], "newnode/gpushare", 1),
+    # Open-Local: 4 replicas with LVM + one HDD device each on demo_1 -- 3 fail without new nodes (their reasons are
+    # open-local's err.Error() texts with sizes, simon_explain_local_detail), all fit with 3 clones of the storage-carrying template
+    ("example_open_local", "cluster/demo_1", [("open_local", "application/open_local")], "", 0),
+    ("example_open_local_3new", "cluster/demo_1", [("open_local", "application/open_local")], "newnode/demo_1", 3),
 ]
-RANDOM_SEEDS = [(3, {}), (14, {}), (15, {"gpu": True}), (112, {}), (201, {"gpu": True}), (7, {"n_nodes": 40, "n_workloads": 30, "max_replicas": 12})]
+RANDOM_SEEDS = [(3, {}), (14, {}), (15, {"gpu": True}), (112, {}), (201, {"gpu": True}), (7, {"n_nodes": 40, "n_workloads": 30, "max_replicas": 12}),
+                (8, {"local": True}), (20, {"local": True, "gpu": True})]
+# the shapes of rounds 3 / 4 (what `table_kernel` generations 6 / 7 take): Services + preferred self anti-affinity + hard zone constraints +
+# required hostname anti-affinity + tolerations / node selectors (synth.typical_cluster_objects), zones round robin
+TYPICAL_SEEDS = [(1, 30, 24, 10), (5, 48, 40, 14)]          # (seed, nodes, workloads, max replicas)
 
 
 def write_yaml_dir(path, objs):
@@ -69,13 +78,45 @@ def make_cases(ref, work):
         nodes, workloads, services = randk8s.rand_cluster(seed, **kw)
         base = os.path.join(work, "cases", f"random_{seed}")
         write_yaml_dir(os.path.join(base, "cluster"), nodes + services)
-        write_yaml_dir(os.path.join(base, "app"), workloads)
+        write_yaml_dir(os.path.join(base, "app"), workloads + (randk8s.STORAGE_CLASSES if kw.get("local") else []))
         cases.append({"name": f"random_{seed}", "cluster": os.path.join(base, "cluster"), "apps": [{"name": "app", "path": os.path.join(base, "app")}],
+                      "new_node": "", "new_nodes": 0})
+    for name, objs in extra_cases():
+        base = os.path.join(work, "cases", name)
+        write_yaml_dir(os.path.join(base, "cluster"), objs["cluster"])
+        write_yaml_dir(os.path.join(base, "app"), objs["app"])
+        cases.append({"name": name, "cluster": os.path.join(base, "cluster"), "apps": [{"name": "app", "path": os.path.join(base, "app")}],
                       "new_node": "", "new_nodes": 0})
     os.makedirs(work, exist_ok=True)
     with open(os.path.join(work, "cases.json"), "w") as f:
         json.dump({"cases": cases}, f, indent=1)
     return cases
+
+
+def extra_cases():
+    """Generated cases beyond tests/randk8s.py: [(name, {"cluster": [objects], "app": [objects]})]."""
+    import randk8s
+    from open_simulator_amd import synth
+    out = []
+    for seed, n_nodes, n_workloads, max_rep in TYPICAL_SEEDS:
+        nodes, workloads, services = synth.typical_cluster_objects(seed, n_nodes, n_workloads, max_rep)
+        for j, n in enumerate(nodes):
+            if j % 7 != 6:                                             # every seventh node carries no zone label
+                n["metadata"]["labels"][k8s.LABEL_ZONE] = f"z{j % 3}"
+        out.append((f"typical_{seed}", {"cluster": nodes + services, "app": workloads}))
+    # pods that ARRIVE with a gpu-index annotation (open-gpu-share.go:51-81: the filter ignores idle memory, Reserve books the listed
+    # devices): bare pods of a GPU cluster, some naming a device that is too full by then, one with an invalid list
+    nodes, workloads, services = randk8s.rand_cluster(31, n_nodes=8, n_workloads=6, gpu=True)
+    gpu_nodes = [n for n in nodes if "alibabacloud.com/gpu-count" in n["status"]["allocatable"]]
+    bare = []
+    for i, idx in enumerate(["0", "1", "0-1", "0", "00-1", "x", "1"]):
+        bare.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": f"arrive-{i}", "namespace": "default",
+                                                                    "annotations": {"alibabacloud.com/gpu-mem": f"{[4, 8, 6, 12, 2, 4, 8][i]}Gi", "alibabacloud.com/gpu-count": str(len(idx.split("-"))) if idx != "x" else "1",
+                                                                                    "alibabacloud.com/gpu-index": idx}},
+                     "spec": {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"cpu": "500m", "memory": "1Gi"}}}]}})
+    if gpu_nodes:
+        out.append(("gpu_index_arriving", {"cluster": nodes + services, "app": bare + workloads}))
+    return out
 
 
 # ---- the mirror's side of one case ------------------------------------------------------------------------------------
@@ -156,11 +197,12 @@ def compare_case(case, ref_res, engine):
     out = engine.run(flat.problem, scen, orders)
     reasons = {}
     if out.unscheduled[0] > 0:
-        _, failed, codes = engine.explain(flat.problem, len(nodes_c), orders[0], int(out.unscheduled[0]))
-        for pid, row in zip(failed.tolist(), codes):
+        _, failed, codes, detail = engine.explain(flat.problem, len(nodes_c), orders[0], int(out.unscheduled[0]))
+        for i, (pid, row) in enumerate(zip(failed.tolist(), codes)):
             ns, name = flat.pod_refs[pid]
             reasons[pid] = fiterror.unscheduled_reason(ns, name, row, node_names=flat.node_names, static_reasons=flat.static_reasons,
-                                                       scalar_names=flat.scalar_names)
+                                                       scalar_names=flat.scalar_names, local_detail=None if detail is None else detail[i],
+                                                       vg_names=flat.info.get("vg_names", ()))
     diffs = []
     for i, e in enumerate(trace):
         j = int(out.placement[0][i])
@@ -189,7 +231,34 @@ class OracleEngine:
     def explain(self, prob, n_nodes, order, max_failed):
         import oracle_lib
         _, (nf, failed, codes) = oracle_lib.run(prob, [[n_nodes, 0]], np.asarray(order)[None], explain_scenario=0, max_failed=max_failed)
-        return nf, failed, codes
+        return nf, failed, codes, oracle_lib.LAST_LOCAL_DETAIL[0]
+
+
+class BothEngines:
+    """--engine both: every case through the C oracle AND the HIP library (a GPU box), which must agree before either is compared with
+    the reference -- so a difference is attributed to the right side."""
+
+    def __init__(self):
+        self.oracle, self.hip = OracleEngine(), sim.HipEngine()
+
+    def run(self, prob, scen, orders, want_placement=True, node_ranks=None, want_gpu_slices=False):
+        a = self.oracle.run(prob, scen, orders, want_placement, node_ranks, want_gpu_slices)
+        b = self.hip.run(prob, scen, orders, want_placement, node_ranks=node_ranks, want_gpu_slices=want_gpu_slices)
+        if not ((a.placement == b.placement).all() and a.unscheduled.tolist() == b.unscheduled.tolist()):
+            raise AssertionError("the HIP engine and the C oracle disagree on this case (before any comparison with the reference)")
+        return b
+
+    def explain(self, prob, n_nodes, order, max_failed):
+        a, b = self.oracle.explain(prob, n_nodes, order, max_failed), self.hip.explain(prob, n_nodes, order, max_failed)
+        same = a[0] == b[0] and a[1].tolist() == b[1].tolist() and (a[2] == b[2]).all() and \
+            ((a[3] is None and b[3] is None) or (a[3] == b[3]).all())
+        if not same:
+            raise AssertionError("the HIP engine and the C oracle disagree on the failure codes of this case")
+        return b
+
+
+def make_engine(kind):
+    return {"oracle": OracleEngine, "hip": sim.HipEngine, "both": BothEngines}[kind]()
 
 
 def compare(work, ref_out, engine=None, verbose=True):
@@ -226,17 +295,11 @@ def selftest(work):
     """The comparison machinery without Go: `ref_out.json` comes from the object-level restatement tests/pyref_sched.py, with the
     pods shuffled inside the freedom sort.Sort has and the clones renamed as utils.NewFakeNodes would."""
     import pyref_sched
-    import randk8s
     rng = np.random.default_rng(7)
-    cases = []
-    for seed, kw in [(3, {}), (15, {"gpu": True})]:
-        nodes, workloads, services = randk8s.rand_cluster(seed, **kw)
-        base = os.path.join(work, "cases", f"random_{seed}")
-        write_yaml_dir(os.path.join(base, "cluster"), nodes + services)
-        write_yaml_dir(os.path.join(base, "app"), workloads)
-        cases.append({"name": f"random_{seed}", "cluster": os.path.join(base, "cluster"), "apps": [{"name": "app", "path": os.path.join(base, "app")}],
-                      "new_node": "", "new_nodes": 0})
-    os.makedirs(work, exist_ok=True)
+    # the generated cases of the real manifest (no example/ inputs: they need the reference tree), a few of each kind
+    picked = ("random_3", "random_15", "random_8", "typical_1", "gpu_index_arriving")
+    cases = [c for c in make_cases("/nonexistent", work) if c["name"] in picked]
+    assert len(cases) == len(picked), [c["name"] for c in cases]
     with open(os.path.join(work, "cases.json"), "w") as f:
         json.dump({"cases": cases}, f)
     results = []
@@ -256,7 +319,7 @@ def selftest(work):
                           "workload_name": a.get(wl.ANNO_WORKLOAD_NAME, ""), "workload_namespace": a.get(wl.ANNO_WORKLOAD_NAMESPACE, ""),
                           "app": (md.get("labels") or {}).get(wl.LABEL_APP_NAME, ""), "has_node_selector": p["spec"].get("nodeSelector") is not None,
                           "has_tolerations": p["spec"].get("tolerations") is not None, "preset_node": p["spec"].get("nodeName") or "",
-                          "pin_node": p.get("_daemon_node", ""), "node": node or "", "reason": ""})
+                          "pin_node": p.get("_daemon_node", ""), "node": node or "", "reason": ""})   # (no reason: only the bindings are compared here)
             if not trace[-1]["workload_kind"]:
                 trace[-1]["name"] = md["name"]                        # bare pods keep their names
         results.append({"name": case["name"], "nodes": [n["metadata"]["name"] for n in nodes], "new_nodes": [], "trace": trace,
@@ -283,6 +346,9 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--work", default=os.path.join(ROOT, "oracle", "_ref", "work"))
     ap.add_argument("--ref-out", default=None)
+    ap.add_argument("--engine", choices=["oracle", "hip", "both"], default="oracle",
+                    help="compare: what the reference's output is compared with -- the C oracle (default, no GPU needed), the HIP library "
+                         "through simulate.HipEngine, or both (they must agree first)")
     a = ap.parse_args()
     if a.mode == "cases":
         cases = make_cases(a.ref, a.work)
@@ -290,7 +356,7 @@ def main():
         return 0
     if a.mode == "selftest":
         return selftest(a.work)
-    return compare(a.work, a.ref_out or os.path.join(a.work, "ref_out.json"))
+    return compare(a.work, a.ref_out or os.path.join(a.work, "ref_out.json"), engine=make_engine(a.engine))
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@
 #      own example/ inputs + seeded random clusters as YAML): per pod, in submission order, the node it was bound to / the FitError;
 #   4. oracle/compare_ref.py compare: the same inputs through the Python mirror + the C oracle with the reference's pod order as
 #      data; placements and reasons diffed pod by pod.  Exit code 0 = identical (or SKIP), 1 = differences, 2 = the job broke.
+#      SIMON_PARITY_ENGINE=hip|both (GPU box) compares the HIP library's placements / reasons instead of / next to the oracle's.
 # Everything it produces stays under oracle/_ref/ (git-ignored).  Optional: REF=/path/to/open-simulator  GO=/path/to/go
 set -u
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -46,4 +47,4 @@ python3 "$HERE/compare_ref.py" cases --ref "$WORK/src" --work "$WORK" || exit 2
 rc=$?
 tail -5 "$WORK/go_test.log"
 if [ $rc -ne 0 ] || [ ! -s "$WORK/ref_out.json" ]; then echo "FAILED: the determinised reference did not run (see $WORK/go_test.log)"; exit 2; fi
-python3 "$HERE/compare_ref.py" compare --work "$WORK" --ref-out "$WORK/ref_out.json"
+python3 "$HERE/compare_ref.py" compare --work "$WORK" --ref-out "$WORK/ref_out.json" --engine "${SIMON_PARITY_ENGINE:-oracle}"

@@ -32,6 +32,10 @@ int simon_oracle_run(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
                      int32_t explain_scenario, int32_t* failed_pods, uint16_t* fail_codes,
                      int32_t max_failed, int32_t* n_failed_out);
 
+/* Where the NEXT explaining run leaves what Open-Local's error texts carry: [max_failed][n_nodes of the scenario][4] int64
+ * {SIMON_LOCAL_ERR_*, a, b, c} (include/simon_hip.h), zero-initialised by the caller; NULL switches it off. */
+void simon_oracle_set_local_detail(int64_t* buf);
+
 /* The same with a canonical node order per scenario: node_rank[s][j] = position of pool node j in scenario s's nodeTree
  * order (V/internal/cache/node_tree.go:119-143); selectHost's first maximum is taken in that order. */
 int simon_oracle_run_ranked(const simon_nodes_soa* nodes, const simon_pods_soa* pods,

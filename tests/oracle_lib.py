@@ -50,6 +50,9 @@ def load():
     return lib
 
 
+LAST_LOCAL_DETAIL = [None]        # [k][n][4] of the last explaining run() (None without Open-Local in the problem)
+
+
 def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=-1, max_failed=0, node_ranks=None, want_gpu_slices=False):
     """Run scenarios on the oracle; returns BatchResult (+ (n_failed, failed_pods, codes) when explaining).
     Thread-safe without node_ranks (the ranked entry keeps the current scenario's ranks in a global)."""
@@ -70,12 +73,19 @@ def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=
         failed = np.full(max_failed, -1, np.int32)
         codes = np.zeros((max_failed, nmax), np.uint16)
         nf = C.c_int32(0)
-        rc = lib.simon_oracle_run_ranked(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
-                                         C.c_int32(len(scen)), capi._ptr(orders, C.c_int32), C.c_int32(orders.shape[0]),
-                                         capi._ptr(ranks, C.c_int32), C.byref(out), C.c_int32(explain_scenario),
-                                         capi._ptr(failed, C.c_int32), capi._ptr(codes, C.c_uint16), C.c_int32(max_failed), C.byref(nf))
+        detail = np.zeros((max_failed, nmax, 4), np.int64)          # what Open-Local's error texts carry (simon_explain_local_detail)
+        lib.simon_oracle_set_local_detail.argtypes = [C.c_void_p]
+        lib.simon_oracle_set_local_detail(detail.ctypes.data_as(C.c_void_p) if prob.local_flags is not None and max_failed > 0 else None)
+        try:
+            rc = lib.simon_oracle_run_ranked(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),
+                                             C.c_int32(len(scen)), capi._ptr(orders, C.c_int32), C.c_int32(orders.shape[0]),
+                                             capi._ptr(ranks, C.c_int32), C.byref(out), C.c_int32(explain_scenario),
+                                             capi._ptr(failed, C.c_int32), capi._ptr(codes, C.c_uint16), C.c_int32(max_failed), C.byref(nf))
+        finally:
+            lib.simon_oracle_set_local_detail(None)
         assert rc == 0, rc
         k = min(nf.value, max_failed)
+        LAST_LOCAL_DETAIL[0] = detail[:k] if prob.local_flags is not None else None
         return res, (nf.value, failed[:k], codes[:k])
     if ranks is not None:
         rc = lib.simon_oracle_run_ranked(C.byref(n), C.byref(p), C.byref(t), scen.ctypes.data_as(C.POINTER(capi.Scenario)),

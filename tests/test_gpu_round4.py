@@ -185,3 +185,30 @@ def test_min_plan_device_hands_out_the_key(monkeypatch):
         hip = C.CDLL("libamdhip64.so")
         assert hip.hipMemcpy(C.c_void_p(key.data_ptr()), d_key, C.c_size_t(8), C.c_int(2)) == 0        # hipMemcpyDeviceToHost
         assert int(key.item()) == (plan.n_nodes << 32 | plan.scenario)
+
+
+@pytest.mark.parametrize("seed", [3, 11, 12])
+def test_open_local_error_sizes_match_the_oracle(seed):
+    """simon_explain_local_detail (ABI v5): for every node that fails a pod with SIMON_FAIL_LOCAL_LVM / _DEV the numbers open-local's
+    error text carries -- err.Error() is the plugin's reason, pkg/simulator/plugin/open-local.go:78-88 -- must be the oracle's, and
+    with them the whole FitError string."""
+    from open_simulator_amd import fiterror
+    prob = randprob.rand_problem(seed, N=40, P=400, local=True, tight_pods=(seed % 2 == 1), init_state=True)
+    scen, orders = randprob.rand_scenarios(seed, prob, S=2)
+    n = int(scen[0, 0])
+    ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=48)
+    want = O.LAST_LOCAL_DETAIL[0]
+    assert nf > 0 and np.isin(codes, (capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL_DEV)).any(), "the case must exercise Open-Local failures"
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        with pytest.raises(capi.SimonError):
+            ctx.explain_local_detail(1, n)                                  # nothing explained yet
+        n2, f2, c2 = ctx.explain(n, orders[scen[0, 1]], max_failed=48)
+        got = ctx.explain_local_detail(len(f2), n)
+    assert n2 == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
+    assert got is not None and got.shape == want.shape
+    assert (got == want).all(), np.argwhere(got != want)[:5]
+    kinds = set(np.unique(got[..., 0]).tolist())
+    assert kinds & {capi.LOCAL_ERR_LVM, capi.LOCAL_ERR_DEVICE}
+    for i in range(len(f2)):
+        assert fiterror.fit_error(c2[i], local_detail=got[i]) == fiterror.fit_error(codes[i], local_detail=want[i])

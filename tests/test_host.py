@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import numpy as np
 
 import oracle_lib as O
@@ -156,3 +158,30 @@ def test_bench_final_line_fits_the_driver(capsys, tmp_path, monkeypatch):
     assert d["parity_sample"] == {"scenarios": 2376, "placement_rows": 2376, "mismatches": 0}
     assert len(d["digest"]["rows"]) == 21 and d["digest"]["rows"][0][0] == "config2" and len(d["digest"]["cols"]) == len(d["digest"]["rows"][0])
     assert json.load(open(side)) == full                                         # nothing is lost: the sidecar holds the whole record
+
+
+def test_quantity_binary_si_and_open_local_reason_texts():
+    """UnscheduledPod.Reason for Open-Local failures is err.Error() of open-local's predicate (pkg/simulator/plugin/open-local.go:78-88).
+    The strings below are written out by hand from vendor/github.com/alibaba/open-local/pkg/scheduler/errors/errors.go (formats) and
+    vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go:407-444 (resource.NewQuantity(x, BinarySI).String())."""
+    from open_simulator_amd import capi, fiterror
+    q = fiterror.quantity_binary_si
+    # below 1024: DecimalSI with an exponent that is a multiple of three; from 1024 on: the factors of 1024 become the suffix
+    assert [q(v) for v in (0, 1, 20, 100, 999, 1000, 1023)] == ["0", "1", "20", "100", "999", "1k", "1023"]
+    assert [q(v) for v in (1024, 1025, 1536, 2048, 1 << 20, 3 << 20, 1 << 30, 100 << 30, 1500 << 20, 1 << 40, 1 << 60)] == \
+        ["1Ki", "1025", "1536", "2Ki", "1Mi", "3Mi", "1Gi", "100Gi", "1500Mi", "1Ti", "1Ei"]
+    G = 1 << 30
+    r = fiterror.local_reason
+    assert r([capi.LOCAL_ERR_LVM, 40 * G, 170 * G, 200 * G], "n1") == "Insufficient LVM storage, requested 40Gi, used 170Gi, capacity 200Gi"
+    assert r([capi.LOCAL_ERR_NO_VG, 0, 0, 0], "worker-7") == "not LVM on node worker-7"
+    assert r([capi.LOCAL_ERR_NO_SUCH_VG, 1, 0, 0], "n1", ["yoda-pool0", "share"]) == "not LVM named share"
+    assert r([capi.LOCAL_ERR_DEVICE, 2, 1, 4], "n1") == "Insufficient Device storage, requested 2, available 1, capacity 4"
+    # the histogram counts each distinct text (generic_scheduler.go:72-90): two nodes with the same sizes share an entry
+    codes = [capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL, capi.FAIL_LOCAL_DEV, capi.FAIL_LOCAL_LVM]
+    detail = [[capi.LOCAL_ERR_LVM, 10 * G, 95 * G, 100 * G], [capi.LOCAL_ERR_LVM, 10 * G, 95 * G, 100 * G], [0, 0, 0, 0],
+              [capi.LOCAL_ERR_DEVICE, 1, 0, 2], [capi.LOCAL_ERR_NO_VG, 0, 0, 0]]
+    assert fiterror.fit_error(codes, node_names=list("abcde"), local_detail=detail) == (
+        "0/5 nodes are available: 1 Insufficient Device storage, requested 1, available 0, capacity 2, "
+        "1 not LVM on node e, 2 Insufficient LVM storage, requested 10Gi, used 95Gi, capacity 100Gi.")
+    with pytest.raises(ValueError):
+        fiterror.fit_error(codes)                                      # the sizes are not optional

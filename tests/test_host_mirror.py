@@ -27,7 +27,7 @@ class OracleEngine:
 
     def explain(self, prob, n_nodes, order, max_failed):
         _, (nf, failed, codes) = O.run(prob, [[n_nodes, 0]], np.asarray(order)[None], explain_scenario=0, max_failed=max_failed)
-        return nf, failed, codes
+        return nf, failed, codes, O.LAST_LOCAL_DETAIL[0]
 
 
 def load_k8s_fixture(name):
@@ -150,9 +150,10 @@ def test_reference_open_local_example_end_to_end():
     assert capped.vg_pct[3] == 10 and capped.vg_pct[4] == 8 and capped.best == 4
     one = sim.simulate(cluster, [app], engine=OracleEngine())
     assert [u["pod"]["metadata"]["name"] for u in one.unscheduled_pods] == ["nginx-lvm-1", "nginx-lvm-2", "nginx-lvm-3"]
-    # master-1 is tainted, master-2/3 have no storage annotation (Unschedulable without a reason), worker-1's device is taken
+    # master-1 is tainted, master-2/3 have no storage annotation (Unschedulable without a reason), worker-1's one device is taken:
+    # ProcessDevicePVC's hdd branch reports the SSD counts (algo/common.go:428-434) -- 0 requested, 0 free -- and the node's device total
     assert one.unscheduled_pods[0]["reason"].endswith(
-        "0/4 nodes are available: 1 insufficient local storage (device), 1 node(s) had taint {node-role.kubernetes.io/master: }, "
+        "0/4 nodes are available: 1 Insufficient Device storage, requested 0, available 0, capacity 1, 1 node(s) had taint {node-role.kubernetes.io/master: }, "
         "that the pod didn't tolerate.")
     del root
 

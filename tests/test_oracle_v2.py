@@ -242,3 +242,47 @@ def test_reciprocal_division_is_the_ieee_quotient():
     out = subprocess.run([exe, "150000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert " 0 mismatches" in out.stdout
+
+
+def test_open_local_error_sizes_of_the_oracle():
+    """What the explaining run reports next to SIMON_FAIL_LOCAL_LVM / _DEV (simon_explain_local_detail's contract), on a hand-made
+    pool -- each row follows one return statement of open-local's algo/common.go:
+    node 0: two groups (100Gi with 95Gi requested, 50Gi with 20Gi requested), the pod wants 40Gi without a group name -> the groups
+            sorted ascending by free size are [5Gi, 30Gi], the LAST one fails the request (:113-124): requested 40Gi, used 20Gi, capacity 50Gi
+    node 1: storage annotation without any group -> NoAvailableVGError (:104-106)
+    node 2: no local storage at all -> SIMON_FAIL_LOCAL, no detail
+    node 3: a second group (100Gi, empty) fits, but the pod also wants one SSD and the node's two devices are HDDs -> count check (:412-418): 1, 0, 2
+    The second pod class names group 7, which only node 3 has, full: :79-81 there (requested 40Gi, used 60Gi, capacity 80Gi), NotSuchVG (:72-74)
+    on node 0, NoAvailableVG on node 1."""
+    G = 1 << 30
+    N, P = 4, 2
+    specs = np.zeros(2, capi.LOCAL_SPEC_DTYPE)
+    specs[0]["n_lvm"], specs[0]["n_ssd"] = 1, 1
+    specs[0]["lvm_size"][0], specs[0]["lvm_vg"][:] = 40 * G, -1
+    specs[0]["ssd_size"][0] = 10 * G
+    specs[1]["n_lvm"] = 1
+    specs[1]["lvm_size"][0], specs[1]["lvm_vg"][:] = 40 * G, -1
+    specs[1]["lvm_vg"][0] = 7
+    vg_cap = np.zeros((N, capi.MAX_VG), np.int64); vg_req = np.zeros((N, capi.MAX_VG), np.int64); vg_name = np.full((N, capi.MAX_VG), -1, np.int32)
+    vg_cap[0, :2], vg_req[0, :2], vg_name[0, :2] = [100 * G, 50 * G], [95 * G, 20 * G], [1, 2]
+    vg_cap[3, :2], vg_req[3, :2], vg_name[3, :2] = [80 * G, 100 * G], [60 * G, 0], [7, 8]
+    dev_cap = np.zeros((N, capi.MAX_LDEV), np.int64)
+    dev_cap[3, :2] = [100 * G, 100 * G]
+    prob = capi.Problem(
+        alloc_cpu=np.full(N, 8000), alloc_mem=np.full(N, 16 * G), alloc_pods=np.full(N, 110),
+        req_cpu=np.full(P, 100), req_mem=np.full(P, G), pod_class=np.array([0, 1], np.int32), n_pod_classes=2, n_node_classes=1,
+        node_class=np.zeros(N, np.int32), simon_raw=np.zeros((2, 1), np.int64),
+        local_flags=np.array([1, 1, 0, 1], np.int32), local_vg_cnt=np.array([2, 0, 0, 2], np.int32), local_vg_cap=vg_cap, init_vg_req=vg_req,
+        local_vg_name=vg_name, local_dev_cnt=np.array([0, 0, 0, 2], np.int32), local_dev_cap=dev_cap,
+        local_dev_media=np.array([0, 0, 0, 2 | (2 << 2)], np.int32), init_dev_alloc=np.zeros(N, np.int32),
+        local_spec_of=np.array([0, 1], np.int32), local_specs=specs).normalise()
+    res, (nf, failed, codes) = O.run(prob, [[N, 0]], np.arange(P, dtype=np.int32)[None], explain_scenario=0, max_failed=4)
+    assert nf == 2 and failed.tolist() == [0, 1]
+    assert codes[0].tolist() == [capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL, capi.FAIL_LOCAL_DEV]
+    assert codes[1].tolist() == [capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL_LVM, capi.FAIL_LOCAL, capi.FAIL_LOCAL_LVM]
+    d = O.LAST_LOCAL_DETAIL[0]
+    assert d[0].tolist() == [[capi.LOCAL_ERR_LVM, 40 * G, 20 * G, 50 * G], [capi.LOCAL_ERR_NO_VG, 0, 0, 0], [0, 0, 0, 0], [capi.LOCAL_ERR_DEVICE, 1, 0, 2]]
+    assert d[1].tolist() == [[capi.LOCAL_ERR_NO_SUCH_VG, 7, 0, 0], [capi.LOCAL_ERR_NO_VG, 0, 0, 0], [0, 0, 0, 0], [capi.LOCAL_ERR_LVM, 40 * G, 60 * G, 80 * G]]
+    from open_simulator_amd import fiterror
+    assert fiterror.fit_error(codes[1], node_names=["a", "b", "c", "d"], local_detail=d[1], vg_names=[str(i) for i in range(7)] + ["pool7"]) == (
+        "0/4 nodes are available: 1 Insufficient LVM storage, requested 40Gi, used 60Gi, capacity 80Gi, 1 not LVM named pool7, 1 not LVM on node b.")

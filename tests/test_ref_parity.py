@@ -72,3 +72,32 @@ def test_gosort_sorts_and_is_deterministic():
     # below 12 elements: ShellSort pass with gap 6 + insertion sort only -- a hand-checkable vector (flags 0 0 1 0 1)
     small = gosort.sort_by_unary_less([("a", False), ("b", False), ("c", True), ("d", False), ("e", True)], lambda x: x[1])
     assert [x[0] for x in small] == ["e", "c", "a", "b", "d"]
+
+
+def test_gosort_against_the_second_restatement_and_committed_vectors():
+    """open-simulator_amd/gosort.py (product path: the mirror's pod order) against oracle/gosort_check.c, an independent C restatement of
+    the published go1.18 sort.go: committed vectors of lengths 13 ... 60 (tests/golden/gosort_vectors.json: quickSort, ninther and
+    duplicate-protection branches) and, when the checker is built, 400 random flag vectors.  Not a Go binary: parity unpinned."""
+    import json
+    from open_simulator_amd import gosort
+    with open(os.path.join(ROOT, "tests", "golden", "gosort_vectors.json")) as f:
+        vectors = json.load(f)["vectors"]
+    assert len(vectors) >= 3 and {len(v["flags"]) for v in vectors} >= {13, 29, 41, 50}
+
+    def mine(flags):
+        items = list(enumerate(c == "1" for c in flags))
+        return [i for i, _ in gosort.sort_by_unary_less(items, lambda x: x[1])]
+    for v in vectors:
+        assert mine(v["flags"]) == v["order"], v["flags"]
+        k = v["flags"].count("1")
+        assert all(v["flags"][i] == "1" for i in v["order"][:k])          # flagged pods first, whatever the permutation inside
+    exe = os.path.join(ROOT, "oracle", "gosort_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "gosort_check"], check=True)
+    rnd = random.Random(11)
+    for _ in range(400):
+        n = rnd.choice(list(range(1, 80)) + [100, 257, 1000])
+        p = rnd.choice([0.05, 0.3, 0.5, 0.8, 0.95])
+        flags = "".join("1" if rnd.random() < p else "0" for _ in range(n))
+        out = subprocess.run([exe, flags], capture_output=True, text=True, check=True).stdout.split()
+        assert [int(x) for x in out] == mine(flags), flags
