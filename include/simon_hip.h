@@ -32,6 +32,7 @@
 #ifndef SIMON_HIP_H
 #define SIMON_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -300,6 +301,9 @@ typedef struct simon_batch_out {
                                       simon/node-gpu-share is summed from (open-gpu-share.go:171-175).  0 for pods without a GPU request, unplaced pods and
                                       pods bound by Spec.NodeName (they never reach Reserve).  optional (NULL = not recorded / not fetched) */
 } simon_batch_out;
+/* struct_size guards: the library takes the current layout and the ABI v3 one, which ended before gpu_slices (a v3 caller simply
+ * gets no device record) -- anything else is refused with SIMON_EINVAL. */
+#define SIMON_BATCH_OUT_SIZE_V3 ((uint32_t)offsetof(simon_batch_out, gpu_slices))
 
 /* Result of the add-nodes search (pkg/apply/apply.go:203-259 + satisfyResourceSetting :689-775) */
 typedef struct simon_plan {

@@ -775,16 +775,16 @@ class Group:
         flags = (WANT_PLACEMENT if want_placement else 0) | (WANT_GPU_SLICES if want_gpu_slices else 0)
         self._check(self.lib.simon_group_run_loaded(self.h, flags), "simon_group_run_loaded")
 
-    def fetch(self, want_placement: bool = True) -> BatchResult:
-        res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement)
+    def fetch(self, want_placement: bool = True, want_gpu_slices: bool = False) -> BatchResult:
+        res = BatchResult.alloc(self.S, self.problem.n_pods, want_placement, want_gpu_slices)
         out = res.c_out()
         self._check(self.lib.simon_group_fetch_results(self.h, C.byref(out)), "simon_group_fetch_results")
         return res
 
-    def run_batch(self, scen, orders: np.ndarray, want_placement: bool = True) -> BatchResult:
+    def run_batch(self, scen, orders: np.ndarray, want_placement: bool = True, want_gpu_slices: bool = False) -> BatchResult:
         self.load_scenarios(scen, orders)
-        self.run_loaded(want_placement)
-        return self.fetch(want_placement)
+        self.run_loaded(want_placement, want_gpu_slices)
+        return self.fetch(want_placement, want_gpu_slices)
 
     def fetch_placement(self, scenario: int) -> np.ndarray:
         row = np.zeros(self.problem.n_pods, np.int32)

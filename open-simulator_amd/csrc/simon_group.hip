@@ -129,6 +129,16 @@ void rccl_teardown(simon_group* g) {
     if (g->rccl) dlclose(g->rccl);
 }
 
+// simon_batch_out as the caller filled it, widened to the current layout: a v3 struct (no gpu_slices member) reads as gpu_slices = NULL
+bool batch_out_view(const simon_batch_out* out, simon_batch_out* v) {
+    if (out->struct_size == sizeof(simon_batch_out)) { *v = *out; return true; }
+    if (out->struct_size != SIMON_BATCH_OUT_SIZE_V3) return false;
+    std::memset(v, 0, sizeof *v);
+    std::memcpy(v, out, SIMON_BATCH_OUT_SIZE_V3);
+    v->struct_size = sizeof *v;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -216,9 +226,10 @@ int simon_group_run_loaded(simon_group* g, int32_t want_placement) {
     return rc;
 }
 
-int simon_group_fetch_results(simon_group* g, simon_batch_out* out) {
-    if (!g || !out) return SIMON_EINVAL;
-    if (out->struct_size != sizeof(simon_batch_out)) return gfail(g, SIMON_EINVAL, "simon_batch_out size mismatch");
+int simon_group_fetch_results(simon_group* g, simon_batch_out* caller_out) {
+    if (!g || !caller_out) return SIMON_EINVAL;
+    simon_batch_out view, *out = &view;
+    if (!batch_out_view(caller_out, out)) return gfail(g, SIMON_EINVAL, "simon_batch_out size mismatch");
     if (!g->have_results) return gfail(g, SIMON_ESTATE, "group fetch_results: nothing has run");
     if (out->placement && !g->have_placement) return gfail(g, SIMON_ESTATE, "group fetch_results: the last run skipped placements");
     const int n = (int)g->ctx.size();
@@ -253,11 +264,13 @@ int simon_group_fetch_results(simon_group* g, simon_batch_out* out) {
 int simon_group_run_batch(simon_group* g, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
                           simon_batch_out* out) {
     if (!g || !out) return SIMON_EINVAL;
+    simon_batch_out view;
+    if (!batch_out_view(out, &view)) return gfail(g, SIMON_EINVAL, "simon_batch_out size mismatch");
     int rc = simon_group_load_scenarios(g, scen, S, orders, n_orders);
     if (rc) return rc;
-    rc = simon_group_run_loaded(g, (out->placement ? SIMON_WANT_PLACEMENT : 0) | (out->gpu_slices ? SIMON_WANT_GPU_SLICES : 0));
+    rc = simon_group_run_loaded(g, (view.placement ? SIMON_WANT_PLACEMENT : 0) | (view.gpu_slices ? SIMON_WANT_GPU_SLICES : 0));
     if (rc) return rc;
-    return simon_group_fetch_results(g, out);
+    return simon_group_fetch_results(g, &view);
 }
 
 int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* placement) {

@@ -109,7 +109,7 @@ struct simon_ctx : simon::HostInputs {
     bool has_static = false;                     // static score tables present (score-table kernel: class term; else all-feature kernel)
     DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
-    bool no_gpu_split = false, force_table = false;
+    bool no_gpu_split = false, force_table = false, no_class_content = false;
     bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     // fold: required anti-affinity / host ports on node-level topology keys as MONOTONE INFEASIBILITY of the score table -- a pod that
@@ -329,7 +329,18 @@ bool spread_supported(simon_ctx* c) {
     if (c->topo_is_hostname.empty()) return false;
     if (!c->ss_idx.empty() && c->spread_log.size() < (size_t)c->N + 1) return false;
     int64_t max_pods = 0;
-    for (int32_t x : c->alloc_pods) { if (x > 255) return false; max_pods = std::max<int64_t>(max_pods, x); }   // the per-position counters are bytes
+    // the per-position counters are bytes.  Pods that pass NodeResourcesFit number at most alloc_pods on a node; pods bound by
+    // Spec.NodeName (presets) skip the filters (V/eventhandlers.go:223-236) and come on top
+    {
+        std::vector<int32_t> preset_on(c->N, 0);
+        for (int p = 0; p < c->P && !c->p_preset.empty(); ++p)
+            if (c->p_preset[p] >= 0 && c->p_preset[p] < c->N) ++preset_on[c->p_preset[p]];
+        for (int j = 0; j < c->N; ++j) {
+            const int64_t x = (int64_t)c->alloc_pods[j] + preset_on[j];
+            if (x > 255) return false;
+            max_pods = std::max<int64_t>(max_pods, x);
+        }
+    }
     // ids: t < Tm = the pods MATCHING term t; Tm + t = the pods OWNING a scoring term t (one weight per pod: InterPodAffinity below)
     c->sp_kind.assign(2 * (size_t)c->Tm, 0); c->sp_row.assign(2 * (size_t)c->Tm, 0); c->sp_zslot.assign(2 * (size_t)c->Tm, 0);
     c->sp_zkeys.clear();
@@ -939,13 +950,33 @@ int stage_narrow(simon_ctx* c) {
         // SPREAD: a class is also split by the domains of the zone-like keys of the soft spread terms (sub = the domains, 5 bits each, 0 =
         // the label is missing): a summary unit then has ONE zone term and "which zones hold a scored node" follows from the feasible-node
         // counters per (signature, class).
+        // The caller's node classes are interned by CONTENT first -- the class's column of every (pod class, node class) table the kernel
+        // reads (Simon raw score, NodeAffinity preferred, TaintToleration PreferNoSchedule, weighted additions), over the table classes in
+        // use.  A host that derives node classes from label / taint sets hands over hundreds (464 in profiles/e2e_sweep.py's mix of 3
+        // capacities) of which few differ in those columns; the static filters are per node (static_mask), not per class.
+        // (SIMON_TABLE_NO_CLASS_CONTENT=1: the caller's ids as they come -- A/B and tests.)
+        std::vector<int32_t> content_of(std::max(c->Cn, 1));
+        {
+            std::map<std::vector<int32_t>, int> col_id;
+            for (int nc = 0; nc < c->Cn; ++nc) {
+                if (c->no_class_content) { content_of[nc] = nc; continue; }
+                std::vector<int32_t> col;
+                col.reserve((size_t)Ctc * 4);
+                for (int tc = 0; tc < Ctc; ++tc) {
+                    col.push_back(raw32[(size_t)tc_rep[tc] * c->Cn + nc]);
+                    for (const std::vector<int64_t>* tab : {&c->na_raw, &c->tt_raw, &c->static_add})
+                        if (!tab->empty()) col.push_back((int32_t)(*tab)[(size_t)tc_rep[tc] * c->Cn + nc]);
+                }
+                content_of[nc] = col_id.emplace(std::move(col), (int)col_id.size()).first->second;
+            }
+        }
         std::map<std::tuple<int32_t, uint32_t, uint32_t, int>, int> cls_id;
         std::vector<ShapeRow> shapes;
         std::vector<int32_t> orig_of, ncls_t(N), sub_of_class;
         bool split_gpu = c->rest && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty() && !c->no_gpu_split;
         if (split_gpu) {
             std::set<std::tuple<int32_t, uint32_t, uint32_t, int>> keys;
-            for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
+            for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
             split_gpu = (int)keys.size() <= kTableMaxClasses;
         }
         auto zone_sub = [&](int j) -> int {
@@ -954,7 +985,7 @@ int stage_narrow(simon_ctx* c) {
             return sub;
         };
         for (int j = 0; j < N && c->table_ok; ++j) {
-            auto key = std::make_tuple(c->node_class[j], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
+            auto key = std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
                 if ((int)shapes.size() == kTableMaxClasses) { c->table_ok = false; break; }
@@ -1196,6 +1227,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_TEAM")) { const int v = atoi(e); c->team_mode = v == 0 ? 0 : (v == 1 || v == kTeamWaves) ? 1 : -1; }
     if (const char* e = getenv("SIMON_TEAM_MAX_S")) c->team_max_s = atoi(e);
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
+    c->no_class_content = getenv("SIMON_TABLE_NO_CLASS_CONTENT") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
     c->table_prof = getenv("SIMON_TABLE_PROF") != nullptr;   // phase profile of simon_table.hip: profiling builds only
@@ -1765,9 +1797,23 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     return SIMON_OK;
 }
 
-int simon_fetch_results(simon_ctx* c, simon_batch_out* out) {
-    if (!c || !out) return SIMON_EINVAL;
-    if (out->struct_size != sizeof(simon_batch_out)) return fail(c, SIMON_EINVAL, "simon_batch_out size mismatch");
+
+// simon_batch_out as the caller filled it, widened to the current layout: a v3 struct (no gpu_slices member) reads as gpu_slices = NULL
+}  // extern "C"
+static bool batch_out_view(const simon_batch_out* out, simon_batch_out* v) {
+    if (out->struct_size == sizeof(simon_batch_out)) { *v = *out; return true; }
+    if (out->struct_size != SIMON_BATCH_OUT_SIZE_V3) return false;
+    std::memset(v, 0, sizeof *v);
+    std::memcpy(v, out, SIMON_BATCH_OUT_SIZE_V3);
+    v->struct_size = sizeof *v;
+    return true;
+}
+extern "C" {
+
+int simon_fetch_results(simon_ctx* c, simon_batch_out* caller_out) {
+    if (!c || !caller_out) return SIMON_EINVAL;
+    simon_batch_out view, *out = &view;
+    if (!batch_out_view(caller_out, out)) return fail(c, SIMON_EINVAL, "simon_batch_out size mismatch");
     if (!c->have_results) return fail(c, SIMON_ESTATE, "fetch_results: nothing has run");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t S = c->S, P = c->P;
@@ -1821,11 +1867,13 @@ int simon_fetch_gpu_slices(simon_ctx* c, int32_t scenario, uint64_t* slices) {
 int simon_run_batch(simon_ctx* c, const simon_scenario* scen, int32_t S, const int32_t* orders, int32_t n_orders,
                     simon_batch_out* out) {
     if (!c || !out) return SIMON_EINVAL;
+    simon_batch_out view;
+    if (!batch_out_view(out, &view)) return fail(c, SIMON_EINVAL, "simon_batch_out size mismatch");
     int rc = simon_load_scenarios(c, scen, S, orders, n_orders);
     if (rc) return rc;
-    rc = simon_run_loaded(c, (out->placement ? SIMON_WANT_PLACEMENT : 0) | (out->gpu_slices ? SIMON_WANT_GPU_SLICES : 0));
+    rc = simon_run_loaded(c, (view.placement ? SIMON_WANT_PLACEMENT : 0) | (view.gpu_slices ? SIMON_WANT_GPU_SLICES : 0));
     if (rc) return rc;
-    return simon_fetch_results(c, out);
+    return simon_fetch_results(c, &view);
 }
 
 int simon_min_plan(simon_ctx* c, int32_t max_cpu_pct, int32_t max_mem_pct, simon_plan* best) {

@@ -9,7 +9,7 @@ import pytest
 import oracle_lib as O
 import randprob
 from open_simulator_amd import capi, synth
-from test_gpu_parity import assert_same
+from test_gpu_parity import assert_same, run_gpu
 from test_gpu_round3 import SPREAD_FEATURES
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +212,101 @@ def test_open_local_error_sizes_match_the_oracle(seed):
     assert kinds & {capi.LOCAL_ERR_LVM, capi.LOCAL_ERR_DEVICE}
     for i in range(len(f2)):
         assert fiterror.fit_error(c2[i], local_detail=got[i]) == fiterror.fit_error(codes[i], local_detail=want[i])
+
+
+def test_hostname_counters_cannot_wrap_through_pods_bound_by_node_name():
+    """generation 7's per-position counters are bytes, bounded by alloc_pods -- but pods bound by Spec.NodeName skip
+    NodeResourcesFit and come on top.  300 preset pods of ONE spread class on one node (alloc_pods 250): the byte would wrap; the host
+    must send the problem to the all-feature kernel, and the result must be the oracle's either way."""
+    prob = randprob.rand_problem(9100, N=60, P=700, spread_soft=True, n_node_classes=3, n_pod_classes=6)
+    prob.alloc_pods = np.full(prob.n_nodes, 250, np.int32)
+    cls = int(np.bincount(prob.pod_class).argmax())
+    preset = np.full(prob.n_pods, -1, np.int32)
+    idx = np.flatnonzero(prob.pod_class == cls)
+    extra = 300 - len(idx)
+    if extra > 0:                                       # make the class large enough: relabel pods of other classes
+        others = np.flatnonzero(prob.pod_class != cls)[:extra]
+        prob.pod_class[others] = cls
+        idx = np.flatnonzero(prob.pod_class == cls)
+    preset[idx[:300]] = 5
+    prob.preset_node = preset
+    prob.req_cpu[idx[:300]] = 1                         # tiny pods: the node's cpu / memory never bind
+    prob.req_mem[idx[:300]] = 1
+    prob.normalise()
+    scen = np.array([[prob.n_nodes, 0], [prob.n_nodes - 7, 1]], np.int32)
+    orders = np.stack([np.arange(prob.n_pods, dtype=np.int32), np.arange(prob.n_pods, dtype=np.int32)[::-1].copy()])
+    ref = O.run(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_WIDE, "a node can hold more than 255 matching pods: the byte counters must not be used"
+    assert_same(res, ref)
+    prob.preset_node = np.where(np.arange(prob.n_pods) < 0, 0, -1).astype(np.int32)    # no presets: back on generation 7
+    prob.normalise()
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        assert ctx.stats().kernel_generation == 7
+    assert_same(res, O.run(prob, scen, orders))
+
+
+def test_abi_v3_batch_out_is_still_accepted():
+    """simon_batch_out grew by gpu_slices in ABI v4; a caller compiled against v3 passes the shorter struct_size and must get its
+    results (no device record), not SIMON_EINVAL.  Any other size is refused."""
+    import ctypes as C
+    prob, scen, orders = synth.config3(n_counts=4, n_orders=1, n_pods=300, n_het=30)
+    ref = O.run(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        res = capi.BatchResult.alloc(len(scen), prob.n_pods, True)
+        out = res.c_out()
+        v3 = capi.BatchOut.gpu_slices.offset
+        assert v3 < C.sizeof(capi.BatchOut)
+        out.struct_size = v3
+        assert ctx.lib.simon_fetch_results(ctx.h, C.byref(out)) == 0
+        assert_same(res, ref)
+        out.struct_size = v3 - 8
+        assert ctx.lib.simon_fetch_results(ctx.h, C.byref(out)) == -22
+
+
+def _expand_node_classes(prob, n_new, seed):
+    """The same problem with `n_new` caller node classes: every new class is a copy of an old one (identical columns in every class table),
+    nodes are re-labelled at random among the copies of their class -- what a host that derives classes from label sets hands over."""
+    rng = np.random.default_rng(seed)
+    old_n = prob.n_node_classes
+    src = np.concatenate([np.arange(old_n), rng.integers(0, old_n, n_new - old_n)])
+    rng.shuffle(src)
+    copies = [np.flatnonzero(src == c) for c in range(old_n)]
+    prob.node_class = np.array([rng.choice(copies[c]) for c in prob.node_class.tolist()], np.int32)
+    for name in ("simon_raw", "node_affinity_raw", "taint_prefer_raw", "static_add"):
+        t = getattr(prob, name, None)
+        if t is not None:
+            setattr(prob, name, np.ascontiguousarray(np.asarray(t).reshape(-1, old_n)[:, src]))
+    prob.n_node_classes = n_new
+    return prob
+
+
+@pytest.mark.parametrize("feat", [dict(), dict(static_scores=True, static_small=True), dict(gpu=True, anti=True), dict(spread_soft=True)])
+def test_hundreds_of_caller_node_classes_with_few_distinct_columns_stay_on_the_score_table(feat, monkeypatch):
+    """VERDICT r3 next-8 (the 64-class cliff): internal node classes are interned by the CONTENT of their class-table columns, so 300
+    caller classes (label-set classes of a real cluster) that differ in nothing the kernel reads cost what their 9 distinct columns cost;
+    with the interning switched off (SIMON_TABLE_NO_CLASS_CONTENT) the same problem leaves the score table -- same placements either way."""
+    for seed, (N, P) in enumerate([(500, 1500), (1400, 2500)]):
+        prob = randprob.rand_problem(8800 + seed, N=N, P=P, n_node_classes=9, n_pod_classes=10, tight_pods=True, **feat)
+        prob = _expand_node_classes(prob, 300, 88 + seed).normalise()
+        assert len(set(prob.node_class.tolist())) > 64
+        scen, orders = randprob.rand_scenarios(880 + seed, prob, S=5)
+        ref = O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders)
+            st = ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation >= 4, (st.kernel_variant, st.kernel_generation)
+        assert_same(res, ref)
+    monkeypatch.setenv("SIMON_TABLE_NO_CLASS_CONTENT", "1")
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        st = ctx.stats()
+    assert not (st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation >= 4)
+    assert_same(res, ref)
