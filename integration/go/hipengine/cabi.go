@@ -343,6 +343,31 @@ func (c *Ctx) ExplainLoaded(scenario, nNodes, maxFailed int) (total int, failed 
 	return splitCodes(int(rc), failed, flat, nNodes, maxFailed, c.check(rc, "simon_explain_loaded"))
 }
 
+// LocalDetail is one row of simon_explain_local_detail: what Open-Local's error text carries for a node that failed a pod with
+// SIMON_FAIL_LOCAL_LVM / _DEV (Kind = SIMON_LOCAL_ERR_*; zero elsewhere).
+type LocalDetail struct{ Kind, A, B, C int64 }
+
+// ExplainLocalDetail returns, after Explain / ExplainLoaded on a problem with local storage, the rows of the first nFailed failed
+// pods: [failed pod][node].  nil when the problem has no local storage.
+func (c *Ctx) ExplainLocalDetail(nFailed, nNodes int) ([][]LocalDetail, error) {
+	if nFailed <= 0 || nNodes <= 0 {
+		return nil, nil
+	}
+	flat := make([]LocalDetail, nFailed*nNodes) // four int64 per row, the layout of the C array
+	rc := C.simon_explain_local_detail(c.h, (*C.int64_t)(unsafe.Pointer(&flat[0])), C.int32_t(nFailed))
+	if err := c.check(rc, "simon_explain_local_detail"); err != nil {
+		return nil, err
+	}
+	if rc == 0 {
+		return nil, nil
+	}
+	rows := make([][]LocalDetail, int(rc))
+	for i := range rows {
+		rows[i] = flat[i*nNodes : (i+1)*nNodes]
+	}
+	return rows, nil
+}
+
 func splitCodes(rc int, failed []int32, flat []uint16, nNodes, maxFailed int, err error) (int, []int32, [][]uint16, error) {
 	if err != nil {
 		return 0, nil, nil, err

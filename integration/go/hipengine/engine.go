@@ -13,13 +13,16 @@ package hipengine
 // by ONE SimulateBatch over every candidate size, accepting the plan MinPlan returns (same rule: first size with no
 // unscheduled pod that passes satisfyResourceSetting).
 //
-// Scope of this file: the inputs whose plugins are per-node and static or NodeResourcesFit-like -- cpu / memory /
-// ephemeral-storage / extended-resource / pod-count requests, NodeUnschedulable, NodeName, TaintToleration, NodeAffinity
-// (required), Open-Gpu-Share incl. pods that arrive with a gpu-index annotation -- i.e. BASELINE configs 1-5.  Supports() answers false (the Go path runs) for everything whose tables
-// this Go flattening does not fill yet: pod (anti-)affinity, topology spread constraints, preferred node affinity /
-// PreferNoSchedule taints, host ports, Open-Local volumes, scheduler configs / extra registries.  The engine itself
-// evaluates all of those (ABI v2 tables); the complete object -> table code is open-simulator_amd/flatten.py, whose
-// port line by line is mechanical (INTEGRATION.md section 3 maps every table to the reference helper that fills it).
+// Scope: everything open-simulator_amd/flatten.py (the GPU-tested twin of this flattening) handles, table by table -- cpu / memory /
+// ephemeral-storage / extended-resource / pod-count requests, NodeUnschedulable, NodeName, TaintToleration (NoSchedule and
+// PreferNoSchedule), NodeAffinity (required and preferred), Open-Gpu-Share incl. pods that arrive with a gpu-index annotation, pod
+// (anti-)affinity (required and preferred), topology spread constraints (explicit, and the system defaults of pods a Service /
+// ReplicaSet / StatefulSet selects), host ports, Open-Local volumes: flatten_terms.go fills those tables.  Supports() answers false
+// (the Go path runs) only for what NEITHER flattening models: scheduler configs / extra registries, pods of different priorities
+// (DefaultPreemption could evict), nodes with a preferAvoidPods annotation or listed images (NodePreferAvoidPods / ImageLocality
+// would not be constants; flatten.py takes them for one cluster size), more extended resources / spread constraints / volumes
+// than the ABI's fixed widths.  Whether a supported input then runs on the score-table kernel or the all-feature kernel is the
+// library's decision (simon_get_stats), never visible in a result.
 
 import (
 	"fmt"
@@ -72,25 +75,7 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 	var prio *int32
 	for _, p := range pods {
 		s := &p.Spec
-		if a := s.Affinity; a != nil {
-			if a.PodAffinity != nil || a.PodAntiAffinity != nil {
-				return false
-			}
-			if a.NodeAffinity != nil && len(a.NodeAffinity.PreferredDuringSchedulingIgnoredDuringExecution) > 0 {
-				return false
-			}
-		}
-		if len(s.TopologySpreadConstraints) > 0 {
-			return false
-		}
-		for _, c := range s.Containers {
-			for _, port := range c.Ports {
-				if port.HostPort > 0 {
-					return false
-				}
-			}
-		}
-		if _, ok := p.Annotations["simon/pod-local-storage"]; ok {
+		if len(s.TopologySpreadConstraints) > 2*maxSpread { // at most SIMON_MAX_SPREAD hard and as many soft constraints (fillTerms checks each kind)
 			return false
 		}
 		if prio != nil && s.Priority != nil && *prio != *s.Priority { // DefaultPreemption could evict
@@ -100,16 +85,7 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 			prio = s.Priority
 		}
 	}
-	// system-default spread constraints apply to pods a Service / ReplicaSet / StatefulSet selects (plugin.go:39-50)
-	if len(cluster.Services)+len(cluster.ReplicaSets)+len(cluster.StatefulSets) > 0 {
-		return false
-	}
 	for _, n := range cluster.Nodes {
-		for _, t := range n.Spec.Taints {
-			if t.Effect == corev1.TaintEffectPreferNoSchedule {
-				return false
-			}
-		}
 		if _, ok := n.Annotations["scheduler.alpha.kubernetes.io/preferAvoidPods"]; ok {
 			return false
 		}
@@ -148,7 +124,7 @@ func podStream(cluster simulator.ResourceTypes, apps []simulator.AppResource, no
 
 // flatten builds the SoA image of (pool, pods).  pool = cluster nodes followed by the new-node clones
 // (utils.NewFakeNodes, pkg/apply/apply.go:205-210); gate[p] = pool index of the clone a DaemonSet pod was made for.
-func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, error) {
+func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod, cluster simulator.ResourceTypes, apps []simulator.AppResource) (*Flat, error) {
 	f := &Flat{}
 	N, P := len(pool), len(pods)
 	index := map[string]int32{}
@@ -165,10 +141,7 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		f.ScalarAlloc = make([]int64, K*N)
 		f.ScalarReq = make([]int64, K*P)
 	}
-	// node class = the node's WHOLE allocatable list (SimonPlugin.Score iterates every allocatable resource,
-	// pkg/simulator/plugin/simon.go:57-66) + its GPU capacity: nodes of one class share a simon_raw column
-	nodeClassOf := map[string]int32{}
-	var classRep []*corev1.Node
+	nodeKeys := make([]string, N) // allocatable + GPU capacity of a node: the part of its class the pods do not influence
 	for j, n := range pool {
 		index[n.Name] = int32(j)
 		r := framework.NewResource(n.Status.Allocatable)
@@ -183,17 +156,9 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		gm := gpushareutils.GetTotalGpuMemory(n)
 		f.GpuCnt = append(f.GpuCnt, gc)
 		f.GpuMemTotal = append(f.GpuMemTotal, gm)
-		k := fmt.Sprintf("%s|%d|%d", resourceListKey(n.Status.Allocatable), gc, gm)
-		c, ok := nodeClassOf[k]
-		if !ok {
-			c = int32(len(classRep))
-			nodeClassOf[k] = c
-			classRep = append(classRep, n)
-		}
-		f.NodeClass = append(f.NodeClass, c)
+		nodeKeys[j] = fmt.Sprintf("%s|%d|%d", resourceListKey(n.Status.Allocatable), gc, gm)
 		f.NodeNames = append(f.NodeNames, n.Name)
 	}
-	f.Cn = len(classRep)
 	// ---- pods: computePodResourceRequest (fit.go:148-165), non-zero requests (V/util/non_zero.go:35-84) ----
 	words := (N + 63) / 64
 	type classKey string
@@ -249,8 +214,10 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		f.Pin = append(f.Pin, pin)
 		// pod class = everything the static filters and the Simon score see: tolerations, node selector / affinity, a preset
 		// node, and the WHOLE request list (simon.go:49-66 reads every requested resource)
-		key := classKey(fmt.Sprintf("%v|%v|%v|%s|%s", classPod.Spec.Tolerations, classPod.Spec.NodeSelector, classPod.Spec.Affinity,
-			classPod.Spec.NodeName, resourceListKey(requestList(p))))
+		// ... and what the placement-dependent plugins read: namespace and labels (selectors), spread constraints, host ports, local volumes
+		key := classKey(fmt.Sprintf("%v|%v|%v|%s|%s|%s|%v|%v|%v|%s", classPod.Spec.Tolerations, classPod.Spec.NodeSelector, classPod.Spec.Affinity,
+			classPod.Spec.NodeName, resourceListKey(requestList(p)), p.Namespace, p.Labels, p.Spec.TopologySpreadConstraints, hostPortsOf(p),
+			p.Annotations[simontype.AnnoPodLocalStorage]))
 		c, ok := classOf[key]
 		if !ok {
 			c = int32(len(classPods))
@@ -263,6 +230,51 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		f.PodGpuIndex = nil
 	}
 	f.Cp = len(classPods)
+	// ---- node classes: nodes that share every column of the (pod class, node class) tables -- the WHOLE allocatable list
+	// (SimonPlugin.Score iterates every allocatable resource, pkg/simulator/plugin/simon.go:57-66), the GPU capacity, and the raw
+	// NodeAffinity / TaintToleration scores of every pod class.  (The library interns classes by column content once more.)
+	naRows, ttRows := staticScores(pool, classPods)
+	nodeClassOf := map[string]int32{}
+	var classRep []*corev1.Node
+	var classRepIdx []int
+	for j, n := range pool {
+		var sb strings.Builder
+		sb.WriteString(nodeKeys[j])
+		for c := range classPods {
+			if naRows != nil && naRows[c] != nil && naRows[c][j] != 0 {
+				fmt.Fprintf(&sb, "|a%d:%d", c, naRows[c][j])
+			}
+			if ttRows != nil && ttRows[c] != nil && ttRows[c][j] != 0 {
+				fmt.Fprintf(&sb, "|t%d:%d", c, ttRows[c][j])
+			}
+		}
+		k := sb.String()
+		c, ok := nodeClassOf[k]
+		if !ok {
+			c = int32(len(classRep))
+			nodeClassOf[k] = c
+			classRep = append(classRep, n)
+			classRepIdx = append(classRepIdx, j)
+		}
+		f.NodeClass = append(f.NodeClass, c)
+	}
+	f.Cn = len(classRep)
+	tableOf := func(rows [][]int64) []int64 { // [Cp][N] rows -> [Cp][Cn] (nil = the plugin scores alike everywhere)
+		if rows == nil {
+			return nil
+		}
+		t := make([]int64, f.Cp*f.Cn)
+		for c, row := range rows {
+			if row == nil {
+				continue
+			}
+			for d, j := range classRepIdx {
+				t[c*f.Cn+d] = row[j]
+			}
+		}
+		return t
+	}
+	f.NodeAffinityRaw, f.TaintPreferRaw = tableOf(naRows), tableOf(ttRows)
 	// ---- class tables: static filters once per (pod class, node), Simon raw score per (pod class, node class) ----
 	f.StaticMask = make([]uint64, f.Cp*words)
 	f.StaticReason = make([]uint8, f.Cp*N)
@@ -300,10 +312,22 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod) (*Flat, erro
 		for d, n := range classRep {
 			f.SimonRaw[c*f.Cn+d] = simonRaw(p, n)
 		}
-		// constant-score plugins x weight under the default profile (SURVEY a8): NodePreferAvoidPods 100 x 10000,
-		// PodTopologySpread 100 x 2, TaintToleration 100 x 1 -- the same on every node, reporting only
-		f.ConstScore[c] = 100*10000 + 100*2 + 100
+		// constant-score plugins x weight under the default profile (SURVEY a8), reporting only: NodePreferAvoidPods 100 x 10000,
+		// TaintToleration 100 x 1 when no node carries a PreferNoSchedule taint the class minds (else taint_prefer_raw scores it);
+		// PodTopologySpread's 100 x 2 is added by fillTerms for the classes without soft constraints
+		f.ConstScore[c] = 100 * 10000
+		if f.TaintPreferRaw == nil {
+			f.ConstScore[c] += 100
+		}
 	}
+	if err := fillTerms(f, pool, classPods, cluster); err != nil {
+		return nil, err
+	}
+	vg, err := fillLocal(f, pool, classPods, cluster, apps)
+	if err != nil {
+		return nil, err
+	}
+	f.VGNames = vg
 	return f, nil
 }
 
@@ -566,7 +590,7 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 	if err != nil {
 		return nil, -1, err
 	}
-	f, err := flatten(pool, nCluster, pods)
+	f, err := flatten(pool, nCluster, pods, cluster, apps)
 	if err != nil {
 		return nil, -1, err
 	}
@@ -629,8 +653,18 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 			if err != nil {
 				return nil, -1, err
 			}
+			var detail [][]LocalDetail // Open-Local's reasons carry sizes (simon_explain_local_detail); nil without local storage
+			if f.LocalFlags != nil {
+				if detail, err = c.ExplainLocalDetail(len(failed), n); err != nil {
+					return nil, -1, err
+				}
+			}
 			for i, pid := range failed {
-				reasons[pid] = FitErrorString(pods[pid], codes[i], f)
+				var row []LocalDetail
+				if detail != nil {
+					row = detail[i]
+				}
+				reasons[pid] = FitErrorString(pods[pid], codes[i], row, f)
 			}
 		}
 		gpuRow := out.GpuRow(s)

@@ -15,6 +15,7 @@ import (
 	"strings"
 
 	corev1 "k8s.io/api/core/v1"
+	"k8s.io/apimachinery/pkg/api/resource"
 )
 
 // reasonsOf turns one node's failure code into the reason strings the plugins' Status carries.
@@ -57,17 +58,47 @@ func reasonsOf(code uint16, f *Flat) []string {
 		return []string{"node(s) didn't match pod topology spread constraints (missing required label)"}
 	case c == C.SIMON_FAIL_PORTS:
 		return []string{"node(s) didn't have free ports for the requested pod ports"}
+	case c == C.SIMON_FAIL_LOCAL: // Unschedulable without a reason text (pkg/simulator/plugin/open-local.go:64-69)
+		return nil
 	}
 	return []string{fmt.Sprintf("code %#x", c)}
 }
 
+// localReason is err.Error() of open-local's predicate (pkg/simulator/plugin/open-local.go:78-88) rebuilt from a
+// simon_explain_local_detail row: the formats of vendor/github.com/alibaba/open-local/pkg/scheduler/errors/errors.go, the sizes
+// printed by resource.NewQuantity(x, resource.BinarySI).String() as the errors do.
+func localReason(d LocalDetail, nodeName string, f *Flat) string {
+	q := func(v int64) string { return resource.NewQuantity(v, resource.BinarySI).String() }
+	switch d.Kind {
+	case C.SIMON_LOCAL_ERR_NO_SUCH_VG: // NotSuchVGError
+		name := fmt.Sprint(d.A)
+		if d.A >= 0 && int(d.A) < len(f.VGNames) {
+			name = f.VGNames[d.A]
+		}
+		return "not LVM named " + name
+	case C.SIMON_LOCAL_ERR_NO_VG: // NoAvailableVGError
+		return "not LVM on node " + nodeName
+	case C.SIMON_LOCAL_ERR_LVM: // InsufficientLVMError
+		return fmt.Sprintf("Insufficient LVM storage, requested %s, used %s, capacity %s", q(d.A), q(d.B), q(d.C))
+	case C.SIMON_LOCAL_ERR_DEVICE: // InsufficientExclusiveResourceError(Device)
+		return fmt.Sprintf("Insufficient Device storage, requested %s, available %s, capacity %s", q(d.A), q(d.B), q(d.C))
+	}
+	return fmt.Sprintf("local storage error %d", d.Kind)
+}
+
 // FitErrorString = "failed to schedule pod (ns/name): Unschedulable: 0/N nodes are available: <count> <reason>, ..." with the reasons
 // sorted as FitError.Error() sorts them (V/core/generic_scheduler.go:72-90).
-func FitErrorString(pod *corev1.Pod, codes []uint16, f *Flat) string {
+//
+// local: the pod's rows of simon_explain_local_detail (nil when the problem has no local storage).
+func FitErrorString(pod *corev1.Pod, codes []uint16, local []LocalDetail, f *Flat) string {
 	hist := map[string]int{}
 	for j, code := range codes {
 		if uint32(code) == C.SIMON_FAIL_GPUSHARE { // the plugin's reason is "Node:<name>" (open-gpu-share.go:64-78)
 			hist["Node:"+f.NodeNames[j]]++
+			continue
+		}
+		if c := uint32(code); (c == C.SIMON_FAIL_LOCAL_LVM || c == C.SIMON_FAIL_LOCAL_DEV) && local != nil {
+			hist[localReason(local[j], f.NodeNames[j], f)]++
 			continue
 		}
 		for _, r := range reasonsOf(code, f) {

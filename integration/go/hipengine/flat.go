@@ -61,6 +61,7 @@ type Flat struct {
 	NodeNames     []string
 	StaticReasons []string // reason id -> FitError text
 	ScalarNames   []string
+	VGNames       []string // interned Open-Local volume-group names (LocalVGName / LocalSpec.LvmVG ids -> text)
 }
 
 // LocalSpec mirrors simon_local_spec (same field order and sizes: it is copied byte for byte).

@@ -53,6 +53,15 @@ for STAGE in "$@"; do
           done
         done
       done ;;
+    new_tests)   # the tests added since the last full run (env KEXPR = pytest -k expression)
+      ( timeout 1500 python -m pytest tests/test_gpu_round4.py -m gpu -q -x -k "${KEXPR:-local or wrap or abi_v3 or hundreds}" 2>&1 | tail -15 ) > "$OUT/pytest_new.log"; tail -3 "$OUT/pytest_new.log" ;;
+    wide_exp)    # the all-feature kernel on the random mix x 64 sizes: workgroup shapes (env SIMON_WG) and its phase profile (prof build)
+      for WG in ${WGS:-512 1024}; do
+        echo "WG=$WG $( SIMON_WG=$WG SIMON_BENCH_DETAIL=/tmp/d.json timeout 600 python bench.py --workload widemix --pmc off --no-cpu-baseline --no-sub --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["roofline"]["kernel_ms"], d["config"].get("workgroup"))' )" | tee -a "$OUT/wide_exp.txt"
+      done
+      if [ -f open-simulator_amd/csrc/libsimon_hip_prof.so ]; then
+        ( SIMON_WIDE_PROF=1 SIMON_HIP_LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_prof.so SIMON_BENCH_DETAIL=/tmp/d.json timeout 600 python bench.py --workload widemix --pmc off --no-cpu-baseline --no-sub --steps 1 --warmup 0 2>&1 | grep SIMON_WIDE_PROF | tail -2 ) > "$OUT/wide_phase_profile.txt"; cut -c1-900 "$OUT/wide_phase_profile.txt"
+      fi ;;
     *) echo "unknown stage $STAGE" ;;
   esac
   echo "[$STAGE] $(( $(date +%s) - t0 )) s"
