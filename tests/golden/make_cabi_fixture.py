@@ -15,6 +15,8 @@ Layout (little endian): "SIMONFX1", int32 N P Cp Cn S n_orders, then
   int32 K has_gpu has_mask, int64 alloc_eph[N] req_eph[P] scalar_alloc[K][N] scalar_req[K][P], int32 preset[P] gate[P] pin[P],
   int64 const_score[Cp], (has_gpu) int32 gpu_cnt[N], int64 gpu_mem_total[N] pod_gpu_mem[P], int32 pod_gpu_cnt[P], uint32 gpu_index[P],
   uint64 golden gpu_slices[S][P], (has_mask) uint64 static_mask[Cp][ceil(N/64)], uint8 static_reason[Cp][N].
+"SIMONFX3" (tests/cabi/cabi_terms.c) is self-describing: every optional array of the three input structs travels by NAME
+(see write_fx3), followed by the golden placements, failure codes and Open-Local error sizes.
 The golden values come from oracle/simon_oracle.c (TEST INFRASTRUCTURE)."""
 import os
 import sys
@@ -74,6 +76,49 @@ def write(path, prob, scen, orders, explain_scenario, ext=False):
     print(path, os.path.getsize(path), "bytes; unscheduled", ref.unscheduled.tolist(), "plan", plan.as_dict())
 
 
+def write_fx3(path, prob, scen, orders, explain_scenario, max_failed=6):
+    """SIMONFX3 (tests/cabi/cabi_terms.c): every optional array by NAME -- the three ctypes structs of capi.py walked field by field."""
+    import ctypes as C
+    from open_simulator_amd import capi
+    prob.normalise()
+    scen = np.ascontiguousarray(scen, np.int32)
+    orders = np.ascontiguousarray(orders, np.int32)
+    ref = O.run(prob, scen, orders)
+    _, (nf, failed, codes) = O.run(prob, scen, orders, explain_scenario=explain_scenario, max_failed=max_failed)
+    detail = O.LAST_LOCAL_DETAIL[0]
+    assert nf > 0, "pick an explain scenario with unscheduled pods"
+    structs = [(0, prob.c_nodes()), (1, prob.c_pods()), (2, prob.c_tables())]
+    attr_of = {(1, "gpu_cnt"): "pod_gpu_cnt"}                 # the Problem attribute behind a struct member (same name otherwise)
+    fields = []
+    for which, st in structs:
+        for name, ctype in st._fields_:
+            if not hasattr(ctype, "contents"):                 # counters, struct_size
+                continue
+            if not getattr(st, name):                          # NULL: optional array absent
+                continue
+            arr = getattr(prob, attr_of.get((which, name), name))
+            fields.append((name, which, np.ascontiguousarray(arr).tobytes()))
+    nd, tb = structs[0][1], structs[2][1]
+    with open(path, "wb") as f:
+        f.write(b"SIMONFX3")
+        f.write(np.array([prob.n_nodes, prob.n_pods, prob.n_pod_classes, prob.n_node_classes, len(scen), len(orders), nd.n_scalar, nd.n_topo_keys,
+                          tb.n_terms, tb.n_node_sets, tb.n_local_specs, len(fields)], "<i4").tobytes())
+        for name, which, data in fields:
+            f.write(name.encode().ljust(24, b"\0")); f.write(np.array([which, 0], "<i4").tobytes()); f.write(np.array([len(data)], "<i8").tobytes())
+            f.write(data + b"\0" * (-len(data) % 8))
+        f.write(scen.astype("<i4").tobytes()); f.write(orders.astype("<i4").tobytes())
+        f.write(ref.unscheduled.astype("<i4").tobytes()); f.write(ref.placement.astype("<i4").tobytes())
+        k = len(failed)
+        f.write(np.array([explain_scenario, k, 0 if detail is None else 1], "<i4").tobytes())
+        fb = failed.astype("<i4").tobytes()
+        f.write(fb + b"\0" * (4 if k & 1 else 0))
+        cb = codes.astype("<u2").tobytes()
+        f.write(cb + b"\0" * (-len(cb) % 8))
+        if detail is not None:
+            f.write(detail.astype("<i8").tobytes())
+    print(path, os.path.getsize(path), "bytes;", len(fields), "fields; unscheduled", ref.unscheduled.tolist())
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from test_oracle import kav_problem
@@ -102,6 +147,18 @@ def main():
     scen, orders = randprob.rand_scenarios(77, prob, S=6)
     ref = O.run(prob, scen, orders)
     write(os.path.join(HERE, "cabi_features.bin"), prob, scen, orders, int(np.argmax(ref.unscheduled)), ext=True)
+    # SIMONFX3: what integration/go/hipengine/flatten_terms.go fills -- required / preferred (anti-)affinity, hard and soft spread
+    # constraints with node sets, host ports, static score tables (the all-feature kernel), and Open-Local with failures whose reasons
+    # carry sizes (simon_explain_local_detail)
+    prob = randprob.rand_problem(91, N=40, P=350, anti=True, aff=True, ipa=True, spread_hard=True, spread_soft=True, static_scores=True, ports=True,
+                                 tight_pods=True, presets=True)
+    scen, orders = randprob.rand_scenarios(91, prob, S=4)
+    ref = O.run(prob, scen, orders)
+    write_fx3(os.path.join(HERE, "cabi_terms.bin"), prob, scen, orders, int(np.argmax(ref.unscheduled)))
+    prob = randprob.rand_problem(3, N=40, P=400, local=True, tight_pods=True, init_state=True)
+    scen, orders = randprob.rand_scenarios(3, prob, S=3)
+    ref = O.run(prob, scen, orders)
+    write_fx3(os.path.join(HERE, "cabi_local.bin"), prob, scen, orders, int(np.argmax(ref.unscheduled)))
 
 
 if __name__ == "__main__":

@@ -215,37 +215,35 @@ def test_open_local_error_sizes_match_the_oracle(seed):
 
 
 def test_hostname_counters_cannot_wrap_through_pods_bound_by_node_name():
-    """generation 7's per-position counters are bytes, bounded by alloc_pods -- but pods bound by Spec.NodeName skip
-    NodeResourcesFit and come on top.  300 preset pods of ONE spread class on one node (alloc_pods 250): the byte would wrap; the host
-    must send the problem to the all-feature kernel, and the result must be the oracle's either way."""
+    """generation 7's per-position counters are bytes, bounded by alloc_pods x multiplicity -- but pods bound by
+    Spec.NodeName skip NodeResourcesFit and come on top.  200 preset pods on one node of alloc_pods 100: up to 300 pods can sit
+    there, a byte counter could wrap; the host must send the problem to the all-feature kernel (the bound is per node, whatever the class), and the result must be the oracle's
+    either way.  Without the presets the same problem runs on generation 7."""
     prob = randprob.rand_problem(9100, N=60, P=700, spread_soft=True, n_node_classes=3, n_pod_classes=6)
-    prob.alloc_pods = np.full(prob.n_nodes, 250, np.int32)
-    cls = int(np.bincount(prob.pod_class).argmax())
-    preset = np.full(prob.n_pods, -1, np.int32)
-    idx = np.flatnonzero(prob.pod_class == cls)
-    extra = 300 - len(idx)
-    if extra > 0:                                       # make the class large enough: relabel pods of other classes
-        others = np.flatnonzero(prob.pod_class != cls)[:extra]
-        prob.pod_class[others] = cls
-        idx = np.flatnonzero(prob.pod_class == cls)
-    preset[idx[:300]] = 5
-    prob.preset_node = preset
-    prob.req_cpu[idx[:300]] = 1                         # tiny pods: the node's cpu / memory never bind
-    prob.req_mem[idx[:300]] = 1
-    prob.normalise()
+    prob.alloc_pods = np.full(prob.n_nodes, 100, np.int32)
     scen = np.array([[prob.n_nodes, 0], [prob.n_nodes - 7, 1]], np.int32)
     orders = np.stack([np.arange(prob.n_pods, dtype=np.int32), np.arange(prob.n_pods, dtype=np.int32)[::-1].copy()])
-    ref = O.run(prob, scen, orders)
-    res, variant = run_gpu(prob, scen, orders)
-    assert variant == capi.KERNEL_WIDE, "a node can hold more than 255 matching pods: the byte counters must not be used"
-    assert_same(res, ref)
-    prob.preset_node = np.where(np.arange(prob.n_pods) < 0, 0, -1).astype(np.int32)    # no presets: back on generation 7
     prob.normalise()
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
         res = ctx.run_batch(scen, orders)
         assert ctx.stats().kernel_generation == 7
     assert_same(res, O.run(prob, scen, orders))
+    cls = int(np.bincount(prob.pod_class).argmax())
+    idx = np.flatnonzero(prob.pod_class == cls)
+    if len(idx) < 200:                                  # make the class large enough: relabel pods of other classes
+        others = np.flatnonzero(prob.pod_class != cls)[:200 - len(idx)]
+        prob.pod_class[others] = cls
+        prob.req_cpu[others], prob.req_mem[others] = prob.req_cpu[idx[0]], prob.req_mem[idx[0]]
+        idx = np.flatnonzero(prob.pod_class == cls)
+    preset = np.full(prob.n_pods, -1, np.int32)
+    preset[idx[:200]] = 5
+    prob.preset_node = preset
+    prob.normalise()
+    ref = O.run(prob, scen, orders)
+    res, variant = run_gpu(prob, scen, orders)
+    assert variant == capi.KERNEL_WIDE, "a node can hold more than 255 matching pods: the byte counters must not be used"
+    assert_same(res, ref)
 
 
 def test_abi_v3_batch_out_is_still_accepted():
@@ -310,3 +308,17 @@ def test_hundreds_of_caller_node_classes_with_few_distinct_columns_stay_on_the_s
         st = ctx.stats()
     assert not (st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation >= 4)
     assert_same(res, ref)
+
+
+def test_c_consumer_attaches_every_optional_array_by_name(tmp_path):
+    """tests/cabi/cabi_terms.c (plain C, stands in for the cgo host): the topology-term tables, static score tables and Open-Local arrays
+    that integration/go/hipengine/flatten_terms.go fills, attached member by member through offsetof, run against the oracle's golden
+    placements, failure codes and Open-Local error sizes (simon_explain_local_detail) of the SIMONFX3 fixtures."""
+    import subprocess
+    from cabi_util import build_cabi_smoke
+    exe = build_cabi_smoke(tmp_path, "cabi_terms")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = [os.path.join(root, "tests", "golden", n) for n in ("cabi_terms.bin", "cabi_local.bin")]
+    out = subprocess.run([exe, *fx], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "cabi_terms ok" in out.stdout and "with Open-Local sizes" in out.stdout

@@ -96,6 +96,10 @@ def test_c_consumer_builds_and_links_against_the_header(tmp_path):
     out = subprocess.run([exe, os.path.join(root, "tests", "golden", "cabi_kav.bin")], capture_output=True, text=True, timeout=300)
     assert out.returncode in (0, 77), out.stdout + out.stderr
     assert f"ABI {capi.ABI_VERSION}" in out.stdout or "cabi_smoke ok" in out.stdout
+    # cabi_terms.c: the consumer that attaches EVERY optional array by name (what integration/go/hipengine/flatten_terms.go fills)
+    exe = build_cabi_smoke(tmp_path, "cabi_terms")
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "cabi_terms.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode in (0, 77), out.stdout + out.stderr
 
 
 def test_cabi_fixtures_match_the_oracle():
