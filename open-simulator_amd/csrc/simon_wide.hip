@@ -612,6 +612,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     __shared__ unsigned long long mbK[2][NW];
     __shared__ unsigned long long mbO[2][NW];
     __shared__ unsigned mbC[2][NW][8];
+    __shared__ unsigned mbZ[2][NW][SIMON_MAX_SPREAD];     // presence masks of the domains of small zone-like keys among a wave's scored nodes
     __shared__ long long red[3][NW];
     // dynamic LDS: [max_n] u32 (base | node class << 16), then, in class mode, two alternating copies of the pod
     // class's rows of the four (pod class, node class) tables as int64 [4][Cn]
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
         }
     }
 
-    int unsched = 0, buf = 0, bufK = 0, bufO = 0, bufC = 0, rows_cls = -1, rows_buf = 0;
+    int unsched = 0, buf = 0, bufK = 0, bufO = 0, bufC = 0, bufZ = 0, rows_cls = -1, rows_buf = 0;
     int32_t* place = A.placement ? A.placement + (size_t)s * P : nullptr;
     int next_pid = P > 0 ? order[0] : 0;
 
@@ -788,6 +789,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             unsigned long long cmask = 0;
             long long lo = 0x7fffffffffffffffll, hi = -0x7fffffffffffffffll, na_max = 0, tt_max = 0, ipa_min = 0, ipa_max = 0;
             long long scored = 0, dst0 = 0, dst1 = 0, dst2 = 0, dst3 = 0;
+            unsigned zm0 = 0, zm1 = 0, zm2 = 0, zm3 = 0;                            // domains of a small zone-like key seen among this lane's scored nodes
             long long l_lo = 0x7fffffffffffffffll, l_hi = -0x7fffffffffffffffll;    // LocalPlugin.NormalizeScore (open-local.go:149-159)
             // bookkeeping of one feasible node (shared by both evaluation paths)
             // Single-pass cycle: with <= 8 node classes and no per-node normalised plugin, the best node of a class is
@@ -867,7 +869,15 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
                         if (q >= n_soft) continue;
                         const int t = COLD(A)->ss_idx[slo + q], key = COLD(A)->term_key[t];
-                        if (COLD(A)->topo_is_hostname[key]) continue;
+                        const unsigned kind = COLD(A)->topo_is_hostname[key];
+                        if (kind & 1u) continue;
+                        if (kind & 2u) {                                           // <= 32 domains: a presence mask, reduced with stage A's reduction
+                            unsigned zm = 0;
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) zm |= (m[u] && !ig[u]) ? 1u << dq[q][u] : 0u;
+                            if (q == 0) zm0 |= zm; else if (q == 1) zm1 |= zm; else if (q == 2) zm2 |= zm; else zm3 |= zm;
+                            continue;
+                        }
                         const int stamp = i * SIMON_MAX_SPREAD + q + 1;
                         int* base_slot = v.seen() + (size_t)q * (COLD(A)->seen_stride / SIMON_MAX_SPREAD) + COLD(A)->key_seen_off[key];
                         int old[kUT];
@@ -1120,8 +1130,24 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                     r[0] = -lo; r[1] = hi; r[2] = na_max; r[3] = tt_max; r[4] = -ipa_min; r[5] = ipa_max;
                     r[6] = -l_lo; r[7] = l_hi;
                     r[8] = scored; r[9] = dst0; r[10] = dst1; r[11] = dst2; r[12] = dst3;
+                    if (soft) {                                                    // the waves' presence masks ride on the reduction's barrier
+                        zm0 = wave_or_u32(zm0); zm1 = wave_or_u32(zm1);
+                        if (n_soft > 2) { zm2 = wave_or_u32(zm2); zm3 = wave_or_u32(zm3); }
+                        if (NW > 1 && lane == 0) { mbZ[bufZ][wave][0] = zm0; mbZ[bufZ][wave][1] = zm1; mbZ[bufZ][wave][2] = zm2; mbZ[bufZ][wave][3] = zm3; }
+                    }
                     wg_reduce<NW>(r, local ? 8 : ipa ? 6 : 4, cm, cs, mbox[buf], wave, lane);
                     buf ^= 1;
+                    if (soft) {
+#pragma unroll
+                        for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
+                            if (q >= n_soft) continue;
+                            if (!(COLD(A)->topo_is_hostname[COLD(A)->term_key[COLD(A)->ss_idx[slo + q]]] & 2u)) continue;
+                            unsigned zm = q == 0 ? zm0 : q == 1 ? zm1 : q == 2 ? zm2 : zm3;       // (one wave: the wave's mask is the answer)
+                            if (NW > 1) { zm = 0; for (int w = 0; w < NW; ++w) zm |= mbZ[bufZ][w][q]; }
+                            r[cm + 1 + q] = __popc(zm);                            // distinct domains among the scored nodes (scoring.go:86-96)
+                        }
+                        bufZ ^= 1;
+                    }
                     lo = -r[0]; hi = r[1]; na_max = r[2]; tt_max = r[3]; ipa_min = -r[4]; ipa_max = r[5];
                     l_lo = -r[6]; l_hi = r[7];
                 } else if (NW > 1) {
@@ -1180,7 +1206,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         if (q >= n_soft) continue;
                         const int key = COLD(A)->term_key[COLD(A)->ss_idx[slo + q]];
                         const long long sz = (COLD(A)->ss_skew[slo + q] & SIMON_SPREAD_DUP_KEY) ? 0   // pair registered by an earlier constraint
-                                         : COLD(A)->topo_is_hostname[key] ? scored : r[cm + 1 + q];
+                                         : (COLD(A)->topo_is_hostname[key] & 1u) ? scored : r[cm + 1 + q];
                         wq[q] = COLD(A)->spread_log[sz];
                     }
                     weight = Weight4{wq[0], wq[1], wq[2], wq[3]};
@@ -1685,6 +1711,12 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     sh_set.resize(std::max<size_t>(in.sh_idx.size(), 1), -1);
     std::vector<uint8_t> is_host = in.topo_is_hostname;
     is_host.resize(std::max(in.Kt, 1), 0);
+    // bit 1: a zone-like key of at most 32 domains -- the kernel counts its distinct domains among the scored nodes with a 32-bit
+    // presence mask per lane and ONE OR-reduction instead of an atomic exchange per scored node on (number of domains) addresses
+    for (int k = 0; k < in.Kt; ++k) {
+        is_host[k] = is_host[k] ? 1 : 0;
+        if (!is_host[k] && k < (int)in.topo_n_dom.size() && in.topo_n_dom[k] <= 32 && !getenv("SIMON_WIDE_NO_ZMASK")) is_host[k] |= 2;
+    }
     // first eligible node per (hard constraint, node's domain): registered(j, n) = first_reg[e][j] < n
     std::vector<int32_t> first_reg(std::max<size_t>(in.sh_idx.size() * N, 1), INT_MAX);
     const size_t words = (N + 63) / 64;

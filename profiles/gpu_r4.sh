@@ -62,6 +62,8 @@ for STAGE in "$@"; do
       if [ -f open-simulator_amd/csrc/libsimon_hip_prof.so ]; then
         ( SIMON_WIDE_PROF=1 SIMON_HIP_LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_prof.so SIMON_BENCH_DETAIL=/tmp/d.json timeout 600 python bench.py --workload widemix --pmc off --no-cpu-baseline --no-sub --steps 1 --warmup 0 2>&1 | grep SIMON_WIDE_PROF | tail -2 ) > "$OUT/wide_phase_profile.txt"; cut -c1-900 "$OUT/wide_phase_profile.txt"
       fi ;;
+    wide_tests)  # the all-feature kernel's parity tests (random feature sets, three workgroup shapes) + the k8s-object sweeps on it
+      ( timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "v2_features or k8s or explain" 2>&1 | tail -8 ) > "$OUT/pytest_wide.log"; tail -3 "$OUT/pytest_wide.log" ;;
     *) echo "unknown stage $STAGE" ;;
   esac
   echo "[$STAGE] $(( $(date +%s) - t0 )) s"

@@ -284,7 +284,7 @@ def _expand_node_classes(prob, n_new, seed):
     return prob
 
 
-@pytest.mark.parametrize("feat", [dict(), dict(static_scores=True, static_small=True), dict(gpu=True, anti=True), dict(spread_soft=True)])
+@pytest.mark.parametrize("feat", [dict(), dict(static_small=True), dict(gpu=True, anti=True), dict(spread_soft=True)])
 def test_hundreds_of_caller_node_classes_with_few_distinct_columns_stay_on_the_score_table(feat, monkeypatch):
     """VERDICT r3 next-8 (the 64-class cliff): internal node classes are interned by the CONTENT of their class-table columns, so 300
     caller classes (label-set classes of a real cluster) that differ in nothing the kernel reads cost what their 9 distinct columns cost;
