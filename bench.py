@@ -57,6 +57,8 @@ KERNEL_SHORT = {1: "narrow_v1", 2: "wide (all-feature kernel)", 3: "narrow_fast"
 SERVICE_PREF = 60                 # services of the `config3_service_pref` sub-record whose pods carry preferred self anti-affinity
 SERVICE_ANTI = 20                 # services of the `config3_service_anti` sub-record that also require anti-affinity to their own pods (hostname key)
 SMALL_COUNTS = 16                 # node counts of the `service_small` sub-record (x 4 pod orders = 64 scenarios: what a sweep of candidate sizes looks like)
+SIG_CLIFF = 300                   # ... and of the `config3_sigs300` row: three groups of 128 signatures per wave (the table's last regime before 384)
+CLASS_CLIFF = 80                  # distinct node shapes of the `config3_classes80` row: more than the 64 internal node classes the score table holds
 SIG_RECORD = 200                  # request signatures of the `config3_sigs` sub-record (beyond the 128 two registers per lane hold; the table takes 384)
 C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
 
@@ -298,6 +300,8 @@ def build_workload(args, synth, world):
         return synth.typical_cluster_sweep(), 1
     if args.workload == "widemix":             # the adversarial random object mix: every plugin, 464 node classes -> the all-feature kernel
         return wide_mix_sweep(), 1
+    if args.workload == "config3classes":      # config 3 with 80 distinct node shapes (more than 64 internal node classes)
+        return synth.config3_classes(CLASS_CLIFF, n_counts=args.counts, n_orders=n_orders, n_pods=args.pods), n_orders
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
         return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
     seed = synth.SEED + (3 if world == 1 else 4)
@@ -333,6 +337,7 @@ def workload_name(args, prob, scen_all, n_orders, S_local, world):
             "service": "config 3 with every pod selected by a Service (system-default soft PodTopologySpread constraints): ",
             "typical": "typical cluster (Kubernetes objects: Deployments behind Services, preferred / required self anti-affinity, hard zone constraints): ",
             "widemix": "random Kubernetes-object mix with every plugin (all-feature kernel): ",
+            "config3classes": f"config 3 variant with {CLASS_CLIFF} distinct node shapes (more than 64 internal node classes): ",
             "config3sig": f"config 3 variant with {args.sigs} request signatures: "}.get(
                 args.workload, f"BASELINE config {'3' if world == 1 else '4-style'}: ")
     return (head + f"{prob.n_pods} pods x {int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, "
@@ -424,6 +429,14 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = wide_mix_sweep()
         child = ["--workload", "widemix"]
         wl, label = "config5", "random object mix, 64 candidate sizes"
+    elif name == "config3sig_cliff":                # the price of the cliffs as numbers: 300 signatures ...
+        prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_CLIFF)
+        child = ["--workload", "config3sig", "--sigs", str(SIG_CLIFF)]
+        wl, label = "config3", f"config 3 with {SIG_CLIFF} request signatures"
+    elif name == "config3_classes":                 # ... and 80 node shapes: beyond 64 internal node classes the problem leaves the score table
+        prob, scen, orders = synth.config3_classes(CLASS_CLIFF)
+        child = ["--workload", "config3classes"]
+        wl, label = "config3", f"config 3 with {CLASS_CLIFF} distinct node shapes"
     elif name == "config3sig":                      # config 3 with SIG_RECORD request signatures: the > 128-signature regime as a number
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_RECORD)
         child = ["--workload", "config3sig", "--sigs", str(SIG_RECORD)]
@@ -434,7 +447,8 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
     rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
-                        "config3sig": f"config3_sigs{SIG_RECORD}"}.get(name, f"config5_S{c5_scen}")}
+                        "config3sig": f"config3_sigs{SIG_RECORD}", "config3sig_cliff": f"config3_sigs{SIG_CLIFF}",
+                        "config3_classes": f"config3_classes{CLASS_CLIFF}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
@@ -699,7 +713,7 @@ def main():
     ap.add_argument("--hard", type=int, default=0, help="--workload service: services (every third) with a hard zone constraint on their own pods (maxSkew 2)")
     ap.add_argument("--pref", type=int, default=0, help="--workload service: services whose pods prefer not to sit next to their own kind (hostname 100, zone 50)")
     ap.add_argument("--anti", type=int, default=0, help="--workload service: services whose pods also require anti-affinity to their own kind on the hostname key")
-    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig", "service", "typical", "widemix"], default="config3",
+    ap.add_argument("--workload", choices=["config3", "config5", "config2", "config3sig", "config3classes", "service", "typical", "widemix"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
                          "(GPU share + anti-affinity + taints) on generation 6 of the score-table kernel, --c5-scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
@@ -842,9 +856,12 @@ def main():
             for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", sub_steps, 1, 64, 0), ("service", sub_steps, 1, 64, 0),
                                                  ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
                                                  ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING),
-                                                 ("service_small", sub_steps, 1, 16, 0), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0)):
+                                                 ("service_small", sub_steps, 1, 16, 0), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
+                                                 ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0)):
                 try:
-                    subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s))
+                    cliff = name in ("config3sig_cliff", "config3_classes")          # the two cliff rows: timing + parity only (no PMC passes)
+                    subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, "off" if cliff else mode, c5s,
+                                           cpu_budget_s=3.0 if cliff else 6.0))
                     if subs[-1].get("parity_sample", {}).get("mismatches"):
                         rc = 3
                 except Exception as e:                         # noqa: BLE001

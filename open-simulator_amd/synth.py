@@ -167,6 +167,31 @@ def config3(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het:
     return prob, np.ascontiguousarray(scen, np.int32), orders
 
 
+def config3_classes(n_classes: int = 80, **kw):
+    """config 3 whose 488 existing nodes come in `n_classes` distinct allocatable shapes (cpu 8..64 cores x memory 2..4 GiB per core, drawn
+    with splitmix64) instead of four: every shape is a node class of its own with its own Simon column -- the "more than 64 internal node
+    classes" regime of the score-table kernel as a workload (bench.py: `config3_classes80`)."""
+    prob, scen, orders = config3(**kw)
+    n_het = int(scen[0, 0])
+    rng = SplitMix64(SEED + 31)
+    shapes = []
+    while len(shapes) < n_classes - 1:
+        cores = 8 + 4 * (rng.next() % 15)
+        gib = cores * (2 + rng.next() % 3) + rng.next() % 4
+        if (cores, gib) not in shapes and (cores, gib) != (32, 64):
+            shapes.append((cores, gib))
+    shapes.append((32, 64))                                   # the new-node template keeps its shape (class n_classes - 1)
+    cls = np.array([rng.next() % (n_classes - 1) for _ in range(n_het)] + [n_classes - 1] * (prob.n_nodes - n_het), np.int32)
+    cls[:n_classes - 1] = np.arange(n_classes - 1)             # every shape occurs
+    prob.node_class = cls
+    prob.alloc_cpu = np.array([shapes[c][0] * 1000 for c in cls], np.int64)
+    prob.alloc_mem = np.array([shapes[c][1] << 30 for c in cls], np.int64)
+    prob.n_node_classes = n_classes
+    _, pod_shapes = classify_pods(prob.req_cpu, prob.req_mem)
+    prob.simon_raw = simon_raw_table(pod_shapes, [str(c) for c, _ in shapes], [f"{g}Gi" for _, g in shapes])
+    return prob.normalise(), scen, orders
+
+
 def config4(rank: int = 0, world: int = 1, n_counts: int = 1024, n_orders: int = 32, **kw):
     """Same pool, 32 pod orders = 32k scenarios, interleaved over `world` ranks (scenario s -> rank s % world)."""
     prob, scen, orders = config3(n_counts=n_counts, n_orders=n_orders, seed=SEED + 4, **kw)
