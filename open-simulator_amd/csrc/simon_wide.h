@@ -126,6 +126,14 @@ struct WideCold {
     // match lists restricted to the terms some class OWNS as required anti-affinity (only those have cnt_owner != 0) resp.
     // as a scoring term (only those have w_owner != 0): what Filter's "existing pods" check and Score's symmetry walk read
     const int32_t* manti_off; const int32_t* manti_idx; const int32_t* mown_off; const int32_t* mown_idx;
+    // The hot lists once more with the term's metadata INLINE (one scalar load per entry instead of idx -> term_dom_off / term_key, a
+    // dependent chain per term and batch): low word = term_dom_off[t], bits 32..47 = topology key, bit 48 = the key's domain of node j
+    // IS j (every node carries the label, domains numbered in node order: hostname-like keys, the node-identity key of NodePorts) --
+    // no domain row to load; bits 49..50 = topo_is_hostname[key].  ss_ent is parallel to ss_idx; filt_ent[filt_off[c] ..) = the counters
+    // that must be 0 for a pod of class c (its anti list against cnt_match, then the matched-and-required terms against cnt_owner:
+    // the offset is absolute inside the scenario's counter block); ipa_ent / ipa_w likewise = the InterPodAffinity raw score's
+    // summands (pref terms x cnt_match with their weights, matched-and-owned terms x w_owner with weight 1).
+    const uint64_t* ss_ent; const int32_t* filt_off; const uint64_t* filt_ent; const int32_t* ipa_off; const uint64_t* ipa_ent; const int32_t* ipa_w;
     const int32_t* aff_off; const int32_t* aff_idx; const uint8_t* class_flags;
     const int32_t* port_off; const int32_t* port_idx;
     const int32_t* pref_off; const int32_t* pref_idx; const int32_t* pref_w;
@@ -195,7 +203,7 @@ struct WideKnobs {
 
 struct WideDevice {
     WideKnobs knobs;
-    void* blobs[80] = {};
+    void* blobs[96] = {};
     int n_blobs = 0;
     int state_chunk = 0;   // scenarios whose state is allocated
     int total_dom = 0, seen_stride = 0;
@@ -215,6 +223,8 @@ struct WideDevice {
             *sh_off = nullptr, *sh_idx = nullptr, *sh_skew = nullptr, *sh_self = nullptr, *sh_set = nullptr,
             *sh_first_reg = nullptr, *ss_off = nullptr, *ss_idx = nullptr, *ss_skew = nullptr, *key_seen_off = nullptr;
     uint64_t* node_sets = nullptr;
+    uint64_t *ss_ent = nullptr, *filt_ent = nullptr, *ipa_ent = nullptr;
+    int32_t *filt_off = nullptr, *ipa_off = nullptr, *ipa_w = nullptr;
     uint8_t *class_flags = nullptr, *topo_is_hostname = nullptr;
     double* spread_log = nullptr;
     WidePod* pods = nullptr;

@@ -204,7 +204,13 @@ __device__ __forceinline__ bool in_set(const WideArgs& A, int set, int j) {
 }
 __device__ __forceinline__ int term_dom(const WideArgs& A, int t, int j) { return COLD(A)->topo_dom[(size_t)COLD(A)->term_key[t] * A.N + j]; }
 
+// packed list entries (WideCold::*_ent): metadata of a term without the idx -> term table chain
+__device__ __forceinline__ int ent_off(unsigned long long e) { return (int)(unsigned)e; }
+__device__ __forceinline__ int ent_key(unsigned long long e) { return (int)((e >> 32) & 0xFFFFu); }
+__device__ __forceinline__ bool ent_ident(unsigned long long e) { return (e >> 48) & 1ull; }
+
 constexpr int kU = 4;    // nodes per lane per load batch, full evaluation
+constexpr int kGather = 4;   // list entries whose counter loads are in flight together (gather_terms)
 #ifndef SIMON_KUT
 #define SIMON_KUT 5   // same-box A/B of 4 / 5 / 6 / 8: 8 spills (i64 batch arrays), 5 fits 10 and 20 nodes per lane without a ragged batch
 #endif
@@ -546,40 +552,51 @@ __device__ __forceinline__ unsigned filter_code(const WideArgs& A, const NodeVie
 // every term costs two memory round trips for the WHOLE batch (domain row,
 // then counters) instead of two per node.  m[u] = node u takes part; results only for those.  Same integer sums, same
 // order of the floating-point additions per node as the scalar versions.
+// state[off_e + domain_e(node)] of a batch of nodes for the entries [lo, hi) of a packed list (WideCold::filt_ent / ipa_ent: the offset
+// is absolute inside the scenario's counter block), kGather entries at a time: their domain rows go out together, then all their
+// counters -- two memory round trips per group instead of two per entry (the per-scenario counters do not fit the L2: a round trip
+// is a trip to the Infinity Cache / HBM).  consume(e, cv): the values of entry e, 0 where the node is not `valid` or lacks the label.
+template <class F>
+__device__ __forceinline__ void gather_terms(const WideArgs& A, const int32_t* state, const uint64_t* ents, int lo, int hi,
+                                             const int (&jn)[kUT], const bool (&valid)[kUT], F consume) {
+    for (int e0 = lo; e0 < hi; e0 += kGather) {
+        uint64_t ent[kGather];
+#pragma unroll
+        for (int g = 0; g < kGather; ++g) ent[g] = ents[e0 + g < hi ? e0 + g : lo];
+        int x[kGather][kUT];
+#pragma unroll
+        for (int g = 0; g < kGather; ++g) {
+            if (ent_ident(ent[g])) {
+#pragma unroll
+                for (int u = 0; u < kUT; ++u) x[g][u] = jn[u];
+            } else {
+                const int32_t* drow = COLD(A)->topo_dom + (size_t)ent_key(ent[g]) * A.N;
+#pragma unroll
+                for (int u = 0; u < kUT; ++u) x[g][u] = drow[jn[u]];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kGather; ++g) {
+            const int off = ent_off(ent[g]);
+#pragma unroll
+            for (int u = 0; u < kUT; ++u) x[g][u] = (valid[u] && x[g][u] >= 0) ? state[off + x[g][u]] : 0;
+        }
+#pragma unroll
+        for (int g = 0; g < kGather; ++g)
+            if (e0 + g < hi) consume(e0 + g, x[g]);
+    }
+}
+
 __device__ __forceinline__ void ipa_raw8(const WideArgs& A, const NodeView& v, const WidePod& p, const int (&jn)[kUT], const bool (&m)[kUT],
                                          long long (&out)[kUT]) {
 #pragma unroll
     for (int u = 0; u < kUT; ++u) out[u] = 0;
-    int d[kUT], last_key = -1;          // lists sorted by topology key: one domain-row load per key
-    for (int e = COLD(A)->pref_off[p.cls]; e < COLD(A)->pref_off[p.cls + 1]; ++e) {
-        const int t = COLD(A)->pref_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
-        const long long w = COLD(A)->pref_w[e];
-        if (key != last_key) {
-            const int32_t* drow = COLD(A)->topo_dom + (size_t)key * A.N;
-#pragma unroll
-            for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
-            last_key = key;
-        }
-        int cv[kUT];
-#pragma unroll
-        for (int u = 0; u < kUT; ++u) cv[u] = (m[u] && d[u] >= 0) ? v.cnt_match()[off + d[u]] : 0;
+    // pref entries read cnt_match (weight pref_w), the matched-and-owned terms read w_owner (weight 1): ONE list (WideCold::ipa_ent)
+    gather_terms(A, v.cnt_match(), COLD(A)->ipa_ent, COLD(A)->ipa_off[p.cls], COLD(A)->ipa_off[p.cls + 1], jn, m, [&](int e, const int (&cv)[kUT]) {
+        const long long w = COLD(A)->ipa_w[e];
 #pragma unroll
         for (int u = 0; u < kUT; ++u) out[u] += w * cv[u];
-    }
-    for (int e = COLD(A)->mown_off[p.cls]; e < COLD(A)->mown_off[p.cls + 1]; ++e) {
-        const int t = COLD(A)->mown_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
-        if (key != last_key) {
-            const int32_t* drow = COLD(A)->topo_dom + (size_t)key * A.N;
-#pragma unroll
-            for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
-            last_key = key;
-        }
-        int cv[kUT];
-#pragma unroll
-        for (int u = 0; u < kUT; ++u) cv[u] = (m[u] && d[u] >= 0) ? v.w_owner()[off + d[u]] : 0;
-#pragma unroll
-        for (int u = 0; u < kUT; ++u) out[u] += cv[u];
-    }
+    });
 }
 __device__ __forceinline__ void pts_raw8(const WideArgs& A, const NodeView& v, const WidePod& p, const int (&jn)[kUT], const bool (&m)[kUT],
                                          const Weight4& weight, long long (&out)[kUT]) {
@@ -588,12 +605,18 @@ __device__ __forceinline__ void pts_raw8(const WideArgs& A, const NodeView& v, c
 #pragma unroll
     for (int u = 0; u < kUT; ++u) score[u] = 0.0;
     for (int e = lo; e < hi; ++e) {
-        const int t = COLD(A)->ss_idx[e], off = COLD(A)->term_dom_off[t];
-        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * A.N;
+        const unsigned long long ent = COLD(A)->ss_ent[e];
+        const int off = ent_off(ent);
+        const int32_t* drow = COLD(A)->topo_dom + (size_t)ent_key(ent) * A.N;
         const double w = sel4(weight, e - lo), add = (double)((COLD(A)->ss_skew[e] & ~SIMON_SPREAD_DUP_KEY) - 1);
         int d[kUT], cv[kUT];
+        if (ent_ident(ent)) {
 #pragma unroll
-        for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : 0;
+            for (int u = 0; u < kUT; ++u) d[u] = m[u] ? jn[u] : 0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUT; ++u) d[u] = m[u] ? drow[jn[u]] : 0;
+        }
 #pragma unroll
         for (int u = 0; u < kUT; ++u) cv[u] = m[u] ? v.cnt_match()[off + d[u]] : 0;
 #pragma unroll
@@ -842,10 +865,15 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                     for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
                         if (q >= n_soft) continue;
-                        const int t = COLD(A)->ss_idx[slo + q];
-                        const int32_t* drow = COLD(A)->topo_dom + (size_t)COLD(A)->term_key[t] * N;
+                        const unsigned long long ent = COLD(A)->ss_ent[slo + q];
+                        if (ent_ident(ent)) {
 #pragma unroll
-                        for (int u = 0; u < kUT; ++u) dq[q][u] = m[u] ? drow[jn[u]] : 0;
+                            for (int u = 0; u < kUT; ++u) dq[q][u] = m[u] ? jn[u] : 0;
+                        } else {
+                            const int32_t* drow = COLD(A)->topo_dom + (size_t)ent_key(ent) * N;
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) dq[q][u] = m[u] ? drow[jn[u]] : 0;
+                        }
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) ig[u] = ig[u] || dq[q][u] < 0;
                     }
@@ -860,7 +888,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                         for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
                             if (q >= n_soft) continue;
-                            const int off = COLD(A)->term_dom_off[COLD(A)->ss_idx[slo + q]];
+                            const int off = ent_off(COLD(A)->ss_ent[slo + q]);
 #pragma unroll
                             for (int u = 0; u < kUT; ++u) cq[q][u] = (m[u] && !ig[u]) ? v.cnt_match()[off + dq[q][u]] : 0;
                         }
@@ -868,8 +896,9 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                     for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
                         if (q >= n_soft) continue;
-                        const int t = COLD(A)->ss_idx[slo + q], key = COLD(A)->term_key[t];
-                        const unsigned kind = COLD(A)->topo_is_hostname[key];
+                        const unsigned long long ent = COLD(A)->ss_ent[slo + q];
+                        const int key = ent_key(ent);
+                        const unsigned kind = (unsigned)(ent >> 49) & 3u;          // topo_is_hostname[key]: bit 0 hostname-like, bit 1 <= 32 domains
                         if (kind & 1u) continue;
                         if (kind & 2u) {                                           // <= 32 domains: a presence mask, reduced with stage A's reduction
                             unsigned zm = 0;
@@ -982,37 +1011,16 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             for (int u = 0; u < kUT; ++u) act[u] = act[u] && (exist[u] || escape);
                         }
                         if (p.flags & kPodFilt) {
-                            // the lists are sorted by topology key at stage time: the domain row of the batch is loaded once
-                            // per key, each term then costs ONE round trip (its counters)
-                            int d[kUT], last_key = -1;
-                            for (int e = COLD(A)->anti_off[p.cls]; e < COLD(A)->anti_off[p.cls + 1]; ++e) {   // filtering.go:334-346
-                                const int t = COLD(A)->anti_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
-                                if (key != last_key) {
-                                    const int32_t* drow = COLD(A)->topo_dom + (size_t)key * N;
+                            // filtering.go:334-346 (the pod's own anti-affinity terms against cnt_match) and :319-332 (existing pods' terms the
+                            // pod matches, against cnt_owner): ONE list of counters that must be 0 (WideCold::filt_ent)
+                            bool was[kUT];
 #pragma unroll
-                                    for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
-                                    last_key = key;
-                                }
-                                int cv[kUT];
-#pragma unroll
-                                for (int u = 0; u < kUT; ++u) cv[u] = (act[u] && d[u] >= 0) ? v.cnt_match()[off + d[u]] : 0;
+                            for (int u = 0; u < kUT; ++u) was[u] = act[u];
+                            gather_terms(A, v.cnt_match(), COLD(A)->filt_ent, COLD(A)->filt_off[p.cls], COLD(A)->filt_off[p.cls + 1], jn, was,
+                                         [&](int, const int (&cv)[kUT]) {
 #pragma unroll
                                 for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
-                            }
-                            for (int e = COLD(A)->manti_off[p.cls]; e < COLD(A)->manti_off[p.cls + 1]; ++e) { // filtering.go:319-332
-                                const int t = COLD(A)->manti_idx[e], off = COLD(A)->term_dom_off[t], key = COLD(A)->term_key[t];
-                                if (key != last_key) {
-                                    const int32_t* drow = COLD(A)->topo_dom + (size_t)key * N;
-#pragma unroll
-                                    for (int u = 0; u < kUT; ++u) d[u] = drow[jn[u]];
-                                    last_key = key;
-                                }
-                                int cv[kUT];
-#pragma unroll
-                                for (int u = 0; u < kUT; ++u) cv[u] = (act[u] && d[u] >= 0) ? v.cnt_owner()[off + d[u]] : 0;
-#pragma unroll
-                                for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
-                            }
+                            });
                         }
                         if (p.flags & kPodLocal) {                                                                // open-local.go:51-91
 #pragma unroll
@@ -1583,6 +1591,7 @@ void fill_args(const WideDevice& w, const HostInputs& in, WideArgs& a, WideCold&
     c.term_key = w.term_key; c.term_dom_off = w.term_dom_off; c.term_set = w.term_set; c.node_sets = w.node_sets;
     c.anti_off = w.anti_off; c.anti_idx = w.anti_idx; c.match_off = w.match_off; c.match_idx = w.match_idx;
     c.manti_off = w.manti_off; c.manti_idx = w.manti_idx; c.mown_off = w.mown_off; c.mown_idx = w.mown_idx;
+    c.ss_ent = w.ss_ent; c.filt_off = w.filt_off; c.filt_ent = w.filt_ent; c.ipa_off = w.ipa_off; c.ipa_ent = w.ipa_ent; c.ipa_w = w.ipa_w;
     c.aff_off = w.aff_off; c.aff_idx = w.aff_idx; c.class_flags = w.class_flags;
     c.port_off = w.port_off; c.port_idx = w.port_idx;
     c.pref_off = w.pref_off; c.pref_idx = w.pref_idx; c.pref_w = w.pref_w;
@@ -1717,6 +1726,29 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         is_host[k] = is_host[k] ? 1 : 0;
         if (!is_host[k] && k < (int)in.topo_n_dom.size() && in.topo_n_dom[k] <= 32 && !getenv("SIMON_WIDE_NO_ZMASK")) is_host[k] |= 2;
     }
+    // the hot lists with their terms' metadata inline (WideCold::*_ent)
+    std::vector<char> key_ident(std::max(in.Kt, 1), 0);
+    for (int k = 0; k < in.Kt && !getenv("SIMON_WIDE_NO_IDENT"); ++k) {
+        bool ok = true;
+        for (size_t j = 0; j < N && ok; ++j) ok = in.topo_dom[(size_t)k * N + j] == (int32_t)j;
+        key_ident[k] = ok;
+    }
+    auto entry = [&](int t, int block) -> uint64_t {      // block: 0 cnt_match, 1 cnt_owner, 2 w_owner (NodeView)
+        if (t < 0 || t >= in.Tm) return 0;
+        const uint64_t key = (uint64_t)in.term_key[t];
+        return (uint64_t)(uint32_t)(dom_off[t] + block * total) | (key << 32) | ((uint64_t)key_ident[key] << 48) | ((uint64_t)(is_host[key] & 3) << 49);
+    };
+    std::vector<uint64_t> ss_ent(in.ss_idx.size()), filt_ent, ipa_ent;
+    for (size_t e = 0; e < in.ss_idx.size(); ++e) ss_ent[e] = entry(in.ss_idx[e], 0);
+    std::vector<int32_t> filt_off(Cp + 1, 0), ipa_off(Cp + 1, 0), ipa_w;
+    for (int c = 0; c < Cp; ++c) {
+        for (int e = anti_off[c]; e < anti_off[c + 1]; ++e) filt_ent.push_back(entry(anti_sorted[e], 0));
+        for (int e = manti_off[c]; e < manti_off[c + 1]; ++e) filt_ent.push_back(entry(manti_idx[e], 1));
+        filt_off[c + 1] = (int32_t)filt_ent.size();
+        for (int e = pref_off[c]; e < pref_off[c + 1]; ++e) { ipa_ent.push_back(entry(pref_sorted[e], 0)); ipa_w.push_back(pref_w_sorted[e]); }
+        for (int e = mown_off[c]; e < mown_off[c + 1]; ++e) { ipa_ent.push_back(entry(mown_idx[e], 2)); ipa_w.push_back(1); }
+        ipa_off[c + 1] = (int32_t)ipa_ent.size();
+    }
     // first eligible node per (hard constraint, node's domain): registered(j, n) = first_reg[e][j] < n
     std::vector<int32_t> first_reg(std::max<size_t>(in.sh_idx.size() * N, 1), INT_MAX);
     const size_t words = (N + 63) / 64;
@@ -1797,6 +1829,7 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     PUT(term_key, in.term_key, 1); PUT(term_dom_off, dom_off, 1); PUT(term_set, term_set, 1); PUT(node_sets, in.node_sets, 1);
     PUT(anti_off, anti_off, 1); PUT(anti_idx, anti_sorted, 1); PUT(match_off, match_off, 1); PUT(match_idx, in.match_idx, 1);
     PUT(manti_off, manti_off, 1); PUT(manti_idx, manti_idx, 1); PUT(mown_off, mown_off, 1); PUT(mown_idx, mown_idx, 1);
+    PUT(ss_ent, ss_ent, 1); PUT(filt_off, filt_off, 1); PUT(filt_ent, filt_ent, 1); PUT(ipa_off, ipa_off, 1); PUT(ipa_ent, ipa_ent, 1); PUT(ipa_w, ipa_w, 1);
     PUT(aff_off, aff_off, 1); PUT(aff_idx, in.aff_idx, 1); PUT(class_flags, class_flags, 1);
     PUT(port_off, port_off, 1); PUT(port_idx, in.port_idx, 1);
     PUT(pref_off, pref_off, 1); PUT(pref_idx, pref_sorted, 1); PUT(pref_w, pref_w_sorted, 1);
