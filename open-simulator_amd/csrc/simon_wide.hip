@@ -95,6 +95,21 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
             for (int k = 0; k < kRed; ++k) if (k < cm || (k >= c0 && k < c0 + cs)) mb[wave][k] = r[k];
         }
         __syncthreads();
+#ifdef SIMON_WG_REDUCE_LANES
+        // lane k combines slot k over the waves (NW reads by kRed lanes instead of NW x kRed reads by every lane), then every lane takes the
+        // kRed results with shuffles.  Measured -3.4 % on the random mix (2 050 -> 1 980 ms, profiles/r04/r04u_*), but with it the
+        // Open-Local case of test_random_v2_features at 1 024 threads reports another used_vg (placements identical): OFF until understood.
+        const int k_ = lane < kRed ? lane : 0;
+        const bool is_max = k_ < cm;
+        long long acc = mb[0][k_];
+        for (int w = 1; w < NW; ++w) { const long long x = mb[w][k_]; acc = is_max ? (x > acc ? x : acc) : acc + x; }
+        const unsigned lo32 = (unsigned)acc, hi32 = (unsigned)((unsigned long long)acc >> 32);
+#pragma unroll
+        for (int k = 0; k < kRed; ++k) {
+            if (k < cm || (k >= c0 && k < c0 + cs))
+                r[k] = (long long)(((unsigned long long)(unsigned)__shfl((int)hi32, k, 64) << 32) | (unsigned)__shfl((int)lo32, k, 64));
+        }
+#else
 #pragma unroll
         for (int k = 0; k < kRed; ++k) {
             if (k < cm) {
@@ -107,6 +122,7 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
                 r[k] = m;
             }
         }
+#endif
     }
 }
 
@@ -114,6 +130,16 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
 // integer correction.  Equals Go's truncating int64 division on these operands.
 __device__ __forceinline__ long long divq(long long num, long long den) {
     long long q = (long long)((double)num / (double)den);
+    const long long r = num - q * den;
+    q += (r >= den) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+// The same quotient from a precomputed rden = 1.0 / (double)den (den uniform over the nodes of a cycle: one division per pod instead of
+// one per node): the product is within one of the quotient for num < 2^52, the integer correction makes it exact.
+__device__ __forceinline__ long long divq_r(long long num, long long den, double rden) {
+    long long q = (long long)((double)num * rden);
     const long long r = num - q * den;
     q += (r >= den) ? 1 : 0;
     q -= (r < 0) ? 1 : 0;
@@ -723,11 +749,14 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     // probes that force loads to complete cost registers and waits the product build must not pay.
 #ifdef SIMON_WIDE_PROFILE
     constexpr bool kProfile = true;
-    unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (A.flags & kArgProf) ? __builtin_amdgcn_s_memtime() : 0;
 #define SIMON_PROF(slot) do { if (A.flags & kArgProf) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf[slot] += t_ - t_prev; t_prev = t_; } } while (0)
+// a stamp INSIDE stage A's batch loop: outstanding loads are waited for first, so the time lands in the phase that issued them
+#define SIMON_PROF_W(slot) do { if (A.flags & kArgProf) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); SIMON_PROF(slot); } } while (0)
 #else
     constexpr bool kProfile = false;
 #define SIMON_PROF(slot) do { } while (0)
+#define SIMON_PROF_W(slot) do { } while (0)
 #endif
     for (int i = 0; i < P; ++i) {
         const int pid = next_pid;
@@ -1010,6 +1039,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                             for (int u = 0; u < kUT; ++u) act[u] = act[u] && (exist[u] || escape);
                         }
+                        SIMON_PROF_W(12);                                       // batch arrived, ports / hard constraints / required affinity
                         if (p.flags & kPodFilt) {
                             // filtering.go:334-346 (the pod's own anti-affinity terms against cnt_match) and :319-332 (existing pods' terms the
                             // pod matches, against cnt_owner): ONE list of counters that must be 0 (WideCold::filt_ent)
@@ -1022,6 +1052,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                                 for (int u = 0; u < kUT; ++u) act[u] = act[u] && cv[u] <= 0;
                             });
                         }
+                        SIMON_PROF_W(13);                                       // the counters that must be 0
                         if (p.flags & kPodLocal) {                                                                // open-local.go:51-91
 #pragma unroll
                             for (int u = 0; u < kUT; ++u)
@@ -1047,7 +1078,9 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #pragma unroll
                         for (int u = 0; u < kUT; ++u)
                             if (act[u]) on_feasible(jn[u], it0 + u, b[u] - 1u, ncl[u]);
+                        SIMON_PROF_W(14);                                       // GPU share / Open-Local filters, bookkeeping of the feasible nodes
                         extras8(jn, act, it0);
+                        SIMON_PROF_W(15);                                       // InterPodAffinity raw scores, soft spread constraints' counts
                     }
                 }
             } else {
@@ -1245,6 +1278,11 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                 // ---------------- stage B: totals, first maximum in canonical order ---------------------------
                 const long long range = hi - lo;
                 const long long ipa_diff = ipa_max - ipa_min;
+                // the per-node normalisations divide by per-pod constants: their reciprocals once (IEEE division), the nodes multiply --
+                // InterPodAffinity needs the correctly rounded quotient (div_by_rcp: two Markstein corrections, integers below 2^53),
+                // PodTopologySpread the truncated integer quotient (divq_r)
+                const double ipa_rc = ipa_diff > 0 ? 1.0 / (double)ipa_diff : 0.0;
+                const double pts_rc = pts_max > 0 ? 1.0 / (double)pts_max : 0.0;
                 // per-class normalised terms: Simon + Open-Gpu-Share (simon.go:90-98, two plugins), NodeAffinity /
                 // TaintToleration (helper/normalize_score.go:27-52), NodePreferAvoidPods
                 auto class_term = [&](int nc) -> long long {
@@ -1284,7 +1322,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                         }
 #pragma unroll
                         for (int u = 0; u < kUT; ++u)
-                            if (val[u]) total[u] += (long long)(100.0 * ((double)(x[u] - ipa_min) / (double)ipa_diff));
+                            if (val[u]) total[u] += (long long)(100.0 * div_by_rcp((double)(x[u] - ipa_min), (double)ipa_diff, ipa_rc));
                     }
                     if (local && l_hi != l_lo) {                   // open-local.go:155-163
 #pragma unroll
@@ -1321,7 +1359,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             long long xx;
                             if ((ign >> (it0 + u)) & 1u) xx = 0;
                             else if (pts_max == 0) xx = 100;
-                            else xx = divq(100 * (pts_max + pts_min - x[u]), pts_max);
+                            else xx = divq_r(100 * (pts_max + pts_min - x[u]), pts_max, pts_rc);
                             total[u] += 2 * xx;
                         }
                     }
@@ -1451,7 +1489,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
 #undef SIMON_PROF
 #ifdef SIMON_WIDE_PROFILE
     if ((A.flags & kArgProf) && lane == 0)
-        for (int k = 0; k < 12; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 16 + k] = pf[k];
+        for (int k = 0; k < 16; ++k) COLD(A)->prof[((size_t)s * 16 + wave) * 16 + k] = pf[k];
 #endif
 
     long long uc = 0, um = 0, uv = 0;
@@ -1933,15 +1971,16 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(d_prof);
-        const char* names[12] = {"pod row", "reduce+barrier", "stage A2 | table-only: batch wait", "stage B + reduce", "assume: counter barrier", "stage A (table only)",
+        const char* names[16] = {"pod row", "reduce+barrier", "stage A2 | table-only: batch wait", "stage B + reduce", "assume: counter barrier", "stage A (table only)",
                                  "stage A (node filters)", "stage A (topology terms)", "assume: row load", "assume: row stores + counters",
-                                 "assume: column", "table-only: setup"};
+                                 "assume: column", "table-only: setup", "A: batch arrival + ports/hard/aff", "A: zero-counter list", "A: gpu/local + feasible bookkeeping",
+                                 "A: extras (ipa + soft)"};
         const int NWv = T / 64;
         for (int w : {0, NWv - 1}) {
-            double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = 0; s < S; ++s) for (int k = 0; k < 12; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 16 + k];
+            double sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < S; ++s) for (int k = 0; k < 16; ++k) sum[k] += (double)h[((size_t)s * 16 + w) * 16 + k];
             fprintf(stderr, "[SIMON_WIDE_PROF] wave %d, ticks per cycle:", w);
-            for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
+            for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.1f", names[k], sum[k] / S / std::max(in.P, 1));
             fprintf(stderr, "\n");
         }
     }

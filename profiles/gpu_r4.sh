@@ -62,6 +62,8 @@ for STAGE in "$@"; do
       if [ -f open-simulator_amd/csrc/libsimon_hip_prof.so ]; then
         ( SIMON_WIDE_PROF=1 SIMON_HIP_LIB=$PWD/open-simulator_amd/csrc/libsimon_hip_prof.so SIMON_BENCH_DETAIL=/tmp/d.json timeout 600 python bench.py --workload widemix --pmc off --no-cpu-baseline --no-sub --steps 1 --warmup 0 2>&1 | grep SIMON_WIDE_PROF | tail -2 ) > "$OUT/wide_phase_profile.txt"; cut -c1-900 "$OUT/wide_phase_profile.txt"
       fi ;;
+    wide_pmc)    # instruction-cache and wave-state counters of the all-feature kernel on the random mix (separate passes, kernel-trace only)
+      ( timeout 900 python profiles/pmc_pass.py "--workload widemix --steps 1 --warmup 0" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH SQ_INSTS_VALU SQ_INSTS_SALU" 2>&1 | tail -6 ) > "$OUT/wide_pmc.txt"; cut -c1-1200 "$OUT/wide_pmc.txt" ;;
     wide_tests)  # the all-feature kernel's parity tests (random feature sets, three workgroup shapes) + the k8s-object sweeps on it
       ( timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "v2_features or k8s or explain" 2>&1 | tail -8 ) > "$OUT/pytest_wide.log"; tail -3 "$OUT/pytest_wide.log" ;;
     *) echo "unknown stage $STAGE" ;;
