@@ -109,7 +109,8 @@ struct simon_ctx : simon::HostInputs {
     bool has_static = false;                     // static score tables present (score-table kernel: class term; else all-feature kernel)
     DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
-    bool no_gpu_split = false, force_table = false, no_class_content = false;
+    bool no_gpu_split = false, force_table = false, no_class_content = false, no_gpu_fold = false;
+    bool gfold = false;                           // Open-Gpu-Share folded into the score table: the GPU request is part of the signature (gfold_supported)
     bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
     // fold: required anti-affinity / host ports on node-level topology keys as MONOTONE INFEASIBILITY of the score table -- a pod that
@@ -308,6 +309,56 @@ bool rest_supported(simon_ctx* c) {
     return true;
 }
 
+// Open-Gpu-Share FOLDED into the score table (round 4).  "GPU request g no longer fits node j" is monotone -- device memory is only ever
+// booked -- which is what a 0 in the (signature, node) table already means.  With the GPU request made part of the request signature
+// the assume of a GPU pod books the devices (Reserve) and zeroes the bytes of the signatures whose request stopped fitting; a GPU pod
+// then needs NO select-time filter: it takes the summary scan, or generation 7's walk when a Service selects it.  Worth it when the
+// signatures stay few (real gpushare workloads: a handful of Deployments) -- config 5's 42 shapes x 8 GPU requests keep the position
+// masks of generation 6.  Needs: no arriving gpu-index lists, GPU quantities on a gcd with quotients < 2^31 (fills g_gpu), at most
+// 128 signatures once the GPU request is part of them.
+bool gfold_supported(simon_ctx* c) {
+    if (c->no_gpu_fold || c->no_rest || !c->has_gpu || c->has_gpu_index || c->gpu_cnt.empty()) return false;   // (SIMON_NO_REST keeps meaning: GPU problems on the all-feature kernel)
+    uint64_t g = 0;
+    auto take = [&](int64_t x) { if (x < 0) return false; g = gcd_u64(g, (uint64_t)x); return true; };
+    for (int j = 0; j < c->N; ++j) {
+        if (c->gpu_mem_total[j] < 0) return false;
+        if (c->gpu_cnt[j] > 0 && !take(c->gpu_mem_total[j] / c->gpu_cnt[j])) return false;
+        for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) if (!take(c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d])) return false;
+    }
+    for (int p = 0; p < c->P; ++p) if (c->p_gpu_mem[p] > 0) take(c->p_gpu_mem[p]);
+    if (!g) g = 1;
+    const uint64_t lim31 = 1ull << 31;
+    for (int j = 0; j < c->N; ++j) {
+        if (c->gpu_cnt[j] > 0 && (uint64_t)(c->gpu_mem_total[j] / c->gpu_cnt[j]) / g >= lim31) return false;
+        for (int d = 0; d < SIMON_MAX_GPU_DEV; ++d) if ((uint64_t)c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d] / g >= lim31) return false;
+    }
+    for (int p = 0; p < c->P; ++p) if (c->p_gpu_mem[p] > 0 && (uint64_t)c->p_gpu_mem[p] / g >= lim31) return false;
+    // signatures the table would need: (request, content of the class's static rows as stage_narrow interns them, GPU request)
+    const int Cp = c->Cp;
+    std::vector<int32_t> content_of(Cp);
+    {
+        const size_t words = (size_t)(c->N + 63) / 64;
+        std::map<std::pair<std::vector<uint64_t>, std::vector<int64_t>>, int> ids;
+        for (int cp = 0; cp < Cp; ++cp) {
+            std::vector<uint64_t> mrow;
+            if (c->has_mask) mrow.assign(c->static_mask.begin() + (size_t)cp * words, c->static_mask.begin() + (size_t)(cp + 1) * words);
+            std::vector<int64_t> rrow;
+            for (const std::vector<int64_t>* tab : {&c->simon_raw, &c->na_raw, &c->tt_raw, &c->static_add})
+                if (!tab->empty()) rrow.insert(rrow.end(), tab->begin() + (size_t)cp * c->Cn, tab->begin() + (size_t)(cp + 1) * c->Cn);
+            content_of[cp] = ids.emplace(std::make_pair(std::move(mrow), std::move(rrow)), (int)ids.size()).first->second;
+        }
+    }
+    std::set<std::tuple<int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, int64_t, int32_t>> sig;
+    for (int p = 0; p < c->P; ++p) {
+        const bool gp = c->p_gpu_mem[p] > 0;
+        sig.insert(std::make_tuple(c->p_req_cpu[p], c->p_req_mem[p], c->p_nz_cpu[p], c->p_nz_mem[p], content_of[c->p_cls[p]],
+                                   c->fold ? c->fold_fc[c->p_cls[p]] : 0, gp ? c->p_gpu_mem[p] : 0, gp ? std::min(c->p_gpu_cnt[p], 64) : 0));
+        if ((int)sig.size() > 128) return false;
+    }
+    c->g_gpu = g;
+    return true;
+}
+
 // Can the score-table kernel's SPREAD path (generation 7) take this problem?  Of the ABI v2 features: SOFT PodTopologySpread constraints
 // (+ the static score tables the class term folds in), InterPodAffinity PREFERRED terms whose owners hold one weight per pod with at
 // most one hostname-like counter per class, HARD spread constraints on zone-like keys whose eligible nodes are all the
@@ -325,7 +376,7 @@ bool spread_supported(simon_ctx* c) {
     if (c->has_ipa_score && c->no_ipa_fold) return false;
     if (c->has_local || !c->aff_idx.empty()) return false;
     if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold) return false;   // required anti-affinity / ports: only folded into the table
-    if (c->has_gpu || c->has_gpu_index) return false;
+    if (c->has_gpu_index || (c->has_gpu && !c->gfold)) return false;      // (GPU share: only folded into the table, gfold_supported)
     if (c->topo_is_hostname.empty()) return false;
     if (!c->ss_idx.empty() && c->spread_log.size() < (size_t)c->N + 1) return false;
     int64_t max_pods = 0;
@@ -637,6 +688,7 @@ void choose_variant(simon_ctx* c) {
     c->spread = false;
     c->has_static = c->has_na || c->has_tt || c->has_add;
     c->fold = fold_supported(c);
+    c->gfold = gfold_supported(c);
     if (c->v2_features_but_ports_and_static()) {
         if (!spread_supported(c)) return;                         // only soft spread constraints: generation 7 of the score-table kernel
         c->spread = true;
@@ -661,7 +713,9 @@ void choose_variant(simon_ctx* c) {
     if (c->fold && c->xres) c->fold = false;                        // (extra-resource rows live on the REST path)
     // anti-affinity / ports without soft spread constraints: the fold while two signatures per lane hold them, else the position masks
     if (c->fold && !c->spread && c->fold_sigs > 128 && rest_supported(c)) c->fold = false;
-    const bool wants_rest = !c->spread && !c->fold && (c->has_gpu || c->Tm > 0 || c->xres);
+    // the GPU fold serves problems that need no other per-node filter row: plain cpu+memory+GPU, and generation 7's (Services next to GPU pods)
+    if (c->gfold && ((!c->spread && c->Tm > 0) || c->xres)) c->gfold = false;
+    const bool wants_rest = !c->spread && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
     if (c->spread && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
     if (c->spread && !c->fold && (!c->anti_idx.empty() || !c->port_idx.empty())) { c->spread = false; return; }
     if (wants_rest && !rest_supported(c)) return;
@@ -755,7 +809,7 @@ int stage_narrow(simon_ctx* c) {
             tc_of[cp] = it.first->second;
         }
         const int Ctc = (int)tc_rep.size();
-        std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t, int32_t>, int> sig_id;
+        std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t, int32_t, uint32_t, int32_t>, int> sig_id;
         std::vector<SigRow> sigs;
         std::vector<int32_t> sig_fc;          // fold: filter class of a signature
         std::vector<PodRowC> rowsC(P);
@@ -763,13 +817,18 @@ int stage_narrow(simon_ctx* c) {
             const PodRowN& r = rows[p];
             const int32_t tc = tc_of[r.cls];
             const int32_t fc = c->fold ? c->fold_fc[r.cls] : 0;
-            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, tc, r.flags, fc);
+            // GPU fold: the (gpu-mem per device in gcd units, device count) request is part of the signature
+            const bool gp = c->gfold && c->p_gpu_mem[p] > 0;
+            const uint32_t gq = gp ? (uint32_t)((uint64_t)c->p_gpu_mem[p] / c->g_gpu) : 0u;
+            const int32_t gn = gp ? std::min(c->p_gpu_cnt[p], 64) : 0;
+            auto key = std::make_tuple(r.req_cpu, r.req_mem, r.nz_cpu, r.nz_mem, tc, r.flags, fc, gq, gn);
             auto it = sig_id.find(key);
             if (it == sig_id.end()) {
                 if ((int)sigs.size() == kTableMaxSigs) { c->table_ok = false; break; }
                 it = sig_id.emplace(key, (int)sigs.size()).first;
                 SigRow sr{};
                 sr.req_c = r.req_cpu; sr.req_m = r.req_mem; sr.nz_c = r.nz_cpu; sr.nz_m = r.nz_mem; sr.cls = tc; sr.flags = r.flags;
+                sr.pad[0] = (int32_t)gq; sr.pad[1] = gp ? (gn > 0 ? gn : -1) : 0;      // (pad[1] != 0 marks a GPU signature; a request without devices fits nowhere)
                 sigs.push_back(sr);
                 sig_fc.push_back(fc);
             }
@@ -779,7 +838,8 @@ int stage_narrow(simon_ctx* c) {
         // above a TWIN -- the same request under another table class -- the kernel evaluates a lane's node byte once for both
         // (TableScalars::static_tables & 16; config 5: 42 request shapes x 2 table classes).  A permutation of the ids, nothing else.
         c->sig_twins = false;
-        if (c->table_ok && !c->no_sig_twins && sigs.size() > 64 && sigs.size() <= 128) {
+        if (c->gfold && sigs.size() > 128) c->table_ok = false;      // (gfold_supported counted them: cannot happen)
+        if (c->table_ok && !c->no_sig_twins && !c->gfold && sigs.size() > 64 && sigs.size() <= 128) {
             const int K = (int)sigs.size(), n_hi = K - 64;
             std::map<std::tuple<double, double, double, double, uint32_t>, std::vector<int>> by_shape;
             for (int k = 0; k < K; ++k) by_shape[std::make_tuple(sigs[k].req_c, sigs[k].req_m, sigs[k].nz_c, sigs[k].nz_m, sigs[k].flags)].push_back(k);
@@ -1078,6 +1138,15 @@ int stage_narrow(simon_ctx* c) {
                 HIP_TRY(c, c->d_gsig.upload(gsigs, st)); HIP_TRY(c, c->d_gpu_cnt.upload(gcnt, st));
                 HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
             }
+            if (c->gfold && !c->rest) {                              // GPU fold: the pool's devices (the kernel keeps them per position)
+                std::vector<uint32_t> devtot(N, 0), gused((size_t)N * 8, 0);
+                for (int j = 0; j < N; ++j) {
+                    if (c->gpu_cnt[j] > 0) devtot[j] = (uint32_t)((uint64_t)(c->gpu_mem_total[j] / c->gpu_cnt[j]) / c->g_gpu);
+                    for (int d = 0; d < 8; ++d) gused[(size_t)j * 8 + d] = (uint32_t)((uint64_t)c->i_gpu_used[(size_t)j * SIMON_MAX_GPU_DEV + d] / c->g_gpu);
+                }
+                HIP_TRY(c, c->d_gpu_cnt.upload(c->gpu_cnt, st));
+                HIP_TRY(c, c->d_gpu_devtot.upload(devtot, st)); HIP_TRY(c, c->d_i_gused.upload(gused, st));
+            }
             if (c->spread) {
                 std::vector<int32_t> sp_term(std::max(2 * c->Tm, 1), 0);      // ids Tm + t: rows that count the OWNERS of scoring term t (no node set)
                 for (int id = 0; id < 2 * c->Tm; ++id)
@@ -1228,6 +1297,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     if (const char* e = getenv("SIMON_TEAM_MAX_S")) c->team_max_s = atoi(e);
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->no_class_content = getenv("SIMON_TABLE_NO_CLASS_CONTENT") != nullptr;
+    c->no_gpu_fold = getenv("SIMON_NO_GPU_FOLD") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
     c->table_prof = getenv("SIMON_TABLE_PROF") != nullptr;   // phase profile of simon_table.hip: profiling builds only
@@ -1549,20 +1619,21 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             if (c->rest) coarse = coarse_ok;                        // the REST path is built on the two-level layout
             if (c->n_sigs > 128) coarse = coarse_ok;                // ... and so are the signature groups beyond 128 (simon_table.hip: MANY)
             if (c->spread) coarse = coarse_ok;                      // ... and the SPREAD path (generation 7)
-            if (c->fold) coarse = coarse_ok;                        // ... and the folded exclusions (carried by the two-level instantiations)
+            if (c->fold || c->gfold) coarse = coarse_ok;            // ... and the folded exclusions / GPU share (carried by the two-level instantiations)
             c->table_coarse = coarse;
             for (int s = 0; s < S; ++s) c->scen_ni[s] = coarse ? ni64[s] : ni16[s];
             const int ni_top = coarse ? top64 : top16;
             c->table_ni_top = ni_top;
             std::vector<unsigned long long> ws_off(S);
             size_t off = 0;
-            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0, c->rest ? (int)c->zone_keys.size() : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0); }
+            for (int b = 0; b < S; ++b) { ws_off[b] = off; off += table_ws_bytes(c->n_sigs, c->scen_ni[perm[b]], c->nzeq, coarse, Ct, c->rest ? c->rest_M : 0, c->rest ? (int)c->zone_keys.size() : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0)
+                                                                    + (c->gfold ? (((size_t)c->scen_ni[perm[b]] * 40 + 127) & ~(size_t)127) : 0); }   // + GPU fold: devices by position
             c->ws_total = off;
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY); else generation 2 / all-feature kernel
-            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest && !c->spread)) && (!c->spread || coarse) && (!c->fold || coarse);
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest && !c->spread)) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || (coarse && c->n_sigs <= 128));
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1662,7 +1733,10 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || c->fold || !c->raw_fits_lds || c->has_ranks || c->has_static;
+        if (getenv("SIMON_DEBUG_ROUTE"))
+            fprintf(stderr, "[route] variant %d rest %d spread %d fold %d gfold %d table_ok %d perm_ok %d coarse %d n_sigs %d Cn_t %d ni_top %d lds %zu max_n %d\n", c->variant, (int)c->rest,
+                    (int)c->spread, (int)c->fold, (int)c->gfold, (int)c->table_ok, (int)c->table_perm_ok, (int)c->table_coarse, c->n_sigs, c->Cn_t, ni_top, table_lds, c->max_n);
+        const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || c->fold || c->gfold || !c->raw_fits_lds || c->has_ranks || c->has_static;
         // Beyond 256 signatures generation 2 (register-resident state, every node re-evaluated per cycle: its time does not depend on
         // the signature count) overtakes the score table (measured, profiles/r03: 300 signatures 124 ms against 119 ms, 384: 169 ms) --
         // where it is eligible; otherwise the table (K <= 384) still beats the all-feature kernel by far.
@@ -1688,6 +1762,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 cold.xrows = c->d_xrows.p; cold.zdom = c->d_zdom.p; cold.xsig = c->d_xsig.p; cold.xalloc = c->d_xalloc.p; cold.i_xused = c->d_i_xused.p;
                 cold.gsig = c->d_gsig.p; cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p;
             }
+            if (c->gfold && !c->rest) { cold.gpu_cnt = c->d_gpu_cnt.p; cold.gpu_devtot = c->d_gpu_devtot.p; cold.i_gused = c->d_i_gused.p; }
             if (c->spread) {
                 cold.sp_ent = (const int2*)c->d_sp_ent.p; cold.spread_log = c->d_spread_log.p;
                 cold.node_sets = c->d_node_sets.p; cold.set_words = (c->N + 63) / 64; cold.cls_zdom = c->d_cls_zdom.p;
@@ -1702,7 +1777,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
             f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty(); f.team = team;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
-            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && (c->ipa_fold || c->hard_fold)) ? 64 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
+            f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && (c->ipa_fold || c->hard_fold)) ? 64 : 0) | (c->gfold ? 128 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_table(f, S, c->has_mask, c->nzeq, c->has_pin, table_lds, c->stream));
             if (want_placement)

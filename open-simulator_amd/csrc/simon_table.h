@@ -15,7 +15,7 @@ struct SigRow {      // one pod request signature (48 B)
     double nz_c, nz_m;     // non-zero request (V/framework/types.go:601-636)
     int32_t cls;           // pod class: row of static_mask / simon_raw
     uint32_t flags;        // bit0: all-zero request (fit.go:244-249)
-    int32_t pad[2];
+    int32_t pad[2];        // GPU fold (TableScalars::static_tables & 128): gpu-mem per device in gcd units, devices requested (0: not a GPU signature; -1: a GPU request for no device)
 };
 static_assert(sizeof(SigRow) == 48, "SigRow must be 48 bytes");
 
@@ -33,7 +33,7 @@ struct PodRowC { int32_t sigcls, preset, gate, rest; };
 struct TableScalars {
     int32_t mask_words, Cn, Cp, P, S, K;
     int32_t rk_stride;   // 0: cls_list = the pool's per-class node lists; N: per-scenario lists in rank order (simon_set_node_ranks)
-    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present; bit 3: record TableCold::gpu_slices; bit 4: signature k + 64 is a twin of k (same request); bit 5: TableCold::foldx present
+    int32_t static_tables;   // bit 0 / 1 / 2: TableCold::na_raw / tt_raw / add_raw present; bit 3: record TableCold::gpu_slices; bit 4: signature k + 64 is a twin of k (same request); bit 5: TableCold::foldx present; bit 6: SPREAD && AFF instantiations; bit 7: Open-Gpu-Share folded into the table (SigRow::pad = GPU request, devices per position behind the workspace)
     int32_t NZ;          // REST: topology keys that are NOT node-level (a term on one marks every position of the pod's domain)
     int32_t M, G, X;     // REST: rows of the per-block position masks (G GPU requests + X extra-resource requests + 2 x terms)
     int32_t TH, TZ, NZK; // SPREAD: hostname-key term rows, zone-key term rows, zone-like topology keys (class split)

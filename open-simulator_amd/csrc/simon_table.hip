@@ -437,6 +437,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     unsigned* g_zcnt = (unsigned*)(g_hrow + (((size_t)TH * ni + 127) & ~(size_t)127));   // [TZ][16] per domain of a zone-like key
     unsigned char* g_hmax = (unsigned char*)(g_zcnt + (((size_t)TZ * 16 + 31) & ~(size_t)31));   // [TH] largest counter of a hostname-key row
     unsigned short* g_canon = (unsigned short*)(g_hmax + (((size_t)TH + 127) & ~(size_t)127));    // [ni] RANKED: rank of the position's node in the scenario's order
+    // GPU fold (TableScalars::static_tables & 128; the two-level instantiations without REST rows): the devices of every position behind
+    // the scenario's workspace -- used [ni][8], per-device total [ni], device count [ni] (gcd units)
+    constexpr bool kGpuFoldable = COARSE && !REST && HAS_PIN && !MANY;
+    const bool gfold = kGpuFoldable && (sc.static_tables & 128);
+    unsigned* g_fu = (unsigned*)(wsb + table_ws_of(K, ni, NZEQ, COARSE, Cn, M, NZ, TH, TZ));
+    unsigned* g_ft = g_fu + (size_t)ni * 8;
+    int* g_fc = (int*)(g_ft + ni);
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = tid; i < K * nbp / 2; i += TT) ((unsigned*)s_sum)[i] = 0u;
@@ -494,11 +501,30 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
         const ShapeRow sh = s_shape[d];
         unsigned char* tp = g_tile + (tile_blk((unsigned)(p >> 4)) + (unsigned)(p & 15));
+        unsigned gu[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gtot = 0;                // GPU fold: this position's devices
+        int gcnt = 0;
+        if constexpr (kGpuFoldable) {
+            if (gfold) {
+                if (real) {
+                    gcnt = cold->gpu_cnt[j]; gtot = cold->gpu_devtot[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gu[e] = cold->i_gused[(size_t)j * 8 + e];
+                }
+                if (p < ni) {
+                    g_fc[p] = gcnt; g_ft[p] = gtot;
+                    *(uint4*)(g_fu + (size_t)p * 8) = make_uint4(gu[0], gu[1], gu[2], gu[3]);
+                    *(uint4*)(g_fu + (size_t)p * 8 + 4) = make_uint4(gu[4], gu[5], gu[6], gu[7]);
+                }
+            }
+        }
         for (int k = 0; k < K; ++k) {
             const SigRow q = sigs[k];
             unsigned b = eval_node(q.req_c, q.req_m, q.nz_c, q.nz_m, q.flags & 1u, (double)st.rq_c, (double)st.rq_m, (double)z.x,
                                    (double)z.y, (int)st.freep, sh);
             b = real ? b : 0u;
+            if constexpr (kGpuFoldable) {                                 // a GPU signature starts infeasible where its request does not fit the devices
+                if (gfold && q.pad[1] != 0) b = gpu_fits_t(gu, gcnt, gtot, (unsigned)q.pad[0], q.pad[1]) ? b : 0u;
+            }
             if (HAS_MASK) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node)
                 const uint64_t w = static_mask[(size_t)q.cls * sc.mask_words + (j >> 6)];
                 b = ((w >> (j & 63)) & 1ull) ? b : 0u;
@@ -597,6 +623,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     double my_req_c[KQ], my_req_m[KQ], my_nz_c[KQ], my_nz_m[KQ];
     bool my_zero[KQ];
     unsigned my_add_c[KQ], my_add_m[KQ], my_addz_c[KQ], my_addz_m[KQ], koff[KQ];
+    unsigned my_greq[KQ];                                             // GPU fold: this lane's signatures' GPU requests (SigRow::pad)
+    int my_gnum[KQ];
     unsigned my_dirty = 0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
@@ -605,6 +633,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const SigRow r = sigs[kk[q]];
         my_req_c[q] = r.req_c; my_req_m[q] = r.req_m; my_nz_c[q] = r.nz_c; my_nz_m[q] = r.nz_m;
         my_zero[q] = r.flags & 1u;
+        my_greq[q] = (unsigned)r.pad[0]; my_gnum[q] = kvalid[q] ? r.pad[1] : 0;
         my_add_c[q] = (unsigned)r.req_c; my_add_m[q] = (unsigned)r.req_m;
         my_addz_c[q] = (unsigned)r.nz_c; my_addz_m[q] = (unsigned)r.nz_m;
         koff[q] = (unsigned)kk[q] * KS;
@@ -1634,6 +1663,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             const int blk = pstar >> 4, pos = pstar & 15;
             RestLoads RL{};
             if (REST && __builtin_expect(rw != 0, 0)) RL = rest_assume_load(pstar, r_nrows, rowv, bound ? -1 : r_gs, r_xs);
+            // GPU fold: the landing position's devices travel with the assume's loads (uniform addresses)
+            uint4 gfa = make_uint4(0, 0, 0, 0), gfb = make_uint4(0, 0, 0, 0);
+            unsigned gft = 0;
+            int gfc = 0;
+            if constexpr (kGpuFoldable) {
+                if (__builtin_expect(gfold, 0)) {
+                    gfc = g_fc[pstar]; gft = g_ft[pstar];
+                    gfa = *(const uint4*)(g_fu + (size_t)pstar * 8); gfb = *(const uint4*)(g_fu + (size_t)pstar * 8 + 4);
+                }
+            }
             SpreadLoads SPL{0u, 0u, false};
             if (SPREAD && sp_match != 0) SPL = spread_count_load(pstar, dstar, res, spv, spt, sp_soft, sp_match);
             const ShapeRow sh = s_shape[dstar];
@@ -1724,6 +1763,30 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if (__builtin_expect(fold, 0)) {                      // folded exclusions: the signatures this landing rules out get byte 0
 #pragma unroll
                     for (int q = 0; q < KQ; ++q) nbq[q] = ((xfold[q] >> (kk[q] & 31)) & 1u) ? 0u : nbq[q];
+                }
+            }
+            if constexpr (kGpuFoldable) {
+                if (__builtin_expect(gfold, 0)) {
+                    // Open-Gpu-Share folded into the table: a GPU pod the scheduler placed books its devices (Reserve,
+                    // open-gpu-share.go:147-188: every lane alike), and the GPU signatures whose request stopped fitting the node get
+                    // byte 0 -- for good (device memory is never released).  Pods bound by Spec.NodeName never reach Reserve.
+                    const unsigned greq = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_greq[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_greq[0], sl));
+                    const int gnum = hiq ? __builtin_amdgcn_readlane(my_gnum[KQ - 1], sl) : __builtin_amdgcn_readlane(my_gnum[0], sl);
+                    if (gnum > 0 && !bound) {
+                        unsigned u[8] = {gfa.x, gfa.y, gfa.z, gfa.w, gfb.x, gfb.y, gfb.z, gfb.w};
+                        const unsigned long long booked = gpu_commit_t(u, gfc, gft, greq, gnum);
+                        if (sc.static_tables & 8) {                       // the caller wants the devices (simon_batch_out.gpu_slices), by pod id
+                            const int pid = __builtin_amdgcn_readfirstlane(order[i0 + il]);
+                            if (lane == 0) cold->gpu_slices[(size_t)s * (size_t)P + (size_t)pid] = booked;
+                        }
+                        if (lane == 0) {
+                            *(uint4*)(g_fu + (size_t)pstar * 8) = make_uint4(u[0], u[1], u[2], u[3]);
+                            *(uint4*)(g_fu + (size_t)pstar * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < KQ; ++q)
+                            if (my_gnum[q] != 0 && !gpu_fits_t(u, gfc, gft, my_greq[q], my_gnum[q])) nbq[q] = 0u;
+                    }
                 }
             }
 #pragma unroll
@@ -1902,7 +1965,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
     if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
         return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
-    has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & 32);   // (& 32: the fold, carried by COARSE && !REST && HAS_PIN)
+    has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & (32 | 128));   // (& 32, & 128: the folds, carried by COARSE && !REST && HAS_PIN)
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }

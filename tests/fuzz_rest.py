@@ -52,6 +52,12 @@ def one_case(case):
         for s, (n, _) in enumerate(np.asarray(scen).tolist()):
             ranks[s, :n] = rng.permutation(n)
     ref = O.run_threaded(prob, scen, orders) if ranks is None else O.run(prob, scen, orders, node_ranks=ranks)
+    # every other case with the GPU fold switched off: the position masks of generation 6 keep their coverage, the fold (GPU share as
+    # monotone infeasibility of the table, few signatures) gets the other half
+    if case % 2:
+        os.environ["SIMON_NO_GPU_FOLD"] = "1"
+    else:
+        os.environ.pop("SIMON_NO_GPU_FOLD", None)
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
@@ -60,6 +66,7 @@ def one_case(case):
         ctx.run_loaded(True)
         res = ctx.fetch(True)
         st = ctx.stats()
+    os.environ.pop("SIMON_NO_GPU_FOLD", None)
     ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
           res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
     return ok, dict(case=case, N=N, P=P, S=S, classes=n_node_classes, pod_classes=n_pod_classes, feat=sorted(feat),

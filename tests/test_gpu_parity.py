@@ -201,6 +201,7 @@ def test_random_rest_features(idx, monkeypatch):
     kernel (generation 6): position masks per block, per-class best + NormalizeScore over the classes that kept a node."""
     feat = REST_FEATURES[idx]
     monkeypatch.setenv("SIMON_NO_FOLD", "1")               # (anti-affinity / ports alone would be folded into the table: the test below)
+    monkeypatch.setenv("SIMON_NO_GPU_FOLD", "1")           # (GPU share alone, with few signatures, likewise: tests/test_gpu_round4.py)
     for seed in range(4):
         N = [37, 150, 700, 1500][seed]
         prob = randprob.rand_problem(7000 + 100 * idx + seed, N=N, P=500 + 300 * seed, n_pod_classes=6 + 5 * seed, n_node_classes=3 + 2 * seed, **feat)
