@@ -600,7 +600,8 @@ bool spread_supported(simon_ctx* c) {
 bool fold_supported(simon_ctx* c) {
     c->fold_fc.clear(); c->fold_x.clear(); c->fold_FC = 0; c->fold_sigs = 0;
     if (c->no_fold || c->Tm <= 0 || (c->anti_idx.empty() && c->port_idx.empty())) return false;
-    if (!c->aff_idx.empty() || c->has_gpu || c->has_gpu_index || c->match_off.empty()) return false;
+    // (GPU share next to the fold: only when it is folded too -- choose_variant drops the fold again when gfold_supported says no)
+    if (!c->aff_idx.empty() || c->has_gpu_index || (c->has_gpu && (c->no_gpu_fold || c->no_rest)) || c->match_off.empty()) return false;
     const int Cp = c->Cp, N = c->N;
     std::vector<char> relevant(c->Tm, 0);
     auto list_of = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& idx, int cp) {
@@ -689,6 +690,7 @@ void choose_variant(simon_ctx* c) {
     c->has_static = c->has_na || c->has_tt || c->has_add;
     c->fold = fold_supported(c);
     c->gfold = gfold_supported(c);
+    if (c->fold && c->has_gpu && !c->gfold) c->fold = false;        // GPU share on position masks (generation 6) takes the terms along
     if (c->v2_features_but_ports_and_static()) {
         if (!spread_supported(c)) return;                         // only soft spread constraints: generation 7 of the score-table kernel
         c->spread = true;
@@ -714,7 +716,7 @@ void choose_variant(simon_ctx* c) {
     // anti-affinity / ports without soft spread constraints: the fold while two signatures per lane hold them, else the position masks
     if (c->fold && !c->spread && c->fold_sigs > 128 && rest_supported(c)) c->fold = false;
     // the GPU fold serves problems that need no other per-node filter row: plain cpu+memory+GPU, and generation 7's (Services next to GPU pods)
-    if (c->gfold && ((!c->spread && c->Tm > 0) || c->xres)) c->gfold = false;
+    if (c->gfold && ((!c->spread && !c->fold && c->Tm > 0) || c->xres)) { c->gfold = false; if (c->has_gpu) c->fold = false; }
     const bool wants_rest = !c->spread && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
     if (c->spread && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
     if (c->spread && !c->fold && (!c->anti_idx.empty() || !c->port_idx.empty())) { c->spread = false; return; }

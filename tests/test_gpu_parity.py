@@ -351,9 +351,10 @@ def test_explain_on_a_narrow_problem():
     assert n == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
 
 
-def test_explain_on_a_generation_6_problem():
+def test_explain_on_a_generation_6_problem(monkeypatch):
     """GPU-share / anti-affinity failure codes of a batch that ran on the score-table kernel's REST path: simon_explain and
     simon_explain_loaded stage the all-feature kernel lazily, the group API shards the same batch over two contexts."""
+    monkeypatch.setenv("SIMON_NO_GPU_FOLD", "1")           # (with few signatures GPU share + hostname anti-affinity would both be folded into the table)
     prob = randprob.rand_problem(7421, N=40, P=500, gpu=True, anti_host=True, tight_pods=True, static_mask=True)
     scen, orders = randprob.rand_scenarios(3, prob, S=4)
     ref, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=32)

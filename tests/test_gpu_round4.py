@@ -325,7 +325,7 @@ def test_c_consumer_attaches_every_optional_array_by_name(tmp_path):
 
 
 GPU_FOLD_FEATURES = [dict(), dict(static_mask=True, presets=True, gates=True), dict(pins=True, tight_pods=True), dict(nz_differs=True, init_state=True),
-                     dict(static_small=True, zero_pods=True)]
+                     dict(static_small=True, zero_pods=True), dict(anti_host=True), dict(anti_host=True, ports=True, presets=True, tight_pods=True)]
 
 
 @pytest.mark.parametrize("idx", range(len(GPU_FOLD_FEATURES)))
@@ -349,16 +349,24 @@ def test_gpu_share_folded_into_the_score_table(idx, spread, monkeypatch):
             ctx.load_problem(prob)
             res = ctx.run_batch(scen, orders, want_gpu_slices=True)
             st = ctx.stats()
-        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == (7 if spread else 5), (st.kernel_variant, st.kernel_generation)
+        # (a random problem whose spread classes stay empty runs the plain two-level kernel)
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation in ((7, 5) if spread else (5,)), (st.kernel_variant, st.kernel_generation)
         assert_same(res, ref)
         assert (res.gpu_slices == ref.gpu_slices).all()
         assert ref.gpu_slices.any(), "the case must book devices"
+        if seed == 0:                                    # FitError inputs of a batch that ran with the fold: the lazily staged all-feature kernel
+            _, (nf, failed, codes) = O.run(prob, scen[:1], orders, explain_scenario=0, max_failed=16)
+            with capi.Context(0) as ctx:
+                ctx.load_problem(prob)
+                ctx.run_batch(scen, orders)
+                n2, f2, c2 = ctx.explain(int(scen[0, 0]), orders[scen[0, 1]], max_failed=16)
+            assert n2 == nf and f2.tolist() == failed.tolist() and (c2 == codes).all()
     monkeypatch.setenv("SIMON_NO_GPU_FOLD", "1")
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
         res = ctx.run_batch(scen, orders, want_gpu_slices=True)
         st = ctx.stats()
-    assert (st.kernel_variant == capi.KERNEL_WIDE) if spread else (st.kernel_generation == 6)
+    assert (st.kernel_variant == capi.KERNEL_WIDE) if spread else (st.kernel_generation == 6)   # (terms next to GPU share: position masks take both)
     assert_same(res, ref)
     assert (res.gpu_slices == ref.gpu_slices).all()
 
