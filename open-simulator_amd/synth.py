@@ -278,7 +278,7 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
 
 
 def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
-                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0):
+                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0, n_gpu: int = 0):
     """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
     request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
     constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
@@ -287,7 +287,9 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
     (selector, zone); the pods of a service match both and nothing else.  `n_anti`: the first n_anti services additionally REQUIRE
     anti-affinity to their own pods on kubernetes.io/hostname (one replica per node: the usual companion of a Service); `n_pref`: the
     LAST n_pref services PREFER not to sit next to their own pods (weight 100 on the hostname key, 50 on the zone key: the chart default);
-    `n_hard`: every third service up to n_hard of them carries a HARD zone constraint on its own pods (maxSkew 2, DoNotSchedule)."""
+    `n_hard`: every third service up to n_hard of them carries a HARD zone constraint on its own pods (maxSkew 2, DoNotSchedule);
+    `n_gpu`: a gpushare cluster behind Services -- 30 % of the nodes carry 4 or 8 GPU devices of 16 GiB, the pods of the first n_gpu
+    services ask for GPU memory (2 / 4 / 8 GiB on one device, or 2 x 8 GiB; one request per service, as a Deployment's template has)."""
     from .gomath import spread_log_table
     n_total = n_het + n_counts
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
@@ -328,6 +330,19 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
         w = np.tile(np.array([-100, -50], np.int32), npf)
         prob.pref_off, prob.pref_idx, prob.pref_w = off, idx, w                          # preferred anti-affinity: negative weights (scoring.go:120-131)
         prob.own_off, prob.own_idx, prob.own_w = off.copy(), idx.copy(), w.copy()        # ... which the placed pods hold against newcomers alike
+    if n_gpu > 0:
+        GiB = 1 << 30
+        rg = SplitMix64(seed ^ 0x475055)
+        gcnt = np.zeros(n_total, np.int32)
+        for j in range(n_total):
+            if rg.next() % 100 < 30:
+                gcnt[j] = 4 if (rg.next() & 1) else 8
+        prob.gpu_cnt = gcnt
+        prob.gpu_mem_total = gcnt.astype(np.int64) * 16 * GiB
+        kind = np.arange(n_services) % 4
+        svc_mem = np.where(np.arange(n_services) < n_gpu, np.array([2, 4, 8, 8])[kind] * GiB, 0).astype(np.int64)
+        svc_cnt = np.where(np.arange(n_services) < n_gpu, np.array([1, 1, 1, 2])[kind], 0).astype(np.int32)
+        prob.gpu_mem, prob.pod_gpu_cnt = svc_mem[svc], svc_cnt[svc]
     prob = prob.normalise()
     orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)
