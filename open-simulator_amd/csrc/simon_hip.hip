@@ -110,6 +110,7 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_t_na, d_t_tt, d_t_add;
     bool raw_fits_lds = true;                    // generations 1 / 2 can run (else: score table or the all-feature kernel)
     bool no_gpu_split = false, force_table = false, no_class_content = false, no_gpu_fold = false;
+    bool debug_route = false;                     // env SIMON_DEBUG_ROUTE: one line per run on stderr with what decided the kernel
     bool gfold = false;                           // Open-Gpu-Share folded into the score table: the GPU request is part of the signature (gfold_supported)
     bool table_prof = false;                     // env SIMON_TABLE_PROF in -DSIMON_TABLE_PROFILE builds
     bool rest = false, no_rest = false;          // no_rest: env SIMON_NO_REST (such problems take the all-feature kernel)
@@ -1300,6 +1301,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->no_class_content = getenv("SIMON_TABLE_NO_CLASS_CONTENT") != nullptr;
     c->no_gpu_fold = getenv("SIMON_NO_GPU_FOLD") != nullptr;
+    c->debug_route = getenv("SIMON_DEBUG_ROUTE") != nullptr;
     c->force_table = getenv("SIMON_FORCE_TABLE") != nullptr;         // A/B + tests: keep 257 .. 384 signatures on the score-table kernel   // A/B: node classes not split into with / without devices
 #ifdef SIMON_TABLE_PROFILE
     c->table_prof = getenv("SIMON_TABLE_PROF") != nullptr;   // phase profile of simon_table.hip: profiling builds only
@@ -1308,6 +1310,8 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->wide.knobs.no_lean = getenv("SIMON_WIDE_NO_LEAN") != nullptr;
     c->wide.knobs.no_table = getenv("SIMON_WIDE_NO_TABLE") != nullptr;
     c->wide.knobs.prof = getenv("SIMON_WIDE_PROF") != nullptr;
+    c->wide.knobs.no_zmask = getenv("SIMON_WIDE_NO_ZMASK") != nullptr;
+    c->wide.knobs.no_ident = getenv("SIMON_WIDE_NO_IDENT") != nullptr;
     if (const char* e = getenv("SIMON_WIDE_NO_CACHE_B")) c->wide.knobs.no_cache_b = *e ? atoi(e) : 3;
     if (const char* e = getenv("SIMON_STATE_BUDGET_MB")) c->wide.knobs.state_budget = (size_t)atoll(e) << 20;
     return c;
@@ -1735,7 +1739,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
-        if (getenv("SIMON_DEBUG_ROUTE"))
+        if (c->debug_route)
             fprintf(stderr, "[route] variant %d rest %d spread %d fold %d gfold %d table_ok %d perm_ok %d coarse %d n_sigs %d Cn_t %d ni_top %d lds %zu max_n %d\n", c->variant, (int)c->rest,
                     (int)c->spread, (int)c->fold, (int)c->gfold, (int)c->table_ok, (int)c->table_perm_ok, (int)c->table_coarse, c->n_sigs, c->Cn_t, ni_top, table_lds, c->max_n);
         const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || c->fold || c->gfold || !c->raw_fits_lds || c->has_ranks || c->has_static;

@@ -199,6 +199,8 @@ struct WideKnobs {
     int no_cache_b = 0;              // SIMON_WIDE_NO_CACHE_B (bit 0: InterPodAffinity scores, bit 1: soft-spread counts; no value = both): stage B gathers its counters again (A/B runs)
     bool prof = false;               // SIMON_WIDE_PROF (only builds with -DSIMON_WIDE_PROFILE act on it)
     size_t state_budget = 16ull << 30;   // SIMON_STATE_BUDGET_MB: HBM for per-scenario state of the all-feature kernel
+    bool no_zmask = false;   // env SIMON_WIDE_NO_ZMASK: distinct zones by atomic stamps instead of presence masks (A/B)
+    bool no_ident = false;   // env SIMON_WIDE_NO_IDENT: domain rows loaded even where the domain of node j is j (A/B)
 };
 
 struct WideDevice {

@@ -1762,11 +1762,11 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
     // presence mask per lane and ONE OR-reduction instead of an atomic exchange per scored node on (number of domains) addresses
     for (int k = 0; k < in.Kt; ++k) {
         is_host[k] = is_host[k] ? 1 : 0;
-        if (!is_host[k] && k < (int)in.topo_n_dom.size() && in.topo_n_dom[k] <= 32 && !getenv("SIMON_WIDE_NO_ZMASK")) is_host[k] |= 2;
+        if (!is_host[k] && k < (int)in.topo_n_dom.size() && in.topo_n_dom[k] <= 32 && !w.knobs.no_zmask) is_host[k] |= 2;
     }
     // the hot lists with their terms' metadata inline (WideCold::*_ent)
     std::vector<char> key_ident(std::max(in.Kt, 1), 0);
-    for (int k = 0; k < in.Kt && !getenv("SIMON_WIDE_NO_IDENT"); ++k) {
+    for (int k = 0; k < in.Kt && !w.knobs.no_ident; ++k) {
         bool ok = true;
         for (size_t j = 0; j < N && ok; ++j) ok = in.topo_dom[(size_t)k * N + j] == (int32_t)j;
         key_ident[k] = ok;
