@@ -418,3 +418,25 @@ def test_gpushare_example_behind_a_service_stays_on_the_score_table():
             if sched.gpu_ids[i]:
                 assert got[p["metadata"]["name"]][1] == "-".join(str(x) for x in sched.gpu_ids[i]), p["metadata"]["name"]
     assert any(v[1] for v in got.values()), "GPU pods carry the devices Reserve booked"
+
+
+@pytest.mark.parametrize("kw,stride", [(dict(), 1), (dict(n_anti=20), 8), (dict(n_pref=60), 8)])
+def test_service_workloads_of_the_bench_row_by_row(kw, stride):
+    """the Service / anti / pref bench workloads were re-checked on 24 - 64 of their 4 096 scenarios.  Here: ALL 4 096
+    scenarios of `config3_service` (10 000 pods x 488..1 511 nodes behind 60 Services) placement row by placement row against the oracle
+    (threaded, ~45 s), and every eighth scenario of the required / preferred self anti-affinity variants."""
+    prob, scen, orders = synth.config_service(**kw)
+    assert len(scen) == 4096
+    pick = np.arange(0, len(scen), stride)
+    ref = O.run_threaded(prob, scen[pick], orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        st = ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7
+        res = ctx.fetch(True)
+    assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
+    assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist() and res.used_mem[pick].tolist() == ref.used_mem.tolist()
+    bad = np.flatnonzero((res.placement[pick] != ref.placement).any(axis=1))
+    assert len(bad) == 0, f"{len(bad)} of {len(pick)} scenarios differ, first: scenario {pick[bad[0]]}"
