@@ -13,7 +13,7 @@ import oracle_lib as O  # noqa: E402
 import randprob  # noqa: E402
 from open_simulator_amd import capi  # noqa: E402
 
-FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small", "anti_host", "ipa_self", "ipa", "hard_simple"]
+FEATURES = ["nz_differs", "init_state", "static_mask", "presets", "gates", "zero_pods", "tight_pods", "pins", "odd_units", "static_small", "anti_host", "ipa_self", "ipa", "hard_simple", "gpu"]
 
 
 def one_case(case):
@@ -26,6 +26,11 @@ def one_case(case):
         feat.pop("static_mask", None)
     prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=(case % 7 != 6 or "ipa_self" not in feat), n_node_classes=int(rng.choice([1, 2, 4, 9])),
                                  n_pod_classes=int(rng.choice([1, 3, 8, 30, 60])), **feat)
+    if "gpu" in feat:                                   # GPU share folded into the table (few request kinds: <= 128 signatures), behind the spread walk
+        G_ = 1 << 30
+        prob.gpu_mem = np.where(prob.gpu_mem > 4 * G_, 8 * G_, np.where(prob.gpu_mem > 0, 2 * G_, 0)).astype(np.int64)
+        prob.pod_gpu_cnt = np.where(prob.gpu_mem > 0, np.where(prob.pod_gpu_cnt >= 2, 2, 1), 0).astype(np.int32)
+        prob.normalise()
     scen, orders = randprob.rand_scenarios(case, prob, S=int(rng.integers(1, 8)), min_n=1 if rng.random() < 0.4 else None)
     ranks = None
     if case % 4 == 3:                                   # per-scenario node order (simon_set_node_ranks): ties follow the ranks
