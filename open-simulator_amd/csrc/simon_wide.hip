@@ -1261,7 +1261,25 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
                             m[u] = j < n && ((feas >> (it0 + u)) & 1u) && !((ign >> (it0 + u)) & 1u);
                             jn[u] = j < n ? j : n - 1;
                         }
-                        pts_raw8(A, v, p, jn, m, weight, x);
+                        if (pts_cache) {                           // the counts stage A left in LDS: pts_raw8's sums in the same order, no second gather
+                            double score[kUT];
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) score[u] = 0.0;
+#pragma unroll
+                            for (int q = 0; q < SIMON_MAX_SPREAD; ++q) {
+                                if (q >= n_soft) continue;
+                                const double w = sel4(weight, q), add = (double)((COLD(A)->ss_skew[slo + q] & ~SIMON_SPREAD_DUP_KEY) - 1);
+#pragma unroll
+                                for (int u = 0; u < kUT; ++u) {
+                                    const int cv = m[u] ? s_pts[q * A.bc_words + jn[u]] : 0;
+                                    score[u] += (double)(long long)cv * w + add;     // scoreForCount (:287-289)
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < kUT; ++u) x[u] = (long long)score[u];
+                        } else {
+                            pts_raw8(A, v, p, jn, m, weight, x);
+                        }
 #pragma unroll
                         for (int u = 0; u < kUT; ++u) {
                             if (!m[u]) continue;
