@@ -147,18 +147,45 @@ def _matches_term(pod_ns: str, pod_labels: dict, namespaces, sel_json: str) -> b
     return pod_ns in namespaces and k8s.label_selector_matches(_parsed(sel_json), pod_labels)
 
 
+_SVC_INDEX: Dict[int, tuple] = {}
+
+
+def _services_that_may_select(services, ns: str, labels: dict):
+    """The Services of namespace `ns` whose selector could match `labels`, in list order (GetPodServices lists them in the lister's
+    order; the merged label set does not depend on it).  A selector with pairs needs its first pair among the pod's labels: services are
+    indexed by (namespace, that pair) once per list -- pod classes x services tests were 0.26 s of a 400-workload cluster's ingest."""
+    key = id(services)
+    hit = _SVC_INDEX.get(key)
+    if hit is None or hit[0] is not services or hit[1] != len(services):
+        by_pair: Dict[tuple, List[int]] = {}
+        always: Dict[str, List[int]] = {}
+        for i, svc in enumerate(services):
+            sel = svc.get("spec", {}).get("selector")
+            if sel is None:
+                continue                                   # services with nil selectors match nothing (helper/spread.go:84-87)
+            sns = svc["metadata"].get("namespace") or "default"
+            if sel:
+                k, v = next(iter(sel.items()))
+                by_pair.setdefault((sns, k, v), []).append(i)
+            else:
+                always.setdefault(sns, []).append(i)
+        _SVC_INDEX.clear()                                 # one list at a time: the index lives as long as its list is the one in use
+        hit = _SVC_INDEX[key] = (services, len(services), by_pair, always)
+    _, _, by_pair, always = hit
+    idx = list(always.get(ns, ()))
+    for k, v in labels.items():
+        idx += by_pair.get((ns, k, v), ())
+    return [services[i] for i in sorted(idx)]
+
+
 def _default_spread_selector(pod: dict, services, replicasets, statefulsets):
     """helper.DefaultSelector (V/framework/plugins/helper/spread.go:28-95): merged Service selectors AND the selectors of
     the matching ReplicaSets / StatefulSets.  Returns a list of LabelSelector dicts to be ANDed (empty = no selector)."""
     ns, labels = pod["metadata"]["namespace"], pod["metadata"].get("labels") or {}
     parts = []
     merged = {}
-    for svc in services:
-        if (svc["metadata"].get("namespace") or "default") != ns:
-            continue
-        sel = svc.get("spec", {}).get("selector")
-        if sel is None:
-            continue
+    for svc in _services_that_may_select(services, ns, labels):
+        sel = svc["spec"]["selector"]
         if all(labels.get(k) == v for k, v in sel.items()):
             merged.update(sel)
     if merged:

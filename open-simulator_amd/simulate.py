@@ -112,10 +112,24 @@ def attach_local_storage(nodes: List[dict], directory: str):
 def _check_prefix_order(pool: List[dict], counts: Sequence[int]):
     """The engine breaks score ties by pool index; that equals nodeTree.list() order for every prefix only when the
     zone round-robin (V/internal/cache/node_tree.go:119-143) keeps insertion order."""
-    for n in sorted(set(counts)):
-        if k8s.canonical_node_order(pool[:n]) != list(range(n)):
-            raise fl.Unsupported("nodes span several zone keys: nodeTree order is not a prefix order; simulate each cluster "
-                                 "size separately (simulate()) or route to the Go path")
+    # nodeTree.list() of a prefix = its nodes sorted by (index inside the zone, zone in first-appearance order): both are the same for
+    # every prefix that holds the node, so ONE pass over the pool decides every size -- the order is the identity up to the first
+    # node whose key does not exceed its predecessor's (this loop ran canonical_node_order once per candidate size: 0.5 s of the
+    # typical cluster's 1.7 s of ingest)
+    zone_idx: Dict[str, int] = {}
+    seen: Dict[int, int] = {}
+    prev, ok_upto = (-1, -1), len(pool)
+    for i, n in enumerate(pool):
+        z = zone_idx.setdefault(k8s.zone_key(n), len(zone_idx))
+        r = seen.get(z, 0)
+        seen[z] = r + 1
+        if (r, z) <= prev:
+            ok_upto = i                                    # prefixes of more than i nodes are not in index order
+            break
+        prev = (r, z)
+    if max(counts, default=0) > ok_upto:
+        raise fl.Unsupported("nodes span several zone keys: nodeTree order is not a prefix order; simulate each cluster "
+                             "size separately (simulate()) or route to the Go path")
 
 
 def _unflatten(flat: fl.Flat, placement: np.ndarray, n_nodes: int, reasons: Dict[int, str], gpu_slices: Optional[np.ndarray] = None):
