@@ -92,13 +92,27 @@ class Quantity:
 ZERO = Quantity()
 
 
+_PARSED: dict = {}          # text -> Quantity (frozen: shared freely); a cluster repeats a few dozen spellings tens of thousands of times
+
+
 def parse_quantity(s) -> Quantity:
     """ParseQuantity fast path (quantity.go:262-330)."""
     if isinstance(s, Quantity):
         return s
     if isinstance(s, (int,)):
         return Quantity(int(s), 0, DECIMAL_SI)
-    s = str(s).strip()
+    if isinstance(s, str):
+        q = _PARSED.get(s)
+        if q is None:
+            q = _parse_text(s)
+            if len(_PARSED) < 65536:
+                _PARSED[s] = q
+        return q
+    return _parse_text(str(s))
+
+
+def _parse_text(s: str) -> Quantity:
+    s = s.strip()
     m = _RE.match(s)
     if not m or (m.group(2) == "" and not m.group(3)):
         raise ValueError(f"unparseable quantity {s!r}")
