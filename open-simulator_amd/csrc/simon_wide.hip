@@ -98,7 +98,8 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
 #ifdef SIMON_WG_REDUCE_LANES
         // lane k combines slot k over the waves (NW reads by kRed lanes instead of NW x kRed reads by every lane), then every lane takes the
         // kRed results with shuffles.  Measured -3.4 % on the random mix (2 050 -> 1 980 ms, profiles/r04/r04u_*), but with it the
-        // Open-Local case of test_random_v2_features at 1 024 threads reports another used_vg (placements identical): OFF until understood.
+        // Open-Local case of test_random_v2_features at 1 024 threads reports another used_vg while placements, unscheduled counts, used cpu
+        // and used memory are the oracle's at every workgroup size (profiles/r04/r05g_*, profiles/dbg/wide_1024_probe.py): OFF until understood.
         const int k_ = lane < kRed ? lane : 0;
         const bool is_max = k_ < cm;
         long long acc = mb[0][k_];
