@@ -59,7 +59,8 @@ SERVICE_ANTI = 20                 # services of the `config3_service_anti` sub-r
 SERVICE_GPU = 20                  # services of the `config3_service_gpu20` sub-record whose pods ask for GPU memory (30 % of the nodes carry devices)
 SMALL_COUNTS = 16                 # node counts of the `service_small` sub-record (x 4 pod orders = 64 scenarios: what a sweep of candidate sizes looks like)
 SIG_CLIFF = 300                   # ... and of the `config3_sigs300` row: three groups of 128 signatures per wave (the table's last regime before 384)
-CLASS_CLIFF = 80                  # distinct node shapes of the `config3_classes80` row: more than the 64 internal node classes the score table holds
+CLASS_RECORD = 80                 # distinct node shapes of the `config3_classes80` row: more than 64 internal node classes (two per lane on the score table)
+CLASS_CLIFF = 160                 # ... and of `config3_classes160`: more than the 128 the score table holds (the priced cliff)
 SIG_RECORD = 200                  # request signatures of the `config3_sigs` sub-record (beyond the 128 two registers per lane hold; the table takes 384)
 C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
 
@@ -301,8 +302,8 @@ def build_workload(args, synth, world):
         return synth.typical_cluster_sweep(), 1
     if args.workload == "widemix":             # the adversarial random object mix: every plugin, 464 node classes -> the all-feature kernel
         return wide_mix_sweep(), 1
-    if args.workload == "config3classes":      # config 3 with 80 distinct node shapes (more than 64 internal node classes)
-        return synth.config3_classes(CLASS_CLIFF, n_counts=args.counts, n_orders=n_orders, n_pods=args.pods), n_orders
+    if args.workload == "config3classes":      # config 3 with `--classes` distinct node shapes (80: two classes per lane; 160: off the score table)
+        return synth.config3_classes(args.classes, n_counts=args.counts, n_orders=n_orders, n_pods=args.pods), n_orders
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
         return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
     seed = synth.SEED + (3 if world == 1 else 4)
@@ -338,7 +339,7 @@ def workload_name(args, prob, scen_all, n_orders, S_local, world):
             "service": "config 3 with every pod selected by a Service (system-default soft PodTopologySpread constraints): ",
             "typical": "typical cluster (Kubernetes objects: Deployments behind Services, preferred / required self anti-affinity, hard zone constraints): ",
             "widemix": "random Kubernetes-object mix with every plugin (all-feature kernel): ",
-            "config3classes": f"config 3 variant with {CLASS_CLIFF} distinct node shapes (more than 64 internal node classes): ",
+            "config3classes": f"config 3 variant with {args.classes} distinct node shapes (internal node classes): ",
             "config3sig": f"config 3 variant with {args.sigs} request signatures: "}.get(
                 args.workload, f"BASELINE config {'3' if world == 1 else '4-style'}: ")
     return (head + f"{prob.n_pods} pods x {int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, "
@@ -438,10 +439,11 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_CLIFF)
         child = ["--workload", "config3sig", "--sigs", str(SIG_CLIFF)]
         wl, label = "config3", f"config 3 with {SIG_CLIFF} request signatures"
-    elif name == "config3_classes":                 # ... and 80 node shapes: beyond 64 internal node classes the problem leaves the score table
-        prob, scen, orders = synth.config3_classes(CLASS_CLIFF)
-        child = ["--workload", "config3classes"]
-        wl, label = "config3", f"config 3 with {CLASS_CLIFF} distinct node shapes"
+    elif name in ("config3_classes", "config3_classes_cliff"):   # ... 80 node shapes (two classes per lane) and 160: beyond 128 internal node classes the problem leaves the score table
+        ncl = CLASS_RECORD if name == "config3_classes" else CLASS_CLIFF
+        prob, scen, orders = synth.config3_classes(ncl)
+        child = ["--workload", "config3classes", "--classes", str(ncl)]
+        wl, label = "config3", f"config 3 with {ncl} distinct node shapes"
     elif name == "config3sig":                      # config 3 with SIG_RECORD request signatures: the > 128-signature regime as a number
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_RECORD)
         child = ["--workload", "config3sig", "--sigs", str(SIG_RECORD)]
@@ -453,7 +455,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
     device = torch.cuda.current_device()
     rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
                         "config3sig": f"config3_sigs{SIG_RECORD}", "config3sig_cliff": f"config3_sigs{SIG_CLIFF}",
-                        "config3_classes": f"config3_classes{CLASS_CLIFF}"}.get(name, f"config5_S{c5_scen}")}
+                        "config3_classes": f"config3_classes{CLASS_RECORD}", "config3_classes_cliff": f"config3_classes{CLASS_CLIFF}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
@@ -708,6 +710,7 @@ def main():
     ap.add_argument("--pods", type=int, default=10000)
     ap.add_argument("--orders-per-gpu", type=int, default=4)
     ap.add_argument("--sigs", type=int, default=100, help="request signatures of --workload config3sig")
+    ap.add_argument("--classes", type=int, default=CLASS_RECORD, help="distinct node shapes of --workload config3classes")
     ap.add_argument("--c5-scenarios", type=int, default=0, help="scenarios per GPU of --workload config5 (default 256; env SIMON_BENCH_C5_SCEN)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity_sample)")
     ap.add_argument("--no-sub", action="store_true", help="skip the config-2 / config-5 sub-records and the end-to-end leg")
@@ -824,7 +827,7 @@ def main():
         mode = args.pmc
         if mode in ("auto", "live") and world == 1:
             child = ["--workload", args.workload, "--steps", "1", "--warmup", "0", "--counts", str(args.counts), "--pods", str(args.pods),
-                     "--orders-per-gpu", str(args.orders_per_gpu), "--sigs", str(args.sigs), "--placement", str(args.placement),
+                     "--orders-per-gpu", str(args.orders_per_gpu), "--sigs", str(args.sigs), "--classes", str(args.classes), "--placement", str(args.placement),
                      "--c5-scenarios", str(c5_scenarios(args))]
             ctx.close()                                        # free the device for the profiled children
             t0 = time.perf_counter()
@@ -863,9 +866,9 @@ def main():
                                                  ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
                                                  ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING),
                                                  ("service_small", sub_steps, 1, 16, 0), ("service_gpu", sub_steps, 1, 16, 0), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
-                                                 ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0)):
+                                                 ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0), ("config3_classes_cliff", sub_steps, 1, 16, 0)):
                 try:
-                    cliff = name in ("config3sig_cliff", "config3_classes")          # the two cliff rows: timing + parity only (no PMC passes)
+                    cliff = name in ("config3sig_cliff", "config3_classes", "config3_classes_cliff")   # the cliff rows: timing + parity only (no PMC passes)
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, "off" if cliff else mode, c5s,
                                            cpu_budget_s=3.0 if cliff else 6.0))
                     if subs[-1].get("parity_sample", {}).get("mismatches"):

@@ -1051,7 +1051,7 @@ int stage_narrow(simon_ctx* c) {
             auto key = std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
-                if ((int)shapes.size() == kTableMaxClasses) { c->table_ok = false; break; }
+                if ((int)shapes.size() == ((c->rest || c->spread) ? kTableMaxClasses : kTableMaxClassesPlain)) { c->table_ok = false; break; }
                 it = cls_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};
                 sh.cap_c = (double)a_cpu[j]; sh.cap_m = (double)a_mem[j];

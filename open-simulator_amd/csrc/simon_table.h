@@ -108,7 +108,8 @@ constexpr int kSpreadTabMax = SIMON_SPREAD_TAB_MAX;       // entries of spread_s
 constexpr int kTeamWaves = 4;           // team mode (table_kernel: NW): waves per scenario, one per SIMD of the CU.  8 and 16 were built and measured
                                         // SLOWER on every batch (profiles/r04/r04b_*: once the walks are a quarter, the leader's chain and the barriers decide)
 constexpr int kTeamWavesMax = 16;       // (the exchange slots are sized for it: a wider team is one more translation unit, simon_table_team<N>.hip)
-constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (node_class, allocatable) pairs: one lane each in the re-base
+constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (column content, allocatable) pairs: one lane each in the REST select and the SPREAD walks
+constexpr int kTableMaxClassesPlain = 128;   // ... two per lane where only the prologue and the class terms' re-base are lane-shaped (no REST rows, no SPREAD)
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD; | 0x100: second score table; | 0x200: team mode)
 size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0);  // HBM workspace of ONE scenario with ni padded positions

@@ -413,9 +413,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    const int ni = __builtin_amdgcn_readlane(incl, 63);               // padded scenario size (classes beyond Cn add nothing)
+    int ni = __builtin_amdgcn_readlane(incl, 63);                     // padded scenario size (classes beyond Cn add nothing)
     if (lead && lane < Cn) s_seg[lane] = incl - pad_d;
+    // 65 .. 128 internal node classes (round 4; the instantiations without REST rows and SPREAD walks -- the host admits them there
+    // only): lane l also owns class 64 + l.  Every per-class quantity of those instantiations lives in LDS / the workspace by class
+    // index already; what is lane-shaped is this prefix scan, the count lookup of the prologue and the class terms' re-base.
+    int cnt_d2 = 0;
+    if (Cn > 64) {
+        cnt_d2 = (64 + lane < Cn) ? clsprefix[(size_t)n * Cn + 64 + lane] : 0;
+        const int pad2 = (cnt_d2 + (UNIT - 1)) & ~(UNIT - 1);
+        int incl2 = pad2;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl2, off, 64);
+            if (lane >= off) incl2 += o;
+        }
+        if (lead && 64 + lane < Cn) s_seg[64 + lane] = ni + incl2 - pad2;
+        ni += __builtin_amdgcn_readlane(incl2, 63);
+    }
     if (lead && lane == 0) s_seg[Cn] = ni;                            // the sentinel: with Cn == 64 no lane Cn exists to write it
+    auto count_of_class = [&](int d) -> int {                        // nodes of class d in this scenario (every lane active: cross-lane reads)
+        const int lo = __shfl(cnt_d, d & 63, 64);
+        if (Cn <= 64) return lo;
+        const int hi = __shfl(cnt_d2, d & 63, 64);
+        return d < 64 ? lo : hi;
+    };
     const int nblk = ni >> 4, nun = ni >> UB;                         // table blocks (16 positions); summary entries
     unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
     NodeState* g_state = (NodeState*)(wsb + (((size_t)nblk * Krow + 127) & ~(size_t)127));
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int r = p - s_seg[d];
         // the cross-lane read runs with EVERY lane active (as the right operand of && it ran only in the lanes with p < ni: in the last,
         // partial chunk the lane holding class d's count could be inactive and read as 0 -- found by tests/fuzz_table.py)
-        const int cnt_of_d = __shfl(cnt_d, d, 64);
+        const int cnt_of_d = count_of_class(d);
         const bool real = p < ni && r < cnt_of_d;
         const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;   // r-th node of class d in canonical order
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
@@ -563,7 +585,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             const int p = p0 + lane;
             const int d = class_of_pos(p);
             const int r = p - s_seg[d];
-            const int cnt_of_d = __shfl(cnt_d, d, 64);
+            const int cnt_of_d = count_of_class(d);
             const bool real = r < cnt_of_d;
             const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;
             const int gc = real ? gpu_cnt[j] : 0;
@@ -695,6 +717,39 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     };
     // Re-base summary row k after the set of node classes with a feasible node changed.
     auto renormalise = [&](int k, int c) {
+        if (Cn > 64) {
+            // 65 .. 128 classes: lane l evaluates classes l and 64 + l -- class_term's formulas with the extremes taken over both halves
+            const bool v1 = 64 + lane < Cn;
+            const int d0 = lane, d1 = v1 ? 64 + lane : 0;
+            const int cn0 = COARSE ? g_cnt[k * Cn + d0] : s_cnt[k * Cn + d0], cn1 = v1 ? (COARSE ? g_cnt[k * Cn + d1] : s_cnt[k * Cn + d1]) : 0;
+            const bool in0 = cn0 > 0, in1 = cn1 > 0;
+            const int raw0 = simon_raw[c * Cn + d0], raw1 = simon_raw[c * Cn + d1];
+            const int lo = min(wave_min_i32(in0 ? raw0 : 0x7fffffff), wave_min_i32(in1 ? raw1 : 0x7fffffff));
+            const int hi = max(wave_max_i32(in0 ? raw0 : (int)0x80000000), wave_max_i32(in1 ? raw1 : (int)0x80000000));
+            const int range = hi >= lo ? hi - lo : 0;
+            const double rr = range ? 1.0 / (double)range : 0.0;
+            int t0 = (in0 && range) ? 2 * (int)__builtin_fma((double)(raw0 - lo) * 100.0, rr, 0.5 * rr) : 0;
+            int t1 = (in1 && range) ? 2 * (int)__builtin_fma((double)(raw1 - lo) * 100.0, rr, 0.5 * rr) : 0;
+            const TableCold* cc = cold;
+            if (sc.static_tables & 1) {
+                const int a0 = cc->na_raw[c * Cn + d0], a1 = cc->na_raw[c * Cn + d1];
+                const int mx = max(wave_max_i32(in0 ? a0 : 0), wave_max_i32(in1 ? a1 : 0));
+                const double r = mx ? 1.0 / (double)mx : 0.0;
+                t0 += (in0 && mx) ? (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 0;
+                t1 += (in1 && mx) ? (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 0;
+            }
+            if (sc.static_tables & 2) {
+                const int a0 = cc->tt_raw[c * Cn + d0], a1 = cc->tt_raw[c * Cn + d1];
+                const int mx = max(wave_max_i32(in0 ? a0 : 0), wave_max_i32(in1 ? a1 : 0));
+                const double r = mx ? 1.0 / (double)mx : 0.0;
+                t0 += in0 ? (mx ? 100 - (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 100) : 0;
+                t1 += in1 ? (mx ? 100 - (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 100) : 0;
+            }
+            if (sc.static_tables & 4) { t0 += in0 ? cc->add_raw[c * Cn + d0] : 0; t1 += in1 ? cc->add_raw[c * Cn + d1] : 0; }
+            s_tmp[d0] = t0 - (int)s_sn[k * Cn + d0];
+            s_sn[k * Cn + d0] = (unsigned short)t0;
+            if (v1) { s_tmp[d1] = t1 - (int)s_sn[k * Cn + d1]; s_sn[k * Cn + d1] = (unsigned short)t1; }
+        } else {
         const int dd = lane < Cn ? lane : 0;
         const int cn = (lane < Cn) ? (COARSE ? g_cnt[k * Cn + dd] : s_cnt[k * Cn + dd]) : 0;
         const bool inb = cn > 0;
@@ -703,6 +758,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         if (lane < Cn) {
             s_tmp[dd] = sn - (int)s_sn[k * Cn + dd];
             s_sn[k * Cn + dd] = (unsigned short)sn;
+        }
         }
         lead_sync();
         unsigned short* srow = s_sum + k * nbp;

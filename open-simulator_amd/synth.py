@@ -170,7 +170,8 @@ def config3(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het:
 def config3_classes(n_classes: int = 80, **kw):
     """config 3 whose 488 existing nodes come in `n_classes` distinct allocatable shapes (cpu 8..64 cores x memory 2..4 GiB per core, drawn
     with splitmix64) instead of four: every shape is a node class of its own with its own Simon column -- the "more than 64 internal node
-    classes" regime of the score-table kernel as a workload (bench.py: `config3_classes80`)."""
+    classes" regimes of the score-table kernel as workloads (bench.py: `config3_classes80` runs two classes per lane, `config3_classes160`
+    is past the 128 the table holds)."""
     prob, scen, orders = config3(**kw)
     n_het = int(scen[0, 0])
     rng = SplitMix64(SEED + 31)

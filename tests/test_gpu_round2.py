@@ -305,18 +305,19 @@ def test_bench_line_is_self_verifying():
     assert e2e["batch_ms"] > e2e["kernel_ms"] > 0 and e2e["load_problem_ms"] > 0 and e2e["scenarios"] == d["config"]["scenarios_per_gpu"]
     names = [w["workload"] for w in d["other_workloads"]]
     assert names == ["config2", "config3_sigs200", "config3_service", "config3_service_anti20", "config3_service_pref60", "config5_S16", "config5_S2048",
-                     "config3_service_S64", "config3_service_gpu20_S256", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80"]
+                     "config3_service_S64", "config3_service_gpu20_S256", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160"]
     for w in d["other_workloads"]:
         assert "error" not in w, w
         assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
         assert w["parity_sample"]["placement_rows"] == w["parity_sample"]["scenarios"] >= 1
         assert w["cpu_baseline"]["kind"] == "port" and w["cpu_baseline"]["value"] > 0
-        if w["workload"] in ("config3_classes80", "config3_sigs300"):   # the cliff rows: whichever kernel the host prefers there (beyond 256 signatures generation 2 where it is eligible)
+        if w["workload"] in ("config3_classes160", "config3_sigs300"):   # the cliff rows: whichever kernel the host prefers there (beyond 256 signatures generation 2 where it is eligible)
             assert w["roofline"]["kernel_ms"] > 0 and w["roofline"]["kernel"] in ("simon::fast_kernel", "simon::narrow_kernel", "simon::wide_kernel")
             continue
         assert w["roofline"]["kernel_ms"] > 0 and w["roofline"]["kernel"] == ("simon::wide_kernel" if w["workload"] == "wide_mix_x64" else "simon::table_kernel")
-    # the cliffs as numbers: 80 node shapes leave the score table
-    assert d["other_workloads"][12]["kernel_generation"] not in (4, 5, 6, 7)
+    # the cliffs as numbers: 80 node shapes stay on the score table (two classes per lane), 160 leave it
+    assert d["other_workloads"][12]["kernel_generation"] in (4, 5)
+    assert d["other_workloads"][13]["kernel_generation"] not in (4, 5, 6, 7)
     assert d["other_workloads"][8]["kernel_generation"] == 7         # a gpushare cluster behind Services: GPU share folded into the table
     # the `simon apply` shapes: 64 candidate scenarios run generation 7 in team mode, with the one-wave time of the same batch beside it
     for w in (d["other_workloads"][7], d["other_workloads"][9]):

@@ -15,14 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("coarse", ["0", "1"])
-@pytest.mark.parametrize("n_classes", [63, 64])
+@pytest.mark.parametrize("n_classes", [63, 64, 65, 100, 128])
 def test_exactly_64_internal_node_classes(n_classes, coarse, monkeypatch):
     """with exactly 64 internal node classes no lane `Cn` exists, so the class-segment sentinel s_seg[Cn]
     was never written and class_of_pos read stale LDS.  16 caller classes x 4 allocatable shapes, every pair present."""
     monkeypatch.setenv("SIMON_TABLE_COARSE", coarse)
     rng = np.random.default_rng(640 + n_classes)
     N, P = 900, 1500
-    prob = randprob.rand_problem(6400 + n_classes, N=N, P=P, n_node_classes=16, n_pod_classes=12, tight_pods=True)
+    # (round 4: 65 .. 128 classes -- two per lane in the instantiations without REST rows / SPREAD walks -- stay on the score table too)
+    prob = randprob.rand_problem(6400 + n_classes, N=N, P=P, n_node_classes=32, n_pod_classes=12, tight_pods=True)
     shapes_c = np.array([4000, 8000, 16000, 32000])
     shapes_m = np.array([8, 16, 64, 128]) << 30
     pair = np.concatenate([np.arange(n_classes), rng.integers(0, n_classes, N - n_classes)])

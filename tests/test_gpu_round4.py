@@ -310,6 +310,44 @@ def test_hundreds_of_caller_node_classes_with_few_distinct_columns_stay_on_the_s
     assert_same(res, ref)
 
 
+WIDE_CLASS_FEATURES = [dict(static_small=True), dict(pins=True, tight_pods=True), dict(static_mask=True, presets=True, gates=True),
+                       dict(nz_differs=True, init_state=True), dict(anti_host=True, ports=True, tight_pods=True), dict(gpu=True)]
+
+
+@pytest.mark.parametrize("idx", range(len(WIDE_CLASS_FEATURES)))
+def test_up_to_128_distinct_node_classes_on_the_score_table(idx, monkeypatch):
+    """VERDICT r3 next-8 (the other half of the 64-class cliff): 65 .. 128 node classes that DO differ in what the kernel reads (distinct
+    score columns x allocatable shapes) run on the score-table instantiations without position-mask rows and spread walks, two classes
+    per lane in the prologue's segment scan and the class terms' re-base; with the static score tables, the pin / anti-affinity / port
+    fold, presets and the GPU fold.  129 classes leave the table (a priced cliff: DESIGN 5.3h)."""
+    feat = WIDE_CLASS_FEATURES[idx]
+    shapes_c = np.array([4000, 8000, 16000, 32000])
+    shapes_m = np.array([8, 16, 64, 128]) << 30
+    for seed, (n_classes, N, P) in enumerate([(65, 400, 1200), (97, 900, 2000), (128, 1400, 2500), (129, 700, 1200)]):
+        rng = np.random.default_rng(9900 + 10 * idx + seed)
+        prob = randprob.rand_problem(9900 + 10 * idx + seed, N=N, P=P, n_node_classes=33, n_pod_classes=8, **feat)
+        pair = np.concatenate([np.arange(n_classes), rng.integers(0, n_classes, N - n_classes)])
+        rng.shuffle(pair)
+        prob.node_class = (pair // 4).astype(np.int32)
+        prob.alloc_cpu = shapes_c[pair % 4].astype(np.int64)
+        prob.alloc_mem = shapes_m[pair % 4].astype(np.int64)
+        if feat.get("gpu"):
+            G_ = 1 << 30
+            prob.gpu_mem = np.where(prob.gpu_mem > 4 * G_, 8 * G_, np.where(prob.gpu_mem > 0, 2 * G_, 0)).astype(np.int64)
+            prob.pod_gpu_cnt = np.where(prob.gpu_mem > 0, np.where(prob.pod_gpu_cnt >= 2, 2, 1), 0).astype(np.int32)
+        prob.normalise()
+        scen, orders = randprob.rand_scenarios(99 + seed, prob, S=5)
+        scen[0, 0] = N
+        ref = O.run(prob, scen, orders, want_gpu_slices=bool(feat.get("gpu")))
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders, want_gpu_slices=bool(feat.get("gpu")))
+            st = ctx.stats()
+        on_table = st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation in (4, 5)
+        assert on_table == (n_classes <= 128), (n_classes, st.kernel_variant, st.kernel_generation)
+        assert_same(res, ref)
+
+
 def test_c_consumer_attaches_every_optional_array_by_name(tmp_path):
     """tests/cabi/cabi_terms.c (plain C, stands in for the cgo host): the topology-term tables, static score tables and Open-Local arrays
     that integration/go/hipengine/flatten_terms.go fills, attached member by member through offsetof, run against the oracle's golden
