@@ -542,11 +542,12 @@ def compact_line(out, detail_name):
     if ps:
         line["parity_sample"] = {k: ps.get(k) for k in ("scenarios", "placement_rows", "mismatches")}
     rk = out.get("ranks") or {}
-    if rk.get("world_size", 1) > 1 or "devices" in rk:
+    if rk.get("world_size", 1) > 1 or "devices" in rk or rk.get("forced_one_rank_group"):
         sc = rk.get("selfcheck") or {}
         line["ranks"] = {k: v for k, v in {"world_size": rk.get("world_size"), "backend": rk.get("backend"), "mode": (rk.get("mode") or "")[:40] or None,
                                            "all_gather_ms_per_step": rk.get("all_gather_ms_per_step"), "collective": rk.get("plan_collective"),
-                                           "distinct_devices": sc.get("distinct_devices_over_ranks"),
+                                           "distinct_devices": sc.get("distinct_devices_over_ranks"), "forced_one_rank_group": rk.get("forced_one_rank_group"),
+                                           "rccl_version": sc.get("rccl_version"),
                                            "one_device_test_hook": sc.get("one_device_test_hook", rk.get("one_device_test_hook"))}.items() if v is not None}
     e2e = out.get("end_to_end")
     if e2e:
@@ -580,6 +581,21 @@ def compact_line(out, detail_name):
     return line
 
 
+_RECORD_OUT = None
+
+
+def claim_stdout():
+    """The record must be the LAST line of stdout, and libraries print there too: RCCL writes its version banner ("RCCL version : ...",
+    five lines) through C stdio when the first communicator comes up, which a pipe delivers at exit -- after the record (seen on the
+    GPU box, r06b).  So the process keeps the real stdout for its own lines and points fd 1 at stderr for everything else."""
+    global _RECORD_OUT
+    if _RECORD_OUT is None:
+        sys.stdout.flush()
+        fd = os.dup(1)
+        os.dup2(2, 1)
+        _RECORD_OUT = os.fdopen(fd, "w", buffering=1)
+
+
 def emit(out):
     """Sidecar + `#detail` lines first, the compact record LAST (flushed): whatever tail of stdout survives holds it whole."""
     path = os.environ.get("SIMON_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
@@ -590,14 +606,15 @@ def emit(out):
     except OSError as e:
         print(f"[bench] could not write {path}: {e}", file=sys.stderr)
         name = None
+    rec_out = _RECORD_OUT or sys.stdout
     head = {k: v for k, v in out.items() if k != "other_workloads"}
-    print("#detail " + json.dumps(head), flush=True)
+    print("#detail " + json.dumps(head), file=rec_out, flush=True)
     for w in out.get("other_workloads", []):
-        print("#detail " + json.dumps(w), flush=True)
+        print("#detail " + json.dumps(w), file=rec_out, flush=True)
     line = compact_line(out, name)
     text = json.dumps(line)
     assert len(text) <= 4096, f"final bench line is {len(text)} bytes"
-    print(text, flush=True)
+    print(text, file=rec_out, flush=True)
 
 
 def multi_rank_selfcheck(torch, dist, world, rank, local_rank, backend):
@@ -730,6 +747,9 @@ def main():
                                                           "instead of one rank per GPU")
     args = ap.parse_args()
 
+    spawning = args.group <= 0 and "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.pmc_child
+    if not spawning:                                          # (the self-spawning parent leaves fd 1 to its ranks)
+        claim_stdout()
     if args.group > 0:
         import torch
         from open_simulator_amd import capi, synth
@@ -758,8 +778,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     selfcheck = None
-    if world > 1:
+    # SIMON_BENCH_FORCE_DIST=1 (test hook): a launch of ONE rank initialises the process group all the same and runs every collective
+    # of the multi-GPU launch (self-check all-gather, plan all-gather, barriers, max over ranks) -- on a one-GPU box that is how the
+    # RCCL calls execute at all; the line says `ranks.forced_one_rank_group`
+    use_dist = world > 1 or os.environ.get("SIMON_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -780,16 +805,16 @@ def main():
     def after_step(plan):                                     # device-side reduction of this rank's batch, then
         rec = sweep.plan_record(bool(plan.found), plan.n_nodes, plan.scenario, plan.order_id, rank, world)
         t0 = time.perf_counter()
-        best[0] = sweep.all_gather_plan(rec, device="cuda" if backend == "nccl" else "cpu").as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
+        best[0] = sweep.all_gather_plan(rec, device="cuda" if backend == "nccl" else "cpu", force=use_dist).as_list()   # RCCL all-gather, 32 B per rank (no-op at N=1)
         gather_s[0] += time.perf_counter() - t0
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     dt, k_ms = time_steps(ctx, args.steps, args.warmup, placement, fence, after_step)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -814,12 +839,12 @@ def main():
                        "scenarios_per_gpu": S_local, "pods": prob.n_pods, "node_pool": prob.n_nodes,
                        "placement_matrix": placement, "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_generation": st.kernel_generation,
                        "workgroup": st.workgroup_size, "slots_per_lane": st.slots_per_lane, "plan": best[0]},
-            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
-                      "backend": (dist.get_backend() if world > 1 else None),
-                      "collective": "all_gather of one 32-byte plan record per rank and step" if world > 1 else None,
-                      "all_gather_ms_per_step": round(gather_s[0] / max(args.steps, 1) * 1e3, 4) if world > 1 else None,
-                      "selfcheck": selfcheck,
-                      "launched_by": "bench.py --gpus N (self-spawned torch.distributed.run)" if os.environ.get("SIMON_BENCH_SELF_SPAWNED") else "external launcher"} if world > 1 else
+            "ranks": {"world_size": dist.get_world_size(),
+                      "backend": dist.get_backend(),
+                      "collective": "all_gather of one 32-byte plan record per rank and step",
+                      "all_gather_ms_per_step": round(gather_s[0] / max(args.steps, 1) * 1e3, 4),
+                      "selfcheck": selfcheck, **({"forced_one_rank_group": True} if world == 1 else {}),
+                      "launched_by": "bench.py --gpus N (self-spawned torch.distributed.run)" if os.environ.get("SIMON_BENCH_SELF_SPAWNED") else "external launcher"} if use_dist else
                      {"world_size": 1, "backend": None},
         }
         # ---- roofline of the dominant kernel ---------------------------------------------------------------------
@@ -880,7 +905,7 @@ def main():
         emit(out)
     else:
         ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rc:

@@ -57,12 +57,13 @@ def reduce_records(records) -> GlobalPlan:
     return GlobalPlan(True, int(best[0]), best_rank, int(best[1]), int(best[2]), int(best[3]))
 
 
-def all_gather_plan(record, device: Optional[str] = None, group=None) -> GlobalPlan:
+def all_gather_plan(record, device: Optional[str] = None, group=None, force: bool = False) -> GlobalPlan:
     """All-gather the per-rank records and take the global minimum.  Without an initialised process group the
-    call degenerates to the single-rank answer."""
+    call degenerates to the single-rank answer (`force`: run the collective even in a group of one rank -- the way a one-GPU box
+    executes the RCCL calls of the multi-GPU launch, bench.py's SIMON_BENCH_FORCE_DIST)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return reduce_records([record])
     world = dist.get_world_size(group)
     mine = torch.tensor(record, dtype=torch.int64, device=device)

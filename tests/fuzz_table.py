@@ -2,7 +2,7 @@
 """Randomised parity sweep aimed at the score-table kernel (simon_table.hip): cpu+memory problems at the sizes and shapes its
 templates switch on -- 1 ... 4 095 nodes (1, 2 or 4 blocks per lane), 1 ... 384 request signatures (one or two per lane in registers, further
 groups of 128 from memory), 1 ...
-64 internal node classes incl. caller classes that do NOT share their allocatable (the kernel refines them), presets, gates,
+128 internal node classes (cases from 300 000 on: 40 ... 128) incl. caller classes that do NOT share their allocatable (the kernel refines them), presets, gates,
 pinned pods, static masks, initial state, NonZeroRequested != Requested, zero requests, tight pod counts, gcd-1 units.  Every
 third case forces the two-level summary (SIMON_TABLE_COARSE=1: classes padded to 64, per-16 entries in HBM).
 Not collected by pytest (a slice runs in tests/test_gpu_round2.py); by hand on a GPU box:
@@ -30,7 +30,8 @@ def one_case(case, coarse=None):
         else int(rng.integers(2100, 4096))
     P = int(rng.integers(20, 400 if size == 0 else 2500))
     feat = {f: True for f in FEATURES if rng.random() < 0.3}
-    n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))
+    wide = case >= 300000                 # cases from 300 000 on: 40 ... 128 node classes (two per lane beyond 64, round 4)
+    n_node_classes = int(rng.choice([40, 65, 70, 100, 128] if wide else [1, 2, 4, 9, 20, 40]))
     n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 65, 100, 128, 129, 200, 256, 384]))
     if size == 3:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
@@ -39,8 +40,9 @@ def one_case(case, coarse=None):
         shapes_c = np.array([4000, 8000, 16000, 32000]) + (rng.integers(0, 5, 4) if "odd_units" in feat else 0)
         shapes_m = (np.array([8, 16, 64, 128]) << 30) + (rng.integers(0, 7, 4) if "odd_units" in feat else 0)
         pick = rng.integers(0, 4, N)
-        if n_node_classes * 4 > 64:
-            pick = prob.node_class % 3
+        lim = 128 if wide else 64
+        if n_node_classes * 4 > lim:
+            pick = prob.node_class % (3 if n_node_classes * 3 <= lim else 1)
         prob.alloc_cpu = shapes_c[pick].astype(np.int64)
         prob.alloc_mem = shapes_m[pick].astype(np.int64)
         if prob.init_req_cpu is not None:

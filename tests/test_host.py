@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -162,6 +163,31 @@ def test_bench_final_line_fits_the_driver(capsys, tmp_path, monkeypatch):
     assert d["parity_sample"] == {"scenarios": 2376, "placement_rows": 2376, "mismatches": 0}
     assert len(d["digest"]["rows"]) == 21 and d["digest"]["rows"][0][0] == "config2" and len(d["digest"]["cols"]) == len(d["digest"]["rows"][0])
     assert json.load(open(side)) == full                                         # nothing is lost: the sidecar holds the whole record
+
+
+def test_bench_record_stays_the_last_stdout_line_when_a_library_prints(tmp_path):
+    """RCCL prints its version banner to stdout through C stdio when a communicator comes up; through a pipe that text arrives at exit,
+    AFTER bench.py's record (seen on the GPU box with a one-rank `nccl` group: profiles/r04/r06b_*).  bench.claim_stdout() keeps the real
+    stdout for the record and points fd 1 at stderr: a C-stdio banner printed before or after the record must not follow it."""
+    import json
+    import subprocess
+    code = (
+        "import ctypes, json, os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "libc = ctypes.CDLL(None)\n"
+        "bench.claim_stdout()\n"
+        "libc.printf(b'RCCL version : banner before\\n')\n"
+        "bench.emit({'metric': 'm', 'value': 1.0, 'unit': 'u', 'n_gpus': 1, 'steps': 1, 'warmup': 0, 'ms_per_step': 1.0, 'higher_is_better': True,\n"
+        "            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic', 'config': {'workload': 'w'}})\n"
+        "libc.printf(b'Librccl path : banner after\\n')\n"
+        "print('a stray python print')\n")
+    env = dict(os.environ, SIMON_BENCH_DETAIL=str(tmp_path / "d.json"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert json.loads(lines[-1])["metric"] == "m" and all(l.startswith("#detail ") for l in lines[:-1])
+    assert "banner before" in out.stderr and "banner after" in out.stderr and "stray python print" in out.stderr
 
 
 def test_quantity_binary_si_and_open_local_reason_texts():
