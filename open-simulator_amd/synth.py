@@ -279,7 +279,7 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
 
 
 def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
-                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0, n_gpu: int = 0):
+                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0, n_gpu: int = 0, taint_pct: int = 0):
     """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
     request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
     constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
@@ -290,7 +290,8 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
     LAST n_pref services PREFER not to sit next to their own pods (weight 100 on the hostname key, 50 on the zone key: the chart default);
     `n_hard`: every third service up to n_hard of them carries a HARD zone constraint on its own pods (maxSkew 2, DoNotSchedule);
     `n_gpu`: a gpushare cluster behind Services -- 30 % of the nodes carry 4 or 8 GPU devices of 16 GiB, the pods of the first n_gpu
-    services ask for GPU memory (2 / 4 / 8 GiB on one device, or 2 x 8 GiB; one request per service, as a Deployment's template has)."""
+    services ask for GPU memory (2 / 4 / 8 GiB on one device, or 2 x 8 GiB; one request per service, as a Deployment's template has);
+    `taint_pct`: that share of the nodes is tainted NoSchedule and only the GPU services tolerate it (dedicated nodes)."""
     from .gomath import spread_log_table
     n_total = n_het + n_counts
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
@@ -344,9 +345,36 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
         svc_mem = np.where(np.arange(n_services) < n_gpu, np.array([2, 4, 8, 8])[kind] * GiB, 0).astype(np.int64)
         svc_cnt = np.where(np.arange(n_services) < n_gpu, np.array([1, 1, 1, 2])[kind], 0).astype(np.int32)
         prob.gpu_mem, prob.pod_gpu_cnt = svc_mem[svc], svc_cnt[svc]
+    if taint_pct > 0:
+        rt = SplitMix64(seed ^ 0x5441494E)
+        tainted = np.array([rt.next() % 100 < taint_pct for _ in range(n_total)], bool)
+        bits = np.zeros((n_total + 63) // 64 * 64, bool)
+        bits[:n_total] = True
+        all_mask = np.packbits(bits, bitorder="little").view(np.uint64)
+        bits[:n_total] = ~tainted
+        untainted = np.packbits(bits, bitorder="little").view(np.uint64)
+        tol = np.arange(n_services) < n_gpu
+        prob.static_mask = np.stack([all_mask if t else untainted for t in tol])
+        prob.static_reason = np.zeros((n_services, n_total), np.uint8)
+        prob.static_reason[np.ix_(~tol, tainted)] = 7               # host id of "node(s) had taint {dedicated: }, ..."
     prob = prob.normalise()
     orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)
+    scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)
+    return prob, np.ascontiguousarray(scen, np.int32), orders
+
+
+def config5_service(n_scen: int = 256, n_orders: int = 4, n_pods: int = 50000, n_nodes: int = 5000, n_services: int = 500, n_anti: int = 40,
+                    n_gpu: int = 80, taint_pct: int = 10):
+    """BASELINE config 5's shape -- 50 000 pods x 2 500 ... 5 000 nodes, GPU share + required self anti-affinity + taints -- as Deployments
+    behind Services: `n_services` services of one request shape each (100 replicas), the first `n_gpu` of them asking for GPU memory and
+    tolerating the dedicated nodes' taint, the first `n_anti` requiring one replica per node, every pod under the system-default soft
+    spread constraints of its Service ("config 5 with every pod behind a Service").  Scenarios as config 5's: node
+    counts spread over the upper half of the pool x `n_orders` pod orders."""
+    prob, _, orders = config_service(n_counts=n_nodes - n_nodes // 2, n_orders=n_orders, n_pods=n_pods, n_het=n_nodes // 2, n_services=n_services,
+                                     seed=SEED + 7, n_anti=n_anti, n_gpu=n_gpu, taint_pct=taint_pct)
+    n_counts = max(1, n_scen // n_orders)
+    counts = np.linspace(n_nodes // 2, n_nodes, n_counts).astype(np.int32)
     scen = np.stack([np.repeat(counts, n_orders), np.tile(np.arange(n_orders, dtype=np.int32), n_counts)], 1)
     return prob, np.ascontiguousarray(scen, np.int32), orders
 

@@ -305,7 +305,7 @@ def test_bench_line_is_self_verifying():
     assert e2e["batch_ms"] > e2e["kernel_ms"] > 0 and e2e["load_problem_ms"] > 0 and e2e["scenarios"] == d["config"]["scenarios_per_gpu"]
     names = [w["workload"] for w in d["other_workloads"]]
     assert names == ["config2", "config3_sigs200", "config3_service", "config3_service_anti20", "config3_service_pref60", "config5_S16", "config5_S2048",
-                     "config3_service_S64", "config3_service_gpu20_S256", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160"]
+                     "config3_service_S64", "config3_service_gpu20_S256", "config5_service_S16", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160"]
     for w in d["other_workloads"]:
         assert "error" not in w, w
         assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
@@ -316,13 +316,14 @@ def test_bench_line_is_self_verifying():
             continue
         assert w["roofline"]["kernel_ms"] > 0 and w["roofline"]["kernel"] == ("simon::wide_kernel" if w["workload"] == "wide_mix_x64" else "simon::table_kernel")
     # the cliffs as numbers: 80 node shapes stay on the score table (two classes per lane), 160 leave it
-    assert d["other_workloads"][12]["kernel_generation"] in (4, 5)
-    assert d["other_workloads"][13]["kernel_generation"] not in (4, 5, 6, 7)
+    assert d["other_workloads"][13]["kernel_generation"] in (4, 5)
+    assert d["other_workloads"][14]["kernel_generation"] not in (4, 5, 6, 7)
     assert d["other_workloads"][8]["kernel_generation"] == 7         # a gpushare cluster behind Services: GPU share folded into the table
+    assert d["other_workloads"][9]["kernel_generation"] == 7 and d["other_workloads"][9]["pods"] == 50000   # config 5's shape behind Services
     # the `simon apply` shapes: 64 candidate scenarios run generation 7 in team mode, with the one-wave time of the same batch beside it
-    for w in (d["other_workloads"][7], d["other_workloads"][9]):
+    for w in (d["other_workloads"][7], d["other_workloads"][10]):
         assert w["kernel_generation"] == 7 and w["workgroup"] == 256 and w["team"]["waves_per_scenario"] == 4 and w["team"]["one_wave_kernel_ms"] > 0
-    assert d["other_workloads"][10]["kernel"].startswith("wide") and d["other_workloads"][10]["scenarios"] == 64
+    assert d["other_workloads"][11]["kernel"].startswith("wide") and d["other_workloads"][11]["scenarios"] == 64
     assert d["other_workloads"][1]["kernel_generation"] == 5 and d["other_workloads"][1]["scenarios"] == 4096
     assert d["other_workloads"][2]["kernel_generation"] == 7 and d["other_workloads"][2]["scenarios"] == 4096
     assert d["other_workloads"][3]["kernel_generation"] == 7 and d["other_workloads"][3]["scenarios"] == 4096
