@@ -1638,8 +1638,9 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             HIP_TRY(c, c->d_ws_off.upload(ws_off, c->stream));
             HIP_TRY(c, c->d_inv_orders.upload(inv, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY); else generation 2 / all-feature kernel
-            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest && !c->spread)) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || (coarse && c->n_sigs <= 128));
+            // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY; since round 4 also under generation 7's
+            // walks); else generation 2 / all-feature kernel
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest)) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || (coarse && c->n_sigs <= 128));
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -354,7 +354,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 #endif
     static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
-    static_assert(!SPREAD || (COARSE && !REST && !MANY), "SPREAD is built on the two-level layout, without the REST rows");
+    static_assert(!SPREAD || (COARSE && !REST), "SPREAD is built on the two-level layout, without the REST rows");
+    static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
@@ -1984,6 +1985,18 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
     if constexpr (PIN) {                                              // soft spread constraints likewise; two-level layout
         if (a.spread) {
             if (!a.coarse || a.rest) return hipErrorInvalidValue;
+            if constexpr (KQ == 2) {
+                // 129 .. 384 signatures behind Services (round 4): the signature groups of MANY under generation 7's walks.  The walk reads
+                // its pod's row of the table whatever the signature's number; the refresh takes the further groups along as it does
+                // without the walks.  One shape (two entries per lane) serves every cluster size: the regime is rare.
+                if (a.sc.K > 128) {
+                    if (a.sc.static_tables & 64)
+                        return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, 2, true, false, true, true, true, true>(a, n_blocks, lds, st)
+                                                   : launch_t7<M, Z, PIN, KQ, 2, true, false, false, true, true, true>(a, n_blocks, lds, st);
+                    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, 2, true, false, true, false, true, true>(a, n_blocks, lds, st)
+                                               : launch_t7<M, Z, PIN, KQ, 2, true, false, false, false, true, true>(a, n_blocks, lds, st);
+                }
+            }
             if (a.sc.static_tables & 64) {                            // preferred pod (anti-)affinity in spread_select: SPREAD && AFF
                 if (a.sc.rk_stride != 0)
                     return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, true, true, false, true>(a, n_blocks, lds, st)

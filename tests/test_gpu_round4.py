@@ -387,6 +387,63 @@ def test_config5_shape_behind_services_stays_on_the_score_table():
     assert int((res.placement >= 0).sum()) > 16 * 30000 and int(res.unscheduled.sum()) > 0      # both outcomes occur
 
 
+MANY_SPREAD_FEATURES = [dict(), dict(static_small=True, presets=True, gates=True), dict(pins=True, tight_pods=True, anti_host=True),
+                        dict(hard_simple=True, init_state=True), dict(static_mask=True, ports=True)]
+
+
+@pytest.mark.parametrize("idx", range(len(MANY_SPREAD_FEATURES)))
+def test_more_than_128_signatures_behind_services_stay_on_generation_7(idx, monkeypatch):
+    """A cliff round 3 left: soft spread constraints (a Service) with more than 128 request signatures meant the all-feature kernel
+    (25 x the cycle cost).  Generation 7 now carries the signature groups beyond 128 (simon_table.hip: MANY && SPREAD, two entries per lane):
+    130 / 200 / 384 pod classes with their own Simon rows -- one signature each -- under soft constraints, hard zone verdicts, the
+    anti-affinity / port fold, presets, pins, with per-scenario node ranks on the third case; every placement against the oracle, 385+
+    signatures must still leave the table.  (Self-referential preferred terms: the Service workload below -- randprob's draws over
+    hundreds of classes always hold one that spread_supported refuses.)"""
+    feat = MANY_SPREAD_FEATURES[idx]
+    for seed, (n_pc, N, P) in enumerate([(130, 60, 700), (200, 500, 1800), (384, 900, 2600), (420, 300, 1500)]):
+        prob = randprob.rand_problem(12000 + 10 * idx + seed, N=N, P=P, spread_soft=True, n_node_classes=3, n_pod_classes=n_pc, **feat)
+        scen, orders = randprob.rand_scenarios(120 + seed, prob, S=4)
+        ranks = None
+        if seed == 2:
+            rng = np.random.default_rng(12 + idx)
+            ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+            for si, (n, _) in enumerate(np.asarray(scen).tolist()):
+                ranks[si, :n] = rng.permutation(n)
+        ref = O.run_threaded(prob, scen, orders) if ranks is None else O.run(prob, scen, orders, node_ranks=ranks)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            if ranks is not None:
+                ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            res = ctx.fetch(True)
+            st = ctx.stats()
+        on7 = st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7
+        assert on7 == (n_pc <= 384), (n_pc, st.kernel_variant, st.kernel_generation)
+        assert_same(res, ref)
+
+
+@pytest.mark.parametrize("kw", [dict(n_pref=200), dict(n_anti=40, n_hard=30), dict(n_pref=60, n_anti=20)])
+def test_service_workload_with_200_request_shapes_on_generation_7(kw):
+    """200 Deployments behind Services, each with a request of its own (200 signatures), preferring / requiring not to sit next to their
+    own replicas, some with hard zone constraints: generation 7 with the signature groups beyond 128; 12 scenarios of 6 000 pods x
+    300 ... 420 nodes, every placement against the oracle."""
+    prob, scen, orders = synth.config_service(n_counts=120, n_orders=2, n_pods=6000, n_het=300, n_services=200, **kw)
+    svc = prob.pod_class.astype(np.int64)
+    prob.req_cpu = (100 + 10 * svc).astype(np.int64)                    # one request per service, all distinct
+    prob.req_mem = ((128 + 16 * (svc % 37)) << 20).astype(np.int64)
+    prob.nz_cpu = prob.nz_mem = None
+    prob.normalise()
+    sub = scen[::20]
+    ref = O.run_threaded(prob, sub, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(sub, orders)
+        st = ctx.stats()
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7, (st.kernel_variant, st.kernel_generation)
+    assert_same(res, ref)
+
+
 def test_c_consumer_attaches_every_optional_array_by_name(tmp_path):
     """tests/cabi/cabi_terms.c (plain C, stands in for the cgo host): the topology-term tables, static score tables and Open-Local arrays
     that integration/go/hipengine/flatten_terms.go fills, attached member by member through offsetof, run against the oracle's golden
