@@ -118,6 +118,7 @@ struct simon_ctx : simon::HostInputs {
     // lands on a node zeroes the node's byte of every signature it excludes there, for good (fold_supported); env SIMON_NO_FOLD
     bool fold = false, no_fold = false;
     int fold_sigs = 0;                            // upper bound of the signatures the fold needs
+    int gfold_sigs = 0, gfold_base_sigs = 0;      // ... and the GPU fold (request shape x table class x filter class x GPU request); the same without the GPU request
     std::vector<int32_t> fold_fc;                 // [Cp] filter class of a pod class
     std::vector<uint8_t> fold_x;                  // [FC][FC]: a pod of filter class L on a node excludes filter class S from it
     int fold_FC = 0;
@@ -316,7 +317,7 @@ bool rest_supported(simon_ctx* c) {
 // then needs NO select-time filter: it takes the summary scan, or generation 7's walk when a Service selects it.  Worth it when the
 // signatures stay few (real gpushare workloads: a handful of Deployments) -- config 5's 42 shapes x 8 GPU requests keep the position
 // masks of generation 6.  Needs: no arriving gpu-index lists, GPU quantities on a gcd with quotients < 2^31 (fills g_gpu), at most
-// 128 signatures once the GPU request is part of them.
+// 384 signatures once the GPU request is part of them (beyond 128 only under generation 7's walks: choose_variant).
 bool gfold_supported(simon_ctx* c) {
     if (c->no_gpu_fold || c->no_rest || !c->has_gpu || c->has_gpu_index || c->gpu_cnt.empty()) return false;   // (SIMON_NO_REST keeps meaning: GPU problems on the all-feature kernel)
     uint64_t g = 0;
@@ -350,12 +351,16 @@ bool gfold_supported(simon_ctx* c) {
         }
     }
     std::set<std::tuple<int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, int64_t, int32_t>> sig;
+    std::set<std::tuple<int64_t, int64_t, int64_t, int64_t, int32_t>> base;   // ... and without the GPU request / filter class: generation 6's signatures
     for (int p = 0; p < c->P; ++p) {
         const bool gp = c->p_gpu_mem[p] > 0;
+        if ((int)base.size() <= 128) base.insert(std::make_tuple(c->p_req_cpu[p], c->p_req_mem[p], c->p_nz_cpu[p], c->p_nz_mem[p], content_of[c->p_cls[p]]));
         sig.insert(std::make_tuple(c->p_req_cpu[p], c->p_req_mem[p], c->p_nz_cpu[p], c->p_nz_mem[p], content_of[c->p_cls[p]],
                                    c->fold ? c->fold_fc[c->p_cls[p]] : 0, gp ? c->p_gpu_mem[p] : 0, gp ? std::min(c->p_gpu_cnt[p], 64) : 0));
-        if ((int)sig.size() > 128) return false;
+        if ((int)sig.size() > kTableMaxSigs) return false;
     }
+    c->gfold_sigs = (int)sig.size();
+    c->gfold_base_sigs = (int)base.size();
     c->g_gpu = g;
     return true;
 }
@@ -716,6 +721,9 @@ void choose_variant(simon_ctx* c) {
     if (c->fold && c->xres) c->fold = false;                        // (extra-resource rows live on the REST path)
     // anti-affinity / ports without soft spread constraints: the fold while two signatures per lane hold them, else the position masks
     if (c->fold && !c->spread && c->fold_sigs > 128 && rest_supported(c)) c->fold = false;
+    // ... and GPU share alike: with more than 128 signatures the device rows of generation 6 beat the signature groups read from memory
+    // (generation 6 itself holds <= 128 signatures: where the requests alone are more, the fold with its signature groups is what is left)
+    if (c->gfold && !c->spread && c->gfold_sigs > 128 && c->gfold_base_sigs <= 128 && rest_supported(c)) { c->gfold = false; c->fold = false; }
     // the GPU fold serves problems that need no other per-node filter row: plain cpu+memory+GPU, and generation 7's (Services next to GPU pods)
     if (c->gfold && ((!c->spread && !c->fold && c->Tm > 0) || c->xres)) { c->gfold = false; if (c->has_gpu) c->fold = false; }
     const bool wants_rest = !c->spread && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
@@ -841,7 +849,7 @@ int stage_narrow(simon_ctx* c) {
         // above a TWIN -- the same request under another table class -- the kernel evaluates a lane's node byte once for both
         // (TableScalars::static_tables & 16; config 5: 42 request shapes x 2 table classes).  A permutation of the ids, nothing else.
         c->sig_twins = false;
-        if (c->gfold && sigs.size() > 128) c->table_ok = false;      // (gfold_supported counted them: cannot happen)
+        if (c->gfold && (int)sigs.size() > kTableMaxSigs) c->table_ok = false;      // (gfold_supported counted them: cannot happen)
         if (c->table_ok && !c->no_sig_twins && !c->gfold && sigs.size() > 64 && sigs.size() <= 128) {
             const int K = (int)sigs.size(), n_hi = K - 64;
             std::map<std::tuple<double, double, double, double, uint32_t>, std::vector<int>> by_shape;
@@ -1640,7 +1648,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY; since round 4 also under generation 7's
             // walks); else generation 2 / all-feature kernel
-            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest)) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || (coarse && c->n_sigs <= 128));
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest)) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || coarse);
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     unsigned short* g_canon = (unsigned short*)(g_hmax + (((size_t)TH + 127) & ~(size_t)127));    // [ni] RANKED: rank of the position's node in the scenario's order
     // GPU fold (TableScalars::static_tables & 128; the two-level instantiations without REST rows): the devices of every position behind
     // the scenario's workspace -- used [ni][8], per-device total [ni], device count [ni] (gcd units)
-    constexpr bool kGpuFoldable = COARSE && !REST && HAS_PIN && !MANY;
+    constexpr bool kGpuFoldable = COARSE && !REST && HAS_PIN;
     const bool gfold = kGpuFoldable && (sc.static_tables & 128);
     unsigned* g_fu = (unsigned*)(wsb + table_ws_of(K, ni, NZEQ, COARSE, Cn, M, NZ, TH, TZ));
     unsigned* g_ft = g_fu + (size_t)ni * 8;
@@ -1822,15 +1822,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     for (int q = 0; q < KQ; ++q) nbq[q] = ((xfold[q] >> (kk[q] & 31)) & 1u) ? 0u : nbq[q];
                 }
             }
+            unsigned gu[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // GPU fold: the landing node's devices after Reserve (MANY: the further groups read them)
+            bool gbooked = false;
             if constexpr (kGpuFoldable) {
                 if (__builtin_expect(gfold, 0)) {
                     // Open-Gpu-Share folded into the table: a GPU pod the scheduler placed books its devices (Reserve,
                     // open-gpu-share.go:147-188: every lane alike), and the GPU signatures whose request stopped fitting the node get
                     // byte 0 -- for good (device memory is never released).  Pods bound by Spec.NodeName never reach Reserve.
-                    const unsigned greq = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_greq[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_greq[0], sl));
-                    const int gnum = hiq ? __builtin_amdgcn_readlane(my_gnum[KQ - 1], sl) : __builtin_amdgcn_readlane(my_gnum[0], sl);
+                    unsigned greq = (unsigned)(hiq ? __builtin_amdgcn_readlane((int)my_greq[KQ - 1], sl) : __builtin_amdgcn_readlane((int)my_greq[0], sl));
+                    int gnum = hiq ? __builtin_amdgcn_readlane(my_gnum[KQ - 1], sl) : __builtin_amdgcn_readlane(my_gnum[0], sl);
+                    if (MANY && __builtin_expect(r_sig >= 64 * KQ, 0)) {   // a signature beyond the register-resident ones: its row (uniform index)
+                        const SigRow rs = sigs[r_sig];
+                        greq = (unsigned)rs.pad[0]; gnum = rs.pad[1];
+                    }
                     if (gnum > 0 && !bound) {
-                        unsigned u[8] = {gfa.x, gfa.y, gfa.z, gfa.w, gfb.x, gfb.y, gfb.z, gfb.w};
+                        unsigned (&u)[8] = gu;
+                        u[0] = gfa.x; u[1] = gfa.y; u[2] = gfa.z; u[3] = gfa.w; u[4] = gfb.x; u[5] = gfb.y; u[6] = gfb.z; u[7] = gfb.w;
+                        gbooked = true;
                         const unsigned long long booked = gpu_commit_t(u, gfc, gft, greq, gnum);
                         if (sc.static_tables & 8) {                       // the caller wants the devices (simon_batch_out.gpu_slices), by pod id
                             const int pid = __builtin_amdgcn_readfirstlane(order[i0 + il]);
@@ -1862,7 +1870,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 #pragma unroll
                         for (int q = 0; q < KQ; ++q)
                             refresh_sig(kg[g][q], 128 * (g + 1) + 64 * q + lane < K,
-                                        (fold && ((xfg[g][q] >> (kg[g][q] & 31)) & 1u)) ? 0u :
+                                        ((fold && ((xfg[g][q] >> (kg[g][q] & 31)) & 1u)) ||
+                                         (kGpuFoldable && gbooked && rg[q].pad[1] != 0 && !gpu_fits_t(gu, gfc, gft, (unsigned)rg[q].pad[0], rg[q].pad[1]))) ? 0u :
                                         eval_node(rg[q].req_c, rg[q].req_m, rg[q].nz_c, rg[q].nz_m, rg[q].flags & 1u, rq_c, rq_m, nzc, nzm, (int)st.freep, sh),
                                         rowg[g][q], Tg[g][q], Fg[g][q], oldg[g][q], sng[q], 2 * (g + 1) + q);
                     }

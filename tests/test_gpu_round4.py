@@ -423,11 +423,12 @@ def test_more_than_128_signatures_behind_services_stay_on_generation_7(idx, monk
         assert_same(res, ref)
 
 
-@pytest.mark.parametrize("kw", [dict(n_pref=200), dict(n_anti=40, n_hard=30), dict(n_pref=60, n_anti=20)])
+@pytest.mark.parametrize("kw", [dict(n_pref=200), dict(n_anti=40, n_hard=30), dict(n_pref=60, n_anti=20), dict(n_gpu=70, n_anti=20, taint_pct=10), dict(n_gpu=200)])
 def test_service_workload_with_200_request_shapes_on_generation_7(kw):
     """200 Deployments behind Services, each with a request of its own (200 signatures), preferring / requiring not to sit next to their
-    own replicas, some with hard zone constraints: generation 7 with the signature groups beyond 128; 12 scenarios of 6 000 pods x
-    300 ... 420 nodes, every placement against the oracle."""
+    own replicas, some with hard zone constraints, some asking for GPU share (the GPU fold with the signature groups beyond 128, booked
+    devices compared): generation 7 with the signature groups beyond 128; 12 scenarios of 6 000 pods x 300 ... 420 nodes, every
+    placement against the oracle."""
     prob, scen, orders = synth.config_service(n_counts=120, n_orders=2, n_pods=6000, n_het=300, n_services=200, **kw)
     svc = prob.pod_class.astype(np.int64)
     prob.req_cpu = (100 + 10 * svc).astype(np.int64)                    # one request per service, all distinct
@@ -435,13 +436,41 @@ def test_service_workload_with_200_request_shapes_on_generation_7(kw):
     prob.nz_cpu = prob.nz_mem = None
     prob.normalise()
     sub = scen[::20]
-    ref = O.run_threaded(prob, sub, orders)
+    gpu = "n_gpu" in kw
+    ref = O.run_threaded(prob, sub, orders, want_gpu_slices=gpu)
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
-        res = ctx.run_batch(sub, orders)
+        res = ctx.run_batch(sub, orders, want_gpu_slices=gpu)
         st = ctx.stats()
     assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7, (st.kernel_variant, st.kernel_generation)
     assert_same(res, ref)
+    if gpu:
+        assert (res.gpu_slices == ref.gpu_slices).all() and int((ref.gpu_slices != 0).sum()) > 1000
+
+
+@pytest.mark.parametrize("n_pc,gen", [(60, 6), (150, 5)])
+def test_gpu_share_with_more_than_128_signatures_without_services(n_pc, gen):
+    """The GPU fold counts the GPU request into the signature.  Beyond 128 such signatures plain GPU share (no Service) keeps the device rows
+    of generation 6 while the requests WITHOUT the GPU part are <= 128 (60 pod classes, 40 of them asking for GPU share in 4 ways); where they alone are more (150
+    classes) generation 6 cannot hold them either and the fold runs with the signature groups read from memory -- same placements, same
+    devices either way."""
+    prob = randprob.rand_problem(13100 + n_pc, N=400, P=2500, n_node_classes=3, n_pod_classes=n_pc, gpu=True)
+    G_ = 1 << 30                                           # a handful of GPU request kinds (generation 6 holds <= 32 of them)
+    prob.gpu_mem = np.where(prob.gpu_mem > 4 * G_, 8 * G_, np.where(prob.gpu_mem > 0, 2 * G_, 0)).astype(np.int64)
+    prob.gpu_mem = np.where(prob.pod_class < 40, prob.gpu_mem, 0).astype(np.int64)              # 40 classes ask for GPU share in 4 ways
+    prob.pod_gpu_cnt = np.where(prob.gpu_mem > 0, np.where(prob.pod_gpu_cnt >= 2, 2, 1), 0).astype(np.int32)
+    prob.normalise()
+    n_fold = len(set(zip(prob.pod_class.tolist(), prob.gpu_mem.tolist(), prob.pod_gpu_cnt.tolist())))
+    assert 128 < n_fold <= 384
+    scen, orders = randprob.rand_scenarios(131, prob, S=4)
+    ref = O.run(prob, scen, orders, want_gpu_slices=True)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders, want_gpu_slices=True)
+        st = ctx.stats()
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == gen, (st.kernel_variant, st.kernel_generation)
+    assert_same(res, ref)
+    assert (res.gpu_slices == ref.gpu_slices).all()
 
 
 def test_c_consumer_attaches_every_optional_array_by_name(tmp_path):
