@@ -683,6 +683,12 @@ bool fold_supported(simon_ctx* c) {
     return true;
 }
 
+// LDS of ONE workgroup of the two-level score-table instantiations: a gfx950 workgroup may hold all 160 KB of its CU (the launch sets
+// hipFuncAttributeMaxDynamicSharedMemorySize).  Past 64 KB a CU holds two, then one scenario -- still far ahead of the all-feature kernel
+// for the problems that need it (hundreds of signatures x thousands of nodes under generation 7's walks); the one-level layout, which
+// exists for occupancy, keeps its 64 KB bound.
+static constexpr size_t kTableLdsMaxWG = 159 * 1024;
+
 // Decide NARROW vs WIDE and compute the gcd normalisation.
 // NARROW needs: cpu+mem+pods only; every quantity non-negative; after dividing by the gcd all
 // node totals and the worst-case accumulated NonZeroRequested stay < 2^31; simon raw scores fit
@@ -1620,7 +1626,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
             const int nzk = c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0)) : -1;   // (| 0x100: the second score table of spread_select)
             const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest, nzk) + c->lds_pad;
-            const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= 64 * 1024;
+            const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= kTableLdsMaxWG;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
             auto cost = [&](int fits, double factor) {
                 auto round_cost = [](int w) { return 1.0 + 0.055 * (std::min(w, 16) - 1) + 0.11 * std::max(w - 16, 0); };
@@ -1743,10 +1749,10 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         auto lds_for = [&](int tm) -> size_t {
             return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0)) : -1) + c->lds_pad : 0;
         };
-        if (team > 1 && lds_for(team) > 64 * 1024) team = 1;           // (its extra table does not fit: the single-wave shape still may)
+        if (team > 1 && lds_for(team) > kTableLdsMaxWG) team = 1;           // (its extra table does not fit: the single-wave shape still may)
         const size_t table_lds = lds_for(team);
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
-                               ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= 64 * 1024;
+                               ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= (c->table_coarse ? kTableLdsMaxWG : (size_t)64 * 1024);
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         if (c->debug_route)
             fprintf(stderr, "[route] variant %d rest %d spread %d fold %d gfold %d table_ok %d perm_ok %d coarse %d n_sigs %d Cn_t %d ni_top %d lds %zu max_n %d\n", c->variant, (int)c->rest,

@@ -473,6 +473,27 @@ def test_gpu_share_with_more_than_128_signatures_without_services(n_pc, gen):
     assert (res.gpu_slices == ref.gpu_slices).all()
 
 
+@pytest.mark.parametrize("spread", [True, False])
+def test_two_level_score_table_with_more_than_64_kb_of_lds(spread, monkeypatch):
+    """A gfx950 workgroup may hold all 160 KB of its CU's LDS: the two-level instantiations take it (simon_hip.hip: kTableLdsMaxWG) where
+    hundreds of signatures meet thousands of nodes -- 384 signatures x 4 000 nodes under generation 7's walks (LDS ~ 75 KB), 384 x 8 000
+    without them (~ 110 KB; SIMON_FORCE_TABLE: a plain problem of that many signatures prefers generation 2) -- instead of leaving the
+    table.  Placements against the oracle; the LDS the launch asked for is in simon_stats."""
+    monkeypatch.setenv("SIMON_FORCE_TABLE", "1")
+    N, P = (4000, 3000) if spread else (8000, 3000)
+    prob = randprob.rand_problem(14000 + spread, N=N, P=P, n_node_classes=3, n_pod_classes=384, tight_pods=not spread, **(dict(spread_soft=True) if spread else {}))
+    scen, orders = randprob.rand_scenarios(140 + spread, prob, S=3)
+    scen[0, 0] = N
+    ref = O.run_threaded(prob, scen, orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders)
+        st = ctx.stats()
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == (7 if spread else 5), (st.kernel_variant, st.kernel_generation)
+    assert st.lds_bytes > 64 * 1024, st.lds_bytes
+    assert_same(res, ref)
+
+
 def test_c_consumer_attaches_every_optional_array_by_name(tmp_path):
     """tests/cabi/cabi_terms.c (plain C, stands in for the cgo host): the topology-term tables, static score tables and Open-Local arrays
     that integration/go/hipengine/flatten_terms.go fills, attached member by member through offsetof, run against the oracle's golden
