@@ -317,7 +317,7 @@ bool rest_supported(simon_ctx* c) {
 // then needs NO select-time filter: it takes the summary scan, or generation 7's walk when a Service selects it.  Worth it when the
 // signatures stay few (real gpushare workloads: a handful of Deployments) -- config 5's 42 shapes x 8 GPU requests keep the position
 // masks of generation 6.  Needs: no arriving gpu-index lists, GPU quantities on a gcd with quotients < 2^31 (fills g_gpu), at most
-// 384 signatures once the GPU request is part of them (beyond 128 only under generation 7's walks: choose_variant).
+// 1 023 signatures once the GPU request is part of them (beyond 128 only under generation 7's walks: choose_variant).
 bool gfold_supported(simon_ctx* c) {
     if (c->no_gpu_fold || c->no_rest || !c->has_gpu || c->has_gpu_index || c->gpu_cnt.empty()) return false;   // (SIMON_NO_REST keeps meaning: GPU problems on the all-feature kernel)
     uint64_t g = 0;

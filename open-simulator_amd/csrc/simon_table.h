@@ -94,7 +94,9 @@ constexpr int kTableMaxNodes = 4095;    // canonical index and padded position a
 constexpr int kTableMaxNodesCoarse = 8191;    // ... 13-bit fields with the two-level summary
 constexpr int kTableMaxPadded = 4096;   // class-major padded positions of one scenario (classes padded to 16)
 constexpr int kTableMaxPaddedCoarse = 8192;   // ... with the two-level summary (classes padded to 64)
-constexpr int kTableMaxSigs = 384;      // two signatures per lane in registers + up to two more groups of 128 read from TableCold::sigs per cycle
+constexpr int kTableMaxSigs = 1023;     // two signatures per lane in registers + further groups of 128 read from TableCold::sigs per cycle (two with group 0's
+                                        // round trip, the rest one each); 10 bits of the pod row name the signature
+constexpr int kTableFastSigs = 384;     // ... the signatures whose rows travel in ONE round trip per cycle
 constexpr size_t kTableLdsPerCU = 160 * 1024;
 constexpr int kTableMaxGpuSigs = 32;    // distinct (gpu-mem, gpu-count) requests: one mask row and one lane each
 constexpr int kTableMaxXres = 32;       // distinct (ephemeral-storage, extended-resource) requests: one mask row and one lane each

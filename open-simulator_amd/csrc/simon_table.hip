@@ -303,7 +303,8 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // run-time tests of the entries' bit 31).
 // MANY: more than 128 signatures (KQ = 2, two-level summary, no REST): signatures 0 .. 127 live in lane registers as usual, the rest is
 // refreshed from TableCold::sigs in up to two further groups of 128 whose table rows are fetched WITH group 0's (one memory round
-// trip per cycle; own instantiation: the extra rows cost ~40 VGPRs the K <= 128 kernels must not pay).
+// trip per cycle; own instantiation: the extra rows cost ~40 VGPRs the K <= 128 kernels must not pay); groups beyond those
+// (385 .. 1 023 signatures, round 4) follow one round trip each.
 // SPREAD (generation 7): pod classes with soft PodTopologySpread constraints (ScheduleAnyway: the system defaults every pod a Service /
 // ReplicaSet / StatefulSet selects gets, podtopologyspread/plugin.go:39-50) -- see spread_select.
 // NW (team mode, SPREAD only): waves per scenario.  A batch with fewer scenarios than the chip has wave slots -- what a real
@@ -1874,6 +1875,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                                          (kGpuFoldable && gbooked && rg[q].pad[1] != 0 && !gpu_fits_t(gu, gfc, gft, (unsigned)rg[q].pad[0], rg[q].pad[1]))) ? 0u :
                                         eval_node(rg[q].req_c, rg[q].req_m, rg[q].nz_c, rg[q].nz_m, rg[q].flags & 1u, rq_c, rq_m, nzc, nzm, (int)st.freep, sh),
                                         rowg[g][q], Tg[g][q], Fg[g][q], oldg[g][q], sng[q], 2 * (g + 1) + q);
+                    }
+                }
+                // 385 .. 1 023 signatures (round 4): the groups beyond the two whose rows travel with group 0's take a round trip of their
+                // own each -- a problem of that many signatures that needs generation 7's walks or a fold has the all-feature kernel as
+                // its alternative, not a faster table.  (uniform trip count; a lane beyond K evaluates signature 0 and stores nothing)
+                for (int g = NG; 128 * (g + 1) < K; ++g) {
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) {
+                        const int kq = 128 * (g + 1) + 64 * q + lane;
+                        const int kx = kq < K ? kq : 0;
+                        unsigned char* rowx = g_tile + (tile_blk((unsigned)(pstar >> 4)) + (unsigned)kx * KS);
+                        const uint4 Tx = *(const uint4*)rowx;
+                        const unsigned oldx = rowx[pstar & 15];
+                        const uint2 Fx = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kx) * 4u);
+                        const unsigned xfx = fold ? cold->foldx[(unsigned)r_sig * KW + ((unsigned)kx >> 5)] : 0u;
+                        const SigRow rx = sigs[kx];
+                        const unsigned snx = s_sn[kx * Cn + dstar];
+                        refresh_sig(kx, kq < K,
+                                    ((fold && ((xfx >> (kx & 31)) & 1u)) ||
+                                     (kGpuFoldable && gbooked && rx.pad[1] != 0 && !gpu_fits_t(gu, gfc, gft, (unsigned)rx.pad[0], rx.pad[1]))) ? 0u :
+                                    eval_node(rx.req_c, rx.req_m, rx.nz_c, rx.nz_m, rx.flags & 1u, rq_c, rq_m, nzc, nzm, (int)st.freep, sh),
+                                    rowx, Tx, Fx, oldx, snx, 2 * (g + 1) + q);
                     }
                 }
             }

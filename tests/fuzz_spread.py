@@ -25,7 +25,7 @@ def one_case(case):
     if size == 2:
         feat.pop("static_mask", None)
     prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=(case % 7 != 6 or "ipa_self" not in feat), n_node_classes=int(rng.choice([1, 2, 4, 9])),
-                                 n_pod_classes=int(rng.choice([130, 200, 300, 384] if case >= 300000 else [1, 3, 8, 30, 60])), **feat)   # cases from 300 000 on: 129 ... 384 signatures (MANY && SPREAD)
+                                 n_pod_classes=int(rng.choice([130, 200, 300, 384, 600, 1000] if case >= 300000 else [1, 3, 8, 30, 60])), **feat)   # cases from 300 000 on: 129 ... 384 signatures (MANY && SPREAD)
     if "gpu" in feat:                                   # GPU share folded into the table (few request kinds: <= 128 signatures), behind the spread walk
         G_ = 1 << 30
         prob.gpu_mem = np.where(prob.gpu_mem > 4 * G_, 8 * G_, np.where(prob.gpu_mem > 0, 2 * G_, 0)).astype(np.int64)

@@ -70,10 +70,11 @@ def test_config5_every_benchmarked_scenario():
         assert not bad_rows, f"{len(bad_rows)} scenarios differ, first (scenario, count, pod) = {bad_rows[0]}"
 
 
-@pytest.mark.parametrize("n_sigs", [129, 200, 300, 384])
+@pytest.mark.parametrize("n_sigs", [129, 200, 300, 384, 385, 700, 1023])
 def test_config3_beyond_128_signatures_stays_on_the_score_table(n_sigs, monkeypatch):
     """129 request signatures used to fall to generation 2 (8x slower).  The score-table kernel now keeps two
-    signatures per lane in registers and refreshes further groups of 128 from TableCold::sigs (K <= 384; beyond 256 the host
+    signatures per lane in registers and refreshes further groups of 128 from TableCold::sigs (K <= 384 in one round trip per cycle, up to 1 023
+    with one more per group since round 4; beyond 256 the host
     prefers generation 2 where that is eligible -- SIMON_FORCE_TABLE keeps the table for this test)."""
     monkeypatch.setenv("SIMON_FORCE_TABLE", "1")
     prob, scen, orders = synth.config3(n_counts=40, n_orders=3, n_pods=5000, n_sigs=n_sigs)
@@ -90,7 +91,7 @@ def test_config3_beyond_128_signatures_stays_on_the_score_table(n_sigs, monkeypa
 
 @pytest.mark.parametrize("n_sigs", [300, 385])
 def test_many_signatures_fall_back_correctly(n_sigs):
-    """Without the knob: 257 .. 384 signatures of a plain cpu+memory problem take generation 2 (faster there), 385+ always."""
+    """Without the knob: from 257 signatures on a plain cpu+memory problem takes generation 2 (faster there)."""
     prob, scen, orders = synth.config3(n_counts=12, n_orders=2, n_pods=4000, n_sigs=n_sigs)
     ref = O.run_threaded(prob, scen, orders)
     with capi.Context(0) as ctx:
