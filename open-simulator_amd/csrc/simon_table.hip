@@ -1964,6 +1964,47 @@ hipError_t SIMON_TEAM_CAT(launch_table_team, SIMON_TABLE_TEAM_TU)(const TableLau
     if (has_mask) return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_team2<false, true>(a, n_blocks, lds_bytes, st) : launch_team2<false, false>(a, n_blocks, lds_bytes, st);
 }
+#elif defined(SIMON_TABLE_SPREAD_TU)
+// ---- this translation unit (simon_table_spread.hip) holds generation 7: the single-wave SPREAD instantiations (80 of the largest kernels of
+// the library -- next to simon_table.hip instead of inside it, build() runs one hipcc process per unit) ----
+template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool MANY>
+static hipError_t launch_sp7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;
+    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, MANY, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    return hipGetLastError();
+}
+template <bool M, bool Z, int KQ>
+static hipError_t launch_sp4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    const bool ranked = a.sc.rk_stride != 0, ipa = (a.sc.static_tables & 64) != 0;     // (& 64: preferred pod (anti-)affinity / hard zone constraints in spread_select: SPREAD && AFF)
+    if constexpr (KQ == 2) {
+        // 129 .. 1 023 signatures behind Services (round 4): the signature groups of MANY under generation 7's walks.  The walk reads its
+        // pod's row of the table whatever the signature's number; the refresh takes the further groups along as it does without the
+        // walks.  One shape (two entries per lane) serves every cluster size: the regime is rare.
+        if (a.sc.K > 128) {
+            if (ipa) return ranked ? launch_sp7<M, Z, KQ, 2, true, true, true>(a, n_blocks, lds, st) : launch_sp7<M, Z, KQ, 2, false, true, true>(a, n_blocks, lds, st);
+            return ranked ? launch_sp7<M, Z, KQ, 2, true, false, true>(a, n_blocks, lds, st) : launch_sp7<M, Z, KQ, 2, false, false, true>(a, n_blocks, lds, st);
+        }
+    }
+    const bool one = a.sc.ni_max / 64 <= 64;
+    if (ipa) {
+        if (ranked) return one ? launch_sp7<M, Z, KQ, 1, true, true, false>(a, n_blocks, lds, st) : launch_sp7<M, Z, KQ, 2, true, true, false>(a, n_blocks, lds, st);
+        return one ? launch_sp7<M, Z, KQ, 1, false, true, false>(a, n_blocks, lds, st) : launch_sp7<M, Z, KQ, 2, false, true, false>(a, n_blocks, lds, st);
+    }
+    if (ranked) return one ? launch_sp7<M, Z, KQ, 1, true, false, false>(a, n_blocks, lds, st) : launch_sp7<M, Z, KQ, 2, true, false, false>(a, n_blocks, lds, st);
+    return one ? launch_sp7<M, Z, KQ, 1, false, false, false>(a, n_blocks, lds, st) : launch_sp7<M, Z, KQ, 2, false, false, false>(a, n_blocks, lds, st);
+}
+template <bool M, bool Z>
+static hipError_t launch_sp2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.K > 64 ? launch_sp4<M, Z, 2>(a, n_blocks, lds, st) : launch_sp4<M, Z, 1>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.spread || !a.coarse || a.rest || a.team > 1) return hipErrorInvalidValue;
+    if (has_mask) return nzeq ? launch_sp2<true, true>(a, n_blocks, lds_bytes, st) : launch_sp2<true, false>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_sp2<false, true>(a, n_blocks, lds_bytes, st) : launch_sp2<false, false>(a, n_blocks, lds_bytes, st);
+}
 #else
 // placement[s][pod] = place_step[s][inv_order[order_id(s)][pod]]: gather (scattered reads hit L2, stores coalesced)
 __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restrict__ place_step, const int32_t* __restrict__ inv_orders,
@@ -2014,35 +2055,7 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
             return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true, true>(a, n_blocks, lds, st)
                                           : launch_t6<M, Z, PIN, KQ, 2, true, true>(a, n_blocks, lds, st);
     }
-    if constexpr (PIN) {                                              // soft spread constraints likewise; two-level layout
-        if (a.spread) {
-            if (!a.coarse || a.rest) return hipErrorInvalidValue;
-            if constexpr (KQ == 2) {
-                // 129 .. 384 signatures behind Services (round 4): the signature groups of MANY under generation 7's walks.  The walk reads
-                // its pod's row of the table whatever the signature's number; the refresh takes the further groups along as it does
-                // without the walks.  One shape (two entries per lane) serves every cluster size: the regime is rare.
-                if (a.sc.K > 128) {
-                    if (a.sc.static_tables & 64)
-                        return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, 2, true, false, true, true, true, true>(a, n_blocks, lds, st)
-                                                   : launch_t7<M, Z, PIN, KQ, 2, true, false, false, true, true, true>(a, n_blocks, lds, st);
-                    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, 2, true, false, true, false, true, true>(a, n_blocks, lds, st)
-                                               : launch_t7<M, Z, PIN, KQ, 2, true, false, false, false, true, true>(a, n_blocks, lds, st);
-                }
-            }
-            if (a.sc.static_tables & 64) {                            // preferred pod (anti-)affinity in spread_select: SPREAD && AFF
-                if (a.sc.rk_stride != 0)
-                    return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, true, true, false, true>(a, n_blocks, lds, st)
-                                                  : launch_t7<M, Z, PIN, KQ, 2, true, false, true, true, false, true>(a, n_blocks, lds, st);
-                return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, false, true, false, true>(a, n_blocks, lds, st)
-                                              : launch_t7<M, Z, PIN, KQ, 2, true, false, false, true, false, true>(a, n_blocks, lds, st);
-            }
-            if (a.sc.rk_stride != 0)
-                return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, true, false, false, true>(a, n_blocks, lds, st)
-                                              : launch_t7<M, Z, PIN, KQ, 2, true, false, true, false, false, true>(a, n_blocks, lds, st);
-            return a.sc.ni_max / 64 <= 64 ? launch_t7<M, Z, PIN, KQ, 1, true, false, false, false, false, true>(a, n_blocks, lds, st)
-                                          : launch_t7<M, Z, PIN, KQ, 2, true, false, false, false, false, true>(a, n_blocks, lds, st);
-        }
-    }
+    if (a.spread) return hipErrorInvalidValue;                        // (generation 7 lives in simon_table_spread.hip: launch_table_spread)
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
         return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 2, true>(a, n_blocks, lds, st);
     }
@@ -2066,7 +2079,8 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
     if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
         return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
-    has_pin = has_pin || a.rest || a.spread || (a.sc.static_tables & (32 | 128));   // (& 32, & 128: the folds, carried by COARSE && !REST && HAS_PIN)
+    if (a.spread) return launch_table_spread(a, n_blocks, has_mask, nzeq, lds_bytes, st);   // generation 7: simon_table_spread.hip
+    has_pin = has_pin || a.rest || (a.sc.static_tables & (32 | 128));   // (& 32, & 128: the folds, carried by COARSE && !REST && HAS_PIN)
     if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
     return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
 }
