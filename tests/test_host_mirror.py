@@ -120,6 +120,13 @@ def test_reference_gpushare_config_end_to_end():
     assert sw.unscheduled == [0, 0, 0] and sw.best == 0
     placed = sum(len(s["pods"]) for s in sw.result.node_status)
     assert placed == 9 and not sw.result.unscheduled_pods
+    # what the mirror hangs on pods for its own use never leaves it; result nodes are objects of their own (top level, metadata, status)
+    assert not any(k.startswith("_") for s in sw.result.node_status for p in s["pods"] for k in p)
+    by_name = {n["metadata"]["name"]: n for n in cfg["cluster"]["Node"]}
+    for s in sw.result.node_status:
+        src = by_name.get(s["node"]["metadata"]["name"])
+        if src is not None:
+            assert s["node"] is not src and s["node"]["metadata"] is not src["metadata"] and s["node"]["status"] is not src["status"]
     # gpu-pod-00 and gpu-pod-02 carry the gpu-mem annotation (gpu-pod-01 has none; the ReplicaSet's sit on the RS object)
     gpu_pods = [p for s in sw.result.node_status for p in s["pods"] if "alibabacloud.com/gpu-mem" in (p["metadata"].get("annotations") or {})]
     assert len(gpu_pods) == 2
