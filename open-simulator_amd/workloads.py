@@ -246,9 +246,16 @@ def make_valid_node(node: dict, name: str) -> dict:
 
 def new_fake_nodes(template: dict, count: int) -> List[dict]:
     """NewFakeNodes (pkg/utils/utils.go:885-901); the reference names them simon-<rand5>, here simon-<index>."""
+    # ONE validated deep copy of the template; the clones own their top level, metadata, labels and annotations and share the rest
+    # read-only (as _replicate does for pods: 2 500 deep copies were a sixth of the host time of a sweep)
+    proto = make_valid_node(template, "")
+    had_labels = (template.get("metadata") or {}).get("labels") is not None
     out = []
     for i in range(count):
-        n = make_valid_node(template, f"{NEW_NODE_NAME_PREFIX}-{i:05d}")
-        n["metadata"]["labels"][LABEL_NEW_NODE] = ""
-        out.append(n)
+        name = f"{NEW_NODE_NAME_PREFIX}-{i:05d}"
+        md = dict(proto["metadata"], name=name, labels=dict(proto["metadata"]["labels"]), annotations=dict(proto["metadata"]["annotations"]))
+        if had_labels:
+            md["labels"][k8s.LABEL_HOSTNAME] = name
+        md["labels"][LABEL_NEW_NODE] = ""
+        out.append(dict(proto, metadata=md))
     return out
