@@ -424,13 +424,16 @@ def test_more_than_128_signatures_behind_services_stay_on_generation_7(idx, monk
         assert_same(res, ref)
 
 
-@pytest.mark.parametrize("kw", [dict(n_pref=200), dict(n_anti=40, n_hard=30), dict(n_pref=60, n_anti=20), dict(n_gpu=70, n_anti=20, taint_pct=10), dict(n_gpu=200)])
+@pytest.mark.parametrize("kw", [dict(n_pref=200), dict(n_anti=40, n_hard=30), dict(n_pref=60, n_anti=20), dict(n_gpu=70, n_anti=20, taint_pct=10), dict(n_gpu=200),
+                                dict(n_services=500, n_gpu=150, n_anti=30), dict(n_services=900, n_pref=300, n_hard=60)])
 def test_service_workload_with_200_request_shapes_on_generation_7(kw):
     """200 Deployments behind Services, each with a request of its own (200 signatures), preferring / requiring not to sit next to their
     own replicas, some with hard zone constraints, some asking for GPU share (the GPU fold with the signature groups beyond 128, booked
     devices compared): generation 7 with the signature groups beyond 128; 12 scenarios of 6 000 pods x 300 ... 420 nodes, every
     placement against the oracle."""
-    prob, scen, orders = synth.config_service(n_counts=120, n_orders=2, n_pods=6000, n_het=300, n_services=200, **kw)
+    kw = dict(kw)
+    n_services = kw.pop("n_services", 200)              # 500 / 900: the signature groups beyond 384 (one round trip each), with the GPU fold / the folds
+    prob, scen, orders = synth.config_service(n_counts=120, n_orders=2, n_pods=6000, n_het=300, n_services=n_services, **kw)
     svc = prob.pod_class.astype(np.int64)
     prob.req_cpu = (100 + 10 * svc).astype(np.int64)                    # one request per service, all distinct
     prob.req_mem = ((128 + 16 * (svc % 37)) << 20).astype(np.int64)
