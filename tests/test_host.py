@@ -59,6 +59,20 @@ def test_library_exports_every_declared_symbol():
         assert lib.simon_ctx_create(0) is None
 
 
+def test_build_covers_every_hip_unit():
+    """__graft_entry__.build() compiles an explicit list of translation units: a .hip file in csrc/ that is not on it (or an #include of
+    the kernel source without the dependency that makes it rebuild) would silently stay out of libsimon_hip.so."""
+    import __graft_entry__ as g
+    csrc = os.path.join(ROOT, "open-simulator_amd", "csrc")
+    on_disk = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert on_disk == sorted(g.HIP_SOURCES)
+    for f in on_disk:
+        for inc in re.findall(r'#include "([a-z_0-9]+\.hip)"', open(os.path.join(csrc, f)).read()):
+            assert inc in g.EXTRA_DEPS.get(f, []), (f, inc)
+    for h in re.findall(r'#include "(simon_[a-z_]+\.h)"', "".join(open(os.path.join(csrc, f)).read() for f in on_disk)):
+        assert h in g.HIP_HEADERS or os.path.join(ROOT, "include", h) in g.HIP_HEADERS, h
+
+
 def test_struct_layouts_match_the_header():
     """ctypes mirrors must have the sizes the C compiler gives the header structs."""
     import subprocess, tempfile, textwrap
