@@ -236,6 +236,9 @@ def _gc_paused(fn):
     pass of the collector walks all of them again: 40 % of the host time of a 50 000-pod sweep (profiles/README.md, round 4)."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
+        import os
+        if os.environ.get("SIMON_HOST_GC") == "1":       # A/B: leave the collector alone
+            return fn(*args, **kwargs)
         was = gc.isenabled()
         gc.disable()
         try:
