@@ -142,11 +142,17 @@ def sort_interface(n: int, less: Callable[[int, int], bool], swap: Callable[[int
     _quick_sort(less, swap, 0, n, _max_depth(n))
 
 
-def sort_by_unary_less(items: Sequence[T], first: Callable[[T], bool]) -> List[T]:
+def sort_by_unary_less(items: Sequence[T], first: Callable[[T], bool], generic: bool = False) -> List[T]:
     """`sort.Sort` of a queue whose `Less(i, j)` is `first(items[i])` -- pkg/algo's AffinityQueue (`Spec.NodeSelector != nil`)
-    and TolerationQueue (`Spec.Tolerations != nil`).  Returns the permuted list; `items` is not modified."""
+    and TolerationQueue (`Spec.Tolerations != nil`).  Returns the permuted list; `items` is not modified.
+    `generic=True` runs the three-callable restatement above; the default is the same algorithm with `Less` and `Swap` written out over
+    a flag list and an index permutation (no calls in the inner loops: half the time on 50 000 pods), held equal to it by
+    tests/test_ref_parity.py on random flag vectors."""
     out = list(items)
     flag = [bool(first(x)) for x in out]
+    if not generic:
+        perm = _sort_unary(flag)
+        return [out[i] for i in perm]
 
     def less(i, j):
         return flag[i]
@@ -157,3 +163,127 @@ def sort_by_unary_less(items: Sequence[T], first: Callable[[T], bool]) -> List[T
 
     sort_interface(len(out), less, swap)
     return out
+
+
+def _sort_unary(flag: List[bool]) -> List[int]:
+    """go1.18 `sort.Sort` with Less(i, j) = f[i], specialised: f (a copy of `flag`) and the permutation p are swapped together.
+    Statement for statement the functions above with `less(x, y)` -> `f[x]` and `swap(x, y)` written out."""
+    f = list(flag)
+    n = len(f)
+    p = list(range(n))
+
+    def med3(m1, m0, m2):
+        if f[m1]:
+            f[m1], f[m0] = f[m0], f[m1]; p[m1], p[m0] = p[m0], p[m1]
+        if f[m2]:
+            f[m2], f[m1] = f[m1], f[m2]; p[m2], p[m1] = p[m1], p[m2]
+            if f[m1]:
+                f[m1], f[m0] = f[m0], f[m1]; p[m1], p[m0] = p[m0], p[m1]
+
+    def sift_down(lo, hi, first):
+        root = lo
+        while True:
+            child = 2 * root + 1
+            if child >= hi:
+                return
+            if child + 1 < hi and f[first + child]:
+                child += 1
+            x, y = first + root, first + child
+            if not f[x]:
+                return
+            f[x], f[y] = f[y], f[x]; p[x], p[y] = p[y], p[x]
+            root = child
+
+    def heap_sort(a, b):
+        first, lo, hi = a, 0, b - a
+        for i in range((hi - 1) // 2, -1, -1):
+            sift_down(i, hi, first)
+        for i in range(hi - 1, -1, -1):
+            y = first + i
+            f[first], f[y] = f[y], f[first]; p[first], p[y] = p[y], p[first]
+            sift_down(lo, i, first)
+
+    def do_pivot(lo, hi):
+        m = (lo + hi) >> 1
+        if hi - lo > 40:
+            s_ = (hi - lo) // 8
+            med3(lo, lo + s_, lo + 2 * s_)
+            med3(m, m - s_, m + s_)
+            med3(hi - 1, hi - 1 - s_, hi - 1 - 2 * s_)
+        med3(lo, m, hi - 1)
+        pivot = lo
+        a, c = lo + 1, hi - 1
+        while a < c and f[a]:
+            a += 1
+        b = a
+        fp = f[pivot]                      # the pivot does not move until the final swap
+        while True:
+            while b < c and not fp:
+                b += 1
+            while b < c and fp:
+                c -= 1
+            if b >= c:
+                break
+            x = c - 1
+            f[b], f[x] = f[x], f[b]; p[b], p[x] = p[x], p[b]
+            b += 1
+            c -= 1
+        protect = hi - c < 5
+        if not protect and hi - c < (hi - lo) // 4:
+            dups = 0
+            if not fp:
+                x = hi - 1
+                f[c], f[x] = f[x], f[c]; p[c], p[x] = p[x], p[c]
+                c += 1
+                dups += 1
+            if not f[b - 1]:
+                b -= 1
+                dups += 1
+            if not f[m]:
+                x = b - 1
+                f[m], f[x] = f[x], f[m]; p[m], p[x] = p[x], p[m]
+                b -= 1
+                dups += 1
+            protect = dups > 1
+        if protect:
+            while True:
+                while a < b and not f[b - 1]:
+                    b -= 1
+                while a < b and f[a]:
+                    a += 1
+                if a >= b:
+                    break
+                x = b - 1
+                f[a], f[x] = f[x], f[a]; p[a], p[x] = p[x], p[a]
+                a += 1
+                b -= 1
+        x = b - 1
+        f[pivot], f[x] = f[x], f[pivot]; p[pivot], p[x] = p[x], p[pivot]
+        return b - 1, c
+
+    def quick_sort(a, b, max_depth):
+        while b - a > 12:
+            if max_depth == 0:
+                heap_sort(a, b)
+                return
+            max_depth -= 1
+            mlo, mhi = do_pivot(a, b)
+            if mlo - a < b - mhi:
+                quick_sort(a, mlo, max_depth)
+                a = mhi
+            else:
+                quick_sort(mhi, b, max_depth)
+                b = mlo
+        if b - a > 1:
+            for i in range(a + 6, b):
+                if f[i]:
+                    j = i - 6
+                    f[i], f[j] = f[j], f[i]; p[i], p[j] = p[j], p[i]
+            for i in range(a + 1, b):
+                j = i
+                while j > a and f[j]:
+                    f[j], f[j - 1] = f[j - 1], f[j]; p[j], p[j - 1] = p[j - 1], p[j]
+                    j -= 1
+
+    quick_sort(0, n, _max_depth(n))
+    return p

@@ -101,3 +101,14 @@ def test_gosort_against_the_second_restatement_and_committed_vectors():
         flags = "".join("1" if rnd.random() < p else "0" for _ in range(n))
         out = subprocess.run([exe, flags], capture_output=True, text=True, check=True).stdout.split()
         assert [int(x) for x in out] == mine(flags), flags
+    # the lengths a real pod stream has (heapSort is reached there: 50 000 pods with a fifth flagged run 18 000 sift-downs) ...
+    for n, p in ((5000, 0.2), (20000, 0.5), (50000, 0.2), (50000, 0.97)):
+        flags = "".join("1" if rnd.random() < p else "0" for _ in range(n))
+        out = subprocess.run([exe, flags], capture_output=True, text=True, check=True).stdout.split()
+        assert [int(x) for x in out] == mine(flags), (n, p)
+    # ... and the written-out form the product path runs (gosort._sort_unary) against the three-callable restatement, statement for statement
+    for trial in range(1500):
+        n = rnd.choice([0, 1, 2, 5, 11, 12, 13, 14, 20, 40, 41, 42, 50, 100, 257, 1000, 3000]) if trial % 3 else rnd.randint(0, 600)
+        p = rnd.choice([0.0, 0.01, 0.1, 0.3, 0.5, 0.7, 0.9, 0.99, 1.0])
+        items = [(i, rnd.random() < p) for i in range(n)]
+        assert gosort.sort_by_unary_less(items, lambda x: x[1]) == gosort.sort_by_unary_less(items, lambda x: x[1], generic=True), (n, p)
