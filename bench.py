@@ -597,10 +597,13 @@ def claim_stdout():
     GPU box, r06b).  So the process keeps the real stdout for its own lines and points fd 1 at stderr for everything else."""
     global _RECORD_OUT
     if _RECORD_OUT is None:
-        sys.stdout.flush()
-        fd = os.dup(1)
-        os.dup2(2, 1)
-        _RECORD_OUT = os.fdopen(fd, "w", buffering=1)
+        try:
+            sys.stdout.flush()
+            fd = os.dup(1)
+            os.dup2(2, 1)
+            _RECORD_OUT = os.fdopen(fd, "w", buffering=1)
+        except OSError as e:                                   # a closed stdout / stderr: print as before
+            print(f"[bench] could not re-point stdout ({e}); library output may follow the record", file=sys.stderr)
 
 
 def emit(out):
