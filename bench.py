@@ -555,6 +555,8 @@ def compact_line(out, detail_name):
                                            "all_gather_ms_per_step": rk.get("all_gather_ms_per_step"), "collective": rk.get("plan_collective"),
                                            "distinct_devices": sc.get("distinct_devices_over_ranks"), "forced_one_rank_group": rk.get("forced_one_rank_group"),
                                            "rccl_version": sc.get("rccl_version"),
+                                           "rccl_ranks": (rk.get("world_size") if rk.get("backend") == "nccl" else 0) if rk.get("world_size") else None,
+                                           "devices": sc.get("device_list"),
                                            "one_device_test_hook": sc.get("one_device_test_hook", rk.get("one_device_test_hook"))}.items() if v is not None}
     e2e = out.get("end_to_end")
     if e2e:
@@ -643,7 +645,10 @@ def multi_rank_selfcheck(torch, dist, world, rank, local_rank, backend):
         if distinct != world:
             raise SystemExit(f"bench.py: {world} ranks share {distinct} device(s): {idents}")
     info = {"visible_devices": ndev, "distinct_devices_over_ranks": distinct, "one_device_test_hook": shared,
-            "devices": [f"rank {r}: local_rank {lr}" for r, lr, _ in idents]}
+            "devices": [f"rank {r}: local_rank {lr}" for r, lr, _ in idents],
+            # per rank, in rank order: local device index and the device's identity (uuid / bus id) -- what the driver's SCALE record
+            # is judged by the day a multi-GPU node runs this
+            "device_list": [f"{lr}:{str(idt)[-12:]}" for _, lr, idt in sorted(idents)]}
     if backend == "nccl":
         try:
             info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())

@@ -72,9 +72,16 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 			return false
 		}
 	}
+	// SIMON_ENGINE_TERMS=0 narrows the engine to what needs no term tables (resources, static filters, GPU share, DaemonSets): the
+	// flattening of affinity / spread constraints / host ports / local volumes (flatten_terms.go) is the youngest and largest part of
+	// this never-compiled package -- a first deployment can run engine_test.go with the switch off, then on.
+	termsOff := os.Getenv("SIMON_ENGINE_TERMS") == "0"
 	var prio *int32
 	for _, p := range pods {
 		s := &p.Spec
+		if termsOff && usesTermTables(p, cluster) {
+			return false
+		}
 		if len(s.TopologySpreadConstraints) > 2*maxSpread { // at most SIMON_MAX_SPREAD hard and as many soft constraints (fillTerms checks each kind)
 			return false
 		}
@@ -94,6 +101,23 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 		}
 	}
 	return true
+}
+
+// usesTermTables: does the pod need anything fillTerms (flatten_terms.go) produces -- pod (anti-)affinity, spread constraints of its
+// own or the system defaults a Service / ReplicaSet / StatefulSet selector gives it, host ports, Open-Local volumes?
+func usesTermTables(p *corev1.Pod, cluster simulator.ResourceTypes) bool {
+	s := &p.Spec
+	if a := s.Affinity; a != nil && (a.PodAffinity != nil || a.PodAntiAffinity != nil) {
+		return true
+	}
+	if len(s.TopologySpreadConstraints) > 0 || len(defaultSpreadSelectors(p, cluster)) > 0 {
+		return true
+	}
+	if len(hostPortsOf(p)) > 0 {
+		return true
+	}
+	_, local := p.Annotations[simontype.AnnoPodLocalStorage]
+	return local
 }
 
 // podStream is the pod sequence one Simulate call feeds the scheduler: cluster pods (core.go:80-95), then each app's

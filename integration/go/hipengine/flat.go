@@ -7,6 +7,18 @@ import "C"
 
 import "unsafe"
 
+// Compile-time checks: the Go constants of flatten_terms.go that restate header constants ARE the header's values (an array type of
+// negative or non-zero length does not convert to [0]struct{}: a mismatch stops the build).  tests/test_go_static.py checks the same
+// from the comments while no Go toolchain is at hand -- the round-4 advisor found spreadDupKey = 1 << 14 against 0x40000000 that way.
+var (
+	_ [0]struct{} = [spreadDupKey - C.SIMON_SPREAD_DUP_KEY]struct{}{}
+	_ [0]struct{} = [maxSpread - C.SIMON_MAX_SPREAD]struct{}{}
+	_ [0]struct{} = [classAffSelf - C.SIMON_CLASS_AFF_SELF]struct{}{}
+	_ [0]struct{} = [maxVG - C.SIMON_MAX_VG]struct{}{}
+	_ [0]struct{} = [maxLDev - C.SIMON_MAX_LDEV]struct{}{}
+	_ [0]struct{} = [maxLVol - C.SIMON_MAX_LVOL]struct{}{}
+)
+
 // Flat is the SoA image of (cluster nodes + new-node clones, ordered pod list, per-class tables): the three input
 // structs of include/simon_hip.h with Go slices in place of the C pointers.  A nil slice = the optional array is
 // absent ("all zero" / feature off), exactly as a NULL pointer in the header.  The reference implementation that fills

@@ -23,6 +23,7 @@ import (
 	corev1 "k8s.io/api/core/v1"
 	metav1 "k8s.io/apimachinery/pkg/apis/meta/v1"
 	"k8s.io/apimachinery/pkg/labels"
+	"k8s.io/component-helpers/scheduling/corev1/nodeaffinity"
 	v1helper "k8s.io/kubernetes/pkg/apis/core/v1/helper"
 	framework "k8s.io/kubernetes/pkg/scheduler/framework"
 	pluginhelper "k8s.io/kubernetes/pkg/scheduler/framework/plugins/helper"
@@ -36,7 +37,7 @@ const (
 	labelZone              = "topology.kubernetes.io/zone"
 	nodeKey                = "\x00node" // synthetic topology key whose domain is the node itself (NodePorts)
 	hardPodAffinityWeight  = 1          // interpodaffinity: DefaultHardPodAffinityWeight (apis/config/v1beta1/defaults.go)
-	spreadDupKey           = 1 << 14    // SIMON_SPREAD_DUP_KEY: a later soft constraint on a key already registered sees size 0
+	spreadDupKey           = 0x40000000 // SIMON_SPREAD_DUP_KEY (include/simon_hip.h:51, capi.SPREAD_DUP_KEY): a later soft constraint on a key already registered sees size 0
 	maxSpread              = 4          // SIMON_MAX_SPREAD
 	classAffSelf           = 1          // SIMON_CLASS_AFF_SELF
 	maxVG, maxLDev, maxLVol = 4, 8, 4   // SIMON_MAX_VG, SIMON_MAX_LDEV, SIMON_MAX_LVOL
@@ -583,22 +584,26 @@ func staticScores(pool []*corev1.Node, classPods []*corev1.Pod) (na, tt [][]int6
 				tolPrefer = append(tolPrefer, t)
 			}
 		}
+		// the reference's own parse + match (nodeaffinity/node_affinity.go:96-103 -> component-helpers nodeaffinity.go:110-146): weight-0
+		// and empty terms are skipped, a term matches on matchExpressions AND matchFields (metadata.name).  A term that does not parse
+		// makes the plugin's Score fail the whole cycle in the reference; Supports() refuses such pods, here they score nothing.
+		var prefTerms *nodeaffinity.PreferredSchedulingTerms
+		if len(prefs) != 0 {
+			if pt, err := nodeaffinity.NewPreferredSchedulingTerms(prefs); err == nil {
+				prefTerms = pt
+			}
+		}
 		for j, n := range pool {
-			for _, term := range prefs {
-				if term.Weight == 0 {
-					continue
+			if prefTerms != nil {
+				if w := prefTerms.Score(n); w != 0 {
+					if na == nil {
+						na = make([][]int64, Cp)
+					}
+					if na[c] == nil {
+						na[c] = make([]int64, N)
+					}
+					na[c][j] += w
 				}
-				sel, err := v1helper.NodeSelectorRequirementsAsSelector(term.Preference.MatchExpressions)
-				if err != nil || !sel.Matches(labels.Set(n.Labels)) {
-					continue
-				}
-				if na == nil {
-					na = make([][]int64, Cp)
-				}
-				if na[c] == nil {
-					na[c] = make([]int64, N)
-				}
-				na[c][j] += int64(term.Weight)
 			}
 			for i := range n.Spec.Taints {
 				taint := &n.Spec.Taints[i]

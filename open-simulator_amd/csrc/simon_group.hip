@@ -8,7 +8,8 @@
 // HIP device and stream.  The one cross-device exchange of the path is the minimum-node plan
 // (north_star: "RCCL all-gather over xGMI only to collect the global minimum-node plan"):
 //   * members on DISTINCT devices: one ncclAllGather of the 8-byte plan key (n_nodes << 32 | scenario, written by plan_kernel)
-//     straight from device memory, on every member's own stream, through communicators made once by ncclCommInitAll at
+//     straight from device memory, on every member's own stream (enqueued for all members by ONE thread inside ncclGroupStart /
+//     ncclGroupEnd: no rank can miss the collective), through communicators made once by ncclCommInitAll at
 //     group creation; every member then holds all keys, member 0's copy is read back and the lexicographic minimum
 //     (n_nodes, global scenario) picks the winner, whose own context fills in the occupancy figures;
 //   * one member, members sharing a device (tests), RCCL not loadable / failing, or SIMON_GROUP_RCCL=0: the same
@@ -44,6 +45,9 @@ struct simon_group {
     ncclResult_t (*p_init_all)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*p_all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*p_abort)(ncclComm_t) = nullptr;
+    ncclResult_t (*p_group_start)() = nullptr;
+    ncclResult_t (*p_group_end)() = nullptr;
     const char* (*p_errstr)(ncclResult_t) = nullptr;
     std::vector<ncclComm_t> comm;
     std::vector<void*> d_gather;
@@ -112,7 +116,10 @@ void rccl_setup(simon_group* g) {
     g->p_all_gather = reinterpret_cast<decltype(g->p_all_gather)>(dlsym(g->rccl, "ncclAllGather"));
     g->p_destroy = reinterpret_cast<decltype(g->p_destroy)>(dlsym(g->rccl, "ncclCommDestroy"));
     g->p_errstr = reinterpret_cast<decltype(g->p_errstr)>(dlsym(g->rccl, "ncclGetErrorString"));
-    if (!g->p_init_all || !g->p_all_gather || !g->p_destroy) return;
+    g->p_abort = reinterpret_cast<decltype(g->p_abort)>(dlsym(g->rccl, "ncclCommAbort"));
+    g->p_group_start = reinterpret_cast<decltype(g->p_group_start)>(dlsym(g->rccl, "ncclGroupStart"));
+    g->p_group_end = reinterpret_cast<decltype(g->p_group_end)>(dlsym(g->rccl, "ncclGroupEnd"));
+    if (!g->p_init_all || !g->p_all_gather || !g->p_destroy || !g->p_group_start || !g->p_group_end) return;
     try { g->comm.assign(n, nullptr); g->d_gather.assign(n, nullptr); } catch (...) { return; }
     std::vector<int> devs(g->device.begin(), g->device.end());
     if (g->p_init_all(g->comm.data(), n, devs.data()) != ncclSuccess) { g->comm.clear(); return; }
@@ -303,23 +310,38 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
         void* stream[64] = {nullptr};
         int rc = on_all(g, "min_plan (plan kernel)", [&](int i) { return simon_min_plan_device(g->ctx[i], max_cpu_pct, max_mem_pct, max_vg_pct, &d_key[i], &stream[i]); });
         if (rc) return rc;
-        ncclResult_t nr[64];
-        for (int i = 0; i < n; ++i) nr[i] = ncclSuccess;
-        hipError_t he[64];
-        for (int i = 0; i < n; ++i) he[i] = hipSuccess;
-        (void)on_all(g, "min_plan (all-gather)", [&](int i) {
-            if ((he[i] = hipSetDevice(g->device[i])) != hipSuccess) return (int)SIMON_OK;   // (still join the collective: the others wait for this rank)
-            nr[i] = g->p_all_gather(d_key[i], g->d_gather[i], 1, ncclUint64, g->comm[i], (hipStream_t)stream[i]);
-            he[i] = hipStreamSynchronize((hipStream_t)stream[i]);
-            return (int)SIMON_OK;
-        });
-        for (int i = 0; i < n; ++i) {
-            if (nr[i] != ncclSuccess) return gfail(g, SIMON_ENODEV, "min_plan: ncclAllGather on member %d: %s", i, g->p_errstr ? g->p_errstr(nr[i]) : "error");
-            if (he[i] != hipSuccess) return gfail(g, SIMON_ENODEV, "min_plan: member %d: %s", i, hipGetErrorString(he[i]));
+        // ONE thread enqueues the collective for every member inside ncclGroupStart / ncclGroupEnd (the single-process multi-GPU
+        // form RCCL documents): no member can miss the collective because its host thread failed to start or its device could not
+        // be selected -- either every rank is enqueued or, on any error, the communicators are aborted (which ends whatever was
+        // launched, so no stream is left waiting for a peer) and this call and all later ones reduce on the host instead.
+        ncclResult_t nr = g->p_group_start();
+        int bad = -1;
+        if (nr == ncclSuccess) {
+            for (int i = 0; i < n; ++i) {
+                const ncclResult_t r = g->p_all_gather(d_key[i], g->d_gather[i], 1, ncclUint64, g->comm[i], (hipStream_t)stream[i]);
+                if (r != ncclSuccess && nr == ncclSuccess) { nr = r; bad = i; }
+            }
+            const ncclResult_t r = g->p_group_end();
+            if (r != ncclSuccess && nr == ncclSuccess) nr = r;
         }
+        hipError_t he = hipSuccess;
+        if (nr == ncclSuccess)
+            for (int i = 0; i < n && he == hipSuccess; ++i) {
+                if ((he = hipSetDevice(g->device[i])) == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream[i]);
+                if (he != hipSuccess) bad = i;
+            }
         unsigned long long keys[64];
-        if (hipSetDevice(g->device[0]) != hipSuccess || hipMemcpy(keys, g->d_gather[0], (size_t)n * sizeof keys[0], hipMemcpyDeviceToHost) != hipSuccess)
-            return gfail(g, SIMON_ENODEV, "min_plan: reading the gathered keys back failed");
+        if (nr == ncclSuccess && he == hipSuccess &&
+            (hipSetDevice(g->device[0]) != hipSuccess || hipMemcpy(keys, g->d_gather[0], (size_t)n * sizeof keys[0], hipMemcpyDeviceToHost) != hipSuccess))
+            he = hipErrorUnknown;
+        if (nr != ncclSuccess || he != hipSuccess) {
+            // first-run safety: never leave a half-entered collective behind
+            if (g->p_abort) for (ncclComm_t& c : g->comm) if (c) { (void)g->p_abort(c); c = nullptr; }
+            g->comm_ok = false;
+            (void)gfail(g, SIMON_ENODEV, "min_plan: RCCL all-gather failed (member %d: %s); reduced on the host instead", bad,
+                        nr != ncclSuccess ? (g->p_errstr ? g->p_errstr(nr) : "nccl error") : hipGetErrorString(he));
+            goto host_reduction;
+        }
         g->collective = 1;
         memset(best, 0, sizeof *best);
         best->scenario = -1;
@@ -339,6 +361,7 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
         if (vg_pct) *vg_pct = vgw;
         return SIMON_OK;
     }
+host_reduction:
     simon_plan plans[64];                                   // at most 64 members (simon_group_create)
     int32_t vg[64] = {0};
     memset(plans, 0, sizeof plans);

@@ -124,6 +124,7 @@ struct simon_ctx : simon::HostInputs {
     int fold_FC = 0;
     DevBuf<uint32_t> d_foldx;                     // [K][ceil(K / 32)]: bit S of row L = signature L landing excludes signature S
     uint64_t g_gpu = 1, g_eph = 1;               // gcd of every GPU memory / ephemeral-storage quantity
+    uint64_t gfold_g = 1;                        // the GPU fold's own gcd: rest_supported() is also called as a PROBE and resets g_gpu
     std::vector<int> zone_keys;                  // topology keys of terms that are not node-level (REST: a domain = many positions)
     std::vector<int> key_zslot;                  // [Kt] index into zone_keys or -1 (node-level / unused)
     DevBuf<int32_t> d_zdom;
@@ -361,6 +362,7 @@ bool gfold_supported(simon_ctx* c) {
     }
     c->gfold_sigs = (int)sig.size();
     c->gfold_base_sigs = (int)base.size();
+    c->gfold_g = g;
     c->g_gpu = g;
     return true;
 }
@@ -733,6 +735,9 @@ void choose_variant(simon_ctx* c) {
     // the GPU fold serves problems that need no other per-node filter row: plain cpu+memory+GPU, and generation 7's (Services next to GPU pods)
     if (c->gfold && ((!c->spread && !c->fold && c->Tm > 0) || c->xres)) { c->gfold = false; if (c->has_gpu) c->fold = false; }
     const bool wants_rest = !c->spread && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
+    // rest_supported() above ran as a probe and leaves g_gpu = 1 when it says no (e.g. more than kTableMaxGpuSigs GPU requests): a fold
+    // that survives the probes stages its quantities on ITS gcd -- the 31-bit bounds were checked against that one, not against 1
+    if (c->gfold) c->g_gpu = c->gfold_g;
     if (c->spread && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
     if (c->spread && !c->fold && (!c->anti_idx.empty() || !c->port_idx.empty())) { c->spread = false; return; }
     if (wants_rest && !rest_supported(c)) return;

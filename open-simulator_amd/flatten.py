@@ -375,6 +375,9 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     if len(node_index) != N:
         raise ValueError("duplicate node names")
     words = (N + 63) // 64
+    # the (namespace, first selector pair) index of the Services is built once PER CALL: a list the caller edited in place between two
+    # calls (same object, same length) must not be read through the previous call's index
+    _SVC_INDEX.clear()
 
     # ---- pods: requests, classes ---------------------------------------------------------------------------
     # Ingest: every per-pod quantity is evaluated once per TEMPLATE.  workloads.py stamps the

@@ -269,6 +269,8 @@ def test_bench_gpus_flag_spawns_the_ranks_itself():
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["backend"] == "gloo" and line["ranks"]["one_device_test_hook"] is True
+    # the parsed line says how many ranks went through RCCL (none here: gloo) and which device every rank sat on
+    assert line["ranks"]["rccl_ranks"] == 0 and len(line["ranks"]["devices"]) == 2 and all(d.startswith("0:") for d in line["ranks"]["devices"])
     d = json.load(open(env["SIMON_BENCH_DETAIL"]))
     assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
     assert "self-spawned" in d["ranks"]["launched_by"]

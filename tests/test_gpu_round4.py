@@ -364,6 +364,7 @@ def test_bench_runs_its_rccl_calls_in_a_group_of_one_rank(tmp_path):
     rk = line["ranks"]
     assert rk["backend"] == "nccl" and rk["world_size"] == 1 and rk["forced_one_rank_group"] is True and rk["all_gather_ms_per_step"] > 0
     assert rk["rccl_version"] and "unavailable" not in rk["rccl_version"]
+    assert rk["rccl_ranks"] == 1 and len(rk["devices"]) == 1 and rk["devices"][0].startswith("0:")
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["plan"][0] > 0
 
 
@@ -473,6 +474,32 @@ def test_gpu_share_with_more_than_128_signatures_without_services(n_pc, gen):
         res = ctx.run_batch(scen, orders, want_gpu_slices=True)
         st = ctx.stats()
     assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == gen, (st.kernel_variant, st.kernel_generation)
+    assert_same(res, ref)
+    assert (res.gpu_slices == ref.gpu_slices).all()
+
+
+def test_gpu_fold_keeps_its_gcd_when_the_position_mask_probe_says_no():
+    """Round-4 advisor finding: choose_variant probes rest_supported() for a plain GPU problem with more than 128 folded signatures; the
+    probe resets g_gpu to 1 and then says no when the problem holds more than 32 distinct GPU requests -- the fold stayed on with a gcd
+    of 1 and Mi-scale gpu-mem (2 GiB = 2^31) was cut to 32 bits.  40 distinct GPU requests x 60 pod classes (<= 128 requests without
+    the GPU part) is exactly that case: the fold must run on ITS gcd, placements and devices must equal the oracle's."""
+    prob = randprob.rand_problem(13377, N=400, P=2500, n_node_classes=3, n_pod_classes=60, gpu=True)
+    Mi = 1 << 20
+    idx = np.arange(prob.n_pods)
+    prob.gpu_mem = np.where(prob.gpu_mem > 0, (1 + idx % 40) * 256 * Mi, 0).astype(np.int64)      # 256 Mi ... 10 Gi in 40 steps
+    prob.pod_gpu_cnt = np.where(prob.gpu_mem > 0, 1, 0).astype(np.int32)
+    prob.normalise()
+    n_req = len(set(zip(prob.gpu_mem[prob.gpu_mem > 0].tolist(), prob.pod_gpu_cnt[prob.gpu_mem > 0].tolist())))
+    n_fold = len(set(zip(prob.pod_class.tolist(), prob.gpu_mem.tolist(), prob.pod_gpu_cnt.tolist())))
+    assert n_req > 32 and n_fold > 128 and len(set(prob.pod_class.tolist())) <= 128
+    scen, orders = randprob.rand_scenarios(137, prob, S=4)
+    ref = O.run(prob, scen, orders, want_gpu_slices=True)
+    assert int((ref.gpu_slices != 0).sum()) > 100
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders, want_gpu_slices=True)
+        st = ctx.stats()
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 5, (st.kernel_variant, st.kernel_generation)
     assert_same(res, ref)
     assert (res.gpu_slices == ref.gpu_slices).all()
 

@@ -179,6 +179,27 @@ def test_bench_final_line_fits_the_driver(capsys, tmp_path, monkeypatch):
     assert json.load(open(side)) == full                                         # nothing is lost: the sidecar holds the whole record
 
 
+def test_bench_line_of_an_eight_rank_rccl_run_names_its_ranks_and_devices(capsys, tmp_path, monkeypatch):
+    """the day `bench.py --gpus 8` runs on a node, the driver's SCALE record must show `rccl_ranks: 8` and the device
+    of every rank in the PARSED line (not only in the sidecar).  emit() on a record shaped like the one rank 0 assembles at world 8."""
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r03", "r03f_bench_default.json")).read().strip().splitlines()[-1])
+    full["n_gpus"] = 8
+    full["ranks"] = {"world_size": 8, "backend": "nccl", "collective": "all_gather of one 32-byte plan record per rank and step", "all_gather_ms_per_step": 0.05,
+                     "selfcheck": {"visible_devices": 8, "distinct_devices_over_ranks": 8, "one_device_test_hook": False, "rccl_version": "2.26.6",
+                                   "devices": [f"rank {r}: local_rank {r}" for r in range(8)],
+                                   "device_list": [f"{r}:GPU-{r:02x}deadbeef" for r in range(8)]},
+                     "launched_by": "external launcher"}
+    monkeypatch.setenv("SIMON_BENCH_DETAIL", str(tmp_path / "d.json"))
+    bench.emit(full)
+    last = capsys.readouterr().out.strip().splitlines()[-1]
+    assert len(last) <= bench.LINE_BUDGET
+    rk = json.loads(last)["ranks"]
+    assert rk["rccl_ranks"] == 8 and rk["world_size"] == 8 and rk["backend"] == "nccl" and rk["distinct_devices"] == 8
+    assert len(rk["devices"]) == 8 and rk["devices"][3].startswith("3:")
+
+
 def test_bench_record_stays_the_last_stdout_line_when_a_library_prints(tmp_path):
     """RCCL prints its version banner to stdout through C stdio when a communicator comes up; through a pipe that text arrives at exit,
     AFTER bench.py's record (seen on the GPU box with a one-rank `nccl` group: profiles/r04/r06b_*).  bench.claim_stdout() keeps the real

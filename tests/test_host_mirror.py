@@ -474,6 +474,26 @@ def test_named_zero_extended_resource_with_no_other_request_is_refused():
     fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
 
 
+def test_service_list_edited_in_place_between_two_flatten_calls_is_read_afresh():
+    """Round-4 advisor finding: the (namespace, first selector pair) index of the Services was validated by list identity and length
+    only, so a selector edited IN PLACE between two flatten() calls kept serving the old index -- default spread selectors from stale
+    selectors, no error.  The index is now built once per flatten() call."""
+    from open_simulator_amd import flatten as fl, workloads as wl
+    nodes = [{"metadata": {"name": f"n{j}", "labels": {"kubernetes.io/hostname": f"n{j}"}},
+              "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "110"}}} for j in range(3)]
+    pod = wl.make_valid_pod({"kind": "Pod", "metadata": {"name": "p", "namespace": "default", "labels": {"app": "a"}},
+                             "spec": {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"cpu": "1", "memory": "1Gi"}}}]}})
+    services = [{"kind": "Service", "metadata": {"name": "s", "namespace": "default"}, "spec": {"selector": {"app": "b"}}}]
+    f1 = fl.flatten(nodes, [pod], services, [], [])
+    assert f1.problem.spread_soft_off is None or int(f1.problem.spread_soft_off[-1]) == 0        # nobody selects the pod
+    services[0]["spec"]["selector"] = {"app": "a"}                                               # same list object, same length
+    f2 = fl.flatten(nodes, [pod], services, [], [])
+    assert f2.problem.spread_soft_off is not None and int(f2.problem.spread_soft_off[-1]) == 2   # the system defaults: hostname + zone
+    services[0]["spec"]["selector"] = {"app": "b"}
+    f3 = fl.flatten(nodes, [pod], services, [], [])
+    assert f3.problem.spread_soft_off is None or int(f3.problem.spread_soft_off[-1]) == 0
+
+
 def test_term_index_finds_every_match(monkeypatch):
     """flatten tries only the terms a class can match (indexed by a matchLabels pair of their selector); SIMON_CHECK_MATCH_INDEX makes it
     compare with the classes x terms evaluation: random clusters with every selector shape randk8s draws."""
