@@ -434,6 +434,10 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config_service(n_counts=SMALL_COUNTS)
         child = ["--workload", "service", "--counts", str(SMALL_COUNTS)]
         wl, label = "config3", f"config 3 with Service-selected pods, {4 * SMALL_COUNTS} scenarios"
+    elif name == "config3_small":                   # the `simon apply` shape without Services: 64 candidate scenarios -- generation 5 as leader + refresher (two waves per scenario)
+        prob, scen, orders = synth.config3(n_counts=SMALL_COUNTS)
+        child = ["--workload", "config3", "--counts", str(SMALL_COUNTS)]
+        wl, label = "config3", f"BASELINE config 3's pool, {4 * SMALL_COUNTS} scenarios"
     elif name == "typical":                         # Kubernetes objects through the host mirror: 50 707 pods x 2 500..5 000 nodes, 64 candidate sizes
         prob, scen, orders = synth.typical_cluster_sweep()
         child = ["--workload", "typical"]
@@ -460,7 +464,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "config5_service": f"config5_service_S{c5_scen}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
+    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "config3_small": f"config3_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "config5_service": f"config5_service_S{c5_scen}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
                         "config3sig": f"config3_sigs{SIG_RECORD}", "config3sig_cliff": f"config3_sigs{SIG_CLIFF}",
                         "config3_classes": f"config3_classes{CLASS_RECORD}", "config3_classes_cliff": f"config3_classes{CLASS_CLIFF}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
@@ -474,8 +478,9 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                     "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                     "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_generation": st.kernel_generation,
                     "kernel_ms": round(k_ms, 3), "workgroup": st.workgroup_size})
-        if st.kernel_generation == 7 and st.workgroup_size > 64:   # team mode: the same batch with ONE wave per scenario, same process (SIMON_TEAM=0)
+        if st.kernel_generation in (5, 6, 7) and st.workgroup_size > 64:   # several waves per scenario (team mode of generation 7; leader + refresher of generations 5 / 6): the same batch with ONE wave per scenario, same process
             os.environ["SIMON_TEAM"] = "0"
+            os.environ["SIMON_DUO"] = "0"
             try:
                 with capi.Context(device) as ctx1:
                     ctx1.load_problem(prob)
@@ -483,6 +488,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                     _, k1 = time_steps(ctx1, max(2, steps // 2), 1, True, torch.cuda.synchronize)
             finally:
                 os.environ.pop("SIMON_TEAM", None)
+                os.environ.pop("SIMON_DUO", None)
             rec["team"] = {"waves_per_scenario": st.workgroup_size // 64, "one_wave_kernel_ms": round(k1, 3), "speedup": round(k1 / k_ms, 3)}
         if oracle_k > 0:
             pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=cpu_budget_s, min_k=min(oracle_k, len(scen)), max_k=max(oracle_k, 1))
@@ -906,10 +912,11 @@ def main():
                                                  ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
                                                  ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING),
                                                  ("service_small", sub_steps, 1, 16, 0), ("service_gpu", sub_steps, 1, 16, 0), ("config5_service", sub_steps, 1, 16, c5_scenarios(args)), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
-                                                 ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0), ("config3_classes_cliff", sub_steps, 1, 16, 0)):
+                                                 ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0), ("config3_classes_cliff", sub_steps, 1, 16, 0),
+                                                 ("config3_small", sub_steps, 1, 16, 0)):
                 try:
-                    cliff = name in ("config3sig_cliff", "config3_classes", "config3_classes_cliff", "config5_service")   # the cliff rows and config 5 behind Services: timing + parity only (no PMC passes)
-                    subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, "off" if cliff else mode, c5s,
+                    cliff = name in ("config3sig_cliff", "config3_classes", "config3_classes_cliff", "config5_service")   # the cliff rows and config 5 behind Services: a shorter CPU sample; since round 5 they carry their live-PMC roofline like every other row
+                    subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s,
                                            cpu_budget_s=3.0 if cliff else 6.0))
                     if subs[-1].get("parity_sample", {}).get("mismatches"):
                         rc = 3

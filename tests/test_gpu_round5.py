@@ -38,16 +38,16 @@ def test_config4_whole_batch_through_a_group_of_eight_members():
         s_win = plan.scenario
         n_win = int(scen[s_win, 0])
         assert n_win == plan.n_nodes
-        # sample: all 32 orders at the winning count and the three counts around it, plus 400 spread over the grid
+        # sample: all 32 orders at the winning count and the three counts around it, plus 480 spread over the grid
         counts = sorted(set(scen[:, 0].tolist()))
         ci = counts.index(n_win)
-        near = [c for c in (ci - 2, ci - 1, ci, ci + 1) if 0 <= c < len(counts)]
+        near = [c for c in (ci - 2, ci - 1, ci, ci + 1, ci + 2, ci + 3) if 0 <= c < len(counts)][:4]
         pick, by_count = set(), {}
         for s in range(len(scen)):
             by_count.setdefault(int(scen[s, 0]), []).append(s)
         for c in near:
             pick.update(by_count[counts[c]])
-        pick.update(np.linspace(0, len(scen) - 1, 400).astype(int).tolist())
+        pick.update(np.linspace(0, len(scen) - 1, 480).astype(int).tolist())
         pick.add(s_win)
         pick = np.array(sorted(pick))
         assert len(pick) >= 512 and set(scen[pick, 1].tolist()) == set(range(32))
@@ -60,3 +60,4 @@ def test_config4_whole_batch_through_a_group_of_eight_members():
         # minimality at the edge: no order fits one node count below the plan's (all 32 of them are in the oracle-checked sample)
         if ci > 0:
             assert all(int(res.unscheduled[s]) > 0 for s in by_count[counts[ci - 1]])
+
