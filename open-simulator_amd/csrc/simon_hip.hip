@@ -1873,6 +1873,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
         const bool two_groups = S >= 2 * n_cu && c->max_n <= 8192;          // 32 nodes per lane at most
         T = c->force_T ? c->force_T : (c->max_n <= 1024 || two_groups ? 256 : c->max_n <= 16384 ? 512 : 1024);
+        if (T == 128) T = 256;                                  // (SIMON_WG=128: the all-feature kernel is built for 64 / 256 / 512 / 1 024 threads since round 5)
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         int rc = wide_run(c->wide, *c, reinterpret_cast<const WideScenario*>(c->d_scen.p), nullptr, S, c->d_orders.p,
                           c->max_n, T, c->d_unsched.p, c->d_used_cpu.p, c->d_used_mem.p, c->d_used_vg.p,
@@ -2049,7 +2050,8 @@ static int explain_impl(simon_ctx* c, int n_nodes, const int32_t* order, int ran
         if (rc) return rc;
         c->wide_staged = true;
     }
-    const int T = c->force_T ? c->force_T : (n_nodes <= 512 ? 256 : n_nodes <= 4096 ? 512 : 1024);
+    int T = c->force_T ? c->force_T : (n_nodes <= 512 ? 256 : n_nodes <= 4096 ? 512 : 1024);
+    if (T == 128) T = 256;
     // with per-scenario node ranks the replay must break ties exactly like the batch did: the ranks of THAT scenario
     const int32_t *rk = nullptr, *iv = nullptr;
     if (ranked_scenario >= 0) {

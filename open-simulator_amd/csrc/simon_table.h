@@ -119,6 +119,8 @@ size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // the same for a.team == kTeamWaves (64 * team threads per scenario; SPREAD problems only): simon_table_team4.hip
 hipError_t launch_table_team4(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
+// generation 6, one wave per scenario (simon_table_rest.hip: the REST instantiations, a translation unit of their own since round 5)
+hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)
 hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

@@ -549,7 +549,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             if constexpr (kGpuFoldable) {                                 // a GPU signature starts infeasible where its request does not fit the devices
                 if (gfold && q.pad[1] != 0) b = gpu_fits_t(gu, gcnt, gtot, (unsigned)q.pad[0], q.pad[1]) ? b : 0u;
             }
-            if (HAS_MASK) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node)
+            if (HAS_MASK && static_mask != nullptr) {   // NodeUnschedulable/NodeName/TaintToleration/NodeAffinity: static per (class, node); a prologue-only test:
+                                                        // since round 5 every launch takes the HAS_MASK instantiation (half the kernels) and a null pointer says "no mask"
                 const uint64_t w = static_mask[(size_t)q.cls * sc.mask_words + (j >> 6)];
                 b = ((w >> (j & 63)) & 1ull) ? b : 0u;
             }
@@ -1933,6 +1934,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     }
 }
 
+// launch of one instantiation of the single-wave kernel (shared by this unit and simon_table_rest.hip: a template costs nothing where it is not used)
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false, bool SPREAD = false>
+static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (REST && !AFF) {
+        if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true>(a, n_blocks, lds, st);
+    }
+    if constexpr (KQ == 2 && COARSE && !REST && !MANY && !SPREAD) {   // more than 128 signatures: the instantiation with further groups
+        if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, false, true>(a, n_blocks, lds, st);
+    }
+    if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;       // simon_hip.hip keeps such batches away (two-level, no REST)
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY, SPREAD>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    return hipGetLastError();
+}
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false>
+static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, true>(a, n_blocks, lds, st)
+                               : launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, false>(a, n_blocks, lds, st);
+}
 #ifdef SIMON_TABLE_TEAM_TU
 // ---- this translation unit (simon_table_team<N>.hip) holds the team-mode instantiations only: NW = SIMON_TABLE_TEAM_TU waves per scenario ----
 constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
@@ -1961,8 +1983,8 @@ static hipError_t launch_team2(const TableLaunch& a, int n_blocks, size_t lds, h
 }
 hipError_t SIMON_TEAM_CAT(launch_table_team, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
     if (!a.spread || !a.coarse || a.rest || a.team != kTuWaves) return hipErrorInvalidValue;
-    if (has_mask) return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
-    return nzeq ? launch_team2<false, true>(a, n_blocks, lds_bytes, st) : launch_team2<false, false>(a, n_blocks, lds_bytes, st);
+    (void)has_mask;                                                   // (a run-time test of the prologue: TableCold::static_mask is null without one)
+    return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
 }
 #elif defined(SIMON_TABLE_SPREAD_TU)
 // ---- this translation unit (simon_table_spread.hip) holds generation 7: the single-wave SPREAD instantiations (80 of the largest kernels of
@@ -2002,8 +2024,21 @@ static hipError_t launch_sp2(const TableLaunch& a, int n_blocks, size_t lds, hip
 }
 hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
     if (!a.spread || !a.coarse || a.rest || a.team > 1) return hipErrorInvalidValue;
-    if (has_mask) return nzeq ? launch_sp2<true, true>(a, n_blocks, lds_bytes, st) : launch_sp2<true, false>(a, n_blocks, lds_bytes, st);
-    return nzeq ? launch_sp2<false, true>(a, n_blocks, lds_bytes, st) : launch_sp2<false, false>(a, n_blocks, lds_bytes, st);
+    (void)has_mask;
+    return nzeq ? launch_sp2<true, true>(a, n_blocks, lds_bytes, st) : launch_sp2<true, false>(a, n_blocks, lds_bytes, st);
+}
+#elif defined(SIMON_TABLE_REST_TU)
+// ---- this translation unit (simon_table_rest.hip) holds generation 6: the REST instantiations (position masks: Open-Gpu-Share devices,
+// required (anti-)affinity, host ports, ephemeral storage / extended resources) -- the 32 largest kernels of the single-wave family ----
+template <bool Z, int KQ>
+static hipError_t launch_rest2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.ni_max / 64 <= 64 ? launch_t6<true, Z, true, KQ, 1, true, true>(a, n_blocks, lds, st)
+                                  : launch_t6<true, Z, true, KQ, 2, true, true>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.rest || !a.coarse || a.spread || a.team > 1) return hipErrorInvalidValue;
+    if (a.sc.K > 64) return nzeq ? launch_rest2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rest2<false, 2>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_rest2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rest2<false, 1>(a, n_blocks, lds_bytes, st);
 }
 #else
 // placement[s][pod] = place_step[s][inv_order[order_id(s)][pod]]: gather (scattered reads hit L2, stores coalesced)
@@ -2028,32 +2063,10 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
     return hipGetLastError();
 }
 
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false, bool SPREAD = false>
-static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if constexpr (REST && !AFF) {
-        if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true>(a, n_blocks, lds, st);
-    }
-    if constexpr (KQ == 2 && COARSE && !REST && !MANY && !SPREAD) {   // more than 128 signatures: the instantiation with further groups
-        if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, false, true>(a, n_blocks, lds, st);
-    }
-    if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;       // simon_hip.hip keeps such batches away (two-level, no REST)
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY, SPREAD>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
-    return hipGetLastError();
-}
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false>
-static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, true>(a, n_blocks, lds, st)
-                               : launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, false>(a, n_blocks, lds, st);
-}
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if constexpr (PIN) {                                              // REST rides on the instantiation that knows pinned pods
-        if (a.rest)
-            return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true, true>(a, n_blocks, lds, st)
-                                          : launch_t6<M, Z, PIN, KQ, 2, true, true>(a, n_blocks, lds, st);
+    if constexpr (PIN) {                                              // REST rides on the instantiation that knows pinned pods: simon_table_rest.hip
+        if (a.rest) return launch_table_rest(a, n_blocks, Z, lds, st);
     }
     if (a.spread) return hipErrorInvalidValue;                        // (generation 7 lives in simon_table_spread.hip: launch_table_spread)
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
@@ -2081,8 +2094,8 @@ hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool 
         return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
     if (a.spread) return launch_table_spread(a, n_blocks, has_mask, nzeq, lds_bytes, st);   // generation 7: simon_table_spread.hip
     has_pin = has_pin || a.rest || (a.sc.static_tables & (32 | 128));   // (& 32, & 128: the folds, carried by COARSE && !REST && HAS_PIN)
-    if (has_mask) return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
-    return nzeq ? launch_t2<false, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<false, false>(a, n_blocks, has_pin, lds_bytes, st);
+    (void)has_mask;                                                   // (HAS_MASK is a prologue-only, run-time test since round 5: one instantiation serves both)
+    return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);
 }
 #endif  // SIMON_TABLE_TEAM_TU
 

@@ -248,6 +248,10 @@ struct WideDevice {
 };
 
 // staging / launching (simon_wide.hip)
+// launches of the instantiations that live outside simon_wide.hip (simon_wide_local.hip: the Open-Local variant; simon_wide_explain.hip:
+// the EXPLAIN form of the full variant); T in {64, 256, 512, 1024}
+hipError_t wide_launch_local(const WideArgs& a, int T, bool explain, size_t lds, hipStream_t st);
+hipError_t wide_launch_explain(const WideArgs& a, int T, size_t lds, hipStream_t st);
 int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string& err);
 int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, const int32_t* h_perm_unused, int S,
              const int32_t* d_orders, int max_n, int T, int32_t* d_unsched, int64_t* d_used_cpu, int64_t* d_used_mem,

@@ -1567,42 +1567,46 @@ static size_t wide_lds_bytes(const WideArgs& a, int T) {
     return lds;
 }
 
-template <bool EXPLAIN>
-hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
-    dim3 grid(a.S);
-    const size_t lds = wide_lds_bytes(a, T);
-    (void)max_n;
+// Launch of one instantiation.  The 20 instantiations (workgroup size x EXPLAIN x variant) live in three translation units since round 5
+// -- this one (lean / full, the scenario kernels), simon_wide_local.hip (the Open-Local variant, both EXPLAIN forms) and
+// simon_wide_explain.hip (the full variant's EXPLAIN form) -- because build() runs one hipcc process per unit and this file alone took
+// 4.6 minutes.  A workgroup of 128 threads runs as 256 (wide_workgroup: the shape is a tuning knob, never visible in a result).
+template <int TT, bool EXPLAIN, int VAR>
+static hipError_t launch_one(const WideArgs& a, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024) {                                                 // beyond the default dynamic-LDS limit: raise it for the instantiation that runs
-        hipError_t e = hipSuccess;
-#define WIDE_ATTR(TT)                                                                                                            \
-        if (a.flags & kArgLocal) e = hipFuncSetAttribute((const void*)wide_kernel<TT, EXPLAIN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-        else if (!EXPLAIN && (a.flags & kArgLean) && !(a.flags & kArgRanked)) e = hipFuncSetAttribute((const void*)wide_kernel<TT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        else e = hipFuncSetAttribute((const void*)wide_kernel<TT, EXPLAIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-        switch (T) {
-            case 64: WIDE_ATTR(64); break;
-            case 128: WIDE_ATTR(128); break;
-            case 256: WIDE_ATTR(256); break;
-            case 512: WIDE_ATTR(512); break;
-            case 1024: WIDE_ATTR(1024); break;
-            default: return hipErrorInvalidValue;
-        }
-#undef WIDE_ATTR
+        hipError_t e = hipFuncSetAttribute((const void*)wide_kernel<TT, EXPLAIN, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-#define WIDE_LAUNCH(TT)                                                                                   \
-    if (a.flags & kArgLocal) hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 2>), grid, dim3(TT), lds, st, a);    \
-    else if (!EXPLAIN && (a.flags & kArgLean) && !(a.flags & kArgRanked)) hipLaunchKernelGGL((wide_kernel<TT, false, 0>), grid, dim3(TT), lds, st, a); \
-    else hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, 1>), grid, dim3(TT), lds, st, a)
+    hipLaunchKernelGGL((wide_kernel<TT, EXPLAIN, VAR>), dim3(a.S), dim3(TT), lds, st, a);
+    return hipGetLastError();
+}
+template <bool EXPLAIN, int VAR>
+static hipError_t launch_sized(const WideArgs& a, int T, size_t lds, hipStream_t st) {
     switch (T) {
-        case 64: WIDE_LAUNCH(64); break;
-        case 128: WIDE_LAUNCH(128); break;
-        case 256: WIDE_LAUNCH(256); break;
-        case 512: WIDE_LAUNCH(512); break;
-        case 1024: WIDE_LAUNCH(1024); break;
+        case 64: return launch_one<64, EXPLAIN, VAR>(a, lds, st);
+        case 256: return launch_one<256, EXPLAIN, VAR>(a, lds, st);
+        case 512: return launch_one<512, EXPLAIN, VAR>(a, lds, st);
+        case 1024: return launch_one<1024, EXPLAIN, VAR>(a, lds, st);
         default: return hipErrorInvalidValue;
     }
-#undef WIDE_LAUNCH
-    return hipGetLastError();
+}
+}  // namespace
+#if defined(SIMON_WIDE_LOCAL_TU)
+hipError_t wide_launch_local(const WideArgs& a, int T, bool explain, size_t lds, hipStream_t st) {
+    return explain ? launch_sized<true, 2>(a, T, lds, st) : launch_sized<false, 2>(a, T, lds, st);
+}
+#elif defined(SIMON_WIDE_EXPLAIN_TU)
+hipError_t wide_launch_explain(const WideArgs& a, int T, size_t lds, hipStream_t st) { return launch_sized<true, 1>(a, T, lds, st); }
+#else
+namespace {
+template <bool EXPLAIN>
+hipError_t launch(const WideArgs& a, int T, int max_n, hipStream_t st) {
+    const size_t lds = wide_lds_bytes(a, T);
+    (void)max_n;
+    if (a.flags & kArgLocal) return wide_launch_local(a, T, EXPLAIN, lds, st);
+    if (!EXPLAIN && (a.flags & kArgLean) && !(a.flags & kArgRanked)) return launch_sized<false, 0>(a, T, lds, st);
+    if (EXPLAIN) return wide_launch_explain(a, T, lds, st);
+    return launch_sized<false, 1>(a, T, lds, st);
 }
 
 template <class T>
@@ -2066,4 +2070,5 @@ int wide_explain(WideDevice& w, const HostInputs& in, int n_nodes, const int32_t
     return nf;
 }
 
+#endif  // SIMON_WIDE_LOCAL_TU / SIMON_WIDE_EXPLAIN_TU
 }  // namespace simon

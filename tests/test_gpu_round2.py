@@ -307,7 +307,7 @@ def test_bench_line_is_self_verifying():
     assert e2e["batch_ms"] > e2e["kernel_ms"] > 0 and e2e["load_problem_ms"] > 0 and e2e["scenarios"] == d["config"]["scenarios_per_gpu"]
     names = [w["workload"] for w in d["other_workloads"]]
     assert names == ["config2", "config3_sigs200", "config3_service", "config3_service_anti20", "config3_service_pref60", "config5_S16", "config5_S2048",
-                     "config3_service_S64", "config3_service_gpu20_S256", "config5_service_S16", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160"]
+                     "config3_service_S64", "config3_service_gpu20_S256", "config5_service_S16", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160", "config3_S64"]
     for w in d["other_workloads"]:
         assert "error" not in w, w
         assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
@@ -331,6 +331,7 @@ def test_bench_line_is_self_verifying():
     assert d["other_workloads"][3]["kernel_generation"] == 7 and d["other_workloads"][3]["scenarios"] == 4096
     assert d["other_workloads"][4]["kernel_generation"] == 7 and d["other_workloads"][4]["scenarios"] == 4096
     assert d["other_workloads"][5]["kernel_generation"] == 6 and d["other_workloads"][6]["scenarios"] == 2048
+    assert d["other_workloads"][15]["kernel_generation"] in (4, 5) and d["other_workloads"][15]["scenarios"] == 64      # BASELINE config 3's pool at the batch a `simon apply` offers
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     for w in d["other_workloads"]:
         assert w["steps"] >= 5, w["workload"]                     # every sub-record times at least five steps

@@ -486,7 +486,7 @@ def test_gpu_fold_keeps_its_gcd_when_the_position_mask_probe_says_no():
     prob = randprob.rand_problem(13377, N=400, P=2500, n_node_classes=3, n_pod_classes=60, gpu=True)
     Mi = 1 << 20
     idx = np.arange(prob.n_pods)
-    prob.gpu_mem = np.where(prob.gpu_mem > 0, (1 + idx % 40) * 256 * Mi, 0).astype(np.int64)      # 256 Mi ... 10 Gi in 40 steps
+    prob.gpu_mem = np.where((prob.gpu_mem > 0) & (prob.pod_class < 20), (1 + idx % 40) * 256 * Mi, 0).astype(np.int64)      # 256 Mi ... 10 Gi in 40 steps, on 20 of the 60 classes (<= 1 023 signatures in all)
     prob.pod_gpu_cnt = np.where(prob.gpu_mem > 0, 1, 0).astype(np.int32)
     prob.normalise()
     n_req = len(set(zip(prob.gpu_mem[prob.gpu_mem > 0].tolist(), prob.pod_gpu_cnt[prob.gpu_mem > 0].tolist())))
