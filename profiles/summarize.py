@@ -52,8 +52,10 @@ def derived(root):
         if "SQ_INSTS_VALU" in c:
             print(f"      VALU issue: {c['SQ_INSTS_VALU']:.4g} wave-instructions / {t * 1e3:.3f} ms = {c['SQ_INSTS_VALU'] / t / 1e9:.1f} G/s = {c['SQ_INSTS_VALU'] / t / 1228.8e9:.4f} of the 1 228.8 G/s peak"
                   + (f"; SALU {c['SQ_INSTS_SALU']:.4g}" if "SQ_INSTS_SALU" in c else ""))
-        if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
-            print(f"      VALU pipe busy: SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CYCLES) = {c['SQ_ACTIVE_INST_VALU'] / (4 * c['SQ_BUSY_CYCLES']):.3f}")
+        if "SQ_ACTIVE_INST_VALU" in c:
+            # quad-cycles in which a wave has a VALU instruction executing, summed over the SIMDs (bench.py: valu_pipe_busy_frac)
+            print(f"      VALU pipe busy: SQ_ACTIVE_INST_VALU x 4 / (1 024 SIMDs x {t * 1e3:.3f} ms x 2.4 GHz) = {c['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * t * 2.4e9):.3f}"
+                  + (f"; {c['SQ_ACTIVE_INST_VALU'] * 4 / c['SQ_INSTS_VALU']:.2f} cycles per VALU instruction" if c.get("SQ_INSTS_VALU") else ""))
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             gb = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / 1e9
             print(f"      HBM traffic: 2 x FETCH_SIZE {2 * c['FETCH_SIZE'] * 1024 / 1e9:.3f} GB + WRITE_SIZE {c['WRITE_SIZE'] * 1024 / 1e9:.3f} GB = {gb:.3f} GB -> {gb / t / 1e3:.3f} TB/s = {gb / t / 8e3:.4f} of 8 TB/s")
