@@ -490,6 +490,17 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                 os.environ.pop("SIMON_TEAM", None)
                 os.environ.pop("SIMON_DUO", None)
             rec["team"] = {"waves_per_scenario": st.workgroup_size // 64, "one_wave_kernel_ms": round(k1, 3), "speedup": round(k1 / k_ms, 3)}
+        if name in ("config2", "config3_small") and st.kernel_generation == 4:   # small batch of a small problem: the scenario's workspace lives in LDS (round 5) -- the same batch with the workspace in HBM, same process
+            os.environ["SIMON_LDS_WS"] = "0"
+            try:
+                with capi.Context(device) as ctx1:
+                    ctx1.load_problem(prob)
+                    ctx1.load_scenarios(scen, orders)
+                    _, k1 = time_steps(ctx1, max(2, steps // 2), 1, True, torch.cuda.synchronize)
+                    lds0 = ctx1.stats().lds_bytes
+            finally:
+                os.environ.pop("SIMON_LDS_WS", None)
+            rec["lds_workspace"] = {"lds_bytes": st.lds_bytes, "in_lds": st.lds_bytes > lds0, "workspace_in_hbm_kernel_ms": round(k1, 3), "speedup": round(k1 / k_ms, 3)}
         if oracle_k > 0:
             pick, refs, tm = oracle_sample(prob, scen, orders, budget_s=cpu_budget_s, min_k=min(oracle_k, len(scen)), max_k=max(oracle_k, 1))
             rec["cpu_baseline"] = cpu_baseline_record(tm, len(scen), label)
@@ -512,7 +523,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
 # ---------------------------------------------------------------------------------------------------------------
 # Output: full record -> sidecar + `#detail` lines; compact record (<= LINE_BUDGET bytes) -> the LAST stdout line
 # ---------------------------------------------------------------------------------------------------------------
-LINE_BUDGET = 3000                # bytes of the final JSON line (the driver keeps ~8 KB of the stdout tail)
+LINE_BUDGET = 3072                # bytes of the final JSON line (the driver keeps ~8 KB of the stdout tail)
 
 
 def _short_roofline(r):
@@ -535,7 +546,7 @@ def _digest_row(w):
     if "error" in w:
         return [w.get("workload"), None, None, None, None, None, None, None, None, "error: " + str(w["error"])[:60]]
     return [w.get("workload"), w.get("value"), w.get("kernel_ms"), w.get("kernel_generation"), r.get("frac"), r.get("measured_hbm_frac"),
-            (w.get("cpu_baseline") or {}).get("value"), (w.get("team") or {}).get("speedup"), (w.get("parity_sample") or {}).get("scenarios"),
+            (w.get("cpu_baseline") or {}).get("value"), (w.get("team") or w.get("lds_workspace") or {}).get("speedup"), (w.get("parity_sample") or {}).get("scenarios"),
             (w.get("parity_sample") or {}).get("mismatches")]
 
 

@@ -146,6 +146,7 @@ struct simon_ctx : simon::HostInputs {
     // unset: batches of at most team_max_s scenarios (default 2 per CU: beyond that one wave per scenario fills the SIMDs by
     // itself -- measured crossover between 512 and 1 024 scenarios, profiles/r04; env SIMON_TEAM_MAX_S)
     int team_mode = -1, team_max_s = -1;
+    int ldsws_mode = -1;                         // env SIMON_LDS_WS = 0 never / 1 whenever it fits / unset: batches of at most one scenario per CU (simon_table.hip: LDSWS)
     std::vector<int> sp_kind, sp_row, sp_zslot;  // per term: 0 unused / 1 hostname-like / 2 zone-like; its counter row; zone key slot
     std::vector<int> sp_set_eff;                  // per id: the node set its row is counted on (-1: every node)
     std::vector<int> sp_rep;                      // per term: the first term with the same key, node set and matching classes (they share a counter row)
@@ -1317,6 +1318,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     if (const char* e = getenv("SIMON_TEAM")) { const int v = atoi(e); c->team_mode = v == 0 ? 0 : (v == 1 || v == kTeamWaves) ? 1 : -1; }
     if (const char* e = getenv("SIMON_TEAM_MAX_S")) c->team_max_s = atoi(e);
+    if (const char* e = getenv("SIMON_LDS_WS")) c->ldsws_mode = atoi(e) ? 1 : 0;
     c->no_gpu_split = getenv("SIMON_TABLE_NO_GPU_SPLIT") != nullptr;
     c->no_class_content = getenv("SIMON_TABLE_NO_CLASS_CONTENT") != nullptr;
     c->no_gpu_fold = getenv("SIMON_NO_GPU_FOLD") != nullptr;
@@ -1755,9 +1757,23 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0)) : -1) + c->lds_pad : 0;
         };
         if (team > 1 && lds_for(team) > kTableLdsMaxWG) team = 1;           // (its extra table does not fit: the single-wave shape still may)
-        const size_t table_lds = lds_for(team);
+        size_t table_lds = lds_for(team);
+        // Generation 4 with the scenario's workspace in LDS (round 5; simon_table.hip: LDSWS): a batch of at most one scenario per CU -- what
+        // a real Applier.Run offers -- of a problem whose byte table + node state fit the CU's LDS next to the summaries.  The one memory
+        // round trip of a scheduling cycle becomes an LDS access.
+        bool lds_ws = false;
+        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && !c->has_ranks && c->n_sigs <= 128 && team == 1 &&
+            c->ldsws_mode != 0) {
+            size_t ws_max = 0;
+            for (int s2 = 0; s2 < S; ++s2) ws_max = std::max(ws_max, table_ws_bytes(c->n_sigs, c->scen_ni[s2], c->nzeq, false, c->Cn_t, 0, 0, 0, 0));
+            const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + ws_max + c->lds_pad;   // (the kernel puts the workspace at the next 128-byte boundary behind tcarve's total)
+            // ... when the whole batch is resident at once all the same: ceil(S / CUs) workgroups of `need` bytes (allocation granularity 1 280 B) per CU
+            const size_t per_cu = (size_t)(S + c->n_cus - 1) / (size_t)std::max(c->n_cus, 1);
+            const bool resident = per_cu * ((need + 1279) / 1280 * 1280) <= kTableLdsPerCU && per_cu <= 32;
+            if (need <= kTableLdsMaxWG && (c->ldsws_mode > 0 || resident)) { lds_ws = true; table_lds = need; }
+        }
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
-                               ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= (c->table_coarse ? kTableLdsMaxWG : (size_t)64 * 1024);
+                               ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= ((c->table_coarse || lds_ws) ? kTableLdsMaxWG : (size_t)64 * 1024);
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         if (c->debug_route)
             fprintf(stderr, "[route] variant %d rest %d spread %d fold %d gfold %d table_ok %d perm_ok %d coarse %d n_sigs %d Cn_t %d ni_top %d lds %zu max_n %d\n", c->variant, (int)c->rest,
@@ -1801,7 +1817,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty(); f.team = team;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty(); f.team = team; f.lds_ws = lds_ws;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && (c->ipa_fold || c->hard_fold)) ? 64 : 0) | (c->gfold ? 128 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

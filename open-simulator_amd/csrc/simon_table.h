@@ -87,6 +87,7 @@ struct TableLaunch {
     bool aff;            // some pod class carries required-affinity entries (REST)
     bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
     bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
+    bool lds_ws;         // generation 4 with the scenario's workspace in LDS (table_kernel: LDSWS; small batches of small problems): the dynamic LDS of the launch = summaries + the largest workspace
     TableScalars sc;
 };
 
@@ -119,6 +120,8 @@ size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int 
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
 // the same for a.team == kTeamWaves (64 * team threads per scenario; SPREAD problems only): simon_table_team4.hip
 hipError_t launch_table_team4(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
+// generation 4 with the workspace in LDS (simon_table_lds.hip; lds_bytes = table_lds_bytes(...) rounded up to 128 + the largest table_ws_bytes of the batch)
+hipError_t launch_table_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 // generation 6, one wave per scenario (simon_table_rest.hip: the REST instantiations, a translation unit of their own since round 5)
 hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)

@@ -314,7 +314,12 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // contiguous share of the units each, and the extremes of pass 1 and the best key of pass 2 are combined through LDS (three
 // s_barriers per spread pod).  The waves of one workgroup share the CU's vector L1 (no tgsplit), so the leader's stores are
 // visible to the helpers after the barrier's s_waitcnt without cache maintenance.  The prologue (K x n table) is split the same way.
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1>
+// LDSWS (round 5): the scenario's WORKSPACE -- byte table, node state -- lives in LDS behind the summaries instead of in HBM.  For the
+// batches a real Applier.Run offers (a handful of sizes: at most one scenario per CU, so the CU's 160 KB are this scenario's) on problems
+// whose table fits (config 3's pool: 1 600 positions x 42 signatures = 86 KB; config 2: 12 KB) the one memory round trip of a scheduling
+// cycle -- the winner's table rows and state from L2 -- becomes an LDS access.  Same code: the pointers are derived from the LDS base in
+// this instantiation, the compiler addresses them as LDS.  Generation 4 only (one-level summary, no REST / SPREAD / folds / ranks).
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1, bool LDSWS = false>
 #ifndef SIMON_SPREAD_WAVES
 #define SIMON_SPREAD_WAVES 4
 #endif
@@ -400,7 +405,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     constexpr bool ranked = RANKED;
     const unsigned rk_off = RANKED ? (unsigned)s * (unsigned)sc.rk_stride : 0u;
     const int32_t* __restrict__ const cls_list = cls_list_pool;
-    unsigned char* const wsb = ws + ws_off[blockIdx.x];
+    static_assert(!LDSWS || (!COARSE && !REST && !SPREAD && !MANY && !RANKED && NW == 1), "the LDS-resident workspace serves generation 4");
+    unsigned char* const wsb = LDSWS ? smem + ((cv.total + 127) & ~127) : ws + ws_off[blockIdx.x];
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
@@ -2027,6 +2033,27 @@ hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask
     (void)has_mask;
     return nzeq ? launch_sp2<true, true>(a, n_blocks, lds_bytes, st) : launch_sp2<true, false>(a, n_blocks, lds_bytes, st);
 }
+#elif defined(SIMON_TABLE_LDS_TU)
+// ---- this translation unit (simon_table_lds.hip) holds generation 4 with the scenario's workspace in LDS (LDSWS): small batches of small problems ----
+template <bool Z, int KQ, int NBQ>
+static hipError_t launch_lds3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, false, false, false, false, false, false, 1, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    return hipGetLastError();
+}
+template <bool Z, int KQ>
+static hipError_t launch_lds2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    const int nblk = a.sc.ni_max / 16;
+    return nblk <= 64 ? launch_lds3<Z, KQ, 1>(a, n_blocks, lds, st) : nblk <= 128 ? launch_lds3<Z, KQ, 2>(a, n_blocks, lds, st) : launch_lds3<Z, KQ, 4>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.lds_ws || a.coarse || a.rest || a.spread || a.team > 1 || a.sc.rk_stride != 0 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
+    if (a.sc.K > 64) return nzeq ? launch_lds2<true, 2>(a, n_blocks, lds_bytes, st) : launch_lds2<false, 2>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_lds2<true, 1>(a, n_blocks, lds_bytes, st) : launch_lds2<false, 1>(a, n_blocks, lds_bytes, st);
+}
 #elif defined(SIMON_TABLE_REST_TU)
 // ---- this translation unit (simon_table_rest.hip) holds generation 6: the REST instantiations (position masks: Open-Gpu-Share devices,
 // required (anti-)affinity, host ports, ephemeral storage / extended resources) -- the 32 largest kernels of the single-wave family ----
@@ -2093,6 +2120,7 @@ hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool 
     if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
         return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
     if (a.spread) return launch_table_spread(a, n_blocks, has_mask, nzeq, lds_bytes, st);   // generation 7: simon_table_spread.hip
+    if (a.lds_ws) return launch_table_lds(a, n_blocks, nzeq, lds_bytes, st);                // generation 4, workspace in LDS: simon_table_lds.hip
     has_pin = has_pin || a.rest || (a.sc.static_tables & (32 | 128));   // (& 32, & 128: the folds, carried by COARSE && !REST && HAS_PIN)
     (void)has_mask;                                                   // (HAS_MASK is a prologue-only, run-time test since round 5: one instantiation serves both)
     return nzeq ? launch_t2<true, true>(a, n_blocks, has_pin, lds_bytes, st) : launch_t2<true, false>(a, n_blocks, has_pin, lds_bytes, st);

@@ -28,3 +28,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _alternate_the_home_of_the_workspace(request, monkeypatch):
+    """Round 5: a batch of at most one scenario per CU whose byte table + node state fit the CU's LDS runs generation 4 with its workspace
+    in LDS (simon_table.hip: LDSWS) -- which is what most cpu+memory parity tests offer.  The workspace in HBM is what the 4 096-scenario
+    benchmark runs, so the suite keeps exercising BOTH: tests alternate by a stable hash of their id (even: SIMON_LDS_WS=0; odd: the
+    library's own choice).  A test that sets SIMON_LDS_WS itself (tests/test_gpu_round5.py runs both on the same problems) overrides this;
+    the library reads the variable once per context."""
+    if "gpu" not in request.keywords or os.environ.get("SIMON_LDS_WS") is not None:
+        yield
+        return
+    import zlib
+    if zlib.crc32(request.node.nodeid.encode()) % 2 == 0:
+        monkeypatch.setenv("SIMON_LDS_WS", "0")
+    yield

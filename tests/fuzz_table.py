@@ -59,13 +59,18 @@ def one_case(case, coarse=None):
             ranks[s, :n] = rng.permutation(n)
     ref = O.run_threaded(prob, scen, orders) if ranks is None else O.run(prob, scen, orders, node_ranks=ranks)
     saved = os.environ.get("SIMON_TABLE_COARSE")
+    saved_ws = os.environ.get("SIMON_LDS_WS")
     if saved is None:
         os.environ["SIMON_TABLE_COARSE"] = "1" if coarse else "0"      # read once, when the context is created
+    if saved_ws is None and (case // 3) % 2 == 1:
+        os.environ["SIMON_LDS_WS"] = "0"                               # round 5: every other case keeps the workspace in HBM (the others: in LDS where it fits)
     try:
         ctx = capi.Context(0)
     finally:
         if saved is None:
             del os.environ["SIMON_TABLE_COARSE"]
+        if saved_ws is None:
+            os.environ.pop("SIMON_LDS_WS", None)
     with ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)

@@ -61,3 +61,73 @@ def test_config4_whole_batch_through_a_group_of_eight_members():
         if ci > 0:
             assert all(int(res.unscheduled[s]) > 0 for s in by_count[counts[ci - 1]])
 
+
+
+# ---- generation 4 with the scenario's workspace in LDS (small batches of small problems) -------------------------------------------------
+import randprob
+from test_gpu_parity import NARROW_FEATURES, assert_same
+
+WS_HOMES = ("0", "1")                            # SIMON_LDS_WS: the workspace in HBM / in LDS whenever it fits
+
+
+def run_ws(prob, scen, orders, home, monkeypatch):
+    monkeypatch.setenv("SIMON_LDS_WS", home)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        return ctx.fetch(True), ctx.stats()
+
+
+@pytest.mark.parametrize("idx", range(len(NARROW_FEATURES)))
+def test_workspace_in_lds_matches_the_oracle(idx, monkeypatch):
+    """Every cpu+memory feature set of the parity suite with the scenario's workspace (byte table, node state, NonZero rows) in HBM and in
+    LDS, against the oracle: static masks, presets, gates, pinned pods, initial state, NonZero != request, zero requests, tight pod
+    counts, gcd-1 units.  Sizes: 1 / 2 / 4 summary entries per lane, <= 64 and > 64 signatures; the last one does not fit 159 KB and must
+    run from HBM whatever the variable says."""
+    feat = NARROW_FEATURES[idx]
+    used_lds = 0
+    for seed in range(4):
+        N = [29, 700, 1800, 3900][seed]
+        prob = randprob.rand_problem(53000 + 100 * idx + seed, N=N, P=400 + 250 * seed, n_pod_classes=[5, 30, 70, 60][seed], n_node_classes=2 + seed, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=5, min_n=1 if seed == 0 else None)
+        ref = O.run_threaded(prob, scen, orders)
+        lds = {}
+        for home in WS_HOMES:
+            res, st = run_ws(prob, scen, orders, home, monkeypatch)
+            assert_same(res, ref)
+            lds[home] = (st.kernel_variant, st.kernel_generation, st.lds_bytes)
+        if lds["0"][0] == capi.KERNEL_NARROW_CACHE and lds["0"][1] == 4 and lds["1"][2] > lds["0"][2]:
+            used_lds += 1
+            assert lds["1"][1] == 4 and lds["1"][2] <= 159 * 1024
+    if not set(feat) & {"odd_units", "nz_differs"}:                       # (those may leave the score table or its one-level layout)
+        assert used_lds >= 2, (feat, used_lds)
+
+
+def test_the_library_puts_the_workspace_in_lds_for_resident_batches_only(monkeypatch):
+    """A batch whose workgroups are all resident at once with table + state + summaries in LDS (64 scenarios of a 1 000-node pool: one per
+    CU, 63 KB each): LDS.  800 scenarios of the same pool (four per CU would need 250 KB): HBM, as the 4 096-scenario benchmark.
+    SIMON_LDS_WS=0 / 1 force either.  Same placements everywhere."""
+    monkeypatch.delenv("SIMON_LDS_WS", raising=False)
+    prob, scen, orders = synth.config3(n_counts=200, n_orders=4, n_pods=400, n_het=900)
+    assert len(scen) == 800
+    ref = O.run_threaded(prob, scen, orders)
+    seen = {}
+    for n_scen in (64, 800):
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen[:n_scen], orders)
+            seen[n_scen] = ctx.stats().lds_bytes
+        assert (res.placement == ref.placement[:n_scen]).all() and res.unscheduled.tolist() == ref.unscheduled[:n_scen].tolist()
+    assert seen[64] > 40 * 1024 > seen[800] > 0, seen
+
+
+def test_config3_sixty_four_scenarios_with_the_workspace_in_lds(monkeypatch):
+    """BASELINE config 3's pool at the batch a real `simon apply` offers (16 node counts x 4 orders = 64 scenarios, 10 000 pods each) and
+    BASELINE config 2 (one scenario): both homes of the workspace against the oracle, every placement."""
+    for prob, scen, orders in (synth.config3(n_counts=16), synth.config2()):
+        ref = O.run_threaded(prob, scen, orders)
+        for home in WS_HOMES:
+            res, st = run_ws(prob, scen, orders, home, monkeypatch)
+            assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4
+            assert_same(res, ref)
