@@ -1772,6 +1772,14 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             const bool resident = per_cu * ((need + 1279) / 1280 * 1280) <= kTableLdsPerCU && per_cu <= 32;
             if (need <= kTableLdsMaxWG && (c->ldsws_mode > 0 || resident)) { lds_ws = true; table_lds = need; }
         }
+        // Generation 6 with its mask rows, row totals and canonical indices in LDS (round 5; simon_table.hip: LDSX), under the same residency rule
+        bool lds_x = false;
+        if (c->table_ok && c->table_coarse && c->rest && !c->spread && !c->has_ranks && team == 1 && c->ldsws_mode != 0) {
+            const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + table_ldsx_bytes(ni_top, c->rest_M) + c->lds_pad;
+            const size_t per_cu = (size_t)(S + c->n_cus - 1) / (size_t)std::max(c->n_cus, 1);
+            const bool resident = per_cu * ((need + 1279) / 1280 * 1280) <= kTableLdsPerCU && per_cu <= 32;
+            if (need <= kTableLdsMaxWG && (c->ldsws_mode > 0 || resident)) { lds_x = true; table_lds = need; }
+        }
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= ((c->table_coarse || lds_ws) ? kTableLdsMaxWG : (size_t)64 * 1024);
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
@@ -1817,7 +1825,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             TableLaunch f{};
             f.cold = reinterpret_cast<const TableCold*>(c->d_table_cold.p);
             f.cls_list = c->has_ranks ? c->d_rk_ids.p : c->d_cls_list.p; f.pods = c->d_podsC.p; f.orders = c->d_orders.p; f.perm = c->d_perm.p;
-            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty(); f.team = team; f.lds_ws = lds_ws;
+            f.ws_off = c->d_ws_off.p; f.ws = c->d_ws.p; f.coarse = c->table_coarse; f.rest = c->rest; f.spread = c->spread; f.aff = c->rest && !c->aff_idx.empty(); f.team = team; f.lds_ws = lds_ws; f.lds_x = lds_x;
             f.place_step = want_placement ? c->d_place_step.p : nullptr;
             f.sc = TableScalars{(c->N + 63) / 64, c->Cn_t, c->Cp, P, S, c->n_sigs, c->has_ranks ? c->N : 0, (c->has_na ? 1 : 0) | (c->has_tt ? 2 : 0) | (c->has_add ? 4 : 0) | (want_slices ? 8 : 0) | (c->sig_twins ? 16 : 0) | (c->fold ? 32 : 0) | ((c->spread && (c->ipa_fold || c->hard_fold)) ? 64 : 0) | (c->gfold ? 128 : 0), c->rest ? (int)c->zone_keys.size() : 0, c->rest ? c->rest_M : 0, c->rest ? c->rest_G : 0, c->rest ? c->rest_X : 0, c->spread ? c->sp_TH : 0, c->spread ? c->sp_TZ : 0, c->spread ? (int)c->sp_zkeys.size() : 0, ni_top, c->g_cpu, c->g_mem};
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

@@ -87,6 +87,7 @@ struct TableLaunch {
     bool aff;            // some pod class carries required-affinity entries (REST)
     bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
     bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
+    bool lds_x;          // generation 6 with its mask rows, row totals and the canonical index of every position in LDS (table_kernel: LDSX; batches resident at once)
     bool lds_ws;         // generation 4 with the scenario's workspace in LDS (table_kernel: LDSWS; small batches of small problems): the dynamic LDS of the launch = summaries + the largest workspace
     TableScalars sc;
 };
@@ -122,6 +123,11 @@ hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool 
 hipError_t launch_table_team4(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
 // generation 4 with the workspace in LDS (simon_table_lds.hip; lds_bytes = table_lds_bytes(...) rounded up to 128 + the largest table_ws_bytes of the batch)
 hipError_t launch_table_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
+// generation 6 with the mask rows in LDS (simon_table_restlds.hip; lds_bytes = table_lds_bytes(...) rounded up to 128 + table_ldsx_bytes(...))
+hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
+inline size_t table_ldsx_bytes(int ni_max, int M) {   // rows [M][ni_max / 16] u16, row totals [M] u32, canonical indices [ni_max] u16 (each rounded up to 128 bytes)
+    return ((((size_t)(ni_max >> 4) * M * 2) + 127) & ~(size_t)127) + (((size_t)M * 4 + 127) & ~(size_t)127) + (((size_t)ni_max * 2 + 127) & ~(size_t)127);
+}
 // generation 6, one wave per scenario (simon_table_rest.hip: the REST instantiations, a translation unit of their own since round 5)
 hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)

@@ -319,7 +319,10 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // whose table fits (config 3's pool: 1 600 positions x 42 signatures = 86 KB; config 2: 12 KB) the one memory round trip of a scheduling
 // cycle -- the winner's table rows and state from L2 -- becomes an LDS access.  Same code: the pointers are derived from the LDS base in
 // this instantiation, the compiler addresses them as LDS.  Generation 4 only (one-level summary, no REST / SPREAD / folds / ranks).
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1, bool LDSWS = false>
+// LDSX (round 5): generation 6's position-mask rows (g_xm), their totals and the canonical index of every position live in LDS -- the
+// same idea for the batches of a gpushare sweep (config 5 x 256: one scenario per CU, 71 KB of rows): the REST select's filter words and
+// the canonical tie-break of the device / device-less twin classes (every other cycle of config 5) stop being memory round trips.
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1, bool LDSWS = false, bool LDSX = false>
 #ifndef SIMON_SPREAD_WAVES
 #define SIMON_SPREAD_WAVES 4
 #endif
@@ -406,6 +409,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     const unsigned rk_off = RANKED ? (unsigned)s * (unsigned)sc.rk_stride : 0u;
     const int32_t* __restrict__ const cls_list = cls_list_pool;
     static_assert(!LDSWS || (!COARSE && !REST && !SPREAD && !MANY && !RANKED && NW == 1), "the LDS-resident workspace serves generation 4");
+    static_assert(!LDSX || (REST && !RANKED && NW == 1 && !LDSWS), "LDS-resident mask rows serve generation 6");
     unsigned char* const wsb = LDSWS ? smem + ((cv.total + 127) & ~127) : ws + ws_off[blockIdx.x];
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
@@ -454,14 +458,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     unsigned short* g_fine = (unsigned short*)((unsigned char*)g_nz + (NZEQ ? 0 : (((size_t)ni * 8 + 127) & ~(size_t)127)));
     int* g_cnt = (int*)((unsigned char*)g_fine + (((size_t)(ni >> 6) * K * 8 + 127) & ~(size_t)127));
     // REST: position masks [nblk][M], GPU devices by position
-    unsigned short* g_xm = (unsigned short*)((unsigned char*)g_cnt + (((size_t)K * Cn * 4 + 127) & ~(size_t)127));
-    unsigned* g_gused = (unsigned*)((unsigned char*)g_xm + (((size_t)nblk * M * 2 + 127) & ~(size_t)127));
+    unsigned short* const g_xm_mem = (unsigned short*)((unsigned char*)g_cnt + (((size_t)K * Cn * 4 + 127) & ~(size_t)127));   // (the HBM slice keeps its layout)
+    // LDSX: rows [M][nblk] behind tcarve's total, then the row totals [M], then the canonical index of every position
+    const unsigned ldsx_x = ((unsigned)cv.total + 127u) & ~127u;
+    const unsigned ldsx_rt = ldsx_x + ((((unsigned)sc.ni_max >> 4) * (unsigned)M * 2u + 127u) & ~127u);
+    const unsigned ldsx_cn = ldsx_rt + (((unsigned)M * 4u + 127u) & ~127u);
+    unsigned short* g_xm = LDSX ? (unsigned short*)(smem + ldsx_x) : g_xm_mem;
+    unsigned short* const sx_canon = (unsigned short*)(smem + ldsx_cn);
+    unsigned* g_gused = (unsigned*)((unsigned char*)g_xm_mem + (((size_t)nblk * M * 2 + 127) & ~(size_t)127));
     unsigned* g_gtot = g_gused + (size_t)ni * 8;
     int* g_gcnt = (int*)(g_gtot + ni);
     unsigned* g_xused = (unsigned*)(g_gcnt + ni);                     // [ni][8]: Requested ephemeral storage, extended resources
     unsigned* g_xalloc = g_xused + (size_t)ni * 8;                    // [ni][8]: their allocatable
     unsigned short* g_pdom = (unsigned short*)(g_xalloc + (size_t)ni * 8);   // [NZ][ni]: domain under a zone-like key, 0xFFFF = no label
-    unsigned* g_rowtot = (unsigned*)(g_pdom + (size_t)NZ * ni);       // [M]: pods that set the row so far (term totals of required affinity)
+    unsigned* g_rowtot = LDSX ? (unsigned*)(smem + ldsx_rt) : (unsigned*)(g_pdom + (size_t)NZ * ni);       // [M]: pods that set the row so far (term totals of required affinity)
     // SPREAD (never together with REST: M == 0, so the block starts where the REST rows would): placed pods a term's selector matches
     unsigned char* g_hrow = (unsigned char*)g_xm;                     // [TH][ni] per position (hostname-like key: domain = node)
     unsigned* g_zcnt = (unsigned*)(g_hrow + (((size_t)TH * ni + 127) & ~(size_t)127));   // [TZ][16] per domain of a zone-like key
@@ -602,6 +612,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             unsigned u[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] = real ? i_gused[(size_t)j * 8 + e] : 0u;
+            if constexpr (LDSX) sx_canon[p] = (unsigned short)(real ? j : (int)PMASK);
             g_gcnt[p] = gc; g_gtot[p] = tot;
             *(uint4*)(g_gused + (size_t)p * 8) = make_uint4(u[0], u[1], u[2], u[3]);
             *(uint4*)(g_gused + (size_t)p * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
@@ -921,8 +932,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         unsigned long long tied = __ballot(present && total == tmax);
         int wl = __builtin_ctzll(tied);
         if (__builtin_expect((tied & (tied - 1)) != 0, 0)) {              // several classes reach the maximum: first in canonical order
-            int canon = (present && total == tmax) ? cls_list[rk_off + (unsigned)idx] : (int)PMASK;
+            int canon;
+            if constexpr (LDSX) canon = (present && total == tmax) ? (int)sx_canon[pos] : (int)PMASK;
+            else {
+            canon = (present && total == tmax) ? cls_list[rk_off + (unsigned)idx] : (int)PMASK;
             if (ranked && present && total == tmax) canon = cold->rk_rank[(size_t)s * (size_t)cold->N + canon];
+            }
             const unsigned cmin = wave_max_u32((present && total == tmax) ? PMASK - (unsigned)canon : 0u);
             wl = __builtin_ctzll(__ballot(present && total == tmax && PMASK - (unsigned)canon == cmin));
         }
@@ -1630,8 +1645,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 for (int q = 0; q < NBQ; ++q) {
                     const int pq = (q * 64 + lane) * UNIT + (UNIT - 1) - (int)(m16q[q] & UMASK);
                     const bool tied = (m16q[q] >> UB) == top && q * 64 + lane < nun;
+                    if constexpr (LDSX) canon[q] = tied ? (int)sx_canon[pq] : (int)PMASK;
+                    else {
                     canon[q] = tied ? cls_list[rk_off + (unsigned)((binfo[q] & 0xFFFF) - 8192 + pq)] : (int)PMASK;
                     if (ranked && tied) canon[q] = cold->rk_rank[(size_t)s * (size_t)cold->N + canon[q]];
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < NBQ; ++q) {
@@ -2054,6 +2072,28 @@ hipError_t launch_table_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_
     if (a.sc.K > 64) return nzeq ? launch_lds2<true, 2>(a, n_blocks, lds_bytes, st) : launch_lds2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_lds2<true, 1>(a, n_blocks, lds_bytes, st) : launch_lds2<false, 1>(a, n_blocks, lds_bytes, st);
 }
+#elif defined(SIMON_TABLE_RESTLDS_TU)
+// ---- this translation unit (simon_table_restlds.hip) holds generation 6 with its mask rows, row totals and canonical indices in LDS (LDSX) ----
+template <bool Z, int KQ, int NBQ, bool AFF>
+static hipError_t launch_rl4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, false, AFF, false, false, 1, false, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    return hipGetLastError();
+}
+template <bool Z, int KQ>
+static hipError_t launch_rl2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    const bool one = a.sc.ni_max / 64 <= 64;
+    if (a.aff) return one ? launch_rl4<Z, KQ, 1, true>(a, n_blocks, lds, st) : launch_rl4<Z, KQ, 2, true>(a, n_blocks, lds, st);
+    return one ? launch_rl4<Z, KQ, 1, false>(a, n_blocks, lds, st) : launch_rl4<Z, KQ, 2, false>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.lds_x || !a.rest || !a.coarse || a.spread || a.team > 1 || a.sc.rk_stride != 0) return hipErrorInvalidValue;
+    if (a.sc.K > 64) return nzeq ? launch_rl2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 2>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_rl2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 1>(a, n_blocks, lds_bytes, st);
+}
 #elif defined(SIMON_TABLE_REST_TU)
 // ---- this translation unit (simon_table_rest.hip) holds generation 6: the REST instantiations (position masks: Open-Gpu-Share devices,
 // required (anti-)affinity, host ports, ephemeral storage / extended resources) -- the 32 largest kernels of the single-wave family ----
@@ -2093,7 +2133,7 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (PIN) {                                              // REST rides on the instantiation that knows pinned pods: simon_table_rest.hip
-        if (a.rest) return launch_table_rest(a, n_blocks, Z, lds, st);
+        if (a.rest) return a.lds_x ? launch_table_rest_lds(a, n_blocks, Z, lds, st) : launch_table_rest(a, n_blocks, Z, lds, st);
     }
     if (a.spread) return hipErrorInvalidValue;                        // (generation 7 lives in simon_table_spread.hip: launch_table_spread)
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions

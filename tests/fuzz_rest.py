@@ -58,6 +58,10 @@ def one_case(case):
         os.environ["SIMON_NO_GPU_FOLD"] = "1"
     else:
         os.environ.pop("SIMON_NO_GPU_FOLD", None)
+    if (case // 2) % 2:                   # round 5: every other pair of cases keeps the mask rows in HBM (the others: in LDS where the batch is resident)
+        os.environ["SIMON_LDS_WS"] = "0"
+    else:
+        os.environ.pop("SIMON_LDS_WS", None)
     with capi.Context(0) as ctx:
         ctx.load_problem(prob)
         ctx.load_scenarios(scen, orders)
@@ -67,6 +71,7 @@ def one_case(case):
         res = ctx.fetch(True)
         st = ctx.stats()
     os.environ.pop("SIMON_NO_GPU_FOLD", None)
+    os.environ.pop("SIMON_LDS_WS", None)
     ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
           res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all())
     return ok, dict(case=case, N=N, P=P, S=S, classes=n_node_classes, pod_classes=n_pod_classes, feat=sorted(feat),

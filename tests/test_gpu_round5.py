@@ -131,3 +131,51 @@ def test_config3_sixty_four_scenarios_with_the_workspace_in_lds(monkeypatch):
             res, st = run_ws(prob, scen, orders, home, monkeypatch)
             assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4
             assert_same(res, ref)
+
+
+# ---- generation 6 with its position-mask rows in LDS (small gpushare sweeps) ---------------------------------------------------------------
+from test_gpu_parity import REST_FEATURES
+
+
+@pytest.mark.parametrize("idx", range(len(REST_FEATURES)))
+def test_mask_rows_in_lds_match_the_oracle(idx, monkeypatch):
+    """Generation 6 (Open-Gpu-Share devices, required (anti-)affinity incl. zone-like keys and the first-pod escape, host ports, ephemeral
+    storage / extended resources as position masks) with the mask rows, their totals and the canonical indices in HBM and in LDS, against
+    the oracle -- placements and the devices Reserve books."""
+    feat = REST_FEATURES[idx]
+    monkeypatch.setenv("SIMON_NO_FOLD", "1")
+    monkeypatch.setenv("SIMON_NO_GPU_FOLD", "1")
+    for seed in range(4):
+        N = [37, 150, 700, 1500][seed]
+        prob = randprob.rand_problem(54000 + 100 * idx + seed, N=N, P=500 + 300 * seed, n_pod_classes=6 + 5 * seed + (60 if seed == 3 else 0), n_node_classes=3 + 2 * seed, **feat)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=5, min_n=1 if seed == 0 else None)
+        gpu = bool(feat.get("gpu"))
+        ref = O.run_threaded(prob, scen, orders, want_gpu_slices=gpu)
+        lds = {}
+        for home in WS_HOMES:
+            monkeypatch.setenv("SIMON_LDS_WS", home)
+            with capi.Context(0) as ctx:
+                ctx.load_problem(prob)
+                res = ctx.run_batch(scen, orders, want_gpu_slices=gpu)
+                st = ctx.stats()
+            assert_same(res, ref)
+            if gpu:
+                assert (res.gpu_slices == ref.gpu_slices).all()
+            lds[home] = (st.kernel_variant, st.kernel_generation, st.lds_bytes)
+        if lds["0"][0] == capi.KERNEL_NARROW_CACHE and lds["0"][1] == 6:
+            assert lds["1"][1] == 6 and lds["1"][2] > lds["0"][2], lds           # the rows did move to LDS
+
+
+def test_config5_sixty_four_full_size_scenarios_with_the_mask_rows_in_lds(monkeypatch):
+    """BASELINE config 5 at full size (50 000 pods x 2 500 .. 5 000 nodes; GPU share + self anti-affinity groups + taints): 64 of the 256
+    benchmarked scenarios with the mask rows in LDS (what a 256-scenario batch gets by default: one scenario per CU), every placement."""
+    monkeypatch.setenv("SIMON_LDS_WS", "1")
+    prob, scen, orders = synth.config5()
+    pick = np.unique(np.linspace(0, len(scen) - 1, 64).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen[pick], orders)
+        st = ctx.stats()
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 6 and st.lds_bytes > 64 * 1024, (st.kernel_generation, st.lds_bytes)
+    assert_same(res, ref)
