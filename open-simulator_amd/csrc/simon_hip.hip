@@ -1762,7 +1762,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // a real Applier.Run offers -- of a problem whose byte table + node state fit the CU's LDS next to the summaries.  The one memory
         // round trip of a scheduling cycle becomes an LDS access.
         bool lds_ws = false;
-        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && !c->has_ranks && c->n_sigs <= 128 && team == 1 &&
+        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && c->n_sigs <= 128 && team == 1 &&
             c->ldsws_mode != 0) {
             size_t ws_max = 0;
             for (int s2 = 0; s2 < S; ++s2) ws_max = std::max(ws_max, table_ws_bytes(c->n_sigs, c->scen_ni[s2], c->nzeq, false, c->Cn_t, 0, 0, 0, 0));
@@ -1774,7 +1774,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         }
         // Generation 6 with its mask rows, row totals and canonical indices in LDS (round 5; simon_table.hip: LDSX), under the same residency rule
         bool lds_x = false;
-        if (c->table_ok && c->table_coarse && c->rest && !c->spread && !c->has_ranks && team == 1 && c->ldsws_mode != 0) {
+        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1 && c->ldsws_mode != 0) {
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + table_ldsx_bytes(ni_top, c->rest_M) + c->lds_pad;
             const size_t per_cu = (size_t)(S + c->n_cus - 1) / (size_t)std::max(c->n_cus, 1);
             const bool resident = per_cu * ((need + 1279) / 1280 * 1280) <= kTableLdsPerCU && per_cu <= 32;

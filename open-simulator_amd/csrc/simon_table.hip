@@ -318,7 +318,7 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // batches a real Applier.Run offers (a handful of sizes: at most one scenario per CU, so the CU's 160 KB are this scenario's) on problems
 // whose table fits (config 3's pool: 1 600 positions x 42 signatures = 86 KB; config 2: 12 KB) the one memory round trip of a scheduling
 // cycle -- the winner's table rows and state from L2 -- becomes an LDS access.  Same code: the pointers are derived from the LDS base in
-// this instantiation, the compiler addresses them as LDS.  Generation 4 only (one-level summary, no REST / SPREAD / folds / ranks).
+// this instantiation, the compiler addresses them as LDS.  Generation 4 only (one-level summary, no REST / SPREAD / folds).
 // LDSX (round 5): generation 6's position-mask rows (g_xm), their totals and the canonical index of every position live in LDS -- the
 // same idea for the batches of a gpushare sweep (config 5 x 256: one scenario per CU, 71 KB of rows): the REST select's filter words and
 // the canonical tie-break of the device / device-less twin classes (every other cycle of config 5) stop being memory round trips.
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     constexpr bool ranked = RANKED;
     const unsigned rk_off = RANKED ? (unsigned)s * (unsigned)sc.rk_stride : 0u;
     const int32_t* __restrict__ const cls_list = cls_list_pool;
-    static_assert(!LDSWS || (!COARSE && !REST && !SPREAD && !MANY && !RANKED && NW == 1), "the LDS-resident workspace serves generation 4");
-    static_assert(!LDSX || (REST && !RANKED && NW == 1 && !LDSWS), "LDS-resident mask rows serve generation 6");
+    static_assert(!LDSWS || (!COARSE && !REST && !SPREAD && !MANY && NW == 1), "the LDS-resident workspace serves generation 4");
+    static_assert(!LDSX || (REST && NW == 1 && !LDSWS), "LDS-resident mask rows serve generation 6");
     unsigned char* const wsb = LDSWS ? smem + ((cv.total + 127) & ~127) : ws + ws_off[blockIdx.x];
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             unsigned u[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] = real ? i_gused[(size_t)j * 8 + e] : 0u;
-            if constexpr (LDSX) sx_canon[p] = (unsigned short)(real ? j : (int)PMASK);
+            if constexpr (LDSX) sx_canon[p] = (unsigned short)(real ? (ranked ? cold->rk_rank[(size_t)s * (size_t)cold->N + j] : j) : (int)PMASK);   // (the rank with per-scenario node order: ties compare it)
             g_gcnt[p] = gc; g_gtot[p] = tot;
             *(uint4*)(g_gused + (size_t)p * 8) = make_uint4(u[0], u[1], u[2], u[3]);
             *(uint4*)(g_gused + (size_t)p * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
@@ -2053,10 +2053,13 @@ hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask
 }
 #elif defined(SIMON_TABLE_LDS_TU)
 // ---- this translation unit (simon_table_lds.hip) holds generation 4 with the scenario's workspace in LDS (LDSWS): small batches of small problems ----
-template <bool Z, int KQ, int NBQ>
+template <bool Z, int KQ, int NBQ, bool RANKED = false>
 static hipError_t launch_lds3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (!RANKED) {                                          // per-scenario node order (a sweep over several zones): its own instantiation
+        if (a.sc.rk_stride != 0) return launch_lds3<Z, KQ, NBQ, true>(a, n_blocks, lds, st);
+    }
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<true, Z, true, KQ, NBQ, false, false, false, false, false, false, 1, true>;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, false, false, RANKED, false, false, false, 1, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2068,16 +2071,19 @@ static hipError_t launch_lds2(const TableLaunch& a, int n_blocks, size_t lds, hi
     return nblk <= 64 ? launch_lds3<Z, KQ, 1>(a, n_blocks, lds, st) : nblk <= 128 ? launch_lds3<Z, KQ, 2>(a, n_blocks, lds, st) : launch_lds3<Z, KQ, 4>(a, n_blocks, lds, st);
 }
 hipError_t launch_table_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.lds_ws || a.coarse || a.rest || a.spread || a.team > 1 || a.sc.rk_stride != 0 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
+    if (!a.lds_ws || a.coarse || a.rest || a.spread || a.team > 1 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
     if (a.sc.K > 64) return nzeq ? launch_lds2<true, 2>(a, n_blocks, lds_bytes, st) : launch_lds2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_lds2<true, 1>(a, n_blocks, lds_bytes, st) : launch_lds2<false, 1>(a, n_blocks, lds_bytes, st);
 }
 #elif defined(SIMON_TABLE_RESTLDS_TU)
 // ---- this translation unit (simon_table_restlds.hip) holds generation 6 with its mask rows, row totals and canonical indices in LDS (LDSX) ----
-template <bool Z, int KQ, int NBQ, bool AFF>
+template <bool Z, int KQ, int NBQ, bool AFF, bool RANKED = false>
 static hipError_t launch_rl4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (!RANKED) {
+        if (a.sc.rk_stride != 0) return launch_rl4<Z, KQ, NBQ, AFF, true>(a, n_blocks, lds, st);
+    }
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, false, AFF, false, false, 1, false, true>;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, RANKED, AFF, false, false, 1, false, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2090,7 +2096,7 @@ static hipError_t launch_rl2(const TableLaunch& a, int n_blocks, size_t lds, hip
     return one ? launch_rl4<Z, KQ, 1, false>(a, n_blocks, lds, st) : launch_rl4<Z, KQ, 2, false>(a, n_blocks, lds, st);
 }
 hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.lds_x || !a.rest || !a.coarse || a.spread || a.team > 1 || a.sc.rk_stride != 0) return hipErrorInvalidValue;
+    if (!a.lds_x || !a.rest || !a.coarse || a.spread || a.team > 1) return hipErrorInvalidValue;
     if (a.sc.K > 64) return nzeq ? launch_rl2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rl2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 1>(a, n_blocks, lds_bytes, st);
 }

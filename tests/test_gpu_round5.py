@@ -122,6 +122,32 @@ def test_the_library_puts_the_workspace_in_lds_for_resident_batches_only(monkeyp
     assert seen[64] > 40 * 1024 > seen[800] > 0, seen
 
 
+def test_workspace_in_lds_with_per_scenario_node_ranks(monkeypatch):
+    """A sweep over a cluster with several zones gives every cluster size its own nodeTree order (simon_set_node_ranks): the LDS home of the
+    workspace has its own instantiations for that; a homogeneous pool makes every cycle a tie that the ranks decide."""
+    prob, scen, orders = synth.config3(n_counts=6, n_orders=2, n_pods=900, n_het=40, homogeneous=True)
+    rng = np.random.default_rng(5)
+    N = prob.n_nodes
+    ranks = np.zeros((len(scen), N), np.int32)
+    for i, (n, _) in enumerate(scen.tolist()):
+        ranks[i, :n] = rng.permutation(n)
+        ranks[i, n:] = np.arange(n, N)
+    ref = O.run(prob, scen, orders, node_ranks=ranks)
+    lds = {}
+    for home in WS_HOMES:
+        monkeypatch.setenv("SIMON_LDS_WS", home)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            res, st = ctx.fetch(True), ctx.stats()
+        assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4
+        assert_same(res, ref)
+        lds[home] = st.lds_bytes
+    assert lds["1"] > lds["0"]
+
+
 def test_config3_sixty_four_scenarios_with_the_workspace_in_lds(monkeypatch):
     """BASELINE config 3's pool at the batch a real `simon apply` offers (16 node counts x 4 orders = 64 scenarios, 10 000 pods each) and
     BASELINE config 2 (one scenario): both homes of the workspace against the oracle, every placement."""
