@@ -298,3 +298,89 @@ def test_go_constants_that_restate_header_constants_hold_the_header_values():
                     bad.append(f"{os.path.relpath(path, ROOT)}:{ln_no}: {name} = {val} but {cite} = {defines[cite]:#x}")
     assert not bad, "\n".join(bad)
     assert seen >= 5, seen
+
+
+GO_BUILTINS = {"len", "cap", "make", "new", "append", "copy", "delete", "panic", "recover", "print", "println", "close", "complex", "real", "imag",
+               "int", "int8", "int16", "int32", "int64", "uint", "uint8", "uint16", "uint32", "uint64", "uintptr", "float32", "float64", "string", "byte",
+               "rune", "bool", "error", "func", "if", "for", "switch", "select", "return", "go", "defer", "range", "case", "else", "map", "chan", "struct", "interface", "var", "const", "type"}
+
+
+def test_go_files_are_balanced_and_use_what_they_import():
+    """Two things a Go compiler refuses outright and a reader easily misses in files that were never compiled: an imported package that the
+    file does not use, and unbalanced brackets."""
+    problems = []
+    for path in go_files():
+        raw = open(path).read()
+        code = strip_go(raw)
+        for o, c in ("()", "[]", "{}"):
+            if code.count(o) != code.count(c):
+                problems.append(f"{os.path.relpath(path, ROOT)}: {code.count(o)} '{o}' against {code.count(c)} '{c}'")
+        # imports incl. the standard library
+        aliases = {}
+        lines = raw.split("\n")
+        i = 0
+        while i < len(lines):
+            ln = lines[i].strip()
+            if ln.startswith("import ("):
+                i += 1
+                while i < len(lines) and lines[i].strip() != ")":
+                    m = IMPORT_LINE.match(lines[i].split("//")[0])
+                    if m:
+                        aliases[m.group(1) or m.group(2).rsplit("/", 1)[-1]] = m.group(2)
+                    i += 1
+            elif ln.startswith("import "):
+                m = IMPORT_LINE.match(ln[len("import "):])
+                if m:
+                    aliases[m.group(1) or m.group(2).rsplit("/", 1)[-1]] = m.group(2)
+            i += 1
+        body = code[code.index("\n", code.rindex("import")):] if "import" in code else code
+        for alias, imp in aliases.items():
+            if alias in ("_", "."):
+                continue
+            if not re.search(r"(?<![\w\.])" + re.escape(alias) + r"\.", body):
+                problems.append(f"{os.path.relpath(path, ROOT)}: imports {imp!r} as {alias} and never uses it (a compile error in Go)")
+    assert not problems, "\n".join(problems)
+
+
+def test_every_function_the_go_package_calls_is_declared_somewhere_in_it():
+    """A bare call `name(...)` inside package hipengine / parity must resolve to a function, type or closure declared in one of the package's
+    files (or to a Go builtin): a helper renamed in one file and still called in another is a compile error nobody has seen yet."""
+    by_pkg = {}
+    for path in go_files():
+        by_pkg.setdefault(os.path.dirname(path), []).append(path)
+    problems = []
+    checked = 0
+    for pkg, files in by_pkg.items():
+        declared = set()
+        codes = {}
+        for path in files:
+            code = strip_go(open(path).read())
+            codes[path] = code
+            declared |= set(re.findall(r"^func\s+(?:\([^)]*\)\s*)?([A-Za-z_]\w*)\s*[\(\[]", code, flags=re.M))      # functions and methods
+            declared |= set(re.findall(r"^type\s+([A-Za-z_]\w*)\b", code, flags=re.M))
+            declared |= set(re.findall(r"^\s*type\s+([A-Za-z_]\w*)\b", code, flags=re.M))                              # types declared inside functions
+            declared |= set(re.findall(r"\b([A-Za-z_]\w*)\s*:=\s*func\b", code))                                        # closures
+            declared |= set(re.findall(r"\bvar\s+([A-Za-z_]\w*)\s+func\b", code))
+            declared |= set(re.findall(r"\b([A-Za-z_]\w*)\s+func\(", code))                                             # parameters of function type
+        # a file that declares itself part of a REFERENCE package (parity_test.go is dropped into pkg/simulator by oracle/run_ref.sh) also sees
+        # that package's own declarations
+        ref_pkgs = {"simulator": os.path.join(REF, "pkg", "simulator")}
+        for path in files:
+            pm = re.search(r"^package\s+(\w+)", codes[path], flags=re.M)
+            if pm and pm.group(1) in ref_pkgs:
+                if not os.path.isdir(ref_pkgs[pm.group(1)]):
+                    codes[path] = ""                                      # no reference tree here (the GPU box): nothing to resolve against
+                else:
+                    declared |= declared_in(ref_pkgs[pm.group(1)])
+        for path, code in codes.items():
+            for m in re.finditer(r"(?<![\w\.\)\]])([A-Za-z_]\w*)\(", code):
+                name = m.group(1)
+                if name in GO_BUILTINS or name in declared:
+                    continue
+                prev = code[max(0, m.start() - 6):m.start()]
+                if prev.rstrip().endswith("func"):
+                    continue
+                checked += 1
+                line = code.count("\n", 0, m.start()) + 1
+                problems.append(f"{os.path.relpath(path, ROOT)}:{line}: {name}( is declared nowhere in {os.path.relpath(pkg, ROOT)}")
+    assert not problems, "\n".join(sorted(set(problems))[:40])
