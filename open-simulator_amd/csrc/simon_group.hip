@@ -52,6 +52,7 @@ struct simon_group {
     std::vector<ncclComm_t> comm;
     std::vector<void*> d_gather;
     bool comm_ok = false;
+    bool fault_inject = false;                  // env SIMON_GROUP_FAULT_INJECT (tests): the next collective is treated as failed after it was enqueued
     int32_t collective = 0;                     // what the last min_plan did: 0 host reduction, 1 RCCL all-gather
 };
 
@@ -127,6 +128,7 @@ void rccl_setup(simon_group* g) {
         if (hipSetDevice(g->device[i]) != hipSuccess || hipMalloc(&g->d_gather[i], (size_t)n * sizeof(unsigned long long)) != hipSuccess) return;
     }
     g->comm_ok = true;
+    g->fault_inject = getenv("SIMON_GROUP_FAULT_INJECT") != nullptr;
 }
 
 void rccl_teardown(simon_group* g) {
@@ -324,6 +326,7 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
             const ncclResult_t r = g->p_group_end();
             if (r != ncclSuccess && nr == ncclSuccess) nr = r;
         }
+        if (g->fault_inject && nr == ncclSuccess) { nr = ncclInternalError; g->fault_inject = false; }   // (test hook: the abort + host fall-back below, with the collective in flight)
         hipError_t he = hipSuccess;
         if (nr == ncclSuccess)
             for (int i = 0; i < n && he == hipSuccess; ++i) {

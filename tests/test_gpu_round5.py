@@ -63,6 +63,30 @@ def test_config4_whole_batch_through_a_group_of_eight_members():
 
 
 
+def test_group_all_gather_failure_aborts_the_communicators_and_reduces_on_the_host(monkeypatch):
+    """First-run safety of the device group: a collective that fails AFTER it was enqueued must not leave a stream
+    waiting for a peer -- the communicators are aborted, this call and every later one reduce the members' plans on the host, the answer
+    is the same.  SIMON_GROUP_FAULT_INJECT makes the next all-gather count as failed once it is in flight (single member, RCCL forced on)."""
+    monkeypatch.setenv("SIMON_GROUP_RCCL", "1")
+    monkeypatch.setenv("SIMON_GROUP_FAULT_INJECT", "1")
+    prob, scen, orders = synth.config3(n_counts=12, n_orders=2, n_pods=500, n_het=40)
+    ref = O.run(prob, scen, orders)
+    rp = O.min_plan(prob, scen, ref)
+    with capi.Group([0]) as grp:
+        grp.load_problem(prob)
+        grp.run_batch(scen, orders)
+        plan, _ = grp.min_plan()
+        assert grp.collective() == "host" and plan.as_dict() == rp.as_dict()            # the injected failure: aborted, reduced on the host
+        plan2, _ = grp.min_plan()
+        assert grp.collective() == "host" and plan2.as_dict() == rp.as_dict()           # ... and it stays there
+    monkeypatch.delenv("SIMON_GROUP_FAULT_INJECT")
+    with capi.Group([0]) as grp:                                                          # without the fault: the collective itself
+        grp.load_problem(prob)
+        grp.run_batch(scen, orders)
+        plan3, _ = grp.min_plan()
+        assert grp.collective() == "rccl_all_gather" and plan3.as_dict() == rp.as_dict()
+
+
 # ---- generation 4 with the scenario's workspace in LDS (small batches of small problems) -------------------------------------------------
 import randprob
 from test_gpu_parity import NARROW_FEATURES, assert_same
