@@ -1841,6 +1841,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 for (int s2 = 0; s2 < S; ++s2) for (int q = 0; q < 24; ++q) acc[q] += (double)hp[(size_t)s2 * 24 + q];
                 fprintf(stderr, "[SIMON_TABLE_PROF] S=%d ticks/cycle: loop %.0f | row+summary read %.0f | key+wavemax %.0f | tie check %.0f | lds(shape,sn) %.0f | mem(state,row) %.0f | state update %.0f | eval+patch+store %.0f | REST assume %.0f | REST select %.0f | canonical tie-breaks per cycle %.3f\n",
                         S, acc[0] / S / P, acc[1] / S / P, acc[2] / S / P, acc[3] / S / P, acc[4] / S / P, acc[5] / S / P, acc[8] / S / P, acc[9] / S / P, acc[6] / S / P, acc[10] / S / P, acc[7] / S / P);
+                if (c->rest)
+                    fprintf(stderr, "[SIMON_TABLE_PROF] REST select, ticks/cycle (averaged over ALL pods): pod row %.0f | filter words + summaries %.0f | candidates %.0f | table rows of excluded bests %.0f (needed on %.3f of the cycles) | per-class best %.0f | class term %.0f | totals + tie %.0f | rest %.0f\n",
+                            acc[11] / S / P, acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[20] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[10] / S / P);
                 if (c->spread)
                     fprintf(stderr, "[SIMON_TABLE_PROF] spread pods, ticks/cycle: descriptor + first loads %.0f | counters, sizes %.0f | zone counters, Log, raw table %.0f | pass 1 %.0f | extremes, totals table %.0f | pass 2 %.0f | winner %.0f | counter stores %.0f\n",
                             acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[18] / S / P, acc[19] / S / P);

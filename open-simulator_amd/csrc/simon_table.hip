@@ -804,6 +804,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         lead_sync();
     };
 
+    TPROF_DECL
     // ---- REST path -------------------------------------------------------------------------------------------------------
     // A REST pod's descriptor (PodRowC::rest) = GPU request + 1 | extra-resource request + 1 << 6 | rows << 12 | offset << 18 into xrows: entry e < rows packs the
     // mask row the pod must find clear (low half) and the row it sets when it lands (high half).  Lane e holds entry e (`rowv`,
@@ -848,6 +849,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // term folded into the summary entry is taken out again (s_sn: whatever is folded in right now, current or not): the term of a
     // REST pod is normalised over the classes that keep a node under ALL filters (simon.go:76-101), which is computed below.
     auto rest_select = [&](int k, int tc, int nrows, int rowv, int gs, int xs, bool esc, int& dstar, int& res) -> int {
+        TPROF(11);                                                         // REST: pod row, descriptor
         const int dd = lane < Cn ? lane : 0;
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
@@ -879,6 +881,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 for (int q = 0; q < NBQ; ++q) { const uint2 v = xw[row + uu[q]]; badw[q].x |= v.x; badw[q].y |= v.y; }
             }
         }
+        TPROF_WAIT_MEM; TPROF_WAIT_LDS; TPROF(12);                        // REST: filter words and summary entries arrived
         // candidate of a unit: byte << 6 | 63 - position inside the unit (0: nothing admitted), class term taken out
         unsigned cand[NBQ];
         bool need[NBQ];
@@ -892,6 +895,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             need[q] = e64[q] != 0u && hit && bad != ~0ull;
             any_need = any_need || need[q];
         }
+        TPROF(13);                                                         // REST: candidates from the summaries
+#ifdef SIMON_TABLE_PROFILE
+        if (__ballot(any_need)) tp_acc[20] += 1;                           // how often table rows are needed
+#endif
         if (__ballot(any_need)) {                                         // some unit's best position is excluded: its 4 x 16 table bytes
             const unsigned koff16 = (unsigned)k * 16u;
             auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
@@ -912,6 +919,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 cand[q] = best;
             }
         }
+        TPROF_WAIT_MEM; TPROF(14);                                         // REST: table rows of the units whose best position is excluded
 #pragma unroll
         for (int q = 0; q < NBQ; ++q)
             if (cand[q]) {                                                // best node of the class: highest base score, first position
@@ -922,11 +930,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
         const bool present = cbest != 0u;
+        TPROF_WAIT_LDS; TPROF(15);                                        // REST: per-class best (LDS max), read back
         if (!__ballot(present)) return -1;
         const int pos = (int)(PMASK - (cbest & PMASK));
         const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
         // the class term over the classes that hold a feasible node (as renormalise does for the summaries)
         const int sn = class_term(present, rawc, tc, dd);
+        TPROF(16);                                                         // REST: class term over the classes present
         const unsigned total = present ? (cbest >> KB) + (unsigned)sn : 0u;   // >= 1 when present (the byte is 1 + score)
         const unsigned tmax = wave_max_u32(total);
         unsigned long long tied = __ballot(present && total == tmax);
@@ -941,6 +951,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             const unsigned cmin = wave_max_u32((present && total == tmax) ? PMASK - (unsigned)canon : 0u);
             wl = __builtin_ctzll(__ballot(present && total == tmax && PMASK - (unsigned)canon == cmin));
         }
+        TPROF(17);                                                         // REST: totals, maximum, tie
         dstar = wl;
         res = __builtin_amdgcn_readlane(idx, wl);
         return __builtin_amdgcn_readlane(pos, wl);
@@ -1046,7 +1057,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // lists give the canonical index of a position).  Everything else about the cycle -- assume, column refresh, summaries -- is the
     // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | preferred-term entries << 10 | hard constraints << 13 | offset << 15 into TableCold::sp_ent; lane e
     // holds entry e (`spv`).
-    TPROF_DECL
     auto spread_select = [&](int k, int tc, int soft_n, int match_n, int ipa_n, int hard_n, int spv, int spt, int& dstar, int& res) -> int {
         // team mode: everything the leader stored in the cycles since the last spread pod -- table bytes, counters, class terms -- is
         // complete (the barrier's release waits for vmcnt / lgkmcnt) before a helper reads it; wave w walks units [ulo, uhi)
