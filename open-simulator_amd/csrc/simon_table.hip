@@ -59,6 +59,24 @@
 
 namespace simon {
 
+// Pointers that arrive through TableCold -- a struct in device memory -- are generic to the compiler: every access through them was a
+// FLAT instruction (round 6: 40 .. 90 per kernel, among them the REST select's Simon row and the pod's filter entries).  A flat load
+// counts on vmcnt AND lgkmcnt, so the next wait for an LDS read also waited for the memory round trip.  gp() names the address
+// space: the tables behind TableCold are global memory, always.
+#ifdef SIMON_TABLE_LDS_TU
+#define SIMON_AS1   // (generation 4 with the workspace in LDS: its cycle touches no global memory, and the unit keeps round 5's code layout -- a single wave per CU is sensitive to it: same-box A/B 5.54 -> 5.80 ms on config 3 x 64 with identical loop bodies)
+#else
+#define SIMON_AS1 __attribute__((address_space(1)))
+#endif
+template <class T> using GPtr = T SIMON_AS1*;
+template <class T> __device__ __forceinline__ GPtr<T> gp(T* p) { return (GPtr<T>)p; }
+// (HIP's uint2 / uint4 / int2 are classes: their copy constructors take generic references, so vectors travel as native ones)
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ uint4 ldg_u4(GPtr<T> p) { const u32x4n v = *(GPtr<const u32x4n>)p; return make_uint4(v.x, v.y, v.z, v.w); }
+template <class T> __device__ __forceinline__ uint2 ldg_u2(GPtr<T> p) { const u32x2n v = *(GPtr<const u32x2n>)p; return make_uint2(v.x, v.y); }
+template <class T> __device__ __forceinline__ int2 ldg_i2(GPtr<T> p) { const u32x2n v = *(GPtr<const u32x2n>)p; return make_int2((int)v.x, (int)v.y); }
+
 typedef unsigned short u16x2t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pkmax_t(unsigned a, unsigned b) {
@@ -174,11 +192,18 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     int o = 0;
     c.sum = o; o += al(K * c.nbp * 2);
     c.sn = o; o += al(K * Cn * 2);
+    // (REST, round 6: the feasible-node counters stay in LDS on the two-level layout as well.  On a gpushare cluster that fills up -- config
+    // 5 -- some (signature, node) byte drops to 0 on almost every cycle, and the counter's read-modify-write in the HBM workspace was a
+    // dependent memory round trip inside the refresh; generation 6 holds <= 128 signatures x <= 64 classes, config 5: 84 x 8 = 2.7 KB.)
+#ifdef SIMON_REST_CNT_HBM
+    (void)rest;
     c.cnt = o; o += coarse ? 0 : al(K * Cn * 4);
+#else
+    c.cnt = o; o += (coarse && !rest) ? 0 : al(K * Cn * 4);
+#endif
     c.shape = o; o += Cn * 48;
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
-    (void)rest;
     // SPREAD (nzk >= 0): zone domain of a class per zone-like key; for spread_select two bytes per position and the score table of
     // the pod being placed
     const bool ipa = nzk >= 0 && (nzk & 0x100);                       // the problem has preferred pod (anti-)affinity terms: a second table
@@ -335,19 +360,20 @@ template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, 
 // the spread entries fetched one pod ahead (+-1 %), 1 / 3 / 4 waves per SIMD as the register budget (within 2 %), 8 and 16 waves
 // per scenario (slower on every batch size, r04b_*))
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD ? (NW > 1 ? 2 : AFF ? SIMON_SPREAD_IPA_WAVES : SIMON_SPREAD_WAVES) : 1))) void table_kernel(
-    const TableCold* __restrict__ cold, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
+    const TableCold* __restrict__ cold_, const int32_t* __restrict__ cls_list_pool, const PodRowC* __restrict__ pods,
     const int32_t* __restrict__ orders, const int32_t* __restrict__ perm, const unsigned long long* __restrict__ ws_off,
     int32_t* __restrict__ place_step, unsigned char* ws, const TableScalars sc) {
     // Pointers the hot loop never touches live in a device-resident struct: as kernel arguments (24 pointers) they kept the
     // loop at the SGPR limit and spilled into VGPR lanes.
-    const int32_t* __restrict__ const ncls = cold->ncls;
-    const int32_t* __restrict__ const cls_off = cold->cls_off; const int32_t* __restrict__ const clsprefix = cold->clsprefix;
-    const int32_t* __restrict__ const a_pods = cold->a_pods; const uint32_t* __restrict__ const i_rq_cpu = cold->i_rq_cpu;
-    const uint32_t* __restrict__ const i_rq_mem = cold->i_rq_mem; const uint32_t* __restrict__ const i_nz_cpu = cold->i_nz_cpu;
-    const uint32_t* __restrict__ const i_nz_mem = cold->i_nz_mem; const int32_t* __restrict__ const i_npods = cold->i_npods;
-    const SigRow* __restrict__ const sigs = cold->sigs; const ShapeRow* __restrict__ const shapes = cold->shapes;
-    const ScenarioDesc* __restrict__ const scen = cold->scen; const uint64_t* __restrict__ const static_mask = cold->static_mask;
-    const int32_t* __restrict__ const simon_raw = cold->simon_raw;
+    GPtr<const TableCold> const cold = gp(cold_);
+    GPtr<const int32_t> __restrict__ const ncls = gp(cold->ncls);
+    GPtr<const int32_t> __restrict__ const cls_off = gp(cold->cls_off); GPtr<const int32_t> __restrict__ const clsprefix = gp(cold->clsprefix);
+    GPtr<const int32_t> __restrict__ const a_pods = gp(cold->a_pods); GPtr<const uint32_t> __restrict__ const i_rq_cpu = gp(cold->i_rq_cpu);
+    GPtr<const uint32_t> __restrict__ const i_rq_mem = gp(cold->i_rq_mem); GPtr<const uint32_t> __restrict__ const i_nz_cpu = gp(cold->i_nz_cpu);
+    GPtr<const uint32_t> __restrict__ const i_nz_mem = gp(cold->i_nz_mem); GPtr<const int32_t> __restrict__ const i_npods = gp(cold->i_npods);
+    const SigRow* __restrict__ const sigs = cold->sigs; const ShapeRow* __restrict__ const shapes = cold->shapes;   // (structs: copied through generic references)
+    const ScenarioDesc* __restrict__ const scen = cold->scen; GPtr<const uint64_t> __restrict__ const static_mask = gp(cold->static_mask);
+    GPtr<const int32_t> __restrict__ const simon_raw = gp(cold->simon_raw);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cn = sc.Cn, Cp = sc.Cp, P = sc.P, K = sc.K;
     constexpr int UB = COARSE ? 6 : 4;                                // log2(positions per summary entry)
@@ -356,6 +382,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     constexpr int KB = COARSE ? 13 : 12;                              // width of the position field of the arg-max key
     constexpr unsigned PMASK = (1u << KB) - 1u;
     static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
+#ifdef SIMON_REST_CNT_HBM
+    constexpr bool CNT_LDS = !COARSE;                                 // A/B builds: round 5's home of the two-level layout's counters
+#else
+    constexpr bool CNT_LDS = !COARSE || REST;                         // feasible-node counters per (signature, class) in LDS (tcarve)
+#endif
 #ifdef SIMON_TIE_SPECULATE
     constexpr bool TIE_FIRST = false;                                 // A/B builds: every instantiation speculates
 #else
@@ -414,7 +445,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     const int32_t* __restrict__ order = orders + (size_t)__builtin_amdgcn_readfirstlane(scen[s].order_id) * P;
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
-    for (int i = tid; i < K * Cn; i += TT) { if (!COARSE) s_cnt[i] = 0; s_sn[i] = 0; }
+    for (int i = tid; i < K * Cn; i += TT) { if (CNT_LDS) s_cnt[i] = 0; s_sn[i] = 0; }
     for (int i = tid; i < Cn * 12; i += TT) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
     // count of class-d nodes among the first n canonical nodes, padded to 16 (COARSE: to 64, one class per summary entry)
     const int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
@@ -488,7 +519,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     unsigned short* s_sum = (unsigned short*)(smem + cv.sum);
     for (int i = tid; i < K * nbp / 2; i += TT) ((unsigned*)s_sum)[i] = 0u;
     if (tid == 0 && ((K * nbp) & 1)) s_sum[K * nbp - 1] = 0;
-    if (COARSE) for (int i = tid; i < K * Cn; i += TT) g_cnt[i] = 0;
+    if (!CNT_LDS) for (int i = tid; i < K * Cn; i += TT) g_cnt[i] = 0;
     if constexpr (NW > 1) __threadfence();                            // (the zeroes are in L2 before another wave's atomics add to them)
     __syncthreads();
 
@@ -531,7 +562,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;   // r-th node of class d in canonical order
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
         if constexpr (SPREAD && RANKED) {                                 // spread_select breaks its ties by rank: one coalesced read per unit
-            if (p < ni) g_canon[p] = (unsigned short)(real ? cold->rk_rank[(size_t)s * (size_t)cold->N + j] : 8191);
+            if (p < ni) g_canon[p] = (unsigned short)(real ? gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + j] : 8191);
         }
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
@@ -546,9 +577,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         if constexpr (kGpuFoldable) {
             if (gfold) {
                 if (real) {
-                    gcnt = cold->gpu_cnt[j]; gtot = cold->gpu_devtot[j];
+                    gcnt = gp(cold->gpu_cnt)[j]; gtot = gp(cold->gpu_devtot)[j];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gu[e] = cold->i_gused[(size_t)j * 8 + e];
+                    for (int e = 0; e < 8; ++e) gu[e] = gp(cold->i_gused)[(size_t)j * 8 + e];
                 }
                 if (p < ni) {
                     g_fc[p] = gcnt; g_ft[p] = gtot;
@@ -581,7 +612,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if (lane == 0) {
                     s_sum[k * nbp + (p0 >> 6)] = (unsigned short)c64;
                     if (nfe) {
-                        if constexpr (NW == 1) g_cnt[k * Cn + d] += nfe;   // lane 0 alone, chunk after chunk: plain (see the refresh)
+                        if constexpr (CNT_LDS) s_cnt[k * Cn + d] += nfe;   // (REST: one wave, lane 0 alone)
+                        else if constexpr (NW == 1) g_cnt[k * Cn + d] += nfe;   // lane 0 alone, chunk after chunk: plain (see the refresh)
                         else atomicAdd(&g_cnt[k * Cn + d], nfe);           // chunks of one class on several waves (L1 is invalidated below)
                     }
                 }
@@ -596,10 +628,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         for (int i = lane; i < nblk * M; i += 64) g_xm[i] = 0;            // no pod placed yet: every term row clear
         for (int i = lane; i < M; i += 64) g_rowtot[i] = 0u;
         // the pool's GPU devices by position, and the row of every GPU signature: bit set = it does not fit the node now
-        const int32_t* __restrict__ const gpu_cnt = cold->gpu_cnt;
-        const uint32_t* __restrict__ const gpu_devtot = cold->gpu_devtot;
-        const uint32_t* __restrict__ const i_gused = cold->i_gused;
-        const uint2* __restrict__ const gsig = cold->gsig;
+        GPtr<const int32_t> __restrict__ const gpu_cnt = gp(cold->gpu_cnt);
+        GPtr<const uint32_t> __restrict__ const gpu_devtot = gp(cold->gpu_devtot);
+        GPtr<const uint32_t> __restrict__ const i_gused = gp(cold->i_gused);
+        GPtr<const uint2> __restrict__ const gsig = gp(cold->gsig);
         for (int p0 = 0; p0 < ni; p0 += 64) {
             const int p = p0 + lane;
             const int d = class_of_pos(p);
@@ -612,34 +644,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             unsigned u[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] = real ? i_gused[(size_t)j * 8 + e] : 0u;
-            if constexpr (LDSX) sx_canon[p] = (unsigned short)(real ? (ranked ? cold->rk_rank[(size_t)s * (size_t)cold->N + j] : j) : (int)PMASK);   // (the rank with per-scenario node order: ties compare it)
+            if constexpr (LDSX) sx_canon[p] = (unsigned short)(real ? (ranked ? gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + j] : j) : (int)PMASK);   // (the rank with per-scenario node order: ties compare it)
             g_gcnt[p] = gc; g_gtot[p] = tot;
             *(uint4*)(g_gused + (size_t)p * 8) = make_uint4(u[0], u[1], u[2], u[3]);
             *(uint4*)(g_gused + (size_t)p * 8 + 4) = make_uint4(u[4], u[5], u[6], u[7]);
             for (int g = 0; g < G; ++g) {
-                const uint2 sg = gsig[g];
+                const uint2 sg = ldg_u2(gsig + g);
                 const bool fits = real && gpu_fits_t(u, gc, tot, sg.x, (int)sg.y);
                 const unsigned long long bal = __ballot(!fits);
                 if ((lane & 15) == 0) g_xm[(size_t)g * nblk + (p >> 4)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
             }
             if (X > 0) {                                                  // extra resources of the position, row of every request
-                const uint4 a0 = real ? *(const uint4*)(cold->xalloc + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
-                const unsigned a4 = real ? cold->xalloc[(size_t)j * 8 + 4] : 0u;
-                const uint4 u0 = real ? *(const uint4*)(cold->i_xused + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
-                const unsigned u4 = real ? cold->i_xused[(size_t)j * 8 + 4] : 0u;
+                const uint4 a0 = real ? ldg_u4(gp(cold->xalloc) + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
+                const unsigned a4 = real ? gp(cold->xalloc)[(size_t)j * 8 + 4] : 0u;
+                const uint4 u0 = real ? ldg_u4(gp(cold->i_xused) + (size_t)j * 8) : make_uint4(0, 0, 0, 0);
+                const unsigned u4 = real ? gp(cold->i_xused)[(size_t)j * 8 + 4] : 0u;
                 *(uint4*)(g_xalloc + (size_t)p * 8) = a0; *(uint4*)(g_xalloc + (size_t)p * 8 + 4) = make_uint4(a4, 0, 0, 0);
                 *(uint4*)(g_xused + (size_t)p * 8) = u0; *(uint4*)(g_xused + (size_t)p * 8 + 4) = make_uint4(u4, 0, 0, 0);
                 const unsigned al[5] = {a0.x, a0.y, a0.z, a0.w, a4}, us[5] = {u0.x, u0.y, u0.z, u0.w, u4};
                 for (int x = 0; x < X; ++x) {
-                    const uint4 q0 = *(const uint4*)(cold->xsig + (size_t)x * 8);
-                    const unsigned rq[5] = {q0.x, q0.y, q0.z, q0.w, cold->xsig[(size_t)x * 8 + 4]};
+                    const uint4 q0 = ldg_u4(gp(cold->xsig) + (size_t)x * 8);
+                    const unsigned rq[5] = {q0.x, q0.y, q0.z, q0.w, gp(cold->xsig)[(size_t)x * 8 + 4]};
                     const bool fits = real && xres_fits_t(rq, us, al);
                     const unsigned long long bal = __ballot(!fits);
                     if ((lane & 15) == 0) g_xm[(size_t)(G + x) * nblk + (p >> 4)] = (unsigned short)((bal >> (lane & 48)) & 0xFFFFull);
                 }
             }
             for (int z = 0; z < NZ; ++z) {
-                const int dz = real ? cold->zdom[(size_t)z * cold->N + j] : -1;
+                const int dz = real ? gp(cold->zdom)[(size_t)z * cold->N + j] : -1;
                 g_pdom[(size_t)z * ni + p] = (unsigned short)(dz >= 0 ? dz : 0xFFFF);
                 // the key's label row (the last NZ rows): bit set = the node lacks the label -- required affinity fails there whatever
                 // has been placed (filtering.go:357-360)
@@ -649,7 +681,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
     }
     if constexpr (SPREAD) {
-        for (int i = tid; i < (NZK > 0 ? NZK : 1) * Cn; i += TT) s_zdom[i] = NZK > 0 ? cold->cls_zdom[i] : (signed char)0;
+        for (int i = tid; i < (NZK > 0 ? NZK : 1) * Cn; i += TT) s_zdom[i] = NZK > 0 ? gp(cold->cls_zdom)[i] : (signed char)0;
         for (size_t i = tid; i < ((size_t)TH * ni + 3) / 4; i += TT) ((unsigned*)g_hrow)[i] = 0u;     // no pod placed yet
         for (int i = tid; i < TZ * 16; i += TT) g_zcnt[i] = 0u;
         for (int i = tid; i < TH; i += TT) g_hmax[i] = 0;
@@ -718,21 +750,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int range = hi >= lo ? hi - lo : 0;
         const double rr = range ? 1.0 / (double)range : 0.0;
         int term = (inb && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
-        const TableCold* cc = cold;
+        GPtr<const TableCold> cc = cold;
         asm volatile("" : "+s"(cc));                                  // rare path: its pointers are fetched here, and only when present
         if (sc.static_tables & 1) {
-            const int v = cc->na_raw[c * Cn + dd];
+            const int v = gp(cc->na_raw)[c * Cn + dd];
             const int mx = wave_max_i32(inb ? v : 0);
             const double r = mx ? 1.0 / (double)mx : 0.0;
             term += (inb && mx) ? (int)__builtin_fma((double)v * 100.0, r, 0.5 * r) : 0;
         }
         if (sc.static_tables & 2) {
-            const int v = cc->tt_raw[c * Cn + dd];
+            const int v = gp(cc->tt_raw)[c * Cn + dd];
             const int mx = wave_max_i32(inb ? v : 0);
             const double r = mx ? 1.0 / (double)mx : 0.0;
             term += inb ? (mx ? 100 - (int)__builtin_fma((double)v * 100.0, r, 0.5 * r) : 100) : 0;
         }
-        if (sc.static_tables & 4) term += inb ? cc->add_raw[c * Cn + dd] : 0;
+        if (sc.static_tables & 4) term += inb ? gp(cc->add_raw)[c * Cn + dd] : 0;
         return term;
     };
     // Re-base summary row k after the set of node classes with a feasible node changed.
@@ -741,7 +773,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             // 65 .. 128 classes: lane l evaluates classes l and 64 + l -- class_term's formulas with the extremes taken over both halves
             const bool v1 = 64 + lane < Cn;
             const int d0 = lane, d1 = v1 ? 64 + lane : 0;
-            const int cn0 = COARSE ? g_cnt[k * Cn + d0] : s_cnt[k * Cn + d0], cn1 = v1 ? (COARSE ? g_cnt[k * Cn + d1] : s_cnt[k * Cn + d1]) : 0;
+            const int cn0 = !CNT_LDS ? g_cnt[k * Cn + d0] : s_cnt[k * Cn + d0], cn1 = v1 ? (!CNT_LDS ? g_cnt[k * Cn + d1] : s_cnt[k * Cn + d1]) : 0;
             const bool in0 = cn0 > 0, in1 = cn1 > 0;
             const int raw0 = simon_raw[c * Cn + d0], raw1 = simon_raw[c * Cn + d1];
             const int lo = min(wave_min_i32(in0 ? raw0 : 0x7fffffff), wave_min_i32(in1 ? raw1 : 0x7fffffff));
@@ -750,28 +782,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             const double rr = range ? 1.0 / (double)range : 0.0;
             int t0 = (in0 && range) ? 2 * (int)__builtin_fma((double)(raw0 - lo) * 100.0, rr, 0.5 * rr) : 0;
             int t1 = (in1 && range) ? 2 * (int)__builtin_fma((double)(raw1 - lo) * 100.0, rr, 0.5 * rr) : 0;
-            const TableCold* cc = cold;
+            GPtr<const TableCold> cc = cold;
             if (sc.static_tables & 1) {
-                const int a0 = cc->na_raw[c * Cn + d0], a1 = cc->na_raw[c * Cn + d1];
+                const int a0 = gp(cc->na_raw)[c * Cn + d0], a1 = gp(cc->na_raw)[c * Cn + d1];
                 const int mx = max(wave_max_i32(in0 ? a0 : 0), wave_max_i32(in1 ? a1 : 0));
                 const double r = mx ? 1.0 / (double)mx : 0.0;
                 t0 += (in0 && mx) ? (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 0;
                 t1 += (in1 && mx) ? (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 0;
             }
             if (sc.static_tables & 2) {
-                const int a0 = cc->tt_raw[c * Cn + d0], a1 = cc->tt_raw[c * Cn + d1];
+                const int a0 = gp(cc->tt_raw)[c * Cn + d0], a1 = gp(cc->tt_raw)[c * Cn + d1];
                 const int mx = max(wave_max_i32(in0 ? a0 : 0), wave_max_i32(in1 ? a1 : 0));
                 const double r = mx ? 1.0 / (double)mx : 0.0;
                 t0 += in0 ? (mx ? 100 - (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 100) : 0;
                 t1 += in1 ? (mx ? 100 - (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 100) : 0;
             }
-            if (sc.static_tables & 4) { t0 += in0 ? cc->add_raw[c * Cn + d0] : 0; t1 += in1 ? cc->add_raw[c * Cn + d1] : 0; }
+            if (sc.static_tables & 4) { t0 += in0 ? gp(cc->add_raw)[c * Cn + d0] : 0; t1 += in1 ? gp(cc->add_raw)[c * Cn + d1] : 0; }
             s_tmp[d0] = t0 - (int)s_sn[k * Cn + d0];
             s_sn[k * Cn + d0] = (unsigned short)t0;
             if (v1) { s_tmp[d1] = t1 - (int)s_sn[k * Cn + d1]; s_sn[k * Cn + d1] = (unsigned short)t1; }
         } else {
         const int dd = lane < Cn ? lane : 0;
-        const int cn = (lane < Cn) ? (COARSE ? g_cnt[k * Cn + dd] : s_cnt[k * Cn + dd]) : 0;
+        const int cn = (lane < Cn) ? (!CNT_LDS ? g_cnt[k * Cn + dd] : s_cnt[k * Cn + dd]) : 0;
         const bool inb = cn > 0;
         const int rawc = simon_raw[c * Cn + dd];                      // global: this path runs a handful of times per signature
         const int sn = class_term(inb, rawc, c, dd);
@@ -809,12 +841,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // A REST pod's descriptor (PodRowC::rest) = GPU request + 1 | extra-resource request + 1 << 6 | rows << 12 | offset << 18 into xrows: entry e < rows packs the
     // mask row the pod must find clear (low half) and the row it sets when it lands (high half).  Lane e holds entry e (`rowv`,
     // ONE vector load per pod, issued when the cycle starts); everything else about the pod's filters is register traffic.
-    const uint2 my_gsig = REST ? cold->gsig[lane < G ? lane : 0] : make_uint2(0, 0);    // lane g: GPU signature g
+    const uint2 my_gsig = REST ? ldg_u2(gp(cold->gsig) + (lane < G ? lane : 0)) : make_uint2(0, 0);    // lane g: GPU signature g
     unsigned my_xsig[5] = {0, 0, 0, 0, 0};                                              // lane 32 + x: extra-resource request x
     if (REST && X > 0) {
         const int x = (lane >= 32 && lane - 32 < X) ? lane - 32 : 0;
-        const uint4 q0 = *(const uint4*)(cold->xsig + (size_t)x * 8);
-        my_xsig[0] = q0.x; my_xsig[1] = q0.y; my_xsig[2] = q0.z; my_xsig[3] = q0.w; my_xsig[4] = cold->xsig[(size_t)x * 8 + 4];
+        const uint4 q0 = ldg_u4(gp(cold->xsig) + (size_t)x * 8);
+        my_xsig[0] = q0.x; my_xsig[1] = q0.y; my_xsig[2] = q0.z; my_xsig[3] = q0.w; my_xsig[4] = gp(cold->xsig)[(size_t)x * 8 + 4];
     }
     // OR of the pod's filter rows for block b (lane-varying b < nblk), all loads independent
     // An entry with bit 31 is a required-affinity term: its row must be SET (a pod matching the term sits in the node's domain) --
@@ -946,7 +978,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             if constexpr (LDSX) canon = (present && total == tmax) ? (int)sx_canon[pos] : (int)PMASK;
             else {
             canon = (present && total == tmax) ? cls_list[rk_off + (unsigned)idx] : (int)PMASK;
-            if (ranked && present && total == tmax) canon = cold->rk_rank[(size_t)s * (size_t)cold->N + canon];
+            if (ranked && present && total == tmax) canon = gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + canon];
             }
             const unsigned cmin = wave_max_u32((present && total == tmax) ? PMASK - (unsigned)canon : 0u);
             wl = __builtin_ctzll(__ballot(present && total == tmax && PMASK - (unsigned)canon == cmin));
@@ -1018,7 +1050,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             const unsigned long long booked = gpu_commit_t(u, L.gc, L.tot, greq, gnum);   // Reserve (open-gpu-share.go:147-188), every lane alike
             if (__builtin_expect(sc.static_tables & 8, 0)) {              // the caller wants the devices (simon_batch_out.gpu_slices), by pod id
                 const int pid = __builtin_amdgcn_readfirstlane(order[step]);
-                if (lane == 0) cold->gpu_slices[(size_t)s * (size_t)P + (size_t)pid] = booked;
+                if (lane == 0) gp(cold->gpu_slices)[(size_t)s * (size_t)P + (size_t)pid] = booked;
             }
             if (lane == 0) {
                 *(uint4*)(g_gused + (size_t)pstar * 8) = make_uint4(u[0], u[1], u[2], u[3]);
@@ -1207,7 +1239,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
         TPROF(13);                                                         // spread: feasible-node counters arrived, sizes
         // (the doubles are built where they are used: the two branches below keep different ones alive)
-        auto w_of = [&](int e) -> double { return e < soft_n ? cold->spread_log[sz[e]] : 0.0; };
+        auto w_of = [&](int e) -> double { return e < soft_n ? gp(cold->spread_log)[sz[e]] : 0.0; };
         auto cst_of = [&](int e) -> double { return (double)(skew[e] - 1); };
         // per class, held by lane = class: the zone term of constraint e (scoreForCount, :287-289, of the class's zone)
         auto az_of = [&](int e) -> double { return (lane < Cn && e < soft_n && kind[e] == 2) ? (double)czv[e] * w_of(e) + cst_of(e) : 0.0; };
@@ -1472,7 +1504,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         L.on = true;
         if (set >= 0) {
             const int jn = cls_list[rk_off + (unsigned)res];              // the node itself (canonical pool index)
-            L.on = (cold->node_sets[(size_t)set * cold->set_words + (jn >> 6)] >> (jn & 63)) & 1ull;
+            L.on = (gp(cold->node_sets)[(size_t)set * cold->set_words + (jn >> 6)] >> (jn & 63)) & 1ull;
         }
         if (kindt == 1) {
             L.old = g_hrow[(size_t)rowt * ni + (unsigned)pstar];
@@ -1528,12 +1560,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         int spv = 0;                                                       // SPREAD: lane e holds entry e of the pod's constraint / counted-term list
         int spt = 0;                                                       // ... and its term's row (TableCold::sp_ent holds both)
         if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match + sp_ipa + sp_hard) {
-            const int2 spe = cold->sp_ent[((unsigned)rw >> 15) + lane];
+            const int2 spe = ldg_i2(gp(cold->sp_ent) + (((unsigned)rw >> 15) + lane));
             spv = spe.x; spt = spe.y;
         }
         const int r_gs = REST ? (rw & 63) - 1 : -1, r_xs = REST ? ((rw >> 6) & 63) - 1 : -1, r_nrows = REST ? (rw >> 12) & 63 : 0;
         int rowv = 0;                                                      // lane e: filter row | row to set << 16 of entry e
-        if (REST && lane < r_nrows) rowv = cold->xrows[((unsigned)rw >> 18) + lane];
+        if (REST && lane < r_nrows) rowv = gp(cold->xrows)[((unsigned)rw >> 18) + lane];
         unsigned rtv = 0;                                                  // lane e: placed pods counted on entry e's row (required affinity)
         if (REST && AFF && lane < r_nrows && ((unsigned)rowv >> 31)) rtv = g_rowtot[(unsigned)rowv & 0xFFFFu];
 
@@ -1549,27 +1581,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             res = -2;
         } else if (__builtin_expect(pk < 0, 0)) {
             const int r_preset = __builtin_amdgcn_readlane(cur.y, il), r_gate = __builtin_amdgcn_readlane(cur.z, il);
-            const TableCold* cc = cold;
+            GPtr<const TableCold> cc = cold;
             asm volatile("" : "+s"(cc));                               // rare paths: fetch their pointers here, not in loop-long SGPRs
             if (r_gate >= n) {
                 res = -2;                                              // pod not part of this scenario
             } else if (r_preset >= 0) {                                // addPodToCache path (V/eventhandlers.go:223-236)
                 bound = true;
-                dstar = __builtin_amdgcn_readfirstlane(cc->ncls[r_preset]);
-                const int rk = __builtin_amdgcn_readfirstlane(ranked ? cc->rk_pos[(size_t)s * (size_t)cc->N + r_preset] : cc->rank[r_preset]);
+                dstar = __builtin_amdgcn_readfirstlane(gp(cc->ncls)[r_preset]);
+                const int rk = __builtin_amdgcn_readfirstlane(ranked ? gp(cc->rk_pos)[(size_t)s * (size_t)cc->N + r_preset] : gp(cc->rank)[r_preset]);
                 pstar = __builtin_amdgcn_readfirstlane(s_seg[dstar]) + rk;
-                res = __builtin_amdgcn_readfirstlane(cc->cls_off[dstar]) + rk;
+                res = __builtin_amdgcn_readfirstlane(gp(cc->cls_off)[dstar]) + rk;
             } else {                                                   // pinned pod (simon_pods_soa.pin_node, stored as -2 - node):
                 const int pin = -2 - r_preset;                         // its node affinity admits ONE node; the table byte of
                 res = -1;                                              // (signature, node) holds static filters + fit
                 if (HAS_PIN && pin < n) {
-                    const int dp = __builtin_amdgcn_readfirstlane(cc->ncls[pin]);
-                    const int rk = __builtin_amdgcn_readfirstlane(ranked ? cc->rk_pos[(size_t)s * (size_t)cc->N + pin] : cc->rank[pin]);
+                    const int dp = __builtin_amdgcn_readfirstlane(gp(cc->ncls)[pin]);
+                    const int rk = __builtin_amdgcn_readfirstlane(ranked ? gp(cc->rk_pos)[(size_t)s * (size_t)cc->N + pin] : gp(cc->rank)[pin]);
                     const int pp = __builtin_amdgcn_readfirstlane(s_seg[dp]) + rk;
                     const unsigned char byte = g_tile[tile_blk((unsigned)(pp >> 4)) + (unsigned)r_sig * KS + (unsigned)(pp & 15)];
                     bool clear = true;
                     if (REST && rw != 0) clear = !((__builtin_amdgcn_readfirstlane(excluded(pp >> 4, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv))) >> (pp & 15)) & 1u);
-                    if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(cc->cls_off[dp]) + rk; pstar = pp; dstar = dp; }
+                    if (byte != 0 && clear) { res = __builtin_amdgcn_readfirstlane(gp(cc->cls_off)[dp]) + rk; pstar = pp; dstar = dp; }
                 }
                 if (res < 0) ++unsched;
             }
@@ -1658,7 +1690,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     if constexpr (LDSX) canon[q] = tied ? (int)sx_canon[pq] : (int)PMASK;
                     else {
                     canon[q] = tied ? cls_list[rk_off + (unsigned)((binfo[q] & 0xFFFF) - 8192 + pq)] : (int)PMASK;
-                    if (ranked && tied) canon[q] = cold->rk_rank[(size_t)s * (size_t)cold->N + canon[q]];
+                    if (ranked && tied) canon[q] = gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + canon[q]];
                     }
                 }
 #pragma unroll
@@ -1706,7 +1738,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             if constexpr (kFoldable) {
                 if (__builtin_expect(fold, 0)) {                      // (a uniform branch)
 #pragma unroll
-                    for (int q = 0; q < KQ; ++q) xfold[q] = cold->foldx[(unsigned)r_sig * KW + ((unsigned)kk[q] >> 5)];
+                    for (int q = 0; q < KQ; ++q) xfold[q] = gp(cold->foldx)[(unsigned)r_sig * KW + ((unsigned)kk[q] >> 5)];
                 }
             }
             // MANY: the rows of the signatures beyond the register-resident ones, same round trip (uniform group conditions)
@@ -1728,7 +1760,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                             Tg[g][q] = *(const uint4*)rowg[g][q];
                             oldg[g][q] = rowg[g][q][pstar & 15];
                             Fg[g][q] = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kg[g][q]) * 4u);
-                            if (__builtin_expect(fold, 0)) xfg[g][q] = cold->foldx[(unsigned)r_sig * KW + ((unsigned)kg[g][q] >> 5)];
+                            if (__builtin_expect(fold, 0)) xfg[g][q] = gp(cold->foldx)[(unsigned)r_sig * KW + ((unsigned)kg[g][q] >> 5)];
                         }
                     }
                 }
@@ -1834,7 +1866,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         int left;
                         // plain read-modify-write (lane-local: a (signature, class) counter belongs to the lane that owns the signature):
                         // an atomic is performed in L2 and would leave the wave's later plain loads of the counter to a stale L1 line
-                        if constexpr (COARSE) { left = g_cnt[cidx] - 1; g_cnt[cidx] = left; }
+                        if constexpr (!CNT_LDS) { left = g_cnt[cidx] - 1; g_cnt[cidx] = left; }
                         else { left = s_cnt[cidx] - 1; s_cnt[cidx] = left; }
                         if (left == 0) my_dirty |= 1u << dirty_bit;       // the class term of row k changes: re-base before its next use
 #ifdef SIMON_TABLE_DEBUG
@@ -1878,7 +1910,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         const unsigned long long booked = gpu_commit_t(u, gfc, gft, greq, gnum);
                         if (sc.static_tables & 8) {                       // the caller wants the devices (simon_batch_out.gpu_slices), by pod id
                             const int pid = __builtin_amdgcn_readfirstlane(order[i0 + il]);
-                            if (lane == 0) cold->gpu_slices[(size_t)s * (size_t)P + (size_t)pid] = booked;
+                            if (lane == 0) gp(cold->gpu_slices)[(size_t)s * (size_t)P + (size_t)pid] = booked;
                         }
                         if (lane == 0) {
                             *(uint4*)(g_fu + (size_t)pstar * 8) = make_uint4(u[0], u[1], u[2], u[3]);
@@ -1924,7 +1956,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         const uint4 Tx = *(const uint4*)rowx;
                         const unsigned oldx = rowx[pstar & 15];
                         const uint2 Fx = *(const uint2*)(g_fine + ((unsigned)(pstar >> 6) * (unsigned)K + (unsigned)kx) * 4u);
-                        const unsigned xfx = fold ? cold->foldx[(unsigned)r_sig * KW + ((unsigned)kx >> 5)] : 0u;
+                        const unsigned xfx = fold ? gp(cold->foldx)[(unsigned)r_sig * KW + ((unsigned)kx >> 5)] : 0u;
                         const SigRow rx = sigs[kx];
                         const unsigned snx = s_sn[kx * Cn + dstar];
                         refresh_sig(kx, kq < K,
@@ -1959,12 +1991,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     um = wave_sum_i64(um);
 #ifdef SIMON_TABLE_PROFILE
     if (lane == 0 && cold->prof)
-        for (int q = 0; q < 24; ++q) cold->prof[(size_t)s * 24 + q] = tp_acc[q];
+        for (int q = 0; q < 24; ++q) gp(cold->prof)[(size_t)s * 24 + q] = tp_acc[q];
 #endif
     if (lane == 0) {
-        cold->unscheduled[s] = unsched;
-        cold->used_cpu[s] = uc * (long long)sc.g_cpu;
-        cold->used_mem[s] = um * (long long)sc.g_mem;
+        gp(cold->unscheduled)[s] = unsched;
+        gp(cold->used_cpu)[s] = uc * (long long)sc.g_cpu;
+        gp(cold->used_mem)[s] = um * (long long)sc.g_mem;
     }
 }
 
