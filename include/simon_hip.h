@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define SIMON_HIP_ABI_VERSION 5   /* v5 (round 4): + simon_min_plan_device, simon_group_collective, simon_explain_local_detail -- additive, every v4 struct unchanged */
+#define SIMON_HIP_ABI_VERSION 6   /* v6 (round 6): + simon_set_scalar_entries, simon_set_pod_priorities, simon_fetch_preempt_risk -- additive, every v5 struct unchanged
+                                     (v5, round 4: + simon_min_plan_device, simon_group_collective, simon_explain_local_detail) */
 
 #define SIMON_MAX_GPU_DEV 8 /* devices per GPU-share node (pkg/type/open-gpu-share/cache/gpunodeinfo.go:34-56) */
 #define SIMON_MAX_SCALAR 4  /* extended ("scalar") resources tracked per node (V/framework/types.go:291) */
@@ -369,6 +370,29 @@ int simon_load_scenarios(simon_ctx* ctx, const simon_scenario* scen, int32_t S,
  * maximum in canonical order) reads it.  Call after simon_load_scenarios; NULL returns to pool order. */
 int simon_set_node_ranks(simon_ctx* ctx, const int32_t* rank /* [S][N] */);
 
+/* ABI v6.  Which extended resources the pod's computed request holds an ENTRY for, whatever the quantity: bit k of entries[p] =
+ * resource k of simon_nodes_soa.scalar_alloc, bit 7 = an entry for a resource no node of the pool advertises.
+ * computePodResourceRequest builds the request with Resource.Add / SetMaxResource (V/framework/plugins/noderesources/fit.go:148-165,
+ * V/framework/types.go:310-326,349-372), which create the ScalarResources map entry even for a ZERO quantity, and fitsRequest's early
+ * return for an all-zero request asks for len(podRequest.ScalarResources) == 0 (fit.go:244-249): a BestEffort pod that lists
+ * `example.com/foo: "0"` is compared with the node's cpu / memory / ephemeral storage like any other pod ("Insufficient cpu" on an
+ * over-committed node), and its zero entry itself is compared too (Allocatable < 0 + Requested, fit.go:275-299).
+ * Call after simon_load_pods (which clears it); NULL = an entry exists exactly where scalar_req is non-zero. */
+int simon_set_scalar_entries(simon_ctx* ctx, const uint8_t* entries /* [P] */);
+
+/* ABI v6.  Pods of unequal priority.  DefaultPreemption (V/scheduler.go:479 -> defaultpreemption/default_preemption.go) runs only
+ * for a pod that FAILED scheduling, and can only evict pods of LOWER priority (selectVictimsOnNode, :578-592).  The engine
+ * does not model evictions; it reports where one could have happened: simon_fetch_preempt_risk()[s] = 1 when in scenario s some
+ * pod failed while a pod of lower priority was already placed (by the scheduler earlier in the stream, bound by Spec.NodeName,
+ * or bound before the stream: init_min_priority = the lowest priority among the pods behind simon_nodes_soa.init_*, INT32_MAX
+ * when there are none).  A scenario with risk 0 is exact -- no pod could have been evicted, the reference ran the same cycles --
+ * and a capacity plan only ever accepts scenarios without a failed pod (pkg/apply/apply.go:218-248), which never carry the flag.
+ * A flagged scenario needs the reference's own path.  priority: spec.priority per pod; NULL = all equal (no risk anywhere).
+ * Call after simon_load_pods (which clears it).  The flags are computed from the placement matrix: a run with priorities
+ * loaded stores it whatever want_placement says. */
+int simon_set_pod_priorities(simon_ctx* ctx, const int32_t* priority /* [P] */, int32_t init_min_priority);
+int simon_fetch_preempt_risk(simon_ctx* ctx, uint8_t* risk /* [S] of the last run; all 0 without priorities */);
+
 /* Run every loaded scenario on the device; results stay in HBM.  This is the timed hot path:
  * per scenario, per pod: findNodesThatFitPod -> prioritizeNodes -> selectHost -> assume
  * (V/core/generic_scheduler.go:131-209, V/scheduler.go:371).  want_placement: bit 0 (SIMON_WANT_PLACEMENT) stores the
@@ -469,6 +493,10 @@ int simon_group_run_batch(simon_group* g, const simon_scenario* scen, int32_t S,
                           simon_batch_out* out);
 int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* placement);
 int simon_group_fetch_gpu_slices(simon_group* g, int32_t scenario, uint64_t* slices);   /* simon_fetch_gpu_slices on the member that ran it */
+/* ABI v6: simon_set_scalar_entries / simon_set_pod_priorities on every member, simon_fetch_preempt_risk in global scenario order */
+int simon_group_set_scalar_entries(simon_group* g, const uint8_t* entries /* [P] */);
+int simon_group_set_pod_priorities(simon_group* g, const int32_t* priority /* [P] */, int32_t init_min_priority);
+int simon_group_fetch_preempt_risk(simon_group* g, uint8_t* risk /* [S] */);
 
 /* The add-nodes search over every device: minimum n_nodes among the scenarios of the last run that schedule every pod
  * within the caps (satisfyResourceSetting, pkg/apply/apply.go:689-775); ties go to the lowest scenario index, exactly

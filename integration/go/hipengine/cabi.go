@@ -23,6 +23,7 @@ import "C"
 
 import (
 	"fmt"
+	"math"
 	"unsafe"
 )
 
@@ -244,7 +245,28 @@ func (c *Ctx) Load(f *Flat) error {
 	if err := c.check(C.simon_load_pods(c.h, &p), "simon_load_pods"); err != nil {
 		return err
 	}
+	// ABI v6: what travels next to simon_pods_soa -- ScalarResources entries of quantity 0, pods of unequal priority
+	if f.ScalarEntries != nil {
+		if err := c.check(C.simon_set_scalar_entries(c.h, a.u8(f.ScalarEntries)), "simon_set_scalar_entries"); err != nil {
+			return err
+		}
+	}
+	if f.Priority != nil {
+		if err := c.check(C.simon_set_pod_priorities(c.h, a.i32(f.Priority), C.int32_t(math.MaxInt32)), "simon_set_pod_priorities"); err != nil {
+			return err
+		}
+	}
 	return c.check(C.simon_load_class_tables(c.h, &t), "simon_load_class_tables")
+}
+
+// FetchPreemptRisk: per scenario of the last run, 1 = some pod failed while a pod of lower priority was placed -- DefaultPreemption
+// (V/scheduler.go:479) could have evicted there and the scenario needs the reference's own path; 0 = exact.
+func (c *Ctx) FetchPreemptRisk(S int) ([]uint8, error) {
+	risk := make([]uint8, S)
+	if S == 0 {
+		return risk, nil
+	}
+	return risk, c.check(C.simon_fetch_preempt_risk(c.h, (*C.uint8_t)(unsafe.Pointer(&risk[0]))), "simon_fetch_preempt_risk")
 }
 
 // a []Scenario has the layout of simon_scenario[] and holds no pointers: it may be passed directly
@@ -424,7 +446,26 @@ func (g *Group) Load(f *Flat) error {
 	if err := g.check(C.simon_group_load_pods(g.h, &p), "simon_group_load_pods"); err != nil {
 		return err
 	}
+	if f.ScalarEntries != nil { // ABI v6, as Ctx.Load
+		if err := g.check(C.simon_group_set_scalar_entries(g.h, a.u8(f.ScalarEntries)), "simon_group_set_scalar_entries"); err != nil {
+			return err
+		}
+	}
+	if f.Priority != nil {
+		if err := g.check(C.simon_group_set_pod_priorities(g.h, a.i32(f.Priority), C.int32_t(math.MaxInt32)), "simon_group_set_pod_priorities"); err != nil {
+			return err
+		}
+	}
 	return g.check(C.simon_group_load_class_tables(g.h, &t), "simon_group_load_class_tables")
+}
+
+// FetchPreemptRisk: Ctx.FetchPreemptRisk over the group, in the caller's scenario order.
+func (g *Group) FetchPreemptRisk(S int) ([]uint8, error) {
+	risk := make([]uint8, S)
+	if S == 0 {
+		return risk, nil
+	}
+	return risk, g.check(C.simon_group_fetch_preempt_risk(g.h, (*C.uint8_t)(unsafe.Pointer(&risk[0]))), "simon_group_fetch_preempt_risk")
 }
 
 // RunBatch deals the scenarios over the members, runs them concurrently, and returns results in the caller's order.

@@ -18,8 +18,8 @@ package hipengine
 // PreferNoSchedule), NodeAffinity (required and preferred), Open-Gpu-Share incl. pods that arrive with a gpu-index annotation, pod
 // (anti-)affinity (required and preferred), topology spread constraints (explicit, and the system defaults of pods a Service /
 // ReplicaSet / StatefulSet selects), host ports, Open-Local volumes: flatten_terms.go fills those tables.  Supports() answers false
-// (the Go path runs) only for what NEITHER flattening models: scheduler configs / extra registries, pods of different priorities
-// (DefaultPreemption could evict), nodes with a preferAvoidPods annotation or listed images (NodePreferAvoidPods / ImageLocality
+// (the Go path runs) only for what NEITHER flattening models: scheduler configs / extra registries (pods of different priorities are
+// accepted since ABI v6: only a scenario in which DefaultPreemption could have acted comes back as ErrNeedsReference), nodes with a preferAvoidPods annotation or listed images (NodePreferAvoidPods / ImageLocality
 // would not be constants; flatten.py takes them for one cluster size), more extended resources / spread constraints / volumes
 // than the ABI's fixed widths.  Whether a supported input then runs on the score-table kernel or the all-feature kernel is the
 // library's decision (simon_get_stats), never visible in a result.
@@ -36,6 +36,7 @@ import (
 
 	corev1 "k8s.io/api/core/v1"
 	"k8s.io/apimachinery/pkg/api/resource"
+	"k8s.io/component-helpers/scheduling/corev1/nodeaffinity"
 	v1helper "k8s.io/kubernetes/pkg/apis/core/v1/helper"
 	pluginhelper "k8s.io/kubernetes/pkg/scheduler/framework/plugins/helper"
 	framework "k8s.io/kubernetes/pkg/scheduler/framework"
@@ -76,7 +77,6 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 	// flattening of affinity / spread constraints / host ports / local volumes (flatten_terms.go) is the youngest and largest part of
 	// this never-compiled package -- a first deployment can run engine_test.go with the switch off, then on.
 	termsOff := os.Getenv("SIMON_ENGINE_TERMS") == "0"
-	var prio *int32
 	for _, p := range pods {
 		s := &p.Spec
 		if termsOff && usesTermTables(p, cluster) {
@@ -85,12 +85,16 @@ func Supports(cluster simulator.ResourceTypes, apps []simulator.AppResource, o O
 		if len(s.TopologySpreadConstraints) > 2*maxSpread { // at most SIMON_MAX_SPREAD hard and as many soft constraints (fillTerms checks each kind)
 			return false
 		}
-		if prio != nil && s.Priority != nil && *prio != *s.Priority { // DefaultPreemption could evict
-			return false
+		// preferred node-affinity terms that do not parse make NodeAffinity.Score fail the whole scheduling cycle in the reference
+		// (nodeaffinity/node_affinity.go:96-103): the class would silently score 0 here (staticScores), so such pods stay on the Go path
+		if a := s.Affinity; a != nil && a.NodeAffinity != nil && len(a.NodeAffinity.PreferredDuringSchedulingIgnoredDuringExecution) != 0 {
+			if _, err := nodeaffinity.NewPreferredSchedulingTerms(a.NodeAffinity.PreferredDuringSchedulingIgnoredDuringExecution); err != nil {
+				return false
+			}
 		}
-		if s.Priority != nil {
-			prio = s.Priority
-		}
+		// (pods of unequal spec.priority are accepted since ABI v6: DefaultPreemption can only act in a scenario where a pod FAILS while a
+		// pod of lower priority is placed; the engine flags exactly those -- simon_fetch_preempt_risk -- and SimulateBatch returns
+		// ErrNeedsReference for them, nothing else of the batch)
 	}
 	for _, n := range cluster.Nodes {
 		if _, ok := n.Annotations["scheduler.alpha.kubernetes.io/preferAvoidPods"]; ok {
@@ -196,6 +200,28 @@ func flatten(pool []*corev1.Node, nCluster int, pods []*corev1.Pod, cluster simu
 		req := podRequest(p)
 		for k, name := range names {
 			f.ScalarReq[k*P+pi] = req.ScalarResources[corev1.ResourceName(name)]
+		}
+		// the map's ENTRIES, quantities of 0 included: fitsRequest's early return asks for len(ScalarResources) == 0 and its loop
+		// compares every entry (fit.go:244-249, 275-299; Resource.Add creates the entry whatever the quantity, V/framework/types.go:320-322)
+		var ent uint8
+		for name := range req.ScalarResources {
+			if k := sort.SearchStrings(names, string(name)); k < len(names) && names[k] == string(name) {
+				ent |= 1 << uint(k)
+			} else {
+				ent |= 0x80
+			}
+		}
+		if ent != 0 && f.ScalarEntries == nil {
+			f.ScalarEntries = make([]uint8, P)
+		}
+		if f.ScalarEntries != nil {
+			f.ScalarEntries[pi] = ent
+		}
+		if p.Spec.Priority != nil && *p.Spec.Priority != 0 && f.Priority == nil {
+			f.Priority = make([]int32, P) // (pods before this one: priority 0, the nil default of podutil.GetPodPriority)
+		}
+		if f.Priority != nil && p.Spec.Priority != nil {
+			f.Priority[pi] = *p.Spec.Priority
 		}
 		gi, _ := gpuIndexOf(p) // Supports() has refused the lists that do not pack
 		if gpushareutils.GetGpuMemoryFromPodAnnotation(p) <= 0 {
@@ -468,7 +494,8 @@ var _ = resource.Quantity{} // Quantity methods used above come from this packag
 
 const maxScalar = 4 // SIMON_MAX_SCALAR
 
-// scalarNames interns the extended resources some pod REQUESTS (non-zero entries of framework.Resource.ScalarResources: everything but
+// scalarNames interns the extended resources some pod REQUESTS a quantity of (non-zero entries of framework.Resource.ScalarResources;
+// entries of quantity 0 travel as Flat.ScalarEntries, ABI v6: everything but
 // cpu / memory / ephemeral-storage, V/framework/types.go:295-326), sorted; ok = false beyond SIMON_MAX_SCALAR.  What nodes merely
 // advertise (the gpu-share nodes' alibabacloud.com/gpu-mem, gpu-count) never reaches fitsRequest, which walks the POD's scalar
 // requests (fit.go:286-299) -- the same rule as open-simulator_amd/flatten.py.
@@ -586,8 +613,17 @@ func Simulate(cluster simulator.ResourceTypes, apps []simulator.AppResource) (*s
 	if err != nil {
 		return nil, err
 	}
+	if res[0] == nil {
+		return nil, ErrNeedsReference
+	}
 	return res[0], nil
 }
+
+// ErrNeedsReference: the scenario is one in which DefaultPreemption could have evicted a placed pod (pods of unequal priority: some pod
+// failed while a pod of lower priority was placed -- simon_fetch_preempt_risk).  The engine does not model evictions; the caller runs
+// the reference's own path for that size (pkg/simulator/core.go: the branch below the SIMON_ENGINE switch).  SimulateBatch leaves
+// such a size's slot nil.
+var ErrNeedsReference = fmt.Errorf("hipengine: a pod failed while a pod of lower priority was placed (DefaultPreemption may evict): reference path")
 
 // SimulateBatch evaluates every candidate cluster size of the add-nodes loop at once: cluster.Nodes plus the first k
 // clones of newNode for every k in newNodeCounts, on the given devices.  It returns one SimulateResult per size (what
@@ -629,6 +665,7 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 	}
 	var out *BatchOut
 	var plan Plan
+	var risk []uint8 // per scenario: DefaultPreemption could have acted (pods of unequal priority, ABI v6); nil = one priority for all
 	maxCPU, maxMem, maxVG := envCap("MaxCPU"), envCap("MaxMemory"), envCap("MaxVG") // simontype.EnvMaxCPU / EnvMaxMemory / EnvMaxVG
 	var explain func(s int, k int) (int, []int32, [][]uint16, error)
 	if len(devices) > 1 && len(scen) >= len(devices) {
@@ -646,6 +683,11 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 		if plan, err = g.MinPlan(maxCPU, maxMem, maxVG); err != nil {
 			return nil, -1, err
 		}
+		if f.Priority != nil {
+			if risk, err = g.FetchPreemptRisk(len(scen)); err != nil {
+				return nil, -1, err
+			}
+		}
 	}
 	c, err := NewCtx(int(devices[0])) // single device, and the FitError replay of any size
 	if err != nil {
@@ -662,11 +704,22 @@ func SimulateBatch(cluster simulator.ResourceTypes, apps []simulator.AppResource
 		if plan, err = c.MinPlan(maxCPU, maxMem, maxVG); err != nil {
 			return nil, -1, err
 		}
+		if f.Priority != nil {
+			if risk, err = c.FetchPreemptRisk(len(scen)); err != nil {
+				return nil, -1, err
+			}
+		}
 	}
 	explain = func(s int, k int) (int, []int32, [][]uint16, error) { return c.Explain(int(scen[s].NNodes), order, k) }
 	results := make([]*simulator.SimulateResult, len(scen))
 	for s := range scen {
 		n := int(scen[s].NNodes)
+		if risk != nil && risk[s] != 0 {
+			// a pod failed while a pod of lower priority was placed: the reference may have evicted a victim there (V/scheduler.go:479).
+			// The scenario's slot stays nil; the caller runs the reference's own Simulate for THIS size (Simulate does it itself,
+			// SimulateBatch's callers see ErrNeedsReference through NeedsReference(results)).  A capacity plan never accepts such a size.
+			continue
+		}
 		res := &simulator.SimulateResult{}
 		for j := 0; j < n; j++ {
 			res.NodeStatus = append(res.NodeStatus, simulator.NodeStatus{Node: pool[j]})

@@ -49,6 +49,8 @@ type Flat struct {
 	PodGpuMem                                         []int64
 	PodGpuCnt                                         []int32
 	PodGpuIndex                                       []uint32 // [P] gpu-index annotation the pod arrives with, packed (PackGpuIndex); nil = none
+	ScalarEntries                                     []uint8  // [P] ABI v6 (simon_set_scalar_entries): bit k = the request holds an ENTRY for ScalarNames[k], bit 7 = for a resource nobody requests a quantity of; nil = none beyond the quantities
+	Priority                                          []int32  // [P] ABI v6 (simon_set_pod_priorities): spec.priority; nil = all equal
 	// ---- simon_class_tables ----
 	Cp, Cn                                            int
 	StaticMask                                        []uint64 // [Cp][ceil(N/64)]

@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_GPU_DEV = 8
 MAX_SCALAR = 4
 
@@ -202,6 +202,9 @@ class Problem:
     gpu_mem: Optional[np.ndarray] = None
     pod_gpu_cnt: Optional[np.ndarray] = None
     gpu_index: Optional[np.ndarray] = None         # [P] uint32: gpu-index annotation the pod arrives with, packed (pack_gpu_index)
+    scalar_entries: Optional[np.ndarray] = None    # [P] uint8, ABI v6: bit k = the request holds an ENTRY for extended resource k (bit 7: one no node tracks), a zero quantity included
+    priority: Optional[np.ndarray] = None          # [P] int32, ABI v6: spec.priority (None: all equal)
+    init_min_priority: int = 0x7fffffff            # lowest priority among the pods bound before the stream (behind init_*)
     # class tables
     n_pod_classes: int = 1
     n_node_classes: int = 1
@@ -293,6 +296,8 @@ class Problem:
         for name in ("pod_class", "preset_node", "gate_node", "pod_gpu_cnt", "pin_node"):
             setattr(self, name, _arr(getattr(self, name), i32, (P,)))
         self.gpu_index = _arr(self.gpu_index, np.uint32, (P,))
+        self.scalar_entries = _arr(self.scalar_entries, np.uint8, (P,))
+        self.priority = _arr(self.priority, i32, (P,))
         self.scalar_req = _arr(self.scalar_req, i64, (K, P)) if self.scalar_req is not None else None
         Cp, Cn = self.n_pod_classes, self.n_node_classes
         words = (N + 63) // 64
@@ -416,6 +421,7 @@ class BatchResult:
     placement: Optional[np.ndarray]
     used_vg: Optional[np.ndarray] = None
     gpu_slices: Optional[np.ndarray] = None        # [S][P] uint64: byte d = gpu-mem slices booked on device d (gpu_ids_of)
+    preempt_risk: Optional[np.ndarray] = None      # [S] uint8 (oracle runs; the library: Context.fetch_preempt_risk)
 
     def c_out(self) -> BatchOut:
         o = BatchOut()
@@ -477,6 +483,8 @@ EXPORTS = [
     "simon_load_nodes", "simon_load_pods", "simon_load_class_tables", "simon_load_scenarios", "simon_run_loaded",
     "simon_fetch_results", "simon_fetch_placement", "simon_fetch_gpu_slices", "simon_run_batch", "simon_min_plan", "simon_min_plan_vg", "simon_min_plan_device", "simon_explain", "simon_set_node_ranks",
     "simon_get_stats", "simon_device_results", "simon_explain_loaded", "simon_explain_local_detail",
+    "simon_set_scalar_entries", "simon_set_pod_priorities", "simon_fetch_preempt_risk",
+    "simon_group_set_scalar_entries", "simon_group_set_pod_priorities", "simon_group_fetch_preempt_risk",
     "simon_group_create", "simon_group_destroy", "simon_group_last_error", "simon_group_size", "simon_group_member",
     "simon_group_load_nodes", "simon_group_load_pods", "simon_group_load_class_tables", "simon_group_load_scenarios",
     "simon_group_run_loaded", "simon_group_fetch_results", "simon_group_run_batch", "simon_group_fetch_placement", "simon_group_fetch_gpu_slices",
@@ -519,6 +527,14 @@ def load_library(path: Optional[str] = None):
     lib.simon_explain.argtypes = [vp, Scenario, _p32, _p32, _pu16, C.c_int32]
     lib.simon_explain_loaded.argtypes = [vp, C.c_int32, _p32, _pu16, C.c_int32]
     lib.simon_explain_local_detail.argtypes = [vp, _p64, C.c_int32]
+    _pu8 = C.POINTER(C.c_uint8)
+    for pre in ("simon_", "simon_group_"):
+        getattr(lib, pre + "set_scalar_entries").argtypes = [vp, _pu8]
+        getattr(lib, pre + "set_scalar_entries").restype = C.c_int
+        getattr(lib, pre + "set_pod_priorities").argtypes = [vp, _p32, C.c_int32]
+        getattr(lib, pre + "set_pod_priorities").restype = C.c_int
+        getattr(lib, pre + "fetch_preempt_risk").argtypes = [vp, _pu8]
+        getattr(lib, pre + "fetch_preempt_risk").restype = C.c_int
     lib.simon_group_create.restype = vp
     lib.simon_group_create.argtypes = [_p32, C.c_int32]
     lib.simon_group_destroy.argtypes = [vp]
@@ -601,6 +617,10 @@ class Context:
         n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
         self._check(self.lib.simon_load_nodes(self.h, C.byref(n)), "simon_load_nodes")
         self._check(self.lib.simon_load_pods(self.h, C.byref(p)), "simon_load_pods")
+        if prob.scalar_entries is not None:
+            self._check(self.lib.simon_set_scalar_entries(self.h, _ptr(prob.scalar_entries, C.c_uint8)), "simon_set_scalar_entries")
+        if prob.priority is not None:
+            self._check(self.lib.simon_set_pod_priorities(self.h, _ptr(prob.priority, C.c_int32), int(prob.init_min_priority)), "simon_set_pod_priorities")
         self._check(self.lib.simon_load_class_tables(self.h, C.byref(t)), "simon_load_class_tables")
         self.problem = prob
 
@@ -626,6 +646,13 @@ class Context:
         row = np.zeros(self.problem.n_pods, np.uint64)
         self._check(self.lib.simon_fetch_gpu_slices(self.h, int(scenario), _ptr(row, C.c_uint64)), "simon_fetch_gpu_slices")
         return row
+
+    def fetch_preempt_risk(self) -> np.ndarray:
+        """[S] uint8: 1 = some pod failed while a pod of lower priority was placed -- DefaultPreemption could have evicted there, the
+        scenario needs the reference's own path; 0 = exact (include/simon_hip.h: simon_fetch_preempt_risk)."""
+        risk = np.zeros(self.S, np.uint8)
+        self._check(self.lib.simon_fetch_preempt_risk(self.h, _ptr(risk, C.c_uint8)), "simon_fetch_preempt_risk")
+        return risk
 
     def fetch_placement(self, scenario: int) -> np.ndarray:
         row = np.zeros(self.problem.n_pods, np.int32)
@@ -761,6 +788,10 @@ class Group:
         n, p, t = prob.c_nodes(), prob.c_pods(), prob.c_tables()
         self._check(self.lib.simon_group_load_nodes(self.h, C.byref(n)), "simon_group_load_nodes")
         self._check(self.lib.simon_group_load_pods(self.h, C.byref(p)), "simon_group_load_pods")
+        if prob.scalar_entries is not None:
+            self._check(self.lib.simon_group_set_scalar_entries(self.h, _ptr(prob.scalar_entries, C.c_uint8)), "simon_group_set_scalar_entries")
+        if prob.priority is not None:
+            self._check(self.lib.simon_group_set_pod_priorities(self.h, _ptr(prob.priority, C.c_int32), int(prob.init_min_priority)), "simon_group_set_pod_priorities")
         self._check(self.lib.simon_group_load_class_tables(self.h, C.byref(t)), "simon_group_load_class_tables")
         self.problem = prob
 
@@ -795,6 +826,11 @@ class Group:
         row = np.zeros(self.problem.n_pods, np.uint64)
         self._check(self.lib.simon_group_fetch_gpu_slices(self.h, int(scenario), _ptr(row, C.c_uint64)), "simon_group_fetch_gpu_slices")
         return row
+
+    def fetch_preempt_risk(self) -> np.ndarray:
+        risk = np.zeros(self.S, np.uint8)
+        self._check(self.lib.simon_group_fetch_preempt_risk(self.h, _ptr(risk, C.c_uint8)), "simon_group_fetch_preempt_risk")
+        return risk
 
     def min_plan(self, max_cpu_pct: int = 100, max_mem_pct: int = 100, max_vg_pct: int = 100):
         plan, vg = Plan(), C.c_int32(0)

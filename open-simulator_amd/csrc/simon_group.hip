@@ -110,7 +110,11 @@ void rccl_setup(simon_group* g) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j)
             if (g->device[i] == g->device[j]) return;           // one communicator rank per device
-    g->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // the copy the host process has mapped already, if any (a Python host with torch: torch/lib/librccl.so -- two copies of RCCL in
+    // one process would each bring their own bootstrap state), else the system's
+    g->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!g->rccl) g->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!g->rccl) g->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!g->rccl) g->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!g->rccl) return;
     g->p_init_all = reinterpret_cast<decltype(g->p_init_all)>(dlsym(g->rccl, "ncclCommInitAll"));
@@ -120,7 +124,9 @@ void rccl_setup(simon_group* g) {
     g->p_abort = reinterpret_cast<decltype(g->p_abort)>(dlsym(g->rccl, "ncclCommAbort"));
     g->p_group_start = reinterpret_cast<decltype(g->p_group_start)>(dlsym(g->rccl, "ncclGroupStart"));
     g->p_group_end = reinterpret_cast<decltype(g->p_group_end)>(dlsym(g->rccl, "ncclGroupEnd"));
-    if (!g->p_init_all || !g->p_all_gather || !g->p_destroy || !g->p_group_start || !g->p_group_end) return;
+    // ncclCommAbort is REQUIRED: it is what ends a half-entered collective on the failure path (without it the communicators would stay
+    // non-null and ncclCommDestroy on them could block in rccl_teardown) -- a library without the symbol reduces on the host
+    if (!g->p_init_all || !g->p_all_gather || !g->p_destroy || !g->p_group_start || !g->p_group_end || !g->p_abort) return;
     try { g->comm.assign(n, nullptr); g->d_gather.assign(n, nullptr); } catch (...) { return; }
     std::vector<int> devs(g->device.begin(), g->device.end());
     if (g->p_init_all(g->comm.data(), n, devs.data()) != ncclSuccess) { g->comm.clear(); return; }
@@ -195,6 +201,17 @@ int simon_group_load_pods(simon_group* g, const simon_pods_soa* pods) {
     g->have_results = false;
     g->P = pods->n_pods;
     return on_all(g, "load_pods", [&](int i) { return simon_load_pods(g->ctx[i], pods); });
+}
+
+int simon_group_set_scalar_entries(simon_group* g, const uint8_t* entries) {
+    if (!g) return SIMON_EINVAL;
+    g->have_results = false;
+    return on_all(g, "set_scalar_entries", [&](int i) { return simon_set_scalar_entries(g->ctx[i], entries); });
+}
+
+int simon_group_set_pod_priorities(simon_group* g, const int32_t* priority, int32_t init_min_priority) {
+    if (!g) return SIMON_EINVAL;
+    return on_all(g, "set_pod_priorities", [&](int i) { return simon_set_pod_priorities(g->ctx[i], priority, init_min_priority); });
 }
 
 int simon_group_load_class_tables(simon_group* g, const simon_class_tables* tables) {
@@ -291,6 +308,19 @@ int simon_group_fetch_placement(simon_group* g, int32_t scenario, int32_t* place
     return rc ? gfail(g, rc, "fetch_placement: member %d: %s", i, simon_last_error(g->ctx[i])) : SIMON_OK;
 }
 
+int simon_group_fetch_preempt_risk(simon_group* g, uint8_t* risk) {
+    if (!g || !risk) return SIMON_EINVAL;
+    if (!g->have_results) return gfail(g, SIMON_ESTATE, "group fetch_preempt_risk: nothing has run");
+    const int n = (int)g->ctx.size();
+    return on_all(g, "fetch_preempt_risk", [&](int i) {
+        std::vector<uint8_t> r(g->part[i].size());
+        int rc = simon_fetch_preempt_risk(g->ctx[i], r.data());
+        if (rc) return rc;
+        for (size_t k = 0; k < r.size(); ++k) risk[k * n + i] = r[k];       // member-local index k = global scenario k * n + i
+        return (int)SIMON_OK;
+    });
+}
+
 int simon_group_fetch_gpu_slices(simon_group* g, int32_t scenario, uint64_t* slices) {
     if (!g || !slices) return SIMON_EINVAL;
     if (!g->have_results) return gfail(g, SIMON_ESTATE, "group fetch_gpu_slices: nothing has run");
@@ -321,7 +351,7 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
         if (nr == ncclSuccess) {
             for (int i = 0; i < n; ++i) {
                 const ncclResult_t r = g->p_all_gather(d_key[i], g->d_gather[i], 1, ncclUint64, g->comm[i], (hipStream_t)stream[i]);
-                if (r != ncclSuccess && nr == ncclSuccess) { nr = r; bad = i; }
+                if (r != ncclSuccess) { nr = r; bad = i; break; }   // (no further rank is enqueued behind a failed one; the group is still closed, then aborted)
             }
             const ncclResult_t r = g->p_group_end();
             if (r != ncclSuccess && nr == ncclSuccess) nr = r;
@@ -339,7 +369,7 @@ int simon_group_min_plan(simon_group* g, int32_t max_cpu_pct, int32_t max_mem_pc
             he = hipErrorUnknown;
         if (nr != ncclSuccess || he != hipSuccess) {
             // first-run safety: never leave a half-entered collective behind
-            if (g->p_abort) for (ncclComm_t& c : g->comm) if (c) { (void)g->p_abort(c); c = nullptr; }
+            for (ncclComm_t& c : g->comm) if (c) { (void)g->p_abort(c); c = nullptr; }
             g->comm_ok = false;
             (void)gfail(g, SIMON_ENODEV, "min_plan: RCCL all-gather failed (member %d: %s); reduced on the host instead", bad,
                         nr != ncclSuccess ? (g->p_errstr ? g->p_errstr(nr) : "nccl error") : hipGetErrorString(he));

@@ -176,6 +176,9 @@ struct simon_ctx : simon::HostInputs {
     DevBuf<int32_t> d_orders, d_perm;
     // outputs
     DevBuf<int32_t> d_unsched, d_place;
+    DevBuf<int32_t> d_prio;                       // ABI v6: spec.priority per pod (simon_set_pod_priorities)
+    DevBuf<unsigned char> d_risk;                 // [S] DefaultPreemption could have acted in the scenario (simon_fetch_preempt_risk)
+    bool prio_staged = false, have_risk = false;
     DevBuf<int64_t> d_used_cpu, d_used_mem, d_used_vg;
     DevBuf<unsigned long long> d_plan;
     bool have_results = false, have_placement = false, have_slices = false;
@@ -793,6 +796,7 @@ int stage_narrow(simon_ctx* c) {
         r.gate = c->p_gate[p];
         bool no_xres = c->p_req_eph[p] == 0;                     // fit.go:244-249: the early return needs EVERY request to be zero
         for (int k = 0; k < c->K && no_xres; ++k) no_xres = c->p_scalar[(size_t)k * c->P + p] == 0;
+        if (!c->p_entries.empty() && c->p_entries[p]) no_xres = false;   // ... and to hold no ScalarResources ENTRY, not even one of quantity 0 (simon_set_scalar_entries)
         r.flags = (c->p_req_cpu[p] == 0 && c->p_req_mem[p] == 0 && no_xres) ? 1u : 0u;
     }
     std::vector<int32_t> raw32(c->simon_raw.begin(), c->simon_raw.end());
@@ -1251,6 +1255,47 @@ int stage(simon_ctx* c) {
     return SIMON_OK;
 }
 
+// ---- DefaultPreemption could have acted (ABI v6: simon_set_pod_priorities / simon_fetch_preempt_risk) ----------------------------------
+// One wave per scenario walks the pods in scheduling order, 64 steps at a time: risk = some pod failed (SIMON_UNSCHEDULED) while a pod of
+// LOWER priority was placed before it -- by the scheduler, by Spec.NodeName, or before the stream (init_min).  PostFilter runs only for a
+// failed pod (V/scheduler.go:479) and selectVictimsOnNode only considers pods of lower priority (default_preemption.go:578-592): without
+// such a pair no eviction can have happened in the reference and the scenario's result is exact.  HBM-bound: 12 B per pod-step.
+__global__ __launch_bounds__(64) void preempt_risk_kernel_impl(const int32_t* __restrict__ place, const int32_t* __restrict__ orders,
+                                                               const ScenarioDesc* __restrict__ scen, const int32_t* __restrict__ prio, int P,
+                                                               int init_min, unsigned char* __restrict__ risk) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int32_t* __restrict__ order = orders + (size_t)scen[s].order_id * P;
+    const int32_t* __restrict__ pl = place + (size_t)s * P;
+    int runmin = init_min;
+    bool bad = false;
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int idx = i0 + lane;
+        int placed_prio = 0x7fffffff, mine = 0;
+        bool failed = false;
+        if (idx < P) {
+            const int pod = order[idx];
+            const int v = pl[pod];
+            mine = prio[pod];
+            if (v >= 0) placed_prio = mine;
+            failed = v == SIMON_UNSCHEDULED;
+        }
+        int inc = placed_prio;                                            // inclusive prefix minimum over the 64 steps
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc = t < inc ? t : inc;
+        }
+        int exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 0x7fffffff;
+        exc = exc < runmin ? exc : runmin;                                // lowest priority among everything placed before this step
+        bad = bad || (failed && mine > exc);
+        const int last = __shfl(inc, 63, 64);
+        runmin = last < runmin ? last : runmin;
+    }
+    const bool any = __ballot(bad) != 0ull;
+    if (lane == 0) risk[s] = any ? 1 : 0;
+}
+
 // ---- min-plan reduction (pkg/apply/apply.go:203-259 + satisfyResourceSetting :689-775) --------
 __global__ void plan_kernel(const ScenarioDesc* __restrict__ scen, int S, const int32_t* __restrict__ unsched,
                             const int64_t* __restrict__ used_cpu, const int64_t* __restrict__ used_mem,
@@ -1439,7 +1484,32 @@ int simon_load_pods(simon_ctx* c, const simon_pods_soa* pd) {
         if (c->p_pin[p] >= 0 && c->p_preset[p] >= 0) return fail(c, SIMON_EINVAL, "pod %d: both preset_node and pin_node", p);
         c->has_pin = c->has_pin || c->p_pin[p] >= 0;
     }
+    c->p_entries.clear(); c->p_priority.clear(); c->init_min_priority = 0x7fffffff;   // (ABI v6 additions: set after the pods)
     c->have_pods = true; c->staged = false; c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_set_scalar_entries(simon_ctx* c, const uint8_t* entries) {
+    if (!c) return SIMON_EINVAL;
+    if (!c->have_pods) return fail(c, SIMON_ESTATE, "set_scalar_entries: load pods first");
+    if (entries) {
+        c->p_entries.assign(entries, entries + c->P);
+        for (int p = 0; p < c->P; ++p) {
+            if (c->p_entries[p] & 0x70u & ~((1u << SIMON_MAX_SCALAR) - 1u)) return fail(c, SIMON_EINVAL, "pod %d: scalar_entries 0x%x names a resource beyond SIMON_MAX_SCALAR", p, c->p_entries[p]);
+            for (int k = 0; k < c->K; ++k)                    // a non-zero quantity IS an entry
+                if (c->p_scalar[(size_t)k * c->P + p] != 0) c->p_entries[p] |= (uint8_t)(1u << k);
+        }
+    } else c->p_entries.clear();
+    c->staged = false; c->wide_staged = false; c->have_results = false;
+    return SIMON_OK;
+}
+
+int simon_set_pod_priorities(simon_ctx* c, const int32_t* priority, int32_t init_min_priority) {
+    if (!c) return SIMON_EINVAL;
+    if (!c->have_pods) return fail(c, SIMON_ESTATE, "set_pod_priorities: load pods first");
+    if (priority) c->p_priority.assign(priority, priority + c->P); else c->p_priority.clear();
+    c->init_min_priority = priority ? init_min_priority : 0x7fffffff;
+    c->prio_staged = false; c->have_risk = false;
     return SIMON_OK;
 }
 
@@ -1728,7 +1798,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
     // bit 1: also record the devices Reserve books for every placed GPU pod (only problems with GPU requests have any)
     const bool want_slices = (want_placement & SIMON_WANT_GPU_SLICES) != 0 && c->has_gpu;
     want_placement &= SIMON_WANT_PLACEMENT;
-    c->have_slices = false;
+    const bool want_risk = !c->p_priority.empty();               // pods of unequal priority: the flags come from the placement matrix
+    if (want_risk) want_placement = SIMON_WANT_PLACEMENT;
+    c->have_slices = false; c->have_risk = false;
     if (want_slices) {
         HIP_TRY(c, c->d_gpu_slices.ensure((size_t)S * P));
         HIP_TRY(c, hipMemsetAsync(c->d_gpu_slices.p, 0, (size_t)S * P * 8, c->stream));
@@ -1915,6 +1987,18 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     }
+    if (want_risk) {                                             // (behind ev1: not part of kernel_ms; one wave per scenario, P / 64 steps)
+        if (!c->prio_staged) {
+            HIP_TRY(c, c->d_prio.ensure((size_t)P));
+            HIP_TRY(c, hipMemcpyAsync(c->d_prio.p, c->p_priority.data(), (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
+            c->prio_staged = true;
+        }
+        HIP_TRY(c, c->d_risk.ensure((size_t)S));
+        hipLaunchKernelGGL(preempt_risk_kernel_impl, dim3(S), dim3(64), 0, c->stream, c->d_place.p, c->d_orders.p, c->d_scen.p, c->d_prio.p, P,
+                           c->init_min_priority, c->d_risk.p);
+        HIP_TRY(c, hipGetLastError());
+        c->have_risk = true;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
@@ -1995,6 +2079,16 @@ int simon_fetch_gpu_slices(simon_ctx* c, int32_t scenario, uint64_t* slices) {
     if (!c->have_slices) return fail(c, SIMON_ESTATE, "fetch_gpu_slices: the last run did not record GPU devices (SIMON_WANT_GPU_SLICES)");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(slices, c->d_gpu_slices.p + (size_t)scenario * c->P, (size_t)c->P * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIMON_OK;
+}
+
+int simon_fetch_preempt_risk(simon_ctx* c, uint8_t* risk) {
+    if (!c || !risk) return SIMON_EINVAL;
+    if (!c->have_results) return fail(c, SIMON_ESTATE, "fetch_preempt_risk: nothing has run");
+    if (!c->have_risk) { memset(risk, 0, (size_t)c->S); return SIMON_OK; }       // one priority for all: DefaultPreemption finds no victim anywhere
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(risk, c->d_risk.p, (size_t)c->S, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SIMON_OK;
 }

@@ -25,6 +25,9 @@ struct HostInputs {
     std::vector<int64_t> p_req_cpu, p_req_mem, p_req_eph, p_nz_cpu, p_nz_mem, p_scalar, p_gpu_mem;
     std::vector<int32_t> p_cls, p_preset, p_gate, p_gpu_cnt, p_pin;
     std::vector<uint32_t> p_gpu_index;   // packed preset device ids (simon_pods_soa.gpu_index), 0 = none
+    std::vector<uint8_t> p_entries;      // ABI v6 (simon_set_scalar_entries): bit k = the request holds an ENTRY for extended resource k (bit 7: one no node tracks); empty = where scalar_req != 0
+    std::vector<int32_t> p_priority;     // ABI v6 (simon_set_pod_priorities): spec.priority; empty = all equal
+    int32_t init_min_priority = 0x7fffffff;
     bool has_pin = false;         // some pod is pinned to one node (simon_pods_soa.pin_node)
     std::vector<uint64_t> static_mask;
     std::vector<uint8_t> static_reason;
@@ -93,7 +96,8 @@ struct WideSig {
 };
 static_assert(sizeof(WideSig) == 96, "WideSig must be 96 bytes");
 constexpr int kMaxWideSigs = 1024;   // more distinct signatures than this: the kernel evaluates every node every cycle
-constexpr uint32_t kPodZero = 1u;      // all-zero request incl. scalars (fit.go:244-249)
+constexpr uint32_t kPodZero = 1u;      // all-zero request incl. scalars (fit.go:244-249): no cpu / memory / ephemeral storage and NO ScalarResources entry
+constexpr uint32_t kPodEntry0 = 1u << 24;   // << k: the request holds an entry for extended resource k although its quantity is 0 (compared all the same, fit.go:275-299)
 constexpr uint32_t kPodTerms = 2u;     // class touches topology counters at assume (match / anti / aff / own lists non-empty)
 constexpr uint32_t kPodFilt = 128u;    // class has an InterPodAffinity FILTER to evaluate per node (anti, owned-anti match or required affinity)
 constexpr uint32_t kPodHard = 4u;      // class has DoNotSchedule spread constraints

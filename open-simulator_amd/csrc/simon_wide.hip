@@ -321,7 +321,7 @@ __device__ __forceinline__ unsigned fit_bits(const WideArgs& A, const Q& q, cons
         if (((A.flags & kArgEph) != 0u)) fit |= (X.ae < q.req_eph + X.re) ? SIMON_FIT_EPH : 0u;
 #pragma unroll
         for (int k = 0; k < SIMON_MAX_SCALAR; ++k) {   // static indices keep the arrays in registers
-            if (k >= A.K || q.scalar[k] == 0) continue;
+            if (k >= A.K || (q.scalar[k] == 0 && !(q.flags & (kPodEntry0 << k)))) continue;   // only the resources the request holds an ENTRY for (a zero quantity included)
             if (X.sa[k] < q.scalar[k] + X.sr[k]) fit |= SIMON_FIT_SCALAR0 << k;
         }
     }
@@ -1837,14 +1837,19 @@ int wide_stage(WideDevice& w, const HostInputs& in, hipStream_t st, std::string&
         r.nz_cpu = in.p_nz_cpu[p]; r.nz_mem = in.p_nz_mem[p]; r.gpu_mem = in.p_gpu_mem[p];
         bool zero = r.req_cpu == 0 && r.req_mem == 0 && r.req_eph == 0;
         for (int k = 0; k < in.K; ++k) { r.scalar[k] = in.p_scalar[(size_t)k * P + p]; zero = zero && r.scalar[k] == 0; }
+        // an entry of quantity 0 (simon_set_scalar_entries): no early return for the pod, and the entry itself is compared (fit.go:244-249, 275-299)
+        const uint32_t ent = in.p_entries.empty() ? 0u : in.p_entries[p];
+        uint32_t ent_bits = 0;
+        for (int k = 0; k < in.K; ++k) if (((ent >> k) & 1u) && r.scalar[k] == 0) ent_bits |= kPodEntry0 << k;
+        zero = zero && ent == 0u;
         r.cls = in.p_cls[p]; r.preset = in.p_preset[p]; r.gate = in.p_gate[p]; r.gpu_cnt = in.p_gpu_cnt[p];
         r.gpu_index = in.p_gpu_index.empty() ? 0u : in.p_gpu_index[p];
         r.pin = in.p_pin.empty() ? -1 : in.p_pin[p];
         const int c = r.cls;
         auto some = [&](const std::vector<int32_t>& off) { return off[c + 1] > off[c]; };
-        r.flags = zero ? kPodZero : 0u;
+        r.flags = (zero ? kPodZero : 0u) | ent_bits;
         if (sig_ok) {   // intern the request signature (row of the (signature, node) table)
-            std::vector<int64_t> key = {r.req_cpu, r.req_mem, r.req_eph, r.nz_cpu, r.nz_mem, r.scalar[0], r.scalar[1], r.scalar[2], r.scalar[3]};
+            std::vector<int64_t> key = {r.req_cpu, r.req_mem, r.req_eph, r.nz_cpu, r.nz_mem, r.scalar[0], r.scalar[1], r.scalar[2], r.scalar[3], (int64_t)r.flags};
             auto it = sig_id.find(key);
             if (it == sig_id.end()) {
                 if ((int)sigs.size() == kMaxWideSigs) { sig_ok = false; }

@@ -409,18 +409,24 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
                 a.get("_class_affinity") == b.get("_class_affinity") and \
                 {k: v for k, v in a["metadata"].items() if k != "name"} == {k: v for k, v in b["metadata"].items() if k != "name"}, \
                 f"pod {a['metadata']['name']} differs from its template"
-    reqs = [k8s.pod_request(p) for p in tpods]
+    # (names that are neither cpu / memory / ephemeral-storage nor scalar resources never reach the scheduler's Resource: dropped here too)
+    reqs = [{name: v for name, v in k8s.pod_request(p).items() if name in ("cpu", "memory", "ephemeral-storage") or k8s.is_scalar_resource_name(name)}
+            for p in tpods]
     scalar_names = sorted({name for r in reqs for name, v in r.items()
                            if name not in ("cpu", "memory", "ephemeral-storage") and v != 0})
     if len(scalar_names) > capi.MAX_SCALAR:
         raise Unsupported(f"more than {capi.MAX_SCALAR} extended resources requested")
-    # fitsRequest's shortcut tests len(podRequest.ScalarResources) == 0 (fit.go:244-249), the engine tests the VALUES: a pod
-    # that names an extended resource with quantity 0 and requests no cpu / memory / ephemeral-storage still runs the
-    # resource checks in Go (it can fail on a node preset pods over-committed).  Not modelled: refuse.
-    for r, p in zip(reqs, tpods):
-        named_zero = any(v == 0 for name, v in r.items() if name not in ("cpu", "memory", "ephemeral-storage"))
-        if named_zero and not any(v for v in r.values()):
-            raise Unsupported(f"pod {p['metadata'].get('name')}: names an extended resource with quantity 0 and requests nothing else")
+    # fitsRequest's shortcut tests len(podRequest.ScalarResources) == 0 (fit.go:244-249), and Resource.Add creates the map entry even for
+    # a quantity of 0 (V/framework/types.go:320-322): a pod that names an extended resource with quantity 0 runs the resource checks in
+    # Go (it can fail on a node preset pods over-committed), and the zero entry itself is compared.  The ENTRIES travel next to the
+    # quantities since ABI v6 (simon_set_scalar_entries): bit k = scalar_names[k], bit 7 = a resource nobody requests a quantity of.
+    ent_t = np.zeros(len(tpods), np.uint8)
+    for t, r in enumerate(reqs):
+        for name in r:
+            if name in ("cpu", "memory", "ephemeral-storage"):
+                continue
+            ent_t[t] |= (1 << scalar_names.index(name)) if name in scalar_names else 0x80
+    scalar_entries = ent_t[tmpl_of] if ent_t.any() else None
     req_cpu = np.array([r.get("cpu", 0) for r in reqs], np.int64)[tmpl_of]
     req_mem = np.array([r.get("memory", 0) for r in reqs], np.int64)[tmpl_of]
     req_eph = np.array([r.get("ephemeral-storage", 0) for r in reqs], np.int64)[tmpl_of]
@@ -470,10 +476,12 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
     pod_class = tmpl_class[tmpl_of]          # class ids number the classes by first occurrence in the stream, as before
     Cp = len(class_rep)
 
-    # ---- DefaultPreemption (V/scheduler.go:479, defaultpreemption/default_preemption.go) finds no victims as long as all
-    # pods share one priority; explicit differing spec.priority values could evict placed pods: Go path.
-    if len({int(p["spec"].get("priority") or 0) for p in tpods}) > 1:
-        raise Unsupported("pods with different spec.priority: DefaultPreemption may evict placed pods")
+    # ---- DefaultPreemption (V/scheduler.go:479, defaultpreemption/default_preemption.go) finds no victims as long as all pods share one
+    # priority.  With differing spec.priority values it can act only in a scenario where some pod FAILS while a pod of lower priority
+    # is placed: the priorities travel (ABI v6, simon_set_pod_priorities) and the engine flags exactly those scenarios
+    # (simon_fetch_preempt_risk); every other scenario -- among them every one a capacity plan accepts -- is exact.
+    prio_t = np.array([int(p["spec"].get("priority") or 0) for p in tpods], np.int32)
+    priority = prio_t[tmpl_of] if len(set(prio_t.tolist())) > 1 else None
 
     # ---- ImageLocality (imagelocality/image_locality.go:53-113) is a constant 0 as long as no node lists an image a pod
     # runs.  Otherwise its score depends on the cluster size (spread = NumNodes / totalNumNodes): with ONE size
@@ -941,7 +949,7 @@ def flatten(nodes: List[dict], pods: List[dict], services=(), replicasets=(), st
         gpu_cnt=node_gpu_cnt if (node_gpu_cnt.any() or gpu_mem.any()) else None,
         gpu_mem_total=node_gpu_mem if (node_gpu_cnt.any() or gpu_mem.any()) else None,
         req_cpu=req_cpu, req_mem=req_mem, req_eph=req_eph if req_eph.any() else None, nz_cpu=nz_cpu, nz_mem=nz_mem,
-        scalar_req=scalar_req if scalar_names else None, pod_class=pod_class,
+        scalar_req=scalar_req if scalar_names else None, scalar_entries=scalar_entries, priority=priority, pod_class=pod_class,
         preset_node=preset if (preset >= 0).any() else None,
         gate_node=np.array(gates, np.int32) if gates is not None and any(g >= 0 for g in gates) else None,
         pin_node=pin if (pin >= 0).any() else None,

@@ -235,6 +235,16 @@ def pod_request(pod: dict) -> Dict[str, int]:
     return total
 
 
+def is_scalar_resource_name(name: str) -> bool:
+    """schedutil.IsScalarResourceName (V/util/utils.go:169-172): extended resources (a domain prefix outside kubernetes.io/, not
+    `requests.`-prefixed: v1helper.IsExtendedResourceName, pkg/apis/core/v1/helper/helpers.go:37-47 -- the qualified-name syntax is
+    the API server's business), hugepages-*, *kubernetes.io/* and attachable-volumes-*.  Resource.Add (V/framework/types.go:310-326)
+    keeps only these next to cpu / memory / pods / ephemeral-storage: any other name a container lists is dropped."""
+    native = "/" not in name or "kubernetes.io/" in name
+    extended = not native and not name.startswith("requests.")
+    return extended or name.startswith("hugepages-") or "kubernetes.io/" in name or name.startswith("attachable-volumes-")
+
+
 def pod_nonzero_request(pod: dict) -> (int, int):
     """calculateResource's non-zero cpu / memory (V/framework/types.go:601-636, V/util/non_zero.go:41-84)."""
     spec = pod["spec"]

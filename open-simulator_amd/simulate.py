@@ -37,6 +37,8 @@ class HipEngine:
                 ctx.run_loaded(want_placement, want_gpu_slices)
                 res = ctx.fetch(want_placement, want_gpu_slices)
             self.last_stats = ctx.stats()             # which kernel ran (simon_get_stats)
+            if prob.priority is not None:             # pods of unequal priority: where DefaultPreemption could have acted (ABI v6)
+                res.preempt_risk = ctx.fetch_preempt_risk()
             return res
 
     def explain(self, prob: capi.Problem, n_nodes: int, order, max_failed: int):
@@ -45,6 +47,17 @@ class HipEngine:
             ctx.load_problem(prob)
             nf, failed, codes = ctx.explain(n_nodes, order, max_failed)
             return nf, failed, codes, ctx.explain_local_detail(len(failed), n_nodes)
+
+
+class NeedsReference(fl.Unsupported):
+    """The scenario is one the engine does not model: a pod failed while a pod of LOWER priority was placed, so DefaultPreemption
+    (V/scheduler.go:479 -> defaultpreemption/default_preemption.go) may have evicted a victim in the reference.  Only this scenario
+    needs the reference's own path -- the same inputs at a size where every pod fits are exact (simon_fetch_preempt_risk)."""
+
+
+def _risk(out, s: int) -> bool:
+    r = getattr(out, "preempt_risk", None)
+    return r is not None and bool(r[s])
 
 
 @dataclass
@@ -267,6 +280,8 @@ def simulate(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], engine
     orders = np.arange(P, dtype=np.int32)[None, :]
     want_gpu = flat.problem.gpu_mem is not None
     out = engine.run(flat.problem, scen, orders, want_gpu_slices=True) if want_gpu else engine.run(flat.problem, scen, orders)
+    if _risk(out, 0):
+        raise NeedsReference(f"{int(out.unscheduled[0])} pod(s) failed while pods of lower priority were placed: DefaultPreemption may evict there")
     reasons = {}
     if out.unscheduled[0] > 0:
         nf, failed, codes, detail = engine.explain(flat.problem, len(nodes), orders[0], int(out.unscheduled[0]))
@@ -290,6 +305,8 @@ class SweepResult:
     best: Optional[int]                  # smallest number of new nodes that schedules everything within the caps
     result: Optional[SimulateResult]     # SimulateResult of that scenario
     vg_pct: Optional[List[int]] = None   # Open-Local volume-group occupancy per scenario (0 without local storage)
+    needs_reference: Optional[List[bool]] = None   # per scenario: a pod failed while a lower-priority pod was placed (DefaultPreemption could have
+                                                   # acted: its unscheduled count is the engine's, not necessarily the reference's); never a scenario the plan accepts
 
 
 def occupancy_pct(used: int, alloc: int) -> int:
@@ -383,14 +400,15 @@ def sweep(cluster: Dict[str, List[dict]], apps: Sequence[AppResource], new_node:
         res, per_node, per_dev = _unflatten(flat, out.placement[best], n, {}, out.gpu_slices[best] if want_gpu and out.gpu_slices is not None else None)
         res.node_status = [{"node": _gpu_node_status(pool[j], per_dev[j]) if j in per_dev else _node_out(pool[j]), "pods": per_node[j]} for j in range(n)]
         result = res
-    return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
+    return SweepResult(counts, out.unscheduled.tolist(), cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct,
+                       [_risk(out, s) for s in range(len(counts))])
 
 
 def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, max_vg) -> SweepResult:
     base = list(cluster.get("Node", []))
     if max_vg > 100 or max_vg < 0:
         max_vg = 100
-    uns, cpu_pct, mem_pct, vg_pct, kept = [], [], [], [], {}
+    uns, cpu_pct, mem_pct, vg_pct, kept, risks = [], [], [], [], {}, []
     for s, k in enumerate(counts):
         nodes = base + (wl.new_fake_nodes(new_node, k) if k > 0 else [])
         pods, _ = build_stream(cluster, apps, nodes, len(nodes))
@@ -402,6 +420,7 @@ def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, m
         out = engine.run(flat.problem, np.array([[len(nodes), 0]], np.int32), np.arange(len(pods), dtype=np.int32)[None, :],
                          **({"want_gpu_slices": True} if want_gpu else {}))
         uns.append(int(out.unscheduled[0]))
+        risks.append(_risk(out, 0))
         cpu_pct.append(occupancy_pct(int(out.used_cpu[0]), int(flat.problem.alloc_cpu.sum())))
         mem_pct.append(occupancy_pct(int(out.used_mem[0]) * 1000, int(flat.problem.alloc_mem.sum()) * 1000))
         vg = 0
@@ -418,7 +437,7 @@ def _sweep_per_size(cluster, apps, new_node, counts, engine, max_cpu, max_mem, m
         res, per_node, per_dev = _unflatten(flat, out.placement[0], len(nodes), {}, out.gpu_slices[0] if out.gpu_slices is not None else None)
         res.node_status = [{"node": _gpu_node_status(n, per_dev[j]) if j in per_dev else _node_out(n), "pods": per_node[j]} for j, n in enumerate(nodes)]
         result = res
-    return SweepResult(list(counts), uns, cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct)
+    return SweepResult(list(counts), uns, cpu_pct, mem_pct, None if best is None else counts[best], result, vg_pct, risks)
 
 
 def load_config(path: str, base_dir: str = ".") -> dict:

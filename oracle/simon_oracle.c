@@ -76,7 +76,19 @@ typedef struct {
     int64_t scalar[SIMON_MAX_SCALAR];
     int32_t cls, preset, gate, gpu_cnt, pin;
     uint32_t gpu_index;   /* packed preset device ids (include/simon_hip.h: simon_pods_soa.gpu_index) */
+    uint8_t entries;      /* ABI v6 (simon_set_scalar_entries): bit k = the request holds a ScalarResources ENTRY for resource k, bit 7 = for one no node tracks */
 } pod_t;
+
+/* ABI v6 inputs that travel outside simon_pods_soa (simon_set_scalar_entries, simon_set_pod_priorities): set per calling thread right
+ * before simon_oracle_run / _run_ranked (tests/oracle_lib.py), NULL = absent.  g_v6_risk receives one byte per scenario of the call. */
+static __thread const uint8_t* g_v6_entries = NULL;
+static __thread const int32_t* g_v6_priority = NULL;
+static __thread int32_t g_v6_init_min = 0x7fffffff;
+static __thread uint8_t* g_v6_risk = NULL;
+static __thread uint8_t* g_v6_risk_slot = NULL;   /* the byte of the scenario being run */
+void simon_oracle_set_v6(const uint8_t* entries, const int32_t* priority, int32_t init_min_priority, uint8_t* risk_out) {
+    g_v6_entries = entries; g_v6_priority = priority; g_v6_init_min = priority ? init_min_priority : 0x7fffffff; g_v6_risk = risk_out;
+}
 
 static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
     pod_t r;
@@ -93,6 +105,8 @@ static pod_t pod_row(const simon_pods_soa* pd, int K, int p) {
     r.gpu_cnt = pd->gpu_cnt ? pd->gpu_cnt[p] : 0;
     r.pin = pd->pin_node ? pd->pin_node[p] : -1;
     r.gpu_index = pd->gpu_index ? pd->gpu_index[p] : 0u;
+    r.entries = g_v6_entries ? g_v6_entries[p] : 0;
+    for (int k = 0; k < K; k++) if (r.scalar[k] != 0) r.entries |= (uint8_t)(1u << k);   /* a non-zero quantity IS an entry */
     return r;
 }
 
@@ -334,15 +348,16 @@ static uint16_t filter_node(const simon_nodes_soa* nd, const simon_class_tables*
     /* NodeResourcesFit: fitsRequest, V/framework/plugins/noderesources/fit.go:230-302 */
     uint16_t fit = 0;
     if (s->npods[j] + 1 > nd->alloc_pods[j]) fit |= SIMON_FIT_PODS;             /* :233-242 */
-    int has_scalar = 0;
-    for (int k = 0; k < K; k++) has_scalar |= (p->scalar[k] != 0);
+    /* :244-249 asks for len(podRequest.ScalarResources) == 0 -- and Resource.Add / SetMaxResource (V/framework/types.go:310-326,349-372)
+     * create the map entry even for a ZERO quantity: an entry, not a non-zero value, disables the early return */
+    int has_scalar = p->entries != 0;
     if (!(p->req_cpu == 0 && p->req_mem == 0 && p->req_eph == 0 && !has_scalar)) { /* :244-249 */
         if (nd->alloc_cpu[j] < p->req_cpu + s->req_cpu[j]) fit |= SIMON_FIT_CPU; /* :251 */
         if (nd->alloc_mem[j] < p->req_mem + s->req_mem[j]) fit |= SIMON_FIT_MEM; /* :260 */
         int64_t aeph = nd->alloc_eph ? nd->alloc_eph[j] : 0;
         if (aeph < p->req_eph + s->req_eph[j]) fit |= SIMON_FIT_EPH;             /* :269 */
         for (int k = 0; k < K; k++) {                                            /* :279-299 */
-            if (p->scalar[k] == 0) continue; /* only resources the pod requests */
+            if (!((p->entries >> k) & 1u)) continue; /* `for rName, rQuant := range podRequest.ScalarResources`: every ENTRY, a zero quantity included */
             if (nd->scalar_alloc[(size_t)k * N + j] < p->scalar[k] + s->scalar_req[(size_t)k * N + j])
                 fit |= (uint16_t)(SIMON_FIT_SCALAR0 << k);
         }
@@ -722,6 +737,10 @@ static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, con
     state_init(&s, nd, tb);
     uint16_t* codes = xcalloc(n, 2);
     int unsched = 0;
+    /* DefaultPreemption (V/scheduler.go:479, defaultpreemption/default_preemption.go:578-592) acts only for a FAILED pod and only on
+     * pods of LOWER priority: risk = such a pair exists in this scenario (include/simon_hip.h: simon_fetch_preempt_risk) */
+    int32_t low = g_v6_init_min;
+    int risk = 0;
     for (int i = 0; i < P; i++) {
         int pid = order ? order[i] : i;
         if (pid < 0 || pid >= P) { free(codes); state_free(&s, T); return SIMON_EINVAL; }
@@ -731,6 +750,7 @@ static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, con
             if (p.preset >= n) { free(codes); state_free(&s, T); return SIMON_EINVAL; }
             add_pod(nd, tb, &s, &p, p.preset, 0);
             if (placement) placement[pid] = p.preset;
+            if (g_v6_priority && g_v6_priority[pid] < low) low = g_v6_priority[pid];
             continue;
         }
         int j = schedule_one(nd, tb, &s, &p, n, codes, NULL, NULL, NULL, NULL, NULL);
@@ -748,8 +768,10 @@ static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, con
             }
             unsched++;
             if (placement) placement[pid] = SIMON_UNSCHEDULED;
+            if (g_v6_priority && g_v6_priority[pid] > low) risk = 1;
             continue;
         }
+        if (g_v6_priority && g_v6_priority[pid] < low) low = g_v6_priority[pid];
         uint64_t sl = add_pod(nd, tb, &s, &p, j, 1);
         if (placement) placement[pid] = j;
         if (gpu_slices) gpu_slices[pid] = sl;
@@ -761,6 +783,7 @@ static int run_scenario(const simon_nodes_soa* nd, const simon_pods_soa* pd, con
             for (int v = 0; v < nd->local_vg_cnt[j]; v++) uv += s.vg_req[(size_t)j * SIMON_MAX_VG + v];
     }
     *unscheduled = unsched; *used_cpu = uc; *used_mem = um;
+    if (g_v6_risk_slot) *g_v6_risk_slot = (uint8_t)risk;
     if (used_vg) *used_vg = uv;
     if (n_failed_out && explain) *n_failed_out = unsched;
     free(codes);
@@ -788,6 +811,7 @@ int simon_oracle_run_ranked(const simon_nodes_soa* nodes, const simon_pods_soa* 
         if (orders && (scen[s].order_id < 0 || scen[s].order_id >= n_orders)) return SIMON_EINVAL;
         const int32_t* ord = orders ? orders + (size_t)scen[s].order_id * P : NULL;
         int explain = (failed_pods && fail_codes && s == explain_scenario);
+        g_v6_risk_slot = g_v6_risk ? g_v6_risk + s : NULL;
         int rc = run_scenario(nodes, pods, tables, scen[s].n_nodes, ord, &out->unscheduled[s], &out->used_cpu[s],
                               &out->used_mem[s], out->used_vg ? &out->used_vg[s] : NULL, out->placement ? out->placement + (size_t)s * P : NULL,
                               out->gpu_slices ? out->gpu_slices + (size_t)s * P : NULL, explain,

@@ -35,6 +35,9 @@ int simon_oracle_run(const simon_nodes_soa* nodes, const simon_pods_soa* pods,
 /* Where the NEXT explaining run leaves what Open-Local's error texts carry: [max_failed][n_nodes of the scenario][4] int64
  * {SIMON_LOCAL_ERR_*, a, b, c} (include/simon_hip.h), zero-initialised by the caller; NULL switches it off. */
 void simon_oracle_set_local_detail(int64_t* buf);
+/* ABI v6 inputs of the NEXT simon_oracle_run / _run_ranked of the calling thread (they travel outside simon_pods_soa in the library too:
+ * simon_set_scalar_entries, simon_set_pod_priorities); risk_out [S] receives simon_fetch_preempt_risk's flags.  NULLs clear. */
+void simon_oracle_set_v6(const uint8_t* entries, const int32_t* priority, int32_t init_min_priority, uint8_t* risk_out);
 
 /* The same with a canonical node order per scenario: node_rank[s][j] = position of pool node j in scenario s's nodeTree
  * order (V/internal/cache/node_tree.go:119-143); selectHost's first maximum is taken in that order. */

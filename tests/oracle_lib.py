@@ -68,6 +68,21 @@ def run(prob: capi.Problem, scen, orders, want_placement=True, explain_scenario=
         ranks = np.ascontiguousarray(node_ranks, np.int32)
         assert ranks.shape == (len(scen), prob.n_nodes)
     lib.simon_oracle_run_ranked.restype = C.c_int
+    # ABI v6 inputs that travel outside simon_pods_soa: per calling thread, for the run below (res.preempt_risk: the oracle's twin of
+    # simon_fetch_preempt_risk)
+    lib.simon_oracle_set_v6.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_uint8)]
+    lib.simon_oracle_set_v6.restype = None
+    risk = np.zeros(len(scen), np.uint8)
+    lib.simon_oracle_set_v6(capi._ptr(prob.scalar_entries, C.c_uint8), capi._ptr(prob.priority, C.c_int32), int(prob.init_min_priority),
+                            capi._ptr(risk, C.c_uint8))
+    res.preempt_risk = risk
+    try:
+        return _run_set(lib, prob, scen, orders, res, out, n, p, t, ranks, explain_scenario, max_failed)
+    finally:
+        lib.simon_oracle_set_v6(None, None, 0x7fffffff, None)
+
+
+def _run_set(lib, prob, scen, orders, res, out, n, p, t, ranks, explain_scenario, max_failed):
     if explain_scenario >= 0:
         nmax = int(scen[explain_scenario, 0])
         failed = np.full(max_failed, -1, np.int32)

@@ -64,14 +64,15 @@ def fits_request(pod, ni):
     if len(ni.pods) + 1 > ni.alloc.get("pods", 0):
         out.append("Too many pods")
     req = k8s.pod_request(pod)
-    if all(v == 0 for v in req.values()):
+    # preFilterState.Resource as Resource.Add builds it (V/framework/types.go:310-326): three fields and a MAP of scalar resources that
+    # gets an entry for every scalar name a container lists -- a quantity of 0 included; other names are dropped
+    scalar = {name: v for name, v in req.items() if name not in ("cpu", "memory", "ephemeral-storage") and k8s.is_scalar_resource_name(name)}
+    if req.get("cpu", 0) == 0 and req.get("memory", 0) == 0 and req.get("ephemeral-storage", 0) == 0 and len(scalar) == 0:   # :244-249
         return out
     for name, text in (("cpu", "Insufficient cpu"), ("memory", "Insufficient memory"), ("ephemeral-storage", "Insufficient ephemeral-storage")):
         if ni.alloc.get(name, 0) < req.get(name, 0) + ni.req.get(name, 0):
             out.append(text)
-    for name, v in req.items():
-        if name in ("cpu", "memory", "ephemeral-storage") or v == 0:
-            continue
+    for name, v in scalar.items():                                    # :275-299: every entry of the map
         if ni.alloc.get(name, 0) < v + ni.req.get(name, 0):
             out.append("Insufficient " + name)
     return out
@@ -473,6 +474,7 @@ class Scheduler:
         by_name = {ni.node["metadata"]["name"]: ni for ni in self.infos}
         out = []
         self.gpu_ids = [None] * len(pods)
+        self.preempt_risk = False      # some pod failed while a node held a pod of lower priority: what DefaultPreemption's dry run looks for
         for pod in pods:
             nn = pod["spec"].get("nodeName")
             if nn:
@@ -482,6 +484,11 @@ class Scheduler:
             ni = self.schedule_one(pod)
             if ni is None:
                 out.append(None)
+                # PostFilter (V/scheduler.go:479): selectVictimsOnNode collects, node by node, the pods whose priority is lower than the
+                # preemptor's (default_preemption.go:578-592); with none anywhere there is nothing to evict and the cycle ends as it did
+                mine = int(pod["spec"].get("priority") or 0)
+                if any(int(e["spec"].get("priority") or 0) < mine for info in self.infos for e in info.pods):
+                    self.preempt_risk = True
                 continue
             mem, cnt = fl._gpu_annotations(pod)
             if mem > 0:

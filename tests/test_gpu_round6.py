@@ -1,0 +1,159 @@
+"""GPU parity tests, round 6 (ABI v6): pods of unequal priority (the DefaultPreemption-risk flag), ScalarResources ENTRIES of quantity 0,
+and the kernels touched this round (generation 6 with its feasible-node counters in LDS; global address space named for every table)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import randprob
+from open_simulator_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+GiB = 1 << 30
+
+
+def run_gpu(prob, scen, orders, env=None, explain=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders, True)
+            res.preempt_risk = ctx.fetch_preempt_risk()
+            st = ctx.stats()
+            ex = ctx.explain(*explain) if explain else None
+            return res, st, ex
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def assert_same(a, b):
+    assert a.unscheduled.tolist() == b.unscheduled.tolist()
+    assert a.used_cpu.tolist() == b.used_cpu.tolist() and a.used_mem.tolist() == b.used_mem.tolist()
+    assert (a.placement == b.placement).all()
+    assert a.preempt_risk.tolist() == b.preempt_risk.tolist()
+
+
+PRIO_FEATURES = [dict(), dict(presets=True, gates=True, tight_pods=True), dict(gpu=True), dict(anti=True, static_mask=True),
+                 dict(spread_soft=True), dict(eph=True, scalars=2, init_state=True)]
+
+
+@pytest.mark.parametrize("idx", range(len(PRIO_FEATURES)))
+def test_preempt_risk_flag_matches_the_oracle_on_every_kernel(idx):
+    """simon_set_pod_priorities / simon_fetch_preempt_risk: per scenario, "some pod failed while a pod of lower priority was placed" --
+    what DefaultPreemption needs to act (V/scheduler.go:479, default_preemption.go:578-592).  The flag is computed on the device from the
+    placement matrix of whatever kernel ran; the oracle keeps a running minimum inside its scheduling loop.  Tight clusters (many failures),
+    preset pods (they count as victims), gated pods (they do not exist), every kernel family, with and without the placement matrix asked for."""
+    feat = PRIO_FEATURES[idx]
+    seen = set()
+    for seed in range(4):
+        prob = randprob.rand_problem(6000 + 100 * idx + seed, N=30 + 17 * seed, P=500, **feat)
+        rng = np.random.default_rng(seed)
+        prob.priority = rng.choice([0, 0, 0, 10, 1000, -5], prob.n_pods).astype(np.int32)
+        prob.init_min_priority = [0x7fffffff, 0, 100, 2000][seed]
+        scen, orders = randprob.rand_scenarios(seed, prob, S=10, min_n=4)
+        ref = O.run(prob, scen, orders)
+        for env in ({}, {"SIMON_FORCE_WIDE": "1"}, {"SIMON_NO_CACHE": "1"}):
+            res, st, _ = run_gpu(prob, scen, orders, env=env)
+            assert_same(res, ref)
+            seen.add((st.kernel_variant, st.kernel_generation))
+        assert ref.preempt_risk.any() or ref.unscheduled.max() == 0 or seed > 0
+        with capi.Context(0) as ctx:                                   # want_placement = 0: the library stores the matrix all the same
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            ctx.run_loaded(False)
+            assert ctx.fetch_preempt_risk().tolist() == ref.preempt_risk.tolist()
+        with capi.Group([0, 0, 0]) as grp:                             # scenario s on member s % 3: flags come back in global order
+            grp.load_problem(prob)
+            grp.load_scenarios(scen, orders)
+            grp.run_loaded(True)
+            assert grp.fetch_preempt_risk().tolist() == ref.preempt_risk.tolist()
+    assert len(seen) >= 2 or idx == 5          # (extra resources over an occupied pool: the all-feature kernel whatever the switch)
+    # no priorities loaded: no flag anywhere, and loading pods again clears what was set
+    prob.priority = None
+    res, _, _ = run_gpu(prob, scen, orders)
+    assert not res.preempt_risk.any()
+
+
+def test_preempt_risk_at_full_size_on_the_benchmarked_batch():
+    """Size-independent property on BASELINE config 3's batch (4 096 scenarios x 10 000 pods): with priorities that DEcrease along every pod
+    order no pod can ever fail above a placed one -- no flag -- and with one low-priority pod first every scenario with a failure is flagged."""
+    prob, scen, orders = synth.config3(n_counts=256, n_orders=1)
+    P = prob.n_pods
+    prio = np.zeros(P, np.int32)
+    prio[orders[0]] = np.arange(P, 0, -1)
+    prob.priority = prio
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders, False)
+        assert not ctx.fetch_preempt_risk().any()
+        prio2 = np.full(P, 5, np.int32)
+        prio2[orders[0][0]] = 1
+        prob.priority = prio2
+        ctx.load_problem(prob)
+        res = ctx.run_batch(scen, orders, False)
+        risk = ctx.fetch_preempt_risk()
+        assert risk.tolist() == (res.unscheduled > 0).astype(np.uint8).tolist() and risk.any() and not risk.all()
+
+
+def test_zero_quantity_scalar_entries_on_every_kernel():
+    """simon_set_scalar_entries: fit.go:244-249 -- len(ScalarResources) == 0, not "all quantities zero" -- and :275-299 -- every ENTRY is
+    compared.  A node that bound pods over-committed (init state) rejects an all-zero pod that holds an entry ("Insufficient cpu" /
+    "Insufficient memory") and admits the same pod without one; an entry for a resource the node is over-committed ON fails with that
+    resource's bit.  Score-table kernel (cpu + memory: the entry only disables the shortcut), generations 1 / 2, the all-feature kernel."""
+    for seed in range(4):
+        prob = randprob.rand_problem(7000 + seed, N=40, P=300, zero_pods=True, nz_differs=True, init_state=True)
+        rng = np.random.default_rng(seed)
+        over = rng.random(prob.n_nodes) < 0.4                          # over-committed at the start: Requested > Allocatable
+        prob.init_req_cpu = np.where(over, prob.alloc_cpu + 1000, prob.init_req_cpu).astype(np.int64)
+        prob.init_nz_cpu = np.maximum(prob.init_nz_cpu, prob.init_req_cpu)
+        zero = (prob.req_cpu == 0) & (prob.req_mem == 0)
+        assert zero.any()
+        ent = np.where(zero & (rng.random(prob.n_pods) < 0.5), 0x80, 0).astype(np.uint8)
+        scen, orders = randprob.rand_scenarios(seed, prob, S=6, min_n=6)
+        base = O.run(prob, scen, orders)
+        prob.scalar_entries = ent
+        ref = O.run(prob, scen, orders)
+        assert (ref.placement != base.placement).any()                 # the entries matter on this input
+        for env in ({}, {"SIMON_FORCE_WIDE": "1"}, {"SIMON_NO_CACHE": "1"}, {"SIMON_NARROW_V1": "1"}, {"SIMON_LDS_WS": "0"}):
+            res, st, _ = run_gpu(prob, scen, orders, env=env)
+            assert_same(res, ref)
+        # tracked resources: quantities for some pods, zero-quantity ENTRIES for others, a pool over-committed on resource 0
+        prob2 = randprob.rand_problem(7100 + seed, N=30, P=250, scalars=2, zero_pods=True, init_state=True)
+        prob2.init_scalar_req = np.zeros((2, prob2.n_nodes), np.int64)
+        prob2.init_scalar_req[0] = np.where(rng.random(prob2.n_nodes) < 0.5, prob2.scalar_alloc[0] + 1, 0)
+        ent2 = np.zeros(prob2.n_pods, np.uint8)
+        pick = (prob2.scalar_req[0] == 0) & (rng.random(prob2.n_pods) < 0.5)
+        ent2[pick] |= 1
+        ent2[(prob2.scalar_req[1] == 0) & (rng.random(prob2.n_pods) < 0.3)] |= 2
+        scen2, orders2 = randprob.rand_scenarios(seed, prob2, S=5, min_n=6)
+        base2 = O.run(prob2, scen2, orders2)
+        prob2.scalar_entries = ent2
+        nmax = int(scen2[0, 0])
+        ref2, (nf, failed, codes) = O.run(prob2, scen2, orders2, explain_scenario=0, max_failed=8)
+        assert (ref2.placement != base2.placement).any()
+        res2, st2, ex = run_gpu(prob2, scen2, orders2, explain=(nmax, orders2[scen2[0, 1]], 8))
+        assert st2.kernel_variant == capi.KERNEL_WIDE                  # an over-committed pool: not the position-mask rows
+        assert_same(res2, ref2)
+        assert ex[0] == nf and ex[1].tolist() == failed.tolist() and (ex[2] == codes).all()
+
+
+def test_config5_and_rest_features_with_counters_in_lds():
+    """Generation 6 keeps its feasible-node counters per (signature, class) in LDS since round 6 (tcarve: rest): a 64-scenario slice of
+    BASELINE config 5 at full size, placement by placement, on both homes of the mask rows."""
+    prob, scen, orders = synth.config5(n_scen=64, n_orders=4)
+    pick = np.arange(0, 64, 8)
+    ref = O.run_threaded(prob, scen[pick], orders)
+    for mode in ("0", "1"):
+        res, st, _ = run_gpu(prob, scen[pick], orders, env={"SIMON_LDS_WS": mode})
+        assert st.kernel_generation == 6
+        assert res.unscheduled.tolist() == ref.unscheduled.tolist()
+        assert (res.placement == ref.placement).all()

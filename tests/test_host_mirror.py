@@ -216,16 +216,87 @@ def test_image_locality_in_a_sweep_runs_size_by_size():
         assert len(sim.simulate(cluster, apps, engine=OracleEngine(), new_nodes=wl.new_fake_nodes(template, k)).unscheduled_pods) == uns
 
 
-def test_differing_priorities_are_refused():
-    """With one priority for all pods DefaultPreemption never finds a victim; explicit differing
-    spec.priority values could evict placed pods in the reference, which the engine does not model."""
-    nodes, workloads, services = randk8s.rand_cluster(6, n_nodes=5, n_workloads=4)
-    extra = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "vip", "namespace": "default"},
-             "spec": {"priority": 1000, "containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"cpu": "100m"}}}]}}
-    cluster = k8s.group_resources(nodes + services)
-    sim.simulate(cluster, [sim.AppResource("app", k8s.group_resources(workloads))], engine=OracleEngine())
-    with pytest.raises(fl.Unsupported, match="DefaultPreemption"):
-        sim.simulate(cluster, [sim.AppResource("app", k8s.group_resources(workloads + [extra]))], engine=OracleEngine())
+def _prio_cluster():
+    node = lambda name: {"apiVersion": "v1", "kind": "Node", "metadata": {"name": name, "labels": {"kubernetes.io/hostname": name}},
+                         "status": {"allocatable": {"cpu": "2", "memory": "4Gi", "pods": "10"}, "capacity": {"cpu": "2", "memory": "4Gi"}}}
+    pod = lambda name, cpu, prio=None: {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "default"},
+                                        "spec": dict({"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"cpu": cpu, "memory": "1Gi"}}}]},
+                                                     **({"priority": prio} if prio is not None else {}))}
+    return node, pod
+
+
+def test_pods_of_unequal_priority_run_on_the_engine_and_only_risky_scenarios_are_flagged():
+    """DefaultPreemption (V/scheduler.go:479, defaultpreemption/default_preemption.go:578-592) acts only for a pod that FAILED and only on pods
+    of lower priority.  The mirror no longer refuses clusters with differing spec.priority (every kubeconfig-dumped cluster has them):
+    the engine flags the scenarios in which such a pair exists, everything else is exact -- checked against the object-level scheduler,
+    which looks for victims the way selectVictimsOnNode does."""
+    node, pod = _prio_cluster()
+    cluster = k8s.group_resources([node("n0")])
+    template = node("tmpl")
+    # low, low, HIGH: on one node (2 cpu) the third pod fails while lower-priority pods sit there -> flagged; with a second node all fit
+    apps = [sim.AppResource("a", k8s.group_resources([pod("low0", "900m", 0), pod("low1", "900m", 0), pod("vip", "900m", 1000)]))]
+    with pytest.raises(sim.NeedsReference, match="DefaultPreemption"):
+        sim.simulate(cluster, apps, engine=OracleEngine())
+    assert isinstance(sim.NeedsReference("x"), fl.Unsupported)            # hosts that catch Unsupported fall back to the Go path as before
+    res = sim.simulate(cluster, apps, engine=OracleEngine(), new_nodes=wl.new_fake_nodes(template, 1))
+    assert not res.unscheduled_pods
+    sw = sim.sweep(cluster, apps, template, [0, 1, 2], engine=OracleEngine())
+    assert sw.unscheduled == [1, 0, 0] and sw.needs_reference == [True, False, False] and sw.best == 1
+    # HIGH first: the pod that fails has the LOWEST priority -> nothing it could evict -> exact, not flagged
+    apps2 = [sim.AppResource("a", k8s.group_resources([pod("vip", "900m", 1000), pod("mid", "900m", 10), pod("low", "900m", 0)]))]
+    res2 = sim.simulate(cluster, apps2, engine=OracleEngine())
+    assert [u["pod"]["metadata"]["name"] for u in res2.unscheduled_pods] == ["low"]
+    assert sim.sweep(cluster, apps2, template, [0, 1], engine=OracleEngine()).needs_reference == [False, False]
+    # equal priorities among the failing and the placed pods: no victim either (strictly lower is required)
+    apps3 = [sim.AppResource("a", k8s.group_resources([pod("a", "900m", 5), pod("b", "900m", 5), pod("c", "900m", 5), pod("d", "100m", 7)]))]
+    assert sim.sweep(cluster, apps3, template, [0], engine=OracleEngine()).needs_reference == [False]
+    # the object-level restatement agrees on random clusters whose pods carry random priorities
+    for seed in (3, 6, 14, 29):
+        nodes, workloads, services = randk8s.rand_cluster(seed, n_nodes=4, n_workloads=8, max_replicas=6)
+        for i, w in enumerate(workloads):
+            spec = w["spec"]["template"]["spec"] if "template" in w.get("spec", {}) else w["spec"]
+            spec["priority"] = [0, 0, 100, 1000][(seed + i) % 4]
+        cl = k8s.group_resources(nodes + services)
+        ap = [sim.AppResource("app", k8s.group_resources(workloads))]
+        pods, _ = sim.build_stream(cl, ap, cl["Node"], len(cl["Node"]))
+        order = k8s.canonical_node_order(cl["Node"])
+        sch = pyref_sched.Scheduler([cl["Node"][j] for j in order], cl.get("Service", []), cl.get("ReplicaSet", []), cl.get("StatefulSet", []))
+        want = sch.run(pods)
+        flagged = False
+        try:
+            got = sim.simulate(cl, ap, engine=OracleEngine())
+            assert len(got.unscheduled_pods) == sum(1 for w_ in want if w_ is None)
+        except sim.NeedsReference:
+            flagged = True
+        assert flagged == sch.preempt_risk, seed
+
+
+def test_a_zero_quantity_scalar_entry_disables_the_all_zero_shortcut():
+    """fit.go:244-249 returns early only for len(podRequest.ScalarResources) == 0, and Resource.Add (V/framework/types.go:320-322) creates the map
+    entry even for a quantity of 0: a BestEffort pod that lists `example.com/foo: "0"` is checked against cpu / memory like any other pod --
+    "Insufficient cpu" on a node that bound pods over-committed -- while the same pod without the entry passes.  """
+    node, pod = _prio_cluster()
+    hog = pod("hog", "3", None)
+    hog["spec"]["nodeName"] = "n0"                                     # bound by Spec.NodeName: no filter, the node ends up over-committed (3 of 2 cpu)
+    be = lambda name, res: {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "default"},
+                            "spec": {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": res}}]}}
+    cluster = k8s.group_resources([node("n0"), hog])
+    for res, fails in (({}, False), ({"example.com/foo": "0"}, True), ({"hugepages-2Mi": "0"}, True), ({"storage": "0"}, False)):
+        apps = [sim.AppResource("a", k8s.group_resources([be("besteffort", res)]))]
+        out = sim.simulate(cluster, apps, engine=OracleEngine())
+        assert bool(out.unscheduled_pods) == fails, res
+        if fails:
+            assert "Insufficient cpu" in out.unscheduled_pods[0]["reason"] and "Insufficient example" not in out.unscheduled_pods[0]["reason"]
+        pods, _ = sim.build_stream(cluster, apps, cluster["Node"], 1)
+        assert (pyref_sched.Scheduler(cluster["Node"]).run(pods)[-1] is None) == fails, res
+    # the zero entry itself is compared too: a node over-committed on THAT resource fails it with the resource's own reason
+    n1 = node("n0")
+    n1["status"]["allocatable"]["example.com/foo"] = "1"
+    hog2 = be("hog2", {"example.com/foo": "2"})
+    hog2["spec"]["nodeName"] = "n0"
+    cl2 = k8s.group_resources([n1, hog2])
+    out = sim.simulate(cl2, [sim.AppResource("a", k8s.group_resources([be("z", {"example.com/foo": "0"}), be("plain", {})]))], engine=OracleEngine())
+    assert [u["pod"]["metadata"]["name"] for u in out.unscheduled_pods] == ["z"] and "Insufficient example.com/foo" in out.unscheduled_pods[0]["reason"]
 
 
 def test_sweep_over_several_zones_runs_every_size_on_its_own(seeds=(11, 31, 47)):
@@ -462,16 +533,15 @@ def test_daemonset_with_hard_spread_constraint_looks_only_at_its_own_node():
     assert [flat.node_names[j] for j in res.placement[0].tolist()] == pyref_sched.Scheduler(nodes_c, [], [], [], randk8s.STORAGE_CLASSES).run(pods)
 
 
-def test_named_zero_extended_resource_with_no_other_request_is_refused():
-    """fit.go:244-249 tests len(ScalarResources) == 0, the engine the values: the one input where they differ is refused."""
+def test_named_zero_extended_resource_with_no_other_request_travels_as_an_entry():
+    """fit.go:244-249 tests len(ScalarResources) == 0; until round 6 the engine tested the values and the mirror refused the one input where
+    they differ.  Now the entries travel (ABI v6): bit 7 for a resource nobody requests a quantity of."""
     nodes = [{"apiVersion": "v1", "kind": "Node", "metadata": {"name": "n0", "labels": {"kubernetes.io/hostname": "n0"}},
               "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "110", "example.com/foo": "4"}}}]
     pod = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p", "namespace": "default"},
            "spec": {"containers": [{"name": "c", "image": "busybox", "resources": {"requests": {"example.com/foo": "0"}}}]}}
-    with pytest.raises(fl.Unsupported, match="quantity 0"):
-        fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
-    pod["spec"]["containers"][0]["resources"]["requests"]["cpu"] = "100m"      # with a real request the shortcut never applies
-    fl.flatten(nodes, [wl.make_valid_pod(pod)], [], [], [])
+    flat = fl.flatten(nodes, [pod], [], [], [])
+    assert flat.problem.scalar_entries.tolist() == [0x80] and flat.problem.scalar_req is None
 
 
 def test_service_list_edited_in_place_between_two_flatten_calls_is_read_afresh():
