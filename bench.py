@@ -291,7 +291,9 @@ def c5_scenarios(args):
 
 
 def build_workload(args, synth, world):
-    n_orders = args.orders_per_gpu * world
+    # weak scaling (default: BASELINE config 4 at N = 8 is 32 orders): every GPU gets --orders-per-gpu orders x every node count;
+    # --strong: the batch stays config 3's 4 096 scenarios whatever N (the ranks split them, s mod N)
+    n_orders = args.orders_per_gpu * (1 if getattr(args, "strong", False) else world)
     if args.workload == "config5":
         return synth.config5(n_scen=c5_scenarios(args) * world, n_orders=n_orders), n_orders
     if args.workload == "config2":
@@ -308,7 +310,7 @@ def build_workload(args, synth, world):
         return synth.config3_classes(args.classes, n_counts=args.counts, n_orders=n_orders, n_pods=args.pods), n_orders
     if args.workload == "config3sig":          # config 3 with `--sigs` distinct request signatures (the > 64-signature regime)
         return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=synth.SEED + 3, n_sigs=args.sigs), n_orders
-    seed = synth.SEED + (3 if world == 1 else 4)
+    seed = synth.SEED + (3 if world == 1 or getattr(args, "strong", False) else 4)
     return synth.config3(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, seed=seed), n_orders
 
 
@@ -344,7 +346,7 @@ def workload_name(args, prob, scen_all, n_orders, S_local, world):
             "widemix": "random Kubernetes-object mix with every plugin (all-feature kernel): ",
             "config3classes": f"config 3 variant with {args.classes} distinct node shapes (internal node classes): ",
             "config3sig": f"config 3 variant with {args.sigs} request signatures: "}.get(
-                args.workload, f"BASELINE config {'3' if world == 1 else '4-style'}: ")
+                args.workload, f"BASELINE config {'3' if world == 1 or getattr(args, 'strong', False) else '4-style'}{' (fixed batch split over the ranks)' if getattr(args, 'strong', False) and world > 1 else ''}: ")
     return (head + f"{prob.n_pods} pods x {int(scen_all[:, 0].min())}..{int(scen_all[:, 0].max())} nodes, "
             f"{len(set(scen_all[:, 0].tolist()))} node counts x {n_orders} pod orders = {len(scen_all)} scenarios ({S_local} per GPU)")
 
@@ -434,7 +436,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config_service(n_counts=SMALL_COUNTS)
         child = ["--workload", "service", "--counts", str(SMALL_COUNTS)]
         wl, label = "config3", f"config 3 with Service-selected pods, {4 * SMALL_COUNTS} scenarios"
-    elif name == "config3_small":                   # the `simon apply` shape without Services: 64 candidate scenarios -- generation 5 as leader + refresher (two waves per scenario)
+    elif name == "config3_small":                   # the `simon apply` shape without Services: 64 candidate scenarios -- generation 4, one wave per scenario, the workspace in LDS (5.3k)
         prob, scen, orders = synth.config3(n_counts=SMALL_COUNTS)
         child = ["--workload", "config3", "--counts", str(SMALL_COUNTS)]
         wl, label = "config3", f"BASELINE config 3's pool, {4 * SMALL_COUNTS} scenarios"
@@ -478,9 +480,8 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                     "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                     "kernel": KERNEL_SHORT.get(st.kernel_variant, "?"), "kernel_generation": st.kernel_generation,
                     "kernel_ms": round(k_ms, 3), "workgroup": st.workgroup_size})
-        if st.kernel_generation in (5, 6, 7) and st.workgroup_size > 64:   # several waves per scenario (team mode of generation 7; leader + refresher of generations 5 / 6): the same batch with ONE wave per scenario, same process
+        if st.kernel_generation == 7 and st.workgroup_size > 64:   # several waves per scenario (team mode of generation 7): the same batch with ONE wave per scenario, same process
             os.environ["SIMON_TEAM"] = "0"
-            os.environ["SIMON_DUO"] = "0"
             try:
                 with capi.Context(device) as ctx1:
                     ctx1.load_problem(prob)
@@ -488,7 +489,6 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
                     _, k1 = time_steps(ctx1, max(2, steps // 2), 1, True, torch.cuda.synchronize)
             finally:
                 os.environ.pop("SIMON_TEAM", None)
-                os.environ.pop("SIMON_DUO", None)
             rec["team"] = {"waves_per_scenario": st.workgroup_size // 64, "one_wave_kernel_ms": round(k1, 3), "speedup": round(k1 / k_ms, 3)}
         if name in ("config2", "config3_small") and st.kernel_generation == 4:   # small batch of a small problem: the scenario's workspace lives in LDS (round 5) -- the same batch with the workspace in HBM, same process
             os.environ["SIMON_LDS_WS"] = "0"
@@ -713,7 +713,7 @@ def run_group(args, capi, synth, torch):
     value = len(scen) * args.steps / dt
     st0 = sts[0]
     out = {"metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3), "unit": "scenarios/s", "n_gpus": n,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
            "vs_baseline": None, "dtype": DTYPE.get(st0.kernel_variant, "int64 + f64"), "data": "synthetic",
            "pods_placed_per_sec": round(value * prob.n_pods, 1),
            "config": {"workload": workload_name(args, prob, scen, n_orders, len(scen) // n, n), "scenarios_per_gpu": len(scen) // n,
@@ -775,6 +775,8 @@ def main():
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
                          "(GPU share + anti-affinity + taints) on generation 6 of the score-table kernel, --c5-scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: BASELINE config 3's fixed batch (--orders-per-gpu orders in total, 4 096 scenarios) "
+                                                          "split over the N ranks instead of a batch that grows with N (the default, weak: config 4 at N = 8)")
     ap.add_argument("--group", type=int, default=0, help="N > 0: ONE process driving N devices through simon_group_* (the Go-host shape) "
                                                           "instead of one rank per GPU")
     args = ap.parse_args()
@@ -864,7 +866,7 @@ def main():
         out = {
             "metric": "capacity-plan scenarios/sec (10k pods x ~1k nodes)", "value": round(value, 3),
             "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": DTYPE.get(st.kernel_variant, "int64 + f64"), "data": "synthetic",
             "pods_placed_per_sec": round(value * prob.n_pods, 1),
             "config": {"workload": workload_name(args, prob, scen_all, n_orders, S_local, world),

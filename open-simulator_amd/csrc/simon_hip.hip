@@ -1833,24 +1833,28 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // Generation 4 with the scenario's workspace in LDS (round 5; simon_table.hip: LDSWS): a batch of at most one scenario per CU -- what
         // a real Applier.Run offers -- of a problem whose byte table + node state fit the CU's LDS next to the summaries.  The one memory
         // round trip of a scheduling cycle becomes an LDS access.
+        // The LDS-resident homes (LDSWS, LDSX) trade occupancy for latency: a workgroup asks for up to 159 KB, so a CU holds ONE.  They are
+        // the default only where that costs nothing whatever the dispatcher does: a batch of at most one scenario per CU (what a real
+        // Applier.Run offers).  Round 5 also took batches of a few workgroups per CU when ceil(S / CUs) of them fit the CU's LDS together --
+        // which assumed the dispatcher places exactly that many per CU, and left simon_load_scenarios' fine / coarse cost model (lds16 /
+        // lds64, fitted before this LDS growth) describing another launch; those batches keep the HBM homes now (SIMON_LDS_WS=1: whenever
+        // one scenario fits).
+        auto lds_home = [&](size_t need) -> bool {
+            if (need > kTableLdsMaxWG || c->ldsws_mode == 0) return false;
+            return c->ldsws_mode > 0 || S <= std::max(c->n_cus, 1);
+        };
         bool lds_ws = false;
-        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && c->n_sigs <= 128 && team == 1 &&
-            c->ldsws_mode != 0) {
+        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && c->n_sigs <= 128 && team == 1) {
             size_t ws_max = 0;
             for (int s2 = 0; s2 < S; ++s2) ws_max = std::max(ws_max, table_ws_bytes(c->n_sigs, c->scen_ni[s2], c->nzeq, false, c->Cn_t, 0, 0, 0, 0));
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + ws_max + c->lds_pad;   // (the kernel puts the workspace at the next 128-byte boundary behind tcarve's total)
-            // ... when the whole batch is resident at once all the same: ceil(S / CUs) workgroups of `need` bytes (allocation granularity 1 280 B) per CU
-            const size_t per_cu = (size_t)(S + c->n_cus - 1) / (size_t)std::max(c->n_cus, 1);
-            const bool resident = per_cu * ((need + 1279) / 1280 * 1280) <= kTableLdsPerCU && per_cu <= 32;
-            if (need <= kTableLdsMaxWG && (c->ldsws_mode > 0 || resident)) { lds_ws = true; table_lds = need; }
+            if (lds_home(need)) { lds_ws = true; table_lds = need; }
         }
-        // Generation 6 with its mask rows, row totals and canonical indices in LDS (round 5; simon_table.hip: LDSX), under the same residency rule
+        // Generation 6 with its mask rows, row totals and canonical indices in LDS (round 5; simon_table.hip: LDSX), under the same rule
         bool lds_x = false;
-        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1 && c->ldsws_mode != 0) {
+        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1) {
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + table_ldsx_bytes(ni_top, c->rest_M) + c->lds_pad;
-            const size_t per_cu = (size_t)(S + c->n_cus - 1) / (size_t)std::max(c->n_cus, 1);
-            const bool resident = per_cu * ((need + 1279) / 1280 * 1280) <= kTableLdsPerCU && per_cu <= 32;
-            if (need <= kTableLdsMaxWG && (c->ldsws_mode > 0 || resident)) { lds_x = true; table_lds = need; }
+            if (lds_home(need)) { lds_x = true; table_lds = need; }
         }
         bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= ((c->table_coarse || lds_ws) ? kTableLdsMaxWG : (size_t)64 * 1024);

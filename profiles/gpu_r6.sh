@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 closing stages (after the 128-class / MANY+SPREAD / GPU-fold-with-groups changes).  usage: bash profiles/gpu_r6.sh <tag> <stage> ...
+# Closing stages of a round (rounds 4 - 6).  usage: bash profiles/gpu_r6.sh <tag> <stage> ...
 #   fuzz   the four fuzzers on the new regimes and a slice of the old ones
 #   tests  every GPU test + smoke
 #   bench  the default bench line + sidecar;  rocprof  kernel trace of the default bench command
@@ -7,6 +7,16 @@ set -u
 TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
+# Standing first stage: a box that has a Go toolchain closes SURVEY 8(c) and (N2) by itself -- the determinised
+# reference against the oracle AND the HIP library, then the never-compiled cgo package through `go vet`.  Prints one line otherwise.
+if command -v go > /dev/null 2>&1 || [ -x /usr/local/go/bin/go ]; then
+  export PATH=$PATH:/usr/local/go/bin
+  ( go version; SIMON_PARITY_ENGINE=both bash oracle/run_ref.sh; echo "run_ref rc=$?";
+    if [ -d "${REF:-/root/reference}" ]; then ( cd integration/go && go vet ./... ); echo "go vet rc=$?"; fi ) > "$OUT/go_parity.txt" 2>&1
+  tail -5 "$OUT/go_parity.txt"
+else
+  echo "go: not on this box (SURVEY 8c / N2 stay unpinned)" | tee "$OUT/go_parity.txt"
+fi
 for STAGE in "$@"; do
   case $STAGE in
     fuzz)

@@ -30,14 +30,32 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture
+def _ws_home():
+    """Which home the scenario's workspace / mask rows get in a GPU test: None = by a stable hash of the test id (below); the core parity
+    module is parametrized over BOTH homes (pytest_generate_tests), so a regression of either shows whatever the test is called."""
+    return None
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__ == "test_gpu_parity" and "_ws_home" in metafunc.fixturenames:
+        metafunc.parametrize("_ws_home", ["hbm", "auto"])
+
+
 @pytest.fixture(autouse=True)
-def _alternate_the_home_of_the_workspace(request, monkeypatch):
+def _alternate_the_home_of_the_workspace(request, monkeypatch, _ws_home):
     """Round 5: a batch of at most one scenario per CU whose byte table + node state fit the CU's LDS runs generation 4 with its workspace
     in LDS (simon_table.hip: LDSWS) -- which is what most cpu+memory parity tests offer.  The workspace in HBM is what the 4 096-scenario
-    benchmark runs, so the suite keeps exercising BOTH: tests alternate by a stable hash of their id (even: SIMON_LDS_WS=0; odd: the
+    benchmark runs, so the suite keeps exercising BOTH: tests/test_gpu_parity.py runs every test on both homes (round 6: the split no
+    longer depends on a test's name there); the other modules alternate by a stable hash of the test id (even: SIMON_LDS_WS=0; odd: the
     library's own choice).  A test that sets SIMON_LDS_WS itself (tests/test_gpu_round5.py runs both on the same problems) overrides this;
     the library reads the variable once per context."""
     if "gpu" not in request.keywords or os.environ.get("SIMON_LDS_WS") is not None:
+        yield
+        return
+    if _ws_home is not None:
+        if _ws_home == "hbm":
+            monkeypatch.setenv("SIMON_LDS_WS", "0")
         yield
         return
     import zlib
