@@ -1378,6 +1378,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->wide.knobs.prof = getenv("SIMON_WIDE_PROF") != nullptr;
     c->wide.knobs.no_zmask = getenv("SIMON_WIDE_NO_ZMASK") != nullptr;
     c->wide.knobs.no_ident = getenv("SIMON_WIDE_NO_IDENT") != nullptr;
+    c->wide.knobs.no_rows_lds = getenv("SIMON_WIDE_NO_ROWS_LDS") != nullptr;
     if (const char* e = getenv("SIMON_WIDE_NO_CACHE_B")) c->wide.knobs.no_cache_b = *e ? atoi(e) : 3;
     if (const char* e = getenv("SIMON_STATE_BUDGET_MB")) c->wide.knobs.state_budget = (size_t)atoll(e) << 20;
     return c;
@@ -1920,12 +1921,6 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                 if (c->rest)
                     fprintf(stderr, "[SIMON_TABLE_PROF] REST select, ticks/cycle (averaged over ALL pods): pod row %.0f | filter words + summaries %.0f | candidates %.0f | table rows of excluded bests %.0f (needed on %.3f of the cycles) | per-class best %.0f | class term %.0f | totals + tie %.0f | rest %.0f\n",
                             acc[11] / S / P, acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[20] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[10] / S / P);
-                if (c->rest) {
-                    unsigned long long same = 0, blk = 0, unit = 0;
-                    for (int s2 = 0; s2 < S; ++s2) { const unsigned long long v = hp[(size_t)s2 * 24 + 23]; same += v & 0xFFFFF; blk += (v >> 20) & 0xFFFFF; unit += v >> 40; }
-                    fprintf(stderr, "[SIMON_TABLE_PROF] PIPE: speculations per cycle %.3f, adopted %.3f | successive winners: same node %.3f, same block of 16 %.3f, same unit of 64 %.3f (of all pods)\n",
-                            acc[22] / S / P, acc[21] / S / P, (double)same / S / P, (double)blk / S / P, (double)unit / S / P);
-                }
                 if (c->spread)
                     fprintf(stderr, "[SIMON_TABLE_PROF] spread pods, ticks/cycle: descriptor + first loads %.0f | counters, sizes %.0f | zone counters, Log, raw table %.0f | pass 1 %.0f | extremes, totals table %.0f | pass 2 %.0f | winner %.0f | counter stores %.0f\n",
                             acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[18] / S / P, acc[19] / S / P);

@@ -194,12 +194,16 @@ constexpr uint32_t kArgGpu = 1u, kArgMask = 2u, kArgEph = 4u, kArgNzeq = 8u, kAr
                    kArgLean = 512u /*no spread constraint, scoring term, host port, required affinity or local volume anywhere*/,
                    // stage A leaves a feasible node's InterPodAffinity raw score / the counts of its soft spread constraints in LDS and
                    // stage B reads them back instead of gathering the counters a second time (wide_run sets them when the arrays fit)
-                   kArgIpaCache = 2048u, kArgPtsCache = 4096u, kArgPtsSlotsShift = 13u /*3 bits: soft constraints per class, at most*/;
+                   kArgIpaCache = 2048u, kArgPtsCache = 4096u, kArgPtsSlotsShift = 13u /*3 bits: soft constraints per class, at most*/,
+                   // more than 64 node classes (no class mode): the pod class's rows of the four (pod class, node class) tables are
+                   // staged in LDS all the same when they fit (round 6: per feasible node they were up to seven dependent FLAT loads)
+                   kArgRowsLds = 65536u;
 
 // tuning / experiment knobs: environment variables read ONCE, when the context is created (simon_ctx_create)
 struct WideKnobs {
     bool no_lean = false;            // SIMON_WIDE_NO_LEAN
     bool no_table = false;           // SIMON_WIDE_NO_TABLE
+    bool no_rows_lds = false;        // SIMON_WIDE_NO_ROWS_LDS: more than 64 node classes read their class rows from global memory as before round 6 (A/B runs)
     int no_cache_b = 0;              // SIMON_WIDE_NO_CACHE_B (bit 0: InterPodAffinity scores, bit 1: soft-spread counts; no value = both): stage B gathers its counters again (A/B runs)
     bool prof = false;               // SIMON_WIDE_PROF (only builds with -DSIMON_WIDE_PROFILE act on it)
     size_t state_budget = 16ull << 30;   // SIMON_STATE_BUDGET_MB: HBM for per-scenario state of the all-feature kernel

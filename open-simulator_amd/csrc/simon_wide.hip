@@ -671,7 +671,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     // per-thread per-class best keys of the single-pass cycle: s_kc[c * T + tid], updated with an LDS max (one LDS
     // instruction per feasible node instead of a compare/select chain over the classes; -4 % on config 5), swapped out
     // against 0 once per cycle
-    unsigned* const s_kc = (unsigned*)(s_rows2 + (((A.flags & kArgClassMode) != 0u) ? 2 * 4 * A.Cn : 0));
+    unsigned* const s_kc = (unsigned*)(s_rows2 + (((A.flags & (kArgClassMode | kArgRowsLds)) != 0u) ? 2 * 4 * A.Cn : 0));
     // caches of stage A's counter gathers for stage B, by node (written and read by the lane that owns the node)
     int* const s_ipa = (int*)(s_kc + ((((A.flags & kArgClassMode) != 0u) && A.Cn <= 8) ? A.Cn * T : 0));
     int* const s_pts = s_ipa + ((A.flags & kArgIpaCache) ? A.bc_words : 0);          // [slot][bc_words]
@@ -685,6 +685,7 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
         for (int c = 0; c < Cn; ++c) s_kc[c * T + tid] = 0u;
     const int32_t* order = A.orders + (size_t)A.scen[s].order_id * P;
     const bool class_mode = ((A.flags & kArgClassMode) != 0u);
+    const bool rows_lds = !class_mode && ((A.flags & kArgRowsLds) != 0u);
     const bool use_tab = !EXPLAIN && A.n_sigs > 0;
     // selectHost's tie-break index of a node / node of a tie-break index: pool order unless the host supplied the scenario's
     // nodeTree ranks (clusters with several zones)
@@ -782,6 +783,30 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
             bool refill = false;
             int64_t* s_rows = nullptr;
             long long rv0 = 0, rv1 = 0, rv2 = 0, rv3 = 0;
+            if (rows_lds) {
+                // More than 64 node classes (round 6): no class mode -- the feasible-class set is no 64-bit mask -- but the rows are staged in
+                // LDS all the same.  Read through the global tables they cost every feasible node up to seven dependent FLAT loads (a
+                // pointer that is LDS in one mode and global in the other is generic to the compiler): three in stage A's bookkeeping, four
+                // in stage B's class term, each with its own s_waitcnt vmcnt(0) lgkmcnt(0).  Pods of one workload arrive in a run, so a
+                // refill is rare: it is done on the spot, behind a barrier; the two copies alternate as in class mode.
+                if (rows_cls != p.cls) {
+                    rows_buf ^= 1;
+                    int64_t* dst = s_rows2 + (size_t)rows_buf * 4 * Cn;
+                    for (int c = tid; c < Cn; c += T) {
+                        dst[c] = raw_row[c];
+                        dst[Cn + c] = na_row ? na_row[c] : 0;
+                        dst[2 * Cn + c] = tt_row ? tt_row[c] : 0;
+                        dst[3 * Cn + c] = add_row ? add_row[c] : 0;
+                    }
+                    rows_cls = p.cls;
+                    __syncthreads();
+                }
+                s_rows = s_rows2 + (size_t)rows_buf * 4 * Cn;
+                raw_row = s_rows;
+                if (na_row) na_row = s_rows + Cn;
+                if (tt_row) tt_row = s_rows + 2 * Cn;
+                if (add_row) add_row = s_rows + 3 * Cn;
+            }
             if (class_mode) {
                 // Refills alternate between two LDS copies: a lane still reading the previous class's rows (e.g. in a
                 // cycle that ended unschedulable, which has no barrier after its reads) is never overwritten, because
@@ -1561,7 +1586,8 @@ int ensure_mask_lanes(WideDevice& w, const HostInputs& in, int T, hipStream_t st
 
 // dynamic LDS of a launch: base | class, class rows, per-class keys, the stage-A caches
 static size_t wide_lds_bytes(const WideArgs& a, int T) {
-    size_t lds = (size_t)a.bc_words * 4 + ((a.flags & kArgClassMode) ? (size_t)2 * 4 * a.Cn * 8 + (a.Cn <= 8 ? (size_t)a.Cn * T * 4 : 0) : 0);
+    size_t lds = (size_t)a.bc_words * 4 + ((a.flags & (kArgClassMode | kArgRowsLds)) ? (size_t)2 * 4 * a.Cn * 8 : 0) +
+                 (((a.flags & kArgClassMode) && a.Cn <= 8) ? (size_t)a.Cn * T * 4 : 0);
     if (a.flags & kArgIpaCache) lds += (size_t)a.bc_words * 4;
     if (a.flags & kArgPtsCache) lds += (size_t)a.bc_words * 4 * ((a.flags >> kArgPtsSlotsShift) & 7u);
     return lds;
@@ -1942,6 +1968,10 @@ int wide_run(WideDevice& w, const HostInputs& in, const WideScenario* d_scen, co
     a.bc_words = (std::max(max_n, 1) + 3) & ~3;
     {   // stage-A caches for stage B (kArgIpaCache / kArgPtsCache): only when they leave the workgroups-per-CU of the launch alone
         const size_t budget = (T == 256 ? 72 : 140) * 1024;
+        if (!(a.flags & kArgClassMode) && !w.knobs.no_rows_lds) {      // more than 64 node classes: the class rows in LDS when they fit (first call on the budget)
+            a.flags |= kArgRowsLds;
+            if (wide_lds_bytes(a, T) > budget) a.flags &= ~kArgRowsLds;
+        }
         if (in.has_ipa_score && !(w.knobs.no_cache_b & 1)) {
             long long maxw = 1, len = 1;
             for (int32_t x : in.pref_w) maxw = std::max<long long>(maxw, std::llabs((long long)x));
