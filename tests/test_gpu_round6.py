@@ -159,3 +159,27 @@ def test_config5_and_rest_features_with_counters_in_lds():
         assert st.kernel_generation == 6
         assert res.unscheduled.tolist() == ref.unscheduled.tolist()
         assert (res.placement == ref.placement).all()
+
+
+def test_bench_strong_scaling_splits_the_fixed_batch_over_the_ranks(tmp_path):
+    """bench.py --gpus 2 --strong: BASELINE config 3's fixed batch (--orders-per-gpu orders in TOTAL) split over the ranks, "scaling": "strong"
+    (the day a SCALE run happens both curves exist).  Two ranks on device 0 over gloo, as the weak-scaling twin in
+    tests/test_gpu_parity.py."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, SIMON_BENCH_BACKEND="gloo", SIMON_BENCH_SHARE_DEVICE="1", SIMON_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--strong", "--steps", "2", "--warmup", "1",
+           "--counts", "32", "--pods", "2000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["scenarios_per_gpu"] == 32 * 4 // 2 and d["value"] > 0
+    assert "4 pod orders = 128 scenarios" in d["config"]["workload"] and "fixed batch" in d["config"]["workload"]

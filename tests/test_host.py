@@ -250,3 +250,15 @@ def test_quantity_binary_si_and_open_local_reason_texts():
         "1 not LVM on node e, 2 Insufficient LVM storage, requested 10Gi, used 95Gi, capacity 100Gi.")
     with pytest.raises(ValueError):
         fiterror.fit_error(codes)                                      # the sizes are not optional
+
+
+def test_bench_strong_mode_keeps_the_batch_fixed():
+    """--strong: the workload is config 3's 4 096 scenarios whatever the world size (weak: 4 orders per rank)."""
+    import argparse
+    import bench
+    from open_simulator_amd import synth
+    base = dict(workload="config3", orders_per_gpu=4, counts=16, pods=300, c5_scenarios=0)
+    (prob, scen_w, _), n_w = bench.build_workload(argparse.Namespace(strong=False, **base), synth, 4)
+    (_, scen_s, _), n_s = bench.build_workload(argparse.Namespace(strong=True, **base), synth, 4)
+    (_, scen_1, _), n_1 = bench.build_workload(argparse.Namespace(strong=False, **base), synth, 1)
+    assert (n_w, n_s, n_1) == (16, 4, 4) and len(scen_w) == 4 * len(scen_s) and (scen_s == scen_1).all()
