@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 6: the four fuzzers at scale on the final kernels.  usage: bash profiles/gpu_fuzz_r6.sh <tag>
+set -u
+TAG=$1
+OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
+{
+  timeout 900 python tests/fuzz_gpu.py ${FG_N:-1000} 61000 2>&1 | tail -2
+  timeout 900 python tests/fuzz_table.py ${FT_N:-1200} 62000 2>&1 | tail -2
+  timeout 900 python tests/fuzz_table.py 300 630000 2>&1 | tail -2
+  timeout 900 python tests/fuzz_rest.py ${FR_N:-1200} 64000 2>&1 | tail -2
+  timeout 900 python tests/fuzz_spread.py ${FS_N:-600} 65000 2>&1 | tail -2
+  timeout 900 python tests/fuzz_spread.py 200 660000 2>&1 | tail -2
+} | grep -v amdgpu.ids > "$OUT/fuzzers_at_scale.txt"
+cat "$OUT/fuzzers_at_scale.txt"

@@ -30,6 +30,22 @@ def main():
         N, P, S = int(rng.integers(3, 300)), int(rng.integers(1, 500)), int(rng.integers(1, 10))
         prob = randprob.rand_problem(70000 + case, N=N, P=P, **feat)
         scen, orders = randprob.rand_scenarios(case, prob, S=S)
+        v6 = []
+        if rng.random() < 0.35:                              # ABI v6: pods of unequal priority -> the DefaultPreemption-risk flag per scenario
+            prob.priority = rng.choice([0, 0, 5, 100, -1], P).astype(np.int32)
+            prob.init_min_priority = int(rng.choice([0x7fffffff, 0, 50]))
+            v6.append("priority")
+        if rng.random() < 0.35:                              # ABI v6: ScalarResources entries of quantity 0 (bit k < K: tracked resources, bit 7: any other)
+            K = 0 if prob.scalar_req is None else prob.scalar_req.shape[0]
+            ent = np.where(rng.random(P) < 0.4, 0x80, 0).astype(np.uint8)
+            for k in range(K):
+                ent |= np.where(rng.random(P) < 0.4, 1 << k, 0).astype(np.uint8)
+            if "zero_pods" in feat and rng.random() < 0.7:   # some pods that request nothing at all: the entry is all that keeps them off the shortcut
+                z = rng.random(P) < 0.3
+                prob.req_cpu = np.where(z, 0, prob.req_cpu).astype(np.int64)
+                prob.req_mem = np.where(z, 0, prob.req_mem).astype(np.int64)
+            prob.scalar_entries = ent
+            v6.append("entries")
         ranks = None
         if rng.random() < 0.3:
             ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
@@ -49,16 +65,17 @@ def main():
                     ctx.set_node_ranks(ranks)
                 ctx.run_loaded(True)
                 res = ctx.fetch(True)
+                risk = ctx.fetch_preempt_risk()
                 variant = ctx.stats().kernel_variant
         finally:
             for k in env:
                 os.environ.pop(k, None)
         ok = (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
               res.used_mem.tolist() == ref.used_mem.tolist() and (res.placement == ref.placement).all() and
-              res.used_vg.tolist() == ref.used_vg.tolist())
+              res.used_vg.tolist() == ref.used_vg.tolist() and risk.tolist() == ref.preempt_risk.tolist())
         if not ok:
             bad += 1
-            print("MISMATCH case", case, "N", N, "P", P, "S", S, "variant", variant, "feat", feat, "ranks", ranks is not None, "env", env, flush=True)
+            print("MISMATCH case", case, "N", N, "P", P, "S", S, "variant", variant, "feat", feat, "ranks", ranks is not None, "env", env, "v6", v6, flush=True)
     print(f"fuzz: {n_cases} cases from {first}, mismatches {bad}")
     return 1 if bad else 0
 
