@@ -57,6 +57,7 @@ KERNEL_SHORT = {1: "narrow_v1", 2: "wide (all-feature kernel)", 3: "narrow_fast"
 SERVICE_PREF = 60                 # services of the `config3_service_pref` sub-record whose pods carry preferred self anti-affinity
 SERVICE_ANTI = 20                 # services of the `config3_service_anti` sub-record that also require anti-affinity to their own pods (hostname key)
 SERVICE_GPU = 20                  # services of the `config3_service_gpu20` sub-record whose pods ask for GPU memory (30 % of the nodes carry devices)
+SERVICE_SHAPES = 30               # node shapes of the `config3_service_shapes30` sub-record: x 3 zones = 90 internal node classes (generation 7, two classes per lane)
 SMALL_COUNTS = 16                 # node counts of the `service_small` sub-record (x 4 pod orders = 64 scenarios: what a sweep of candidate sizes looks like)
 SIG_CLIFF = 300                   # ... and of the `config3_sigs300` row: three groups of 128 signatures per wave (the table's last regime before 384)
 CLASS_RECORD = 80                 # distinct node shapes of the `config3_classes80` row: more than 64 internal node classes (two per lane on the score table)
@@ -299,7 +300,7 @@ def build_workload(args, synth, world):
     if args.workload == "config2":
         return synth.config2(), 1
     if args.workload == "service":             # config 3's pool and sweep, every pod selected by a Service (system-default soft spread)
-        return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, n_anti=args.anti, n_pref=args.pref, n_hard=args.hard, n_gpu=args.gpu_services), n_orders
+        return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, n_anti=args.anti, n_pref=args.pref, n_hard=args.hard, n_gpu=args.gpu_services, n_shapes=args.shapes), n_orders
     if args.workload == "config5service":      # config 5's shape as Deployments behind Services: GPU share + required self anti-affinity + taints + soft spread
         return synth.config5_service(n_scen=c5_scenarios(args), n_orders=4), 4
     if args.workload == "typical":             # Kubernetes objects of a typical cluster, 64 candidate sizes (the `simon apply` shape; team mode of generation 7)
@@ -424,6 +425,10 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config_service(n_pref=SERVICE_PREF)
         child = ["--workload", "service", "--pref", str(SERVICE_PREF)]
         wl, label = "config3", f"config 3 with Service-selected pods that prefer not to sit next to their own kind ({SERVICE_PREF} services, hostname 100 + zone 50)"
+    elif name == "service_shapes":                  # ... the existing nodes in 30 shapes: x 3 zones = 90 internal node classes (round 6: two classes per lane in the walks; was: the all-feature kernel)
+        prob, scen, orders = synth.config_service(n_counts=SMALL_COUNTS * 4, n_shapes=SERVICE_SHAPES)
+        child = ["--workload", "service", "--counts", str(SMALL_COUNTS * 4), "--shapes", str(SERVICE_SHAPES)]
+        wl, label = "config3", f"config 3 with Service-selected pods, nodes in {SERVICE_SHAPES} shapes x 3 zones, {16 * SMALL_COUNTS} scenarios"
     elif name == "service_gpu":                     # a gpushare cluster behind Services: GPU share folded into the table, on generation 7 (was: the all-feature kernel)
         prob, scen, orders = synth.config_service(n_counts=SMALL_COUNTS * 4, n_gpu=SERVICE_GPU)
         child = ["--workload", "service", "--counts", str(SMALL_COUNTS * 4), "--gpu-services", str(SERVICE_GPU)]
@@ -466,7 +471,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "config3_small": f"config3_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "config5_service": f"config5_service_S{c5_scen}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
+    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "config3_small": f"config3_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "service_shapes": f"config3_service_shapes{SERVICE_SHAPES}_S{16 * SMALL_COUNTS}", "config5_service": f"config5_service_S{c5_scen}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
                         "config3sig": f"config3_sigs{SIG_RECORD}", "config3sig_cliff": f"config3_sigs{SIG_CLIFF}",
                         "config3_classes": f"config3_classes{CLASS_RECORD}", "config3_classes_cliff": f"config3_classes{CLASS_CLIFF}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
@@ -770,6 +775,7 @@ def main():
     ap.add_argument("--hard", type=int, default=0, help="--workload service: services (every third) with a hard zone constraint on their own pods (maxSkew 2)")
     ap.add_argument("--pref", type=int, default=0, help="--workload service: services whose pods prefer not to sit next to their own kind (hostname 100, zone 50)")
     ap.add_argument("--gpu-services", type=int, default=0, help="--workload service: services whose pods ask for GPU share (a gpushare cluster behind Services)")
+    ap.add_argument("--shapes", type=int, default=0, help="--workload service: distinct node shapes of the existing nodes (x 3 zones = internal node classes of generation 7)")
     ap.add_argument("--anti", type=int, default=0, help="--workload service: services whose pods also require anti-affinity to their own kind on the hostname key")
     ap.add_argument("--workload", choices=["config3", "config5", "config5service", "config2", "config3sig", "config3classes", "service", "typical", "widemix"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
@@ -924,7 +930,7 @@ def main():
             for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", sub_steps, 1, 64, 0), ("service", sub_steps, 1, 64, 0),
                                                  ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
                                                  ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING),
-                                                 ("service_small", sub_steps, 1, 16, 0), ("service_gpu", sub_steps, 1, 16, 0), ("config5_service", sub_steps, 1, 16, c5_scenarios(args)), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
+                                                 ("service_small", sub_steps, 1, 16, 0), ("service_gpu", sub_steps, 1, 16, 0), ("service_shapes", sub_steps, 1, 16, 0), ("config5_service", sub_steps, 1, 16, c5_scenarios(args)), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
                                                  ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0), ("config3_classes_cliff", sub_steps, 1, 16, 0),
                                                  ("config3_small", sub_steps, 1, 16, 0)):
                 try:

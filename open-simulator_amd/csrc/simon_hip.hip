@@ -139,6 +139,7 @@ struct simon_ctx : simon::HostInputs {
     // InterPodAffinity preferred terms in self-referential form, scored in spread_select's table (spread_supported); env SIMON_NO_IPA_FOLD
     bool hard_fold = false, no_hard_fold = false; // hard spread constraints on zone-like keys as per-class verdicts of spread_select; env SIMON_NO_HARD_FOLD
     bool ipa_fold = false, no_ipa_fold = false;
+    bool no_cn2 = false;                          // env SIMON_NO_CN2: generation 7 stays at 64 node classes (A/B + tests)
     std::vector<int32_t> ipa_h_term, ipa_h_w;     // [Cp] the hostname-like term of a class's raw score (-1: none) and its coefficient
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
@@ -1075,7 +1076,10 @@ int stage_narrow(simon_ctx* c) {
             auto key = std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
-                if ((int)shapes.size() == ((c->rest || c->spread) ? kTableMaxClasses : kTableMaxClassesPlain)) { c->table_ok = false; break; }
+                // one class per lane in the REST select and in a walk that scores preferred / hard terms; two per lane in the walks of soft
+                // constraints alone (round 6, simon_table.hip: CN2) as in the instantiations without rows and walks
+                const int cls_max = c->rest ? kTableMaxClasses : c->spread ? ((c->ipa_fold || c->hard_fold || c->no_cn2) ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
+                if ((int)shapes.size() == cls_max) { c->table_ok = false; break; }
                 it = cls_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};
                 sh.cap_c = (double)a_cpu[j]; sh.cap_m = (double)a_mem[j];
@@ -1087,6 +1091,7 @@ int stage_narrow(simon_ctx* c) {
             }
             ncls_t[j] = it->second;
         }
+        if (c->table_ok && c->spread && (int)shapes.size() > kTableMaxClasses && sigs.size() > 128) c->table_ok = false;   // (CN2 serves <= 128 signatures)
         if (c->table_ok) {
             const int Ct = (int)shapes.size();
             c->n_sigs = (int)sigs.size(); c->Cn_t = Ct;
@@ -1359,6 +1364,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_fold = getenv("SIMON_NO_FOLD") != nullptr;                  // A/B + tests: anti-affinity / ports through the position masks (or the all-feature kernel)
     c->no_sig_twins = getenv("SIMON_TABLE_NO_TWINS") != nullptr;      // A/B: signature ids in order of appearance
     c->no_hard_fold = getenv("SIMON_NO_HARD_FOLD") != nullptr;        // A/B + tests: hard spread constraints always on the all-feature kernel
+    c->no_cn2 = getenv("SIMON_NO_CN2") != nullptr;
     c->no_ipa_fold = getenv("SIMON_NO_IPA_FOLD") != nullptr;          // A/B + tests: preferred pod (anti-)affinity always on the all-feature kernel
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     if (const char* e = getenv("SIMON_TEAM")) { const int v = atoi(e); c->team_mode = v == 0 ? 0 : (v == 1 || v == kTeamWaves) ? 1 : -1; }
@@ -1702,7 +1708,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             // 256 scenarios 7.7 ms, 4 096 14.0 ms, 8 192 27.5 ms one-level / 32.3 ms two-level; 100 signatures 39.5 / 32.1 ms):
             // a round of w waves per CU takes 1 + 0.055 (w - 1) units up to 16 waves and 0.11 per wave beyond.
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
-            const int nzk = c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0)) : -1;   // (| 0x100: the second score table of spread_select)
+            const int nzk = c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (Ct > kTableMaxClasses ? 0x400 : 0)) : -1;   // (| 0x100: the second score table of spread_select; | 0x400: CN2's larger one)
             const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest, nzk) + c->lds_pad;
             const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= kTableLdsMaxWG;
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
@@ -1827,7 +1833,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         const int team_max = c->team_max_s >= 0 ? c->team_max_s : 2 * c->n_cus;
         int team = (c->spread && c->table_coarse && !c->rest && c->n_sigs <= 128 && c->team_mode != 0 && (c->team_mode > 0 || S <= team_max)) ? kTeamWaves : 1;
         auto lds_for = [&](int tm) -> size_t {
-            return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0)) : -1) + c->lds_pad : 0;
+            return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0) | (c->Cn_t > kTableMaxClasses ? 0x400 : 0)) : -1) + c->lds_pad : 0;
         };
         if (team > 1 && lds_for(team) > kTableLdsMaxWG) team = 1;           // (its extra table does not fit: the single-wave shape still may)
         size_t table_lds = lds_for(team);

@@ -109,13 +109,15 @@ constexpr int kSpreadMaxHostTerms = 4096, kSpreadMaxZoneTerms = 1024, kSpreadMax
 #define SIMON_SPREAD_TAB_MAX 512          // (tests build a library with a tiny table to drive every pod through the general walk)
 #endif
 constexpr int kSpreadTabMax = SIMON_SPREAD_TAB_MAX;       // entries of spread_select's per-pod score table in LDS: classes x (largest counter + 1, a power of two)
+constexpr int kSpreadTabMax2 = 2048;    // ... of the instantiations for 65 .. 128 node classes (table_kernel: CN2)
 constexpr int kTeamWaves = 4;           // team mode (table_kernel: NW): waves per scenario, one per SIMD of the CU.  8 and 16 were built and measured
                                         // SLOWER on every batch (profiles/r04/r04b_*: once the walks are a quarter, the leader's chain and the barriers decide)
 constexpr int kTeamWavesMax = 16;       // (the exchange slots are sized for it: a wider team is one more translation unit, simon_table_team<N>.hip)
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (column content, allocatable) pairs: one lane each in the REST select and the SPREAD walks
+constexpr int kTableMaxClassesSpread = 128;  // ... two per lane in the SPREAD walks as well when the walk scores soft constraints only (CN2, round 6)
 constexpr int kTableMaxClassesPlain = 128;   // ... two per lane where only the prologue and the class terms' re-base are lane-shaped (no REST rows, no SPREAD)
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD; | 0x100: second score table; | 0x200: team mode)
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD; | 0x100: second score table; | 0x200: team mode; | 0x400: CN2's larger score table)
 size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0);  // HBM workspace of ONE scenario with ni padded positions
 // launches n_blocks scenarios (one 64-thread workgroup each), scenario of block b = a.perm[b]
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st);
@@ -132,6 +134,7 @@ inline size_t table_ldsx_bytes(int ni_max, int M) {   // rows [M][ni_max / 16] u
 hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)
 hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
+hipError_t launch_table_spread2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);   // ... for 65 .. 128 node classes (simon_table_spread2.hip)
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
                             int32_t* placement, hipStream_t st);

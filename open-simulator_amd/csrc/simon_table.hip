@@ -208,12 +208,13 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     // the pod being placed
     const bool ipa = nzk >= 0 && (nzk & 0x100);                       // the problem has preferred pod (anti-)affinity terms: a second table
     const bool team = nzk >= 0 && (nzk & 0x200);                      // several waves per scenario (table_kernel: NW > 1): totals table of its own + exchange slots
+    const bool cn2 = nzk >= 0 && (nzk & 0x400);                       // 65 .. 128 node classes under the walks (table_kernel: CN2): a score table of kSpreadTabMax2 entries
     if (nzk >= 0) nzk &= 0xFF;
     c.zdom = o; o += nzk >= 0 ? al((nzk > 0 ? nzk : 1) * Cn) : 0;
     c.stash = o; o += nzk >= 0 ? al(ni_max * 2) : 0;
-    c.tab = o; o += nzk >= 0 ? kSpreadTabMax * 4 : 0;
+    c.tab = o; o += nzk >= 0 ? (cn2 ? kSpreadTabMax2 : kSpreadTabMax) * 4 : 0;
     c.tabi = o; o += ipa ? kSpreadTabMax * 4 : 0;
-    c.tab2 = o; o += team ? kSpreadTabMax * 4 : 0;
+    c.tab2 = o; o += team ? (cn2 ? kSpreadTabMax2 : kSpreadTabMax) * 4 : 0;
     c.xch = o; o += team ? kTeamWavesMax * 6 * 4 : 0;
     c.total = o;
     return c;
@@ -347,7 +348,11 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // LDSX (round 5): generation 6's position-mask rows (g_xm), their totals and the canonical index of every position live in LDS -- the
 // same idea for the batches of a gpushare sweep (config 5 x 256: one scenario per CU, 71 KB of rows): the REST select's filter words and
 // the canonical tie-break of the device / device-less twin classes (every other cycle of config 5) stop being memory round trips.
-template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1, bool LDSWS = false, bool LDSX = false>
+// CN2 (round 6): 65 .. 128 internal node classes under generation 7's walks -- the zone split multiplies the node shapes by the zones, so 25
+// shapes in 3 zones used to leave the table.  spread_select keeps its per-class values one per lane; here lane l also holds class 64 + l
+// (as the prologue and the re-base do for the instantiations without walks since round 4).  Own instantiations (the second set of
+// per-class registers would spill in the 128-VGPR kernels that serve <= 64 classes); single wave, no preferred / hard terms in the walk.
+template <bool HAS_MASK, bool NZEQ, bool HAS_PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF, bool MANY, bool SPREAD, int NW = 1, bool LDSWS = false, bool LDSX = false, bool CN2 = false>
 #ifndef SIMON_SPREAD_WAVES
 #define SIMON_SPREAD_WAVES 4
 #endif
@@ -397,7 +402,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     static_assert(!SPREAD || (COARSE && !REST), "SPREAD is built on the two-level layout, without the REST rows");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0)) : -1);
+    static_assert(!CN2 || (SPREAD && !AFF && !MANY), "CN2 = two node classes per lane in spread_select: soft constraints only, <= 128 signatures");
+    constexpr int TABMAX = CN2 ? kSpreadTabMax2 : kSpreadTabMax;
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0) | (CN2 ? 0x400 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
     signed char* s_zdom = (signed char*)(smem + cv.zdom);          // SPREAD: [NZK][Cn]
     unsigned short* s_stash = (unsigned short*)(smem + cv.stash);  // SPREAD: [positions] count | table byte << 8 of the pod being placed
@@ -1113,6 +1120,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             }
         };
         const int dd = lane < Cn ? lane : 0;
+        const bool v2 = CN2 && 64 + lane < Cn;                            // CN2: this lane's second class, 64 + lane
+        const int dd2 = v2 ? 64 + lane : 0;
         int kind[4], rowi[4], zsl[4], skew[4];
         bool dup[4];
 #pragma unroll
@@ -1177,6 +1186,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 czv[e] = zd >= 0 ? g_zcnt[rowi[e] * 16 + zd] : 0u;
             }
         }
+        int cntd2 = 0;
+        unsigned czv2[4] = {0u, 0u, 0u, 0u};
+        if constexpr (CN2) {
+            cntd2 = v2 ? g_cnt[k * Cn + dd2] : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v2 && e < soft_n && kind[e] == 2) {
+                    const int zd = s_zdom[zsl[e] * Cn + dd2];
+                    czv2[e] = zd >= 0 ? g_zcnt[rowi[e] * 16 + zd] : 0u;
+                }
+        }
         int zipa = 0;                                                     // per class: the zone-like part of the InterPodAffinity raw score
         if constexpr (kIpa) {
 #pragma unroll
@@ -1213,6 +1233,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (e < soft_n && kind[e] == 2) ign = ign || s_zdom[zsl[e] * Cn + dd] < 0;
+        bool ign2 = false;
+        if constexpr (CN2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < soft_n && kind[e] == 2) ign2 = ign2 || s_zdom[zsl[e] * Cn + dd2] < 0;
+        }
         bool excl = false;                                                // this class fails a hard constraint of the pod
         if constexpr (kIpa) {
 #pragma unroll
@@ -1227,14 +1253,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
         }
         const bool scored = lane < Cn && cntd > 0 && !ign && !excl;
-        const int F = __builtin_amdgcn_readfirstlane(wave_sum_i32_t(scored ? cntd : 0));   // len(filteredNodes) - len(IgnoredNodes)
+        const bool scored2 = CN2 && v2 && cntd2 > 0 && !ign2;
+        const int F = __builtin_amdgcn_readfirstlane(wave_sum_i32_t((scored ? cntd : 0) + (scored2 ? cntd2 : 0)));   // len(filteredNodes) - len(IgnoredNodes)
         int sz[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                                     // TopologyNormalizingWeight (:98-106, :279-281): its size argument
             sz[e] = 0;
             if (e < soft_n && !dup[e]) {
                 if (kind[e] == 1) sz[e] = F;
-                else sz[e] = __popc((unsigned)__builtin_amdgcn_readfirstlane((int)wave_or_u32_t(scored ? 1u << (s_zdom[zsl[e] * Cn + dd] & 31) : 0u)));
+                else sz[e] = __popc((unsigned)__builtin_amdgcn_readfirstlane((int)wave_or_u32_t((scored ? 1u << (s_zdom[zsl[e] * Cn + dd] & 31) : 0u) |
+                                                                                                   (scored2 ? 1u << (s_zdom[zsl[e] * Cn + dd2] & 31) : 0u))));
             }
         }
         TPROF(13);                                                         // spread: feasible-node counters arrived, sizes
@@ -1243,6 +1271,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         auto cst_of = [&](int e) -> double { return (double)(skew[e] - 1); };
         // per class, held by lane = class: the zone term of constraint e (scoreForCount, :287-289, of the class's zone)
         auto az_of = [&](int e) -> double { return (lane < Cn && e < soft_n && kind[e] == 2) ? (double)czv[e] * w_of(e) + cst_of(e) : 0.0; };
+        auto az2_of = [&](int e) -> double { return (v2 && e < soft_n && kind[e] == 2) ? (double)czv2[e] * w_of(e) + cst_of(e) : 0.0; };   // (CN2: class 64 + lane)
         // per class as well: "ignored" and the class term of the signature's row
         // (bit 30: excluded -- its nodes count as infeasible; the Simon normalisation then runs over the classes that are left, simon.go:76-101)
         int ctermv = (int)s_sn[k * Cn + dd];
@@ -1251,6 +1280,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 ctermv = class_term(lane < Cn && cntd > 0 && !excl, simon_raw[tc * Cn + dd], tc, dd);
         }
         const int clsw = (int)((unsigned)ctermv | (ign ? 0x80000000u : 0u) | (excl ? 0x40000000u : 0u));
+        const int clsw2 = CN2 ? (int)((unsigned)s_sn[k * Cn + dd2] | (ign2 ? 0x80000000u : 0u)) : 0;
+        auto cls_word = [&](int c) -> int {                                // the word of class c (uniform), from the lane that holds it
+            if constexpr (CN2) {
+                const int a = __builtin_amdgcn_readlane(clsw, c & 63), b = __builtin_amdgcn_readlane(clsw2, c & 63);
+                return c < 64 ? a : b;
+            } else return __builtin_amdgcn_readlane(clsw, c);
+        };
         auto lane_f64 = [&](double v, int l) -> double {
             const unsigned long long b = (unsigned long long)__double_as_longlong(v);
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
@@ -1268,7 +1304,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int hmx = __builtin_amdgcn_readfirstlane(hmx_v);
         const int lg = 32 - __clz(hmx);                                  // counts 0 .. (1 << lg) - 1
         const int E = Cn << lg;
-        if (simple && E <= kSpreadTabMax) {
+        if (simple && E <= TABMAX) {
             const double ws = nh == 1 ? w_of(0) : 0.0, cs = nh == 1 ? cst_of(0) : 0.0;
             const bool ipa_pod = kIpa && ipa_n > 0;
             // the per-class part: the zone-like constraints in list order (float addition is not associative; x + 0.0 == x)
@@ -1277,10 +1313,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             for (int e = 0; e < 4; ++e)
                 if (e < soft_n && kind[e] == 2) pcl = pcl + az_of(e);
             const unsigned long long pclb = (unsigned long long)__double_as_longlong(pcl);
+            unsigned long long pclb2 = 0ull;
+            if constexpr (CN2) {
+                double pcl2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < soft_n && kind[e] == 2) pcl2 = pcl2 + az2_of(e);
+                pclb2 = (unsigned long long)__double_as_longlong(pcl2);
+            }
             const int hmask = (1 << lg) - 1;
             for (int i0 = 0; i0 < E; i0 += 64) {                          // raw(class, count) = int64((count * w + c) + zone terms of the class)
-                const int i = i0 + lane, c4 = min(i >> lg, Cn - 1) * 4;
-                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)pclb), hi = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)(pclb >> 32));
+                const int i = i0 + lane, ci = min(i >> lg, Cn - 1), c4 = (CN2 ? ci & 63 : ci) * 4;
+                unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)pclb), hi = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)(pclb >> 32));
+                if constexpr (CN2) {
+                    const unsigned lo2 = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)pclb2), hi2 = (unsigned)__builtin_amdgcn_ds_bpermute(c4, (int)(unsigned)(pclb2 >> 32));
+                    lo = ci < 64 ? lo : lo2; hi = ci < 64 ? hi : hi2;
+                }
                 const double pc = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
                 const int raw = (int)(((double)(i & hmask) * ws + cs) + pc);
                 if (i < E) s_tab[i] = raw;
@@ -1301,7 +1349,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         const int c = winner_info(u) >> 16;
                         const int idx = (c << lg) + ((int)h1[j] & hmask);     // (padding positions and the no-hostname-term case read arbitrary bytes)
                         const int raw = s_tab[idx];
-                        const int cwv = __builtin_amdgcn_readlane(clsw, c);
+                        const int cwv = cls_word(c);
                         unsigned beff = byte1[j];
                         if constexpr (kIpa) beff = (cwv & 0x40000000) ? 0u : beff;   // a class a hard constraint excludes: no feasible node
                         const bool ok = (beff != 0u) & (cwv >= 0);            // (no short circuit: no branch)
@@ -1334,7 +1382,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             for (int i0 = 0; i0 < E; i0 += 64) {                          // class term + 2 x NormalizeScore (:217-256), in place
                 const int i = i0 + lane;
                 const int raw = s_tab[min(i, E - 1)];
-                const int cw = __builtin_amdgcn_ds_bpermute(min(i >> lg, Cn - 1) * 4, clsw);
+                const int ci = min(i >> lg, Cn - 1);
+                int cw = __builtin_amdgcn_ds_bpermute((CN2 ? ci & 63 : ci) * 4, clsw);
+                if constexpr (CN2) { const int cw2 = __builtin_amdgcn_ds_bpermute((ci & 63) * 4, clsw2); cw = ci < 64 ? cw : cw2; }
                 // (an entry no feasible scored node has may lie outside [min, max]: its value is never looked up)
                 int v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmm - raw)), rinv, hrinv);
                 v = cw >= 0 ? v : 0;                                      // ignored nodes score 0
@@ -1378,6 +1428,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 hb[e] = (e < soft_n && kind[e] == 1) ? g_hrow + (size_t)rowi[e] * ni : (const unsigned char*)g_tile;
                 w[e] = w_of(e); cst[e] = cst_of(e); azv[e] = az_of(e);
             }
+            double azv2[4] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (CN2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) azv2[e] = az2_of(e);
+            }
             // (InterPodAffinity raw score per position here: the count of its hostname-like term + the class's zone part)
             const unsigned char* hbI = ipa_h ? g_hrow + (size_t)rI[0] * ni : (const unsigned char*)g_tile;
             const bool ipa_pod = kIpa && ipa_n > 0;
@@ -1386,7 +1441,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 double scv = 0.0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const double az = lane_f64(azv[e], c);
+                    double az = lane_f64(azv[e], CN2 ? c & 63 : c);
+                    if constexpr (CN2) { const double az2 = lane_f64(azv2[e], c & 63); az = c < 64 ? az : az2; }
                     const double ah = (double)h[e] * w[e] + cst[e];
                     const double A = e < soft_n ? (kind[e] == 1 ? ah : az) : 0.0;
                     scv = scv + A;
@@ -1407,7 +1463,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 for (int j = 0; j < SG; ++j) {
                     const int c = winner_info(min(u0 + j, uhi - 1)) >> 16;
                     const int raw = raw_of(h[j], c);
-                    const int cwv = __builtin_amdgcn_readlane(clsw, c);
+                    const int cwv = cls_word(c);
                     unsigned beff = byte[j];
                     if constexpr (kIpa) beff = (cwv & 0x40000000) ? 0u : beff;
                     const bool ok = (beff != 0u) & (cwv >= 0);
@@ -1444,7 +1500,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     const int u = min(u0 + j, uhi - 1);
                     const int c = infoj[j] >> 16;
                     const int raw = raw_of(h[j], c);
-                    const int cw = __builtin_amdgcn_readlane(clsw, c);
+                    const int cw = cls_word(c);
                     int v = 0;
                     if (cw >= 0) v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmax + pmin - raw)), rinv, hrinv);
                     int iv = 0;                                           // InterPodAffinity NormalizeScore (:258-271)
@@ -2026,10 +2082,13 @@ static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipS
 constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
 #define SIMON_TEAM_CAT2(a, b) a##b
 #define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
-template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF>
+template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTuWaves>;
+    if constexpr (!AFF && !CN2) {                                     // 65 .. 128 node classes: two per lane in the walks (soft constraints only)
+        if (a.sc.Cn > 64) return launch_team6<M, Z, KQ, NBQ, RANKED, false, true>(a, n_blocks, lds, st);
+    }
+    if (a.sc.K > 64 * KQ || (!CN2 && a.sc.Cn > 64)) return hipErrorInvalidValue;
+    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTuWaves, false, false, CN2>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * kTuWaves), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2092,6 +2151,30 @@ hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask
     if (!a.spread || !a.coarse || a.rest || a.team > 1) return hipErrorInvalidValue;
     (void)has_mask;
     return nzeq ? launch_sp2<true, true>(a, n_blocks, lds_bytes, st) : launch_sp2<true, false>(a, n_blocks, lds_bytes, st);
+}
+#elif defined(SIMON_TABLE_SPREAD2_TU)
+// ---- this translation unit (simon_table_spread2.hip) holds generation 7 for 65 .. 128 internal node classes (CN2): soft constraints only,
+// <= 128 signatures, one wave per scenario ----
+template <bool Z, int KQ, int NBQ, bool RANKED = false>
+static hipError_t launch_sc3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (!RANKED) {
+        if (a.sc.rk_stride != 0) return launch_sc3<Z, KQ, NBQ, true>(a, n_blocks, lds, st);
+    }
+    if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, false, RANKED, false, false, true, 1, false, false, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    return hipGetLastError();
+}
+template <bool Z, int KQ>
+static hipError_t launch_sc2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.ni_max / 64 <= 64 ? launch_sc3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_sc3<Z, KQ, 2>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_spread2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.spread || !a.coarse || a.rest || a.team > 1 || a.sc.Cn <= 64 || a.sc.K > 128 || (a.sc.static_tables & 64)) return hipErrorInvalidValue;
+    if (a.sc.K > 64) return nzeq ? launch_sc2<true, 2>(a, n_blocks, lds_bytes, st) : launch_sc2<false, 2>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_sc2<true, 1>(a, n_blocks, lds_bytes, st) : launch_sc2<false, 1>(a, n_blocks, lds_bytes, st);
 }
 #elif defined(SIMON_TABLE_LDS_TU)
 // ---- this translation unit (simon_table_lds.hip) holds generation 4 with the scenario's workspace in LDS (LDSWS): small batches of small problems ----
@@ -2207,6 +2290,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
     if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
         return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
+    if (a.spread && a.sc.Cn > 64) return launch_table_spread2(a, n_blocks, nzeq, lds_bytes, st);   // generation 7, two node classes per lane: simon_table_spread2.hip
     if (a.spread) return launch_table_spread(a, n_blocks, has_mask, nzeq, lds_bytes, st);   // generation 7: simon_table_spread.hip
     if (a.lds_ws) return launch_table_lds(a, n_blocks, nzeq, lds_bytes, st);                // generation 4, workspace in LDS: simon_table_lds.hip
     has_pin = has_pin || a.rest || (a.sc.static_tables & (32 | 128));   // (& 32, & 128: the folds, carried by COARSE && !REST && HAS_PIN)

@@ -110,6 +110,9 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
             if (k < cm || (k >= c0 && k < c0 + cs))
                 r[k] = (long long)(((unsigned long long)(unsigned)__shfl((int)hi32, k, 64) << 32) | (unsigned)__shfl((int)lo32, k, 64));
         }
+#if defined(SIMON_WG_DBG) && (SIMON_WG_DBG & 1)
+        __syncthreads();
+#endif
 #else
 #pragma unroll
         for (int k = 0; k < kRed; ++k) {
@@ -1549,6 +1552,13 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     if (tid == 0) {
         uc = 0; um = 0; uv = 0;
         for (int w = 0; w < NW; ++w) { uc += red[0][w]; um += red[1][w]; uv += red[2][w]; }
+#if defined(SIMON_WG_DBG) && (SIMON_WG_DBG & 2)
+        if (LOCAL && (A.flags & kArgLocal)) {
+            uv = 0;
+            for (int j = 0; j < n; ++j)
+                if (COLD(A)->l_flags[j] & 1) for (int q = 0; q < COLD(A)->l_vg_cnt[j]; ++q) uv += v.st_vg()[(size_t)j * SIMON_MAX_VG + q];
+        }
+#endif
         A.unscheduled[s] = unsched;
         A.used_cpu[s] = uc;
         A.used_mem[s] = um;

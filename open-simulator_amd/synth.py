@@ -173,7 +173,14 @@ def config3_classes(n_classes: int = 80, **kw):
     classes" regimes of the score-table kernel as workloads (bench.py: `config3_classes80` runs two classes per lane, `config3_classes160`
     is past the 128 the table holds)."""
     prob, scen, orders = config3(**kw)
-    n_het = int(scen[0, 0])
+    _, pod_shapes = classify_pods(prob.req_cpu, prob.req_mem)
+    reshape_nodes(prob, int(scen[0, 0]), n_classes, pod_shapes)
+    return prob.normalise(), scen, orders
+
+
+def reshape_nodes(prob, n_het: int, n_classes: int, pod_shapes):
+    """The first n_het nodes of the pool in `n_classes - 1` distinct allocatable shapes (cpu 8..64 cores x memory 2..4 GiB per core, drawn with
+    splitmix64), the new-node template keeps (32 cores, 64 GiB) as class n_classes - 1; the Simon table is rebuilt for the shapes."""
     rng = SplitMix64(SEED + 31)
     shapes = []
     while len(shapes) < n_classes - 1:
@@ -188,9 +195,7 @@ def config3_classes(n_classes: int = 80, **kw):
     prob.alloc_cpu = np.array([shapes[c][0] * 1000 for c in cls], np.int64)
     prob.alloc_mem = np.array([shapes[c][1] << 30 for c in cls], np.int64)
     prob.n_node_classes = n_classes
-    _, pod_shapes = classify_pods(prob.req_cpu, prob.req_mem)
     prob.simon_raw = simon_raw_table(pod_shapes, [str(c) for c, _ in shapes], [f"{g}Gi" for _, g in shapes])
-    return prob.normalise(), scen, orders
 
 
 def config4(rank: int = 0, world: int = 1, n_counts: int = 1024, n_orders: int = 32, **kw):
@@ -279,7 +284,7 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
 
 
 def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000, n_het: int = 488, n_services: int = 60, n_zones: int = 3,
-                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0, n_gpu: int = 0, taint_pct: int = 0):
+                   seed: int = SEED + 6, n_anti: int = 0, n_pref: int = 0, n_hard: int = 0, n_gpu: int = 0, taint_pct: int = 0, n_shapes: int = 0):
     """BASELINE config 3's pool and sweep with every pod SELECTED BY A SERVICE: `n_services` Deployments behind a Service each (one
     request shape per service, replicas spread over the stream), so every pod carries the system-default soft PodTopologySpread
     constraints (podtopologyspread/plugin.go:39-50: maxSkew 3 on kubernetes.io/hostname, 5 on topology.kubernetes.io/zone,
@@ -291,7 +296,9 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
     `n_hard`: every third service up to n_hard of them carries a HARD zone constraint on its own pods (maxSkew 2, DoNotSchedule);
     `n_gpu`: a gpushare cluster behind Services -- 30 % of the nodes carry 4 or 8 GPU devices of 16 GiB, the pods of the first n_gpu
     services ask for GPU memory (2 / 4 / 8 GiB on one device, or 2 x 8 GiB; one request per service, as a Deployment's template has);
-    `taint_pct`: that share of the nodes is tainted NoSchedule and only the GPU services tolerate it (dedicated nodes)."""
+    `taint_pct`: that share of the nodes is tainted NoSchedule and only the GPU services tolerate it (dedicated nodes);
+    `n_shapes`: the existing nodes come in that many distinct allocatable shapes (config3_classes' draw) instead of four -- with the zone
+    split of generation 7 that is n_shapes x n_zones internal node classes (30 x 3: the two-classes-per-lane walks, simon_table.hip: CN2)."""
     from .gomath import spread_log_table
     n_total = n_het + n_counts
     cpu, mem, pods, ncls = gen_nodes(seed, n_het, n_total)
@@ -357,6 +364,9 @@ def config_service(n_counts: int = 1024, n_orders: int = 4, n_pods: int = 10000,
         prob.static_mask = np.stack([all_mask if t else untainted for t in tol])
         prob.static_reason = np.zeros((n_services, n_total), np.uint8)
         prob.static_reason[np.ix_(~tol, tainted)] = 7               # host id of "node(s) had taint {dedicated: }, ..."
+    if n_shapes > 0:
+        reshape_nodes(prob, n_het, n_shapes, shapes)
+        cpu, mem = prob.alloc_cpu, prob.alloc_mem
     prob = prob.normalise()
     orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
     counts = np.arange(n_het, n_het + n_counts, dtype=np.int32)

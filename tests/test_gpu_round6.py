@@ -183,3 +183,43 @@ def test_bench_strong_scaling_splits_the_fixed_batch_over_the_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["scenarios_per_gpu"] == 32 * 4 // 2 and d["value"] > 0
     assert "4 pod orders = 128 scenarios" in d["config"]["workload"] and "fixed batch" in d["config"]["workload"]
+
+
+def test_service_workload_with_30_node_shapes_in_3_zones_stays_on_generation_7():
+    """Generation 7 splits the internal node classes by zone, so 30 node shapes in 3 zones are 90 classes: since round 6 the walks of
+    soft constraints keep two classes per lane (simon_table.hip: CN2, simon_table_spread2.hip) instead of handing the problem to the
+    all-feature kernel.  BASELINE config 3's pool behind Services with the existing nodes in 30 shapes; random problems with 65 .. 128
+    classes, NonZeroRequested differing, presets / gates / pins, per-scenario node ranks; SIMON_NO_CN2 = the old route, same answers."""
+    prob, scen, orders = synth.config_service(n_counts=24, n_pods=4000, n_shapes=30)
+    pick = np.array([0, 5, 37, 70, 95])
+    ref = O.run_threaded(prob, scen[pick], orders)
+    for team, wg in (("0", 64), ("1", 256)):                           # one wave per scenario; a team of four (what a batch this small gets)
+        res, st, _ = run_gpu(prob, scen[pick], orders, env={"SIMON_TEAM": team})
+        assert st.kernel_generation == 7 and st.workgroup_size == wg
+        assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
+        assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
+    res0, st0, _ = run_gpu(prob, scen[pick], orders, env={"SIMON_NO_CN2": "1"})
+    assert st0.kernel_variant == capi.KERNEL_WIDE and (res0.placement == ref.placement).all()
+    on7 = 0
+    for seed, (N, P, ncls, feat) in enumerate([(400, 600, 20, {}), (900, 1200, 25, dict(nz_differs=True, init_state=True)), (2500, 1500, 22, dict(gates=True, presets=True)),
+                                               (700, 900, 18, dict(static_small=True, tight_pods=True, zero_pods=True)), (4000, 1200, 24, dict(pins=True, odd_units=True))]):
+        p2 = randprob.rand_problem(4242 + seed, N=N, P=P, spread_soft=True, n_node_classes=ncls, n_pod_classes=[3, 30, 60, 8, 100][seed], **feat)
+        s2, o2 = randprob.rand_scenarios(seed, p2, S=4, min_n=N // 3)
+        ranks = None
+        if seed % 2:                                                   # per-scenario node order: ties follow the ranks
+            rng = np.random.default_rng(seed)
+            ranks = np.zeros((len(s2), p2.n_nodes), np.int32)
+            for i, (n, _) in enumerate(np.asarray(s2).tolist()):
+                ranks[i, :n] = rng.permutation(n)
+        ref2 = O.run(p2, s2, o2, node_ranks=ranks) if ranks is not None else O.run_threaded(p2, s2, o2)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(p2)
+            ctx.load_scenarios(s2, o2)
+            if ranks is not None:
+                ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            r2 = ctx.fetch(True)
+            on7 += ctx.stats().kernel_generation == 7
+        assert r2.unscheduled.tolist() == ref2.unscheduled.tolist() and (r2.placement == ref2.placement).all()
+        assert r2.used_cpu.tolist() == ref2.used_cpu.tolist() and r2.used_mem.tolist() == ref2.used_mem.tolist()
+    assert on7 >= 4
