@@ -95,11 +95,12 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
             for (int k = 0; k < kRed; ++k) if (k < cm || (k >= c0 && k < c0 + cs)) mb[wave][k] = r[k];
         }
         __syncthreads();
-#ifdef SIMON_WG_REDUCE_LANES
+#ifndef SIMON_WG_REDUCE_PLAIN
         // lane k combines slot k over the waves (NW reads by kRed lanes instead of NW x kRed reads by every lane), then every lane takes the
-        // kRed results with shuffles.  Measured -3.4 % on the random mix (2 050 -> 1 980 ms, profiles/r04/r04u_*), but with it the
-        // Open-Local case of test_random_v2_features at 1 024 threads reports another used_vg while placements, unscheduled counts, used cpu
-        // and used memory are the oracle's at every workgroup size (profiles/r04/r05g_*, profiles/dbg/wide_1024_probe.py): OFF until understood.
+        // kRed results with shuffles.  Measured -3.4 % on the random mix (2 050 -> 1 980 ms, profiles/r04/r04u_*).  Rounds 4 / 5 kept it behind a
+        // #define because one build of it reported another used_vg at 1 024 threads with everything else right; round 6 found the cause in
+        // that build's ISA, not in this code: the register allocator spilled the final sum's address ahead of a join block's EXEC restore
+        // (profiles/spill_scan.py, which build() now runs over every unit).  -DSIMON_WG_REDUCE_PLAIN = the per-lane form (A/B).
         const int k_ = lane < kRed ? lane : 0;
         const bool is_max = k_ < cm;
         long long acc = mb[0][k_];
@@ -110,9 +111,6 @@ __device__ __forceinline__ void wg_reduce(long long (&r)[kRed], int cm, int c0, 
             if (k < cm || (k >= c0 && k < c0 + cs))
                 r[k] = (long long)(((unsigned long long)(unsigned)__shfl((int)hi32, k, 64) << 32) | (unsigned)__shfl((int)lo32, k, 64));
         }
-#if defined(SIMON_WG_DBG) && (SIMON_WG_DBG & 1)
-        __syncthreads();
-#endif
 #else
 #pragma unroll
         for (int k = 0; k < kRed; ++k) {
@@ -1552,13 +1550,6 @@ __global__ __launch_bounds__(T, T == 256 ? 2 : 1) void wide_kernel(const WideArg
     if (tid == 0) {
         uc = 0; um = 0; uv = 0;
         for (int w = 0; w < NW; ++w) { uc += red[0][w]; um += red[1][w]; uv += red[2][w]; }
-#if defined(SIMON_WG_DBG) && (SIMON_WG_DBG & 2)
-        if (LOCAL && (A.flags & kArgLocal)) {
-            uv = 0;
-            for (int j = 0; j < n; ++j)
-                if (COLD(A)->l_flags[j] & 1) for (int q = 0; q < COLD(A)->l_vg_cnt[j]; ++q) uv += v.st_vg()[(size_t)j * SIMON_MAX_VG + q];
-        }
-#endif
         A.unscheduled[s] = unsched;
         A.used_cpu[s] = uc;
         A.used_mem[s] = um;

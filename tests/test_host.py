@@ -262,3 +262,22 @@ def test_bench_strong_mode_keeps_the_batch_fixed():
     (_, scen_s, _), n_s = bench.build_workload(argparse.Namespace(strong=True, **base), synth, 4)
     (_, scen_1, _), n_1 = bench.build_workload(argparse.Namespace(strong=False, **base), synth, 1)
     assert (n_w, n_s, n_1) == (16, 4, 4) and len(scen_w) == 4 * len(scen_s) and (scen_s == scen_1).all()
+
+
+def test_spill_scan_flags_a_spill_ahead_of_the_exec_restore(tmp_path):
+    """profiles/spill_scan.py (run by build() over every unit's ISA): the one pattern that cost a wrong `used_vg` in an experimental build -- a VGPR
+    spill in a join block's prologue, BEFORE the block's `s_or_b64 exec, exec, ...` -- is reported; the same store after the restore, or behind
+    real work of the block, is not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("spill_scan", os.path.join(ROOT, "profiles", "spill_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = tmp_path / "bad.s"
+    bad.write_text("kern:\n\ts_cbranch_execz .LBB0_2\n.LBB0_1:\n\tglobal_store_dword v[2:3], v1, off\n.LBB0_2:\n\ts_mov_b32 s61, s39\n"
+                   "\tscratch_store_dwordx2 off, v[12:13], off offset:796 ; 8-byte Folded Spill\n\ts_or_b64 exec, exec, s[0:1]\n\ts_endpgm\n")
+    n, found = mod.scan(str(bad))
+    assert n == 1 and len(found) == 1 and found[0][0] == "kern" and found[0][1] == ".LBB0_2"
+    good = tmp_path / "good.s"
+    good.write_text("kern:\n.LBB0_2:\n\ts_or_b64 exec, exec, s[0:1]\n\tscratch_store_dwordx2 off, v[12:13], off offset:796 ; 8-byte Folded Spill\n"
+                    ".LBB0_3:\n\tv_add_u32_e32 v0, 1, v0\n\tscratch_store_dword off, v0, off offset:4 ; 4-byte Folded Spill\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n")
+    assert mod.scan(str(good)) == (2, [])
