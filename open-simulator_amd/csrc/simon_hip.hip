@@ -1065,7 +1065,7 @@ int stage_narrow(simon_ctx* c) {
         if (split_gpu) {
             std::set<std::tuple<int32_t, uint32_t, uint32_t, int>> keys;
             for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
-            split_gpu = (int)keys.size() <= kTableMaxClasses;
+            split_gpu = (int)keys.size() <= kTableMaxClasses;        // (the split is an optimisation: never at the price of the second class per lane)
         }
         auto zone_sub = [&](int j) -> int {
             int sub = 0;
@@ -1076,9 +1076,9 @@ int stage_narrow(simon_ctx* c) {
             auto key = std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
-                // one class per lane in the REST select and in a walk that scores preferred / hard terms; two per lane in the walks of soft
+                // one class per lane in a walk that scores preferred / hard terms; two per lane in the REST select and in the walks of soft
                 // constraints alone (round 6, simon_table.hip: CN2) as in the instantiations without rows and walks
-                const int cls_max = c->rest ? kTableMaxClasses : c->spread ? ((c->ipa_fold || c->hard_fold || c->no_cn2) ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
+                const int cls_max = (c->rest || c->spread) ? (((c->spread && (c->ipa_fold || c->hard_fold)) || c->no_cn2) ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
                 if ((int)shapes.size() == cls_max) { c->table_ok = false; break; }
                 it = cls_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};
@@ -1859,7 +1859,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         }
         // Generation 6 with its mask rows, row totals and canonical indices in LDS (round 5; simon_table.hip: LDSX), under the same rule
         bool lds_x = false;
-        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1) {
+        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1 && c->Cn_t <= kTableMaxClasses) {   // (65 .. 128 node classes: the rows stay in HBM, simon_table_rest2.hip)
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + table_ldsx_bytes(ni_top, c->rest_M) + c->lds_pad;
             if (lds_home(need)) { lds_x = true; table_lds = need; }
         }

@@ -36,7 +36,7 @@
 // required anti-affinity on node-level topology keys) scan their signature's rows under per-block position masks.
 //
 // Limits: K <= 384 signatures (two per lane in registers, further groups of 128 from memory), padded scenario size <= 4096 positions (<= 4095 nodes; two-level: 8192 /
-// 8191), <= 64 node classes, NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are
+// 8191), <= 128 node classes (two per lane where a select / walk is lane-shaped: CN2), NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are
 // permutations; REST: <= 32 GPU requests, <= 120 terms, <= 63 mask rows per pod.
 #include "simon_table.h"
 
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     static_assert(!SPREAD || (COARSE && !REST), "SPREAD is built on the two-level layout, without the REST rows");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
-    static_assert(!CN2 || (SPREAD && !AFF && !MANY), "CN2 = two node classes per lane in spread_select: soft constraints only, <= 128 signatures");
+    static_assert(!CN2 || (SPREAD && !AFF && !MANY) || (REST && !LDSX), "CN2 = two node classes per lane in spread_select (soft constraints only, <= 128 signatures) or in rest_select (rows in HBM)");
     constexpr int TABMAX = CN2 ? kSpreadTabMax2 : kSpreadTabMax;
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0) | (CN2 ? 0x400 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
@@ -892,6 +892,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int dd = lane < Cn ? lane : 0;
         const int rawc = simon_raw[tc * Cn + dd];                         // needed after the scan: in flight meanwhile
         if (lane < Cn) s_tmp[lane] = 0;
+        const bool v2 = CN2 && 64 + lane < Cn;                            // CN2: this lane's second class, 64 + lane
+        const int dd2 = v2 ? 64 + lane : 0;
+        int rawc2 = 0;
+        if constexpr (CN2) {
+            rawc2 = simon_raw[tc * Cn + dd2];
+            if (v2) s_tmp[dd2] = 0;
+        }
         __builtin_amdgcn_wave_barrier();
         const unsigned short* srow = s_sum + k * nbp;
         const uint2* xw = (const uint2*)g_xm;                             // [row][nun] words of 64 positions
@@ -970,6 +977,54 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const unsigned cbest = lane < Cn ? (unsigned)s_tmp[dd] : 0u;
         const bool present = cbest != 0u;
         TPROF_WAIT_LDS; TPROF(15);                                        // REST: per-class best (LDS max), read back
+        if constexpr (CN2) {
+            // 65 .. 128 node classes: the same per-class steps on both halves (lane l: classes l and 64 + l); the class term as renormalise forms it
+            const unsigned cbest2 = v2 ? (unsigned)s_tmp[dd2] : 0u;
+            const bool present2 = cbest2 != 0u;
+            if (!__ballot(present || present2)) return -1;
+            const int pos = (int)(PMASK - (cbest & PMASK)), pos2 = (int)(PMASK - (cbest2 & PMASK));
+            const int idx = cls_off[dd] - s_seg[dd] + pos, idx2 = cls_off[dd2] - s_seg[dd2] + pos2;
+            const int lo = min(wave_min_i32(present ? rawc : 0x7fffffff), wave_min_i32(present2 ? rawc2 : 0x7fffffff));
+            const int hi = max(wave_max_i32(present ? rawc : (int)0x80000000), wave_max_i32(present2 ? rawc2 : (int)0x80000000));
+            const int range = hi >= lo ? hi - lo : 0;
+            const double rr = range ? 1.0 / (double)range : 0.0;
+            int sn = (present && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
+            int sn2 = (present2 && range) ? 2 * (int)__builtin_fma((double)(rawc2 - lo) * 100.0, rr, 0.5 * rr) : 0;
+            GPtr<const TableCold> cc = cold;
+            if (sc.static_tables & 1) {
+                const int a0 = gp(cc->na_raw)[tc * Cn + dd], a1 = gp(cc->na_raw)[tc * Cn + dd2];
+                const int mx = max(wave_max_i32(present ? a0 : 0), wave_max_i32(present2 ? a1 : 0));
+                const double r = mx ? 1.0 / (double)mx : 0.0;
+                sn += (present && mx) ? (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 0;
+                sn2 += (present2 && mx) ? (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 0;
+            }
+            if (sc.static_tables & 2) {
+                const int a0 = gp(cc->tt_raw)[tc * Cn + dd], a1 = gp(cc->tt_raw)[tc * Cn + dd2];
+                const int mx = max(wave_max_i32(present ? a0 : 0), wave_max_i32(present2 ? a1 : 0));
+                const double r = mx ? 1.0 / (double)mx : 0.0;
+                sn += present ? (mx ? 100 - (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 100) : 0;
+                sn2 += present2 ? (mx ? 100 - (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 100) : 0;
+            }
+            if (sc.static_tables & 4) { sn += present ? gp(cc->add_raw)[tc * Cn + dd] : 0; sn2 += present2 ? gp(cc->add_raw)[tc * Cn + dd2] : 0; }
+            const unsigned total = present ? (cbest >> KB) + (unsigned)sn : 0u, total2 = present2 ? (cbest2 >> KB) + (unsigned)sn2 : 0u;
+            const unsigned tmax = max(wave_max_u32(total), wave_max_u32(total2));
+            const bool t0 = present && total == tmax, t1 = present2 && total2 == tmax;
+            unsigned long long tied0 = __ballot(t0), tied1 = __ballot(t1);
+            if (__builtin_expect(__popcll(tied0) + __popcll(tied1) > 1, 0)) {   // several classes reach the maximum: first in canonical order
+                int canon0 = t0 ? cls_list[rk_off + (unsigned)idx] : (int)PMASK, canon1 = t1 ? cls_list[rk_off + (unsigned)idx2] : (int)PMASK;
+                if (ranked && t0) canon0 = gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + canon0];
+                if (ranked && t1) canon1 = gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + canon1];
+                const unsigned cmin = max(wave_max_u32(t0 ? PMASK - (unsigned)canon0 : 0u), wave_max_u32(t1 ? PMASK - (unsigned)canon1 : 0u));
+                tied0 = __ballot(t0 && PMASK - (unsigned)canon0 == cmin); tied1 = __ballot(t1 && PMASK - (unsigned)canon1 == cmin);
+            }
+            const bool half = tied0 == 0ull;
+            const int wl = __builtin_ctzll(half ? tied1 : tied0);
+            const int r0 = __builtin_amdgcn_readlane(idx, wl), r1 = __builtin_amdgcn_readlane(idx2, wl);
+            const int p0 = __builtin_amdgcn_readlane(pos, wl), p1 = __builtin_amdgcn_readlane(pos2, wl);
+            dstar = half ? 64 + wl : wl;
+            res = half ? r1 : r0;
+            return half ? p1 : p0;
+        }
         if (!__ballot(present)) return -1;
         const int pos = (int)(PMASK - (cbest & PMASK));
         const int idx = cls_off[dd] - s_seg[dd] + pos;                    // index into the static per-class node lists
@@ -2057,25 +2112,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 }
 
 // launch of one instantiation of the single-wave kernel (shared by this unit and simon_table_rest.hip: a template costs nothing where it is not used)
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false, bool SPREAD = false>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST, bool RANKED, bool AFF = false, bool MANY = false, bool SPREAD = false, bool CN2 = false>
 static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (REST && !AFF) {
-        if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true>(a, n_blocks, lds, st);
+        if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true, false, false, CN2>(a, n_blocks, lds, st);
     }
+    if (REST && !CN2 && a.sc.Cn > 64) return hipErrorInvalidValue;    // (65 .. 128 node classes under the REST select: simon_table_rest2.hip)
     if constexpr (KQ == 2 && COARSE && !REST && !MANY && !SPREAD) {   // more than 128 signatures: the instantiation with further groups
         if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, false, true>(a, n_blocks, lds, st);
     }
     if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;       // simon_hip.hip keeps such batches away (two-level, no REST)
-    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY, SPREAD>;
+    auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY, SPREAD, 1, false, false, CN2>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
     return hipGetLastError();
 }
-template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false>
+template <bool M, bool Z, bool PIN, int KQ, int NBQ, bool COARSE, bool REST = false, bool CN2 = false>
 static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, true>(a, n_blocks, lds, st)
-                               : launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, false>(a, n_blocks, lds, st);
+    return a.sc.rk_stride != 0 ? launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, true, false, false, false, CN2>(a, n_blocks, lds, st)
+                               : launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, false, false, false, false, CN2>(a, n_blocks, lds, st);
 }
 #ifdef SIMON_TABLE_TEAM_TU
 // ---- this translation unit (simon_table_team<N>.hip) holds the team-mode instantiations only: NW = SIMON_TABLE_TEAM_TU waves per scenario ----
@@ -2225,6 +2281,18 @@ hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, 
     if (a.sc.K > 64) return nzeq ? launch_rl2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rl2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 1>(a, n_blocks, lds_bytes, st);
 }
+#elif defined(SIMON_TABLE_REST2_TU)
+// ---- this translation unit (simon_table_rest2.hip) holds generation 6 for 65 .. 128 internal node classes (CN2 in rest_select; rows in HBM) ----
+template <bool Z, int KQ>
+static hipError_t launch_rest2c(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.ni_max / 64 <= 64 ? launch_t6<true, Z, true, KQ, 1, true, true, true>(a, n_blocks, lds, st)
+                                  : launch_t6<true, Z, true, KQ, 2, true, true, true>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_rest2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.rest || !a.coarse || a.spread || a.team > 1 || a.lds_x || a.sc.Cn <= 64) return hipErrorInvalidValue;
+    if (a.sc.K > 64) return nzeq ? launch_rest2c<true, 2>(a, n_blocks, lds_bytes, st) : launch_rest2c<false, 2>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_rest2c<true, 1>(a, n_blocks, lds_bytes, st) : launch_rest2c<false, 1>(a, n_blocks, lds_bytes, st);
+}
 #elif defined(SIMON_TABLE_REST_TU)
 // ---- this translation unit (simon_table_rest.hip) holds generation 6: the REST instantiations (position masks: Open-Gpu-Share devices,
 // required (anti-)affinity, host ports, ephemeral storage / extended resources) -- the 32 largest kernels of the single-wave family ----
@@ -2264,6 +2332,7 @@ hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders
 template <bool M, bool Z, bool PIN, int KQ>
 static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (PIN) {                                              // REST rides on the instantiation that knows pinned pods: simon_table_rest.hip
+        if (a.rest && a.sc.Cn > 64) return launch_table_rest2(a, n_blocks, Z, lds, st);   // two node classes per lane in the REST select: simon_table_rest2.hip
         if (a.rest) return a.lds_x ? launch_table_rest_lds(a, n_blocks, Z, lds, st) : launch_table_rest(a, n_blocks, Z, lds, st);
     }
     if (a.spread) return hipErrorInvalidValue;                        // (generation 7 lives in simon_table_spread.hip: launch_table_spread)

@@ -207,11 +207,13 @@ def config4(rank: int = 0, world: int = 1, n_counts: int = 1024, n_orders: int =
 
 
 def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_orders: int = 4, n_groups: int = 50,
-            group_size: int = 100, seed: int = SEED + 5):
+            group_size: int = 100, seed: int = SEED + 5, n_shapes: int = 0):
     """gpushare-style workload (BASELINE config 5 / SURVEY 8d): 30 % GPU nodes (4 or 8 devices x 16 GiB), 20 % GPU
     pods (gpu-mem 2/4/8/16 GiB, count 1/1/1/2), `n_groups` groups of `group_size` pods with required self
     anti-affinity on kubernetes.io/hostname, 10 % of the nodes tainted NoSchedule with 20 % of the pods tolerating.
-    Scenarios: node counts spread over the upper half of the pool x `n_orders` pod orders."""
+    Scenarios: node counts spread over the upper half of the pool x `n_orders` pod orders.
+    `n_shapes`: the nodes come in that many distinct allocatable shapes (config3_classes' draw) instead of four -- beyond 64 the REST select of
+    generation 6 keeps two node classes per lane (simon_table.hip: CN2)."""
     GiB = 1 << 30
     rng = SplitMix64(seed)
     cpu, mem, pods, ncls = gen_nodes(seed, n_nodes, n_nodes)
@@ -276,6 +278,10 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
                    const_score=np.full(Cp, CONST_SCORE, np.int64), term_topo_key=np.zeros(n_groups, np.int32),
                    anti_off=np.array(anti_off, np.int32), anti_idx=np.array(anti_idx or [0], np.int32),
                    match_off=np.array(match_off, np.int32), match_idx=np.array(match_idx or [0], np.int32)).normalise()
+    if n_shapes > 0:
+        reshape_nodes(prob, n_nodes, n_shapes + 1, [(t[0], t[1]) for t in table])    # (+ 1: the template's shape, which no node of this pool has)
+        prob = prob.normalise()
+        cpu, mem = prob.alloc_cpu, prob.alloc_mem
     orders = make_orders(seed, pcpu, pmem, int(cpu.sum()), int(mem.sum()), n_orders)
     n_counts = max(1, n_scen // n_orders)
     counts = np.linspace(n_nodes // 2, n_nodes, n_counts).astype(np.int32)

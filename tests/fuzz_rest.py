@@ -41,7 +41,7 @@ def one_case(case):
         feat["aff"] = True                # required affinity (derived terms, first-pod escape) beside the anti-affinity terms
     if size >= 2:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
-    n_node_classes = int(rng.choice([1, 2, 4, 9, 20, 40]))
+    n_node_classes = int(rng.choice([70, 90, 110] if case >= 500000 else [1, 2, 4, 9, 20, 40]))   # cases from 500 000 on: 65 .. 128 internal node classes (CN2 in rest_select)
     n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 120]))
     prob = randprob.rand_problem(62000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
     S = int(rng.integers(1, 7))

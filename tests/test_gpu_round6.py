@@ -223,3 +223,43 @@ def test_service_workload_with_30_node_shapes_in_3_zones_stays_on_generation_7()
         assert r2.unscheduled.tolist() == ref2.unscheduled.tolist() and (r2.placement == ref2.placement).all()
         assert r2.used_cpu.tolist() == ref2.used_cpu.tolist() and r2.used_mem.tolist() == ref2.used_mem.tolist()
     assert on7 >= 4
+
+
+def test_gpushare_cluster_with_80_node_shapes_stays_on_generation_6():
+    """Generation 6's REST select keeps two node classes per lane beyond 64 internal classes (simon_table.hip: CN2, simon_table_rest2.hip):
+    BASELINE config 5's shape on 80 node shapes -- GPU share, required self anti-affinity, taints -- placement by placement and with the
+    booked devices compared; random problems with 70 .. 110 node classes and every REST feature (zone-level terms, required affinity, ports,
+    ephemeral storage / extended resources, per-scenario ranks); SIMON_NO_CN2 = the old route (all-feature kernel), same answers."""
+    prob, scen, orders = synth.config5(n_pods=6000, n_nodes=900, n_scen=8, n_orders=2, n_groups=20, group_size=30, n_shapes=80)
+    ref = O.run_threaded(prob, scen, orders)
+    res, st, _ = run_gpu(prob, scen, orders)
+    assert st.kernel_generation == 6
+    assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
+    assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
+    res0, st0, _ = run_gpu(prob, scen, orders, env={"SIMON_NO_CN2": "1"})
+    assert st0.kernel_variant == capi.KERNEL_WIDE and (res0.placement == ref.placement).all()
+    on6 = 0
+    feats = [dict(gpu=True), dict(gpu=True, anti=True, aff=True), dict(anti_host=True, ports=True, nz_differs=True), dict(gpu=True, eph=True, scalars=2, anti_host=True),
+             dict(anti=True, presets=True, gates=True, tight_pods=True), dict(gpu=True, anti_host=True, static_small=True, zero_pods=True)]
+    for seed, feat in enumerate(feats):
+        N = [300, 700, 1500, 500, 2500, 900][seed]
+        p2 = randprob.rand_problem(5150 + seed, N=N, P=700, n_node_classes=[70, 90, 110, 80, 100, 120][seed], n_pod_classes=[3, 30, 60, 8, 100, 20][seed], **feat)
+        s2, o2 = randprob.rand_scenarios(seed, p2, S=4, min_n=N // 2)
+        ranks = None
+        if seed % 3 == 2:
+            rng = np.random.default_rng(seed)
+            ranks = np.zeros((len(s2), p2.n_nodes), np.int32)
+            for i, (n, _) in enumerate(np.asarray(s2).tolist()):
+                ranks[i, :n] = rng.permutation(n)
+        ref2 = O.run(p2, s2, o2, node_ranks=ranks) if ranks is not None else O.run_threaded(p2, s2, o2)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(p2)
+            ctx.load_scenarios(s2, o2)
+            if ranks is not None:
+                ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            r2 = ctx.fetch(True)
+            on6 += ctx.stats().kernel_generation == 6
+        assert r2.unscheduled.tolist() == ref2.unscheduled.tolist() and (r2.placement == ref2.placement).all()
+        assert r2.used_cpu.tolist() == ref2.used_cpu.tolist() and r2.used_mem.tolist() == ref2.used_mem.tolist()
+    assert on6 >= 4
