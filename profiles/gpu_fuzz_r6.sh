@@ -10,5 +10,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
   timeout 900 python tests/fuzz_rest.py ${FR_N:-1200} 64000 2>&1 | tail -2
   timeout 900 python tests/fuzz_spread.py ${FS_N:-600} 65000 2>&1 | tail -2
   timeout 900 python tests/fuzz_spread.py 200 660000 2>&1 | tail -2
+  timeout 900 python tests/fuzz_rest.py ${FR2_N:-400} 510000 2>&1 | tail -2          # 70 .. 110 node classes: two per lane in the REST select (CN2)
+  timeout 900 python tests/fuzz_spread.py ${FS2_N:-400} 610000 2>&1 | tail -2        # 65 .. 128 internal classes under the spread walks (CN2)
 } | grep -v amdgpu.ids > "$OUT/fuzzers_at_scale.txt"
 cat "$OUT/fuzzers_at_scale.txt"
