@@ -109,7 +109,10 @@ constexpr int kSpreadMaxHostTerms = 4096, kSpreadMaxZoneTerms = 1024, kSpreadMax
 #define SIMON_SPREAD_TAB_MAX 512          // (tests build a library with a tiny table to drive every pod through the general walk)
 #endif
 constexpr int kSpreadTabMax = SIMON_SPREAD_TAB_MAX;       // entries of spread_select's per-pod score table in LDS: classes x (largest counter + 1, a power of two)
-constexpr int kSpreadTabMax2 = 2048;    // ... of the instantiations for 65 .. 128 node classes (table_kernel: CN2)
+#ifndef SIMON_SPREAD_TAB_MAX2
+#define SIMON_SPREAD_TAB_MAX2 2048
+#endif
+constexpr int kSpreadTabMax2 = SIMON_SPREAD_TAB_MAX2;    // ... of the instantiations for 65 .. 128 node classes (table_kernel: CN2)
 constexpr int kTeamWaves = 4;           // team mode (table_kernel: NW): waves per scenario, one per SIMD of the CU.  8 and 16 were built and measured
                                         // SLOWER on every batch (profiles/r04/r04b_*: once the walks are a quarter, the leader's chain and the barriers decide)
 constexpr int kTeamWavesMax = 16;       // (the exchange slots are sized for it: a wider team is one more translation unit, simon_table_team<N>.hip)
