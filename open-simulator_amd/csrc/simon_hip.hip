@@ -1076,9 +1076,9 @@ int stage_narrow(simon_ctx* c) {
             auto key = std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->spread ? zone_sub(j) : (split_gpu && c->gpu_cnt[j] > 0) ? 1 : 0);
             auto it = cls_id.find(key);
             if (it == cls_id.end()) {
-                // one class per lane in a walk that scores preferred / hard terms; two per lane in the REST select and in the walks of soft
-                // constraints alone (round 6, simon_table.hip: CN2) as in the instantiations without rows and walks
-                const int cls_max = (c->rest || c->spread) ? (((c->spread && (c->ipa_fold || c->hard_fold)) || c->no_cn2) ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
+                // two classes per lane in the REST select and in the SPREAD walks beyond 64 (round 6, simon_table.hip: CN2), as in the
+                // instantiations without rows and walks
+                const int cls_max = (c->rest || c->spread) ? (c->no_cn2 ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
                 if ((int)shapes.size() == cls_max) { c->table_ok = false; break; }
                 it = cls_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};

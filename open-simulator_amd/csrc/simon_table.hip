@@ -213,7 +213,7 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.zdom = o; o += nzk >= 0 ? al((nzk > 0 ? nzk : 1) * Cn) : 0;
     c.stash = o; o += nzk >= 0 ? al(ni_max * 2) : 0;
     c.tab = o; o += nzk >= 0 ? (cn2 ? kSpreadTabMax2 : kSpreadTabMax) * 4 : 0;
-    c.tabi = o; o += ipa ? kSpreadTabMax * 4 : 0;
+    c.tabi = o; o += ipa ? (cn2 ? kSpreadTabMax2 : kSpreadTabMax) * 4 : 0;
     c.tab2 = o; o += team ? (cn2 ? kSpreadTabMax2 : kSpreadTabMax) * 4 : 0;
     c.xch = o; o += team ? kTeamWavesMax * 6 * 4 : 0;
     c.total = o;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     static_assert(!SPREAD || (COARSE && !REST), "SPREAD is built on the two-level layout, without the REST rows");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
-    static_assert(!CN2 || (SPREAD && !AFF && !MANY) || (REST && !LDSX), "CN2 = two node classes per lane in spread_select (soft constraints only, <= 128 signatures) or in rest_select (rows in HBM)");
+    static_assert(!CN2 || (SPREAD && !MANY) || (REST && !LDSX), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
     constexpr int TABMAX = CN2 ? kSpreadTabMax2 : kSpreadTabMax;
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0) | (CN2 ? 0x400 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
@@ -774,6 +774,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         if (sc.static_tables & 4) term += inb ? gp(cc->add_raw)[c * Cn + dd] : 0;
         return term;
     };
+    // class_term for two classes per lane (CN2: lane l holds classes d0 = l and d1 = 64 + l): the same formulas with the extremes and
+    // maxima taken over both halves (renormalise's form for more than 64 classes), every lane calling
+    auto class_term2 = [&](bool in0, bool in1, int raw0, int raw1, int c, int d0, int d1, int& t0, int& t1) {
+        const int lo = min(wave_min_i32(in0 ? raw0 : 0x7fffffff), wave_min_i32(in1 ? raw1 : 0x7fffffff));
+        const int hi = max(wave_max_i32(in0 ? raw0 : (int)0x80000000), wave_max_i32(in1 ? raw1 : (int)0x80000000));
+        const int range = hi >= lo ? hi - lo : 0;
+        const double rr = range ? 1.0 / (double)range : 0.0;
+        t0 = (in0 && range) ? 2 * (int)__builtin_fma((double)(raw0 - lo) * 100.0, rr, 0.5 * rr) : 0;
+        t1 = (in1 && range) ? 2 * (int)__builtin_fma((double)(raw1 - lo) * 100.0, rr, 0.5 * rr) : 0;
+        GPtr<const TableCold> cc = cold;
+        if (sc.static_tables & 1) {
+            const int a0 = gp(cc->na_raw)[c * Cn + d0], a1 = gp(cc->na_raw)[c * Cn + d1];
+            const int mx = max(wave_max_i32(in0 ? a0 : 0), wave_max_i32(in1 ? a1 : 0));
+            const double r = mx ? 1.0 / (double)mx : 0.0;
+            t0 += (in0 && mx) ? (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 0;
+            t1 += (in1 && mx) ? (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 0;
+        }
+        if (sc.static_tables & 2) {
+            const int a0 = gp(cc->tt_raw)[c * Cn + d0], a1 = gp(cc->tt_raw)[c * Cn + d1];
+            const int mx = max(wave_max_i32(in0 ? a0 : 0), wave_max_i32(in1 ? a1 : 0));
+            const double r = mx ? 1.0 / (double)mx : 0.0;
+            t0 += in0 ? (mx ? 100 - (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 100) : 0;
+            t1 += in1 ? (mx ? 100 - (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 100) : 0;
+        }
+        if (sc.static_tables & 4) { t0 += in0 ? gp(cc->add_raw)[c * Cn + d0] : 0; t1 += in1 ? gp(cc->add_raw)[c * Cn + d1] : 0; }
+    };
     // Re-base summary row k after the set of node classes with a feasible node changed.
     auto renormalise = [&](int k, int c) {
         if (Cn > 64) {
@@ -984,28 +1010,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             if (!__ballot(present || present2)) return -1;
             const int pos = (int)(PMASK - (cbest & PMASK)), pos2 = (int)(PMASK - (cbest2 & PMASK));
             const int idx = cls_off[dd] - s_seg[dd] + pos, idx2 = cls_off[dd2] - s_seg[dd2] + pos2;
-            const int lo = min(wave_min_i32(present ? rawc : 0x7fffffff), wave_min_i32(present2 ? rawc2 : 0x7fffffff));
-            const int hi = max(wave_max_i32(present ? rawc : (int)0x80000000), wave_max_i32(present2 ? rawc2 : (int)0x80000000));
-            const int range = hi >= lo ? hi - lo : 0;
-            const double rr = range ? 1.0 / (double)range : 0.0;
-            int sn = (present && range) ? 2 * (int)__builtin_fma((double)(rawc - lo) * 100.0, rr, 0.5 * rr) : 0;
-            int sn2 = (present2 && range) ? 2 * (int)__builtin_fma((double)(rawc2 - lo) * 100.0, rr, 0.5 * rr) : 0;
-            GPtr<const TableCold> cc = cold;
-            if (sc.static_tables & 1) {
-                const int a0 = gp(cc->na_raw)[tc * Cn + dd], a1 = gp(cc->na_raw)[tc * Cn + dd2];
-                const int mx = max(wave_max_i32(present ? a0 : 0), wave_max_i32(present2 ? a1 : 0));
-                const double r = mx ? 1.0 / (double)mx : 0.0;
-                sn += (present && mx) ? (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 0;
-                sn2 += (present2 && mx) ? (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 0;
-            }
-            if (sc.static_tables & 2) {
-                const int a0 = gp(cc->tt_raw)[tc * Cn + dd], a1 = gp(cc->tt_raw)[tc * Cn + dd2];
-                const int mx = max(wave_max_i32(present ? a0 : 0), wave_max_i32(present2 ? a1 : 0));
-                const double r = mx ? 1.0 / (double)mx : 0.0;
-                sn += present ? (mx ? 100 - (int)__builtin_fma((double)a0 * 100.0, r, 0.5 * r) : 100) : 0;
-                sn2 += present2 ? (mx ? 100 - (int)__builtin_fma((double)a1 * 100.0, r, 0.5 * r) : 100) : 0;
-            }
-            if (sc.static_tables & 4) { sn += present ? gp(cc->add_raw)[tc * Cn + dd] : 0; sn2 += present2 ? gp(cc->add_raw)[tc * Cn + dd2] : 0; }
+            int sn, sn2;
+            class_term2(present, present2, rawc, rawc2, tc, dd, dd2, sn, sn2);
             const unsigned total = present ? (cbest >> KB) + (unsigned)sn : 0u, total2 = present2 ? (cbest2 >> KB) + (unsigned)sn2 : 0u;
             const unsigned tmax = max(wave_max_u32(total), wave_max_u32(total2));
             const bool t0 = present && total == tmax, t1 = present2 && total2 == tmax;
@@ -1271,6 +1277,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     hcz[i] = hzd[i] >= 0 ? g_zcnt[hR[i] * 16 + hzd[i]] : 0u;
                 }
         }
+        int zipa2 = 0;                                                    // (CN2: the same for class 64 + lane)
+        unsigned hcz2[3] = {0u, 0u, 0u};
+        int hzd2[3] = {0, 0, 0};
+        if constexpr (kIpa && CN2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (v2 && kI[i] == 2) {
+                    const int zd = s_zdom[zI[i] * Cn + dd2];
+                    zipa2 += zd >= 0 ? wI[i] * (int)g_zcnt[rI[i] * 16 + zd] : 0;
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < hard_n) {
+                    hzd2[i] = v2 ? (int)s_zdom[hZ[i] * Cn + dd2] : -1;
+                    hcz2[i] = hzd2[i] >= 0 ? g_zcnt[hR[i] * 16 + hzd2[i]] : 0u;
+                }
+        }
         const unsigned char* hb1 = has_hrow ? g_hrow + (size_t)hrow_i * ni : (const unsigned char*)g_tile;   // (no hostname term: value unused)
         const int hmx_v = (simple && has_hrow) ? (int)g_hmax[hrow_i] : 0;   // largest counter of the row (uniform address)
         unsigned byte1[SB], h1[SB];
@@ -1295,6 +1318,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if (e < soft_n && kind[e] == 2) ign2 = ign2 || s_zdom[zsl[e] * Cn + dd2] < 0;
         }
         bool excl = false;                                                // this class fails a hard constraint of the pod
+        bool excl2 = false;
         if constexpr (kIpa) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -1302,13 +1326,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     // registered zones (:236-251): those of the scenario's labelled nodes (the host admits eligibility sets that leave out
                     // unlabelled nodes only); criticalPaths minimum over them (:272-278), math.MaxInt32 when there is none
                     const bool reg = lane < Cn && cnt_d > 0 && hzd[i] >= 0;
-                    const int mn = wave_min_i32(reg ? (int)hcz[i] : 0x7fffffff);
+                    int mn = wave_min_i32(reg ? (int)hcz[i] : 0x7fffffff);
+                    if constexpr (CN2) {
+                        const bool reg2 = v2 && cnt_d2 > 0 && hzd2[i] >= 0;
+                        mn = min(mn, wave_min_i32(reg2 ? (int)hcz2[i] : 0x7fffffff));
+                        const long long skew2 = (long long)hcz2[i] + ((hS[i] >> 14) & 1) - (long long)mn;
+                        excl2 = excl2 || hzd2[i] < 0 || skew2 > (long long)(hS[i] & 0x3FFF);
+                    }
                     const long long skew = (long long)hcz[i] + ((hS[i] >> 14) & 1) - (long long)mn;
                     excl = excl || hzd[i] < 0 || skew > (long long)(hS[i] & 0x3FFF);
                 }
         }
         const bool scored = lane < Cn && cntd > 0 && !ign && !excl;
-        const bool scored2 = CN2 && v2 && cntd2 > 0 && !ign2;
+        const bool scored2 = CN2 && v2 && cntd2 > 0 && !ign2 && !excl2;
         const int F = __builtin_amdgcn_readfirstlane(wave_sum_i32_t((scored ? cntd : 0) + (scored2 ? cntd2 : 0)));   // len(filteredNodes) - len(IgnoredNodes)
         int sz[4];
 #pragma unroll
@@ -1330,17 +1360,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         // per class as well: "ignored" and the class term of the signature's row
         // (bit 30: excluded -- its nodes count as infeasible; the Simon normalisation then runs over the classes that are left, simon.go:76-101)
         int ctermv = (int)s_sn[k * Cn + dd];
-        if constexpr (kIpa) {
+        int ctermv2 = CN2 ? (int)s_sn[k * Cn + dd2] : 0;
+        if constexpr (kIpa && CN2) {
+            if (hard_n > 0 && __ballot((cntd > 0 && excl) || (v2 && cntd2 > 0 && excl2)) != 0ull)
+                class_term2(cntd > 0 && !excl, v2 && cntd2 > 0 && !excl2, simon_raw[tc * Cn + dd], simon_raw[tc * Cn + dd2], tc, dd, dd2, ctermv, ctermv2);
+        } else if constexpr (kIpa) {
             if (hard_n > 0 && __ballot(lane < Cn && cntd > 0 && excl) != 0ull)
                 ctermv = class_term(lane < Cn && cntd > 0 && !excl, simon_raw[tc * Cn + dd], tc, dd);
         }
         const int clsw = (int)((unsigned)ctermv | (ign ? 0x80000000u : 0u) | (excl ? 0x40000000u : 0u));
-        const int clsw2 = CN2 ? (int)((unsigned)s_sn[k * Cn + dd2] | (ign2 ? 0x80000000u : 0u)) : 0;
+        const int clsw2 = CN2 ? (int)((unsigned)ctermv2 | (ign2 ? 0x80000000u : 0u) | (excl2 ? 0x40000000u : 0u)) : 0;
         auto cls_word = [&](int c) -> int {                                // the word of class c (uniform), from the lane that holds it
             if constexpr (CN2) {
                 const int a = __builtin_amdgcn_readlane(clsw, c & 63), b = __builtin_amdgcn_readlane(clsw2, c & 63);
                 return c < 64 ? a : b;
             } else return __builtin_amdgcn_readlane(clsw, c);
+        };
+        auto zipa_of = [&](int c) -> int {                                 // the zone-like part of the InterPodAffinity raw score of class c (uniform)
+            if constexpr (CN2) {
+                const int a = __builtin_amdgcn_readlane(zipa, c & 63), b = __builtin_amdgcn_readlane(zipa2, c & 63);
+                return c < 64 ? a : b;
+            } else return __builtin_amdgcn_readlane(zipa, c);
         };
         auto lane_f64 = [&](double v, int l) -> double {
             const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -1388,7 +1428,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 const int raw = (int)(((double)(i & hmask) * ws + cs) + pc);
                 if (i < E) s_tab[i] = raw;
                 if constexpr (kIpa) {                                     // InterPodAffinity raw score of (class, count): integer (scoring.go:211-236)
-                    const int zc = __builtin_amdgcn_ds_bpermute(c4, zipa);    // (every lane: the source lane of a permute must be active)
+                    int zc = __builtin_amdgcn_ds_bpermute(c4, zipa);          // (every lane: the source lane of a permute must be active)
+                    if constexpr (CN2) { const int zc2 = __builtin_amdgcn_ds_bpermute(c4, zipa2); zc = ci < 64 ? zc : zc2; }
                     if (ipa_pod && i < E) s_tabi[i] = Wh * (i & hmask) + zc;
                 }
             }
@@ -1525,7 +1566,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     pmin = min(pmin, ok ? raw : 0x7fffffff);
                     pmax = max(pmax, ok ? raw : 0);
                     if constexpr (kIpa) {
-                        const int ir = (ipa_h ? Wh * (int)hI[j] : 0) + __builtin_amdgcn_readlane(zipa, c);
+                        const int ir = (ipa_h ? Wh * (int)hI[j] : 0) + zipa_of(c);
                         imin = min(imin, (ipa_pod && beff != 0u) ? ir : 0);
                         imax = max(imax, (ipa_pod && beff != 0u) ? ir : 0);
                     }
@@ -1560,7 +1601,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                     if (cw >= 0) v = pmax == 0 ? 100 : (int)__builtin_fma((double)(100 * (pmax + pmin - raw)), rinv, hrinv);
                     int iv = 0;                                           // InterPodAffinity NormalizeScore (:258-271)
                     if constexpr (kIpa) {
-                        if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)((ipa_h ? Wh * (int)hI[j] : 0) + __builtin_amdgcn_readlane(zipa, c) - imin) / (double)idiff));
+                        if (ipa_pod && idiff > 0) iv = (int)(100.0 * ((double)((ipa_h ? Wh * (int)hI[j] : 0) + zipa_of(c) - imin) / (double)idiff));
                     }
                     unsigned beff = byte[j];
                     if constexpr (kIpa) beff = (cw & 0x40000000) ? 0u : beff;
@@ -2140,8 +2181,8 @@ constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
 #define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
 template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if constexpr (!AFF && !CN2) {                                     // 65 .. 128 node classes: two per lane in the walks (soft constraints only)
-        if (a.sc.Cn > 64) return launch_team6<M, Z, KQ, NBQ, RANKED, false, true>(a, n_blocks, lds, st);
+    if constexpr (!CN2) {                                             // 65 .. 128 node classes: two per lane in the walks
+        if (a.sc.Cn > 64) return launch_team6<M, Z, KQ, NBQ, RANKED, AFF, true>(a, n_blocks, lds, st);
     }
     if (a.sc.K > 64 * KQ || (!CN2 && a.sc.Cn > 64)) return hipErrorInvalidValue;
     auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTuWaves, false, false, CN2>;
@@ -2209,15 +2250,18 @@ hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask
     return nzeq ? launch_sp2<true, true>(a, n_blocks, lds_bytes, st) : launch_sp2<true, false>(a, n_blocks, lds_bytes, st);
 }
 #elif defined(SIMON_TABLE_SPREAD2_TU)
-// ---- this translation unit (simon_table_spread2.hip) holds generation 7 for 65 .. 128 internal node classes (CN2): soft constraints only,
-// <= 128 signatures, one wave per scenario ----
-template <bool Z, int KQ, int NBQ, bool RANKED = false>
+// ---- this translation unit (simon_table_spread2.hip) holds generation 7 for 65 .. 128 internal node classes (CN2): <= 128 signatures,
+// one wave per scenario ----
+template <bool Z, int KQ, int NBQ, bool RANKED = false, bool AFF = false>
 static hipError_t launch_sc3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (!RANKED) {
-        if (a.sc.rk_stride != 0) return launch_sc3<Z, KQ, NBQ, true>(a, n_blocks, lds, st);
+        if (a.sc.rk_stride != 0) return launch_sc3<Z, KQ, NBQ, true, AFF>(a, n_blocks, lds, st);
+    }
+    if constexpr (!AFF) {                                             // (& 64: preferred pod (anti-)affinity / hard zone constraints in spread_select: SPREAD && AFF)
+        if (a.sc.static_tables & 64) return launch_sc3<Z, KQ, NBQ, RANKED, true>(a, n_blocks, lds, st);
     }
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, false, RANKED, false, false, true, 1, false, false, true>;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, 1, false, false, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2228,7 +2272,7 @@ static hipError_t launch_sc2(const TableLaunch& a, int n_blocks, size_t lds, hip
     return a.sc.ni_max / 64 <= 64 ? launch_sc3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_sc3<Z, KQ, 2>(a, n_blocks, lds, st);
 }
 hipError_t launch_table_spread2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.coarse || a.rest || a.team > 1 || a.sc.Cn <= 64 || a.sc.K > 128 || (a.sc.static_tables & 64)) return hipErrorInvalidValue;
+    if (!a.spread || !a.coarse || a.rest || a.team > 1 || a.sc.Cn <= 64 || a.sc.K > 128) return hipErrorInvalidValue;
     if (a.sc.K > 64) return nzeq ? launch_sc2<true, 2>(a, n_blocks, lds_bytes, st) : launch_sc2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_sc2<true, 1>(a, n_blocks, lds_bytes, st) : launch_sc2<false, 1>(a, n_blocks, lds_bytes, st);
 }

@@ -25,9 +25,6 @@ def one_case(case):
     if size == 2:
         feat.pop("static_mask", None)
     many_classes = case >= 600000                       # cases from 600 000 on: 65 .. 128 internal node classes (node shapes x zones; simon_table.hip: CN2)
-    if many_classes:
-        for f in ("ipa_self", "ipa", "hard_simple"):    # (a walk that scores preferred / hard terms keeps one class per lane)
-            feat.pop(f, None)
     prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=(case % 7 != 6 or "ipa_self" not in feat), n_node_classes=int(rng.choice([14, 18, 22, 25] if many_classes else [1, 2, 4, 9])),
                                  n_pod_classes=int(rng.choice([130, 200, 300, 384, 600, 1000] if case >= 300000 else [1, 3, 8, 30, 60])), **feat)   # cases from 300 000 on: 129 ... 384 signatures (MANY && SPREAD)
     if "gpu" in feat:                                   # GPU share folded into the table (few request kinds: <= 128 signatures), behind the spread walk
