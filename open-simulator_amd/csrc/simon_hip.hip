@@ -140,6 +140,11 @@ struct simon_ctx : simon::HostInputs {
     bool hard_fold = false, no_hard_fold = false; // hard spread constraints on zone-like keys as per-class verdicts of spread_select; env SIMON_NO_HARD_FOLD
     bool ipa_fold = false, no_ipa_fold = false;
     bool no_cn2 = false;                          // env SIMON_NO_CN2: generation 7 stays at 64 node classes (A/B + tests)
+    // REST && SPREAD (round 6, simon_table_rs.hip): soft spread constraints next to GPU requests / required anti-affinity / ports / extra
+    // resources that do not fold into the table -- generation 7's walks over generation 6's position-mask rows.  rs_probe: spread_supported
+    // called to answer "would the walks take it if the rows carried the filters"; env SIMON_NO_RS: never (A/B + tests)
+    bool rs = false, rs_probe = false, no_rs = false;
+    DevBuf<int32_t> d_sp_word;                   // [P] SPREAD descriptor by pod id (TableCold::sp_word)
     std::vector<int32_t> ipa_h_term, ipa_h_w;     // [Cp] the hostname-like term of a class's raw score (-1: none) and its coefficient
     std::vector<std::vector<std::pair<int32_t, int32_t>>> ipa_z;   // [Cp] (zone-like term, coefficient)
     bool spread = false, no_spread = false;      // no_spread: env SIMON_NO_SPREAD (such problems take the all-feature kernel)
@@ -234,7 +239,16 @@ bool rest_supported(simon_ctx* c) {
     std::vector<int> key_kind(std::max(c->Kt, 1), -1);   // 1 node-level, 0 zone-like
     c->zone_keys.clear();
     c->key_zslot.assign(std::max(c->Kt, 1), -1);
+    // (REST && SPREAD: the rows of a term nobody holds against others are never read -- stage_narrow drops them -- so the terms the spread
+    // constraints alone count may carry node sets and any key)
+    std::vector<char> row_read(std::max(c->Tm, 1), c->rs ? 0 : 1);
+    if (c->rs)
+        for (int cp = 0; cp < c->Cp; ++cp) {
+            for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) if (c->anti_idx[e] >= 0 && c->anti_idx[e] < c->Tm) row_read[c->anti_idx[e]] = 1;
+            for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) if (c->port_idx[e] >= 0 && c->port_idx[e] < c->Tm) row_read[c->port_idx[e]] = 1;
+        }
     for (int t = 0; t < c->Tm; ++t) {
+        if (!row_read[t]) continue;
         if (!c->term_set.empty() && c->term_set[t] >= 0) return false;
         const int k = c->term_key[t];
         if (key_kind[k] < 0) {
@@ -388,8 +402,8 @@ bool spread_supported(simon_ctx* c) {
     if (!c->sh_idx.empty() && c->no_hard_fold) return false;
     if (c->has_ipa_score && c->no_ipa_fold) return false;
     if (c->has_local || !c->aff_idx.empty()) return false;
-    if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold) return false;   // required anti-affinity / ports: only folded into the table
-    if (c->has_gpu_index || (c->has_gpu && !c->gfold)) return false;      // (GPU share: only folded into the table, gfold_supported)
+    if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold && !c->rs_probe) return false;   // required anti-affinity / ports: folded into the table, or (rs_probe) on the mask rows
+    if (c->has_gpu_index || (c->has_gpu && !c->gfold && !c->rs_probe)) return false;      // (GPU share: folded into the table, gfold_supported -- or on the mask rows)
     if (c->topo_is_hostname.empty()) return false;
     if (!c->ss_idx.empty() && c->spread_log.size() < (size_t)c->N + 1) return false;
     int64_t max_pods = 0;
@@ -710,8 +724,20 @@ void choose_variant(simon_ctx* c) {
     c->fold = fold_supported(c);
     c->gfold = gfold_supported(c);
     if (c->fold && c->has_gpu && !c->gfold) c->fold = false;        // GPU share on position masks (generation 6) takes the terms along
+    c->rs = false;
     if (c->v2_features_but_ports_and_static()) {
-        if (!spread_supported(c)) return;                         // only soft spread constraints: generation 7 of the score-table kernel
+        if (!spread_supported(c)) {                               // only soft spread constraints: generation 7 of the score-table kernel
+            // ... or its walks over the position-mask rows, when GPU share / required anti-affinity / ports are what keeps it out and the
+            // walk scores soft constraints only
+            if (c->no_rs || c->no_rest) return;
+            c->rs_probe = true;
+            const bool ok = spread_supported(c);
+            c->rs_probe = false;
+            if (c->debug_route) fprintf(stderr, "[route] walks over the mask rows: probe %d ipa %d hard %d soft %d\n", (int)ok, (int)c->ipa_fold, (int)c->hard_fold, (int)!c->ss_idx.empty());
+            if (!ok || c->ipa_fold || c->hard_fold || c->ss_idx.empty()) return;
+            c->rs = true;
+            c->fold = false; c->gfold = false;
+        }
         c->spread = true;
     }
     if (c->has_static) {
@@ -739,13 +765,17 @@ void choose_variant(simon_ctx* c) {
     if (c->gfold && !c->spread && c->gfold_sigs > 128 && c->gfold_base_sigs <= 128 && rest_supported(c)) { c->gfold = false; c->fold = false; }
     // the GPU fold serves problems that need no other per-node filter row: plain cpu+memory+GPU, and generation 7's (Services next to GPU pods)
     if (c->gfold && ((!c->spread && !c->fold && c->Tm > 0) || c->xres)) { c->gfold = false; if (c->has_gpu) c->fold = false; }
-    const bool wants_rest = !c->spread && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
+    if (c->spread && !c->rs && !c->no_rs && !c->no_rest && c->xres && !c->ipa_fold && !c->hard_fold && !c->ss_idx.empty() && c->aff_idx.empty()) {
+        c->rs = true; c->fold = false; c->gfold = false;            // extra-resource rows under the walks: the same instantiation
+    }
+    const bool wants_rest = (!c->spread || c->rs) && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
     // rest_supported() above ran as a probe and leaves g_gpu = 1 when it says no (e.g. more than kTableMaxGpuSigs GPU requests): a fold
     // that survives the probes stages its quantities on ITS gcd -- the 31-bit bounds were checked against that one, not against 1
     if (c->gfold) c->g_gpu = c->gfold_g;
-    if (c->spread && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
-    if (c->spread && !c->fold && (!c->anti_idx.empty() || !c->port_idx.empty())) { c->spread = false; return; }
-    if (wants_rest && !rest_supported(c)) return;
+    if (c->spread && !c->rs && c->xres) { c->spread = false; return; }       // extra-resource rows live on the REST path: all-feature kernel
+    if (c->spread && !c->rs && !c->fold && (!c->anti_idx.empty() || !c->port_idx.empty())) { c->spread = false; return; }
+    if (c->rs && !wants_rest) c->rs = false;
+    if (wants_rest && !rest_supported(c)) { if (c->debug_route) fprintf(stderr, "[route] mask rows refused (rs %d)\n", (int)c->rs); return; }
     if (c->N >= (1 << 20) - 1) return;
     const uint64_t gc = gcd_of({&c->alloc_cpu, &c->i_req_cpu, &c->i_nz_cpu, &c->p_req_cpu, &c->p_nz_cpu});
     const uint64_t gm = gcd_of({&c->alloc_mem, &c->i_req_mem, &c->i_nz_mem, &c->p_req_mem, &c->p_nz_mem});
@@ -925,6 +955,14 @@ int stage_narrow(simon_ctx* c) {
             c->rest_G = G; c->rest_X = Xn; c->rest_M = LBL + NZk;
             std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;   // -> n | offset << 6
             std::vector<int> xc_of(c->Cp, 0);
+            // REST && SPREAD: the match lists also name the terms the spread constraints count -- rows nobody ever tests (and on a zone-like
+            // key a set-row costs a pass over the scenario's blocks per landing pod): keep the terms some class holds against others
+            std::vector<char> row_read(std::max(T, 1), c->rs ? 0 : 1);
+            if (c->rs)
+                for (int cp = 0; cp < c->Cp; ++cp) {
+                    for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) row_read[c->anti_idx[e]] = 1;
+                    for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) row_read[c->port_idx[e]] = 1;
+                }
             for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
                 std::vector<int32_t> anti(c->anti_idx.begin() + c->anti_off[cp], c->anti_idx.begin() + c->anti_off[cp + 1]);
                 std::vector<int32_t> match(c->match_idx.begin() + c->match_off[cp], c->match_idx.begin() + c->match_off[cp + 1]);
@@ -936,6 +974,7 @@ int stage_narrow(simon_ctx* c) {
                 if (!c->port_off.empty()) port.assign(c->port_idx.begin() + c->port_off[cp], c->port_idx.begin() + c->port_off[cp + 1]);
                 std::sort(anti.begin(), anti.end()); anti.erase(std::unique(anti.begin(), anti.end()), anti.end());
                 std::sort(match.begin(), match.end()); match.erase(std::unique(match.begin(), match.end()), match.end());
+                match.erase(std::remove_if(match.begin(), match.end(), [&](int32_t t) { return !row_read[t]; }), match.end());
                 std::sort(port.begin(), port.end()); port.erase(std::unique(port.begin(), port.end()), port.end());
                 if (anti.empty() && match.empty() && port.empty() && aff.empty()) continue;
                 size_t n_lbl = 0;              // one label entry per zone-like key among the affinity terms
@@ -974,7 +1013,7 @@ int stage_narrow(simon_ctx* c) {
             }
             // GPU nodes without a GPU pod, terms no pod of the stream carries: nothing for the REST path to do -- generations 4 / 5
             // run the batch (their cycle is 17 % shorter than the REST instantiation's, profiles/README.md)
-            if (!any_rest && c->table_ok) { c->rest = false; c->rest_M = c->rest_G = c->rest_X = 0; }
+            if (!any_rest && c->table_ok) { c->rest = false; c->rs = false; c->rest_M = c->rest_G = c->rest_X = 0; }
         }
         // SPREAD descriptors: per pod class its soft constraints (term | maxSkew << 16 | dup << 30), the terms with a counter row its pods
         // are COUNTED on (term | multiplicity << 16) and the entries of its InterPodAffinity raw score (coefficient; the hostname-like term
@@ -1026,7 +1065,13 @@ int stage_narrow(simon_ctx* c) {
                 }
                 desc_of[cp] = it->second;
             }
-            for (int p = 0; p < P && c->table_ok; ++p) rowsC[p].rest = desc_of[c->p_cls[p]];
+            if (c->rs) {                                                   // PodRowC::rest keeps the REST descriptor: the SPREAD word travels by pod id
+                std::vector<int32_t> spw(std::max(P, 1), 0);
+                for (int p = 0; p < P; ++p) spw[p] = desc_of[c->p_cls[p]];
+                HIP_TRY(c, c->d_sp_word.upload(spw, st));
+            } else {
+                for (int p = 0; p < P && c->table_ok; ++p) rowsC[p].rest = desc_of[c->p_cls[p]];
+            }
             if (c->Tm >= (1 << 16)) c->table_ok = false;
         }
         // Internal node class = (caller's node class, allocatable cpu, allocatable memory).  The caller's classes share their
@@ -1061,7 +1106,7 @@ int stage_narrow(simon_ctx* c) {
         std::map<std::tuple<int32_t, uint32_t, uint32_t, int>, int> cls_id;
         std::vector<ShapeRow> shapes;
         std::vector<int32_t> orig_of, ncls_t(N), sub_of_class;
-        bool split_gpu = c->rest && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty() && !c->no_gpu_split;
+        bool split_gpu = c->rest && !c->spread && c->has_gpu && c->rest_G > 0 && !c->gpu_cnt.empty() && !c->no_gpu_split;
         if (split_gpu) {
             std::set<std::tuple<int32_t, uint32_t, uint32_t, int>> keys;
             for (int j = 0; j < N; ++j) keys.insert(std::make_tuple(content_of[c->node_class[j]], a_cpu[j], a_mem[j], c->gpu_cnt[j] > 0 ? 1 : 0));
@@ -1078,7 +1123,7 @@ int stage_narrow(simon_ctx* c) {
             if (it == cls_id.end()) {
                 // two classes per lane in the REST select and in the SPREAD walks beyond 64 (round 6, simon_table.hip: CN2), as in the
                 // instantiations without rows and walks
-                const int cls_max = (c->rest || c->spread) ? (c->no_cn2 ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
+                const int cls_max = (c->rest || c->spread) ? ((c->no_cn2 || c->rs) ? kTableMaxClasses : kTableMaxClassesSpread) : kTableMaxClassesPlain;
                 if ((int)shapes.size() == cls_max) { c->table_ok = false; break; }
                 it = cls_id.emplace(key, (int)shapes.size()).first;
                 ShapeRow sh{};
@@ -1092,6 +1137,7 @@ int stage_narrow(simon_ctx* c) {
             ncls_t[j] = it->second;
         }
         if (c->table_ok && c->spread && (int)shapes.size() > kTableMaxClasses && sigs.size() > 128) c->table_ok = false;   // (CN2 serves <= 128 signatures)
+        if (c->table_ok && c->rs && sigs.size() > 128) c->table_ok = false;                                                 // (... and so do the walks over the mask rows)
         if (c->table_ok) {
             const int Ct = (int)shapes.size();
             c->n_sigs = (int)sigs.size(); c->Cn_t = Ct;
@@ -1365,6 +1411,7 @@ simon_ctx* simon_ctx_create(int device_id) {
     c->no_sig_twins = getenv("SIMON_TABLE_NO_TWINS") != nullptr;      // A/B: signature ids in order of appearance
     c->no_hard_fold = getenv("SIMON_NO_HARD_FOLD") != nullptr;        // A/B + tests: hard spread constraints always on the all-feature kernel
     c->no_cn2 = getenv("SIMON_NO_CN2") != nullptr;
+    c->no_rs = getenv("SIMON_NO_RS") != nullptr;
     c->no_ipa_fold = getenv("SIMON_NO_IPA_FOLD") != nullptr;          // A/B + tests: preferred pod (anti-)affinity always on the all-feature kernel
     c->no_spread = getenv("SIMON_NO_SPREAD") != nullptr;              // A/B + tests: soft spread constraints on the all-feature kernel
     if (const char* e = getenv("SIMON_TEAM")) { const int v = atoi(e); c->team_mode = v == 0 ? 0 : (v == 1 || v == kTeamWaves) ? 1 : -1; }
@@ -1899,6 +1946,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             if (c->spread) {
                 cold.sp_ent = (const int2*)c->d_sp_ent.p; cold.spread_log = c->d_spread_log.p;
                 cold.node_sets = c->d_node_sets.p; cold.set_words = (c->N + 63) / 64; cold.cls_zdom = c->d_cls_zdom.p;
+                if (c->rest) cold.sp_word = c->d_sp_word.p;
             }
             const bool tprof = c->table_prof;
             if (tprof) { HIP_TRY(c, c->d_table_prof.ensure((size_t)S * 24)); HIP_TRY(c, hipMemsetAsync(c->d_table_prof.p, 0, (size_t)S * 192, c->stream)); cold.prof = c->d_table_prof.p; }

@@ -75,6 +75,9 @@ struct TableCold {
     const signed char* cls_zdom;    // [NZK][Cn] domain of an internal node class under zone key slot z (-1: the label is missing)
     const int32_t* gpu_cnt;         // [N]
     const uint32_t *gpu_devtot, *i_gused;   // [N] per-device total, [N][8] used at the start (gcd units)
+    // REST && SPREAD in one instantiation (round 6): PodRowC::rest keeps the REST descriptor (per pod: its GPU request is part of it), the
+    // SPREAD descriptor travels here, by pod id
+    const int32_t* sp_word;         // [P]
 };
 
 struct TableLaunch {
@@ -83,7 +86,7 @@ struct TableLaunch {
     const unsigned long long* ws_off;   // [n_blocks] byte offset of a workgroup's slice of ws (table_ws_bytes of its own scenario)
     unsigned char* ws;   // HBM workspace: byte table + node state (+ per-16 summary entries and counters when coarse) of every scenario
     int team;            // waves per scenario: 0 / 1 = one (the throughput shape); kTeamWaves = team mode (SPREAD only; small batches)
-    bool spread;         // some pod class carries soft spread constraints (generation 7; implies coarse, excludes rest)
+    bool spread;         // some pod class carries soft spread constraints (generation 7; implies coarse; together with rest: simon_table_rs.hip)
     bool aff;            // some pod class carries required-affinity entries (REST)
     bool rest;           // some pods need the per-node filters of the REST path (implies coarse)
     bool coarse;         // two-level summary: LDS entries cover 64 positions, per-16 entries live in the workspace (tcarve)
@@ -138,6 +141,8 @@ hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size
 hipError_t launch_table_rest2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);   // ... for 65 .. 128 node classes (simon_table_rest2.hip)
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)
 hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
+// generation 7 over the position-mask rows of generation 6 (REST && SPREAD: simon_table_rs.hip; one wave per scenario, <= 64 node classes, <= 128 signatures)
+hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 hipError_t launch_table_spread2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);   // ... for 65 .. 128 node classes (simon_table_spread2.hip)
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,

@@ -399,10 +399,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 #endif
     static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
-    static_assert(!SPREAD || (COARSE && !REST), "SPREAD is built on the two-level layout, without the REST rows");
+    static_assert(!SPREAD || COARSE, "SPREAD is built on the two-level layout");
+    constexpr bool RS = REST && SPREAD;                               // generation 7's walks over generation 6's position-mask rows (round 6)
+    static_assert(!RS || (NW == 1 && !AFF && !MANY && !LDSX && !CN2), "REST && SPREAD: one wave, no required affinity / preferred / hard terms, <= 64 classes");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
-    static_assert(!CN2 || (SPREAD && !MANY) || (REST && !LDSX), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
+    static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
     constexpr int TABMAX = CN2 ? kSpreadTabMax2 : kSpreadTabMax;
     const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0) | (CN2 ? 0x400 : 0)) : -1);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
@@ -510,8 +512,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     unsigned* g_xalloc = g_xused + (size_t)ni * 8;                    // [ni][8]: their allocatable
     unsigned short* g_pdom = (unsigned short*)(g_xalloc + (size_t)ni * 8);   // [NZ][ni]: domain under a zone-like key, 0xFFFF = no label
     unsigned* g_rowtot = LDSX ? (unsigned*)(smem + ldsx_rt) : (unsigned*)(g_pdom + (size_t)NZ * ni);       // [M]: pods that set the row so far (term totals of required affinity)
-    // SPREAD (never together with REST: M == 0, so the block starts where the REST rows would): placed pods a term's selector matches
-    unsigned char* g_hrow = (unsigned char*)g_xm;                     // [TH][ni] per position (hostname-like key: domain = node)
+    // SPREAD (without REST: M == 0, the block starts where the REST rows would; with REST: behind the row totals): placed pods a term's selector matches
+    unsigned char* g_hrow = RS ? (unsigned char*)(g_pdom + (size_t)NZ * ni) + (((size_t)M * 4 + 127) & ~(size_t)127) : (unsigned char*)g_xm_mem;   // [TH][ni] per position (hostname-like key: domain = node)
     unsigned* g_zcnt = (unsigned*)(g_hrow + (((size_t)TH * ni + 127) & ~(size_t)127));   // [TZ][16] per domain of a zone-like key
     unsigned char* g_hmax = (unsigned char*)(g_zcnt + (((size_t)TZ * 16 + 31) & ~(size_t)31));   // [TH] largest counter of a hostname-key row
     unsigned short* g_canon = (unsigned short*)(g_hmax + (((size_t)TH + 127) & ~(size_t)127));    // [ni] RANKED: rank of the position's node in the scenario's order
@@ -972,14 +974,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         if (__ballot(any_need)) tp_acc[20] += 1;                           // how often table rows are needed
 #endif
         if (__ballot(any_need)) {                                         // some unit's best position is excluded: its 4 x 16 table bytes
-            const unsigned koff16 = (unsigned)k * 16u;
+            const unsigned koff16 = (unsigned)k * KS;                       // (SPREAD keeps [unit][K][64]: tile_blk)
             auto keep = [&](unsigned w, unsigned nib) -> unsigned { return w & ~((((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu); };
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
                 if (!need[q]) continue;
                 uint4 R[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = *(const uint4*)(g_tile + ((uu[q] * 4u + (unsigned)j) * Krow + koff16));
+                for (int j = 0; j < 4; ++j) R[j] = *(const uint4*)(g_tile + (tile_blk(uu[q] * 4u + (unsigned)j) + koff16));
                 unsigned best = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1157,7 +1159,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // lists give the canonical index of a position).  Everything else about the cycle -- assume, column refresh, summaries -- is the
     // table path's.  Descriptor (PodRowC::rest) = soft constraints | counted terms << 3 | preferred-term entries << 10 | hard constraints << 13 | offset << 15 into TableCold::sp_ent; lane e
     // holds entry e (`spv`).
-    auto spread_select = [&](int k, int tc, int soft_n, int match_n, int ipa_n, int hard_n, int spv, int spt, int& dstar, int& res) -> int {
+    // (REST && SPREAD: f_* = the pod's REST descriptor -- GPU request row, extra-resource row, filter entries in the lanes of f_rowv; a pod that
+    // carries any walks under them: a position a row excludes counts as infeasible -- in the sizes, the extremes and the totals)
+    auto spread_select = [&](int k, int tc, int soft_n, int match_n, int ipa_n, int hard_n, int spv, int spt, int& dstar, int& res,
+                             int f_nrows = 0, int f_rowv = 0, int f_gs = -1, int f_xs = -1) -> int {
         // team mode: everything the leader stored in the cycles since the last spread pod -- table bytes, counters, class terms -- is
         // complete (the barrier's release waits for vmcnt / lgkmcnt) before a helper reads it; wave w walks units [ulo, uhi)
         if constexpr (NW > 1) __syncthreads();
@@ -1237,7 +1242,43 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         // slots beyond it repeat the last unit; profiles/r04/r04b_team_ab_*.txt)
         constexpr int SB = kSpreadBatch1, SC = kSpreadBatch2, SG = kSpreadBatch4;
         // the first loads of the walk go out before the class bookkeeping below waits for its own (memory is served in order)
-        const int cntd = lane < Cn ? g_cnt[k * Cn + dd] : 0;              // feasible nodes of class d for signature k
+        const bool filt = RS && (f_gs >= 0 || f_xs >= 0 || f_nrows > 0);
+        const uint2* const fxw = (const uint2*)g_xm;                      // RS: [row][nun] words of 64 positions, bit = excluded
+        auto bad_of = [&](int u) -> unsigned long long {                  // the pod's filter rows ORed for unit u (uniform address: one line per row)
+            uint2 b = f_gs >= 0 ? fxw[(unsigned)f_gs * (unsigned)nun + (unsigned)u] : make_uint2(0u, 0u);
+            if (f_xs >= 0) { const uint2 v = fxw[(unsigned)(G + f_xs) * (unsigned)nun + (unsigned)u]; b.x |= v.x; b.y |= v.y; }
+            for (int e = 0; e < f_nrows; ++e) {
+                const unsigned ent = (unsigned)__builtin_amdgcn_readlane(f_rowv, e);
+                const uint2 v = fxw[(ent & 0xFFFFu) * (unsigned)nun + (unsigned)u];
+                b.x |= v.x; b.y |= v.y;
+            }
+            return ((unsigned long long)b.y << 32) | b.x;
+        };
+        int cntd_f = 0;
+        if constexpr (RS) {
+            if (filt) {
+                // the feasible-node counters per (signature, class) know nothing of the rows: count the admitted positions of every class first
+                // (F, the zone sizes and the Simon class term are taken over the nodes that pass ALL filters, generic_scheduler.go:131-209)
+                constexpr int PB = 8;
+                for (int u0 = ulo; u0 < uhi; u0 += PB) {
+                    unsigned b0[PB];
+                    unsigned long long x0[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        const int u = min(u0 + j, uhi - 1);
+                        b0[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
+                        x0[j] = bad_of(u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        const int n_ok = __popcll(__ballot(b0[j] != 0u && !((x0[j] >> lane) & 1ull)));
+                        const int c = winner_info(min(u0 + j, uhi - 1)) >> 16;
+                        cntd_f += (u0 + j < uhi && lane == c) ? n_ok : 0;
+                    }
+                }
+            }
+        }
+        const int cntd = filt ? cntd_f : (lane < Cn ? (CNT_LDS ? s_cnt : g_cnt)[k * Cn + dd] : 0);   // feasible nodes of class d for signature k
         unsigned czv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1297,12 +1338,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const unsigned char* hb1 = has_hrow ? g_hrow + (size_t)hrow_i * ni : (const unsigned char*)g_tile;   // (no hostname term: value unused)
         const int hmx_v = (simple && has_hrow) ? (int)g_hmax[hrow_i] : 0;   // largest counter of the row (uniform address)
         unsigned byte1[SB], h1[SB];
+        unsigned long long bad1[RS ? SB : 1];
         auto load1 = [&](int u0) {
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
                 const int u = min(u0 + j, uhi - 1);                       // a slot beyond the last unit repeats it (changes nothing)
                 byte1[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
                 h1[j] = hb1[(unsigned)(u * 64 + lane)];
+                if constexpr (RS) bad1[j] = filt ? bad_of(u) : 0ull;
             }
         };
         if (simple && have) load1(ulo);
@@ -1360,6 +1403,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         // per class as well: "ignored" and the class term of the signature's row
         // (bit 30: excluded -- its nodes count as infeasible; the Simon normalisation then runs over the classes that are left, simon.go:76-101)
         int ctermv = (int)s_sn[k * Cn + dd];
+        if constexpr (RS) {                                               // under filter rows: the Simon term over the classes that keep an admitted node (simon.go:76-101)
+            if (filt) ctermv = class_term(lane < Cn && cntd > 0, simon_raw[tc * Cn + dd], tc, dd);
+        }
         int ctermv2 = CN2 ? (int)s_sn[k * Cn + dd2] : 0;
         if constexpr (kIpa && CN2) {
             if (hard_n > 0 && __ballot((cntd > 0 && excl) || (v2 && cntd2 > 0 && excl2)) != 0ull)
@@ -1447,6 +1493,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         const int raw = s_tab[idx];
                         const int cwv = cls_word(c);
                         unsigned beff = byte1[j];
+                        if constexpr (RS) beff = ((bad1[j] >> lane) & 1ull) ? 0u : beff;   // a position the pod's filter rows exclude
                         if constexpr (kIpa) beff = (cwv & 0x40000000) ? 0u : beff;   // a class a hard constraint excludes: no feasible node
                         const bool ok = (beff != 0u) & (cwv >= 0);            // (no short circuit: no branch)
                         pmin = min(pmin, ok ? raw : 0x7fffffff);
@@ -1551,6 +1598,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 for (int j = 0; j < SG; ++j) {
                     const int u = min(u0 + j, uhi - 1);
                     byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
+                    if constexpr (RS) { if (filt) byte[j] = ((bad_of(u) >> lane) & 1ull) ? 0u : byte[j]; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
                     hI[j] = kIpa ? hbI[(unsigned)(u * 64 + lane)] : 0u;
@@ -1585,6 +1633,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 for (int j = 0; j < SG; ++j) {
                     const int u = min(u0 + j, uhi - 1);
                     byte[j] = g_tile[(unsigned)u * (Krow * 4u) + toff];
+                    if constexpr (RS) { if (filt) byte[j] = ((bad_of(u) >> lane) & 1ull) ? 0u : byte[j]; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = hb[e][(unsigned)(u * 64 + lane)];
                     hI[j] = kIpa ? hbI[(unsigned)(u * 64 + lane)] : 0u;
@@ -1697,10 +1746,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         return make_int4(r.sigcls | (special ? (int)0x80000000 : 0), r.preset, r.gate, r.rest);
     };
     int4 nxt = load_chunk(0);
+    auto load_spw = [&](int i0) -> int {                                   // REST && SPREAD: the SPREAD descriptor, by pod id (TableCold::sp_word)
+        if constexpr (RS) { const int idx = i0 + lane; return idx < P ? gp(cold->sp_word)[order[idx]] : 0; }
+        else return 0;
+    };
+    int nxt_sw = load_spw(0);
 
     for (int i0 = 0; i0 < P; i0 += 64) {
         const int4 cur = nxt;
         nxt = load_chunk(i0 + 64);
+        const int cur_sw = nxt_sw;
+        if constexpr (RS) nxt_sw = load_spw(i0 + 64);
         const int steps = P - i0 < 64 ? P - i0 : 64;
         int plreg = -2;
         for (int il = 0; il < steps; ++il) {
@@ -1708,11 +1764,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int pk = __builtin_amdgcn_readlane(cur.x, il);
         const int r_sig = pk & 0x3FF, r_cls = (pk >> 10) & 0x1FFFFF;
         const int rw = (REST || SPREAD) ? __builtin_amdgcn_readlane(cur.w, il) : 0;    // REST / SPREAD descriptor (0: the score table alone decides the pod)
-        const int sp_soft = SPREAD ? (rw & 7) : 0, sp_match = SPREAD ? ((rw >> 3) & 127) : 0, sp_ipa = SPREAD ? ((rw >> 10) & 7) : 0, sp_hard = SPREAD ? ((rw >> 13) & 3) : 0;
+        const int sw = RS ? __builtin_amdgcn_readlane(cur_sw, il) : rw;    // the SPREAD descriptor (REST && SPREAD: a word of its own)
+        const int sp_soft = SPREAD ? (sw & 7) : 0, sp_match = SPREAD ? ((sw >> 3) & 127) : 0, sp_ipa = SPREAD ? ((sw >> 10) & 7) : 0, sp_hard = SPREAD ? ((sw >> 13) & 3) : 0;
         int spv = 0;                                                       // SPREAD: lane e holds entry e of the pod's constraint / counted-term list
         int spt = 0;                                                       // ... and its term's row (TableCold::sp_ent holds both)
-        if (SPREAD && __builtin_expect(rw != 0, 0) && lane < sp_soft + sp_match + sp_ipa + sp_hard) {
-            const int2 spe = ldg_i2(gp(cold->sp_ent) + (((unsigned)rw >> 15) + lane));
+        if (SPREAD && __builtin_expect(sw != 0, 0) && lane < sp_soft + sp_match + sp_ipa + sp_hard) {
+            const int2 spe = ldg_i2(gp(cold->sp_ent) + (((unsigned)sw >> 15) + lane));
             spv = spe.x; spt = spe.y;
         }
         const int r_gs = REST ? (rw & 63) - 1 : -1, r_xs = REST ? ((rw >> 6) & 63) - 1 : -1, r_nrows = REST ? (rw >> 12) & 63 : 0;
@@ -1757,7 +1814,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
                 if (res < 0) ++unsched;
             }
-        } else if (REST && __builtin_expect(rw != 0, 0)) {                 // (cold for the register allocator: spills belong here)
+        } else if (REST && __builtin_expect(rw != 0, 0) && !(RS && spread_pod)) {   // (cold for the register allocator: spills belong here)
             pstar = rest_select(r_sig, r_cls, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv), dstar, res);
             TPROF(10);                                                 // REST pods: the whole select
             if (pstar < 0) { ++unsched; res = -1; }
@@ -1769,7 +1826,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
             if constexpr (NW == 1) {                                   // (one wave: the select sits where it always sat -- the team's call site is below)
-                pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
+                if constexpr (RS) pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res, r_nrows, rowv, r_gs, r_xs);
+                else pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
                 TPROF(18);                                             // spread: winner
                 if (pstar < 0) { ++unsched; res = -1; }
             }
@@ -2325,6 +2383,30 @@ hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, 
     if (a.sc.K > 64) return nzeq ? launch_rl2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rl2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rl2<false, 1>(a, n_blocks, lds_bytes, st);
 }
+#elif defined(SIMON_TABLE_RS_TU)
+// ---- this translation unit (simon_table_rs.hip) holds generation 7's walks over generation 6's position-mask rows (REST && SPREAD): one wave per
+// scenario, <= 64 node classes, <= 128 signatures, soft constraints only ----
+template <bool Z, int KQ, int NBQ, bool RANKED = false>
+static hipError_t launch_rs3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (!RANKED) {
+        if (a.sc.rk_stride != 0) return launch_rs3<Z, KQ, NBQ, true>(a, n_blocks, lds, st);
+    }
+    if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, RANKED, false, false, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+    return hipGetLastError();
+}
+template <bool Z, int KQ>
+static hipError_t launch_rs2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.ni_max / 64 <= 64 ? launch_rs3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (!a.spread || !a.rest || !a.coarse || a.aff || a.team > 1 || a.lds_x || a.sc.Cn > 64 || a.sc.K > 128 || (a.sc.static_tables & (32 | 64 | 128))) return hipErrorInvalidValue;
+    if (a.sc.K > 64) return nzeq ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 2>(a, n_blocks, lds_bytes, st);
+    return nzeq ? launch_rs2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
+}
 #elif defined(SIMON_TABLE_REST2_TU)
 // ---- this translation unit (simon_table_rest2.hip) holds generation 6 for 65 .. 128 internal node classes (CN2 in rest_select; rows in HBM) ----
 template <bool Z, int KQ>
@@ -2403,6 +2485,7 @@ static hipError_t launch_t2(const TableLaunch& a, int n_blocks, bool has_pin, si
 hipError_t launch_table(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, bool has_pin, size_t lds_bytes, hipStream_t st) {
     if (a.team > 1)                                                   // several waves per scenario: simon_table_team<N>.hip
         return a.team == kTeamWaves ? launch_table_team4(a, n_blocks, has_mask, nzeq, lds_bytes, st) : hipErrorInvalidValue;
+    if (a.spread && a.rest) return launch_table_rs(a, n_blocks, nzeq, lds_bytes, st);             // generation 7 over the position-mask rows: simon_table_rs.hip
     if (a.spread && a.sc.Cn > 64) return launch_table_spread2(a, n_blocks, nzeq, lds_bytes, st);   // generation 7, two node classes per lane: simon_table_spread2.hip
     if (a.spread) return launch_table_spread(a, n_blocks, has_mask, nzeq, lds_bytes, st);   // generation 7: simon_table_spread.hip
     if (a.lds_ws) return launch_table_lds(a, n_blocks, nzeq, lds_bytes, st);                // generation 4, workspace in LDS: simon_table_lds.hip

@@ -207,13 +207,17 @@ def config4(rank: int = 0, world: int = 1, n_counts: int = 1024, n_orders: int =
 
 
 def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_orders: int = 4, n_groups: int = 50,
-            group_size: int = 100, seed: int = SEED + 5, n_shapes: int = 0):
+            group_size: int = 100, seed: int = SEED + 5, n_shapes: int = 0, services: bool = False, n_zones: int = 3):
     """gpushare-style workload (BASELINE config 5 / SURVEY 8d): 30 % GPU nodes (4 or 8 devices x 16 GiB), 20 % GPU
     pods (gpu-mem 2/4/8/16 GiB, count 1/1/1/2), `n_groups` groups of `group_size` pods with required self
     anti-affinity on kubernetes.io/hostname, 10 % of the nodes tainted NoSchedule with 20 % of the pods tolerating.
     Scenarios: node counts spread over the upper half of the pool x `n_orders` pod orders.
     `n_shapes`: the nodes come in that many distinct allocatable shapes (config3_classes' draw) instead of four -- beyond 64 the REST select of
-    generation 6 keeps two node classes per lane (simon_table.hip: CN2)."""
+    generation 6 keeps two node classes per lane (simon_table.hip: CN2).
+    `services`: every anti-affinity group sits behind a Service -- its pods also carry the system-default soft PodTopologySpread constraints
+    (maxSkew 3 on the hostname key, 5 on the zone key, selector = the group's: podtopologyspread/plugin.go:39-50); nodes are zoned round robin.
+    The per-pod GPU requests and per-pod request shapes stay as drawn, so neither folds into the table: generation 7's walks run over
+    generation 6's position-mask rows (simon_table_rs.hip)."""
     GiB = 1 << 30
     rng = SplitMix64(seed)
     cpu, mem, pods, ncls = gen_nodes(seed, n_nodes, n_nodes)
@@ -278,6 +282,27 @@ def config5(n_pods: int = 50000, n_nodes: int = 5000, n_scen: int = 256, n_order
                    const_score=np.full(Cp, CONST_SCORE, np.int64), term_topo_key=np.zeros(n_groups, np.int32),
                    anti_off=np.array(anti_off, np.int32), anti_idx=np.array(anti_idx or [0], np.int32),
                    match_off=np.array(match_off, np.int32), match_idx=np.array(match_idx or [0], np.int32)).normalise()
+    if services:
+        from .gomath import spread_log_table
+        # term g = (selector of group g, hostname) -- the anti-affinity term, which the hostname constraint counts as well --, term n_groups + g =
+        # (selector of group g, zone); a class of group g matches both and spreads over both
+        prob.topo_dom = np.stack([np.arange(n_nodes, dtype=np.int32), (np.arange(n_nodes) % n_zones).astype(np.int32)])
+        prob.topo_n_dom = np.array([n_nodes, n_zones], np.int32)
+        prob.topo_is_hostname = np.array([1, 0], np.uint8)
+        prob.term_topo_key = np.concatenate([np.zeros(n_groups, np.int32), np.ones(n_groups, np.int32)])
+        prob.term_node_set = np.full(2 * n_groups, -1, np.int32)
+        m_off, m_idx, s_off, s_idx, s_skew = [0], [], [0], [], []
+        for t in table:
+            if t[3] >= 0:
+                m_idx += [t[3], n_groups + t[3]]
+                s_idx += [t[3], n_groups + t[3]]
+                s_skew += [3, 5]
+            m_off.append(len(m_idx)); s_off.append(len(s_idx))
+        prob.match_off, prob.match_idx = np.array(m_off, np.int32), np.array(m_idx or [0], np.int32)
+        prob.spread_soft_off, prob.spread_soft_idx = np.array(s_off, np.int32), np.array(s_idx or [0], np.int32)
+        prob.spread_soft_skew = np.array(s_skew or [1], np.int32)
+        prob.spread_log = spread_log_table(n_nodes)
+        prob = prob.normalise()
     if n_shapes > 0:
         reshape_nodes(prob, n_nodes, n_shapes + 1, [(t[0], t[1]) for t in table])    # (+ 1: the template's shape, which no node of this pool has)
         prob = prob.normalise()

@@ -2,7 +2,7 @@
 """Same-box A/B of library builds over the digest workloads: kernel time (HIP events, best and mean of `reps`) and a checksum of every
 placement row, so that two builds can be compared for speed AND for identical results in one gpurun call.
 usage: python profiles/ab_probe.py <workload,workload,...> [reps=3]      (library: SIMON_HIP_LIB, see profiles/build_variant.sh)
-workloads: c5s256 c5s2048 c5s64 c3 c3s64 c2 widemix typical service64 service shapes30 c5shapes80 c5service c3sig200 c3cls80"""
+workloads: c5s256 c5s2048 c5s64 c3 c3s64 c2 widemix typical service64 service shapes30 c5shapes80 c5asdrawn c5asdrawn64 c5service c3sig200 c3cls80"""
 import hashlib
 import os
 import sys
@@ -31,6 +31,10 @@ def build(name):
         return synth.config_service(n_counts=64, n_shapes=30)
     if name == "c5shapes80":                         # config 5 on 80 node shapes: generation 6 with two node classes per lane (CN2), 64 scenarios
         return synth.config5(n_scen=64, n_orders=4, n_shapes=80)
+    if name == "c5asdrawn":                          # BASELINE config 5 as it is drawn with its anti-affinity groups behind Services: REST && SPREAD (simon_table_rs.hip)
+        return synth.config5(n_scen=256, n_orders=4, services=True)
+    if name == "c5asdrawn64":
+        return synth.config5(n_scen=64, n_orders=4, services=True)
     if name == "c5service":
         return synth.config5_service(n_scen=256, n_orders=4)
     if name == "typical":

@@ -24,9 +24,20 @@ def one_case(case):
     feat = {f: True for f in FEATURES if rng.random() < 0.3}
     if size == 2:
         feat.pop("static_mask", None)
-    many_classes = case >= 600000                       # cases from 600 000 on: 65 .. 128 internal node classes (node shapes x zones; simon_table.hip: CN2)
+    mask_rows = case >= 700000                          # cases from 700 000 on: GPU share / required anti-affinity / ports / extra resources that do NOT fold into
+    if mask_rows:                                       # the table, next to the soft constraints: the walks over the position-mask rows (REST && SPREAD)
+        for f in ("ipa_self", "ipa", "hard_simple"):
+            feat.pop(f, None)
+        for f, pr in (("gpu", 0.6), ("anti_host", 0.4), ("anti", 0.3), ("ports", 0.25), ("eph", 0.2)):
+            if rng.random() < pr:
+                feat[f] = True
+        if rng.random() < 0.2:
+            feat["scalars"] = int(rng.integers(1, 4))
+        if "anti" in feat:
+            feat.pop("anti_host", None)
+    many_classes = 600000 <= case < 700000                       # cases from 600 000 on: 65 .. 128 internal node classes (node shapes x zones; simon_table.hip: CN2)
     prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=(case % 7 != 6 or "ipa_self" not in feat), n_node_classes=int(rng.choice([14, 18, 22, 25] if many_classes else [1, 2, 4, 9])),
-                                 n_pod_classes=int(rng.choice([130, 200, 300, 384, 600, 1000] if case >= 300000 else [1, 3, 8, 30, 60])), **feat)   # cases from 300 000 on: 129 ... 384 signatures (MANY && SPREAD)
+                                 n_pod_classes=int(rng.choice([130, 200, 300, 384, 600, 1000] if 300000 <= case < 600000 else [1, 3, 8, 30, 60])), **feat)   # cases from 300 000 on: 129 ... 384 signatures (MANY && SPREAD)
     if "gpu" in feat:                                   # GPU share folded into the table (few request kinds: <= 128 signatures), behind the spread walk
         G_ = 1 << 30
         prob.gpu_mem = np.where(prob.gpu_mem > 4 * G_, 8 * G_, np.where(prob.gpu_mem > 0, 2 * G_, 0)).astype(np.int64)
@@ -39,6 +50,8 @@ def one_case(case):
         for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
             ranks[s_, :n] = rng.permutation(n)
     ref = O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run_threaded(prob, scen, orders)
+    if mask_rows:
+        os.environ["SIMON_NO_FOLD"] = "1"; os.environ["SIMON_NO_GPU_FOLD"] = "1"
     ok, teams = True, 0
     for team in ("0", "1"):                             # one wave per scenario, then a team of waves (simon_table.hip: NW waves per scenario)
         os.environ["SIMON_TEAM"] = team
@@ -58,6 +71,7 @@ def one_case(case):
         teams += st.workgroup_size > 64 and st.kernel_generation == 7
         ok = ok and (res.unscheduled.tolist() == ref.unscheduled.tolist() and res.used_cpu.tolist() == ref.used_cpu.tolist() and
                      res.used_mem.tolist() == ref.used_mem.tolist() and bool((res.placement == ref.placement).all()))
+    os.environ.pop("SIMON_NO_FOLD", None); os.environ.pop("SIMON_NO_GPU_FOLD", None)
     return ok, dict(case=case, N=N, P=P, S=len(scen), feat=sorted(feat), generation=st.kernel_generation, variant=st.kernel_variant, team=teams)
 
 
