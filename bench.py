@@ -301,6 +301,8 @@ def build_workload(args, synth, world):
         return synth.config2(), 1
     if args.workload == "service":             # config 3's pool and sweep, every pod selected by a Service (system-default soft spread)
         return synth.config_service(n_counts=args.counts, n_orders=n_orders, n_pods=args.pods, n_anti=args.anti, n_pref=args.pref, n_hard=args.hard, n_gpu=args.gpu_services, n_shapes=args.shapes), n_orders
+    if args.workload == "config5asdrawn":      # BASELINE config 5 AS DRAWN (per-pod requests and GPU requests) with its anti-affinity groups behind Services: the walks over the mask rows
+        return synth.config5(n_scen=c5_scenarios(args), n_orders=4, services=True), 4
     if args.workload == "config5service":      # config 5's shape as Deployments behind Services: GPU share + required self anti-affinity + taints + soft spread
         return synth.config5_service(n_scen=c5_scenarios(args), n_orders=4), 4
     if args.workload == "typical":             # Kubernetes objects of a typical cluster, 64 candidate sizes (the `simon apply` shape; team mode of generation 7)
@@ -341,6 +343,7 @@ def wide_mix_sweep(n_nodes=2500, new_nodes=2500, n_workloads=400, max_replicas=2
 
 def workload_name(args, prob, scen_all, n_orders, S_local, world):
     head = {"config5": "BASELINE config 5-style (gpushare): ", "config2": "BASELINE config 2: ",
+            "config5asdrawn": "BASELINE config 5 as drawn, its anti-affinity groups behind Services (walks over the position-mask rows): ",
             "config5service": "config 5's shape behind Services (GPU share + required self anti-affinity + taints + soft spread constraints): ",
             "service": "config 3 with every pod selected by a Service (system-default soft PodTopologySpread constraints): ",
             "typical": "typical cluster (Kubernetes objects: Deployments behind Services, preferred / required self anti-affinity, hard zone constraints): ",
@@ -433,6 +436,10 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config_service(n_counts=SMALL_COUNTS * 4, n_gpu=SERVICE_GPU)
         child = ["--workload", "service", "--counts", str(SMALL_COUNTS * 4), "--gpu-services", str(SERVICE_GPU)]
         wl, label = "config3", f"config 3 with Service-selected pods, {SERVICE_GPU} of the 60 services asking for GPU share, {16 * SMALL_COUNTS} scenarios"
+    elif name == "config5_asdrawn":                 # BASELINE config 5 as drawn, its anti-affinity groups behind Services: REST && SPREAD in one instantiation
+        prob, scen, orders = synth.config5(n_scen=c5_scen, n_orders=4, services=True)
+        child = ["--workload", "config5asdrawn", "--c5-scenarios", str(c5_scen)]
+        wl, label = "config5", f"BASELINE config 5 as drawn, its anti-affinity groups behind Services, at {c5_scen} scenarios"
     elif name == "config5_service":                 # config 5's shape as Deployments behind Services: GPU fold + anti-affinity fold + generation 7's walk
         prob, scen, orders = synth.config5_service(n_scen=c5_scen, n_orders=4)
         child = ["--workload", "config5service", "--c5-scenarios", str(c5_scen)]
@@ -471,7 +478,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         child = ["--workload", "config5", "--c5-scenarios", str(c5_scen)]
         wl, label = "config5", f"BASELINE config 5 at {c5_scen} scenarios"
     device = torch.cuda.current_device()
-    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "config3_small": f"config3_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "service_shapes": f"config3_service_shapes{SERVICE_SHAPES}_S{16 * SMALL_COUNTS}", "config5_service": f"config5_service_S{c5_scen}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
+    rec = {"workload": {"config2": "config2", "service": "config3_service", "service_small": f"config3_service_S{4 * SMALL_COUNTS}", "config3_small": f"config3_S{4 * SMALL_COUNTS}", "service_gpu": f"config3_service_gpu{SERVICE_GPU}_S{16 * SMALL_COUNTS}", "service_shapes": f"config3_service_shapes{SERVICE_SHAPES}_S{16 * SMALL_COUNTS}", "config5_service": f"config5_service_S{c5_scen}", "config5_asdrawn": f"config5_asdrawn_service_S{c5_scen}", "typical": "typical_cluster_x64", "widemix": "wide_mix_x64", "service_anti": f"config3_service_anti{SERVICE_ANTI}", "service_pref": f"config3_service_pref{SERVICE_PREF}",
                         "config3sig": f"config3_sigs{SIG_RECORD}", "config3sig_cliff": f"config3_sigs{SIG_CLIFF}",
                         "config3_classes": f"config3_classes{CLASS_RECORD}", "config3_classes_cliff": f"config3_classes{CLASS_CLIFF}"}.get(name, f"config5_S{c5_scen}")}
     with capi.Context(device) as ctx:
@@ -777,7 +784,7 @@ def main():
     ap.add_argument("--gpu-services", type=int, default=0, help="--workload service: services whose pods ask for GPU share (a gpushare cluster behind Services)")
     ap.add_argument("--shapes", type=int, default=0, help="--workload service: distinct node shapes of the existing nodes (x 3 zones = internal node classes of generation 7)")
     ap.add_argument("--anti", type=int, default=0, help="--workload service: services whose pods also require anti-affinity to their own kind on the hostname key")
-    ap.add_argument("--workload", choices=["config3", "config5", "config5service", "config2", "config3sig", "config3classes", "service", "typical", "widemix"], default="config3",
+    ap.add_argument("--workload", choices=["config3", "config5", "config5service", "config5asdrawn", "config2", "config3sig", "config3classes", "service", "typical", "widemix"], default="config3",
                     help="config3 = the BASELINE metric's workload (default); config5 = gpushare-style 50k pods x 5k nodes "
                          "(GPU share + anti-affinity + taints) on generation 6 of the score-table kernel, --c5-scenarios per GPU")
     ap.add_argument("--placement", type=int, default=1, help="store the [S][P] placement matrix in HBM (default on)")
@@ -930,11 +937,11 @@ def main():
             for name, steps, warm, nchk, c5s in (("config2", 20, 2, 1, 0), ("config3sig", sub_steps, 1, 64, 0), ("service", sub_steps, 1, 64, 0),
                                                  ("service_anti", sub_steps, 1, 48, 0), ("service_pref", sub_steps, 1, 48, 0),
                                                  ("config5", sub_steps, 1, nchk5, c5_scenarios(args)), ("config5", sub_steps, 1, nchk5, C5_SATURATING),
-                                                 ("service_small", sub_steps, 1, 16, 0), ("service_gpu", sub_steps, 1, 16, 0), ("service_shapes", sub_steps, 1, 16, 0), ("config5_service", sub_steps, 1, 16, c5_scenarios(args)), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
+                                                 ("service_small", sub_steps, 1, 16, 0), ("service_gpu", sub_steps, 1, 16, 0), ("service_shapes", sub_steps, 1, 16, 0), ("config5_service", sub_steps, 1, 16, c5_scenarios(args)), ("config5_asdrawn", sub_steps, 1, 16, c5_scenarios(args)), ("typical", sub_steps, 1, 2, 0), ("widemix", sub_steps, 1, 2, 0),
                                                  ("config3sig_cliff", sub_steps, 1, 16, 0), ("config3_classes", sub_steps, 1, 16, 0), ("config3_classes_cliff", sub_steps, 1, 16, 0),
                                                  ("config3_small", sub_steps, 1, 16, 0)):
                 try:
-                    cliff = name in ("config3sig_cliff", "config3_classes", "config3_classes_cliff", "config5_service")   # the cliff rows and config 5 behind Services: a shorter CPU sample; since round 5 they carry their live-PMC roofline like every other row
+                    cliff = name in ("config3sig_cliff", "config3_classes", "config3_classes_cliff", "config5_service", "config5_asdrawn")   # the cliff rows and config 5 behind Services: a shorter CPU sample; since round 5 they carry their live-PMC roofline like every other row
                     subs.append(sub_record(name, capi, synth, torch, steps, warm, 0 if args.no_cpu_baseline else nchk, mode, c5s,
                                            cpu_budget_s=3.0 if cliff else 6.0))
                     if subs[-1].get("parity_sample", {}).get("mismatches"):

@@ -263,3 +263,51 @@ def test_gpushare_cluster_with_80_node_shapes_stays_on_generation_6():
         assert r2.unscheduled.tolist() == ref2.unscheduled.tolist() and (r2.placement == ref2.placement).all()
         assert r2.used_cpu.tolist() == ref2.used_cpu.tolist() and r2.used_mem.tolist() == ref2.used_mem.tolist()
     assert on6 >= 4
+
+
+def test_soft_spread_constraints_over_the_position_mask_rows():
+    """REST && SPREAD in one instantiation (simon_table_rs.hip): pods behind Services next to Open-Gpu-Share requests,
+    required anti-affinity (hostname and zone-like keys), host ports and extra resources that do NOT fold into the table -- the spread walk
+    honours the mask rows and counts the admitted nodes of every class itself (podtopologyspread/scoring.go:60-256 runs over the nodes that
+    pass ALL filters).  BASELINE config 5 as it is drawn with its anti-affinity groups behind Services (folds switched off: at this size they
+    would still take it); random problems per feature; SIMON_NO_RS = the old route, same answers."""
+    env = {"SIMON_NO_FOLD": "1", "SIMON_NO_GPU_FOLD": "1"}
+    prob, scen, orders = synth.config5(n_pods=6000, n_nodes=900, n_scen=8, n_orders=2, n_groups=20, group_size=30, services=True)
+    ref = O.run_threaded(prob, scen, orders)
+    res, st, _ = run_gpu(prob, scen, orders, env=env)
+    assert st.kernel_generation == 7 and st.kernel_variant != capi.KERNEL_WIDE
+    assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
+    assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
+    res0, st0, _ = run_gpu(prob, scen, orders, env=dict(env, SIMON_NO_RS="1"))
+    assert st0.kernel_variant == capi.KERNEL_WIDE and (res0.placement == ref.placement).all()
+    on7 = 0
+    feats = [dict(gpu=True), dict(anti_host=True, ports=True), dict(gpu=True, anti_host=True, nz_differs=True, init_state=True), dict(gpu=True, presets=True, gates=True, pins=True),
+             dict(anti=True, tight_pods=True, zero_pods=True), dict(gpu=True, anti=True, static_small=True, odd_units=True)]
+    for seed, feat in enumerate(feats):
+        N = [200, 500, 1400, 300, 2600, 800][seed]
+        p2 = randprob.rand_problem(7300 + seed, N=N, P=700, spread_soft=True, n_node_classes=[4, 2, 9, 1, 4, 6][seed], n_pod_classes=[3, 30, 60, 8, 20, 40][seed], **feat)
+        s2, o2 = randprob.rand_scenarios(seed, p2, S=4, min_n=max(1, N // 2))
+        ranks = None
+        if seed % 3 == 1:
+            rng = np.random.default_rng(seed)
+            ranks = np.zeros((len(s2), p2.n_nodes), np.int32)
+            for i, (n, _) in enumerate(np.asarray(s2).tolist()):
+                ranks[i, :n] = rng.permutation(n)
+        ref2 = O.run(p2, s2, o2, node_ranks=ranks) if ranks is not None else O.run_threaded(p2, s2, o2)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with capi.Context(0) as ctx:
+                ctx.load_problem(p2)
+                ctx.load_scenarios(s2, o2)
+                if ranks is not None:
+                    ctx.set_node_ranks(ranks)
+                ctx.run_loaded(True)
+                r2 = ctx.fetch(True)
+                on7 += ctx.stats().kernel_generation == 7
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert r2.unscheduled.tolist() == ref2.unscheduled.tolist() and (r2.placement == ref2.placement).all()
+        assert r2.used_cpu.tolist() == ref2.used_cpu.tolist() and r2.used_mem.tolist() == ref2.used_mem.tolist()
+    assert on7 >= 5
