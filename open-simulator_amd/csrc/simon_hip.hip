@@ -233,7 +233,7 @@ uint64_t gcd_of(std::initializer_list<const std::vector<int64_t>*> vs) {
 bool rest_supported(simon_ctx* c) {
     if (c->no_rest) return false;
     if (c->has_gpu_index) return false;   // pods that arrive with a gpu-index annotation (their own filter and Reserve rule): all-feature kernel
-    if (c->Tm > kTableMaxTerms) return false;
+    if (c->Tm > kTableMaxTerms && !c->rs) return false;
     // a term's topology key is node-level (every node its own domain: kubernetes.io/hostname) or zone-like (a domain = several
     // nodes, some nodes without the label): at most 6 of the latter, domain ids below 65 535
     std::vector<int> key_kind(std::max(c->Kt, 1), -1);   // 1 node-level, 0 zone-like
@@ -247,6 +247,11 @@ bool rest_supported(simon_ctx* c) {
             for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) if (c->anti_idx[e] >= 0 && c->anti_idx[e] < c->Tm) row_read[c->anti_idx[e]] = 1;
             for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) if (c->port_idx[e] >= 0 && c->port_idx[e] < c->Tm) row_read[c->port_idx[e]] = 1;
         }
+    if (c->rs) {                                                          // (... and only those get rows: stage_narrow)
+        int n_read = 0;
+        for (int t = 0; t < c->Tm; ++t) n_read += row_read[t];
+        if (n_read > kTableMaxTerms) return false;
+    }
     for (int t = 0; t < c->Tm; ++t) {
         if (!row_read[t]) continue;
         if (!c->term_set.empty() && c->term_set[t] >= 0) return false;
@@ -948,21 +953,26 @@ int stage_narrow(simon_ctx* c) {
                 xs_of[p] = it.first->second;
             }
             const int Xn = (int)xs_id.size();
-            const int G = (int)gsigs.size(), T = c->Tm, B = G + Xn;          // term rows start behind the request rows
+            // REST && SPREAD: the match lists also name the terms the spread constraints count -- rows nobody ever tests (and on a zone-like
+            // key a set-row costs a pass over the scenario's blocks per landing pod): only the terms some class holds AGAINST others get
+            // rows there (tm: term -> its row pair), so a cluster of hundreds of Services next to a few anti-affinity terms fits
+            std::vector<char> row_read(std::max(c->Tm, 1), c->rs ? 0 : 1);
+            if (c->rs)
+                for (int cp = 0; cp < c->Cp; ++cp) {
+                    for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) row_read[c->anti_idx[e]] = 1;
+                    for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) row_read[c->port_idx[e]] = 1;
+                }
+            std::vector<int> tm(std::max(c->Tm, 1), 0);
+            int n_rows_t = 0;
+            for (int t = 0; t < c->Tm; ++t) if (row_read[t]) tm[t] = n_rows_t++;
+            const int G = (int)gsigs.size(), T = n_rows_t, B = G + Xn;       // term rows start behind the request rows
             const int NZk = (int)c->zone_keys.size(), SCR = B + 2 * T, LBL = SCR + 1;
             // rows: requests | "a pod MATCHING t is here" | "a pod REQUIRING t is here" | scratch (set by entries that set nothing,
             // never read) | per zone-like key "the node lacks the label"
             c->rest_G = G; c->rest_X = Xn; c->rest_M = LBL + NZk;
             std::map<std::pair<std::vector<int32_t>, std::vector<int32_t>>, int> xc_id;   // -> n | offset << 6
             std::vector<int> xc_of(c->Cp, 0);
-            // REST && SPREAD: the match lists also name the terms the spread constraints count -- rows nobody ever tests (and on a zone-like
-            // key a set-row costs a pass over the scenario's blocks per landing pod): keep the terms some class holds against others
-            std::vector<char> row_read(std::max(T, 1), c->rs ? 0 : 1);
-            if (c->rs)
-                for (int cp = 0; cp < c->Cp; ++cp) {
-                    for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) row_read[c->anti_idx[e]] = 1;
-                    for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) row_read[c->port_idx[e]] = 1;
-                }
+
             for (int cp = 0; cp < c->Cp && T > 0; ++cp) {
                 std::vector<int32_t> anti(c->anti_idx.begin() + c->anti_off[cp], c->anti_idx.begin() + c->anti_off[cp + 1]);
                 std::vector<int32_t> match(c->match_idx.begin() + c->match_off[cp], c->match_idx.begin() + c->match_off[cp + 1]);
@@ -990,16 +1000,16 @@ int stage_narrow(simon_ctx* c) {
                     // REQUIRES a term that matches me (row B + T + t); AddPod sets the mirror rows (oracle/simon_oracle.c: add_pod)
                     // bits 28..30: zone key + 1 of the term (the set-row then covers every position of the pod's domain)
                     auto zs = [&](int t) { return (unsigned)(c->key_zslot[c->term_key[t]] + 1) << 28; };
-                    for (int t : anti) xrows.push_back((int)((unsigned)(B + t) | ((unsigned)(B + T + t) << 16) | zs(t)));
-                    for (int t : match) xrows.push_back((int)((unsigned)(B + T + t) | ((unsigned)(B + t) << 16) | zs(t)));
+                    for (int t : anti) xrows.push_back((int)((unsigned)(B + tm[t]) | ((unsigned)(B + T + tm[t]) << 16) | zs(t)));
+                    for (int t : match) xrows.push_back((int)((unsigned)(B + T + tm[t]) | ((unsigned)(B + tm[t]) << 16) | zs(t)));
                     // a conflicting port is in use on the node: a placed pod MATCHES (binds) port term t; nothing to set -- the
                     // entry's set-row repeats a row the class sets anyway, or a scratch row behind the last term row
-                    for (int t : port) xrows.push_back((B + t) | (SCR << 16));
+                    for (int t : port) xrows.push_back((B + tm[t]) | (SCR << 16));
                     // required affinity: row B + t must be SET (bit 31; bit 27: the class matches its own terms -- the first-pod
                     // escape); on a zone-like key the node must carry the label whatever the escape says (label row, plain entry)
                     std::set<int> zk;
                     for (int t : aff) {
-                        xrows.push_back((int)((unsigned)(B + t) | ((unsigned)SCR << 16) | (aff_self ? 1u << 27 : 0u) | (1u << 31)));
+                        xrows.push_back((int)((unsigned)(B + tm[t]) | ((unsigned)SCR << 16) | (aff_self ? 1u << 27 : 0u) | (1u << 31)));
                         const int z = c->key_zslot[c->term_key[t]];
                         if (z >= 0 && zk.insert(z).second) xrows.push_back((LBL + z) | (SCR << 16));
                     }

@@ -23,6 +23,8 @@ def check(name, prob, scen, orders):
               f"(unscheduled {ref.unscheduled.tolist()[:6]}, differing placements {int((res.placement != ref.placement).sum())})", flush=True)
 check("c5svc small", *synth.config5(n_pods=1500, n_nodes=300, n_scen=4, n_orders=2, n_groups=10, group_size=20, services=True))
 check("c5svc mid", *synth.config5(n_pods=8000, n_nodes=1200, n_scen=8, n_orders=2, n_groups=20, group_size=40, services=True))
+os.environ["SIMON_NO_GPU_FOLD"] = "1"; os.environ["SIMON_NO_FOLD"] = "1"
+check("200 services, 10 anti, 20 gpu", *synth.config_service(n_counts=4, n_pods=5000, n_services=200, n_anti=10, n_gpu=20))
 for seed, feat in enumerate([dict(gpu=True), dict(anti_host=True), dict(gpu=True, anti_host=True, nz_differs=True), dict(gpu=True, presets=True, gates=True), dict(anti=True, tight_pods=True), dict(gpu=True, eph=True, scalars=2)]):
     prob = randprob.rand_problem(7300 + seed, N=[200, 500, 900, 300, 700, 400][seed], P=600, spread_soft=True, n_node_classes=4, n_pod_classes=[3, 30, 60, 8, 20, 5][seed], **feat)
     scen, orders = randprob.rand_scenarios(seed, prob, S=4)
