@@ -307,7 +307,7 @@ def test_bench_line_is_self_verifying():
     assert e2e["batch_ms"] > e2e["kernel_ms"] > 0 and e2e["load_problem_ms"] > 0 and e2e["scenarios"] == d["config"]["scenarios_per_gpu"]
     names = [w["workload"] for w in d["other_workloads"]]
     assert names == ["config2", "config3_sigs200", "config3_service", "config3_service_anti20", "config3_service_pref60", "config5_S16", "config5_S2048",
-                     "config3_service_S64", "config3_service_gpu20_S256", "config5_service_S16", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160", "config3_S64"]
+                     "config3_service_S64", "config3_service_gpu20_S256", "config3_service_shapes30_S256", "config5_service_S16", "config5_asdrawn_service_S16", "typical_cluster_x64", "wide_mix_x64", "config3_sigs300", "config3_classes80", "config3_classes160", "config3_S64"]
     for w in d["other_workloads"]:
         assert "error" not in w, w
         assert w["parity_sample"]["mismatches"] == 0 and w["value"] > 0
@@ -317,21 +317,24 @@ def test_bench_line_is_self_verifying():
             assert w["roofline"]["kernel_ms"] > 0 and w["roofline"]["kernel"] in ("simon::fast_kernel", "simon::narrow_kernel", "simon::wide_kernel")
             continue
         assert w["roofline"]["kernel_ms"] > 0 and w["roofline"]["kernel"] == ("simon::wide_kernel" if w["workload"] == "wide_mix_x64" else "simon::table_kernel")
+    by = {w["workload"]: w for w in d["other_workloads"]}
     # the cliffs as numbers: 80 node shapes stay on the score table (two classes per lane), 160 leave it
-    assert d["other_workloads"][13]["kernel_generation"] in (4, 5)
-    assert d["other_workloads"][14]["kernel_generation"] not in (4, 5, 6, 7)
-    assert d["other_workloads"][8]["kernel_generation"] == 7         # a gpushare cluster behind Services: GPU share folded into the table
-    assert d["other_workloads"][9]["kernel_generation"] == 7 and d["other_workloads"][9]["pods"] == 50000   # config 5's shape behind Services
+    assert by["config3_classes80"]["kernel_generation"] in (4, 5)
+    assert by["config3_classes160"]["kernel_generation"] not in (4, 5, 6, 7)
+    assert by["config3_service_gpu20_S256"]["kernel_generation"] == 7         # a gpushare cluster behind Services: GPU share folded into the table
+    assert by["config3_service_shapes30_S256"]["kernel_generation"] == 7      # 30 node shapes x 3 zones: two node classes per lane in the walks (round 6)
+    assert by["config5_service_S16"]["kernel_generation"] == 7 and by["config5_service_S16"]["pods"] == 50000   # config 5's shape behind Services
+    assert by["config5_asdrawn_service_S16"]["kernel_generation"] == 7 and by["config5_asdrawn_service_S16"]["pods"] == 50000   # ... and as drawn: the walks over the mask rows (round 6)
     # the `simon apply` shapes: 64 candidate scenarios run generation 7 in team mode, with the one-wave time of the same batch beside it
-    for w in (d["other_workloads"][7], d["other_workloads"][10]):
+    for w in (by["config3_service_S64"], by["typical_cluster_x64"]):
         assert w["kernel_generation"] == 7 and w["workgroup"] == 256 and w["team"]["waves_per_scenario"] == 4 and w["team"]["one_wave_kernel_ms"] > 0
-    assert d["other_workloads"][11]["kernel"].startswith("wide") and d["other_workloads"][11]["scenarios"] == 64
-    assert d["other_workloads"][1]["kernel_generation"] == 5 and d["other_workloads"][1]["scenarios"] == 4096
-    assert d["other_workloads"][2]["kernel_generation"] == 7 and d["other_workloads"][2]["scenarios"] == 4096
-    assert d["other_workloads"][3]["kernel_generation"] == 7 and d["other_workloads"][3]["scenarios"] == 4096
-    assert d["other_workloads"][4]["kernel_generation"] == 7 and d["other_workloads"][4]["scenarios"] == 4096
-    assert d["other_workloads"][5]["kernel_generation"] == 6 and d["other_workloads"][6]["scenarios"] == 2048
-    assert d["other_workloads"][15]["kernel_generation"] in (4, 5) and d["other_workloads"][15]["scenarios"] == 64      # BASELINE config 3's pool at the batch a `simon apply` offers
+    assert by["wide_mix_x64"]["kernel"].startswith("wide") and by["wide_mix_x64"]["scenarios"] == 64
+    assert by["config3_sigs200"]["kernel_generation"] == 5 and by["config3_sigs200"]["scenarios"] == 4096
+    assert by["config3_service"]["kernel_generation"] == 7 and by["config3_service"]["scenarios"] == 4096
+    assert by["config3_service_anti20"]["kernel_generation"] == 7 and by["config3_service_anti20"]["scenarios"] == 4096
+    assert by["config3_service_pref60"]["kernel_generation"] == 7 and by["config3_service_pref60"]["scenarios"] == 4096
+    assert by["config5_S16"]["kernel_generation"] == 6 and by["config5_S2048"]["scenarios"] == 2048
+    assert by["config3_S64"]["kernel_generation"] in (4, 5) and by["config3_S64"]["scenarios"] == 64      # BASELINE config 3's pool at the batch a `simon apply` offers
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     for w in d["other_workloads"]:
         assert w["steps"] >= 5, w["workload"]                     # every sub-record times at least five steps

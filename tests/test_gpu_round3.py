@@ -252,7 +252,10 @@ def test_soft_spread_constraints_with_required_hostname_anti_affinity(feat):
             assert ctx.stats().kernel_generation == 7
             assert_same(ctx.fetch(True), O.run(prob, scen, orders, node_ranks=ranks))
         on7 += 1
-    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_FOLD": "1"})          # without the fold: the all-feature kernel
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_FOLD": "1"})          # without the fold: the walks over the position-mask rows (round 6) ...
+    assert variant == capi.KERNEL_NARROW_CACHE
+    assert_same(res, ref)
+    res, variant = run_gpu(prob, scen, orders, env={"SIMON_NO_FOLD": "1", "SIMON_NO_RS": "1"})   # ... and without those: the all-feature kernel
     assert variant == capi.KERNEL_WIDE
     assert_same(res, ref)
 

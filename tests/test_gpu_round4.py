@@ -581,9 +581,18 @@ def test_gpu_share_folded_into_the_score_table(idx, spread, monkeypatch):
         ctx.load_problem(prob)
         res = ctx.run_batch(scen, orders, want_gpu_slices=True)
         st = ctx.stats()
-    assert (st.kernel_variant == capi.KERNEL_WIDE) if spread else (st.kernel_generation == 6)   # (terms next to GPU share: position masks take both)
+    # (terms next to GPU share: position masks take both; behind a Service: generation 7's walks over those rows since round 6)
+    assert (st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 7) if spread else (st.kernel_generation == 6)
     assert_same(res, ref)
     assert (res.gpu_slices == ref.gpu_slices).all()
+    if spread:
+        monkeypatch.setenv("SIMON_NO_RS", "1")
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            res = ctx.run_batch(scen, orders, want_gpu_slices=True)
+            assert ctx.stats().kernel_variant == capi.KERNEL_WIDE
+        assert_same(res, ref)
+        assert (res.gpu_slices == ref.gpu_slices).all()
 
 
 def test_gpushare_example_behind_a_service_stays_on_the_score_table():
