@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
     static_assert(!SPREAD || COARSE, "SPREAD is built on the two-level layout");
     constexpr bool RS = REST && SPREAD;                               // generation 7's walks over generation 6's position-mask rows (round 6)
-    static_assert(!RS || (NW == 1 && !AFF && !MANY && !LDSX && !CN2), "REST && SPREAD: one wave, no required affinity / preferred / hard terms, <= 64 classes");
+    static_assert(!RS || (!AFF && !MANY && !LDSX && !CN2), "REST && SPREAD: no required affinity / preferred / hard terms, <= 64 classes, <= 128 signatures");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
     static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
@@ -621,7 +621,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if (lane == 0) {
                     s_sum[k * nbp + (p0 >> 6)] = (unsigned short)c64;
                     if (nfe) {
-                        if constexpr (CNT_LDS) s_cnt[k * Cn + d] += nfe;   // (REST: one wave, lane 0 alone)
+                        if constexpr (CNT_LDS && NW == 1) s_cnt[k * Cn + d] += nfe;   // (REST: one wave, lane 0 alone)
+                        else if constexpr (CNT_LDS) atomicAdd(&s_cnt[k * Cn + d], nfe);   // (REST && SPREAD in team mode: chunks of one class on several waves)
                         else if constexpr (NW == 1) g_cnt[k * Cn + d] += nfe;   // lane 0 alone, chunk after chunk: plain (see the refresh)
                         else atomicAdd(&g_cnt[k * Cn + d], nfe);           // chunks of one class on several waves (L1 is invalidated below)
                     }
@@ -1278,6 +1279,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
             }
         }
+        if constexpr (RS && NW > 1) {
+            if (filt) {                                                   // the team's counts: every wave's share through the (still unused) score table
+                s_tab[wv * 64 + lane] = cntd_f;
+                __syncthreads();
+                cntd_f = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) cntd_f += s_tab[w * 64 + lane];
+                __syncthreads();
+            }
+        }
         const int cntd = filt ? cntd_f : (lane < Cn ? (CNT_LDS ? s_cnt : g_cnt)[k * Cn + dd] : 0);   // feasible nodes of class d for signature k
         unsigned czv[4];
 #pragma unroll
@@ -1871,7 +1882,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
         if constexpr (NW > 1) {
             if (spread_pod) {                                          // every wave of the team
-                pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
+                if constexpr (RS) pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res, r_nrows, rowv, r_gs, r_xs);
+                else pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
                 TPROF(18);                                             // spread: winner
                 if (pstar < 0) { ++unsched; res = -1; }
             }
@@ -2237,13 +2249,17 @@ static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipS
 constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
 #define SIMON_TEAM_CAT2(a, b) a##b
 #define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
-template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false>
+template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false, bool REST = false>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if constexpr (!CN2) {                                             // 65 .. 128 node classes: two per lane in the walks
+    if constexpr (!AFF && !CN2 && !REST) {                            // the walks over the position-mask rows (REST && SPREAD): soft constraints only, <= 64 classes
+        if (a.rest) return (a.aff || a.sc.Cn > 64) ? hipErrorInvalidValue : launch_team6<M, Z, KQ, NBQ, RANKED, false, false, true>(a, n_blocks, lds, st);
+    }
+    if (a.rest && !REST) return hipErrorInvalidValue;
+    if constexpr (!CN2 && !REST) {                                    // 65 .. 128 node classes: two per lane in the walks
         if (a.sc.Cn > 64) return launch_team6<M, Z, KQ, NBQ, RANKED, AFF, true>(a, n_blocks, lds, st);
     }
     if (a.sc.K > 64 * KQ || (!CN2 && a.sc.Cn > 64)) return hipErrorInvalidValue;
-    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, false, RANKED, AFF, false, true, kTuWaves, false, false, CN2>;
+    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, REST, RANKED, AFF, false, true, kTuWaves, false, false, CN2>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * kTuWaves), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2262,7 +2278,7 @@ static hipError_t launch_team2(const TableLaunch& a, int n_blocks, size_t lds, h
     return one ? launch_team4<M, Z, 1, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 1, 2>(a, n_blocks, lds, st);
 }
 hipError_t SIMON_TEAM_CAT(launch_table_team, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.coarse || a.rest || a.team != kTuWaves) return hipErrorInvalidValue;
+    if (!a.spread || !a.coarse || a.team != kTuWaves) return hipErrorInvalidValue;
     (void)has_mask;                                                   // (a run-time test of the prologue: TableCold::static_mask is null without one)
     return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
 }
