@@ -739,7 +739,7 @@ void choose_variant(simon_ctx* c) {
             const bool ok = spread_supported(c);
             c->rs_probe = false;
             if (c->debug_route) fprintf(stderr, "[route] walks over the mask rows: probe %d ipa %d hard %d soft %d\n", (int)ok, (int)c->ipa_fold, (int)c->hard_fold, (int)!c->ss_idx.empty());
-            if (!ok || c->ipa_fold || c->hard_fold || c->ss_idx.empty()) return;
+            if (!ok) return;
             c->rs = true;
             c->fold = false; c->gfold = false;
         }
@@ -770,7 +770,7 @@ void choose_variant(simon_ctx* c) {
     if (c->gfold && !c->spread && c->gfold_sigs > 128 && c->gfold_base_sigs <= 128 && rest_supported(c)) { c->gfold = false; c->fold = false; }
     // the GPU fold serves problems that need no other per-node filter row: plain cpu+memory+GPU, and generation 7's (Services next to GPU pods)
     if (c->gfold && ((!c->spread && !c->fold && c->Tm > 0) || c->xres)) { c->gfold = false; if (c->has_gpu) c->fold = false; }
-    if (c->spread && !c->rs && !c->no_rs && !c->no_rest && c->xres && !c->ipa_fold && !c->hard_fold && !c->ss_idx.empty() && c->aff_idx.empty()) {
+    if (c->spread && !c->rs && !c->no_rs && !c->no_rest && c->xres && c->aff_idx.empty()) {
         c->rs = true; c->fold = false; c->gfold = false;            // extra-resource rows under the walks: the same instantiation
     }
     const bool wants_rest = (!c->spread || c->rs) && !c->fold && ((c->has_gpu && !c->gfold) || c->Tm > 0 || c->xres);
@@ -1924,8 +1924,9 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= ((c->table_coarse || lds_ws) ? kTableLdsMaxWG : (size_t)64 * 1024);
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         if (c->debug_route)
-            fprintf(stderr, "[route] variant %d rest %d spread %d fold %d gfold %d table_ok %d perm_ok %d coarse %d n_sigs %d Cn_t %d ni_top %d lds %zu max_n %d\n", c->variant, (int)c->rest,
-                    (int)c->spread, (int)c->fold, (int)c->gfold, (int)c->table_ok, (int)c->table_perm_ok, (int)c->table_coarse, c->n_sigs, c->Cn_t, ni_top, table_lds, c->max_n);
+            fprintf(stderr, "[route] variant %d rest %d spread %d fold %d gfold %d table_ok %d perm_ok %d coarse %d n_sigs %d Cn_t %d ni_top %d lds %zu max_n %d M %d NZ %d TH %d TZ %d\n", c->variant, (int)c->rest,
+                    (int)c->spread, (int)c->fold, (int)c->gfold, (int)c->table_ok, (int)c->table_perm_ok, (int)c->table_coarse, c->n_sigs, c->Cn_t, ni_top, table_lds, c->max_n,
+                    c->rest_M, (int)c->zone_keys.size(), c->sp_TH, c->sp_TZ);
         const bool needs_table_or_wide = c->has_pin || too_big || c->rest || c->spread || c->fold || c->gfold || !c->raw_fits_lds || c->has_ranks || c->has_static;
         // Beyond 256 signatures generation 2 (register-resident state, every node re-evaluated per cycle: its time does not depend on
         // the signature count) overtakes the score table (measured, profiles/r03: 300 signatures 124 ms against 119 ms, 384: 169 ms) --
@@ -1936,6 +1937,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             // falls through to the all-feature kernel below
         } else if (use_table) {
             HIP_TRY(c, c->d_ws.ensure(c->ws_total));
+            if (const char* fill = getenv("SIMON_WS_FILL"))          // debugging aid: the workspace starts from a byte pattern (a read of something the prologue never wrote shows)
+                HIP_TRY(c, hipMemsetAsync(c->d_ws.p, atoi(fill), c->ws_total, c->stream));
             if (want_placement) HIP_TRY(c, c->d_place_step.ensure((size_t)S * P));
             TableCold cold{};
             cold.ncls = c->d_t_ncls.p; cold.rank = c->d_rank.p; cold.cls_off = c->d_cls_off.p;

@@ -401,7 +401,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
     static_assert(!SPREAD || COARSE, "SPREAD is built on the two-level layout");
     constexpr bool RS = REST && SPREAD;                               // generation 7's walks over generation 6's position-mask rows (round 6)
-    static_assert(!RS || (!AFF && !MANY && !LDSX && !CN2), "REST && SPREAD: no required affinity / preferred / hard terms, <= 64 classes, <= 128 signatures");
+    // (AFF names two things: required-affinity entries to the REST half, preferred / hard terms in the walk to the SPREAD half.  REST && SPREAD
+    // && AFF is launched for the latter -- spread_supported keeps required affinity out -- and carries the former's code unused.)
+    static_assert(!RS || (!MANY && !LDSX && !CN2), "REST && SPREAD: <= 64 classes, <= 128 signatures");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
     static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
@@ -571,7 +573,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const int j = real ? cls_list[rk_off + (unsigned)(cls_off[d] + r)] : 0;   // r-th node of class d in canonical order
         const NodeState st = real ? NodeState{i_rq_cpu[j], i_rq_mem[j], (unsigned)(a_pods[j] - i_npods[j])} : NodeState{0, 0, 0};
         if constexpr (SPREAD && RANKED) {                                 // spread_select breaks its ties by rank: one coalesced read per unit
-            if (p < ni) g_canon[p] = (unsigned short)(real ? gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + j] : 8191);
+            // (no term with a counter row -- preferred terms whose weights cancel --: the workspace holds no SPREAD block, table_ws_of, and no pod walks)
+            if (p < ni && (TH | TZ) != 0) g_canon[p] = (unsigned short)(real ? gp(cold->rk_rank)[(size_t)s * (size_t)cold->N + j] : 8191);
         }
         uint2 z = make_uint2(0, 0);
         if (!NZEQ && real) z = make_uint2(i_nz_cpu[j], i_nz_mem[j]);
@@ -2251,8 +2254,8 @@ constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
 #define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
 template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false, bool REST = false>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    if constexpr (!AFF && !CN2 && !REST) {                            // the walks over the position-mask rows (REST && SPREAD): soft constraints only, <= 64 classes
-        if (a.rest) return (a.aff || a.sc.Cn > 64) ? hipErrorInvalidValue : launch_team6<M, Z, KQ, NBQ, RANKED, false, false, true>(a, n_blocks, lds, st);
+    if constexpr (!CN2 && !REST) {                                    // the walks over the position-mask rows (REST && SPREAD): <= 64 classes
+        if (a.rest) return (a.aff || a.sc.Cn > 64) ? hipErrorInvalidValue : launch_team6<M, Z, KQ, NBQ, RANKED, AFF, false, true>(a, n_blocks, lds, st);
     }
     if (a.rest && !REST) return hipErrorInvalidValue;
     if constexpr (!CN2 && !REST) {                                    // 65 .. 128 node classes: two per lane in the walks
@@ -2401,14 +2404,17 @@ hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, 
 }
 #elif defined(SIMON_TABLE_RS_TU)
 // ---- this translation unit (simon_table_rs.hip) holds generation 7's walks over generation 6's position-mask rows (REST && SPREAD): one wave per
-// scenario, <= 64 node classes, <= 128 signatures, soft constraints only ----
-template <bool Z, int KQ, int NBQ, bool RANKED = false>
+// scenario, <= 64 node classes, <= 128 signatures ----
+template <bool Z, int KQ, int NBQ, bool RANKED = false, bool AFF = false>
 static hipError_t launch_rs3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (!RANKED) {
-        if (a.sc.rk_stride != 0) return launch_rs3<Z, KQ, NBQ, true>(a, n_blocks, lds, st);
+        if (a.sc.rk_stride != 0) return launch_rs3<Z, KQ, NBQ, true, AFF>(a, n_blocks, lds, st);
+    }
+    if constexpr (!AFF) {                                             // (& 64: preferred pod (anti-)affinity / hard zone constraints in the walk)
+        if (a.sc.static_tables & 64) return launch_rs3<Z, KQ, NBQ, RANKED, true>(a, n_blocks, lds, st);
     }
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
-    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, RANKED, false, false, true>;
+    auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, RANKED, AFF, false, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2419,7 +2425,7 @@ static hipError_t launch_rs2(const TableLaunch& a, int n_blocks, size_t lds, hip
     return a.sc.ni_max / 64 <= 64 ? launch_rs3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st);
 }
 hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.rest || !a.coarse || a.aff || a.team > 1 || a.lds_x || a.sc.Cn > 64 || a.sc.K > 128 || (a.sc.static_tables & (32 | 64 | 128))) return hipErrorInvalidValue;
+    if (!a.spread || !a.rest || !a.coarse || a.aff || a.team > 1 || a.lds_x || a.sc.Cn > 64 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
     if (a.sc.K > 64) return nzeq ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rs2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
 }

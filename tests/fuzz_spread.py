@@ -26,8 +26,6 @@ def one_case(case):
         feat.pop("static_mask", None)
     mask_rows = case >= 700000                          # cases from 700 000 on: GPU share / required anti-affinity / ports / extra resources that do NOT fold into
     if mask_rows:                                       # the table, next to the soft constraints: the walks over the position-mask rows (REST && SPREAD)
-        for f in ("ipa_self", "ipa", "hard_simple"):
-            feat.pop(f, None)
         for f, pr in (("gpu", 0.6), ("anti_host", 0.4), ("anti", 0.3), ("ports", 0.25), ("eph", 0.2)):
             if rng.random() < pr:
                 feat[f] = True

@@ -311,3 +311,15 @@ def test_soft_spread_constraints_over_the_position_mask_rows():
         assert r2.unscheduled.tolist() == ref2.unscheduled.tolist() and (r2.placement == ref2.placement).all()
         assert r2.used_cpu.tolist() == ref2.used_cpu.tolist() and r2.used_mem.tolist() == ref2.used_mem.tolist()
     assert on7 >= 5
+
+
+def test_ranked_generation_7_without_counter_rows_stays_inside_its_workspace_slice(monkeypatch):
+    """Found by fuzz_spread.py case 702439 (round 6): per-scenario node ranks + preferred terms whose weights cancel -- no term keeps a counter row,
+    so the scenario's workspace slice has no SPREAD block, and the prologue wrote the per-position ranks behind the slice: into the NEXT scenario's
+    byte table (wrong placements that depended on what ran before).  The workspace starts from a byte pattern here so that a stray read or write
+    shows whatever ran before."""
+    import fuzz_spread
+    monkeypatch.setenv("SIMON_WS_FILL", "170")
+    for case in (702439, 702439):
+        ok, info = fuzz_spread.one_case(case)
+        assert ok, info
