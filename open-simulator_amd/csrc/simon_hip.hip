@@ -246,6 +246,7 @@ bool rest_supported(simon_ctx* c) {
         for (int cp = 0; cp < c->Cp; ++cp) {
             for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) if (c->anti_idx[e] >= 0 && c->anti_idx[e] < c->Tm) row_read[c->anti_idx[e]] = 1;
             for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) if (c->port_idx[e] >= 0 && c->port_idx[e] < c->Tm) row_read[c->port_idx[e]] = 1;
+            for (int e = c->aff_off.empty() ? 0 : c->aff_off[cp]; !c->aff_off.empty() && e < c->aff_off[cp + 1]; ++e) if (c->aff_idx[e] >= 0 && c->aff_idx[e] < c->Tm) row_read[c->aff_idx[e]] = 1;
         }
     if (c->rs) {                                                          // (... and only those get rows: stage_narrow)
         int n_read = 0;
@@ -406,7 +407,7 @@ bool spread_supported(simon_ctx* c) {
     if (c->no_spread || (c->ss_idx.empty() && !c->has_ipa_score && c->sh_idx.empty())) return false;
     if (!c->sh_idx.empty() && c->no_hard_fold) return false;
     if (c->has_ipa_score && c->no_ipa_fold) return false;
-    if (c->has_local || !c->aff_idx.empty()) return false;
+    if (c->has_local || (!c->aff_idx.empty() && !c->rs_probe)) return false;   // (required affinity: rows that must be SET -- the mask rows, rs_probe)
     if ((!c->anti_idx.empty() || !c->port_idx.empty()) && !c->fold && !c->rs_probe) return false;   // required anti-affinity / ports: folded into the table, or (rs_probe) on the mask rows
     if (c->has_gpu_index || (c->has_gpu && !c->gfold && !c->rs_probe)) return false;      // (GPU share: folded into the table, gfold_supported -- or on the mask rows)
     if (c->topo_is_hostname.empty()) return false;
@@ -961,6 +962,7 @@ int stage_narrow(simon_ctx* c) {
                 for (int cp = 0; cp < c->Cp; ++cp) {
                     for (int e = c->anti_off.empty() ? 0 : c->anti_off[cp]; !c->anti_off.empty() && e < c->anti_off[cp + 1]; ++e) row_read[c->anti_idx[e]] = 1;
                     for (int e = c->port_off.empty() ? 0 : c->port_off[cp]; !c->port_off.empty() && e < c->port_off[cp + 1]; ++e) row_read[c->port_idx[e]] = 1;
+                    for (int e = c->aff_off.empty() ? 0 : c->aff_off[cp]; !c->aff_off.empty() && e < c->aff_off[cp + 1]; ++e) row_read[c->aff_idx[e]] = 1;
                 }
             std::vector<int> tm(std::max(c->Tm, 1), 0);
             int n_rows_t = 0;

@@ -1166,10 +1166,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // (REST && SPREAD: f_* = the pod's REST descriptor -- GPU request row, extra-resource row, filter entries in the lanes of f_rowv; a pod that
     // carries any walks under them: a position a row excludes counts as infeasible -- in the sizes, the extremes and the totals)
     auto spread_select = [&](int k, int tc, int soft_n, int match_n, int ipa_n, int hard_n, int spv, int spt, int& dstar, int& res,
-                             int f_nrows = 0, int f_rowv = 0, int f_gs = -1, int f_xs = -1) -> int {
+                             int f_nrows = 0, int f_rowv = 0, int f_gs = -1, int f_xs = -1, bool f_esc = false) -> int {
         // team mode: everything the leader stored in the cycles since the last spread pod -- table bytes, counters, class terms -- is
         // complete (the barrier's release waits for vmcnt / lgkmcnt) before a helper reads it; wave w walks units [ulo, uhi)
         if constexpr (NW > 1) __syncthreads();
+        if constexpr (RS && AFF && NW > 1) {
+            // a helper read the totals of its required-affinity rows when it reached this pod -- ahead of the leader's assumes: again, behind the barrier
+            const unsigned rt2 = (lane < f_nrows && ((unsigned)f_rowv >> 31)) ? g_rowtot[(unsigned)f_rowv & 0xFFFFu] : 0u;
+            f_esc = aff_escape(f_nrows, f_rowv, rt2);
+        }
         int ulo = 0, uhi = nun;
         if constexpr (NW > 1) {
             const int per = (nun + NW - 1) / NW;
@@ -1254,7 +1259,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             for (int e = 0; e < f_nrows; ++e) {
                 const unsigned ent = (unsigned)__builtin_amdgcn_readlane(f_rowv, e);
                 const uint2 v = fxw[(ent & 0xFFFFu) * (unsigned)nun + (unsigned)u];
-                b.x |= v.x; b.y |= v.y;
+                if (AFF && (ent >> 31)) { if (!f_esc) { b.x |= ~v.x; b.y |= ~v.y; } }   // required affinity: the row must be SET, unless the first-pod escape holds (excluded)
+                else { b.x |= v.x; b.y |= v.y; }
             }
             return ((unsigned long long)b.y << 32) | b.x;
         };
@@ -1840,7 +1846,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 if (lane == (k & 63)) my_dirty &= ~(1u << (k >> 6));
             }
             if constexpr (NW == 1) {                                   // (one wave: the select sits where it always sat -- the team's call site is below)
-                if constexpr (RS) pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res, r_nrows, rowv, r_gs, r_xs);
+                if constexpr (RS) pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv));
                 else pstar = spread_select(k, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
                 TPROF(18);                                             // spread: winner
                 if (pstar < 0) { ++unsched; res = -1; }
@@ -1885,7 +1891,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
         if constexpr (NW > 1) {
             if (spread_pod) {                                          // every wave of the team
-                if constexpr (RS) pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res, r_nrows, rowv, r_gs, r_xs);
+                if constexpr (RS) pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res, r_nrows, rowv, r_gs, r_xs, aff_escape(r_nrows, rowv, rtv));
                 else pstar = spread_select(r_sig, r_cls, sp_soft, sp_match, sp_ipa, sp_hard, spv, spt, dstar, res);
                 TPROF(18);                                             // spread: winner
                 if (pstar < 0) { ++unsched; res = -1; }
@@ -2255,7 +2261,11 @@ constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
 template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false, bool REST = false>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (!CN2 && !REST) {                                    // the walks over the position-mask rows (REST && SPREAD): <= 64 classes
-        if (a.rest) return (a.aff || a.sc.Cn > 64) ? hipErrorInvalidValue : launch_team6<M, Z, KQ, NBQ, RANKED, AFF, false, true>(a, n_blocks, lds, st);
+        if (a.rest) {
+            if (a.sc.Cn > 64) return hipErrorInvalidValue;
+            if constexpr (!AFF) { if (a.aff) return launch_team6<M, Z, KQ, NBQ, RANKED, true, false, true>(a, n_blocks, lds, st); }
+            return launch_team6<M, Z, KQ, NBQ, RANKED, AFF, false, true>(a, n_blocks, lds, st);
+        }
     }
     if (a.rest && !REST) return hipErrorInvalidValue;
     if constexpr (!CN2 && !REST) {                                    // 65 .. 128 node classes: two per lane in the walks
@@ -2410,8 +2420,8 @@ static hipError_t launch_rs3(const TableLaunch& a, int n_blocks, size_t lds, hip
     if constexpr (!RANKED) {
         if (a.sc.rk_stride != 0) return launch_rs3<Z, KQ, NBQ, true, AFF>(a, n_blocks, lds, st);
     }
-    if constexpr (!AFF) {                                             // (& 64: preferred pod (anti-)affinity / hard zone constraints in the walk)
-        if (a.sc.static_tables & 64) return launch_rs3<Z, KQ, NBQ, RANKED, true>(a, n_blocks, lds, st);
+    if constexpr (!AFF) {                                             // (& 64: preferred pod (anti-)affinity / hard zone constraints in the walk; a.aff: required-affinity entries)
+        if ((a.sc.static_tables & 64) || a.aff) return launch_rs3<Z, KQ, NBQ, RANKED, true>(a, n_blocks, lds, st);
     }
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
     auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, RANKED, AFF, false, true>;
@@ -2425,7 +2435,7 @@ static hipError_t launch_rs2(const TableLaunch& a, int n_blocks, size_t lds, hip
     return a.sc.ni_max / 64 <= 64 ? launch_rs3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st);
 }
 hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.rest || !a.coarse || a.aff || a.team > 1 || a.lds_x || a.sc.Cn > 64 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
+    if (!a.spread || !a.rest || !a.coarse || a.team > 1 || a.lds_x || a.sc.Cn > 64 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
     if (a.sc.K > 64) return nzeq ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rs2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
 }

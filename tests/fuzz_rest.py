@@ -42,8 +42,7 @@ def one_case(case):
     if size >= 2:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
     if case >= 800000:                    # cases from 800 000 on: the same filters next to soft PodTopologySpread constraints -- generation 7's walks over
-        feat["spread_soft"] = True        # these mask rows (REST && SPREAD, simon_table_rs.hip); required affinity stays out of that instantiation
-        feat.pop("aff", None)
+        feat["spread_soft"] = True        # these mask rows (REST && SPREAD, simon_table_rs.hip), required affinity included
     n_node_classes = int(rng.choice([70, 90, 110] if 500000 <= case < 800000 else [1, 2, 4, 9, 20, 40]))   # cases from 500 000 on: 65 .. 128 internal node classes (CN2 in rest_select)
     n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 120]))
     prob = randprob.rand_problem(62000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
@@ -84,15 +83,16 @@ def one_case(case):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, on_rest, on_walks = 0, 0, 0
+    bad, on_rest, on_walks, aff_walks = 0, 0, 0, 0
     for case in range(first, first + n_cases):
         ok, info = one_case(case)
         on_rest += info["generation"] == 6
         on_walks += info["generation"] == 7
+        aff_walks += info["generation"] == 7 and "aff" in info["feat"]
         if not ok:
             bad += 1
             print("MISMATCH", info, flush=True)
-    print(f"fuzz_rest: {n_cases} cases from {first}, {on_rest} on generation 6, {on_walks} on generation 7, mismatches {bad}")
+    print(f"fuzz_rest: {n_cases} cases from {first}, {on_rest} on generation 6, {on_walks} on generation 7 ({aff_walks} of them with required affinity), mismatches {bad}")
     return 1 if bad else 0
 
 

@@ -33,6 +33,8 @@ def one_case(case):
             feat["scalars"] = int(rng.integers(1, 4))
         if "anti" in feat:
             feat.pop("anti_host", None)
+            if rng.random() < 0.4:
+                feat["aff"] = True                      # required affinity beside the anti-affinity terms (rows that must be SET, first-pod escape)
     many_classes = 600000 <= case < 700000                       # cases from 600 000 on: 65 .. 128 internal node classes (node shapes x zones; simon_table.hip: CN2)
     prob = randprob.rand_problem(99000 + case, N=N, P=P, spread_soft=(case % 7 != 6 or "ipa_self" not in feat), n_node_classes=int(rng.choice([14, 18, 22, 25] if many_classes else [1, 2, 4, 9])),
                                  n_pod_classes=int(rng.choice([130, 200, 300, 384, 600, 1000] if 300000 <= case < 600000 else [1, 3, 8, 30, 60])), **feat)   # cases from 300 000 on: 129 ... 384 signatures (MANY && SPREAD)
