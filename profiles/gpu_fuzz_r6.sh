@@ -12,5 +12,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
   timeout 900 python tests/fuzz_spread.py 200 660000 2>&1 | tail -2
   timeout 900 python tests/fuzz_rest.py ${FR2_N:-400} 510000 2>&1 | tail -2          # 70 .. 110 node classes: two per lane in the REST select (CN2)
   timeout 900 python tests/fuzz_spread.py ${FS2_N:-400} 610000 2>&1 | tail -2        # 65 .. 128 internal classes under the spread walks (CN2)
+  timeout 1200 python tests/fuzz_spread.py ${FS3_N:-600} 710000 2>&1 | tail -2       # soft constraints next to filters that do not fold: the walks over the mask rows (REST && SPREAD), both shapes
+  timeout 900 python tests/fuzz_rest.py ${FR3_N:-500} 810000 2>&1 | tail -2          # ... drawn from the REST side (required affinity included)
 } | grep -v amdgpu.ids > "$OUT/fuzzers_at_scale.txt"
 cat "$OUT/fuzzers_at_scale.txt"
