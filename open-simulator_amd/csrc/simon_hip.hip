@@ -1149,7 +1149,7 @@ int stage_narrow(simon_ctx* c) {
             ncls_t[j] = it->second;
         }
         if (c->table_ok && c->spread && (int)shapes.size() > kTableMaxClasses && sigs.size() > 128) c->table_ok = false;   // (CN2 serves <= 128 signatures)
-        if (c->table_ok && c->rs && sigs.size() > 128) c->table_ok = false;                                                 // (... and so do the walks over the mask rows)
+        if (c->table_ok && c->rest && (int)shapes.size() > kTableMaxClasses && sigs.size() > 128) c->table_ok = false;        // (... and so does the second class per lane of the REST select)
         if (c->table_ok) {
             const int Ct = (int)shapes.size();
             c->n_sigs = (int)sigs.size(); c->Cn_t = Ct;
@@ -1797,7 +1797,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             // more than 128 signatures: two-level layout without the REST path (simon_table.hip: MANY; since round 4 also under generation 7's
             // walks); else generation 2 / all-feature kernel
-            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || (coarse && !c->rest)) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || coarse);
+            c->table_perm_ok = (!c->rest || coarse) && (c->n_sigs <= 128 || coarse) && (!c->spread || coarse) && (!c->fold || coarse) && (!c->gfold || coarse);
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1918,7 +1918,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         }
         // Generation 6 with its mask rows, row totals and canonical indices in LDS (round 5; simon_table.hip: LDSX), under the same rule
         bool lds_x = false;
-        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1 && c->Cn_t <= kTableMaxClasses) {   // (65 .. 128 node classes: the rows stay in HBM, simon_table_rest2.hip)
+        if (c->table_ok && c->table_coarse && c->rest && !c->spread && team == 1 && c->Cn_t <= kTableMaxClasses && c->n_sigs <= 128) {   // (65 .. 128 node classes: the rows stay in HBM, simon_table_rest2.hip)
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + table_ldsx_bytes(ni_top, c->rest_M) + c->lds_pad;
             if (lds_home(need)) { lds_x = true; table_lds = need; }
         }

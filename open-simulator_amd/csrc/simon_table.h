@@ -141,7 +141,7 @@ hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size
 hipError_t launch_table_rest2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);   // ... for 65 .. 128 node classes (simon_table_rest2.hip)
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)
 hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);
-// generation 7 over the position-mask rows of generation 6 (REST && SPREAD: simon_table_rs.hip; one wave per scenario, <= 64 node classes, <= 128 signatures)
+// generation 7 over the position-mask rows of generation 6 (REST && SPREAD: simon_table_rs.hip; <= 64 node classes)
 hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
 hipError_t launch_table_spread2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);   // ... for 65 .. 128 node classes (simon_table_spread2.hip)
 // placement[s][pod] = place_step[s][inverse order of s][pod]: the kernel records placements by scheduling STEP (coalesced)

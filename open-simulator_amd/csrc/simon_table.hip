@@ -194,7 +194,7 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.sn = o; o += al(K * Cn * 2);
     // (REST, round 6: the feasible-node counters stay in LDS on the two-level layout as well.  On a gpushare cluster that fills up -- config
     // 5 -- some (signature, node) byte drops to 0 on almost every cycle, and the counter's read-modify-write in the HBM workspace was a
-    // dependent memory round trip inside the refresh; generation 6 holds <= 128 signatures x <= 64 classes, config 5: 84 x 8 = 2.7 KB.)
+    // dependent memory round trip inside the refresh; config 5: 84 signatures x 8 classes = 2.7 KB; with hundreds of signatures the host's LDS bound decides.)
 #ifdef SIMON_REST_CNT_HBM
     (void)rest;
     c.cnt = o; o += coarse ? 0 : al(K * Cn * 4);
@@ -327,7 +327,7 @@ constexpr int kSpreadBatch1 = SIMON_SPREAD_BATCH1, kSpreadBatch2 = SIMON_SPREAD_
 // preset pods, the 64-step placement flush): as a run-time flag it cost config 5 4 % (same-box A/B, profiles/README.md).
 // AFF: some pod class carries required-affinity entries (REST only; own instantiation for the same reason: +5.7 % on config 5 as
 // run-time tests of the entries' bit 31).
-// MANY: more than 128 signatures (KQ = 2, two-level summary, no REST): signatures 0 .. 127 live in lane registers as usual, the rest is
+// MANY: more than 128 signatures (KQ = 2, two-level summary; since round 6 also with the REST rows): signatures 0 .. 127 live in lane registers as usual, the rest is
 // refreshed from TableCold::sigs in up to two further groups of 128 whose table rows are fetched WITH group 0's (one memory round
 // trip per cycle; own instantiation: the extra rows cost ~40 VGPRs the K <= 128 kernels must not pay); groups beyond those
 // (385 .. 1 023 signatures, round 4) follow one round trip each.
@@ -397,13 +397,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 #else
     constexpr bool TIE_FIRST = REST || MANY;                          // MANY: a lost speculation would reload three groups of rows
 #endif
-    static_assert(!MANY || (KQ == 2 && COARSE && !REST), "MANY = groups of 128 signatures on the two-level layout");
+    static_assert(!MANY || (KQ == 2 && COARSE && !CN2 && !LDSX), "MANY = groups of 128 signatures on the two-level layout (since round 6 also under the REST select: its rows and counters are indexed by signature already)");
     constexpr int NG = MANY ? 2 : 0;                                  // further signature groups (K <= 128 (1 + NG))
     static_assert(!SPREAD || COARSE, "SPREAD is built on the two-level layout");
     constexpr bool RS = REST && SPREAD;                               // generation 7's walks over generation 6's position-mask rows (round 6)
     // (AFF names two things: required-affinity entries to the REST half, preferred / hard terms in the walk to the SPREAD half.  REST && SPREAD
     // && AFF is launched for the latter -- spread_supported keeps required affinity out -- and carries the former's code unused.)
-    static_assert(!RS || (!MANY && !LDSX && !CN2), "REST && SPREAD: <= 64 classes, <= 128 signatures");
+    static_assert(!RS || (!LDSX && !CN2), "REST && SPREAD: <= 64 classes");
     static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
     static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
@@ -2238,8 +2238,8 @@ static hipError_t launch_t7(const TableLaunch& a, int n_blocks, size_t lds, hipS
         if (a.aff) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, true, false, false, CN2>(a, n_blocks, lds, st);
     }
     if (REST && !CN2 && a.sc.Cn > 64) return hipErrorInvalidValue;    // (65 .. 128 node classes under the REST select: simon_table_rest2.hip)
-    if constexpr (KQ == 2 && COARSE && !REST && !MANY && !SPREAD) {   // more than 128 signatures: the instantiation with further groups
-        if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, false, true>(a, n_blocks, lds, st);
+    if constexpr (KQ == 2 && COARSE && !MANY && !SPREAD && !CN2) {    // more than 128 signatures: the instantiation with further groups (round 6: also with the REST rows)
+        if (a.sc.K > 128) return launch_t7<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, true>(a, n_blocks, lds, st);
     }
     if (!MANY && a.sc.K > 64 * KQ) return hipErrorInvalidValue;       // simon_hip.hip keeps such batches away (two-level, no REST)
     auto kern = table_kernel<M, Z, PIN, KQ, NBQ, COARSE, REST, RANKED, AFF, MANY, SPREAD, 1, false, false, CN2>;
@@ -2414,7 +2414,7 @@ hipError_t launch_table_rest_lds(const TableLaunch& a, int n_blocks, bool nzeq, 
 }
 #elif defined(SIMON_TABLE_RS_TU)
 // ---- this translation unit (simon_table_rs.hip) holds generation 7's walks over generation 6's position-mask rows (REST && SPREAD): one wave per
-// scenario, <= 64 node classes, <= 128 signatures ----
+// scenario (or the team unit's four), <= 64 node classes ----
 template <bool Z, int KQ, int NBQ, bool RANKED = false, bool AFF = false>
 static hipError_t launch_rs3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (!RANKED) {
@@ -2422,6 +2422,15 @@ static hipError_t launch_rs3(const TableLaunch& a, int n_blocks, size_t lds, hip
     }
     if constexpr (!AFF) {                                             // (& 64: preferred pod (anti-)affinity / hard zone constraints in the walk; a.aff: required-affinity entries)
         if ((a.sc.static_tables & 64) || a.aff) return launch_rs3<Z, KQ, NBQ, RANKED, true>(a, n_blocks, lds, st);
+    }
+    if constexpr (KQ == 2 && NBQ == 2) {                              // 129 .. 1 023 signatures: the signature groups of MANY (one shape, as for generation 7 alone)
+        if (a.sc.K > 128) {
+            auto kern = table_kernel<true, Z, true, 2, 2, true, true, RANKED, AFF, true, true>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
+            return hipGetLastError();
+        }
     }
     if (a.sc.K > 64 * KQ) return hipErrorInvalidValue;
     auto kern = table_kernel<true, Z, true, KQ, NBQ, true, true, RANKED, AFF, false, true>;
@@ -2432,10 +2441,11 @@ static hipError_t launch_rs3(const TableLaunch& a, int n_blocks, size_t lds, hip
 }
 template <bool Z, int KQ>
 static hipError_t launch_rs2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    if constexpr (KQ == 2) { if (a.sc.K > 128) return launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st); }
     return a.sc.ni_max / 64 <= 64 ? launch_rs3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st);
 }
 hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
-    if (!a.spread || !a.rest || !a.coarse || a.team > 1 || a.lds_x || a.sc.Cn > 64 || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
+    if (!a.spread || !a.rest || !a.coarse || a.team > 1 || a.lds_x || a.sc.Cn > 64 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
     if (a.sc.K > 64) return nzeq ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rs2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
 }

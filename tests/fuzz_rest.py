@@ -41,10 +41,10 @@ def one_case(case):
         feat["aff"] = True                # required affinity (derived terms, first-pod escape) beside the anti-affinity terms
     if size >= 2:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
-    if case >= 800000:                    # cases from 800 000 on: the same filters next to soft PodTopologySpread constraints -- generation 7's walks over
+    if 800000 <= case < 900000 or (case >= 900000 and case % 2):   # cases from 800 000 on (every other one from 900 000 on): the same filters next to soft PodTopologySpread constraints -- generation 7's walks over
         feat["spread_soft"] = True        # these mask rows (REST && SPREAD, simon_table_rs.hip), required affinity included
     n_node_classes = int(rng.choice([70, 90, 110] if 500000 <= case < 800000 else [1, 2, 4, 9, 20, 40]))   # cases from 500 000 on: 65 .. 128 internal node classes (CN2 in rest_select)
-    n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 120]))
+    n_pod_classes = int(rng.choice([130, 200, 300, 500] if case >= 900000 else [1, 3, 8, 30, 64, 120]))   # cases from 900 000 on: 129 .. 1 023 signatures under the REST rows (MANY && REST; with spread_soft: && SPREAD)
     prob = randprob.rand_problem(62000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
     S = int(rng.integers(1, 7))
     scen, orders = randprob.rand_scenarios(case, prob, S=S, min_n=1 if rng.random() < 0.5 else None)
