@@ -1890,7 +1890,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
         // team mode: a small batch of a problem with soft spread constraints gets kTeamWaves waves per scenario (the walks of
         // spread_select and the prologue are split; LDS: + one score table, the canonical indices and the exchange slots)
         const int team_max = c->team_max_s >= 0 ? c->team_max_s : 2 * c->n_cus;
-        int team = (c->spread && c->table_coarse && (!c->rest || c->rs) && c->n_sigs <= 128 && c->team_mode != 0 && (c->team_mode > 0 || S <= team_max)) ? kTeamWaves : 1;
+        int team = (c->spread && c->table_coarse && (!c->rest || c->rs) && c->team_mode != 0 && (c->team_mode > 0 || S <= team_max)) ? kTeamWaves : 1;
         auto lds_for = [&](int tm) -> size_t {
             return c->table_ok ? table_lds_bytes(c->n_sigs, ni_top, c->Cn_t, c->table_coarse, c->rest, c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (tm > 1 ? 0x200 : 0) | (c->Cn_t > kTableMaxClasses ? 0x400 : 0)) : -1) + c->lds_pad : 0;
         };

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // (AFF names two things: required-affinity entries to the REST half, preferred / hard terms in the walk to the SPREAD half.  REST && SPREAD
     // && AFF is launched for the latter -- spread_supported keeps required affinity out -- and carries the former's code unused.)
     static_assert(!RS || (!LDSX && !CN2), "REST && SPREAD: <= 64 classes");
-    static_assert(!(SPREAD && MANY) || (NBQ == 2 && NW == 1), "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations of one wave only");
+    static_assert(!(SPREAD && MANY) || NBQ == 2, "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
     static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
     constexpr int TABMAX = CN2 ? kSpreadTabMax2 : kSpreadTabMax;
@@ -2258,7 +2258,7 @@ static hipError_t launch_t6(const TableLaunch& a, int n_blocks, size_t lds, hipS
 constexpr int kTuWaves = SIMON_TABLE_TEAM_TU;
 #define SIMON_TEAM_CAT2(a, b) a##b
 #define SIMON_TEAM_CAT(a, b) SIMON_TEAM_CAT2(a, b)
-template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false, bool REST = false>
+template <bool M, bool Z, int KQ, int NBQ, bool RANKED, bool AFF, bool CN2 = false, bool REST = false, bool MANY = false>
 static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
     if constexpr (!CN2 && !REST) {                                    // the walks over the position-mask rows (REST && SPREAD): <= 64 classes
         if (a.rest) {
@@ -2271,8 +2271,11 @@ static hipError_t launch_team6(const TableLaunch& a, int n_blocks, size_t lds, h
     if constexpr (!CN2 && !REST) {                                    // 65 .. 128 node classes: two per lane in the walks
         if (a.sc.Cn > 64) return launch_team6<M, Z, KQ, NBQ, RANKED, AFF, true>(a, n_blocks, lds, st);
     }
-    if (a.sc.K > 64 * KQ || (!CN2 && a.sc.Cn > 64)) return hipErrorInvalidValue;
-    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, REST, RANKED, AFF, false, true, kTuWaves, false, false, CN2>;
+    if constexpr (KQ == 2 && NBQ == 2 && !CN2 && !MANY) {             // 129 .. 1 023 signatures (round 6: the leader's refresh takes the further groups along as the single wave does)
+        if (a.sc.K > 128) return launch_team6<M, Z, KQ, NBQ, RANKED, AFF, false, REST, true>(a, n_blocks, lds, st);
+    }
+    if ((!MANY && a.sc.K > 64 * KQ) || (!CN2 && a.sc.Cn > 64)) return hipErrorInvalidValue;
+    auto kern = table_kernel<M, Z, true, KQ, NBQ, true, REST, RANKED, AFF, MANY, true, kTuWaves, false, false, CN2>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * kTuWaves), lds, st, a.cold, a.cls_list, a.pods, a.orders, a.perm, a.ws_off, a.place_step, a.ws, a.sc);
@@ -2286,7 +2289,7 @@ static hipError_t launch_team4(const TableLaunch& a, int n_blocks, size_t lds, h
 }
 template <bool M, bool Z>
 static hipError_t launch_team2(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
-    const bool one = a.sc.ni_max / 64 <= 64;
+    const bool one = a.sc.ni_max / 64 <= 64 && a.sc.K <= 128;        // (more than 128 signatures: one shape, two entries per lane)
     if (a.sc.K > 64) return one ? launch_team4<M, Z, 2, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 2, 2>(a, n_blocks, lds, st);
     return one ? launch_team4<M, Z, 1, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 1, 2>(a, n_blocks, lds, st);
 }

@@ -323,3 +323,15 @@ def test_ranked_generation_7_without_counter_rows_stays_inside_its_workspace_sli
     for case in (702439, 702439):
         ok, info = fuzz_spread.one_case(case)
         assert ok, info
+
+
+def test_team_mode_beyond_128_signatures():
+    """Round 6: the team of waves takes the signature groups of MANY along (129 .. 1 023 signatures next to soft constraints) -- a slice of
+    fuzz_spread.py's cases from 300 000 on, each run on one wave and on the team; at least some must land on generation 7's team shape."""
+    import fuzz_spread
+    teams = 0
+    for case in range(300000, 300024):
+        ok, info = fuzz_spread.one_case(case)
+        assert ok, info
+        teams += info["team"]
+    assert teams >= 3, teams
