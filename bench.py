@@ -61,7 +61,7 @@ SERVICE_SHAPES = 30               # node shapes of the `config3_service_shapes30
 SMALL_COUNTS = 16                 # node counts of the `service_small` sub-record (x 4 pod orders = 64 scenarios: what a sweep of candidate sizes looks like)
 SIG_CLIFF = 300                   # ... and of the `config3_sigs300` row: three groups of 128 signatures per wave (the table's last regime before 384)
 CLASS_RECORD = 80                 # distinct node shapes of the `config3_classes80` row: more than 64 internal node classes (two per lane on the score table)
-CLASS_CLIFF = 160                 # ... and of `config3_classes160`: more than the 128 the score table holds (the priced cliff)
+CLASS_CLIFF = 160                 # ... and of `config3_classes160`: 129 .. 256 classes run generation 4's kernels of simon_table_cls4.hip since the end of round 6 (before: generation 1, the priced cliff)
 SIG_RECORD = 200                  # request signatures of the `config3_sigs` sub-record (beyond the 128 two registers per lane hold; the table takes 384)
 C5_SATURATING = 2048              # config-5 scenarios per GPU at which generation 6 saturates the chip (8 resident waves per CU; profiles/README.md)
 
@@ -464,7 +464,7 @@ def sub_record(name, capi, synth, torch, steps, warmup, oracle_k, pmc_mode, c5_s
         prob, scen, orders = synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=SIG_CLIFF)
         child = ["--workload", "config3sig", "--sigs", str(SIG_CLIFF)]
         wl, label = "config3", f"config 3 with {SIG_CLIFF} request signatures"
-    elif name in ("config3_classes", "config3_classes_cliff"):   # ... 80 node shapes (two classes per lane) and 160: beyond 128 internal node classes the problem leaves the score table
+    elif name in ("config3_classes", "config3_classes_cliff"):   # ... 80 node shapes (two classes per lane) and 160 (four, simon_table_cls4.hip; beyond 256 internal node classes the problem leaves the score table)
         ncl = CLASS_RECORD if name == "config3_classes" else CLASS_CLIFF
         prob, scen, orders = synth.config3_classes(ncl)
         child = ["--workload", "config3classes", "--classes", str(ncl)]

@@ -1769,7 +1769,7 @@ int simon_load_scenarios(simon_ctx* c, const simon_scenario* scen, int32_t S, co
             auto fit = [](size_t lds) { const size_t g = (lds + 1279) / 1280 * 1280; return g ? (int)std::min<size_t>(32, kTableLdsPerCU / g) : 32; };
             const int nzk = c->spread ? ((int)c->sp_zkeys.size() | ((c->ipa_fold || c->hard_fold) ? 0x100 : 0) | (Ct > kTableMaxClasses ? 0x400 : 0)) : -1;   // (| 0x100: the second score table of spread_select; | 0x400: CN2's larger one)
             const size_t lds16 = table_lds_bytes(c->n_sigs, top16, Ct, false, false) + c->lds_pad, lds64 = table_lds_bytes(c->n_sigs, top64, Ct, true, c->rest, nzk) + c->lds_pad;
-            const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= kTableLdsMaxWG;
+            const bool fine_ok = max_n <= kTableMaxNodes && top16 <= kTableMaxPadded && lds16 <= 64 * 1024, coarse_ok = top64 <= kTableMaxPaddedCoarse && lds64 <= kTableLdsMaxWG && Ct <= 128;   // (129 .. 256 classes: one-level only, simon_table_cls4.hip)
             const int per_cu = (S + c->n_cus - 1) / std::max(c->n_cus, 1);
             auto cost = [&](int fits, double factor) {
                 auto round_cost = [](int w) { return 1.0 + 0.055 * (std::min(w, 16) - 1) + 0.11 * std::max(w - 16, 0); };
@@ -1910,7 +1910,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             return c->ldsws_mode > 0 || S <= std::max(c->n_cus, 1);
         };
         bool lds_ws = false;
-        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && c->n_sigs <= 128 && team == 1) {
+        if (c->table_ok && !c->table_coarse && !c->rest && !c->spread && !c->fold && !c->gfold && c->n_sigs <= 128 && c->Cn_t <= 128 && team == 1) {
             size_t ws_max = 0;
             for (int s2 = 0; s2 < S; ++s2) ws_max = std::max(ws_max, table_ws_bytes(c->n_sigs, c->scen_ni[s2], c->nzeq, false, c->Cn_t, 0, 0, 0, 0));
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + ws_max + c->lds_pad;   // (the kernel puts the workspace at the next 128-byte boundary behind tcarve's total)
@@ -1922,7 +1922,7 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
             const size_t need = ((table_lds - c->lds_pad + 127) & ~(size_t)127) + table_ldsx_bytes(ni_top, c->rest_M) + c->lds_pad;
             if (lds_home(need)) { lds_x = true; table_lds = need; }
         }
-        bool use_table = c->table_ok && c->table_perm_ok && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
+        bool use_table = c->table_ok && c->table_perm_ok && (c->Cn_t <= 128 || (!c->table_coarse && !c->fold && !c->gfold && c->n_sigs <= 128)) && !c->no_cache && !c->force_v1 && c->max_n <= (c->table_coarse ? kTableMaxNodesCoarse : kTableMaxNodes) &&
                                ni_top <= (c->table_coarse ? kTableMaxPaddedCoarse : kTableMaxPadded) && table_lds <= ((c->table_coarse || lds_ws) ? kTableLdsMaxWG : (size_t)64 * 1024);
         // pinned pods (pin_node) are known to the score-table kernel and the all-feature kernel only
         if (c->debug_route)

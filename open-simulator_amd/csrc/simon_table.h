@@ -121,7 +121,7 @@ constexpr int kTeamWaves = 4;           // team mode (table_kernel: NW): waves p
 constexpr int kTeamWavesMax = 16;       // (the exchange slots are sized for it: a wider team is one more translation unit, simon_table_team<N>.hip)
 constexpr int kTableMaxClasses = 64;    // internal node classes = distinct (column content, allocatable) pairs: one lane each in the REST select and the SPREAD walks
 constexpr int kTableMaxClassesSpread = 128;  // ... two per lane in the REST select and in the SPREAD walks that score soft constraints only (CN2, round 6)
-constexpr int kTableMaxClassesPlain = 128;   // ... two per lane where only the prologue and the class terms' re-base are lane-shaped (no REST rows, no SPREAD)
+constexpr int kTableMaxClassesPlain = 256;   // ... up to four per lane where only the prologue and the class terms' re-base are lane-shaped (no REST rows, no SPREAD; 129 .. 256: end of round 6)
 
 size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1);   // LDS per workgroup for padded scenario sizes up to ni_max (nzk >= 0: SPREAD; | 0x100: second score table; | 0x200: team mode; | 0x400: CN2's larger score table)
 size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0);  // HBM workspace of ONE scenario with ni padded positions
@@ -138,6 +138,7 @@ inline size_t table_ldsx_bytes(int ni_max, int M) {   // rows [M][ni_max / 16] u
 }
 // generation 6, one wave per scenario (simon_table_rest.hip: the REST instantiations, a translation unit of their own since round 5)
 hipError_t launch_table_rest(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);
+hipError_t launch_table_cls4(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);    // generation 4 for 129 .. 256 node classes (simon_table_cls4.hip)
 hipError_t launch_table_rest2(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st);   // ... for 65 .. 128 node classes (simon_table_rest2.hip)
 // generation 7, one wave per scenario (simon_table_spread.hip: the SPREAD instantiations, a translation unit of their own)
 hipError_t launch_table_spread(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st);

@@ -185,7 +185,7 @@ __host__ __device__ inline int table_nbp(int nblk) { return (nblk & 1) || (nblk 
 // signatures keep 16+ scenario waves per CU -- and the per-16 entries move to the scenario's HBM workspace, where only the assume
 // reads them (4 entries = 8 bytes per signature, fetched with the table row, off the dependent chain); the feasible-node counters
 // move there too (touched on the rare cycle a node becomes infeasible for a signature).  Classes are then padded to 64 positions.
-__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1) {
+__host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk = -1, bool cls4 = false) {   // (cls4: 129 .. 256 classes, simon_table_cls4.hip -- a constant to every kernel)
     auto al = [](int x) { return (x + 15) & ~15; };
     TCarve c;
     c.nbp = table_nbp(ni_max / (coarse ? 64 : 16));
@@ -199,9 +199,9 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     (void)rest;
     c.cnt = o; o += coarse ? 0 : al(K * Cn * 4);
 #else
-    c.cnt = o; o += (coarse && !rest) ? 0 : al(K * Cn * 4);
+    c.cnt = o; o += ((coarse && !rest) || cls4) ? 0 : al(K * Cn * 4);   // (129 .. 256 classes, simon_table_cls4.hip: counters in the workspace, 32-byte shapes)
 #endif
-    c.shape = o; o += Cn * 48;
+    c.shape = o; o += Cn * (cls4 ? 32 : 48);
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
     // SPREAD (nzk >= 0): zone domain of a class per zone-like key; for spread_select two bytes per position and the score table of
@@ -225,11 +225,12 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
 // ... and (REST, M mask rows) the position masks [ni / 16][M] u16 and the GPU devices of every position: used [ni][8], per-device
 // total [ni], device count [ni] (u32 each), extra-resource Requested [ni][8] and allocatable [ni][8], and the topology domain of every
 // position under the NZ keys that are not node-level [NZ][ni] u16
-__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0) {
+__host__ __device__ inline size_t table_ws_of(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH = 0, int TZ = 0, bool cls4 = false) {
     size_t w = ((size_t)(ni / 16) * K * 16 + 127) & ~(size_t)127;
     w += ((size_t)ni * 12 + 127) & ~(size_t)127;
     if (!nzeq) w += ((size_t)ni * 8 + 127) & ~(size_t)127;
     if (coarse) w += (((size_t)(ni / 64) * K * 8 + 127) & ~(size_t)127) + (((size_t)K * Cn * 4 + 127) & ~(size_t)127);
+    else if (cls4) w += ((size_t)K * Cn * 4 + 127) & ~(size_t)127;   // (simon_table_cls4.hip: the feasible-node counters)
     if (M > 0) w += (((size_t)(ni / 16) * M * 2 + 127) & ~(size_t)127) + (size_t)ni * (40 + 64) + (size_t)NZ * ni * 2 + (((size_t)M * 4 + 127) & ~(size_t)127);
     // SPREAD: matching pods per (hostname-key term, position) u8 [TH][ni], per (zone-key term, domain) u32 [TZ][16]
     if (TH > 0 || TZ > 0) w += (((size_t)TH * ni + 127) & ~(size_t)127) + (((size_t)TZ * 16 * 4 + 127) & ~(size_t)127) + (((size_t)TH + 127) & ~(size_t)127)
@@ -387,10 +388,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     constexpr int KB = COARSE ? 13 : 12;                              // width of the position field of the arg-max key
     constexpr unsigned PMASK = (1u << KB) - 1u;
     static_assert(!REST || COARSE, "the REST path is built on the two-level layout");
+    // 129 .. 256 internal node classes (end of round 6): where no select is lane-shaped -- no REST rows, no SPREAD walks -- the prologue's scan and the class terms'
+    // re-base take further groups of 64 classes.  The re-base sits INSIDE the scheduling cycle's register budget (as a run-time branch it cost every kernel of the
+    // family 2 .. 8 VGPRs, the 127-VGPR ones their fourth wave per SIMD), so it is compiled into eight kernels of their own: simon_table_cls4.hip.  One-level layout
+    // only: a class segment is padded to a summary unit, and 129 units of 64 positions are more than the two-level table holds.  What grows with the class count is
+    // kept out of LDS where the cycle does not read it (tcarve): the feasible-node counters live in the scenario's workspace (read-modify-written on the rare cycle
+    // a byte drops to 0), a class shape is 32 B (the two 100/cap factors are one IEEE multiplication each, as the host computes them) -- BASELINE config 3's 42
+    // signatures on 160 shapes ask for 38.6 KB instead of 68 KB, four scenarios per CU instead of two.
+    constexpr bool kCls4 = CN2 && !REST && !SPREAD;
 #ifdef SIMON_REST_CNT_HBM
     constexpr bool CNT_LDS = !COARSE;                                 // A/B builds: round 5's home of the two-level layout's counters
 #else
-    constexpr bool CNT_LDS = !COARSE || REST;                         // feasible-node counters per (signature, class) in LDS (tcarve)
+    constexpr bool CNT_LDS = (!COARSE || REST) && !kCls4;             // feasible-node counters per (signature, class) in LDS (tcarve)
 #endif
 #ifdef SIMON_TIE_SPECULATE
     constexpr bool TIE_FIRST = false;                                 // A/B builds: every instantiation speculates
@@ -406,9 +415,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     static_assert(!RS || (!LDSX && !CN2), "REST && SPREAD: <= 64 classes");
     static_assert(!(SPREAD && MANY) || NBQ == 2, "SPREAD with more than 128 signatures: the two-blocks-per-lane instantiations only");
     static_assert(NW == 1 || SPREAD, "team mode exists for the SPREAD instantiations");
-    static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM)");
+    static_assert(!CN2 || (SPREAD && !MANY && !REST) || (REST && !LDSX && !SPREAD) || (!REST && !SPREAD && !COARSE && !MANY && !LDSWS), "CN2 = two node classes per lane in spread_select (<= 128 signatures) or in rest_select (rows in HBM); without rows and walks: 129 .. 256 classes on the one-level layout (simon_table_cls4.hip)");
     constexpr int TABMAX = CN2 ? kSpreadTabMax2 : kSpreadTabMax;
-    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0) | (CN2 ? 0x400 : 0)) : -1);
+    const TCarve cv = tcarve(K, sc.ni_max, Cn, COARSE, REST, SPREAD ? (sc.NZK | ((sc.static_tables & 64) ? 0x100 : 0) | (NW > 1 ? 0x200 : 0) | (CN2 ? 0x400 : 0)) : -1, kCls4);
     const int TH = SPREAD ? sc.TH : 0, TZ = SPREAD ? sc.TZ : 0, NZK = SPREAD ? sc.NZK : 0;
     signed char* s_zdom = (signed char*)(smem + cv.zdom);          // SPREAD: [NZK][Cn]
     unsigned short* s_stash = (unsigned short*)(smem + cv.stash);  // SPREAD: [positions] count | table byte << 8 of the pod being placed
@@ -420,7 +429,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     const int nbp = cv.nbp;
     unsigned short* s_sn = (unsigned short*)(smem + cv.sn);         // [K][Cn]: the class term (<= 822) currently folded into row k
     int* s_cnt = (int*)(smem + cv.cnt);                             // [K][Cn]: feasible nodes of class d for signature k (!COARSE)
-    const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);   // [Cn]: shape of a node class (a class shares its allocatable)
+    const ShapeRow* s_shape = (const ShapeRow*)(smem + cv.shape);   // [Cn]: shape of a node class (a class shares its allocatable); kCls4: 32 B rows (capacity, reciprocal)
+    auto shape_of = [&](int d) -> ShapeRow {
+        if constexpr (kCls4) {
+            const double* r = (const double*)(smem + cv.shape) + 4 * d;
+            return ShapeRow{r[0], r[1], r[2], r[3], 100.0 * r[2], 100.0 * r[3]};      // (simon_hip.hip: rc100 = 100.0 * rc, IEEE; the library is built without contraction)
+        } else return s_shape[d];
+    };
     int* s_seg = (int*)(smem + cv.seg);                             // [Cn + 1]: first position of a class segment
     int* s_tmp = (int*)(smem + cv.tmp);
 
@@ -457,7 +472,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 
     // ---- prologue 1: clear, tables -> LDS, class segments --------------------------------------
     for (int i = tid; i < K * Cn; i += TT) { if (CNT_LDS) s_cnt[i] = 0; s_sn[i] = 0; }
-    for (int i = tid; i < Cn * 12; i += TT) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
+    if constexpr (kCls4) { for (int i = tid; i < Cn * 8; i += TT) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[(i >> 3) * 12 + (i & 7)]; }
+    else for (int i = tid; i < Cn * 12; i += TT) ((int*)(smem + cv.shape))[i] = ((const int*)shapes)[i];
     // count of class-d nodes among the first n canonical nodes, padded to 16 (COARSE: to 64, one class per summary entry)
     const int cnt_d = (lane < Cn) ? clsprefix[(size_t)n * Cn + lane] : 0;
     const int pad_d = (cnt_d + (UNIT - 1)) & ~(UNIT - 1);
@@ -484,13 +500,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         }
         if (lead && 64 + lane < Cn) s_seg[64 + lane] = ni + incl2 - pad2;
         ni += __builtin_amdgcn_readlane(incl2, 63);
+        // 129 .. 256 classes (end of round 6, same instantiations): the further groups of 64 extend the scan; their counts are not kept in
+        // registers (count_of_class reads the prefix table for them -- the prologue alone asks)
+        if constexpr (kCls4) {
+#pragma nounroll
+        for (int g = 2; g * 64 < Cn; ++g) {
+            const int cg = (g * 64 + lane < Cn) ? clsprefix[(size_t)n * Cn + g * 64 + lane] : 0;
+            const int padg = (cg + (UNIT - 1)) & ~(UNIT - 1);
+            int inclg = padg;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inclg, off, 64);
+                if (lane >= off) inclg += o;
+            }
+            if (lead && g * 64 + lane < Cn) s_seg[g * 64 + lane] = ni + inclg - padg;
+            ni += __builtin_amdgcn_readlane(inclg, 63);
+        }
+        }
     }
     if (lead && lane == 0) s_seg[Cn] = ni;                            // the sentinel: with Cn == 64 no lane Cn exists to write it
     auto count_of_class = [&](int d) -> int {                        // nodes of class d in this scenario (every lane active: cross-lane reads)
         const int lo = __shfl(cnt_d, d & 63, 64);
         if (Cn <= 64) return lo;
         const int hi = __shfl(cnt_d2, d & 63, 64);
-        return d < 64 ? lo : hi;
+        int r = d < 64 ? lo : hi;
+        if (kCls4 && d >= 128) r = clsprefix[(size_t)n * Cn + (d < Cn ? d : 0)];   // (classes 128 ..: from the prefix table)
+        return r;
     };
     const int nblk = ni >> 4, nun = ni >> UB;                         // table blocks (16 positions); summary entries
     unsigned char* g_tile = wsb;                                      // [block][K][16] bytes: 0 = infeasible, else 1 + LA + BA
@@ -498,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     uint2* g_nz = (uint2*)((unsigned char*)g_state + (((size_t)ni * 12 + 127) & ~(size_t)127));   // NonZeroRequested (only when !NZEQ)
     // COARSE: per-16 entries [ni / 64][K][4] u16 and feasible-node counters [K][Cn] behind the node state
     unsigned short* g_fine = (unsigned short*)((unsigned char*)g_nz + (NZEQ ? 0 : (((size_t)ni * 8 + 127) & ~(size_t)127)));
-    int* g_cnt = (int*)((unsigned char*)g_fine + (((size_t)(ni >> 6) * K * 8 + 127) & ~(size_t)127));
+    int* g_cnt = (int*)((unsigned char*)g_fine + (COARSE ? (((size_t)(ni >> 6) * K * 8 + 127) & ~(size_t)127) : (size_t)0));   // (kCls4: the counters alone)
     // REST: position masks [nblk][M], GPU devices by position
     unsigned short* const g_xm_mem = (unsigned short*)((unsigned char*)g_cnt + (((size_t)K * Cn * 4 + 127) & ~(size_t)127));   // (the HBM slice keeps its layout)
     // LDSX: rows [M][nblk] behind tcarve's total, then the row totals [M], then the canonical index of every position
@@ -523,7 +558,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     // the scenario's workspace -- used [ni][8], per-device total [ni], device count [ni] (gcd units)
     constexpr bool kGpuFoldable = COARSE && !REST && HAS_PIN;
     const bool gfold = kGpuFoldable && (sc.static_tables & 128);
-    unsigned* g_fu = (unsigned*)(wsb + table_ws_of(K, ni, NZEQ, COARSE, Cn, M, NZ, TH, TZ));
+    unsigned* g_fu = (unsigned*)(wsb + table_ws_of(K, ni, NZEQ, COARSE, Cn, M, NZ, TH, TZ, kCls4));
     unsigned* g_ft = g_fu + (size_t)ni * 8;
     int* g_fc = (int*)(g_ft + ni);
     // [K][nbp] in LDS: (best byte + class term) << 4 | 15 - position of a block of 16; COARSE: ... << 6 | 63 - position of 64 positions
@@ -582,7 +617,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             g_state[p] = st;
             if (!NZEQ) g_nz[p] = z;
         }
-        const ShapeRow sh = s_shape[d];
+        const ShapeRow sh = shape_of(d);
         unsigned char* tp = g_tile + (tile_blk((unsigned)(p >> 4)) + (unsigned)(p & 15));
         unsigned gu[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gtot = 0;                // GPU fold: this position's devices
         int gcnt = 0;
@@ -632,7 +667,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                 }
             } else {
                 if ((lane & 15) == 0 && p < ni) s_sum[k * nbp + (p >> 4)] = (unsigned short)m16;
-                if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
+                if constexpr (kCls4) {                                // (performed in L2: L1 is invalidated behind the prologue; 16 positions = one class: one atomic per group)
+                    const int n16 = __popc((unsigned)((__ballot(b != 0) >> (lane & 48)) & 0xFFFFull));
+                    if ((lane & 15) == 0 && n16) atomicAdd(&g_cnt[k * Cn + d], n16);
+                }
+                else if (b) atomicAdd(&s_cnt[k * Cn + d], 1);
             }
 
         }
@@ -700,7 +739,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         for (int i = tid; i < TH; i += TT) g_hmax[i] = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (NW > 1) __threadfence();                            // the counters were added to in L2 (atomics): no stale L1 line may serve the plain loads of the loop
+    if constexpr (NW > 1 || kCls4) __threadfence();                   // the counters were added to in L2 (atomics): no stale L1 line may serve the plain loads of the loop
     __syncthreads();
     if constexpr (NW > 1) __threadfence();
 
@@ -808,7 +847,64 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     };
     // Re-base summary row k after the set of node classes with a feasible node changed.
     auto renormalise = [&](int k, int c) {
-        if (Cn > 64) {
+        if (kCls4 && Cn > 128) {
+            // 129 .. 256 classes: lane l evaluates classes l, 64 + l, 128 + l, 192 + l -- class_term's formulas with the extremes and maxima taken over all four
+            // groups.  Every load of a pass is in flight at once (the first form walked the groups in a rolled loop: four dependent L2 round trips per pass, and
+            // with 159 classes of three nodes each a signature is re-based a hundred times per scenario -- config 3 on 160 shapes spent a third of its time here).
+            int dq[4], cnq[4], rawq[4], tq[4];
+            bool inq[4];
+            int lo = 0x7fffffff, hi = (int)0x80000000;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bool v = g * 64 + lane < Cn;
+                dq[g] = v ? g * 64 + lane : 0;
+                cnq[g] = g_cnt[k * Cn + dq[g]];
+                rawq[g] = simon_raw[c * Cn + dq[g]];
+                inq[g] = v && cnq[g] > 0;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { lo = min(lo, inq[g] ? rawq[g] : 0x7fffffff); hi = max(hi, inq[g] ? rawq[g] : (int)0x80000000); }
+            lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+            const int range = hi >= lo ? hi - lo : 0;
+            const double rr = range ? 1.0 / (double)range : 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tq[g] = (inq[g] && range) ? 2 * (int)__builtin_fma((double)(rawq[g] - lo) * 100.0, rr, 0.5 * rr) : 0;
+            GPtr<const TableCold> cc = cold;
+            asm volatile("" : "+s"(cc));                                  // rare path: its pointers are fetched here, and only when present
+            if (sc.static_tables & 1) {
+                int a[4], mx = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a[g] = gp(cc->na_raw)[c * Cn + dq[g]];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mx = max(mx, inq[g] ? a[g] : 0);
+                mx = wave_max_i32(mx);
+                const double r = mx ? 1.0 / (double)mx : 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tq[g] += (inq[g] && mx) ? (int)__builtin_fma((double)a[g] * 100.0, r, 0.5 * r) : 0;
+            }
+            if (sc.static_tables & 2) {
+                int a[4], mx = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a[g] = gp(cc->tt_raw)[c * Cn + dq[g]];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mx = max(mx, inq[g] ? a[g] : 0);
+                mx = wave_max_i32(mx);
+                const double r = mx ? 1.0 / (double)mx : 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tq[g] += inq[g] ? (mx ? 100 - (int)__builtin_fma((double)a[g] * 100.0, r, 0.5 * r) : 100) : 0;
+            }
+            if (sc.static_tables & 4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tq[g] += inq[g] ? gp(cc->add_raw)[c * Cn + dq[g]] : 0;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g * 64 + lane < Cn) {
+                    s_tmp[dq[g]] = tq[g] - (int)s_sn[k * Cn + dq[g]];
+                    s_sn[k * Cn + dq[g]] = (unsigned short)tq[g];
+                }
+            }
+        } else if (Cn > 64) {
             // 65 .. 128 classes: lane l evaluates classes l and 64 + l -- class_term's formulas with the extremes taken over both halves
             const bool v1 = 64 + lane < Cn;
             const int d0 = lane, d1 = v1 ? 64 + lane : 0;
@@ -2031,7 +2127,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             }
             SpreadLoads SPL{0u, 0u, false};
             if (SPREAD && sp_match != 0) SPL = spread_count_load(pstar, dstar, res, spv, spt, sp_soft, sp_match);
-            const ShapeRow sh = s_shape[dstar];
+            const ShapeRow sh = shape_of(dstar);
             unsigned snq[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) snq[q] = s_sn[kk[q] * Cn + dstar];
@@ -2452,6 +2548,17 @@ hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t
     if (a.sc.K > 64) return nzeq ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 2>(a, n_blocks, lds_bytes, st);
     return nzeq ? launch_rs2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
 }
+#elif defined(SIMON_TABLE_CLS4_TU)
+// ---- this translation unit (simon_table_cls4.hip) holds generations 4 for 129 .. 256 internal node classes: one-level layout, > 2 048 padded positions (a class
+// segment is padded to 16), so NBQ = 4; the instantiation that knows pinned pods serves every problem ----
+template <bool Z>
+static hipError_t launch_cls4b(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {
+    return a.sc.K > 64 ? launch_t6<true, Z, true, 2, 4, false, false, true>(a, n_blocks, lds, st) : launch_t6<true, Z, true, 1, 4, false, false, true>(a, n_blocks, lds, st);
+}
+hipError_t launch_table_cls4(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
+    if (a.rest || a.spread || a.coarse || a.team > 1 || a.lds_ws || a.sc.Cn <= 128 || a.sc.Cn > kTableMaxClassesPlain || a.sc.K > 128 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
+    return nzeq ? launch_cls4b<true>(a, n_blocks, lds_bytes, st) : launch_cls4b<false>(a, n_blocks, lds_bytes, st);
+}
 #elif defined(SIMON_TABLE_REST2_TU)
 // ---- this translation unit (simon_table_rest2.hip) holds generation 6 for 65 .. 128 internal node classes (CN2 in rest_select; rows in HBM) ----
 template <bool Z, int KQ>
@@ -2510,13 +2617,14 @@ static hipError_t launch_t4(const TableLaunch& a, int n_blocks, size_t lds, hipS
     if (a.coarse) {                                                   // entries of 64 positions: <= 8192 padded positions
         return a.sc.ni_max / 64 <= 64 ? launch_t6<M, Z, PIN, KQ, 1, true>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 2, true>(a, n_blocks, lds, st);
     }
+    if (a.sc.Cn > 128) return launch_table_cls4(a, n_blocks, Z, lds, st);   // 129 .. 256 node classes: simon_table_cls4.hip
     const int nblk = a.sc.ni_max / 16;
     return nblk <= 64 ? launch_t6<M, Z, PIN, KQ, 1, false>(a, n_blocks, lds, st)
            : nblk <= 128 ? launch_t6<M, Z, PIN, KQ, 2, false>(a, n_blocks, lds, st) : launch_t6<M, Z, PIN, KQ, 4, false>(a, n_blocks, lds, st);
 }
 
-size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk) { return (size_t)tcarve(K, ni_max, Cn, coarse, rest, nzk).total; }
-size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH, int TZ) { return table_ws_of(K, ni, nzeq, coarse, Cn, M, NZ, TH, TZ); }
+size_t table_lds_bytes(int K, int ni_max, int Cn, bool coarse, bool rest, int nzk) { return (size_t)tcarve(K, ni_max, Cn, coarse, rest, nzk, !coarse && Cn > 128).total; }
+size_t table_ws_bytes(int K, int ni, bool nzeq, bool coarse, int Cn, int M, int NZ, int TH, int TZ) { return table_ws_of(K, ni, nzeq, coarse, Cn, M, NZ, TH, TZ, !coarse && Cn > 128); }
 
 template <bool M, bool Z, bool PIN>
 static hipError_t launch_t3(const TableLaunch& a, int n_blocks, size_t lds, hipStream_t st) {

@@ -2,7 +2,7 @@
 """Same-box A/B of library builds over the digest workloads: kernel time (HIP events, best and mean of `reps`) and a checksum of every
 placement row, so that two builds can be compared for speed AND for identical results in one gpurun call.
 usage: python profiles/ab_probe.py <workload,workload,...> [reps=3]      (library: SIMON_HIP_LIB, see profiles/build_variant.sh)
-workloads: c5s256 c5s2048 c5s64 c3 c3s64 c2 widemix typical service64 service shapes30 c5shapes80 c5asdrawn c5asdrawn64 c5service c3sig200 c3cls80"""
+workloads: c5s256 c5s2048 c5s64 c3 c3s64 c2 widemix typical service64 service shapes30 c5shapes80 c5asdrawn c5asdrawn64 c5service c3sig200 c3cls80 c3cls160"""
 import hashlib
 import os
 import sys
@@ -43,6 +43,8 @@ def build(name):
         return synth.config3(n_counts=1024, n_orders=4, n_pods=10000, seed=synth.SEED + 3, n_sigs=200)
     if name == "c3cls80":
         return synth.config3_classes(80)
+    if name == "c3cls160":                           # 160 node shapes: generation 4 for 129 .. 256 classes (simon_table_cls4.hip)
+        return synth.config3_classes(160)
     if name == "widemix":
         import bench
         return bench.wide_mix_sweep()

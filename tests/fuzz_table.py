@@ -33,6 +33,10 @@ def one_case(case, coarse=None):
     wide = case >= 300000                 # cases from 300 000 on: 40 ... 128 node classes (two per lane beyond 64, round 4)
     n_node_classes = int(rng.choice([40, 65, 70, 100, 128] if wide else [1, 2, 4, 9, 20, 40]))
     n_pod_classes = int(rng.choice([1, 3, 8, 30, 64, 65, 100, 128, 129, 200, 256, 384]))
+    if case >= 900000:                    # cases from 900 000 on: 129 ... 256 node classes (simon_table_cls4.hip, end of round 6): one-level layout, few enough
+        n_node_classes = int(rng.choice([129, 140, 160, 192, 200, 256, 257]))   # signatures for its LDS (257 classes: off the table)
+        n_pod_classes = int(rng.choice([1, 3, 8, 20, 40]))
+        N = max(N, int(rng.integers(300, 1500)))
     if size == 3:                         # static masks are O(Cp N) Python work in the generator
         feat.pop("static_mask", None)
     prob = randprob.rand_problem(52000 + case, N=N, P=P, n_node_classes=n_node_classes, n_pod_classes=n_pod_classes, **feat)
@@ -40,7 +44,7 @@ def one_case(case, coarse=None):
         shapes_c = np.array([4000, 8000, 16000, 32000]) + (rng.integers(0, 5, 4) if "odd_units" in feat else 0)
         shapes_m = (np.array([8, 16, 64, 128]) << 30) + (rng.integers(0, 7, 4) if "odd_units" in feat else 0)
         pick = rng.integers(0, 4, N)
-        lim = 128 if wide else 64
+        lim = 256 if case >= 900000 else 128 if wide else 64
         if n_node_classes * 4 > lim:
             pick = prob.node_class % (3 if n_node_classes * 3 <= lim else 1)
         prob.alloc_cpu = shapes_c[pick].astype(np.int64)

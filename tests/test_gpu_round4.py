@@ -319,7 +319,7 @@ def test_up_to_128_distinct_node_classes_on_the_score_table(idx, monkeypatch):
     """VERDICT r3 next-8 (the other half of the 64-class cliff): 65 .. 128 node classes that DO differ in what the kernel reads (distinct
     score columns x allocatable shapes) run on the score-table instantiations without position-mask rows and spread walks, two classes
     per lane in the prologue's segment scan and the class terms' re-base; with the static score tables, the pin / anti-affinity / port
-    fold, presets and the GPU fold.  129 classes leave the table (a priced cliff: DESIGN 5.3h)."""
+    fold, presets and the GPU fold.  129 classes leave the table only with the folds (round 6: simon_table_cls4.hip takes 129 .. 256 on the one-level layout)."""
     feat = WIDE_CLASS_FEATURES[idx]
     shapes_c = np.array([4000, 8000, 16000, 32000])
     shapes_m = np.array([8, 16, 64, 128]) << 30
@@ -344,7 +344,8 @@ def test_up_to_128_distinct_node_classes_on_the_score_table(idx, monkeypatch):
             res = ctx.run_batch(scen, orders, want_gpu_slices=bool(feat.get("gpu")))
             st = ctx.stats()
         on_table = st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation in (4, 5)
-        assert on_table == (n_classes <= 128), (n_classes, st.kernel_variant, st.kernel_generation)
+        # (129 .. 256 classes stay on the one-level table since the end of round 6, simon_table_cls4.hip -- not with the folds, which ride on the two-level layout)
+        assert on_table == (n_classes <= 128 or not (feat.get("anti_host") or feat.get("gpu"))), (n_classes, st.kernel_variant, st.kernel_generation)
         assert_same(res, ref)
 
 

@@ -335,3 +335,57 @@ def test_team_mode_beyond_128_signatures():
         assert ok, info
         teams += info["team"]
     assert teams >= 3, teams
+
+
+MANY_CLASS_FEATURES = [dict(), dict(static_small=True, tight_pods=True), dict(pins=True, presets=True, gates=True), dict(nz_differs=True, init_state=True, static_mask=True)]
+
+
+@pytest.mark.parametrize("idx", range(len(MANY_CLASS_FEATURES)))
+def test_129_to_256_distinct_node_classes_on_the_score_table(idx):
+    """VERDICT r5 next-6 (second half): clusters of more than 128 distinct node shapes stay on the score table -- generation 4's one-level layout (a class segment
+    padded to 16 positions), the class terms' re-base walking four groups of 64 classes (simon_table_cls4.hip).  With the static score tables (their maxima run over
+    all groups), pins / presets / gates, NonZeroRequested != Requested, and per-scenario node ranks; 257 classes leave the table."""
+    feat = MANY_CLASS_FEATURES[idx]
+    for seed, (n_classes, N, P) in enumerate([(129, 400, 1200), (160, 700, 2000), (200, 1500, 2500), (256, 1000, 1500), (257, 600, 800)]):
+        rng = np.random.default_rng(9600 + 10 * idx + seed)
+        prob = randprob.rand_problem(9600 + 10 * idx + seed, N=N, P=P, n_node_classes=n_classes, n_pod_classes=6, **feat)
+        cls = np.concatenate([np.arange(n_classes), rng.integers(0, n_classes, N - n_classes)]).astype(np.int32)   # every class occurs
+        rng.shuffle(cls)
+        prob.node_class = cls
+        cpu = 2000 + 500 * (np.arange(n_classes) % 23) + 7000 * (np.arange(n_classes) // 23)                      # a distinct allocatable per class
+        prob.alloc_cpu = cpu[cls].astype(np.int64)
+        prob.alloc_mem = ((4 + np.arange(n_classes) % 9)[cls].astype(np.int64)) << 30
+        if prob.init_req_cpu is not None:
+            prob.init_req_cpu = np.minimum(prob.init_req_cpu, prob.alloc_cpu // 2); prob.init_req_mem = np.minimum(prob.init_req_mem, prob.alloc_mem // 2)
+            prob.init_nz_cpu = np.maximum(prob.init_nz_cpu, prob.init_req_cpu); prob.init_nz_mem = np.maximum(prob.init_nz_mem, prob.init_req_mem)
+        prob.normalise()
+        scen, orders = randprob.rand_scenarios(96 + seed, prob, S=5)
+        scen[0, 0] = N
+        ranks = None
+        if seed % 2 == 1:
+            ranks = np.zeros((len(scen), prob.n_nodes), np.int32)
+            for s_, (n, _) in enumerate(np.asarray(scen).tolist()):
+                ranks[s_, :n] = rng.permutation(n)
+        ref = O.run(prob, scen, orders, node_ranks=ranks) if ranks is not None else O.run_threaded(prob, scen, orders)
+        with capi.Context(0) as ctx:
+            ctx.load_problem(prob)
+            ctx.load_scenarios(scen, orders)
+            if ranks is not None:
+                ctx.set_node_ranks(ranks)
+            ctx.run_loaded(True)
+            res = ctx.fetch(True)
+            st = ctx.stats()
+        on_table = st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4
+        assert on_table == (n_classes <= 256), (n_classes, st.kernel_variant, st.kernel_generation)
+        assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
+        assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
+
+
+def test_config3_on_160_node_shapes_stays_on_generation_4():
+    """bench.py's `config3_classes160` row at a size the oracle finishes: BASELINE config 3's pods on 160 distinct node shapes."""
+    prob, scen, orders = synth.config3_classes(160, n_counts=12, n_orders=2, n_pods=4000)
+    ref = O.run_threaded(prob, scen, orders)
+    res, st, _ = run_gpu(prob, scen, orders)
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4, (st.kernel_variant, st.kernel_generation)
+    assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
+    assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
