@@ -171,7 +171,7 @@ __device__ __forceinline__ unsigned wave_or_u32_t(unsigned v) {
 struct NodeState { unsigned rq_c, rq_m, freep; };   // Requested cpu / mem (gcd units), free pod slots: 12 B per position
 
 struct TCarve {
-    int sum, sn, cnt, shape, seg, tmp, zdom, stash, tab, tabi, tab2, xch, total;   // LDS offsets (multiples of 16)
+    int sum, sn, cnt, shape, seg, tmp, ext, zdom, stash, tab, tabi, tab2, xch, total;   // LDS offsets (multiples of 16)
     int nbp;
 };
 // summary row pitch in u16 entries: >= nblk with an odd pitch in dwords or an odd pitch in entries, so that the K column
@@ -204,6 +204,7 @@ __host__ __device__ inline TCarve tcarve(int K, int ni_max, int Cn, bool coarse,
     c.shape = o; o += Cn * (cls4 ? 32 : 48);
     c.seg = o; o += al((Cn + 1) * 4);
     c.tmp = o; o += al(Cn * 4);
+    c.ext = o; o += cls4 ? al(K * 8) : 0;                              // cls4: [K] extremes of the Simon raw scores at the last re-base (table_kernel: the interior-class test)
     // SPREAD (nzk >= 0): zone domain of a class per zone-like key; for spread_select two bytes per position and the score table of
     // the pod being placed
     const bool ipa = nzk >= 0 && (nzk & 0x100);                       // the problem has preferred pod (anti-)affinity terms: a second table
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     };
     int* s_seg = (int*)(smem + cv.seg);                             // [Cn + 1]: first position of a class segment
     int* s_tmp = (int*)(smem + cv.tmp);
+    int2* s_ext = (int2*)(smem + cv.ext);                           // kCls4: [K] (lo, hi) of the Simon raw scores over the classes that held a feasible node at row k's last re-base
 
     const unsigned Krow = (unsigned)K * 16u;                          // bytes of one block's rows
     // Byte offset of (block of 16 positions, signature k) = tile_blk(block) + k * KS.  The table is [block][K][16]: a placement
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
     bool kvalid[KQ];
     double my_req_c[KQ], my_req_m[KQ], my_nz_c[KQ], my_nz_m[KQ];
     bool my_zero[KQ];
+    int my_tc[KQ];                                                    // kCls4: the signatures' table class (row of simon_raw)
     unsigned my_add_c[KQ], my_add_m[KQ], my_addz_c[KQ], my_addz_m[KQ], koff[KQ];
     unsigned my_greq[KQ];                                             // GPU fold: this lane's signatures' GPU requests (SigRow::pad)
     int my_gnum[KQ];
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
         const SigRow r = sigs[kk[q]];
         my_req_c[q] = r.req_c; my_req_m[q] = r.req_m; my_nz_c[q] = r.nz_c; my_nz_m[q] = r.nz_m;
         my_zero[q] = r.flags & 1u;
+        if constexpr (kCls4) my_tc[q] = r.cls;
         my_greq[q] = (unsigned)r.pad[0]; my_gnum[q] = kvalid[q] ? r.pad[1] : 0;
         my_add_c[q] = (unsigned)r.req_c; my_add_m[q] = (unsigned)r.req_m;
         my_addz_c[q] = (unsigned)r.nz_c; my_addz_m[q] = (unsigned)r.nz_m;
@@ -865,6 +869,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
 #pragma unroll
             for (int g = 0; g < 4; ++g) { lo = min(lo, inq[g] ? rawq[g] : 0x7fffffff); hi = max(hi, inq[g] ? rawq[g] : (int)0x80000000); }
             lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+            if (lane == 0) s_ext[k] = make_int2(lo, hi);
             const int range = hi >= lo ? hi - lo : 0;
             const double rr = range ? 1.0 / (double)range : 0.0;
 #pragma unroll
@@ -2195,7 +2200,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
                         // an atomic is performed in L2 and would leave the wave's later plain loads of the counter to a stale L1 line
                         if constexpr (!CNT_LDS) { left = g_cnt[cidx] - 1; g_cnt[cidx] = left; }
                         else { left = s_cnt[cidx] - 1; s_cnt[cidx] = left; }
-                        if (left == 0) my_dirty |= 1u << dirty_bit;       // the class term of row k changes: re-base before its next use
+                        // The class term of row k changes: re-base before its next use -- unless (kCls4: hundreds of small classes, each leaving the
+                        // feasible set of every signature at some point) the class that left sat strictly INSIDE the extremes of the last re-base:
+                        // lo and hi are then attained by classes that stay, the min-max normalisation (simon.go:76-101) of every other class is
+                        // what it was, and the leaver's own entries are all 0 and stay 0 (bytes never come back).  While a row is dirty the stored
+                        // extremes may be stale -- it is re-based before its next use whatever this test says.  Static score tables have maxima
+                        // of their own: with them every leave re-bases.
+                        bool rebase = left == 0;
+                        if constexpr (kCls4) {
+                            if (rebase && !(sc.static_tables & 7)) {
+                                const int raw = simon_raw[((KQ > 1 && dirty_bit == KQ - 1) ? my_tc[KQ - 1] : my_tc[0]) * Cn + dstar];
+                                const int2 e = s_ext[k];
+                                rebase = !(e.x < raw && raw < e.y);
+                            }
+                        }
+                        if (rebase) my_dirty |= 1u << dirty_bit;
 #ifdef SIMON_TABLE_DEBUG
                         printf("DBG s=%d step=%d CNT k=%d class=%d left=%d\n", s, i0 + il, k, dstar, left);
 #endif
