@@ -36,7 +36,7 @@
 // required anti-affinity on node-level topology keys) scan their signature's rows under per-block position masks.
 //
 // Limits: K <= 384 signatures (two per lane in registers, further groups of 128 from memory), padded scenario size <= 4096 positions (<= 4095 nodes; two-level: 8192 /
-// 8191), <= 128 node classes (two per lane where a select / walk is lane-shaped: CN2), NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are
+// 8191), <= 128 node classes (two per lane where a select / walk is lane-shaped: CN2; 129 .. 256 without rows and walks on the one-level layout: simon_table_cls4.hip), NARROW preconditions (simon_hip.hip::choose_variant), no zero-capacity node, orders are
 // permutations; REST: <= 32 GPU requests, <= 120 terms, <= 63 mask rows per pod.
 #include "simon_table.h"
 
