@@ -1991,8 +1991,8 @@ int simon_run_loaded(simon_ctx* c, int32_t want_placement) {
                     fprintf(stderr, "[SIMON_TABLE_PROF] REST select, ticks/cycle (averaged over ALL pods): pod row %.0f | filter words + summaries %.0f | candidates %.0f | table rows of excluded bests %.0f (needed on %.3f of the cycles) | per-class best %.0f | class term %.0f | totals + tie %.0f | rest %.0f\n",
                             acc[11] / S / P, acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[20] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[10] / S / P);
                 if (c->spread)
-                    fprintf(stderr, "[SIMON_TABLE_PROF] spread pods, ticks/cycle: descriptor + first loads %.0f | counters, sizes %.0f | zone counters, Log, raw table %.0f | pass 1 %.0f | extremes, totals table %.0f | pass 2 %.0f | winner %.0f | counter stores %.0f\n",
-                            acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[18] / S / P, acc[19] / S / P);
+                    fprintf(stderr, "[SIMON_TABLE_PROF] spread pods, ticks/cycle: entries arrived %.0f | descriptor + first loads %.0f | counters, sizes %.0f | zone counters, Log, raw table %.0f | pass 1 %.0f | extremes, totals table %.0f | pass 2 %.0f | winner %.0f | counter stores %.0f\n",
+                            acc[21] / S / P, acc[12] / S / P, acc[13] / S / P, acc[14] / S / P, acc[15] / S / P, acc[16] / S / P, acc[17] / S / P, acc[18] / S / P, acc[19] / S / P);
             }
             variant_used = SIMON_KERNEL_NARROW_CACHE;
             T = 64 * team; slots = (ni_top / (c->table_coarse ? 64 : 16) + 63) / 64; lds = table_lds;

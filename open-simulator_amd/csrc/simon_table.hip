@@ -1307,6 +1307,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPREAD 
             kind[e] = ti & 3; rowi[e] = (ti >> 2) & 0x3FFF; zsl[e] = (ti >> 16) & 7;
             skew[e] = (ent >> 16) & 0x3FFF; dup[e] = (ent >> 30) & 1;
         }
+        TPROF(21);                                                         // spread: the pod's entries arrived (loop top -> here)
         int nh = 0, eh = 0;                                               // hostname-like constraints (each has its own counter row)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
