@@ -389,3 +389,22 @@ def test_config3_on_160_node_shapes_stays_on_generation_4():
     assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4, (st.kernel_variant, st.kernel_generation)
     assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
     assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
+
+
+def test_config3_classes160_benchmarked_batch_against_the_oracle():
+    """The batch of bench.py's `config3_classes160` row (10 000 pods x 488 .. 1 511 nodes in 160 shapes, 4 096 scenarios, four per CU on the kernels of
+    simon_table_cls4.hip): 1 024 evenly spaced scenarios of the FULL batch row by row against the oracle (~10 s on 16 host threads; 256 on a small box)."""
+    prob, scen, orders = synth.config3_classes(160)
+    pick = np.unique(np.linspace(0, len(scen) - 1, 1024 if O.host_threads() >= 8 else 256).astype(int))
+    ref = O.run_threaded(prob, scen[pick], orders)
+    with capi.Context(0) as ctx:
+        ctx.load_problem(prob)
+        ctx.load_scenarios(scen, orders)
+        ctx.run_loaded(True)
+        st = ctx.stats()
+        res = ctx.fetch(True)
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE and st.kernel_generation == 4 and len(scen) == 4096
+    assert res.unscheduled[pick].tolist() == ref.unscheduled.tolist()
+    assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist() and res.used_mem[pick].tolist() == ref.used_mem.tolist()
+    bad = np.argwhere(res.placement[pick] != ref.placement)
+    assert len(bad) == 0, f"{len(bad)} placements differ, first (scenario, pod) = {bad[0].tolist()}"
