@@ -2409,11 +2409,20 @@ static hipError_t launch_team2(const TableLaunch& a, int n_blocks, size_t lds, h
     if (a.sc.K > 64) return one ? launch_team4<M, Z, 2, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 2, 2>(a, n_blocks, lds, st);
     return one ? launch_team4<M, Z, 1, 1>(a, n_blocks, lds, st) : launch_team4<M, Z, 1, 2>(a, n_blocks, lds, st);
 }
+// The unit's instantiations in two halves by NonZero == request (Z), each a hipcc process of its own (the unit was the build's longest pole by far:
+// 4 m 37 s next to 16 others on 8 cores): simon_table_team<N>z.hip defines SIMON_TABLE_NZEQ_HALF and holds Z = true, simon_table_team<N>.hip the rest + the entry.
+#ifdef SIMON_TABLE_NZEQ_HALF
+hipError_t SIMON_TEAM_CAT(launch_table_team_nzeq, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, size_t lds_bytes, hipStream_t st) {
+    return launch_team2<true, true>(a, n_blocks, lds_bytes, st);
+}
+#else
+hipError_t SIMON_TEAM_CAT(launch_table_team_nzeq, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, size_t lds_bytes, hipStream_t st);
 hipError_t SIMON_TEAM_CAT(launch_table_team, SIMON_TABLE_TEAM_TU)(const TableLaunch& a, int n_blocks, bool has_mask, bool nzeq, size_t lds_bytes, hipStream_t st) {
     if (!a.spread || !a.coarse || a.team != kTuWaves) return hipErrorInvalidValue;
     (void)has_mask;                                                   // (a run-time test of the prologue: TableCold::static_mask is null without one)
-    return nzeq ? launch_team2<true, true>(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
+    return nzeq ? SIMON_TEAM_CAT(launch_table_team_nzeq, SIMON_TABLE_TEAM_TU)(a, n_blocks, lds_bytes, st) : launch_team2<true, false>(a, n_blocks, lds_bytes, st);
 }
+#endif
 #elif defined(SIMON_TABLE_SPREAD_TU)
 // ---- this translation unit (simon_table_spread.hip) holds generation 7: the single-wave SPREAD instantiations (80 of the largest kernels of
 // the library -- next to simon_table.hip instead of inside it, build() runs one hipcc process per unit) ----
@@ -2563,11 +2572,19 @@ static hipError_t launch_rs2(const TableLaunch& a, int n_blocks, size_t lds, hip
     if constexpr (KQ == 2) { if (a.sc.K > 128) return launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st); }
     return a.sc.ni_max / 64 <= 64 ? launch_rs3<Z, KQ, 1>(a, n_blocks, lds, st) : launch_rs3<Z, KQ, 2>(a, n_blocks, lds, st);
 }
+// (two halves by NonZero == request, as the team unit: simon_table_rsz.hip holds Z = true, simon_table_rs.hip the rest + the entry)
+#ifdef SIMON_TABLE_NZEQ_HALF
+hipError_t launch_table_rs_nzeq(const TableLaunch& a, int n_blocks, size_t lds_bytes, hipStream_t st) {
+    return a.sc.K > 64 ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<true, 1>(a, n_blocks, lds_bytes, st);
+}
+#else
+hipError_t launch_table_rs_nzeq(const TableLaunch& a, int n_blocks, size_t lds_bytes, hipStream_t st);
 hipError_t launch_table_rs(const TableLaunch& a, int n_blocks, bool nzeq, size_t lds_bytes, hipStream_t st) {
     if (!a.spread || !a.rest || !a.coarse || a.team > 1 || a.lds_x || a.sc.Cn > 64 || (a.sc.static_tables & (32 | 128))) return hipErrorInvalidValue;
-    if (a.sc.K > 64) return nzeq ? launch_rs2<true, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 2>(a, n_blocks, lds_bytes, st);
-    return nzeq ? launch_rs2<true, 1>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
+    if (nzeq) return launch_table_rs_nzeq(a, n_blocks, lds_bytes, st);
+    return a.sc.K > 64 ? launch_rs2<false, 2>(a, n_blocks, lds_bytes, st) : launch_rs2<false, 1>(a, n_blocks, lds_bytes, st);
 }
+#endif
 #elif defined(SIMON_TABLE_CLS4_TU)
 // ---- this translation unit (simon_table_cls4.hip) holds generations 4 for 129 .. 256 internal node classes: one-level layout, > 2 048 padded positions (a class
 // segment is padded to 16), so NBQ = 4; the instantiation that knows pinned pods serves every problem ----

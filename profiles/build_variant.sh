@@ -8,7 +8,7 @@ NAME=$1; shift
 C=open-simulator_amd/csrc
 python __graft_entry__.py > /dev/null          # the regular objects
 OBJS=""
-for F in simon_hip simon_group simon_narrow simon_fast simon_table simon_table_spread simon_table_spread2 simon_table_team4 simon_table_rest simon_table_rest2 simon_table_rs simon_table_cls4 simon_table_lds simon_table_restlds simon_wide simon_wide_local simon_wide_explain; do
+for F in simon_hip simon_group simon_narrow simon_fast simon_table simon_table_spread simon_table_spread2 simon_table_team4 simon_table_team4z simon_table_rest simon_table_rest2 simon_table_rs simon_table_rsz simon_table_cls4 simon_table_lds simon_table_restlds simon_wide simon_wide_local simon_wide_explain; do
   if [ "${F#simon_wide}" != "$F" ] || [ "${F#simon_table}" != "$F" ] || [ "$F" = simon_hip ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC "$@" -c -o $C/${F}_$NAME.o $C/$F.hip &
     OBJS="$OBJS $C/${F}_$NAME.o"
