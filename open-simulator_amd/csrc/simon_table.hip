@@ -2632,9 +2632,28 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const int32_t* __restric
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[inv[p]];
 }
 
+// The same through LDS, one workgroup per scenario, for rows of at most 64 KB (P <= 16 384; config 3: 40 KB, four workgroups per CU): the
+// row arrives coalesced and the gather runs in LDS -- 64 scattered dwords of a 40 KB row cost the texture path one cache line each
+// (config 3's 4 096 rows: 154 us per batch, 1.1 % of the step; the row is read once and written once either way).
+__global__ __launch_bounds__(512) void unpermute_lds_kernel(const int32_t* __restrict__ place_step, const int32_t* __restrict__ inv_orders,
+                                                            const ScenarioDesc* __restrict__ scen, int P, int32_t* __restrict__ placement) {
+    extern __shared__ int32_t s_unp_row[];
+    const int s = blockIdx.x;
+    const int32_t* __restrict__ inv = inv_orders + (size_t)scen[s].order_id * P;
+    const int32_t* __restrict__ src = place_step + (size_t)s * P;
+    int32_t* __restrict__ dst = placement + (size_t)s * P;
+    for (int i = threadIdx.x; i < P; i += 512) s_unp_row[i] = src[i];
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 512) dst[p] = s_unp_row[inv[p]];
+}
+
 hipError_t launch_unpermute(const int32_t* place_step, const int32_t* inv_orders, const ScenarioDesc* scen, int S, int P,
                             int32_t* placement, hipStream_t st) {
     if (S <= 0 || P <= 0) return hipSuccess;
+    if (P >= 2048 && P <= 16384) {
+        hipLaunchKernelGGL(unpermute_lds_kernel, dim3(S), dim3(512), (size_t)P * 4, st, place_step, inv_orders, scen, P, placement);
+        return hipGetLastError();
+    }
     const int bx = std::min(64, (P + 255) / 256);
     for (int s0 = 0; s0 < S; s0 += 65535) {   // gridDim.y limit
         const int ns = std::min(65535, S - s0);
