@@ -408,3 +408,15 @@ def test_config3_classes160_benchmarked_batch_against_the_oracle():
     assert res.used_cpu[pick].tolist() == ref.used_cpu.tolist() and res.used_mem[pick].tolist() == ref.used_mem.tolist()
     bad = np.argwhere(res.placement[pick] != ref.placement)
     assert len(bad) == 0, f"{len(bad)} placements differ, first (scenario, pod) = {bad[0].tolist()}"
+
+
+@pytest.mark.parametrize("n_pods", [2047, 2048, 5003, 16384, 16385])
+def test_placement_rows_through_the_lds_unpermute(n_pods):
+    """`unpermute_lds_kernel` (rows of 2 048 .. 16 384 pods: the step-ordered row staged in LDS, gathered there) and the gather through L2 on both
+    sides of its limits -- 16 384 pods ask for exactly the 64 KB a workgroup gets without an attribute; every placement row against the oracle."""
+    prob, scen, orders = synth.config3(n_counts=3, n_orders=2, n_pods=n_pods, n_het=900)
+    ref = O.run_threaded(prob, scen, orders)
+    res, st, _ = run_gpu(prob, scen, orders)
+    assert st.kernel_variant == capi.KERNEL_NARROW_CACHE, st.kernel_variant
+    assert res.unscheduled.tolist() == ref.unscheduled.tolist() and (res.placement == ref.placement).all()
+    assert res.used_cpu.tolist() == ref.used_cpu.tolist() and res.used_mem.tolist() == ref.used_mem.tolist()
